@@ -1,0 +1,274 @@
+"""CPU oracle for the open-muse MaskGit hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a functional, CPU-only (torch fp32 / numpy) restatement of the algorithm of the
+reference's hot path.  It is the *checker* for the HIP kernels: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing
+under ``open-muse_amd/`` imports it, and the product path raises if the HIP library is missing
+instead of falling back to this file.
+
+Parity status: **pinned**.  ``tests/golden/make_golden.py`` imports the real reference from
+``/root/reference`` (possible only in the build container), runs it on seeded inputs and writes
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` replays the same inputs through this file and
+compares.  The reference itself ships no golden vectors / unit tests for this path.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+State dicts use the reference's parameter names and shapes, so a ``pytorch_model.bin`` written by the
+reference can be fed in unchanged.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------------------------
+# MaskGitTransformer  (muse/modeling_transformer.py)
+# ----------------------------------------------------------------------------------------------
+def _ln(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    # weight-only LayerNorm: muse/modeling_transformer.py:124-137
+    return F.layer_norm(x, (x.shape[-1],), w, None, eps)
+
+
+def attention(x: Tensor, sd: SD, prefix: str, num_heads: int) -> Tensor:
+    """Full-visibility self attention.  muse/modeling_transformer.py:190-241 (non-xformers branch).
+
+    scores = (q k^T) * (1/sqrt(hd)) via baddbmm alpha (:226-231), softmax over keys (:236), P@V (:238),
+    heads re-assembled side by side (:240), then the bias-free ``out`` projection (:218).
+    """
+    B, S, H = x.shape
+    hd = H // num_heads
+    q = x @ sd[prefix + "query.weight"].t()
+    k = x @ sd[prefix + "key.weight"].t()
+    v = x @ sd[prefix + "value.weight"].t()
+    q = q.view(B, S, num_heads, hd).transpose(1, 2)
+    k = k.view(B, S, num_heads, hd).transpose(1, 2)
+    v = v.view(B, S, num_heads, hd).transpose(1, 2)
+    # the reference divides by float32(sqrt(float32(hd))) through baddbmm's alpha
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+    scores = torch.matmul(q, k.transpose(-1, -2)) * alpha
+    probs = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(probs, v).transpose(1, 2).reshape(B, S, H)
+    return ctx @ sd[prefix + "out.weight"].t()
+
+
+def feed_forward(x: Tensor, sd: SD, prefix: str, eps: float) -> Tensor:
+    """NormFormer GLU MLP.  muse/modeling_transformer.py:785-799.
+
+    LN(H) -> gelu_erf(x W0^T) * (x W1^T) -> LN(I) -> Wo.
+    """
+    h = _ln(x, sd[prefix + "pre_mlp_layer_norm.weight"], eps)
+    g = F.gelu(h @ sd[prefix + "wi_0.weight"].t())
+    lin = h @ sd[prefix + "wi_1.weight"].t()
+    h = _ln(g * lin, sd[prefix + "mid_mlp_layer_norm.weight"], eps)
+    return h @ sd[prefix + "wo.weight"].t()
+
+
+def transformer_layer(x: Tensor, sd: SD, prefix: str, num_heads: int, eps: float) -> Tensor:
+    """Pre-LN + NormFormer block.  muse/modeling_transformer.py:875-904 (no cross attention)."""
+    a = attention(_ln(x, sd[prefix + "attn_layer_norm.weight"], eps), sd, prefix + "attention.", num_heads)
+    x = x + _ln(a, sd[prefix + "post_attn_layer_norm.weight"], eps)
+    return x + feed_forward(x, sd, prefix + "ffn.", eps)
+
+
+def transformer_forward(
+    sd: SD,
+    cfg: dict,
+    input_ids: Tensor,
+    labels: Optional[Tensor] = None,
+    label_smoothing: float = 0.0,
+):
+    """MaskGitTransformer.forward.  muse/modeling_transformer.py:1224-1281.
+
+    Embed (:942-957) -> L x TransformerLayer -> encoder_layer_norm (:1268) -> MlmLayer (:979-985)
+    -> F.cross_entropy(ignore_index=-100) (:1276-1279).  Dropout is the identity (p=0 / eval).
+    """
+    eps = float(cfg.get("layer_norm_eps", 1e-5))
+    nh = int(cfg["num_attention_heads"])
+    L = int(cfg["num_hidden_layers"])
+    S = input_ids.shape[-1]
+    x = sd["embed.word_embeddings.weight"][input_ids] + sd["embed.position_embeddings.weight"][:S][None]
+    for i in range(L):
+        x = transformer_layer(x, sd, f"transformer_layers.{i}.", nh, eps)
+    x = _ln(x, sd["encoder_layer_norm.weight"], eps)
+    h = F.gelu(x @ sd["mlm_layer.mlm_dense.weight"].t())
+    h = _ln(h, sd["mlm_layer.mlm_ln.weight"], eps)
+    logits = h @ sd["mlm_layer.to_logits.weight"].t()
+    if labels is None:
+        return logits
+    V = logits.shape[-1]
+    loss = F.cross_entropy(logits.view(-1, V), labels.view(-1), ignore_index=-100, label_smoothing=label_smoothing)
+    return logits, loss
+
+
+def transformer_loss_and_grads(sd: SD, cfg: dict, input_ids: Tensor, labels: Tensor, label_smoothing: float = 0.0):
+    """loss.backward() of the forward above (train_maskgit_imagenet.py:426-433); returns (logits, loss, grads)."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    logits, loss = transformer_forward(leaf, cfg, input_ids, labels, label_smoothing)
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    return logits.detach(), loss.detach(), grads
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float, beta2: float,
+               eps: float, weight_decay: float) -> None:
+    """torch.optim.AdamW single-tensor update (decoupled weight decay), as selected at
+    training/train_maskgit_imagenet.py:242-261 and stepped at :438.  In place on p, m, v."""
+    p.mul_(1.0 - lr * weight_decay)
+    m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# ----------------------------------------------------------------------------------------------
+# mask sampling of the train step  (training/train_maskgit_imagenet.py:357-394)
+# ----------------------------------------------------------------------------------------------
+def cosine_schedule(t: Tensor) -> Tensor:
+    # muse/sampling.py:38-39
+    return torch.cos(t * math.pi * 0.5)
+
+
+def prepare_inputs_and_labels(
+    image_tokens: Tensor,
+    class_ids: Tensor,
+    timesteps: Tensor,
+    noise: Tensor,
+    mask_id: int,
+    codebook_size: int,
+    min_masking_rate: float = 0.0,
+):
+    """training/train_maskgit_imagenet.py:371-394, with the two torch.rand draws (:375, :381) supplied by
+    the caller so that CPU and GPU see identical uniforms.
+
+    Note the reference thresholds the *argsort array itself* (:381-382): position j is masked iff the index of
+    the j-th smallest noise value is < num_token_masked.
+    """
+    B, S = image_tokens.shape
+    mask_prob = cosine_schedule(timesteps).clip(min_masking_rate)
+    num_token_masked = (S * mask_prob).round().clamp(min=1)
+    batch_randperm = noise.argsort(dim=-1)
+    mask = batch_randperm < num_token_masked.unsqueeze(-1)
+    input_ids = torch.where(mask, mask_id, image_tokens)
+    labels = torch.where(mask, image_tokens, -100)
+    cls = (class_ids + codebook_size).unsqueeze(-1)
+    input_ids = torch.cat([cls, input_ids], dim=-1)
+    labels = torch.cat([torch.full_like(cls, -100), labels], dim=-1)
+    return input_ids, labels, mask_prob
+
+
+# ----------------------------------------------------------------------------------------------
+# MaskGitVQGAN  (muse/modeling_maskgit_vqgan.py)
+# ----------------------------------------------------------------------------------------------
+def _conv_same(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    # Conv2dSame, stride 1: muse/modeling_maskgit_vqgan.py:33-45 (pad (k-1)//2 left/top, rest right/bottom)
+    k = w.shape[-1]
+    p = k - 1
+    if p > 0:
+        x = F.pad(x, [p // 2, p - p // 2, p // 2, p - p // 2])
+    return F.conv2d(x, w, b)
+
+
+def _gn_silu(x: Tensor, sd: SD, prefix: str) -> Tensor:
+    # GroupNorm(32, eps=1e-6, affine) followed by SiLU: muse/modeling_maskgit_vqgan.py:61,73-74
+    return F.silu(F.group_norm(x, 32, sd[prefix + "weight"], sd[prefix + "bias"], 1e-6))
+
+
+def resnet_block(x: Tensor, sd: SD, prefix: str) -> Tensor:
+    """muse/modeling_maskgit_vqgan.py:71-85.  Quirk kept: when channels change the 'shortcut' is a 1x1 conv of the
+    conv2 *output* (:82-83), i.e. out = h + nin(h); the block input is dropped."""
+    h = _conv_same(_gn_silu(x, sd, prefix + "norm1."), sd[prefix + "conv1.weight"], None)
+    h = _conv_same(_gn_silu(h, sd, prefix + "norm2."), sd[prefix + "conv2.weight"], None)
+    if (prefix + "nin_shortcut.weight") in sd:
+        res = _conv_same(h, sd[prefix + "nin_shortcut.weight"], None)
+    else:
+        res = x
+    return h + res
+
+
+def vqgan_encoder(sd: SD, cfg: dict, pixel_values: Tensor) -> Tensor:
+    """Encoder.forward, muse/modeling_maskgit_vqgan.py:175-189 (+ DownsamplingBlock :107-114)."""
+    nres = len(cfg["channel_mult"])
+    nb = int(cfg["num_res_blocks"])
+    h = _conv_same(pixel_values, sd["encoder.conv_in.weight"], None)
+    for lvl in range(nres):
+        for b in range(nb):
+            h = resnet_block(h, sd, f"encoder.down.{lvl}.block.{b}.")
+        if lvl != nres - 1:
+            h = F.avg_pool2d(h, kernel_size=2, stride=2)
+    for b in range(nb):
+        h = resnet_block(h, sd, f"encoder.mid.{b}.")
+    h = _gn_silu(h, sd, "encoder.norm_out.")
+    return _conv_same(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"])
+
+
+def vq_distances(z_flat: Tensor, codebook: Tensor) -> Tensor:
+    """VectorQuantizer.compute_distances, muse/modeling_maskgit_vqgan.py:303-316:
+    addmm(|z|^2 + |e|^2, z, e^T, alpha=-2)."""
+    zn = z_flat.pow(2.0).sum(dim=1, keepdim=True)
+    en = codebook.t().pow(2.0).sum(dim=0, keepdim=True)
+    return torch.addmm(zn + en, z_flat, codebook.t(), alpha=-2.0)
+
+
+def vq_indices(z: Tensor, codebook: Tensor) -> Tensor:
+    """VectorQuantizer.get_code, muse/modeling_maskgit_vqgan.py:342-348: NCHW -> NHWC -> argmin of distances."""
+    B = z.shape[0]
+    zf = z.permute(0, 2, 3, 1).contiguous().reshape(-1, codebook.shape[1])
+    return torch.argmin(vq_distances(zf, codebook), dim=1).reshape(B, -1)
+
+
+def vqgan_encode(sd: SD, cfg: dict, pixel_values: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """MaskGitVQGAN.encode, muse/modeling_maskgit_vqgan.py:380-386 -> (z, z_q, indices)."""
+    z = vqgan_encoder(sd, cfg, pixel_values)
+    cb = sd["quantize.embedding.weight"]
+    idx = vq_indices(z, cb)
+    B, C, Hh, Ww = z.shape
+    z_q = cb[idx].view(B, Hh, Ww, C).permute(0, 3, 1, 2).contiguous()  # == one-hot @ codebook (:280-284,299)
+    return z, z_q, idx
+
+
+def vqgan_decoder(sd: SD, cfg: dict, z_q: Tensor) -> Tensor:
+    """Decoder.forward, muse/modeling_maskgit_vqgan.py:223-240 (+ UpsamplingBlock :141-149)."""
+    nres = len(cfg["channel_mult"])
+    nb = int(cfg["num_res_blocks"])
+    h = _conv_same(z_q, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"])
+    for b in range(nb):
+        h = resnet_block(h, sd, f"decoder.mid.{b}.")
+    for lvl in reversed(range(nres)):
+        for b in range(nb):
+            h = resnet_block(h, sd, f"decoder.up.{lvl}.block.{b}.")
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = _conv_same(h, sd[f"decoder.up.{lvl}.upsample_conv.weight"], sd[f"decoder.up.{lvl}.upsample_conv.bias"])
+    h = _gn_silu(h, sd, "decoder.norm_out.")
+    return _conv_same(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"])
+
+
+def vqgan_decode_code(sd: SD, cfg: dict, indices: Tensor) -> Tensor:
+    """MaskGitVQGAN.decode_code, muse/modeling_maskgit_vqgan.py:392-395 (+ get_codebook_entry :318-324)."""
+    B, T = indices.shape
+    side = int(math.sqrt(T))
+    z_q = sd["quantize.embedding.weight"][indices].reshape(B, side, side, -1).permute(0, 3, 1, 2)
+    return vqgan_decoder(sd, cfg, z_q)
+
+
+# ----------------------------------------------------------------------------------------------
+# One full train step, exactly as training/train_maskgit_imagenet.py:357-452 strings the pieces together
+# ----------------------------------------------------------------------------------------------
+def train_step(vq_sd: SD, vq_cfg: dict, tr_sd: SD, tr_cfg: dict, pixel_values: Tensor, class_ids: Tensor,
+               timesteps: Tensor, noise: Tensor, label_smoothing: float = 0.0):
+    with torch.no_grad():
+        _, _, tokens = vqgan_encode(vq_sd, vq_cfg, pixel_values)
+        input_ids, labels, mask_prob = prepare_inputs_and_labels(
+            tokens, class_ids, timesteps, noise, mask_id=int(tr_cfg["vocab_size"]) - 1,
+            codebook_size=int(vq_cfg["num_embeddings"]))
+    logits, loss, grads = transformer_loss_and_grads(tr_sd, tr_cfg, input_ids, labels, label_smoothing)
+    return dict(tokens=tokens, input_ids=input_ids, labels=labels, mask_prob=mask_prob, logits=logits, loss=loss,
+                grads=grads)

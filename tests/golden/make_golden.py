@@ -1,0 +1,103 @@
+"""Generate golden vectors by running the REAL reference (/root/reference, importable only in the build
+container) on seeded inputs.  Output: tests/golden/*.npz (committed).  Re-run:
+
+    python tests/golden/make_golden.py
+
+The reference ships no golden vectors for this path, so these are the pins for oracle/.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+
+import weights as W  # noqa: E402
+
+import muse as ref_muse  # noqa: E402  (the reference package)
+from muse.sampling import cosine_schedule  # noqa: E402
+
+torch.set_num_threads(1)  # one reduction order, reproducible
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def golden_transformer(name, cfg, batch, seed, label_smoothing):
+    model = ref_muse.MaskGitTransformer(**cfg)
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer")
+    missing = model.load_state_dict(sd, strict=True)
+    model.train()  # dropout p=0 -> identity; same branch the training script takes
+    input_ids, labels = W.transformer_inputs(cfg, batch, seed + 1)
+    logits, loss = model(input_ids=input_ids, labels=labels, label_smoothing=label_smoothing)
+    loss.backward()
+    out = dict(logits=np_(logits), loss=np_(loss), label_smoothing=np.float32(label_smoothing),
+               batch=np.int64(batch), seed=np.int64(seed))
+    for k, p in model.named_parameters():
+        out["grad." + k] = np_(p.grad)
+    # one AdamW step with the target config's hyper-parameters (configs/imagenet.yaml:64-72)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
+    opt.step()
+    for k in ("mlm_layer.to_logits.weight", "transformer_layers.0.ffn.wo.weight", "encoder_layer_norm.weight"):
+        out["adamw." + k] = np_(dict(model.named_parameters())[k])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", float(loss), "logits", logits.shape)
+
+
+def golden_vqgan(name, cfg, batch, seed):
+    model = ref_muse.MaskGitVQGAN(**cfg)
+    sd = W.fill_state_dict(W.vqgan_shapes(cfg), seed, "vqgan")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    px = W.images(batch, cfg["resolution"], seed + 1)
+    with torch.no_grad():
+        z = model.encoder(px)
+        z_q, idx = model.encode(px)
+        rec = model.decode_code(idx)
+        code = model.get_code(px)
+        dist = model.quantize.compute_distances(z.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(code, idx)
+    top2 = torch.topk(dist, 2, dim=1, largest=False).values
+    out = dict(z=np_(z), z_q=np_(z_q), indices=np_(idx), rec=np_(rec), margin=np_(top2[:, 1] - top2[:, 0]),
+               batch=np.int64(batch), seed=np.int64(seed))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "z", z.shape, "idx", idx.shape, "rec", rec.shape, "min margin", float(out["margin"].min()))
+
+
+def golden_mask(name, batch, seq, seed, mask_id, codebook_size, min_rate):
+    """training/train_maskgit_imagenet.py:371-394 executed line by line with supplied uniforms."""
+    rng = np.random.default_rng(seed)
+    image_tokens = torch.from_numpy(rng.integers(0, codebook_size, size=(batch, seq)).astype(np.int64))
+    class_ids = torch.from_numpy(rng.integers(0, 1000, size=(batch,)).astype(np.int64))
+    timesteps = W.uniforms((batch,), seed + 1)
+    noise = W.uniforms((batch, seq), seed + 2)
+    # --- reference lines (:376-393), rand draws replaced by the tensors above ---
+    mask_prob = cosine_schedule(timesteps)
+    mask_prob = mask_prob.clip(min_rate)
+    num_token_masked = (seq * mask_prob).round().clamp(min=1)
+    batch_randperm = noise.argsort(dim=-1)
+    mask = batch_randperm < num_token_masked.unsqueeze(-1)
+    input_ids = torch.where(mask, mask_id, image_tokens)
+    labels = torch.where(mask, image_tokens, -100)
+    class_ids_s = class_ids + codebook_size
+    input_ids = torch.cat([class_ids_s.unsqueeze(-1), input_ids], dim=-1)
+    labels_mask = torch.ones_like(class_ids_s).unsqueeze(-1).fill_(-100)
+    labels = torch.cat([labels_mask, labels], dim=-1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), image_tokens=np_(image_tokens), class_ids=np_(class_ids),
+                        timesteps=np_(timesteps), noise=np_(noise), input_ids=np_(input_ids), labels=np_(labels),
+                        mask_prob=np_(mask_prob), mask_id=np.int64(mask_id), codebook_size=np.int64(codebook_size),
+                        min_rate=np.float32(min_rate))
+    print(name, "masked per row", mask.sum(-1)[:8].tolist())
+
+
+if __name__ == "__main__":
+    golden_transformer("transformer_tiny", W.TRANSFORMER_TINY, batch=3, seed=100, label_smoothing=0.0)
+    golden_transformer("transformer_tiny_ls", W.TRANSFORMER_TINY, batch=2, seed=110, label_smoothing=0.1)
+    golden_transformer("transformer_hd48", W.TRANSFORMER_HD48, batch=2, seed=120, label_smoothing=0.0)
+    golden_vqgan("vqgan_tiny", W.VQGAN_TINY, batch=2, seed=200)
+    golden_mask("mask_b64", batch=64, seq=256, seed=300, mask_id=2047, codebook_size=1024, min_rate=0.0)
+    golden_mask("mask_small", batch=5, seq=16, seed=310, mask_id=47, codebook_size=32, min_rate=0.3)

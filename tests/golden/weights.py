@@ -1,0 +1,174 @@
+"""Deterministic weights and inputs shared by the golden generator, the oracle tests and the GPU parity tests.
+
+numpy's PCG64 stream is stable across numpy versions and machines, so the build container (where the real
+reference is importable) and the GPU box (where it is not) construct bit-identical tensors from a seed.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+# ---- tiny configs used for the committed golden vectors -------------------------------------------------------
+TRANSFORMER_TINY = dict(
+    vocab_size=48, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+    max_position_embeddings=24, codebook_size=32, num_vq_tokens=16, num_classes=10,
+    hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-5,
+)
+# head_dim 48 (= configs/imagenet.yaml's 768/16), odd sequence length
+TRANSFORMER_HD48 = dict(
+    vocab_size=80, hidden_size=96, num_hidden_layers=1, num_attention_heads=2, intermediate_size=160,
+    max_position_embeddings=40, codebook_size=64, num_vq_tokens=36, num_classes=10,
+    hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-6,
+)
+VQGAN_TINY = dict(
+    resolution=16, num_channels=3, hidden_channels=32, channel_mult=(1, 2, 2), num_res_blocks=1,
+    z_channels=16, num_embeddings=32, quantized_embed_dim=16,
+)
+
+# ---- full-size configs (SURVEY.md section 8 legend) --------------------------------------------------------------
+TRANSFORMER_A = dict(  # README.md:90-100 ("hidden=512, 8 layers" in BASELINE.json)
+    vocab_size=2025, hidden_size=512, num_hidden_layers=8, num_attention_heads=8, intermediate_size=2048,
+    max_position_embeddings=257, codebook_size=1024, num_vq_tokens=256, num_classes=1000,
+    hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-5,
+)
+TRANSFORMER_B = dict(  # configs/imagenet.yaml:23-42
+    vocab_size=2048, hidden_size=768, num_hidden_layers=24, num_attention_heads=16, intermediate_size=3072,
+    max_position_embeddings=264, codebook_size=1024, num_vq_tokens=256, num_classes=1000,
+    initializer_range=0.02, norm_type="layernorm", layer_norm_eps=1e-6, use_normformer=True,
+    use_encoder_layernorm=True, use_mlm_layer=True, use_mlm_layernorm=True, use_bias=False,
+    hidden_dropout=0.0, attention_dropout=0.0,
+)
+VQGAN_F16 = dict(  # muse/modeling_maskgit_vqgan.py:352-367 defaults
+    resolution=256, num_channels=3, hidden_channels=128, channel_mult=(1, 1, 2, 2, 4), num_res_blocks=2,
+    z_channels=256, num_embeddings=1024, quantized_embed_dim=256,
+)
+
+
+def transformer_shapes(cfg: dict) -> dict:
+    """state_dict template of muse.MaskGitTransformer."""
+    H, I, V, P = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["max_position_embeddings"]
+    s = {"embed.word_embeddings.weight": (V, H), "embed.position_embeddings.weight": (P, H)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"transformer_layers.{i}."
+        s[p + "attn_layer_norm.weight"] = (H,)
+        for n in ("query", "key", "value", "out"):
+            s[p + f"attention.{n}.weight"] = (H, H)
+        s[p + "post_attn_layer_norm.weight"] = (H,)
+        s[p + "ffn.pre_mlp_layer_norm.weight"] = (H,)
+        s[p + "ffn.wi_0.weight"] = (I, H)
+        s[p + "ffn.wi_1.weight"] = (I, H)
+        s[p + "ffn.mid_mlp_layer_norm.weight"] = (I,)
+        s[p + "ffn.wo.weight"] = (H, I)
+    s["encoder_layer_norm.weight"] = (H,)
+    s["mlm_layer.mlm_dense.weight"] = (H, H)
+    s["mlm_layer.mlm_ln.weight"] = (H,)
+    s["mlm_layer.to_logits.weight"] = (V, H)
+    return s
+
+
+def vqgan_shapes(cfg: dict) -> dict:
+    """state_dict template of muse.MaskGitVQGAN."""
+    hc, mult, nb = cfg["hidden_channels"], tuple(cfg["channel_mult"]), cfg["num_res_blocks"]
+    nres = len(mult)
+    s = {}
+
+    def res(prefix, cin, cout):
+        s[prefix + "norm1.weight"] = (cin,)
+        s[prefix + "norm1.bias"] = (cin,)
+        s[prefix + "conv1.weight"] = (cout, cin, 3, 3)
+        s[prefix + "norm2.weight"] = (cout,)
+        s[prefix + "norm2.bias"] = (cout,)
+        s[prefix + "conv2.weight"] = (cout, cout, 3, 3)
+        if cin != cout:
+            s[prefix + "nin_shortcut.weight"] = (cout, cout, 1, 1)
+
+    s["encoder.conv_in.weight"] = (hc, cfg["num_channels"], 3, 3)
+    in_mult = (1,) + mult
+    for lvl in range(nres):
+        cin, cout = hc * in_mult[lvl], hc * mult[lvl]
+        for b in range(nb):
+            res(f"encoder.down.{lvl}.block.{b}.", cin, cout)
+            cin = cout
+    mid = hc * mult[-1]
+    for b in range(nb):
+        res(f"encoder.mid.{b}.", mid, mid)
+    s["encoder.norm_out.weight"] = (mid,)
+    s["encoder.norm_out.bias"] = (mid,)
+    s["encoder.conv_out.weight"] = (cfg["z_channels"], mid, 1, 1)
+    s["encoder.conv_out.bias"] = (cfg["z_channels"],)
+
+    s["decoder.conv_in.weight"] = (mid, cfg["z_channels"], 3, 3)
+    s["decoder.conv_in.bias"] = (mid,)
+    for b in range(nb):
+        res(f"decoder.mid.{b}.", mid, mid)
+    for lvl in range(nres):
+        cin = hc * mult[-1] if lvl == nres - 1 else hc * mult[lvl + 1]
+        cout = hc * mult[lvl]
+        for b in range(nb):
+            res(f"decoder.up.{lvl}.block.{b}.", cin, cout)
+            cin = cout
+        if lvl != 0:
+            s[f"decoder.up.{lvl}.upsample_conv.weight"] = (cout, cout, 3, 3)
+            s[f"decoder.up.{lvl}.upsample_conv.bias"] = (cout,)
+    s["decoder.norm_out.weight"] = (hc * mult[0],)
+    s["decoder.norm_out.bias"] = (hc * mult[0],)
+    s["decoder.conv_out.weight"] = (cfg["num_channels"], hc * mult[0], 3, 3)
+    s["decoder.conv_out.bias"] = (cfg["num_channels"],)
+    s["quantize.embedding.weight"] = (cfg["num_embeddings"], cfg["quantized_embed_dim"])
+    return s
+
+
+def fill_state_dict(shapes: dict, seed: int, kind: str) -> dict:
+    """Seeded fp32 weights, filled in sorted-key order.
+
+    Norm scales are 1 + 0.1 N(0,1) (so a dropped/mis-indexed scale is visible), norm biases 0.1 N(0,1),
+    linear / embedding weights N(0, std) with a std that keeps activations O(1) through the depth, and the
+    VQ codebook N(0,1) * 0.5 so that nearest-code margins are far above fp32 round-off.
+    """
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for k in sorted(shapes):
+        shp = shapes[k]
+        x = rng.standard_normal(shp).astype(np.float32)
+        if "norm" in k or k.endswith("_ln.weight"):
+            x = (1.0 + 0.1 * x) if k.endswith("weight") else 0.1 * x
+        elif k == "quantize.embedding.weight":
+            x = 0.5 * x
+        elif k.endswith("bias"):
+            x = 0.05 * x
+        elif kind == "transformer":
+            fan_in = shp[-1]
+            x = x * (0.08 if "embeddings" in k else 1.0 / np.sqrt(fan_in))
+        else:  # conv weight (Cout, Cin, k, k)
+            fan_in = shp[1] * shp[2] * shp[3]
+            x = x * (1.0 / np.sqrt(fan_in))
+        sd[k] = torch.from_numpy(np.ascontiguousarray(x.astype(np.float32)))
+    return sd
+
+
+def transformer_inputs(cfg: dict, batch: int, seed: int):
+    """Seeded (input_ids, labels) shaped like the output of prepare_inputs_and_labels."""
+    rng = np.random.default_rng(seed)
+    S = cfg["num_vq_tokens"]
+    cb, V = cfg["codebook_size"], cfg["vocab_size"]
+    tokens = rng.integers(0, cb, size=(batch, S))
+    mask = rng.random((batch, S)) < 0.55
+    mask[:, 0] = True
+    input_ids = np.where(mask, V - 1, tokens)
+    labels = np.where(mask, tokens, -100)
+    cls = rng.integers(0, cfg["num_classes"], size=(batch, 1)) + cb
+    input_ids = np.concatenate([cls, input_ids], axis=1)
+    labels = np.concatenate([np.full((batch, 1), -100), labels], axis=1)
+    return torch.from_numpy(input_ids.astype(np.int64)), torch.from_numpy(labels.astype(np.int64))
+
+
+def images(batch: int, res: int, seed: int) -> torch.Tensor:
+    """Seeded synthetic images in [0,1] (ToTensor range, training/data.py:117-133), smooth + noise."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((batch, 3, res, res)).astype(np.float32)
+    return torch.from_numpy(x)
+
+
+def uniforms(shape, seed: int) -> torch.Tensor:
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.random(shape).astype(np.float32))

@@ -1,0 +1,67 @@
+"""CPU: the oracle restatement (oracle/maskgit_oracle.py) against golden vectors produced by the real reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from oracle import maskgit_oracle as O
+
+torch.set_num_threads(1)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("name,cfg", [("transformer_tiny", W.TRANSFORMER_TINY),
+                                      ("transformer_tiny_ls", W.TRANSFORMER_TINY),
+                                      ("transformer_hd48", W.TRANSFORMER_HD48)])
+def test_transformer_forward_backward(golden_dir, name, cfg):
+    g = _load(golden_dir, name)
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer")
+    ids, labels = W.transformer_inputs(cfg, int(g["batch"]), int(g["seed"]) + 1)
+    logits, loss, grads = O.transformer_loss_and_grads(sd, cfg, ids, labels, float(g["label_smoothing"]))
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-6)
+    for k, v in grads.items():
+        ref = g["grad." + k]
+        scale = max(float(np.abs(ref).max()), 1e-8)
+        assert float(np.abs(v.numpy() - ref).max()) <= 2e-5 * scale + 1e-9, k
+
+
+def test_adamw_step(golden_dir):
+    cfg = W.TRANSFORMER_TINY
+    g = _load(golden_dir, "transformer_tiny")
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer")
+    for k in ("mlm_layer.to_logits.weight", "transformer_layers.0.ffn.wo.weight", "encoder_layer_norm.weight"):
+        p = sd[k].clone()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        O.adamw_step(p, torch.from_numpy(g["grad." + k]), m, v, 1, 1e-4, 0.9, 0.999, 1e-8, 0.01)
+        np.testing.assert_allclose(p.numpy(), g["adamw." + k], rtol=0, atol=2e-7)
+
+
+def test_vqgan_encode_decode(golden_dir):
+    cfg = W.VQGAN_TINY
+    g = _load(golden_dir, "vqgan_tiny")
+    sd = W.fill_state_dict(W.vqgan_shapes(cfg), int(g["seed"]), "vqgan")
+    px = W.images(int(g["batch"]), cfg["resolution"], int(g["seed"]) + 1)
+    z, z_q, idx = O.vqgan_encode(sd, cfg, px)
+    np.testing.assert_allclose(z.numpy(), g["z"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(idx.numpy(), g["indices"])  # bit-exact token indices
+    np.testing.assert_allclose(z_q.numpy(), g["z_q"], rtol=0, atol=0)
+    rec = O.vqgan_decode_code(sd, cfg, idx)
+    np.testing.assert_allclose(rec.numpy(), g["rec"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["mask_b64", "mask_small"])
+def test_mask_sampling(golden_dir, name):
+    g = _load(golden_dir, name)
+    ids, labels, prob = O.prepare_inputs_and_labels(
+        torch.from_numpy(g["image_tokens"]), torch.from_numpy(g["class_ids"]), torch.from_numpy(g["timesteps"]),
+        torch.from_numpy(g["noise"]), int(g["mask_id"]), int(g["codebook_size"]), float(g["min_rate"]))
+    assert np.array_equal(ids.numpy(), g["input_ids"])      # bit-exact mask indices
+    assert np.array_equal(labels.numpy(), g["labels"])
+    np.testing.assert_array_equal(prob.numpy(), g["mask_prob"])
