@@ -1,0 +1,164 @@
+/* libmuse_hip — C-ABI of the MI355X (gfx950) kernels behind the open-muse MaskGit hot path.
+ *
+ * The reference (huggingface/open-muse) has no first-party native code: its hot path reaches native kernels only
+ * through torch / xformers / apex / flash_attn call sites.  Each entry point below names
+ * the reference call site it replaces (paths relative to the reference repo root).  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; the library holds no memory);
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*) and never synchronises;
+ *   - return 0 on success, a hipError_t (> 0) for launch errors, or a negative MUSE_ERR_* for argument errors;
+ *   - bf16 tensors are raw uint16 storage; "f32" is IEEE binary32; indices are int64 like torch.long;
+ *   - activations are row-major [tokens, features] (transformer) or NHWC (VQGAN).
+ */
+#ifndef MUSE_HIP_H
+#define MUSE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MUSE_F32 = 0, MUSE_BF16 = 1 };
+enum { MUSE_ERR_BAD_ARG = -1, MUSE_ERR_ALIGN = -2, MUSE_ERR_UNSUPPORTED = -3 };
+
+int muse_version(void); /* ABI version of this header */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * muse_gemm — C = epilogue(alpha * A * B^T), strided-batched, MFMA (bf16: v_mfma_f32_16x16x32_bf16,
+ * f32: v_mfma_f32_16x16x4_f32 = exact fp32 fma chain).
+ * layout_x = 0: X(r,k) at X + r*ld + k ("k-contiguous", the nn.Linear weight layout);
+ * layout_x = 1: X(r,k) at X + k*ld + r ("k-major", the transposed view backward needs).
+ * Replaces: every nn.Linear on the path (muse/modeling_transformer.py:198-200,218,789-798,979-984) and their
+ * autograd backward, torch.baddbmm / torch.matmul of Attention.attention (:226-238), and the VQ addmm
+ * (muse/modeling_maskgit_vqgan.py:310-315, via rowvec/bias: C = (zn[m] + en[n]) - 2 z.e).
+ * Batch index z in [0,batch) addresses X + (z / zdiv) * sX0 + (z % zdiv) * sX1  (e.g. (image, head)).
+ * Requirements: A, B 16-byte aligned; lda/ldb and batch strides multiples of 16 bytes; for a k-contiguous operand
+ * with K % (16/elsize) != 0 the row must be physically padded with zeros up to the next 16-byte chunk.
+ */
+typedef struct muse_gemm_desc {
+  const void* A;
+  const void* B;
+  void* C;
+  const void* bias;     /* f32 [N] or NULL: added per output column                       */
+  const void* rowvec;   /* f32 [M] or NULL: added per output row                          */
+  const void* residual; /* out_dtype [M, ldr] or NULL: added after the activation         */
+  int32_t dtype;        /* MUSE_F32 | MUSE_BF16 (A and B)                                  */
+  int32_t out_dtype;    /* MUSE_F32 | MUSE_BF16 (bf16 only with bf16 inputs)               */
+  int32_t layout_a, layout_b;
+  int32_t M, N, K;
+  int32_t batch, zdiv;
+  int64_t lda, ldb, ldc, ldr;
+  int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+  float alpha;
+  int32_t accumulate; /* C += ...                                                          */
+  int32_t act;        /* 0 none, 1 erf-GELU (F.gelu)                                       */
+} muse_gemm_desc;
+int muse_gemm(const muse_gemm_desc* d, void* stream);
+
+/* 2-D transpose out[c, r] = in[r, c] (strided-batched); used only by the fallback that feeds k-major operands to
+ * the k-contiguous GEMM path (MUSE_GEMM_TR=0). */
+int muse_transpose(const void* in, void* out, int32_t dtype, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out,
+                   int32_t batch, int64_t stride_in, int64_t stride_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Transformer element/row kernels.
+ * muse_layernorm_fwd: y = LayerNorm(x) * w (+ residual), weight-only LN (muse/modeling_transformer.py:124-137 at
+ *   :878,:883,:786,:796,:1269,:983) with the residual add of :884 / :903 fused.  mean/rstd [rows] f32 are saved.
+ * muse_layernorm_bwd: dx = LN'(dy) (+ dres);  dw_partial [nblk, cols] f32 holds per-block column sums of dy*xhat,
+ *   reduced into dw by muse_colsum (deterministic two-stage reduction).  Returns nblk via *nblk_out when dx==NULL.
+ */
+int muse_layernorm_fwd(const void* x, int32_t x_dtype, const float* w, const float* residual, void* y, int32_t y_dtype,
+                       float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream);
+int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* w,
+                       const float* mean, const float* rstd, const float* dres, void* dx, int32_t dx_dtype,
+                       float* dw_partial, int32_t nblk, int32_t rows, int32_t cols, void* stream);
+int muse_layernorm_bwd_nblk(int32_t rows);
+/* out[c] (+)= sum_r in[r, c], f32 */
+int muse_colsum(const float* in, float* out, int32_t rows, int32_t cols, int32_t accumulate, void* stream);
+
+/* softmax over the last dim of [rows, ld] (first `cols` valid, pad columns written as 0), in place capable.
+ * Replaces F.softmax at muse/modeling_transformer.py:236.  bwd: ds = p * (dp - sum(p*dp)). */
+int muse_softmax_fwd(const void* x, void* y, int32_t dtype, int64_t rows, int32_t cols, int64_t ld, void* stream);
+int muse_softmax_bwd(const void* p, const void* dp, void* ds, int32_t dtype, int64_t rows, int32_t cols, int64_t ld,
+                     void* stream);
+
+/* GLU: h = gelu_erf(a) * b with ab = [rows, 2*inter] (a = first half).  muse/modeling_transformer.py:789-792. */
+int muse_glu_fwd(const void* ab, void* h, int32_t dtype, int64_t rows, int32_t inter, void* stream);
+int muse_glu_bwd(const void* ab, const void* dh, void* dab, int32_t dtype, int64_t rows, int32_t inter, void* stream);
+/* y = gelu_erf(x); dx = dy * gelu'(x).  muse/modeling_transformer.py:981. */
+int muse_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream);
+int muse_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, void* stream);
+
+/* Embed.forward (muse/modeling_transformer.py:942-957): out[b,s,:] = word[ids[b,s],:] + pos[s,:], f32 out.
+ * bwd: deterministic (sorted by id on device, no float atomics): dword[v,:] (+)= sum over positions with id v,
+ * dpos[s,:] (+)= sum_b dout[b,s,:].  `scratch` needs muse_embed_bwd_scratch_floats(hidden, vocab) f32. */
+int muse_embed_fwd(const int64_t* ids, const float* word, const float* pos, float* out, int32_t batch, int32_t seq,
+                   int32_t hidden, int32_t vocab, void* stream);
+int muse_embed_bwd(const int64_t* ids, const float* dout, float* dword, float* dpos, float* scratch, int32_t batch,
+                   int32_t seq, int32_t hidden, int32_t vocab, int32_t accumulate, void* stream);
+int64_t muse_embed_bwd_scratch_floats(int32_t hidden, int32_t vocab);
+
+/* F.cross_entropy(logits, labels, ignore_index=-100, label_smoothing) (muse/modeling_transformer.py:1276-1279).
+ * fwd: row_loss[r], lse[r] per row, then loss = sum(row_loss over valid) / n_valid into loss_out[0], n_valid into
+ * loss_out[1] (f32).  bwd: dlogits = (softmax - target) * gscale / n_valid, 0 for ignored rows. */
+int muse_cross_entropy_fwd(const void* logits, int32_t dtype, const int64_t* labels, float* row_loss, float* lse,
+                           float* loss_out, int64_t rows, int32_t vocab, int64_t ld, float label_smoothing, void* stream);
+int muse_cross_entropy_bwd(const void* logits, int32_t dtype, const int64_t* labels, const float* lse,
+                           const float* loss_out, const float* grad_out, void* dlogits, int32_t dl_dtype, int64_t rows,
+                           int32_t vocab, int64_t ld, float label_smoothing, void* stream);
+
+/* AdamW over one flat f32 buffer (torch.optim.AdamW / apex FusedAdam(adam_w_mode) semantics,
+ * training/train_maskgit_imagenet.py:242-261,438); optionally refreshes the bf16 compute copy of the weights. */
+int muse_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
+
+/* prepare_inputs_and_labels (training/train_maskgit_imagenet.py:371-394) given the two uniform draws.
+ * tokens [B,S] i64, class_ids [B] i64, timesteps [B] f32, noise [B,S] f32 ->
+ * input_ids, labels [B,S+1] i64, mask_prob [B] f32.  S <= 1024. */
+int muse_mask_sample(const int64_t* tokens, const int64_t* class_ids, const float* timesteps, const float* noise,
+                     int64_t* input_ids, int64_t* labels, float* mask_prob, int32_t batch, int32_t seq, int64_t mask_id,
+                     int64_t codebook_size, float min_masking_rate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * MaskGitVQGAN kernels (NHWC activations).
+ * muse_conv2d_nhwc: stride-1 SAME convolution (Conv2dSame, muse/modeling_maskgit_vqgan.py:33-45) as implicit GEMM
+ *   on MFMA; weight pre-permuted to [Cout][KS][KS][Cin]; optional bias (f32 [Cout]), optional residual add
+ *   (ResnetBlock :85), optional nearest x2 upsample of the input folded into the gather (UpsamplingBlock :146-147).
+ *   H, W are the OUTPUT spatial dims.  Cin must be a multiple of 16/elsize.
+ */
+int muse_conv2d_nhwc(const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                     int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS,
+                     int32_t upsample, void* stream);
+/* GroupNorm(32, eps, affine) + SiLU (muse/modeling_maskgit_vqgan.py:61,73-78,186-187,236-237).
+ * stats: partial [B, nchunk, G, 2] f64 -> apply.  `partial` needs B*nchunk*G*2 doubles (nchunk from _nchunk). */
+int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, const float* gamma, const float* beta,
+                             double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
+                             int32_t apply_silu, void* stream);
+int muse_groupnorm_nchunk(int32_t HW);
+int muse_avgpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t C,
+                         void* stream); /* F.avg_pool2d(2,2), :112; H,W = input dims */
+/* layout / dtype conversion: NCHW f32 <-> NHWC (f32|bf16), channel padding with zeros up to Cpad */
+int muse_nchw_to_nhwc(const float* in, void* out, int32_t out_dtype, int32_t batch, int32_t C, int32_t HW, int32_t Cpad,
+                      void* stream);
+int muse_nhwc_to_nchw(const void* in, int32_t in_dtype, float* out, int32_t batch, int32_t C, int32_t HW, int32_t Cpad,
+                      void* stream);
+/* argmin over codes of dist [rows, ncodes] f32 (first index wins ties, like torch.argmin), :279/:346 */
+int muse_argmin_rows(const float* dist, int64_t* idx, int64_t rows, int32_t ncodes, int64_t ld, void* stream);
+/* sum of squares per row, f32 in / f32 out (VectorQuantizer.compute_distances :308-309) */
+int muse_row_sumsq(const float* x, float* out, int64_t rows, int32_t cols, int64_t ld, void* stream);
+/* codebook gather (get_codebook_entry :318-324): out[r, :] = codebook[idx[r], :] (f32 -> out_dtype) */
+int muse_gather_rows(const float* table, const int64_t* idx, void* out, int32_t out_dtype, int64_t rows, int32_t cols,
+                     void* stream);
+
+/* Probe used by the test-suite to pin the ds_read_b64_tr_b16 lane mapping this library relies on:
+ * out[lane*4 + j] for a 64-lane wave reading lds[i] = i (uint16) with per-lane byte address addr[lane]. */
+int muse_probe_tr16(const int32_t* addr, int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSE_HIP_H */

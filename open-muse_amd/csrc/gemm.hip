@@ -1,0 +1,39 @@
+// Dense / strided-batched GEMM entry point of libmuse_hip (see include/muse_hip.h: muse_gemm).
+#include "gemm_core.h"
+#include "../../include/muse_hip.h"
+
+template <typename T, typename TC>
+static int dispatch_layout(const GemmParams& p, int la, int lb, int batch, hipStream_t s) {
+  if (la == 0 && lb == 0) return launch_gemm<T, TC, 0, 0, PlainLoader<T, 0>, PlainLoader<T, 0>>(p, batch, s);
+  if (la == 0 && lb == 1) return launch_gemm<T, TC, 0, 1, PlainLoader<T, 0>, PlainLoader<T, 1>>(p, batch, s);
+  if (la == 1 && lb == 1) return launch_gemm<T, TC, 1, 1, PlainLoader<T, 1>, PlainLoader<T, 1>>(p, batch, s);
+  if (la == 1 && lb == 0) return launch_gemm<T, TC, 1, 0, PlainLoader<T, 1>, PlainLoader<T, 0>>(p, batch, s);
+  return MUSE_ERR_BAD_ARG;
+}
+
+extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return MUSE_ERR_BAD_ARG;
+  const int esz = d->dtype == MUSE_BF16 ? 2 : 4;
+  const int ch = 16 / esz;
+  // 16-byte vector loads: leading dimensions and sub-matrix offsets must be multiples of one chunk
+  if ((d->lda % ch) || (d->ldb % ch) || (((uintptr_t)d->A) & 15) || (((uintptr_t)d->B) & 15)) return MUSE_ERR_ALIGN;
+  if ((d->sA0 % ch) || (d->sA1 % ch) || (d->sB0 % ch) || (d->sB1 % ch)) return MUSE_ERR_ALIGN;
+  GemmParams p;
+  p.A = d->A; p.B = d->B; p.C = d->C;
+  p.bias = (const float*)d->bias; p.rowvec = (const float*)d->rowvec; p.residual = d->residual;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.zdiv = d->zdiv > 0 ? d->zdiv : 1;
+  p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
+  p.alpha = d->alpha; p.accumulate = d->accumulate; p.act = d->act;
+  p.cH = p.cW = p.cCin = p.cKS = p.cUps = 0;
+  const int batch = d->batch > 0 ? d->batch : 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == MUSE_BF16) {
+    if (d->out_dtype == MUSE_BF16) return dispatch_layout<bf16_t, bf16_t>(p, d->layout_a, d->layout_b, batch, s);
+    if (d->out_dtype == MUSE_F32) return dispatch_layout<bf16_t, float>(p, d->layout_a, d->layout_b, batch, s);
+  } else if (d->dtype == MUSE_F32 && d->out_dtype == MUSE_F32) {
+    return dispatch_layout<float, float>(p, d->layout_a, d->layout_b, batch, s);
+  }
+  return MUSE_ERR_BAD_ARG;
+}

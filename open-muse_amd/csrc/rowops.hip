@@ -1,0 +1,667 @@
+// Row / element kernels of the MaskGitTransformer path: LayerNorm, softmax, GLU, GELU, cross-entropy, embedding,
+// AdamW, casts, mask sampling.  All HBM-bound: 8/16-byte vector accesses, wave64 shuffle reductions, one wave per
+// row where a row fits a wave's registers.
+#include "common.h"
+#include "../../include/muse_hip.h"
+
+// ---- 4-element vector access helpers ---------------------------------------------------------------------------
+template <typename T> struct V4;
+template <> struct V4<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+template <> struct V4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    const u32x2 t = *(const u32x2*)p;
+    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    u32x2 t;
+    t[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    t[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *(u32x2*)p = t;
+  }
+};
+
+// =================================================================================================================
+// LayerNorm (weight only).  One wave per row, 4 rows per 256-thread block.
+// =================================================================================================================
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ res, TO* __restrict__ y,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows,
+                                                     int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const TI* xr = x + (long)row * cols;
+  float s = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) { float v[4]; V4<TI>::load(xr + c, v); s += (v[0] + v[1]) + (v[2] + v[3]); }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    float v[4]; V4<TI>::load(xr + c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; q = fmaf(d, d, q); }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+  if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  for (int c = lane * 4; c < cols; c += 256) {
+    float v[4], g[4], o[4];
+    V4<TI>::load(xr + c, v); V4<float>::load(w + c, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd * g[j];
+    if (res) { float r[4]; V4<float>::load(res + (long)row * cols + c, r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += r[j]; }
+    V4<TO>::store(y + (long)row * cols + c, o);
+  }
+}
+
+template <typename TI, typename TO>
+static int ln_fwd_launch(const void* x, const float* w, const float* res, void* y, float* mean, float* rstd, int rows,
+                         int cols, float eps, hipStream_t s) {
+  hipLaunchKernelGGL((ln_fwd_kernel<TI, TO>), dim3((rows + 3) / 4), dim3(256), 0, s, (const TI*)x, w, res, (TO*)y, mean, rstd,
+                     rows, cols, eps);
+  return (int)hipGetLastError();
+}
+
+extern "C" int muse_layernorm_fwd(const void* x, int32_t x_dtype, const float* w, const float* residual, void* y,
+                                  int32_t y_dtype, float* mean, float* rstd, int32_t rows, int32_t cols, float eps,
+                                  void* stream) {
+  if (cols % 4 || rows <= 0) return rows == 0 ? 0 : MUSE_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == MUSE_F32 && y_dtype == MUSE_F32) return ln_fwd_launch<float, float>(x, w, residual, y, mean, rstd, rows, cols, eps, s);
+  if (x_dtype == MUSE_F32 && y_dtype == MUSE_BF16) return ln_fwd_launch<float, bf16_t>(x, w, residual, y, mean, rstd, rows, cols, eps, s);
+  if (x_dtype == MUSE_BF16 && y_dtype == MUSE_F32) return ln_fwd_launch<bf16_t, float>(x, w, residual, y, mean, rstd, rows, cols, eps, s);
+  if (x_dtype == MUSE_BF16 && y_dtype == MUSE_BF16) return ln_fwd_launch<bf16_t, bf16_t>(x, w, residual, y, mean, rstd, rows, cols, eps, s);
+  return MUSE_ERR_BAD_ARG;
+}
+
+// backward: 64 rows per block (16 per wave); per-column dw partials live in registers (NIT*4 per lane).
+#define LN_BWD_ROWS 64
+template <typename TDY, typename TX, typename TDX, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     TDX* __restrict__ dx, float* __restrict__ dwp, int rows, int cols) {
+  __shared__ float red[4][NIT * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dwacc[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dwacc[it][j] = 0.f;
+  const int rbeg = blockIdx.x * LN_BWD_ROWS + wave * (LN_BWD_ROWS / 4);
+  for (int rr = 0; rr < LN_BWD_ROWS / 4; ++rr) {
+    const int row = rbeg + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    const TDY* dyr = dy + (long)row * cols;
+    const TX* xr = x + (long)row * cols;
+    float s1 = 0.f, s2 = 0.f;
+    float gk[NIT][4], xh[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < cols) {
+        float d[4], v[4], g[4];
+        V4<TDY>::load(dyr + c, d); V4<TX>::load(xr + c, v); V4<float>::load(w + c, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[it][j] = (v[j] - mu) * rs;
+          gk[it][j] = d[j] * g[j];
+          s1 += gk[it][j];
+          s2 = fmaf(gk[it][j], xh[it][j], s2);
+          dwacc[it][j] = fmaf(d[j], xh[it][j], dwacc[it][j]);
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)cols, c2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < cols) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rs * (gk[it][j] - c1 - xh[it][j] * c2);
+        if (dres) { float r[4]; V4<float>::load(dres + (long)row * cols + c, r);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += r[j]; }
+        V4<TDX>::store(dx + (long)row * cols + c, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][it * 256 + lane * 4 + j] = dwacc[it][j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256)
+    dwp[(long)blockIdx.x * cols + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+extern "C" int muse_layernorm_bwd_nblk(int32_t rows) { return (rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }
+
+template <typename TDY, typename TX, typename TDX>
+static int ln_bwd_launch(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                         const float* dres, void* dx, float* dwp, int nblk, int rows, int cols, hipStream_t s) {
+#define LNB(NIT) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, NIT>), dim3(nblk), dim3(256), 0, s, (const TDY*)dy, \
+                                    (const TX*)x, w, mean, rstd, dres, (TDX*)dx, dwp, rows, cols)
+  if (cols <= 256) LNB(1);
+  else if (cols <= 512) LNB(2);
+  else if (cols <= 1024) LNB(4);
+  else if (cols <= 2048) LNB(8);
+  else if (cols <= 3072) LNB(12);
+  else if (cols <= 4096) LNB(16);
+  else return MUSE_ERR_UNSUPPORTED;
+#undef LNB
+  return (int)hipGetLastError();
+}
+
+extern "C" int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* w,
+                                  const float* mean, const float* rstd, const float* dres, void* dx, int32_t dx_dtype,
+                                  float* dw_partial, int32_t nblk, int32_t rows, int32_t cols, void* stream) {
+  if (cols % 4) return MUSE_ERR_BAD_ARG;
+  if (rows <= 0) return 0;
+  if (nblk != muse_layernorm_bwd_nblk(rows)) return MUSE_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int key = dy_dtype * 4 + x_dtype * 2 + dx_dtype;
+  switch (key) {
+    case 0: return ln_bwd_launch<float, float, float>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+    case 1: return ln_bwd_launch<float, float, bf16_t>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+    case 2: return ln_bwd_launch<float, bf16_t, float>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+    case 3: return ln_bwd_launch<float, bf16_t, bf16_t>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+    case 4: return ln_bwd_launch<bf16_t, float, float>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+    case 5: return ln_bwd_launch<bf16_t, float, bf16_t>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+    case 6: return ln_bwd_launch<bf16_t, bf16_t, float>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+    case 7: return ln_bwd_launch<bf16_t, bf16_t, bf16_t>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+  }
+  return MUSE_ERR_BAD_ARG;
+}
+
+// out[c] (+)= sum_r in[r,c]; one thread per column, rows walked in order (deterministic)
+__global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int acc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < rows; r += 4) {
+    s0 += in[(long)r * cols + c]; s1 += in[(long)(r + 1) * cols + c];
+    s2 += in[(long)(r + 2) * cols + c]; s3 += in[(long)(r + 3) * cols + c];
+  }
+  for (; r < rows; ++r) s0 += in[(long)r * cols + c];
+  const float s = (s0 + s1) + (s2 + s3);
+  out[c] = acc ? out[c] + s : s;
+}
+extern "C" int muse_colsum(const float* in, float* out, int32_t rows, int32_t cols, int32_t accumulate, void* stream) {
+  if (cols <= 0) return 0;
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, rows, cols, accumulate);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// softmax over rows of [rows, ld] (cols valid); one wave per row, pad columns [cols, ld) written as 0
+// =================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int cols, long ld) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ld;
+  T* yr = y + row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, Elem<T>::load(xr + c));
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += expf(Elem<T>::load(xr + c) - m);
+  s = wave_sum(s);
+  const float inv = 1.0f / s;
+  for (int c = lane; c < (int)ld; c += 64) {
+    const float v = c < cols ? expf(Elem<T>::load(xr + c) - m) * inv : 0.f;
+    Elem<T>::store(yr + c, v);
+  }
+}
+extern "C" int muse_softmax_fwd(const void* x, void* y, int32_t dtype, int64_t rows, int32_t cols, int64_t ld, void* stream) {
+  if (rows <= 0) return 0;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == MUSE_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, (long)rows, cols, (long)ld);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)rows, cols, (long)ld);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ p, const T* __restrict__ dp, T* __restrict__ ds,
+                                                          long rows, int cols, long ld) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* pr = p + row * ld;
+  const T* dr = dp + row * ld;
+  T* sr = ds + row * ld;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s = fmaf(Elem<T>::load(pr + c), Elem<T>::load(dr + c), s);
+  s = wave_sum(s);
+  for (int c = lane; c < (int)ld; c += 64) {
+    const float v = c < cols ? Elem<T>::load(pr + c) * (Elem<T>::load(dr + c) - s) : 0.f;
+    Elem<T>::store(sr + c, v);
+  }
+}
+extern "C" int muse_softmax_bwd(const void* p, const void* dp, void* ds, int32_t dtype, int64_t rows, int32_t cols,
+                                int64_t ld, void* stream) {
+  if (rows <= 0) return 0;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == MUSE_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)p, (const float*)dp, (float*)ds, (long)rows, cols, (long)ld);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)ds, (long)rows, cols, (long)ld);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// GLU / GELU element kernels (4 elements per thread)
+// =================================================================================================================
+template <typename T>
+__global__ void glu_fwd_kernel(const T* __restrict__ ab, T* __restrict__ h, long rows, int inter) {
+  const long n4 = rows * (inter / 4);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (inter / 4);
+    const int c = (int)(i - r * (inter / 4)) * 4;
+    float a[4], b[4], o[4];
+    V4<T>::load(ab + r * 2 * inter + c, a);
+    V4<T>::load(ab + r * 2 * inter + inter + c, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]) * b[j];
+    V4<T>::store(h + r * inter + c, o);
+  }
+}
+template <typename T>
+__global__ void glu_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ dh, T* __restrict__ dab, long rows, int inter) {
+  const long n4 = rows * (inter / 4);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (inter / 4);
+    const int c = (int)(i - r * (inter / 4)) * 4;
+    float a[4], b[4], d[4], da[4], db[4];
+    V4<T>::load(ab + r * 2 * inter + c, a);
+    V4<T>::load(ab + r * 2 * inter + inter + c, b);
+    V4<T>::load(dh + r * inter + c, d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { da[j] = d[j] * b[j] * gelu_erf_grad(a[j]); db[j] = d[j] * gelu_erf(a[j]); }
+    V4<T>::store(dab + r * 2 * inter + c, da);
+    V4<T>::store(dab + r * 2 * inter + inter + c, db);
+  }
+}
+static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+extern "C" int muse_glu_fwd(const void* ab, void* h, int32_t dtype, int64_t rows, int32_t inter, void* stream) {
+  if (inter % 4) return MUSE_ERR_BAD_ARG;
+  if (rows <= 0) return 0;
+  const int g = ew_grid(rows * (inter / 4));
+  if (dtype == MUSE_F32) hipLaunchKernelGGL(glu_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)ab, (float*)h, (long)rows, inter);
+  else hipLaunchKernelGGL(glu_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ab, (bf16_t*)h, (long)rows, inter);
+  return (int)hipGetLastError();
+}
+extern "C" int muse_glu_bwd(const void* ab, const void* dh, void* dab, int32_t dtype, int64_t rows, int32_t inter, void* stream) {
+  if (inter % 4) return MUSE_ERR_BAD_ARG;
+  if (rows <= 0) return 0;
+  const int g = ew_grid(rows * (inter / 4));
+  if (dtype == MUSE_F32) hipLaunchKernelGGL(glu_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)ab, (const float*)dh, (float*)dab, (long)rows, inter);
+  else hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ab, (const bf16_t*)dh, (bf16_t*)dab, (long)rows, inter);
+  return (int)hipGetLastError();
+}
+
+template <typename T, int MODE>  // MODE 0: y = gelu(x); 1: dx = dy * gelu'(x)
+__global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, long n) {
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float a[4], o[4];
+    V4<T>::load(x + i * 4, a);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]);
+    } else {
+      float d[4]; V4<T>::load(dy + i * 4, d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = d[j] * gelu_erf_grad(a[j]);
+    }
+    V4<T>::store(out + i * 4, o);
+  }
+}
+extern "C" int muse_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream) {
+  if (n % 4) return MUSE_ERR_BAD_ARG;
+  if (n <= 0) return 0;
+  if (dtype == MUSE_F32) hipLaunchKernelGGL((gelu_kernel<float, 0>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)nullptr, (float*)y, (long)n);
+  else hipLaunchKernelGGL((gelu_kernel<bf16_t, 0>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, (long)n);
+  return (int)hipGetLastError();
+}
+extern "C" int muse_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, void* stream) {
+  if (n % 4) return MUSE_ERR_BAD_ARG;
+  if (n <= 0) return 0;
+  if (dtype == MUSE_F32) hipLaunchKernelGGL((gelu_kernel<float, 1>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, (long)n);
+  else hipLaunchKernelGGL((gelu_kernel<bf16_t, 1>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long)n);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// Embedding: word[ids] + pos[s]  (f32).  Backward is deterministic: no float atomics anywhere.
+// =================================================================================================================
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+                                 float* __restrict__ out, int seq, int hidden, int vocab) {
+  const int t = blockIdx.x;  // token index b*seq + s
+  const int s = t % seq;
+  long id = ids[t];
+  if (id < 0 || id >= vocab) id = 0;  // torch would raise; keep the kernel memory safe
+  for (int c = threadIdx.x * 4; c < hidden; c += blockDim.x * 4) {
+    float a[4], b[4], o[4];
+    V4<float>::load(word + id * hidden + c, a); V4<float>::load(pos + (long)s * hidden + c, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = a[j] + b[j];
+    V4<float>::store(out + (long)t * hidden + c, o);
+  }
+}
+extern "C" int muse_embed_fwd(const int64_t* ids, const float* word, const float* pos, float* out, int32_t batch,
+                              int32_t seq, int32_t hidden, int32_t vocab, void* stream) {
+  if (hidden % 4) return MUSE_ERR_BAD_ARG;
+  if (batch * seq <= 0) return 0;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(batch * seq), dim3(64), 0, (hipStream_t)stream, ids, word, pos, out, seq, hidden, vocab);
+  return (int)hipGetLastError();
+}
+
+#define EMB_SPLIT 8
+// partial[split][v][:] = sum (in position order) of dout[t,:] over tokens t in this split with ids[t] == v
+__global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                                float* __restrict__ partial, int ntok, int hidden, int vocab) {
+  const int v = blockIdx.x, sp = blockIdx.y;
+  const int per = (ntok + EMB_SPLIT - 1) / EMB_SPLIT;
+  const int t0 = sp * per, t1 = min(ntok, t0 + per);
+  __shared__ int hits[256];
+  __shared__ int nhit;
+  // up to 16 columns per thread (hidden <= 4096)
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int base = t0; base < t1; base += 256) {
+    const int t = base + threadIdx.x;
+    const bool hit = (t < t1) && (ids[t] == (int64_t)v);
+    // ordered compaction of this chunk's hits
+    const unsigned long long bal = __ballot(hit);
+    __shared__ int wcnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wcnt[w];
+    if (hit) hits[off + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+    if (threadIdx.x == 0) nhit = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+    const int n = nhit;
+    for (int h = 0; h < n; ++h) {
+      const float* src = dout + (long)hits[h] * hidden;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { const int c = threadIdx.x + j * 256; if (c < hidden) acc[j] += src[c]; }
+    }
+    __syncthreads();
+  }
+  float* dst = partial + ((long)sp * vocab + v) * hidden;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { const int c = threadIdx.x + j * 256; if (c < hidden) dst[c] = acc[j]; }
+}
+__global__ void embed_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dword, long n, int acc) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < EMB_SPLIT; ++sp) s += partial[(long)sp * n + i];
+    dword[i] = acc ? dword[i] + s : s;
+  }
+}
+__global__ void embed_bwd_pos_kernel(const float* __restrict__ dout, float* __restrict__ dpos, int batch, int seq, int hidden, int acc) {
+  const int s = blockIdx.x;
+  for (int c = threadIdx.x; c < hidden; c += blockDim.x) {
+    float a = 0.f;
+    for (int b = 0; b < batch; ++b) a += dout[((long)b * seq + s) * hidden + c];
+    float* d = dpos + (long)s * hidden + c;
+    *d = acc ? *d + a : a;
+  }
+}
+extern "C" int muse_embed_bwd(const int64_t* ids, const float* dout, float* dword, float* dpos, float* scratch,
+                              int32_t batch, int32_t seq, int32_t hidden, int32_t vocab, int32_t accumulate, void* stream) {
+  if (hidden > 4096) return MUSE_ERR_UNSUPPORTED;
+  if (batch * seq <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_bwd_partial_kernel, dim3(vocab, EMB_SPLIT), dim3(256), 0, s, ids, dout, scratch, batch * seq, hidden, vocab);
+  const long n = (long)vocab * hidden;
+  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)scratch, dword, n, accumulate);
+  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(seq), dim3(256), 0, s, dout, dpos, batch, seq, hidden, accumulate);
+  return (int)hipGetLastError();
+}
+extern "C" int64_t muse_embed_bwd_scratch_floats(int32_t hidden, int32_t vocab) { return (int64_t)EMB_SPLIT * vocab * hidden; }
+
+// =================================================================================================================
+// Cross entropy (ignore_index = -100, label smoothing, mean over valid rows)
+// =================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                     float* __restrict__ row_loss, float* __restrict__ lse_o, long rows,
+                                                     int vocab, long ld, float ls) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = logits + row * ld;
+  float m = -INFINITY, sx = 0.f;
+  for (int c = lane; c < vocab; c += 64) { const float v = Elem<T>::load(xr + c); m = fmaxf(m, v); sx += v; }
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < vocab; c += 64) s += expf(Elem<T>::load(xr + c) - m);
+  s = wave_sum(s);
+  sx = wave_sum(sx);
+  const float lse = m + logf(s);
+  if (lane == 0) {
+    lse_o[row] = lse;
+    const int64_t lab = labels[row];
+    float l = 0.f;
+    if (lab >= 0 && lab < vocab) {
+      const float nll = lse - Elem<T>::load(xr + lab);
+      const float smooth = lse - sx / (float)vocab;
+      l = (1.0f - ls) * nll + ls * smooth;
+    }
+    row_loss[row] = l;
+  }
+}
+__global__ __launch_bounds__(1024) void ce_reduce_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels,
+                                                         float* __restrict__ out, long rows, int vocab) {
+  __shared__ double ssum[16];
+  __shared__ int scnt[16];
+  double s = 0.0; int n = 0;
+  for (long r = threadIdx.x; r < rows; r += 1024) {
+    const int64_t lab = labels[r];
+    if (lab >= 0 && lab < vocab) { s += (double)row_loss[r]; ++n; }
+  }
+  s = wave_sum_d(s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0; int c = 0;
+    for (int i = 0; i < 16; ++i) { t += ssum[i]; c += scnt[i]; }
+    out[0] = (float)(t / (double)c);  // 0/0 -> nan, like torch
+    out[1] = (float)c;
+  }
+}
+extern "C" int muse_cross_entropy_fwd(const void* logits, int32_t dtype, const int64_t* labels, float* row_loss, float* lse,
+                                      float* loss_out, int64_t rows, int32_t vocab, int64_t ld, float label_smoothing,
+                                      void* stream) {
+  if (rows <= 0) return MUSE_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == MUSE_F32) hipLaunchKernelGGL(ce_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)logits, labels, row_loss, lse, (long)rows, vocab, (long)ld, label_smoothing);
+  else hipLaunchKernelGGL(ce_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)logits, labels, row_loss, lse, (long)rows, vocab, (long)ld, label_smoothing);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_loss, labels, loss_out, (long)rows, vocab);
+  return (int)hipGetLastError();
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ lse, const float* __restrict__ loss_out,
+                                                     const float* __restrict__ gout, TO* __restrict__ dl, long rows, int vocab,
+                                                     long ld, float ls) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t lab = labels[row];
+  TO* dr = dl + row * ld;
+  if (lab < 0 || lab >= vocab) {
+    for (int c = lane; c < vocab; c += 64) Elem<TO>::store(dr + c, 0.f);
+    return;
+  }
+  const float g = gout[0] / loss_out[1];
+  const float l = lse[row];
+  const T* xr = logits + row * ld;
+  const float off = ls / (float)vocab;
+  for (int c = lane; c < vocab; c += 64) {
+    float p = expf(Elem<T>::load(xr + c) - l) - off;
+    if (c == (int)lab) p -= (1.0f - ls);
+    Elem<TO>::store(dr + c, p * g);
+  }
+}
+extern "C" int muse_cross_entropy_bwd(const void* logits, int32_t dtype, const int64_t* labels, const float* lse,
+                                      const float* loss_out, const float* grad_out, void* dlogits, int32_t dl_dtype,
+                                      int64_t rows, int32_t vocab, int64_t ld, float label_smoothing, void* stream) {
+  if (rows <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+#define CEB(T, TO) hipLaunchKernelGGL((ce_bwd_kernel<T, TO>), grid, dim3(256), 0, s, (const T*)logits, labels, lse, loss_out, grad_out, (TO*)dlogits, (long)rows, vocab, (long)ld, label_smoothing)
+  if (dtype == MUSE_F32 && dl_dtype == MUSE_F32) CEB(float, float);
+  else if (dtype == MUSE_F32 && dl_dtype == MUSE_BF16) CEB(float, bf16_t);
+  else if (dtype == MUSE_BF16 && dl_dtype == MUSE_F32) CEB(bf16_t, float);
+  else CEB(bf16_t, bf16_t);
+#undef CEB
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// AdamW over a flat f32 buffer; optional bf16 shadow refresh.  7 x 4 B per parameter of HBM traffic (+2 B shadow).
+// =================================================================================================================
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
+                                                    float b2, float eps, float wd, float step_size, float inv_bc2_sqrt,
+                                                    float gscale) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float pp[4], gg[4], mm[4], vv[4];
+    V4<float>::load(p + i * 4, pp); V4<float>::load(g + i * 4, gg); V4<float>::load(m + i * 4, mm); V4<float>::load(v + i * 4, vv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * gscale;
+      pp[j] = pp[j] * (1.0f - lr * wd);
+      mm[j] = fmaf(1.0f - b1, gr - mm[j], mm[j]);      // exp_avg.lerp_(grad, 1 - beta1)
+      vv[j] = fmaf(1.0f - b2, gr * gr, vv[j] * b2);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float denom = sqrtf(vv[j]) * inv_bc2_sqrt + eps;
+      pp[j] = pp[j] - step_size * (mm[j] / denom);
+    }
+    V4<float>::store(p + i * 4, pp); V4<float>::store(m + i * 4, mm); V4<float>::store(v + i * 4, vv);
+    if (pb) V4<bf16_t>::store(pb + i * 4, pp);
+  }
+  // tail (n % 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const float gr = g[i] * gscale;
+    float pp = p[i] * (1.0f - lr * wd);
+    const float mm = fmaf(1.0f - b1, gr - m[i], m[i]);
+    const float vv = fmaf(1.0f - b2, gr * gr, v[i] * b2);
+    pp = pp - step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (pb) pb[i] = f32_to_bf16(pp);
+  }
+}
+extern "C" int muse_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+  if (n <= 0) return 0;
+  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return MUSE_ERR_ALIGN;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
+                     (long)n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale);
+  return (int)hipGetLastError();
+}
+
+__global__ void cast_f2b_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float a[4]; V4<float>::load(in + i * 4, a); V4<bf16_t>::store(out + i * 4, a);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const long i = (n4 << 2) + threadIdx.x; out[i] = f32_to_bf16(in[i]); }
+}
+__global__ void cast_b2f_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float a[4]; V4<bf16_t>::load(in + i * 4, a); V4<float>::store(out + i * 4, a);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const long i = (n4 << 2) + threadIdx.x; out[i] = bf16_to_f32(in[i]); }
+}
+extern "C" int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  if ((((uintptr_t)in) & 15) || (((uintptr_t)out) & 7)) return MUSE_ERR_ALIGN;
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)n);
+  return (int)hipGetLastError();
+}
+extern "C" int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  if ((((uintptr_t)out) & 15) || (((uintptr_t)in) & 7)) return MUSE_ERR_ALIGN;
+  hipLaunchKernelGGL(cast_b2f_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, out, (long)n);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// Mask sampling of the train step: cosine schedule -> count -> argsort(noise) -> threshold the argsort array.
+// One block per image; rank by counting (S <= 1024), ties broken by position (stable order).
+// =================================================================================================================
+__global__ __launch_bounds__(256) void mask_sample_kernel(const int64_t* __restrict__ tokens, const int64_t* __restrict__ class_ids,
+                                                          const float* __restrict__ timesteps, const float* __restrict__ noise,
+                                                          int64_t* __restrict__ input_ids, int64_t* __restrict__ labels,
+                                                          float* __restrict__ mask_prob, int seq, int64_t mask_id,
+                                                          int64_t codebook, float min_rate) {
+  __shared__ float nz[1024];
+  __shared__ int perm[1024];
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < seq; i += 256) nz[i] = noise[(long)b * seq + i];
+  __syncthreads();
+  // cos(t * pi * 0.5) in the reference is fl32(fl32(t * fl32(pi)) * 0.5) then cosf; evaluate the cosine in f64 and
+  // round once so the result is the correctly rounded f32 cosine of that argument.
+  const float arg = (timesteps[b] * 3.14159265358979323846f) * 0.5f;
+  float prob = (float)cos((double)arg);
+  prob = fmaxf(prob, min_rate);
+  float kf = rintf((float)seq * prob);  // torch.round = half-to-even
+  kf = fmaxf(kf, 1.0f);
+  const int k = (int)kf;
+  for (int i = threadIdx.x; i < seq; i += 256) {
+    const float v = nz[i];
+    int r = 0;
+    for (int j = 0; j < seq; ++j) { const float u = nz[j]; r += (u < v) || (u == v && j < i); }
+    perm[r] = i;
+  }
+  __syncthreads();
+  int64_t* ir = input_ids + (long)b * (seq + 1);
+  int64_t* lr = labels + (long)b * (seq + 1);
+  if (threadIdx.x == 0) { ir[0] = class_ids[b] + codebook; lr[0] = -100; mask_prob[b] = prob; }
+  for (int j = threadIdx.x; j < seq; j += 256) {
+    const bool masked = perm[j] < k;
+    const int64_t t = tokens[(long)b * seq + j];
+    ir[j + 1] = masked ? mask_id : t;
+    lr[j + 1] = masked ? t : (int64_t)-100;
+  }
+}
+extern "C" int muse_mask_sample(const int64_t* tokens, const int64_t* class_ids, const float* timesteps, const float* noise,
+                                int64_t* input_ids, int64_t* labels, float* mask_prob, int32_t batch, int32_t seq,
+                                int64_t mask_id, int64_t codebook_size, float min_masking_rate, void* stream) {
+  if (seq > 1024 || seq <= 0) return MUSE_ERR_UNSUPPORTED;
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(mask_sample_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, tokens, class_ids, timesteps, noise,
+                     input_ids, labels, mask_prob, seq, mask_id, codebook_size, min_masking_rate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int muse_version(void) { return 1; }

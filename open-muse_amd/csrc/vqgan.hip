@@ -1,0 +1,340 @@
+// MaskGitVQGAN kernels (NHWC): implicit-GEMM convolution entry, GroupNorm+SiLU, avg-pool, layout changes,
+// VQ helpers (row |z|^2, argmin, codebook gather), 2-D transpose and the tr16 probe.
+#include "gemm_core.h"
+#include "../../include/muse_hip.h"
+
+// =================================================================================================================
+// conv2d NHWC stride-1 SAME as implicit GEMM:  M = B*H*W pixels, N = Cout, K = KS*KS*Cin
+// =================================================================================================================
+extern "C" int muse_conv2d_nhwc(const void* in, const void* weight, const float* bias, const void* residual, void* out,
+                                int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS,
+                                int32_t upsample, void* stream) {
+  const int esz = dtype == MUSE_BF16 ? 2 : 4, ch = 16 / esz;
+  if (Cin % ch) return MUSE_ERR_ALIGN;
+  if ((((uintptr_t)in) & 15) || (((uintptr_t)weight) & 15)) return MUSE_ERR_ALIGN;
+  if (KS != 1 && KS != 3) return MUSE_ERR_UNSUPPORTED;
+  if (upsample && ((H | W) & 1)) return MUSE_ERR_BAD_ARG;
+  GemmParams p;
+  p.A = in; p.B = weight; p.C = out;
+  p.bias = bias; p.rowvec = nullptr; p.residual = residual;
+  p.M = batch * H * W; p.N = Cout; p.K = KS * KS * Cin;
+  p.lda = 0; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
+  p.zdiv = 1; p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
+  p.alpha = 1.0f; p.accumulate = 0; p.act = 0;
+  p.cH = H; p.cW = W; p.cCin = Cin; p.cKS = KS; p.cUps = upsample ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MUSE_BF16) return launch_gemm<bf16_t, bf16_t, 0, 0, ConvLoader<bf16_t>, PlainLoader<bf16_t, 0>>(p, 1, s);
+  if (dtype == MUSE_F32) return launch_gemm<float, float, 0, 0, ConvLoader<float>, PlainLoader<float, 0>>(p, 1, s);
+  return MUSE_ERR_BAD_ARG;
+}
+
+// =================================================================================================================
+// GroupNorm(G) + SiLU over NHWC.  Pass 1: per (image, pixel-chunk) partial sum / sum-of-squares per group in f64.
+// Pass 2: each block folds the partials of its image (fixed order), then y = silu((x - mean) * rstd * gamma + beta).
+// =================================================================================================================
+#define GN_PIX_PER_CHUNK 1024
+extern "C" int muse_groupnorm_nchunk(int32_t HW) { return (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK; }
+
+template <typename T, int VEC>
+__device__ __forceinline__ void loadv(const T* p, float (&v)[VEC]);
+template <> __device__ __forceinline__ void loadv<float, 4>(const float* p, float (&v)[4]) {
+  const f32x4 t = *(const f32x4*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void loadv<bf16_t, 8>(const bf16_t* p, float (&v)[8]) {
+  const u32x4 t = *(const u32x4*)p;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(t[j] << 16); v[2 * j + 1] = __uint_as_float(t[j] & 0xffff0000u); }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void storev(T* p, const float (&v)[VEC]);
+template <> __device__ __forceinline__ void storev<float, 4>(float* p, const float (&v)[4]) { *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]}; }
+template <> __device__ __forceinline__ void storev<bf16_t, 8>(bf16_t* p, const float (&v)[8]) {
+  u32x4 t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = (uint32_t)f32_to_bf16(v[2 * j]) | ((uint32_t)f32_to_bf16(v[2 * j + 1]) << 16);
+  *(u32x4*)p = t;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ partial, int HW, int C, int G) {
+  __shared__ double gs[64], gq[64];
+  const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+  if (threadIdx.x < G) { gs[threadIdx.x] = 0.0; gq[threadIdx.x] = 0.0; }
+  __syncthreads();
+  const int vpp = C / VEC;             // vectors per pixel
+  const int cpg = C / G;
+  const int p0 = chunk * GN_PIX_PER_CHUNK, p1 = min(HW, p0 + GN_PIX_PER_CHUNK);
+  double s[VEC], q[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s[j] = 0.0; q[j] = 0.0; }
+  const int vc = threadIdx.x % vpp;    // fixed channel-vector per thread (vpp divides 256 or exceeds it)
+  if (vpp <= 256) {
+    const int ppi = 256 / vpp;         // pixels per block iteration
+    for (int p = p0 + threadIdx.x / vpp; p < p1; p += ppi) {
+      float v[VEC];
+      loadv<T, VEC>(x + ((long)b * HW + p) * C + vc * VEC, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += (double)v[j]; q[j] += (double)v[j] * (double)v[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int g = (vc * VEC + j) / cpg;
+      atomicAdd(&gs[g], s[j]); atomicAdd(&gq[g], q[j]);
+    }
+  } else {  // very wide C: walk channel vectors too
+    for (int p = p0; p < p1; ++p)
+      for (int v0 = threadIdx.x; v0 < vpp; v0 += 256) {
+        float v[VEC];
+        loadv<T, VEC>(x + ((long)b * HW + p) * C + v0 * VEC, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const int g = (v0 * VEC + j) / cpg;
+          atomicAdd(&gs[g], (double)v[j]); atomicAdd(&gq[g], (double)v[j] * (double)v[j]);
+        }
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    double* o = partial + (((long)b * nchunk + chunk) * G + threadIdx.x) * 2;
+    o[0] = gs[threadIdx.x]; o[1] = gq[threadIdx.x];
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const double* __restrict__ partial,
+                                                       int HW, int C, int G, int nchunk, float eps, int silu) {
+  __shared__ float sc[2048], sh[2048];
+  __shared__ float gmean[64], grstd[64];
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpg = C / G;
+  if (threadIdx.x < G) {
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+      const double* o = partial + (((long)b * nchunk + c) * G + threadIdx.x) * 2;
+      s += o[0]; q += o[1];
+    }
+    const double n = (double)HW * (double)cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gmean[threadIdx.x] = (float)mean;
+    grstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    const float scale = grstd[g] * gamma[c];
+    sc[c] = scale;
+    sh[c] = beta[c] - scale * gmean[g];
+  }
+  __syncthreads();
+  const int vpp = C / VEC;
+  const int p0 = chunk * GN_PIX_PER_CHUNK, p1 = min(HW, p0 + GN_PIX_PER_CHUNK);
+  const long nv = (long)(p1 - p0) * vpp;
+  for (long i = threadIdx.x; i < nv; i += 256) {
+    const int p = p0 + (int)(i / vpp), vc = (int)(i % vpp);
+    const long off = ((long)b * HW + p) * C + vc * VEC;
+    float v[VEC];
+    loadv<T, VEC>(x + off, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = v[j] * sc[vc * VEC + j] + sh[vc * VEC + j];
+      if (silu) t = t / (1.0f + expf(-t));
+      v[j] = t;
+    }
+    storev<T, VEC>(y + off, v);
+  }
+}
+
+extern "C" int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, const float* gamma, const float* beta,
+                                        double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
+                                        int32_t apply_silu, void* stream) {
+  const int vec = dtype == MUSE_BF16 ? 8 : 4;
+  if (groups > 64 || C > 2048 || (C % groups) || (C % vec)) return MUSE_ERR_UNSUPPORTED;
+  const int vpp = C / vec;
+  if (vpp <= 256 && (256 % vpp)) return MUSE_ERR_UNSUPPORTED;
+  if (batch <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = muse_groupnorm_nchunk(HW);
+  dim3 grid(nchunk, batch);
+  if (dtype == MUSE_F32) {
+    hipLaunchKernelGGL((gn_stats_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, partial, HW, C, groups);
+    hipLaunchKernelGGL((gn_apply_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, (float*)y, gamma, beta,
+                       (const double*)partial, HW, C, groups, nchunk, eps, apply_silu);
+  } else {
+    hipLaunchKernelGGL((gn_stats_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, partial, HW, C, groups);
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, gamma, beta,
+                       (const double*)partial, HW, C, groups, nchunk, eps, apply_silu);
+  }
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// avg_pool2d(2,2) NHWC
+// =================================================================================================================
+template <typename T, int VEC>
+__global__ void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  const int oh = H >> 1, ow = W >> 1, vpp = C / VEC;
+  const long n = (long)B * oh * ow * vpp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int vc = (int)(i % vpp);
+    long t = i / vpp;
+    const int ox = (int)(t % ow); t /= ow;
+    const int oy = (int)(t % oh);
+    const int b = (int)(t / oh);
+    const T* src = x + (((long)b * H + 2 * oy) * W + 2 * ox) * C + vc * VEC;
+    float a[VEC], c0[VEC], c1[VEC], c2[VEC];
+    loadv<T, VEC>(src, a); loadv<T, VEC>(src + C, c0); loadv<T, VEC>(src + (long)W * C, c1); loadv<T, VEC>(src + (long)W * C + C, c2);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a[j] = (((a[j] + c0[j]) + c1[j]) + c2[j]) * 0.25f;
+    storev<T, VEC>(y + (((long)b * oh + oy) * ow + ox) * C + vc * VEC, a);
+  }
+}
+extern "C" int muse_avgpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t C,
+                                    void* stream) {
+  const int vec = dtype == MUSE_BF16 ? 8 : 4;
+  if ((C % vec) || ((H | W) & 1)) return MUSE_ERR_BAD_ARG;
+  const long n = (long)batch * (H / 2) * (W / 2) * (C / vec);
+  if (n <= 0) return 0;
+  long g = (n + 255) / 256; if (g > 8192) g = 8192;
+  if (dtype == MUSE_F32) hipLaunchKernelGGL((avgpool_kernel<float, 4>), dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, batch, H, W, C);
+  else hipLaunchKernelGGL((avgpool_kernel<bf16_t, 8>), dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, batch, H, W, C);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// layout conversion NCHW f32 <-> NHWC (f32 | bf16) with zero channel padding
+// =================================================================================================================
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int C, int HW, int Cpad, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW; const int p = (int)(i - b * HW);
+    for (int c = 0; c < Cpad; ++c) {
+      const float v = c < C ? in[(b * C + c) * HW + p] : 0.f;
+      Elem<T>::store(out + i * Cpad + c, v);
+    }
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int C, int HW, int Cpad, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW; const int p = (int)(i - b * HW);
+    for (int c = 0; c < C; ++c) out[(b * C + c) * HW + p] = Elem<T>::load(in + i * Cpad + c);
+  }
+}
+extern "C" int muse_nchw_to_nhwc(const float* in, void* out, int32_t out_dtype, int32_t batch, int32_t C, int32_t HW,
+                                 int32_t Cpad, void* stream) {
+  const long npix = (long)batch * HW;
+  if (npix <= 0) return 0;
+  long g = (npix + 255) / 256; if (g > 8192) g = 8192;
+  if (out_dtype == MUSE_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, in, (float*)out, C, HW, Cpad, npix);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, C, HW, Cpad, npix);
+  return (int)hipGetLastError();
+}
+extern "C" int muse_nhwc_to_nchw(const void* in, int32_t in_dtype, float* out, int32_t batch, int32_t C, int32_t HW,
+                                 int32_t Cpad, void* stream) {
+  const long npix = (long)batch * HW;
+  if (npix <= 0) return 0;
+  long g = (npix + 255) / 256; if (g > 8192) g = 8192;
+  if (in_dtype == MUSE_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const float*)in, out, C, HW, Cpad, npix);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, out, C, HW, Cpad, npix);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// VQ helpers
+// =================================================================================================================
+__global__ __launch_bounds__(256) void argmin_rows_kernel(const float* __restrict__ d, int64_t* __restrict__ idx, long rows, int n, long ld) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* r = d + row * ld;
+  float best = INFINITY; int bi = 0x7fffffff;
+  for (int c = lane; c < n; c += 64) { const float v = r[c]; if (v < best) { best = v; bi = c; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) idx[row] = (int64_t)bi;
+}
+extern "C" int muse_argmin_rows(const float* dist, int64_t* idx, int64_t rows, int32_t ncodes, int64_t ld, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(argmin_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dist, idx, (long)rows, ncodes, (long)ld);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int cols, long ld) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  double s = 0.0;
+  for (int c = lane; c < cols; c += 64) { const double v = (double)x[row * ld + c]; s += v * v; }
+  s = wave_sum_d(s);
+  if (lane == 0) out[row] = (float)s;
+}
+extern "C" int muse_row_sumsq(const float* x, float* out, int64_t rows, int32_t cols, int64_t ld, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(row_sumsq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, (long)rows, cols, (long)ld);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, T* __restrict__ out, long rows, int cols) {
+  const long r = blockIdx.x;
+  const int64_t id = idx[r];
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) Elem<T>::store(out + r * cols + c, table[id * cols + c]);
+}
+extern "C" int muse_gather_rows(const float* table, const int64_t* idx, void* out, int32_t out_dtype, int64_t rows, int32_t cols,
+                                void* stream) {
+  if (rows <= 0) return 0;
+  if (out_dtype == MUSE_F32) hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, table, idx, (float*)out, (long)rows, cols);
+  else hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, table, idx, (bf16_t*)out, (long)rows, cols);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// 2-D transpose (fallback path only) and the tr16 probe
+// =================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int rows, int cols, long ldi,
+                                                        long ldo, long si, long so) {
+  __shared__ T tile[32][33];
+  const T* ib = in + (long)blockIdx.z * si;
+  T* ob = out + (long)blockIdx.z * so;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    if (r < rows && c < cols) tile[j][tx] = ib[(long)r * ldi + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < rows && c < cols) ob[(long)c * ldo + r] = tile[tx][j];
+  }
+}
+extern "C" int muse_transpose(const void* in, void* out, int32_t dtype, int32_t rows, int32_t cols, int64_t ld_in,
+                              int64_t ld_out, int32_t batch, int64_t stride_in, int64_t stride_out, void* stream) {
+  if (rows <= 0 || cols <= 0 || batch <= 0) return 0;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  if (dtype == MUSE_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, rows, cols, (long)ld_in, (long)ld_out, (long)stride_in, (long)stride_out);
+  else hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, rows, cols, (long)ld_in, (long)ld_out, (long)stride_in, (long)stride_out);
+  return (int)hipGetLastError();
+}
+
+__global__ void probe_tr16_kernel(const int* __restrict__ addr, int* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[8192];
+  for (int i = threadIdx.x; i < 8192; i += 64) lds[i] = (unsigned short)i;
+  __syncthreads();
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const unsigned char* a = (const unsigned char*)lds + addr[threadIdx.x];
+  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (int)(unsigned short)r[j];
+}
+extern "C" int muse_probe_tr16(const int32_t* addr, int32_t* out, void* stream) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, addr, out);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,330 @@
+"""Thin Python wrappers over the libmuse_hip C-ABI (one function per kernel entry point, no autograd here).
+
+Tensors are allocated by PyTorch; every wrapper enqueues on torch's current HIP stream.  All of them raise
+MuseHipError if the tensors are not on the GPU or the native library is missing: there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _hip
+from ._hip import BF16, F32, GemmDesc, check, dt, lib, ptr, require_gpu, stream
+
+# MUSE_GEMM_TR=0 routes k-major GEMM operands through an explicit transpose + the k-contiguous path instead of the
+# ds_read_b64_tr_b16 path (debug / bring-up switch; both run on the GPU through libmuse_hip).
+USE_TR = os.environ.get("MUSE_GEMM_TR", "1") != "0"
+
+
+def _esz(t):
+    return t.element_size()
+
+
+def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, rowvec=None,
+         residual=None, ldr=0, batch=1, zdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), accumulate=False, act=0):
+    """C[z] = epilogue(alpha * A[z] @ B[z]^T).  A/B/C_ are tensors, *_off element offsets of the (0,0) entry.
+
+    la/lb = 0: operand(r,k) at base + r*ld + k;  1: at base + k*ld + r (see include/muse_hip.h).
+    """
+    require_gpu(A, B, C_)
+    if A.dtype != B.dtype:
+        raise _hip.MuseHipError("gemm operands must share a dtype")
+    if not USE_TR and A.dtype == torch.bfloat16 and (la == 1 or lb == 1):
+        return _gemm_via_transpose(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec,
+                                   residual, ldr, batch, zdiv, sA, sB, sC, accumulate, act)
+    d = GemmDesc()
+    d.A = A.data_ptr() + a_off * _esz(A)
+    d.B = B.data_ptr() + b_off * _esz(B)
+    d.C = C_.data_ptr() + c_off * _esz(C_)
+    d.bias = ptr(bias)
+    d.rowvec = ptr(rowvec)
+    d.residual = ptr(residual)
+    d.dtype = dt(A)
+    d.out_dtype = dt(C_)
+    d.layout_a, d.layout_b = la, lb
+    d.M, d.N, d.K = M, N, K
+    d.batch, d.zdiv = batch, zdiv
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.sA0, d.sA1 = sA
+    d.sB0, d.sB1 = sB
+    d.sC0, d.sC1 = sC
+    d.alpha = alpha
+    d.accumulate = 1 if accumulate else 0
+    d.act = act
+    check(lib().muse_gemm(C.byref(d), stream()), "muse_gemm")
+    return C_
+
+
+def _gemm_via_transpose(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec, residual,
+                        ldr, batch, zdiv, sA, sB, sC, accumulate, act):
+    """Bring-up fallback: materialise k-contiguous copies of k-major operands with muse_transpose."""
+    Kp = (K + 7) // 8 * 8
+
+    def fix(X, layout, R, ld, off, s):
+        if layout == 0:
+            return X, ld, off, s
+        # X(r,k) at off + k*ld + r  ->  T[z][r][k], zero padded to Kp
+        T = torch.zeros((batch, R, Kp), dtype=X.dtype, device=X.device)
+        for z in range(batch):  # batches are few in this debug path
+            zo = off + (z // zdiv) * s[0] + (z % zdiv) * s[1]
+            check(lib().muse_transpose(X.data_ptr() + zo * _esz(X), T[z].data_ptr(), dt(X), K, R, ld, Kp, 1, 0, 0,
+                                       stream()), "muse_transpose")
+        return T, Kp, 0, (zdiv * R * Kp, R * Kp)
+
+    A2, lda2, a_off2, sA2 = fix(A, la, M, lda, a_off, sA)
+    B2, ldb2, b_off2, sB2 = fix(B, lb, N, ldb, b_off, sB)
+    return gemm(A2, B2, C_, M, N, K, la=0, lb=0, lda=lda2, ldb=ldb2, ldc=ldc, a_off=a_off2, b_off=b_off2, c_off=c_off,
+                alpha=alpha, bias=bias, rowvec=rowvec, residual=residual, ldr=ldr, batch=batch, zdiv=zdiv, sA=sA2,
+                sB=sB2, sC=sC, accumulate=accumulate, act=act)
+
+
+def linear(x, w, out=None, *, out_dtype=None, residual=None, act=0, bias=None):
+    """y[T,N] = x[T,K] @ w[N,K]^T (+bias) (gelu) (+residual)   — nn.Linear forward."""
+    T_, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((T_, N), dtype=out_dtype or x.dtype, device=x.device)
+    return gemm(x, w, out, T_, N, K, la=0, lb=0, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), residual=residual,
+                ldr=residual.stride(0) if residual is not None else 0, act=act, bias=bias)
+
+
+def linear_dgrad(dy, w, out=None):
+    """dx[T,K] = dy[T,N] @ w[N,K]    (w consumed as a k-major operand)."""
+    T_, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty((T_, K), dtype=dy.dtype, device=dy.device)
+    return gemm(dy, w, out, T_, K, N, la=0, lb=1, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0))
+
+
+def linear_wgrad(dy, x, dw, accumulate):
+    """dw[N,K] (+)= dy[T,N]^T @ x[T,K]   (both operands k-major, f32 output into the flat grad buffer)."""
+    T_, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, x, dw, N, K, T_, la=1, lb=1, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), accumulate=accumulate)
+
+
+def layernorm_fwd(x, w, eps, out_dtype, residual=None):
+    require_gpu(x, w)
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().muse_layernorm_fwd(x.data_ptr(), dt(x), w.data_ptr(), ptr(residual), y.data_ptr(), dt(y), mean.data_ptr(),
+                                   rstd.data_ptr(), rows, cols, eps, stream()), "muse_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None):
+    """returns dx (= LN'(dy) + dres); dw (+)= column sums of dy * xhat."""
+    require_gpu(dy, x, w)
+    rows, cols = x.shape
+    dx = torch.empty((rows, cols), dtype=dx_dtype, device=x.device)
+    nblk = lib().muse_layernorm_bwd_nblk(rows)
+    part = torch.empty((nblk, cols), dtype=torch.float32, device=x.device)
+    check(lib().muse_layernorm_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), dt(x), w.data_ptr(), mean.data_ptr(),
+                                   rstd.data_ptr(), ptr(dres), dx.data_ptr(), dt(dx), part.data_ptr(), nblk, rows, cols,
+                                   stream()), "muse_layernorm_bwd")
+    check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, cols, 1 if accumulate else 0, stream()), "muse_colsum")
+    return dx
+
+
+def softmax_(x, rows, cols, ld):
+    require_gpu(x)
+    check(lib().muse_softmax_fwd(x.data_ptr(), x.data_ptr(), dt(x), rows, cols, ld, stream()), "muse_softmax_fwd")
+    return x
+
+
+def softmax_bwd_(p, dp, rows, cols, ld):
+    """in place on dp: ds = p * (dp - sum(p*dp))"""
+    require_gpu(p, dp)
+    check(lib().muse_softmax_bwd(p.data_ptr(), dp.data_ptr(), dp.data_ptr(), dt(p), rows, cols, ld, stream()), "muse_softmax_bwd")
+    return dp
+
+
+def glu_fwd(ab):
+    require_gpu(ab)
+    rows, two_i = ab.shape
+    h = torch.empty((rows, two_i // 2), dtype=ab.dtype, device=ab.device)
+    check(lib().muse_glu_fwd(ab.data_ptr(), h.data_ptr(), dt(ab), rows, two_i // 2, stream()), "muse_glu_fwd")
+    return h
+
+
+def glu_bwd(ab, dh):
+    require_gpu(ab, dh)
+    rows, two_i = ab.shape
+    dab = torch.empty_like(ab)
+    check(lib().muse_glu_bwd(ab.data_ptr(), dh.data_ptr(), dab.data_ptr(), dt(ab), rows, two_i // 2, stream()), "muse_glu_bwd")
+    return dab
+
+
+def gelu_fwd(x):
+    require_gpu(x)
+    y = torch.empty_like(x)
+    check(lib().muse_gelu_fwd(x.data_ptr(), y.data_ptr(), dt(x), x.numel(), stream()), "muse_gelu_fwd")
+    return y
+
+
+def gelu_bwd(x, dy):
+    require_gpu(x, dy)
+    dx = torch.empty_like(x)
+    check(lib().muse_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), dt(x), x.numel(), stream()), "muse_gelu_bwd")
+    return dx
+
+
+def embed_fwd(ids, word, pos):
+    require_gpu(ids, word, pos)
+    B, S = ids.shape
+    V, H = word.shape
+    out = torch.empty((B * S, H), dtype=torch.float32, device=ids.device)
+    check(lib().muse_embed_fwd(ids.data_ptr(), word.data_ptr(), pos.data_ptr(), out.data_ptr(), B, S, H, V, stream()), "muse_embed_fwd")
+    return out
+
+
+def embed_bwd(ids, dout, dword, dpos, accumulate):
+    require_gpu(ids, dout, dword, dpos)
+    B, S = ids.shape
+    V, H = dword.shape
+    n = lib().muse_embed_bwd_scratch_floats(H, V)
+    scratch = torch.empty(n, dtype=torch.float32, device=ids.device)
+    check(lib().muse_embed_bwd(ids.data_ptr(), dout.data_ptr(), dword.data_ptr(), dpos.data_ptr(), scratch.data_ptr(), B, S, H,
+                               V, 1 if accumulate else 0, stream()), "muse_embed_bwd")
+
+
+def cross_entropy_fwd(logits, labels, label_smoothing):
+    """returns (loss_out[2] = (mean loss, n_valid), lse[rows])"""
+    require_gpu(logits, labels)
+    rows, V = logits.shape
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    loss_out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    check(lib().muse_cross_entropy_fwd(logits.data_ptr(), dt(logits), labels.data_ptr(), row_loss.data_ptr(), lse.data_ptr(),
+                                       loss_out.data_ptr(), rows, V, logits.stride(0), label_smoothing, stream()),
+          "muse_cross_entropy_fwd")
+    return loss_out, lse
+
+
+def cross_entropy_bwd(logits, labels, lse, loss_out, grad_out, label_smoothing, out_dtype):
+    require_gpu(logits, labels, grad_out)
+    rows, V = logits.shape
+    dl = torch.empty((rows, V), dtype=out_dtype, device=logits.device)
+    check(lib().muse_cross_entropy_bwd(logits.data_ptr(), dt(logits), labels.data_ptr(), lse.data_ptr(), loss_out.data_ptr(),
+                                       grad_out.data_ptr(), dl.data_ptr(), dt(dl), rows, V, logits.stride(0), label_smoothing,
+                                       stream()), "muse_cross_entropy_bwd")
+    return dl
+
+
+def adamw_flat(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    require_gpu(p, g, m, v)
+    check(lib().muse_adamw_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(p_bf16), p.numel(), lr, beta1,
+                                beta2, eps, weight_decay, step, grad_scale, stream()), "muse_adamw_flat")
+
+
+def cast_to_bf16(src, dst=None):
+    require_gpu(src)
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(lib().muse_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), stream()), "muse_cast_f32_to_bf16")
+    return dst
+
+
+def cast_to_f32(src, dst=None):
+    require_gpu(src)
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    check(lib().muse_cast_bf16_to_f32(src.data_ptr(), dst.data_ptr(), src.numel(), stream()), "muse_cast_bf16_to_f32")
+    return dst
+
+
+def mask_sample(tokens, class_ids, timesteps, noise, mask_id, codebook_size, min_masking_rate=0.0):
+    require_gpu(tokens, class_ids, timesteps, noise)
+    B, S = tokens.shape
+    input_ids = torch.empty((B, S + 1), dtype=torch.int64, device=tokens.device)
+    labels = torch.empty((B, S + 1), dtype=torch.int64, device=tokens.device)
+    mask_prob = torch.empty(B, dtype=torch.float32, device=tokens.device)
+    check(lib().muse_mask_sample(tokens.data_ptr(), class_ids.data_ptr(), timesteps.data_ptr(), noise.data_ptr(),
+                                 input_ids.data_ptr(), labels.data_ptr(), mask_prob.data_ptr(), B, S, mask_id, codebook_size,
+                                 min_masking_rate, stream()), "muse_mask_sample")
+    return input_ids, labels, mask_prob
+
+
+# ---- VQGAN (NHWC) ----------------------------------------------------------------------------------------------
+def conv2d_nhwc(x, w, B, H, W, Cin, Cout, KS, bias=None, residual=None, upsample=False):
+    """x: [B, Hin, Win, Cin] (Hin = H/2 if upsample), w: [Cout, KS, KS, Cin]; returns [B, H, W, Cout]."""
+    require_gpu(x, w)
+    out = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    check(lib().muse_conv2d_nhwc(x.data_ptr(), w.data_ptr(), ptr(bias), ptr(residual), out.data_ptr(), dt(x), B, H, W, Cin,
+                                 Cout, KS, 1 if upsample else 0, stream()), "muse_conv2d_nhwc")
+    return out
+
+
+def groupnorm_silu_nhwc(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, silu=True):
+    require_gpu(x, gamma, beta)
+    y = torch.empty_like(x)
+    nchunk = lib().muse_groupnorm_nchunk(HW)
+    part = torch.empty(B * nchunk * groups * 2, dtype=torch.float64, device=x.device)
+    check(lib().muse_groupnorm_silu_nhwc(x.data_ptr(), y.data_ptr(), dt(x), gamma.data_ptr(), beta.data_ptr(), part.data_ptr(),
+                                         B, HW, C, groups, eps, 1 if silu else 0, stream()), "muse_groupnorm_silu_nhwc")
+    return y
+
+
+def avgpool2x2_nhwc(x, B, H, W, C_):
+    require_gpu(x)
+    y = torch.empty((B, H // 2, W // 2, C_), dtype=x.dtype, device=x.device)
+    check(lib().muse_avgpool2x2_nhwc(x.data_ptr(), y.data_ptr(), dt(x), B, H, W, C_, stream()), "muse_avgpool2x2_nhwc")
+    return y
+
+
+def nchw_to_nhwc(x, out_dtype, cpad):
+    require_gpu(x)
+    B, C_, H, W = x.shape
+    x = x.contiguous()
+    out = torch.empty((B, H, W, cpad), dtype=out_dtype, device=x.device)
+    check(lib().muse_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), dt(out), B, C_, H * W, cpad, stream()), "muse_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, C_):
+    require_gpu(x)
+    B, H, W, cpad = x.shape
+    out = torch.empty((B, C_, H, W), dtype=torch.float32, device=x.device)
+    check(lib().muse_nhwc_to_nchw(x.data_ptr(), dt(x), out.data_ptr(), B, C_, H * W, cpad, stream()), "muse_nhwc_to_nchw")
+    return out
+
+
+def vq_nearest(z_flat, codebook, en=None):
+    """argmin_j |z - e_j|^2 computed as the reference does: addmm(|z|^2 + |e|^2, z, e^T, alpha=-2) then argmin.
+
+    z_flat [N, D] f32, codebook [Kc, D] f32 -> int64 [N]."""
+    require_gpu(z_flat, codebook)
+    N, D = z_flat.shape
+    Kc = codebook.shape[0]
+    zn = torch.empty(N, dtype=torch.float32, device=z_flat.device)
+    check(lib().muse_row_sumsq(z_flat.data_ptr(), zn.data_ptr(), N, D, z_flat.stride(0), stream()), "muse_row_sumsq")
+    if en is None:
+        en = torch.empty(Kc, dtype=torch.float32, device=z_flat.device)
+        check(lib().muse_row_sumsq(codebook.data_ptr(), en.data_ptr(), Kc, D, codebook.stride(0), stream()), "muse_row_sumsq")
+    dist = torch.empty((N, Kc), dtype=torch.float32, device=z_flat.device)
+    gemm(z_flat, codebook, dist, N, Kc, D, la=0, lb=0, lda=z_flat.stride(0), ldb=codebook.stride(0), ldc=Kc, alpha=-2.0,
+         bias=en, rowvec=zn)
+    idx = torch.empty(N, dtype=torch.int64, device=z_flat.device)
+    check(lib().muse_argmin_rows(dist.data_ptr(), idx.data_ptr(), N, Kc, Kc, stream()), "muse_argmin_rows")
+    return idx
+
+
+def gather_rows(table, idx, out_dtype):
+    require_gpu(table, idx)
+    rows = idx.numel()
+    cols = table.shape[1]
+    out = torch.empty((rows, cols), dtype=out_dtype, device=table.device)
+    check(lib().muse_gather_rows(table.data_ptr(), idx.data_ptr(), out.data_ptr(), dt(out), rows, cols, stream()), "muse_gather_rows")
+    return out
+
+
+def probe_tr16(addr):
+    require_gpu(addr)
+    out = torch.empty(256, dtype=torch.int32, device=addr.device)
+    check(lib().muse_probe_tr16(addr.data_ptr(), out.data_ptr(), stream()), "muse_probe_tr16")
+    return out
