@@ -512,16 +512,19 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
   const int64_t lab = labels[row];
   TO* dr = dl + row * ld;
   if (lab < 0 || lab >= vocab) {
-    for (int c = lane; c < vocab; c += 64) Elem<TO>::store(dr + c, 0.f);
+    for (int c = lane; c < (int)ld; c += 64) Elem<TO>::store(dr + c, 0.f);
     return;
   }
   const float g = gout[0] / loss_out[1];
   const float l = lse[row];
   const T* xr = logits + row * ld;
   const float off = ls / (float)vocab;
-  for (int c = lane; c < vocab; c += 64) {
-    float p = expf(Elem<T>::load(xr + c) - l) - off;
-    if (c == (int)lab) p -= (1.0f - ls);
+  for (int c = lane; c < (int)ld; c += 64) {  // pad columns [vocab, ld) are written as 0 (they feed GEMM K-chunks)
+    float p = 0.f;
+    if (c < vocab) {
+      p = expf(Elem<T>::load(xr + c) - l) - off;
+      if (c == (int)lab) p -= (1.0f - ls);
+    }
     Elem<TO>::store(dr + c, p * g);
   }
 }

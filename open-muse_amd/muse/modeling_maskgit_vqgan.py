@@ -1,0 +1,295 @@
+"""muse.MaskGitVQGAN for MI355X: the reference's class surface (muse/modeling_maskgit_vqgan.py:351-414) over HIP kernels.
+
+Same constructor kwargs, config keys, state_dict names/shapes and methods (`encode`, `decode`, `decode_code`,
+`get_code`, `get_soft_code`, `forward`).  Underneath, activations are NHWC and every layer is a libmuse_hip call:
+implicit-GEMM MFMA convolution (SAME padding, bias, residual add and the decoder's nearest x2 upsample folded in),
+GroupNorm+SiLU (two-pass f64 statistics), 2x2 average pool, and the VQ lookup (f32 MFMA distance GEMM with the
+reference's addmm rounding order + first-index argmin).
+
+compute_dtype = torch.float32 (default) keeps the reference's precision (the training script runs the frozen VQGAN in
+f32 outside autocast: training/train_maskgit_imagenet.py:306,369) on the exact-f32 MFMA; torch.bfloat16 is the fast mode
+(bf16 activations/weights, f32 accumulation, f32 VQ lookup).  The VQGAN is a frozen tokenizer on this path: there is no
+backward through it, and no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from ._hip import MuseHipError
+from .modeling_utils import ConfigMixin, ModelMixin, register_to_config
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, bias):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Conv2d default init
+        if bias:
+            bound = 1.0 / math.sqrt(cin * k * k)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _Norm(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _Res(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1 = _Norm(cin)
+        self.conv1 = _Conv(cin, cout, 3, False)
+        self.norm2 = _Norm(cout)
+        self.conv2 = _Conv(cout, cout, 3, False)
+        if cin != cout:
+            self.nin_shortcut = _Conv(cout, cout, 1, False)
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, nb):
+        super().__init__()
+        self.block = nn.ModuleList([_Res(cin if i == 0 else cout, cout) for i in range(nb)])
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout, nb, upsample):
+        super().__init__()
+        self.block = nn.ModuleList([_Res(cin if i == 0 else cout, cout) for i in range(nb)])
+        if upsample:
+            self.upsample_conv = _Conv(cout, cout, 3, True)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        hc, mult, nb = cfg.hidden_channels, tuple(cfg.channel_mult), cfg.num_res_blocks
+        self.conv_in = _Conv(cfg.num_channels, hc, 3, False)
+        in_mult = (1,) + mult
+        self.down = nn.ModuleList([_Down(hc * in_mult[i], hc * mult[i], nb) for i in range(len(mult))])
+        mid = hc * mult[-1]
+        self.mid = nn.ModuleList([_Res(mid, mid) for _ in range(nb)])
+        self.norm_out = _Norm(mid)
+        self.conv_out = _Conv(mid, cfg.z_channels, 1, True)
+
+
+class _Decoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        hc, mult, nb = cfg.hidden_channels, tuple(cfg.channel_mult), cfg.num_res_blocks
+        nres = len(mult)
+        mid = hc * mult[-1]
+        self.conv_in = _Conv(cfg.z_channels, mid, 3, True)
+        self.mid = nn.ModuleList([_Res(mid, mid) for _ in range(nb)])
+        ups = []
+        for lvl in range(nres):
+            cin = hc * mult[-1] if lvl == nres - 1 else hc * mult[lvl + 1]
+            ups.append(_Up(cin, hc * mult[lvl], nb, lvl != 0))
+        self.up = nn.ModuleList(ups)
+        self.norm_out = _Norm(hc * mult[0])
+        self.conv_out = _Conv(hc * mult[0], cfg.num_channels, 3, True)
+
+
+class _Quantizer(nn.Module):
+    def __init__(self, n, d):
+        super().__init__()
+        self.embedding = nn.Embedding(n, d)
+        self.embedding.weight.data.uniform_(-1.0 / n, 1.0 / n)  # reference :265
+
+
+class MaskGitVQGAN(ModelMixin, ConfigMixin):
+    @register_to_config
+    def __init__(
+        self,
+        resolution: int = 256,
+        num_channels: int = 3,
+        hidden_channels: int = 128,
+        channel_mult: Tuple = (1, 1, 2, 2, 4),
+        num_res_blocks: int = 2,
+        attn_resolutions: int = (16,),
+        z_channels: int = 256,
+        num_embeddings: int = 1024,
+        quantized_embed_dim: int = 256,
+        dropout: float = 0.0,
+        resample_with_conv: bool = True,
+        commitment_cost: float = 0.25,
+    ):
+        super().__init__()
+        if dropout != 0.0:
+            raise NotImplementedError("dropout > 0 in the VQGAN is outside the MI355X hot-path build")
+        if z_channels != quantized_embed_dim:
+            raise ValueError("z_channels must equal quantized_embed_dim")
+        self.config.num_resolutions = len(channel_mult)
+        self.config.reduction_factor = 2 ** (self.config.num_resolutions - 1)
+        self.config.latent_size = resolution // self.config.reduction_factor
+        self.encoder = _Encoder(self.config)
+        self.decoder = _Decoder(self.config)
+        self.quantize = _Quantizer(num_embeddings, quantized_embed_dim)
+        self.compute_dtype = torch.float32
+        self._packed = {}
+
+    # ---- weight packing: [Cout,Cin,k,k] -> [Cout,k,k,Cin_pad] in the compute dtype ------------------------------------
+    def set_compute_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
+
+    def _apply(self, fn, recurse=True):
+        self._packed = {}
+        return super()._apply(fn, recurse)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        self._packed = {}
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    def _cpad(self, c, cd):
+        q = 8 if cd == torch.bfloat16 else 4
+        return (c + q - 1) // q * q
+
+    def _w(self, conv: _Conv, cd):
+        key = (id(conv), cd)
+        hit = self._packed.get(key)
+        if hit is None:
+            w = conv.weight.data
+            cout, cin, k, _ = w.shape
+            cp = self._cpad(cin, cd)
+            wp = torch.zeros((cout, k, k, cp), dtype=torch.float32, device=w.device)
+            wp[..., :cin] = w.permute(0, 2, 3, 1)
+            wp = wp.contiguous()
+            if cd == torch.bfloat16:
+                wp = ops.cast_to_bf16(wp)
+            hit = (wp, cp, cout, k, None if conv.bias is None else conv.bias.data.float().contiguous())
+            self._packed[key] = hit
+        return hit
+
+    def _conv(self, x, conv, B, H, W, cd, residual=None, upsample=False):
+        wp, cp, cout, k, bias = self._w(conv, cd)
+        return ops.conv2d_nhwc(x, wp, B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
+
+    def _gn(self, x, norm: _Norm, B, HW, C):
+        return ops.groupnorm_silu_nhwc(x, norm.weight.data, norm.bias.data, B, HW, C, groups=32, eps=1e-6, silu=True)
+
+    def _res(self, x, blk: _Res, B, H, W, cd):
+        cin = blk.conv1.weight.shape[1]
+        cout = blk.conv1.weight.shape[0]
+        h = self._conv(self._gn(x, blk.norm1, B, H * W, cin), blk.conv1, B, H, W, cd)
+        if cin == cout:
+            return self._conv(self._gn(h, blk.norm2, B, H * W, cout), blk.conv2, B, H, W, cd, residual=x)
+        h = self._conv(self._gn(h, blk.norm2, B, H * W, cout), blk.conv2, B, H, W, cd)
+        # reference quirk (:82-85): the "shortcut" is a 1x1 conv of the conv2 output, out = h + nin(h)
+        return self._conv(h, blk.nin_shortcut, B, H, W, cd, residual=h)
+
+    def _check(self, t):
+        if not t.is_cuda:
+            raise MuseHipError("MaskGitVQGAN (MI355X build) has no CPU path: move the model and inputs to the GPU")
+
+    # ---- encoder / decoder ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _encode_nhwc(self, pixel_values):
+        """NCHW f32 pixels -> z as [B*h*w, z_channels] f32 (NHWC flattened) and (B, h, w)."""
+        self._check(pixel_values)
+        cd = self.compute_dtype
+        enc = self.encoder
+        B, C, H, W = pixel_values.shape
+        x = ops.nchw_to_nhwc(pixel_values.float(), cd, self._cpad(C, cd))
+        h = self._conv(x, enc.conv_in, B, H, W, cd)
+        nres = self.config.num_resolutions
+        for lvl, down in enumerate(enc.down):
+            for blk in down.block:
+                h = self._res(h, blk, B, H, W, cd)
+            if lvl != nres - 1:
+                h = ops.avgpool2x2_nhwc(h, B, H, W, h.shape[-1])
+                H, W = H // 2, W // 2
+        for blk in enc.mid:
+            h = self._res(h, blk, B, H, W, cd)
+        h = self._gn(h, enc.norm_out, B, H * W, h.shape[-1])
+        z = self._conv(h, enc.conv_out, B, H, W, cd)
+        z = z.view(B * H * W, -1)
+        if z.dtype != torch.float32:
+            z = ops.cast_to_f32(z)
+        return z, (B, H, W)
+
+    @torch.no_grad()
+    def _decode_nhwc(self, zq, B, H, W):
+        """zq: [B, H, W, z_channels] in the compute dtype -> NCHW f32 image."""
+        cd = self.compute_dtype
+        dec = self.decoder
+        nres = self.config.num_resolutions
+        h = self._conv(zq, dec.conv_in, B, H, W, cd)
+        for blk in dec.mid:
+            h = self._res(h, blk, B, H, W, cd)
+        for lvl in reversed(range(nres)):
+            up = dec.up[lvl]
+            for blk in up.block:
+                h = self._res(h, blk, B, H, W, cd)
+            if lvl != 0:
+                H, W = H * 2, W * 2
+                h = self._conv(h, up.upsample_conv, B, H, W, cd, upsample=True)
+        h = self._gn(h, dec.norm_out, B, H * W, h.shape[-1])
+        out = self._conv(h, dec.conv_out, B, H, W, cd)
+        return ops.nhwc_to_nchw(out, self.config.num_channels)
+
+    def _codebook(self):
+        return self.quantize.embedding.weight.data
+
+    # ---- public surface (reference :380-414) ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, pixel_values, return_loss=False):
+        z, (B, H, W) = self._encode_nhwc(pixel_values)
+        cb = self._codebook()
+        idx = ops.vq_nearest(z, cb)
+        zq_rows = ops.gather_rows(cb, idx, torch.float32)                    # == one-hot @ codebook (:280-284)
+        zq = ops.nhwc_to_nchw(zq_rows.view(B, H, W, -1), zq_rows.shape[1])   # (B, C, h, w) like :299
+        out = (zq, idx.view(B, H * W))
+        if return_loss:
+            zc = ops.nhwc_to_nchw(z.view(B, H, W, -1), z.shape[1])
+            mse = torch.mean((zq - zc) ** 2)
+            out = out + (mse + self.config.commitment_cost * mse,)
+        return out
+
+    @torch.no_grad()
+    def decode(self, quantized_states):
+        self._check(quantized_states)
+        B, C, H, W = quantized_states.shape
+        cd = self.compute_dtype
+        zq = ops.nchw_to_nhwc(quantized_states.float(), cd, C)
+        return self._decode_nhwc(zq, B, H, W)
+
+    @torch.no_grad()
+    def decode_code(self, codebook_indices):
+        self._check(codebook_indices)
+        B, T = codebook_indices.shape
+        side = int(math.sqrt(T))
+        zq = ops.gather_rows(self._codebook(), codebook_indices.contiguous().view(-1), self.compute_dtype)
+        return self._decode_nhwc(zq.view(B, side, side, -1), B, side, side)
+
+    @torch.no_grad()
+    def get_code(self, pixel_values):
+        z, (B, H, W) = self._encode_nhwc(pixel_values)
+        return ops.vq_nearest(z, self._codebook()).view(B, H * W)
+
+    @torch.no_grad()
+    def get_soft_code(self, pixel_values, temp=1.0, stochastic=False):
+        z, (B, H, W) = self._encode_nhwc(pixel_values)
+        cb = self._codebook()
+        dist = torch.cdist(z, cb).pow(2)  # adjacent feature (soft targets), torch op on the GPU
+        soft = F.softmax(-dist / temp, dim=-1)
+        code = torch.multinomial(soft, 1) if stochastic else ops.vq_nearest(z, cb)
+        return soft.view(B, H * W, -1), code.view(B, H * W)
+
+    def forward(self, pixel_values, return_loss=False):
+        enc = self.encode(pixel_values, return_loss)
+        rec = self.decode(enc[0])
+        out = (rec, enc[0], enc[1])
+        if return_loss:
+            out = out + (enc[2],)
+        return out

@@ -1,0 +1,560 @@
+"""muse.MaskGitTransformer for MI355X: the reference's class surface over hand-written HIP kernels.
+
+Replaces muse/modeling_transformer.py:1083-1456 of the reference (constructor kwargs, config keys, state_dict names
+and shapes, `forward(input_ids, labels=..., label_smoothing=...) -> logits | (logits, loss)`, `generate2`).
+The computation underneath is not an nn.Module graph: one autograd node runs a hand-scheduled forward and a
+hand-written backward over libmuse_hip (MFMA GEMMs, fused LayerNorm(+residual), softmax, GLU, fused cross-entropy),
+with
+
+  * all parameters living in ONE flat f32 buffer (q/k/v and wi_0/wi_1 adjacent, so the fused [3H,H] / [2I,H] GEMM
+    weights are plain views) and all gradients in one flat f32 buffer written directly by the backward kernels
+    (no autograd accumulation pass, bucket all-reduce without copies, single-launch AdamW);
+  * a bf16 compute copy of the flat weights when compute_dtype is bfloat16 (the reference's autocast regime:
+    residual stream / LayerNorm statistics / softmax / loss in f32, GEMM operands bf16, f32 MFMA accumulation).
+
+There is no CPU path: calling forward with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Callable, List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._hip import MuseHipError
+from .modeling_utils import ConfigMixin, ModelMixin, register_to_config
+from .sampling import cosine_schedule, mask_by_random_topk
+
+_ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the flat buffer
+
+
+class _W(nn.Module):
+    """Parameter holder named like the reference's nn.Linear / nn.Embedding / LayerNorm leaf (`.weight`)."""
+
+    def __init__(self, *shape):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape))
+
+
+class _Attention(nn.Module):
+    def __init__(self, H):
+        super().__init__()
+        self.query, self.key, self.value, self.out = _W(H, H), _W(H, H), _W(H, H), _W(H, H)
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, H, I):
+        super().__init__()
+        self.pre_mlp_layer_norm = _W(H)
+        self.wi_0, self.wi_1 = _W(I, H), _W(I, H)
+        self.mid_mlp_layer_norm = _W(I)
+        self.wo = _W(H, I)
+
+
+class _Layer(nn.Module):
+    def __init__(self, H, I):
+        super().__init__()
+        self.attn_layer_norm = _W(H)
+        self.attention = _Attention(H)
+        self.post_attn_layer_norm = _W(H)
+        self.ffn = _FeedForward(H, I)
+
+
+class _Embed(nn.Module):
+    def __init__(self, V, P, H):
+        super().__init__()
+        self.word_embeddings = _W(V, H)
+        self.position_embeddings = _W(P, H)
+
+
+class _Mlm(nn.Module):
+    def __init__(self, H, V):
+        super().__init__()
+        self.mlm_dense = _W(H, H)
+        self.mlm_ln = _W(H)
+        self.to_logits = _W(V, H)
+
+
+class _MaskGitFn(torch.autograd.Function):
+    """One autograd node for the whole network.  Parameter gradients are written straight into the model's flat grad
+    buffer (p.grad are views of it) unless model.direct_grad is False, in which case they are returned to autograd."""
+
+    @staticmethod
+    def forward(ctx, model, input_ids, labels, label_smoothing, *params):
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        logits, loss, saved = model._run_forward(input_ids, labels, label_smoothing, need_grad)
+        ctx.model, ctx.saved = model, saved
+        ctx.set_materialize_grads(False)
+        if loss is None:
+            return logits
+        return logits, loss
+
+    @staticmethod
+    def backward(ctx, g_logits, g_loss=None):
+        model = ctx.model
+        if ctx.saved is None:
+            raise MuseHipError("backward called on a forward that ran without grad")
+        grads = model._run_backward(ctx.saved, g_logits, g_loss)
+        ctx.saved = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class MaskGitTransformer(ModelMixin, ConfigMixin):
+    _supports_gradient_checkpointing = True
+
+    @register_to_config
+    def __init__(
+        self,
+        vocab_size,
+        hidden_size=768,
+        embedding_size=None,
+        num_hidden_layers=12,
+        num_attention_heads=12,
+        intermediate_size=3072,
+        hidden_dropout=0.1,
+        attention_dropout=0.1,
+        max_position_embeddings=256,
+        add_cross_attention=False,
+        encoder_hidden_size=1024,
+        project_encoder_hidden_states=False,
+        initializer_range=0.02,
+        norm_type="layernorm",
+        layer_norm_eps=1e-5,
+        use_normformer=True,
+        use_encoder_layernorm=True,
+        use_mlm_layer=True,
+        use_mlm_layernorm=True,
+        use_bias=False,
+        codebook_size=1024,
+        num_vq_tokens=256,
+        num_classes=None,
+        use_codebook_size_for_output=False,
+        use_conv_in_out=False,
+        patch_size=1,
+        **kwargs,
+    ):
+        super().__init__()
+        unsupported = []
+        if add_cross_attention or project_encoder_hidden_states:
+            unsupported.append("cross attention (text conditioning)")
+        if norm_type != "layernorm":
+            unsupported.append(f"norm_type={norm_type}")
+        if not (use_normformer and use_encoder_layernorm and use_mlm_layer and use_mlm_layernorm):
+            unsupported.append("non-NormFormer / no-MLM-layer variants")
+        if use_bias or use_conv_in_out:
+            unsupported.append("use_bias / use_conv_in_out")
+        if embedding_size not in (None, hidden_size):
+            unsupported.append("embedding_size != hidden_size")
+        if unsupported:
+            raise NotImplementedError("MI355X hot-path build covers the class-conditional MaskGit configs "
+                                      "(README example, configs/imagenet.yaml); unsupported here: " + ", ".join(unsupported))
+        if hidden_size % num_attention_heads:
+            raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {hidden_size} and"
+                             f" `num_heads`: {num_attention_heads}).")
+        head_dim = hidden_size // num_attention_heads
+        if hidden_size % 8 or intermediate_size % 8 or head_dim % 8:
+            raise ValueError("hidden_size, intermediate_size and head_dim must be multiples of 8 (16-byte MFMA operand rows)")
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.intermediate_size = intermediate_size
+        self.hidden_dropout = hidden_dropout
+        self.attention_dropout = attention_dropout
+        self.max_position_embeddings = max_position_embeddings
+        self.initializer_range = initializer_range
+        self.embedding_size = embedding_size or hidden_size
+        self.register_to_config(mask_token_id=vocab_size - 1)
+        self.output_size = codebook_size if use_codebook_size_for_output else vocab_size
+
+        H, I, V = hidden_size, intermediate_size, vocab_size
+        self.embed = _Embed(V, max_position_embeddings, H)
+        self.transformer_layers = nn.ModuleList([_Layer(H, I) for _ in range(num_hidden_layers)])
+        self.encoder_layer_norm = _W(H)
+        self.mlm_layer = _Mlm(H, self.output_size)
+        self.gradient_checkpointing = False
+
+        # engine state
+        self.compute_dtype = "auto"   # "auto": bf16 under torch.autocast(bf16), else f32 (what the reference would do)
+        self.direct_grad = True       # backward writes p.grad (views of the flat grad buffer) itself
+        self.grad_ready_hook: Optional[Callable[[int, int], None]] = None  # (flat_begin, flat_end) after each segment
+        self._flat = self._flat_grad = self._flat_c = None
+        self._shadow_fresh = False
+        self._build_flat()
+        self._init_weights()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # flat parameter storage
+    # ------------------------------------------------------------------------------------------------------------
+    def _param_order(self) -> List[nn.Parameter]:
+        order = [self.embed.word_embeddings.weight, self.embed.position_embeddings.weight]
+        for l in self.transformer_layers:
+            a, f = l.attention, l.ffn
+            order += [l.attn_layer_norm.weight, a.query.weight, a.key.weight, a.value.weight, a.out.weight,
+                      l.post_attn_layer_norm.weight, f.pre_mlp_layer_norm.weight, f.wi_0.weight, f.wi_1.weight,
+                      f.mid_mlp_layer_norm.weight, f.wo.weight]
+        m = self.mlm_layer
+        order += [self.encoder_layer_norm.weight, m.mlm_dense.weight, m.mlm_ln.weight, m.to_logits.weight]
+        return order
+
+    def _build_flat(self, device=None):
+        """(Re)allocate the flat f32 parameter buffer on `device` and point every parameter at its slice."""
+        params = self._param_order()
+        device = device or params[0].device
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.zeros(n, dtype=torch.float32, device=device)
+        for p, o in zip(params, offs):
+            view = flat[o:o + p.numel()].view(p.shape)
+            if p.data.numel() == view.numel() and p.data.device.type != "meta":
+                view.copy_(p.data.to(torch.float32))
+            p.data = view
+            p._muse_owner = weakref.ref(self)
+        self._flat, self._offsets, self._flat_n = flat, offs, n
+        self._flat_grad = None
+        self._flat_c = None
+        self._shadow_fresh = False
+        self._grad_views = None
+
+    def _flat_ok(self) -> bool:
+        f = self._flat
+        if f is None:
+            return False
+        params = self._param_order()
+        base = f.data_ptr()
+        return all(p.data_ptr() == base + o * 4 and p.dtype == torch.float32 and p.device == f.device
+                   for p, o in zip(params, self._offsets))
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if self._flat is not None:
+            p0 = self._param_order()[0]
+            if p0.dtype != torch.float32:
+                raise MuseHipError("master parameters stay float32 (compute precision is selected with set_compute_dtype)")
+            self._build_flat(p0.device)
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        if not self._flat_ok():
+            self._build_flat()
+        self._shadow_fresh = False
+        return out
+
+    def _init_weights(self):
+        """trunc_normal_(std=initializer_range) for Linear / Embedding weights, ones for LayerNorm
+        (reference :1203-1219)."""
+        for name, p in self.named_parameters():
+            if p.dim() == 1:
+                p.data.fill_(1.0)
+            else:
+                nn.init.trunc_normal_(p.data, std=self.config.initializer_range)
+
+    def _set_gradient_checkpointing(self, module, value=False):
+        self.gradient_checkpointing = True  # accepted and ignored: activations fit (288 GB HBM), never recomputed
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in ("auto", torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be 'auto', torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        self._shadow_fresh = False
+        return self
+
+    def _resolve_cd(self):
+        if self.compute_dtype != "auto":
+            return self.compute_dtype
+        if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            return torch.bfloat16
+        return torch.float32
+
+    # flat gradient buffer --------------------------------------------------------------------------------------
+    def flat_params(self) -> torch.Tensor:
+        return self._flat
+
+    def flat_grads(self) -> torch.Tensor:
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros(self._flat_n, dtype=torch.float32, device=self._flat.device)
+            self._grad_views = [self._flat_grad[o:o + p.numel()].view(p.shape)
+                                for p, o in zip(self._param_order(), self._offsets)]
+        return self._flat_grad
+
+    def compute_weights(self, cd) -> torch.Tensor:
+        """flat weights in the compute dtype (the f32 master itself, or its bf16 shadow)."""
+        if cd == torch.float32:
+            return self._flat
+        if self._flat_c is None or self._flat_c.device != self._flat.device:
+            self._flat_c = torch.empty(self._flat_n, dtype=torch.bfloat16, device=self._flat.device)
+            self._shadow_fresh = False
+        if not self._shadow_fresh:
+            ops.cast_to_bf16(self._flat, self._flat_c)
+            self._shadow_fresh = True
+        return self._flat_c
+
+    # ------------------------------------------------------------------------------------------------------------
+    # forward / backward
+    # ------------------------------------------------------------------------------------------------------------
+    def forward(self, input_ids, encoder_hidden_states=None, encoder_attention_mask=None, labels=None,
+                label_smoothing=0.0, cond_dropout_prob=0.0, **kwargs):
+        if encoder_hidden_states is not None:
+            raise NotImplementedError("text conditioning (encoder_hidden_states) is outside the MI355X hot-path build")
+        if self.training and (self.hidden_dropout > 0.0 or self.attention_dropout > 0.0):
+            raise NotImplementedError("dropout > 0 is not implemented (target configs use 0.0: configs/imagenet.yaml:41-42)")
+        if not input_ids.is_cuda:
+            raise MuseHipError("MaskGitTransformer (MI355X build) has no CPU path: move the model and inputs to the GPU")
+        if not self._flat_ok():
+            self._build_flat()
+        out = _MaskGitFn.apply(self, input_ids, labels, float(label_smoothing), *self._param_order())
+        return out
+
+    def _segments(self, L):
+        """flat-buffer views of the compute weights for layer L and the head (element offsets)."""
+        raise NotImplementedError
+
+    def _run_forward(self, input_ids, labels, label_smoothing, need_grad):
+        cd = self._resolve_cd()
+        H, I, nh, V = self.hidden_size, self.intermediate_size, self.num_attention_heads, self.output_size
+        hd = H // nh
+        B, S = input_ids.shape
+        T = B * S
+        Sp = (S + 7) // 8 * 8
+        eps = float(self.config.layer_norm_eps)
+        alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+        dev = input_ids.device
+        Wc = self.compute_weights(cd)           # flat, compute dtype
+        Wf = self._flat                         # flat, f32 (LayerNorm scales, embeddings)
+        off = self._offsets
+        ids = input_ids.contiguous()
+
+        def wview(t, idx, shape):
+            o = off[idx]
+            n = 1
+            for s in shape:
+                n *= s
+            return t[o:o + n].view(shape)
+
+        x = ops.embed_fwd(ids, self.embed.word_embeddings.weight.data, self.embed.position_embeddings.weight.data)
+        saved = {"layers": [], "cd": cd, "ids": ids, "B": B, "S": S, "Sp": Sp} if need_grad else None
+
+        for li in range(self.num_hidden_layers):
+            b0 = 2 + li * 11
+            w_ln1 = wview(Wf, b0 + 0, (H,))
+            w_qkv = wview(Wc, b0 + 1, (3 * H, H))
+            w_out = wview(Wc, b0 + 4, (H, H))
+            w_post = wview(Wf, b0 + 5, (H,))
+            w_pre = wview(Wf, b0 + 6, (H,))
+            w_01 = wview(Wc, b0 + 7, (2 * I, H))
+            w_mid = wview(Wf, b0 + 9, (I,))
+            w_o2 = wview(Wc, b0 + 10, (H, I))
+
+            ln1, mu1, rs1 = ops.layernorm_fwd(x, w_ln1, eps, cd)
+            qkv = ops.linear(ln1, w_qkv)
+            P = torch.empty((B * nh, S, Sp), dtype=cd, device=dev)
+            # scores[b,h] = alpha * Q K^T        (reference :226-231)
+            ops.gemm(qkv, qkv, P, S, S, hd, la=0, lb=0, lda=3 * H, ldb=3 * H, ldc=Sp, a_off=0, b_off=H, alpha=alpha,
+                     batch=B * nh, zdiv=nh, sA=(S * 3 * H, hd), sB=(S * 3 * H, hd), sC=(nh * S * Sp, S * Sp))
+            ops.softmax_(P, B * nh * S, S, Sp)
+            ctx = torch.empty((T, H), dtype=cd, device=dev)
+            # ctx[b,:,h] = P V                   (reference :238-240)
+            ops.gemm(P, qkv, ctx, S, hd, S, la=0, lb=1, lda=Sp, ldb=3 * H, ldc=H, b_off=2 * H, batch=B * nh, zdiv=nh,
+                     sA=(nh * S * Sp, S * Sp), sB=(S * 3 * H, hd), sC=(S * H, hd))
+            ao = ops.linear(ctx, w_out)
+            x1, mu_p, rs_p = ops.layernorm_fwd(ao, w_post, eps, torch.float32, residual=x)   # x + LN(attn)  (:882-884)
+            ln2, mu2, rs2 = ops.layernorm_fwd(x1, w_pre, eps, cd)
+            ab = ops.linear(ln2, w_01)
+            h = ops.glu_fwd(ab)
+            hm, mu_m, rs_m = ops.layernorm_fwd(h, w_mid, eps, cd)
+            x2 = ops.linear(hm, w_o2, out_dtype=torch.float32, residual=x1)                  # x + FFN(x)    (:902-903)
+            if need_grad:
+                saved["layers"].append(dict(x=x, mu1=mu1, rs1=rs1, ln1=ln1, qkv=qkv, P=P, ctx=ctx, ao=ao, mu_p=mu_p,
+                                            rs_p=rs_p, x1=x1, mu2=mu2, rs2=rs2, ln2=ln2, ab=ab, h=h, mu_m=mu_m,
+                                            rs_m=rs_m, hm=hm))
+            x = x2
+
+        t0 = 2 + self.num_hidden_layers * 11
+        w_enc = wview(Wf, t0 + 0, (H,))
+        w_dense = wview(Wc, t0 + 1, (H, H))
+        w_mln = wview(Wf, t0 + 2, (H,))
+        w_log = wview(Wc, t0 + 3, (V, H))
+        xf, mu_e, rs_e = ops.layernorm_fwd(x, w_enc, eps, cd)
+        d = ops.linear(xf, w_dense)
+        g = ops.gelu_fwd(d)
+        gl, mu_g, rs_g = ops.layernorm_fwd(g, w_mln, eps, cd)
+        Vp = (V + 7) // 8 * 8   # 16-byte rows for the backward GEMMs (vocab 2025 -> 2032); pad columns never read as logits
+        logits = torch.empty((T, Vp), dtype=torch.float32, device=dev)
+        ops.gemm(gl, w_log, logits, T, V, H, la=0, lb=0, lda=H, ldb=H, ldc=Vp)
+
+        loss = None
+        loss_out = lse = lab = None
+        if labels is not None:
+            lab = labels.contiguous().view(-1)
+            loss_out, lse = ops.cross_entropy_fwd(logits, lab, label_smoothing, vocab=V)
+            loss = loss_out[0]
+        if need_grad:
+            saved.update(x_last=x, mu_e=mu_e, rs_e=rs_e, xf=xf, d=d, g=g, mu_g=mu_g, rs_g=rs_g, gl=gl, logits=logits,
+                         loss_out=loss_out, lse=lse, labels=lab, ls=label_smoothing)
+        out_logits = logits.view(B, S, V) if Vp == V else logits[:, :V].contiguous().view(B, S, V)
+        return out_logits, loss, saved
+
+    def _run_backward(self, sv, g_logits, g_loss):
+        cd = sv["cd"]
+        H, I, nh, V = self.hidden_size, self.intermediate_size, self.num_attention_heads, self.output_size
+        hd = H // nh
+        B, S, Sp = sv["B"], sv["S"], sv["Sp"]
+        T = B * S
+        alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+        dev = sv["ids"].device
+        Wc = self.compute_weights(cd)
+        Wf = self._flat
+        off = self._offsets
+        params = self._param_order()
+        G = self.flat_grads()
+        # accumulate iff the parameter already has a gradient (autograd semantics: None -> assign, else add)
+        acc = [p.grad is not None for p in params]
+        if self.direct_grad:
+            for p, gv in zip(params, self._grad_views):
+                if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                    if p.grad is not None:
+                        gv.copy_(p.grad)
+                    p.grad = gv
+            GW = G
+        else:
+            GW = torch.zeros_like(G)
+            acc = [False] * len(params)
+
+        def view(t, idx, shape):
+            o = off[idx]
+            n = 1
+            for s in shape:
+                n *= s
+            return t[o:o + n].view(shape)
+
+        def to_cd(t):
+            return t if cd == torch.float32 else ops.cast_to_bf16(t)
+
+        def ready(i0, i1):
+            if self.grad_ready_hook is not None and self.direct_grad:
+                end = off[i1] if i1 < len(off) else self._flat_n
+                self.grad_ready_hook(off[i0], end)
+
+        # ---- loss / head ----------------------------------------------------------------------------------------
+        dlog = None
+        if g_loss is not None and sv["labels"] is not None:
+            dlog = ops.cross_entropy_bwd(sv["logits"], sv["labels"], sv["lse"], sv["loss_out"],
+                                         g_loss.reshape(1).to(torch.float32).contiguous(), sv["ls"], cd, vocab=V)
+        Vp = sv["logits"].shape[1]
+        if g_logits is not None:
+            gl_ = torch.zeros((T, Vp), dtype=cd, device=dev)
+            gl_[:, :V] = g_logits.reshape(T, V).to(cd)
+            dlog = gl_ if dlog is None else dlog + gl_
+        if dlog is None:
+            raise MuseHipError("backward without an incoming gradient")
+        t0 = 2 + self.num_hidden_layers * 11
+        w_enc, w_dense = view(Wf, t0 + 0, (H,)), view(Wc, t0 + 1, (H, H))
+        w_mln, w_log = view(Wf, t0 + 2, (H,)), view(Wc, t0 + 3, (V, H))
+        # dW_logits[V,H] = dlog^T gl ; dgl[T,H] = dlog W_logits   (dlog rows are Vp wide, only V valid)
+        ops.gemm(dlog, sv["gl"], view(GW, t0 + 3, (V, H)), V, H, T, la=1, lb=1, lda=Vp, ldb=H, ldc=H, accumulate=acc[t0 + 3])
+        dgl = torch.empty((T, H), dtype=cd, device=dev)
+        ops.gemm(dlog, w_log, dgl, T, H, V, la=0, lb=1, lda=Vp, ldb=H, ldc=H)
+        dg = ops.layernorm_bwd(dgl, sv["g"], w_mln, sv["mu_g"], sv["rs_g"], cd, view(GW, t0 + 2, (H,)), acc[t0 + 2])
+        dd = ops.gelu_bwd(sv["d"], dg)
+        ops.linear_wgrad(dd, sv["xf"], view(GW, t0 + 1, (H, H)), acc[t0 + 1])
+        dxf = ops.linear_dgrad(dd, w_dense)
+        dx = ops.layernorm_bwd(dxf, sv["x_last"], w_enc, sv["mu_e"], sv["rs_e"], torch.float32, view(GW, t0 + 0, (H,)),
+                               acc[t0 + 0])
+        ready(t0, t0 + 4)
+
+        # ---- layers, last to first ----------------------------------------------------------------------------------
+        for li in reversed(range(self.num_hidden_layers)):
+            s = sv["layers"][li]
+            b0 = 2 + li * 11
+            w_ln1, w_qkv, w_out = view(Wf, b0 + 0, (H,)), view(Wc, b0 + 1, (3 * H, H)), view(Wc, b0 + 4, (H, H))
+            w_post, w_pre = view(Wf, b0 + 5, (H,)), view(Wf, b0 + 6, (H,))
+            w_01, w_mid, w_o2 = view(Wc, b0 + 7, (2 * I, H)), view(Wf, b0 + 9, (I,)), view(Wc, b0 + 10, (H, I))
+            # FFN
+            dxc = to_cd(dx)
+            ops.linear_wgrad(dxc, s["hm"], view(GW, b0 + 10, (H, I)), acc[b0 + 10])
+            dhm = ops.linear_dgrad(dxc, w_o2)
+            dh = ops.layernorm_bwd(dhm, s["h"], w_mid, s["mu_m"], s["rs_m"], cd, view(GW, b0 + 9, (I,)), acc[b0 + 9])
+            dab = ops.glu_bwd(s["ab"], dh)
+            ops.linear_wgrad(dab, s["ln2"], view(GW, b0 + 7, (2 * I, H)), acc[b0 + 7])
+            dln2 = ops.linear_dgrad(dab, w_01)
+            dx1 = ops.layernorm_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], torch.float32, view(GW, b0 + 6, (H,)),
+                                    acc[b0 + 6], dres=dx)
+            # attention
+            dao = ops.layernorm_bwd(dx1, s["ao"], w_post, s["mu_p"], s["rs_p"], cd, view(GW, b0 + 5, (H,)), acc[b0 + 5])
+            ops.linear_wgrad(dao, s["ctx"], view(GW, b0 + 4, (H, H)), acc[b0 + 4])
+            dctx = ops.linear_dgrad(dao, w_out)
+            qkv, P = s["qkv"], s["P"]
+            dqkv = torch.empty((T, 3 * H), dtype=cd, device=dev)
+            sQ, sP_, sX = (S * 3 * H, hd), (nh * S * Sp, S * Sp), (S * H, hd)
+            # dV = P^T dctx
+            ops.gemm(P, dctx, dqkv, S, hd, S, la=1, lb=1, lda=Sp, ldb=H, ldc=3 * H, c_off=2 * H, batch=B * nh, zdiv=nh,
+                     sA=sP_, sB=sX, sC=sQ)
+            # dP = dctx V^T
+            dP = torch.empty((B * nh, S, Sp), dtype=cd, device=dev)
+            ops.gemm(dctx, qkv, dP, S, S, hd, la=0, lb=0, lda=H, ldb=3 * H, ldc=Sp, b_off=2 * H, batch=B * nh, zdiv=nh,
+                     sA=sX, sB=sQ, sC=sP_)
+            ops.softmax_bwd_(P, dP, B * nh * S, S, Sp)   # dS in place
+            # dQ = alpha dS K ; dK = alpha dS^T Q
+            ops.gemm(dP, qkv, dqkv, S, hd, S, la=0, lb=1, lda=Sp, ldb=3 * H, ldc=3 * H, b_off=H, c_off=0, alpha=alpha,
+                     batch=B * nh, zdiv=nh, sA=sP_, sB=sQ, sC=sQ)
+            ops.gemm(dP, qkv, dqkv, S, hd, S, la=1, lb=1, lda=Sp, ldb=3 * H, ldc=3 * H, b_off=0, c_off=H, alpha=alpha,
+                     batch=B * nh, zdiv=nh, sA=sP_, sB=sQ, sC=sQ)
+            ops.linear_wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
+            dln1 = ops.linear_dgrad(dqkv, w_qkv)
+            dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
+                                   acc[b0 + 0], dres=dx1)
+            sv["layers"][li] = None  # free activations as we go
+            ready(b0, b0 + 11)
+
+        ops.embed_bwd(sv["ids"], dx, view(GW, 0, tuple(params[0].shape)), view(GW, 1, tuple(params[1].shape)), acc[0])
+        # position rows beyond S received no gradient this step
+        if not acc[1] and S < self.max_position_embeddings:
+            view(GW, 1, tuple(params[1].shape))[S:].zero_()
+        ready(0, 2)
+        if self.direct_grad:
+            return [None] * len(params)
+        return [view(GW, i, tuple(p.shape)) for i, p in enumerate(params)]
+
+    # ------------------------------------------------------------------------------------------------------------
+    # sampling (reference :1363-1456).  Adjacent to the hot path ("next" row in SURVEY.md section 8f): the network
+    # forward runs on the HIP kernels, the per-step token bookkeeping uses torch ops on the GPU.
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate2(self, input_ids=None, class_ids=None, encoder_hidden_states=None, negative_embeds=None, temperature=1.0,
+                  timesteps=18, guidance_scale=0, noise_schedule=cosine_schedule, generator=None, **kwargs):
+        if encoder_hidden_states is not None:
+            raise NotImplementedError("text conditioning is outside the MI355X hot-path build")
+        mask_token_id = self.config.mask_token_id
+        seq_len = self.config.num_vq_tokens
+        batch_size = len(class_ids)
+        class_ids = class_ids + self.config.codebook_size  # (the reference mutates the caller's tensor in place)
+        if input_ids is None:
+            input_ids = torch.full((batch_size, seq_len), mask_token_id, dtype=torch.long, device=self.device)
+        sampled_ids = input_ids
+        for step in range(timesteps):
+            model_in = torch.cat([class_ids[:, None], input_ids], dim=1)
+            logits = self(model_in)[..., : self.config.codebook_size][:, 1:]
+            probs = logits.softmax(dim=-1)
+            sampled_ids = torch.multinomial(probs.reshape(-1, probs.size(-1)), 1, generator=generator)[:, 0].view(batch_size, seq_len)
+            unknown_map = input_ids == mask_token_id
+            sampled_ids = torch.where(unknown_map, sampled_ids, input_ids)
+            ratio = 1.0 * (step + 1) / timesteps
+            mask_ratio = noise_schedule(torch.tensor(ratio))
+            selected_probs = torch.gather(probs, -1, sampled_ids.long()[..., None]).squeeze(-1)
+            selected_probs = torch.where(unknown_map, selected_probs, torch.finfo(selected_probs.dtype).max)
+            mask_len = (seq_len * mask_ratio).floor().unsqueeze(0).to(logits.device)
+            mask_len = torch.max(torch.tensor([1], device=logits.device),
+                                 torch.min(unknown_map.sum(dim=-1, keepdim=True) - 1, mask_len))
+            temperature = temperature * (1.0 - ratio)
+            masking = mask_by_random_topk(mask_len, selected_probs, temperature, generator=generator)
+            input_ids = torch.where(masking, mask_token_id, sampled_ids)
+        return sampled_ids
+
+    def generate(self, *args, **kwargs):
+        raise NotImplementedError("use generate2 (the reference's generate() is broken: modeling_transformer.py:1307)")

@@ -193,10 +193,11 @@ def embed_bwd(ids, dout, dword, dpos, accumulate):
                                V, 1 if accumulate else 0, stream()), "muse_embed_bwd")
 
 
-def cross_entropy_fwd(logits, labels, label_smoothing):
-    """returns (loss_out[2] = (mean loss, n_valid), lse[rows])"""
+def cross_entropy_fwd(logits, labels, label_smoothing, vocab=None):
+    """logits [rows, ld] with the first `vocab` columns valid; returns (loss_out[2] = (mean loss, n_valid), lse[rows])"""
     require_gpu(logits, labels)
-    rows, V = logits.shape
+    rows = logits.shape[0]
+    V = vocab or logits.shape[1]
     row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
     lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
     loss_out = torch.empty(2, dtype=torch.float32, device=logits.device)
@@ -206,10 +207,12 @@ def cross_entropy_fwd(logits, labels, label_smoothing):
     return loss_out, lse
 
 
-def cross_entropy_bwd(logits, labels, lse, loss_out, grad_out, label_smoothing, out_dtype):
+def cross_entropy_bwd(logits, labels, lse, loss_out, grad_out, label_smoothing, out_dtype, vocab=None):
+    """dlogits has the same (padded) row stride as logits; pad columns are written as zeros."""
     require_gpu(logits, labels, grad_out)
-    rows, V = logits.shape
-    dl = torch.empty((rows, V), dtype=out_dtype, device=logits.device)
+    rows = logits.shape[0]
+    V = vocab or logits.shape[1]
+    dl = torch.empty((rows, logits.shape[1]), dtype=out_dtype, device=logits.device)
     check(lib().muse_cross_entropy_bwd(logits.data_ptr(), dt(logits), labels.data_ptr(), lse.data_ptr(), loss_out.data_ptr(),
                                        grad_out.data_ptr(), dl.data_ptr(), dt(dl), rows, V, logits.stride(0), label_smoothing,
                                        stream()), "muse_cross_entropy_bwd")

@@ -1,0 +1,50 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient reducer (the N>1 path of bench.py)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import muse
+    import weights as W
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # different init per rank: the reducer must broadcast rank 0's weights
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TINY)
+    red = muse.GradReducer(m, bucket_bytes=16 * 1024)
+    p_after = m.flat_params().clone()
+    g = m.flat_grads()
+    n = g.numel()
+    g.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+    # replay backward's report order: head, layers last->first, embeddings
+    off = m._offsets
+    L = m.num_hidden_layers
+    t0 = 2 + L * 11
+    m.grad_ready_hook(off[t0], n)
+    for li in reversed(range(L)):
+        b0 = 2 + li * 11
+        m.grad_ready_hook(off[b0], off[b0 + 11])
+    m.grad_ready_hook(off[0], off[2])
+    red.finish()
+    torch.save({"p": p_after, "g": g.clone()}, os.path.join(out, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["p"], r1["p"])                      # broadcast from rank 0
+    n = r0["g"].numel()
+    expect = torch.arange(n, dtype=torch.float32) * 1.5       # mean of (1x, 2x)
+    assert torch.allclose(r0["g"], expect) and torch.equal(r0["g"], r1["g"])

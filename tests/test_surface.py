@@ -1,0 +1,112 @@
+"""CPU: class surface / file formats of the drop-in boundary, C-ABI symbol export, host logic."""
+import ctypes
+import os
+import re
+import tempfile
+
+import pytest
+import torch
+
+import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_transformer_surface_and_roundtrip(golden_dir):
+    import muse
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TINY)
+    shapes = W.transformer_shapes(W.TRANSFORMER_TINY)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    assert m.config.mask_token_id == W.TRANSFORMER_TINY["vocab_size"] - 1
+    assert m.output_size == W.TRANSFORMER_TINY["vocab_size"]
+    # config.json byte-identical to what the reference writes for the same kwargs
+    assert m.to_json_string() == open(os.path.join(golden_dir, "config_transformer_tiny.json")).read()
+    with tempfile.TemporaryDirectory() as d:
+        m.save_pretrained(d)
+        assert sorted(os.listdir(d)) == ["config.json", "pytorch_model.bin"]
+        m2 = muse.MaskGitTransformer.from_pretrained(d)
+        assert not m2.training and m2.config._name_or_path == d
+        for a, b in zip(sd.values(), m2.state_dict().values()):
+            assert torch.equal(a, b)
+        bad = {k: v for k, v in sd.items() if k != "encoder_layer_norm.weight"}
+        torch.save(bad, os.path.join(d, "pytorch_model.bin"))
+        with pytest.raises(ValueError):
+            muse.MaskGitTransformer.from_pretrained(d)
+    with pytest.raises(EnvironmentError):
+        muse.MaskGitTransformer.from_pretrained("/nonexistent/dir/for/sure")
+    m.enable_xformers_memory_efficient_attention()  # accepted no-op (train script calls it)
+    assert m.num_parameters() == sum(int(torch.tensor(s).prod()) for s in shapes.values())
+
+
+def test_flat_parameter_storage():
+    import muse
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TINY)
+    assert m._flat_ok()
+    l0 = m.transformer_layers[0]
+    q, k, v = l0.attention.query.weight, l0.attention.key.weight, l0.attention.value.weight
+    assert k.data_ptr() == q.data_ptr() + q.numel() * 4 and v.data_ptr() == k.data_ptr() + k.numel() * 4
+    assert l0.ffn.wi_1.weight.data_ptr() == l0.ffn.wi_0.weight.data_ptr() + l0.ffn.wi_0.weight.numel() * 4
+    sd = W.fill_state_dict(W.transformer_shapes(W.TRANSFORMER_TINY), 7, "transformer")
+    m.load_state_dict(sd)
+    assert m._flat_ok() and torch.equal(m.state_dict()["mlm_layer.to_logits.weight"], sd["mlm_layer.to_logits.weight"])
+    m.double if False else None
+    g = m.flat_grads()
+    assert g.numel() == m.flat_params().numel()
+
+
+def test_vqgan_surface(golden_dir):
+    import muse
+    v = muse.MaskGitVQGAN(**W.VQGAN_TINY)
+    shapes = W.vqgan_shapes(W.VQGAN_TINY)
+    sd = v.state_dict()
+    assert set(sd.keys()) == set(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    assert v.num_embeddings == W.VQGAN_TINY["num_embeddings"]
+    assert v.to_json_string() == open(os.path.join(golden_dir, "config_vqgan_tiny.json")).read()
+    full = muse.MaskGitVQGAN()
+    assert full.num_parameters() == 54515587
+    assert len(full.state_dict()) == 168
+
+
+def test_no_cpu_fallback():
+    import muse
+    from muse._hip import MuseHipError
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TINY)
+    with pytest.raises(MuseHipError):
+        m(torch.zeros(2, 17, dtype=torch.long))
+    v = muse.MaskGitVQGAN(**W.VQGAN_TINY)
+    with pytest.raises(MuseHipError):
+        v.encode(torch.zeros(1, 3, 16, 16))
+
+
+def test_unsupported_configs_fail_loudly():
+    import muse
+    with pytest.raises(NotImplementedError):
+        muse.MaskGitTransformer(vocab_size=48, hidden_size=32, num_attention_heads=2, add_cross_attention=True)
+    with pytest.raises(ValueError):
+        muse.MaskGitTransformer(vocab_size=48, hidden_size=30, num_attention_heads=4)
+
+
+def test_library_exports_every_declared_symbol():
+    """the C-ABI library loads and exports every symbol include/muse_hip.h declares (no compute calls on CPU)"""
+    hdr = open(os.path.join(ROOT, "include", "muse_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(muse_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 30
+    from muse import _hip
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _hip.lib().muse_version() == 1
+    assert _hip.lib().muse_layernorm_bwd_nblk(16448) == 257
+
+
+def test_sampling_schedules():
+    from muse.sampling import cosine_schedule, get_mask_chedule
+    t = torch.tensor([0.0, 0.5, 1.0])
+    assert torch.allclose(cosine_schedule(t), torch.tensor([1.0, 0.70710678, 0.0]), atol=1e-6)
+    assert get_mask_chedule("cosine") is cosine_schedule
+    with pytest.raises(ValueError):
+        get_mask_chedule("nope")
