@@ -22,6 +22,38 @@ def _esz(t):
     return t.element_size()
 
 
+# ---- optional per-launch timing of the MFMA kernels (bench.py's roofline leg): HIP events on the launch stream ----------
+_PROF = None
+
+
+def profile_start():
+    global _PROF
+    _PROF = []
+
+
+def profile_stop():
+    """-> list of (kernel name, algorithmic flops, milliseconds) per launch"""
+    global _PROF
+    rec, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    return [(n, f, e0.elapsed_time(e1)) for n, f, e0, e1 in rec]
+
+
+def _prof_begin():
+    if _PROF is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(e0, name, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        _PROF.append((name, flops, e0, e1))
+
+
 def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, rowvec=None,
          residual=None, ldr=0, batch=1, zdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), accumulate=False, act=0):
     """C[z] = epilogue(alpha * A[z] @ B[z]^T).  A/B/C_ are tensors, *_off element offsets of the (0,0) entry.
@@ -53,7 +85,9 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     d.alpha = alpha
     d.accumulate = 1 if accumulate else 0
     d.act = act
+    e0 = _prof_begin()
     check(lib().muse_gemm(C.byref(d), stream()), "muse_gemm")
+    _prof_end(e0, f"gemm_{'bf16' if d.dtype == BF16 else 'f32'}_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
     return C_
 
 
@@ -258,8 +292,10 @@ def conv2d_nhwc(x, w, B, H, W, Cin, Cout, KS, bias=None, residual=None, upsample
     """x: [B, Hin, Win, Cin] (Hin = H/2 if upsample), w: [Cout, KS, KS, Cin]; returns [B, H, W, Cout]."""
     require_gpu(x, w)
     out = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    e0 = _prof_begin()
     check(lib().muse_conv2d_nhwc(x.data_ptr(), w.data_ptr(), ptr(bias), ptr(residual), out.data_ptr(), dt(x), B, H, W, Cin,
                                  Cout, KS, 1 if upsample else 0, stream()), "muse_conv2d_nhwc")
+    _prof_end(e0, f"conv_{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", 2.0 * B * H * W * Cout * KS * KS * Cin)
     return out
 
 

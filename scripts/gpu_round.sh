@@ -1,0 +1,30 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, rocprof.  Everything lands under gpurun_out/.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+O=gpurun_out
+mkdir -p $O
+STAGE=${1:-all}
+rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > $O/device.txt
+nproc >> $O/device.txt; grep -m1 "model name" /proc/cpuinfo >> $O/device.txt
+if [[ $STAGE == all || $STAGE == test ]]; then
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/pytest_gpu.txt 2>&1
+  echo "pytest exit $?" >> $O/pytest_gpu.txt
+  tail -60 $O/pytest_gpu.txt
+fi
+if [[ $STAGE == all || $STAGE == smoke ]]; then
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke exit $?" >> $O/smoke.txt
+  tail -5 $O/smoke.txt
+fi
+if [[ $STAGE == all || $STAGE == bench ]]; then
+  timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 ${BENCH_ARGS} > $O/bench.txt 2>&1; echo "bench exit $?" >> $O/bench.txt
+  tail -5 $O/bench.txt
+fi
+if [[ $STAGE == all || $STAGE == prof ]]; then
+  rm -rf $O/prof
+  timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o r1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $O/prof.txt 2>&1
+  echo "prof exit $?" >> $O/prof.txt
+  find $O/prof -name "*kernel_stats*" | head; f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
+  # keep only the small summaries (the trace itself can be large)
+  find $O/prof -name "*kernel_trace*" -size +8M -delete
+fi

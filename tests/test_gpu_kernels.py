@@ -1,0 +1,351 @@
+"""GPU (-m gpu): every libmuse_hip kernel against a CPU reference on the same seeded inputs, through the C-ABI.
+
+Integer / index outputs are bit-exact; floating point tolerances are written next to each check.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from muse import ops
+    return ops
+
+
+def rnd(shape, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_loaded_native_library():
+    from muse import _hip
+    assert os.path.exists(_hip.LIB_PATH)
+    assert _hip.lib().muse_version() == 1
+    assert torch.cuda.is_available()
+
+
+def test_tr16_lane_mapping():
+    """ds_read_b64_tr_b16 semantics the k-major GEMM path relies on: within each 16-lane group the lanes supply a 4x16
+    matrix (lane p -> row p/4, cols 4*(p%4)..+3) and lane i receives column i."""
+    ops = _ops()
+    addr = torch.arange(64, dtype=torch.int32) * 8
+    out = ops.probe_tr16(addr.to(DEV)).cpu().view(64, 4)
+    exp = torch.empty(64, 4, dtype=torch.int32)
+    for l in range(64):
+        for j in range(4):
+            exp[l, j] = (l & 15) + j * 16 + (l >> 4) * 64
+    assert torch.equal(out, exp), out[:20]
+    # free row stride: lane p reads row p/4 at stride 144 elements
+    addr2 = torch.tensor([((l >> 4) * 4 + ((l & 15) >> 2)) * 288 + (l & 3) * 8 for l in range(64)], dtype=torch.int32)
+    out2 = ops.probe_tr16(addr2.to(DEV)).cpu().view(64, 4)
+    for l in range(64):
+        for j in range(4):
+            assert int(out2[l, j]) == ((l >> 4) * 4 + j) * 144 + (l & 15)
+
+
+GEMM_CASES = [
+    # M, N, K, la, lb
+    (128, 128, 64, 0, 0), (257, 130, 72, 0, 0), (300, 257, 264, 0, 1), (257, 64, 257, 0, 1), (200, 136, 257, 1, 1),
+    (64, 48, 515, 1, 1), (130, 257, 48, 0, 0), (1000, 96, 40, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,la,lb", GEMM_CASES)
+def test_gemm_layouts(dtype, M, N, K, la, lb):
+    ops = _ops()
+    pad = lambda n: (n + 7) // 8 * 8
+    # build operands in their storage layout with zero padding up to a 16-byte chunk
+    if la == 0:
+        A = torch.zeros(M, pad(K)); A[:, :K] = rnd((M, K), 1)
+        Am = A[:, :K]
+    else:
+        A = torch.zeros(K, pad(M)); A[:, :M] = rnd((K, M), 1)
+        Am = A[:, :M].t()
+    if lb == 0:
+        B = torch.zeros(N, pad(K)); B[:, :K] = rnd((N, K), 2)
+        Bm = B[:, :K]
+    else:
+        B = torch.zeros(K, pad(N)); B[:, :N] = rnd((K, N), 2)
+        Bm = B[:, :N].t()
+    Ad, Bd = A.to(DEV, dtype), B.to(DEV, dtype)
+    ref = (Ad.cpu().double()[:, :K] if la == 0 else Ad.cpu().double()[:, :M].t()) @ \
+          (Bd.cpu().double()[:, :K] if lb == 0 else Bd.cpu().double()[:, :N].t()).t()
+    C = torch.full((M, N + 3), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm(Ad, Bd, C, M, N, K, la=la, lb=lb, lda=A.shape[1], ldb=B.shape[1], ldc=N + 3, alpha=0.5)
+    out = C.cpu()
+    assert torch.all(out[:, N:] == 7.0), "wrote outside N"
+    tol = 2e-6 if dtype == torch.float32 else 2e-5  # bf16 inputs are exact in the reference; only f32 accumulation order differs
+    err = rel_err(out[:, :N], 0.5 * ref)
+    assert err < tol * math.sqrt(K), (err, M, N, K, la, lb)
+
+
+def test_gemm_epilogue_batch_bf16_out():
+    ops = _ops()
+    Bt, nh, S, hd = 3, 2, 37, 16
+    H = nh * hd
+    qkv = rnd((Bt * S, 3 * H), 3).to(DEV, torch.bfloat16)
+    Sp = 40
+    P = torch.zeros((Bt * nh, S, Sp), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(qkv, qkv, P, S, S, hd, la=0, lb=0, lda=3 * H, ldb=3 * H, ldc=Sp, a_off=0, b_off=H, alpha=0.25, batch=Bt * nh,
+             zdiv=nh, sA=(S * 3 * H, hd), sB=(S * 3 * H, hd), sC=(nh * S * Sp, S * Sp))
+    q = qkv.float().cpu().view(Bt, S, 3, nh, hd)
+    ref = torch.einsum("bqhd,bkhd->bhqk", q[:, :, 0], q[:, :, 1]) * 0.25
+    got = P.float().cpu().view(Bt, nh, S, Sp)[..., :S]
+    assert rel_err(got, ref) < 1e-2  # bf16 output rounding
+    assert torch.all(P.float().cpu().view(Bt, nh, S, Sp)[..., S:] == 0)
+    # bias + gelu + residual + accumulate, f32
+    x, w = rnd((70, 24), 4).to(DEV), rnd((50, 24), 5).to(DEV)
+    bias, res = rnd((50,), 6).to(DEV), rnd((70, 50), 7).to(DEV)
+    out = torch.ones((70, 50), device=DEV)
+    ops.gemm(x, w, out, 70, 50, 24, lda=24, ldb=24, ldc=50, bias=bias, residual=res, ldr=50, act=1, accumulate=True)
+    ref = F.gelu(x.cpu().double() @ w.cpu().double().t() + bias.cpu().double()) + res.cpu().double() + 1.0
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 32), (130, 768), (67, 3072), (33, 160)])
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                       (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16)])
+def test_layernorm_fwd_bwd(rows, cols, din, dout):
+    ops = _ops()
+    x = rnd((rows, cols), 10, 2.0).to(din)
+    w = 1.0 + 0.1 * rnd((cols,), 11)
+    res = rnd((rows, cols), 12)
+    eps = 1e-5
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), eps, dout, residual=res.to(DEV) if dout == torch.float32 else None)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (cols,), wr, None, eps)
+    ref = yr + (res.double() if dout == torch.float32 else 0)
+    tol = 1e-5 if dout == torch.float32 else 1e-2
+    assert rel_err(y.float(), ref.detach()) < tol
+    dy = rnd((rows, cols), 13).to(dout)
+    dres = rnd((rows, cols), 14)
+    dw = torch.empty(cols, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, din if din == torch.bfloat16 else torch.float32, dw,
+                           False, dres=dres.to(DEV))
+    yr.backward(dy.double())
+    tol = 2e-5 if din == torch.float32 else 1e-2
+    assert rel_err(dx.float(), xr.grad + dres.double()) < tol
+    assert rel_err(dw, wr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_softmax_glu_gelu(dtype):
+    ops = _ops()
+    rows, cols, ld = 300, 257, 264
+    x = torch.zeros(rows, ld)
+    x[:, :cols] = rnd((rows, cols), 20, 3.0)
+    x[:, cols:] = float("nan") if dtype == torch.float32 else 1e30  # pad garbage must not leak
+    xd = x.to(DEV, dtype)
+    ref = torch.softmax(xd.cpu().double()[:, :cols], dim=-1)
+    p = ops.softmax_(xd.clone(), rows, cols, ld)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert rel_err(p[:, :cols].float(), ref) < tol
+    assert torch.all(p[:, cols:].float() == 0)
+    dp = torch.zeros(rows, ld)
+    dp[:, :cols] = rnd((rows, cols), 21)
+    dpd = dp.to(DEV, dtype)
+    pr = p.cpu().double()[:, :cols]
+    dsr = pr * (dpd.cpu().double()[:, :cols] - (pr * dpd.cpu().double()[:, :cols]).sum(-1, keepdim=True))
+    ds = ops.softmax_bwd_(p, dpd.clone(), rows, cols, ld)
+    assert rel_err(ds[:, :cols].float(), dsr) < (1e-5 if dtype == torch.float32 else 2e-2)
+    # GLU
+    ab = rnd((50, 2 * 96), 22).to(dtype)
+    a, b = ab.double()[:, :96].requires_grad_(True), ab.double()[:, 96:].requires_grad_(True)
+    hr = F.gelu(a) * b
+    h = ops.glu_fwd(ab.to(DEV))
+    assert rel_err(h.float(), hr.detach()) < (1e-6 if dtype == torch.float32 else 1e-2)
+    dh = rnd((50, 96), 23).to(dtype)
+    hr.backward(dh.double())
+    dab = ops.glu_bwd(ab.to(DEV), dh.to(DEV))
+    assert rel_err(dab.float(), torch.cat([a.grad, b.grad], 1)) < (2e-6 if dtype == torch.float32 else 1e-2)
+    # GELU
+    xg = rnd((64, 40), 24, 2.0).to(dtype)
+    xr = xg.double().requires_grad_(True)
+    yr = F.gelu(xr)
+    assert rel_err(ops.gelu_fwd(xg.to(DEV)).float(), yr.detach()) < (1e-6 if dtype == torch.float32 else 1e-2)
+    yr.backward(dh.double()[:, :40].repeat(2, 1)[:64])
+    dxg = ops.gelu_bwd(xg.to(DEV), dh[:, :40].repeat(2, 1)[:64].contiguous().to(DEV))
+    assert rel_err(dxg.float(), xr.grad) < (2e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+@pytest.mark.parametrize("V,ld", [(48, 48), (2025, 2032)])
+def test_cross_entropy(ls, V, ld):
+    ops = _ops()
+    rows = 203
+    logits = torch.zeros(rows, ld)
+    logits[:, :V] = rnd((rows, V), 30, 2.0)
+    rng = np.random.default_rng(31)
+    labels = torch.from_numpy(rng.integers(0, V, size=rows))
+    labels[rng.random(rows) < 0.4] = -100
+    lr = logits[:, :V].double().requires_grad_(True)
+    ref = F.cross_entropy(lr, labels, ignore_index=-100, label_smoothing=ls)
+    ref.backward(torch.tensor(2.0, dtype=torch.float64))
+    ld_ = logits.to(DEV)
+    loss_out, lse = ops.cross_entropy_fwd(ld_, labels.to(DEV), ls, vocab=V)
+    assert abs(float(loss_out[0]) - float(ref)) < 1e-5 * abs(float(ref))  # f32 loss, rel 1e-5
+    assert int(loss_out[1]) == int((labels >= 0).sum())
+    dl = ops.cross_entropy_bwd(ld_, labels.to(DEV), lse, loss_out, torch.tensor([2.0], device=DEV), ls, torch.float32, vocab=V)
+    assert rel_err(dl[:, :V], lr.grad) < 1e-5
+    assert torch.all(dl[:, V:] == 0)
+
+
+def test_embedding_fwd_bwd_deterministic():
+    ops = _ops()
+    B, S, H, V = 6, 17, 32, 48
+    rng = np.random.default_rng(40)
+    ids = torch.from_numpy(rng.integers(0, V, size=(B, S)))
+    ids[:, 3:9] = V - 1  # heavy hitter (mask token)
+    word, pos = rnd((V, H), 41), rnd((24, H), 42)
+    out = ops.embed_fwd(ids.to(DEV), word.to(DEV), pos.to(DEV))
+    ref = word[ids] + pos[:S][None]
+    assert torch.equal(out.cpu().view(B, S, H), ref)  # one f32 add: bit-exact
+    dout = rnd((B * S, H), 43)
+    dword = torch.full((V, H), 5.0, device=DEV)
+    dpos = torch.full((24, H), 5.0, device=DEV)
+    ops.embed_bwd(ids.to(DEV), dout.to(DEV), dword, dpos, False)
+    rw = torch.zeros(V, H, dtype=torch.float64).index_add_(0, ids.view(-1), dout.double())
+    rp = dout.double().view(B, S, H).sum(0)
+    assert rel_err(dword, rw) < 1e-6
+    assert rel_err(dpos[:S], rp) < 1e-6
+    d2 = torch.empty_like(dword)
+    p2 = torch.empty_like(dpos)
+    ops.embed_bwd(ids.to(DEV), dout.to(DEV), d2, p2, False)
+    assert torch.equal(d2, dword)  # run-to-run deterministic (no float atomics)
+
+
+def test_adamw_matches_torch():
+    ops = _ops()
+    n = 4099
+    p0, g = rnd((n,), 50), rnd((n,), 51, 0.1)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    pd = p0.to(DEV).clone()
+    pad = torch.zeros(4100, device=DEV); pad[:n] = pd
+    gd = torch.zeros(4100, device=DEV); gd[:n] = g.to(DEV)
+    m, v = torch.zeros(4100, device=DEV), torch.zeros(4100, device=DEV)
+    shadow = torch.zeros(4100, dtype=torch.bfloat16, device=DEV)
+    for step in range(1, 4):
+        p.grad = g.clone()
+        opt.step()
+        ops.adamw_flat(pad, gd, m, v, shadow, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    assert float((pad[:n].cpu() - p.data).abs().max()) < 2e-7
+    assert torch.equal(shadow[:n].cpu(), pad[:n].cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("name", ["mask_b64", "mask_small"])
+def test_mask_sampling_bit_exact(golden_dir, name):
+    """HIP mask sampler vs the reference's own output (golden) and the oracle: bit-exact ids / labels."""
+    ops = _ops()
+    from oracle import maskgit_oracle as O
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    tok, cls = torch.from_numpy(g["image_tokens"]), torch.from_numpy(g["class_ids"])
+    t, nz = torch.from_numpy(g["timesteps"]), torch.from_numpy(g["noise"])
+    ids, labels, prob = ops.mask_sample(tok.to(DEV), cls.to(DEV), t.to(DEV), nz.to(DEV), int(g["mask_id"]),
+                                        int(g["codebook_size"]), float(g["min_rate"]))
+    assert np.array_equal(ids.cpu().numpy(), g["input_ids"])
+    assert np.array_equal(labels.cpu().numpy(), g["labels"])
+    np.testing.assert_allclose(prob.cpu().numpy(), g["mask_prob"], rtol=2e-7, atol=1e-7)  # <= 1 ulp (f32 cos)
+    o_ids, o_lab, _ = O.prepare_inputs_and_labels(tok, cls, t, nz, int(g["mask_id"]), int(g["codebook_size"]), float(g["min_rate"]))
+    assert torch.equal(ids.cpu(), o_ids) and torch.equal(labels.cpu(), o_lab)
+
+
+def test_mask_sampling_full_size_properties():
+    ops = _ops()
+    B, S = 64, 256
+    rng = np.random.default_rng(60)
+    tok = torch.from_numpy(rng.integers(0, 1024, size=(B, S))).to(DEV)
+    cls = torch.from_numpy(rng.integers(0, 1000, size=(B,))).to(DEV)
+    t = torch.from_numpy(rng.random(B).astype(np.float32)).to(DEV)
+    nz = torch.from_numpy(rng.random((B, S)).astype(np.float32)).to(DEV)
+    ids, labels, prob = ops.mask_sample(tok, cls, t, nz, 2047, 1024)
+    masked = ids[:, 1:] == 2047
+    k = torch.clamp(torch.round(S * prob), min=1).long()
+    assert torch.equal(masked.sum(-1), k)                         # exactly k masked per row
+    assert torch.equal(labels[:, 1:][masked], tok[masked])        # labels carry the hidden tokens
+    assert torch.all(labels[:, 1:][~masked] == -100) and torch.all(labels[:, 0] == -100)
+    assert torch.equal(ids[:, 1:][~masked], tok[~masked]) and torch.equal(ids[:, 0], cls + 1024)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cin,Cout,KS,ups,bias,res", [(32, 64, 3, False, False, False), (64, 32, 1, False, False, True),
+                                                       (8, 40, 3, False, True, False), (32, 32, 3, True, True, False),
+                                                       (128, 3, 3, False, True, False)])
+def test_conv2d_nhwc(dtype, Cin, Cout, KS, ups, bias, res):
+    ops = _ops()
+    B, H, W = 2, 12, 10
+    ih, iw = (H // 2, W // 2) if ups else (H, W)
+    x = rnd((B, Cin, ih, iw), 70).to(dtype)
+    w = (rnd((Cout, Cin, KS, KS), 71) / math.sqrt(Cin * KS * KS)).to(dtype)
+    bvec = rnd((Cout,), 72) if bias else None
+    rr = rnd((B, Cout, H, W), 73).to(dtype) if res else None
+    xr = x.double()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    p = KS - 1
+    ref = F.conv2d(F.pad(xr, [p // 2, p - p // 2, p // 2, p - p // 2]), w.double(), bvec.double() if bias else None)
+    if res:
+        ref = ref + rr.double()
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wn = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = ops.conv2d_nhwc(xn, wn, B, H, W, Cin, Cout, KS, bias=bvec.to(DEV) if bias else None,
+                          residual=rr.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None, upsample=ups)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < (1e-5 if dtype == torch.float32 else 1e-2), (Cin, Cout, KS, ups)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,HW", [(32, 64), (64, 1500), (128, 4096), (512, 256)])
+def test_groupnorm_silu_and_pool(dtype, C, HW):
+    ops = _ops()
+    B = 2
+    x = (rnd((B, C, HW), 80, 1.5) + 0.7).to(dtype)
+    gam, bet = 1 + 0.1 * rnd((C,), 81), 0.1 * rnd((C,), 82)
+    ref = F.silu(F.group_norm(x.double(), 32, gam.double(), bet.double(), 1e-6))
+    xn = x.permute(0, 2, 1).contiguous().to(DEV)
+    y = ops.groupnorm_silu_nhwc(xn, gam.to(DEV), bet.to(DEV), B, HW, C)
+    assert rel_err(y.float().cpu().permute(0, 2, 1), ref) < (2e-6 if dtype == torch.float32 else 1e-2)
+    if HW == 4096:
+        xi = x.view(B, C, 64, 64)
+        pr = F.avg_pool2d(xi.double(), 2, 2)
+        yp = ops.avgpool2x2_nhwc(xi.permute(0, 2, 3, 1).contiguous().to(DEV), B, 64, 64, C)
+        assert rel_err(yp.float().cpu().permute(0, 3, 1, 2), pr) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+def test_layout_and_vq_lookup():
+    ops = _ops()
+    from oracle import maskgit_oracle as O
+    x = rnd((2, 3, 8, 8), 90)
+    n = ops.nchw_to_nhwc(x.to(DEV), torch.float32, 4)
+    assert torch.equal(n[..., :3].cpu(), x.permute(0, 2, 3, 1)) and torch.all(n[..., 3] == 0)
+    assert torch.equal(ops.nhwc_to_nchw(n, 3).cpu(), x)
+    # VQ nearest neighbour: bit-exact indices vs the oracle on a well separated codebook and on the U(+-1/K) init
+    z = rnd((4096, 256), 91)
+    for cb in (0.5 * rnd((1024, 256), 92), (torch.from_numpy(np.random.default_rng(93).random((1024, 256)).astype(np.float32)) * 2 - 1) / 1024):
+        zf = z if cb.abs().max() > 0.1 else 0.05 * z
+        idx = ops.vq_nearest(zf.to(DEV), cb.to(DEV)).cpu()
+        dist = O.vq_distances(zf, cb)
+        ref = dist.argmin(1)
+        mism = (idx != ref).nonzero().flatten()
+        # any disagreement must be an f32 near-tie of the reference's own distances (|d_a - d_b| <= 4 ulp)
+        for r in mism.tolist():
+            da, db = float(dist[r, idx[r]]), float(dist[r, ref[r]])
+            assert abs(da - db) <= 4 * np.spacing(np.float32(abs(db))), (r, da, db)
+        assert len(mism) <= 4, len(mism)
+    g = ops.gather_rows(cb.to(DEV), idx.to(DEV), torch.float32)
+    assert torch.equal(g.cpu(), cb[idx])
