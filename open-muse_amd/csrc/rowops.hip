@@ -548,8 +548,8 @@ extern "C" int muse_cross_entropy_bwd(const void* logits, int32_t dtype, const i
 // =================================================================================================================
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
-                                                    float b2, float eps, float wd, float step_size, float inv_bc2_sqrt,
-                                                    float gscale) {
+                                                    float b2, float eps, float decay, float omb1, float omb2,
+                                                    float step_size, float bc2_sqrt, float gscale) {
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     float pp[4], gg[4], mm[4], vv[4];
@@ -557,11 +557,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gr = gg[j] * gscale;
-      pp[j] = pp[j] * (1.0f - lr * wd);
-      mm[j] = fmaf(1.0f - b1, gr - mm[j], mm[j]);      // exp_avg.lerp_(grad, 1 - beta1)
-      vv[j] = fmaf(1.0f - b2, gr * gr, vv[j] * b2);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-      const float denom = sqrtf(vv[j]) * inv_bc2_sqrt + eps;
-      pp[j] = pp[j] - step_size * (mm[j] / denom);
+      pp[j] = pp[j] * decay;                           // param.mul_(1 - lr * weight_decay), factor rounded once on the host
+      mm[j] = fmaf(omb1, gr - mm[j], mm[j]);           // exp_avg.lerp_(grad, 1 - beta1)
+      vv[j] = fmaf(omb2, gr * gr, vv[j] * b2);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pp[j] = pp[j] - step_size * (mm[j] / denom);     // param.addcdiv_(exp_avg, denom, value=-step_size)
     }
     V4<float>::store(p + i * 4, pp); V4<float>::store(m + i * 4, mm); V4<float>::store(v + i * 4, vv);
     if (pb) V4<bf16_t>::store(pb + i * 4, pp);
@@ -570,10 +570,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long i = (n4 << 2) + threadIdx.x;
     const float gr = g[i] * gscale;
-    float pp = p[i] * (1.0f - lr * wd);
-    const float mm = fmaf(1.0f - b1, gr - m[i], m[i]);
-    const float vv = fmaf(1.0f - b2, gr * gr, v[i] * b2);
-    pp = pp - step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+    float pp = p[i] * decay;
+    const float mm = fmaf(omb1, gr - m[i], m[i]);
+    const float vv = fmaf(omb2, gr * gr, v[i] * b2);
+    pp = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     p[i] = pp; m[i] = mm; v[i] = vv;
     if (pb) pb[i] = f32_to_bf16(pp);
   }
@@ -585,9 +585,11 @@ extern "C" int muse_adamw_flat(float* p, const float* g, float* m, float* v, voi
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);
-  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
-                     (long)n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale);
+                     (long)n, lr, beta1, beta2, eps, decay, omb1, omb2, step_size, bc2_sqrt, grad_scale);
   return (int)hipGetLastError();
 }
 

@@ -83,8 +83,7 @@ class _MaskGitFn(torch.autograd.Function):
     buffer (p.grad are views of it) unless model.direct_grad is False, in which case they are returned to autograd."""
 
     @staticmethod
-    def forward(ctx, model, input_ids, labels, label_smoothing, *params):
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, model, input_ids, labels, label_smoothing, need_grad, *params):
         logits, loss, saved = model._run_forward(input_ids, labels, label_smoothing, need_grad)
         ctx.model, ctx.saved = model, saved
         ctx.set_materialize_grads(False)
@@ -99,7 +98,7 @@ class _MaskGitFn(torch.autograd.Function):
             raise MuseHipError("backward called on a forward that ran without grad")
         grads = model._run_backward(ctx.saved, g_logits, g_loss)
         ctx.saved = None
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class MaskGitTransformer(ModelMixin, ConfigMixin):
@@ -308,7 +307,9 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             raise MuseHipError("MaskGitTransformer (MI355X build) has no CPU path: move the model and inputs to the GPU")
         if not self._flat_ok():
             self._build_flat()
-        out = _MaskGitFn.apply(self, input_ids, labels, float(label_smoothing), *self._param_order())
+        params = self._param_order()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)  # (grad mode is off inside Function.forward)
+        out = _MaskGitFn.apply(self, input_ids, labels, float(label_smoothing), need_grad, *params)
         return out
 
     def _segments(self, L):

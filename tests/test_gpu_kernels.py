@@ -244,7 +244,7 @@ def test_adamw_matches_torch():
         p.grad = g.clone()
         opt.step()
         ops.adamw_flat(pad, gd, m, v, shadow, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
-    assert float((pad[:n].cpu() - p.data).abs().max()) < 2e-7
+    assert float((pad[:n].cpu() - p.data).abs().max()) < 1e-6  # a few f32 ulp after 3 steps
     assert torch.equal(shadow[:n].cpu(), pad[:n].cpu().to(torch.bfloat16))
 
 
