@@ -84,6 +84,16 @@ int muse_softmax_fwd(const void* x, void* y, int32_t dtype, int64_t rows, int32_
 int muse_softmax_bwd(const void* p, const void* dp, void* ds, int32_t dtype, int64_t rows, int32_t cols, int64_t ld,
                      void* stream);
 
+/* Fused full-visibility attention (bf16 in/out, f32 softmax), S <= 288, head_dim in {16,32,48,64}: replaces
+ * Attention.attention (muse/modeling_transformer.py:221-241) and the xformers seam (:206-210) without materialising the
+ * S x S matrix.  qkv [B*S, 3*H] (q | k | v, H = heads*head_dim), ctx [B*S, H], lse / dsum [B*heads, seq_pad] f32
+ * (seq_pad = muse_attention_seq_pad(seq)); dqkv [B*S, 3*H].  alpha = 1/sqrt(head_dim) (the baddbmm alpha, :168,:230). */
+int muse_attention_seq_pad(int32_t seq);
+int muse_attention_fwd(const void* qkv, void* ctx, float* lse, int32_t batch, int32_t seq, int32_t heads,
+                       int32_t head_dim, float alpha, void* stream);
+int muse_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dsum, void* dqkv,
+                       int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, float alpha, void* stream);
+
 /* GLU: h = gelu_erf(a) * b with ab = [rows, 2*inter] (a = first half).  muse/modeling_transformer.py:789-792. */
 int muse_glu_fwd(const void* ab, void* h, int32_t dtype, int64_t rows, int32_t inter, void* stream);
 int muse_glu_bwd(const void* ab, const void* dh, void* dab, int32_t dtype, int64_t rows, int32_t inter, void* stream);

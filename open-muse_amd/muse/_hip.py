@@ -44,6 +44,10 @@ SIGNATURES = {
     "muse_colsum": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "muse_softmax_fwd": [c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],
     "muse_softmax_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],
+    "muse_attention_seq_pad": [c_int],
+    "muse_attention_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "muse_attention_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                           c_void_p],
     "muse_glu_fwd": [c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_glu_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_gelu_fwd": [c_void_p, c_void_p, c_int, c_i64, c_void_p],

@@ -179,6 +179,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         # engine state
         self.compute_dtype = "auto"   # "auto": bf16 under torch.autocast(bf16), else f32 (what the reference would do)
         self.direct_grad = True       # backward writes p.grad (views of the flat grad buffer) itself
+        self.fused_attention = True   # bf16 compute: fused attention kernels (f32 parity mode keeps the reference algorithm)
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None  # (flat_begin, flat_end) after each segment
         self._flat = self._flat_grad = self._flat_c = None
         self._shadow_fresh = False
@@ -339,7 +340,8 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             return t[o:o + n].view(shape)
 
         x = ops.embed_fwd(ids, self.embed.word_embeddings.weight.data, self.embed.position_embeddings.weight.data)
-        saved = {"layers": [], "cd": cd, "ids": ids, "B": B, "S": S, "Sp": Sp} if need_grad else None
+        fused = self.fused_attention and ops.attention_supported(cd, S, hd)
+        saved = {"layers": [], "cd": cd, "ids": ids, "B": B, "S": S, "Sp": Sp, "fused": fused} if need_grad else None
 
         for li in range(self.num_hidden_layers):
             b0 = 2 + li * 11
@@ -354,15 +356,19 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
 
             ln1, mu1, rs1 = ops.layernorm_fwd(x, w_ln1, eps, cd)
             qkv = ops.linear(ln1, w_qkv)
-            P = torch.empty((B * nh, S, Sp), dtype=cd, device=dev)
-            # scores[b,h] = alpha * Q K^T        (reference :226-231)
-            ops.gemm(qkv, qkv, P, S, S, hd, la=0, lb=0, lda=3 * H, ldb=3 * H, ldc=Sp, a_off=0, b_off=H, alpha=alpha,
-                     batch=B * nh, zdiv=nh, sA=(S * 3 * H, hd), sB=(S * 3 * H, hd), sC=(nh * S * Sp, S * Sp))
-            ops.softmax_(P, B * nh * S, S, Sp)
-            ctx = torch.empty((T, H), dtype=cd, device=dev)
-            # ctx[b,:,h] = P V                   (reference :238-240)
-            ops.gemm(P, qkv, ctx, S, hd, S, la=0, lb=1, lda=Sp, ldb=3 * H, ldc=H, b_off=2 * H, batch=B * nh, zdiv=nh,
-                     sA=(nh * S * Sp, S * Sp), sB=(S * 3 * H, hd), sC=(S * H, hd))
+            if fused:
+                # softmax(alpha Q K^T) V in one kernel, S x S never leaves the CU (reference :206-210 / :226-240)
+                ctx, P = ops.attention_fwd(qkv, B, S, nh, hd, alpha)   # P := row log-sum-exp
+            else:
+                P = torch.empty((B * nh, S, Sp), dtype=cd, device=dev)
+                # scores[b,h] = alpha * Q K^T        (reference :226-231)
+                ops.gemm(qkv, qkv, P, S, S, hd, la=0, lb=0, lda=3 * H, ldb=3 * H, ldc=Sp, a_off=0, b_off=H, alpha=alpha,
+                         batch=B * nh, zdiv=nh, sA=(S * 3 * H, hd), sB=(S * 3 * H, hd), sC=(nh * S * Sp, S * Sp))
+                ops.softmax_(P, B * nh * S, S, Sp)
+                ctx = torch.empty((T, H), dtype=cd, device=dev)
+                # ctx[b,:,h] = P V                   (reference :238-240)
+                ops.gemm(P, qkv, ctx, S, hd, S, la=0, lb=1, lda=Sp, ldb=3 * H, ldc=H, b_off=2 * H, batch=B * nh, zdiv=nh,
+                         sA=(nh * S * Sp, S * Sp), sB=(S * 3 * H, hd), sC=(S * H, hd))
             ao = ops.linear(ctx, w_out)
             x1, mu_p, rs_p = ops.layernorm_fwd(ao, w_post, eps, torch.float32, residual=x)   # x + LN(attn)  (:882-884)
             ln2, mu2, rs2 = ops.layernorm_fwd(x1, w_pre, eps, cd)
@@ -491,6 +497,15 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             ops.linear_wgrad(dao, s["ctx"], view(GW, b0 + 4, (H, H)), acc[b0 + 4])
             dctx = ops.linear_dgrad(dao, w_out)
             qkv, P = s["qkv"], s["P"]
+            if sv["fused"]:
+                dqkv = ops.attention_bwd(qkv, s["ctx"], dctx, P, B, S, nh, hd, alpha)
+                ops.linear_wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
+                dln1 = ops.linear_dgrad(dqkv, w_qkv)
+                dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
+                                       acc[b0 + 0], dres=dx1)
+                sv["layers"][li] = None
+                ready(b0, b0 + 11)
+                continue
             dqkv = torch.empty((T, 3 * H), dtype=cd, device=dev)
             sQ, sP_, sX = (S * 3 * H, hd), (nh * S * Sp, S * Sp), (S * H, hd)
             # dV = P^T dctx

@@ -178,6 +178,35 @@ def softmax_bwd_(p, dp, rows, cols, ld):
     return dp
 
 
+def attention_supported(dtype, seq, head_dim):
+    return dtype == torch.bfloat16 and 0 < seq <= 288 and head_dim in (16, 32, 48, 64)
+
+
+def attention_fwd(qkv, B, S, nh, hd, alpha):
+    """fused softmax(alpha q k^T) v; qkv [B*S, 3H] bf16 -> (ctx [B*S, H] bf16, lse [B*nh, seq_pad] f32)"""
+    require_gpu(qkv)
+    H = nh * hd
+    ctx = torch.empty((B * S, H), dtype=qkv.dtype, device=qkv.device)
+    sp = lib().muse_attention_seq_pad(S)
+    lse = torch.empty((B * nh, sp), dtype=torch.float32, device=qkv.device)
+    e0 = _prof_begin()
+    check(lib().muse_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, S, nh, hd, alpha, stream()), "muse_attention_fwd")
+    _prof_end(e0, "attn_fwd_bf16", 4.0 * B * nh * S * S * hd)
+    return ctx, lse
+
+
+def attention_bwd(qkv, ctx, dctx, lse, B, S, nh, hd, alpha):
+    """-> dqkv [B*S, 3H] bf16"""
+    require_gpu(qkv, ctx, dctx, lse)
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty_like(lse)
+    e0 = _prof_begin()
+    check(lib().muse_attention_bwd(qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
+                                   dqkv.data_ptr(), B, S, nh, hd, alpha, stream()), "muse_attention_bwd")
+    _prof_end(e0, "attn_bwd_bf16", 10.0 * B * nh * S * S * hd)
+    return dqkv
+
+
 def glu_fwd(ab):
     require_gpu(ab)
     rows, two_i = ab.shape

@@ -349,3 +349,27 @@ def test_layout_and_vq_lookup():
         assert len(mism) <= 4, len(mism)
     g = ops.gather_rows(cb.to(DEV), idx.to(DEV), torch.float32)
     assert torch.equal(g.cpu(), cb[idx])
+
+
+@pytest.mark.parametrize("B,S,nh,hd", [(2, 17, 2, 16), (2, 37, 2, 48), (3, 257, 4, 64), (2, 257, 3, 48), (1, 64, 2, 32)])
+def test_fused_attention_fwd_bwd(B, S, nh, hd):
+    """fused attention vs softmax(alpha q k^T) v evaluated in f64 on the same bf16 inputs (and its autograd backward)"""
+    ops = _ops()
+    H = nh * hd
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+    qkv = (rnd((B * S, 3 * H), 100, 1.0)).to(torch.bfloat16)
+    dctx = rnd((B * S, H), 101).to(torch.bfloat16)
+    x = qkv.double().view(B, S, 3, nh, hd).requires_grad_(True)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    p = torch.softmax(q @ k.transpose(-1, -2) * alpha, dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(B * S, H)
+    ref.backward(dctx.double())
+    ctx, lse = ops.attention_fwd(qkv.to(DEV), B, S, nh, hd, alpha)
+    assert rel_err(ctx.float(), ref.detach()) < 1.5e-2          # bf16 P and bf16 output
+    lse_ref = torch.logsumexp(q @ k.transpose(-1, -2) * alpha, dim=-1).reshape(B * nh, S)
+    assert rel_err(lse[:, :S], lse_ref.detach()) < 1e-5
+    dqkv = ops.attention_bwd(qkv.to(DEV), ctx, dctx.to(DEV), lse, B, S, nh, hd, alpha)
+    g = x.grad.reshape(B * S, 3 * H)
+    for i, nm in enumerate("qkv"):
+        e = rel_err(dqkv[:, i * H:(i + 1) * H].float(), g[:, i * H:(i + 1) * H])
+        assert e < 3e-2, (nm, e)
