@@ -54,6 +54,8 @@ typedef struct muse_gemm_desc {
   float alpha;
   int32_t accumulate; /* C += ...                                                          */
   int32_t act;        /* 0 none, 1 erf-GELU (F.gelu)                                       */
+  int32_t split_k;    /* > 1: K is cut into that many slices, each added to C (f32, no epilogue extras) with
+                         hardware f32 atomics; the caller pre-initialises C (zeros, or the value to accumulate into) */
 } muse_gemm_desc;
 int muse_gemm(const muse_gemm_desc* d, void* stream);
 

@@ -319,11 +319,11 @@ static int attn_fwd_launch(const void* qkv, void* ctx, float* lse, int B, int S,
   const size_t lds = 2 * (size_t)SKP * C::RS;
   if (SKP <= 64) {
     auto k = attn_fwd_kernel<HD, 4>;
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(B * nh), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, S, SKP, nh, alpha);
   } else {
     auto k = attn_fwd_kernel<HD, 18>;
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(B * nh), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, S, SKP, nh, alpha);
   }
   return (int)hipGetLastError();
@@ -339,8 +339,8 @@ static int attn_bwd_launch(const void* qkv, const void* ctx, const void* dctx, c
                      (const bf16_t*)dctx, dsum, S, SKP, nh, total);
   auto k1 = attn_bwd_dkv_kernel<HD>;
   auto k2 = attn_bwd_dq_kernel<HD>;
-  hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k1, dim3(B * nh), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, (const float*)dsum,
                      (bf16_t*)dqkv, S, SKP, nh, alpha);
   hipLaunchKernelGGL(k2, dim3(B * nh), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, (const float*)dsum,

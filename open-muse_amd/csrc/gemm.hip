@@ -2,13 +2,18 @@
 #include "gemm_core.h"
 #include "../../include/muse_hip.h"
 
+template <typename T, typename TC, int BM>
+static int dispatch_bm(const GemmParams& p, int la, int lb, int batch, hipStream_t s) {
+  constexpr int NT = BM * 2;
+  if (la == 0 && lb == 0) return launch_gemm<T, TC, 0, 0, BM, PlainLoader<T, 0, BM, NT>, PlainLoader<T, 0, 128, NT>>(p, batch, s);
+  if (la == 0 && lb == 1) return launch_gemm<T, TC, 0, 1, BM, PlainLoader<T, 0, BM, NT>, PlainLoader<T, 1, 128, NT>>(p, batch, s);
+  if (la == 1 && lb == 1) return launch_gemm<T, TC, 1, 1, BM, PlainLoader<T, 1, BM, NT>, PlainLoader<T, 1, 128, NT>>(p, batch, s);
+  if (la == 1 && lb == 0) return launch_gemm<T, TC, 1, 0, BM, PlainLoader<T, 1, BM, NT>, PlainLoader<T, 0, 128, NT>>(p, batch, s);
+  return MUSE_ERR_BAD_ARG;
+}
 template <typename T, typename TC>
 static int dispatch_layout(const GemmParams& p, int la, int lb, int batch, hipStream_t s) {
-  if (la == 0 && lb == 0) return launch_gemm<T, TC, 0, 0, PlainLoader<T, 0>, PlainLoader<T, 0>>(p, batch, s);
-  if (la == 0 && lb == 1) return launch_gemm<T, TC, 0, 1, PlainLoader<T, 0>, PlainLoader<T, 1>>(p, batch, s);
-  if (la == 1 && lb == 1) return launch_gemm<T, TC, 1, 1, PlainLoader<T, 1>, PlainLoader<T, 1>>(p, batch, s);
-  if (la == 1 && lb == 0) return launch_gemm<T, TC, 1, 0, PlainLoader<T, 1>, PlainLoader<T, 0>>(p, batch, s);
-  return MUSE_ERR_BAD_ARG;
+  return use_bm256(p, batch) ? dispatch_bm<T, TC, 256>(p, la, lb, batch, s) : dispatch_bm<T, TC, 128>(p, la, lb, batch, s);
 }
 
 extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
@@ -26,7 +31,9 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   p.zdiv = d->zdiv > 0 ? d->zdiv : 1;
   p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
   p.alpha = d->alpha; p.accumulate = d->accumulate; p.act = d->act;
-  p.cH = p.cW = p.cCin = p.cKS = p.cUps = 0;
+  p.split_k = d->split_k > 1 ? d->split_k : 1;
+  if (p.split_k > 1 && (d->out_dtype != MUSE_F32 || d->bias || d->rowvec || d->residual || d->act)) return MUSE_ERR_BAD_ARG;
+  p.cH = p.cW = p.cCin = p.cKS = p.cUps = 0; p.cCinShift = -1;
   const int batch = d->batch > 0 ? d->batch : 1;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == MUSE_BF16) {

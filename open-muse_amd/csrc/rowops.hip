@@ -81,8 +81,8 @@ extern "C" int muse_layernorm_fwd(const void* x, int32_t x_dtype, const float* w
   return MUSE_ERR_BAD_ARG;
 }
 
-// backward: 64 rows per block (16 per wave); per-column dw partials live in registers (NIT*4 per lane).
-#define LN_BWD_ROWS 64
+// backward: 16 rows per block (4 per wave, >= 4 blocks per CU in flight); per-column dw partials live in registers.
+#define LN_BWD_ROWS 16
 template <typename TDY, typename TX, typename TDX, int NIT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
@@ -183,23 +183,27 @@ extern "C" int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* 
   return MUSE_ERR_BAD_ARG;
 }
 
-// out[c] (+)= sum_r in[r,c]; one thread per column, rows walked in order (deterministic)
-__global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int acc) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 3 < rows; r += 4) {
-    s0 += in[(long)r * cols + c]; s1 += in[(long)(r + 1) * cols + c];
-    s2 += in[(long)(r + 2) * cols + c]; s3 += in[(long)(r + 3) * cols + c];
+// out[c] (+)= sum_r in[r,c]; 64 columns x 4 row-groups per block, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int acc) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int r = w;
+    for (; r + 4 < rows; r += 8) { s0 += in[(long)r * cols + c]; s1 += in[(long)(r + 4) * cols + c]; }
+    if (r < rows) s0 += in[(long)r * cols + c];
   }
-  for (; r < rows; ++r) s0 += in[(long)r * cols + c];
-  const float s = (s0 + s1) + (s2 + s3);
-  out[c] = acc ? out[c] + s : s;
+  red[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < cols) {
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[c] = acc ? out[c] + s : s;
+  }
 }
 extern "C" int muse_colsum(const float* in, float* out, int32_t rows, int32_t cols, int32_t accumulate, void* stream) {
   if (cols <= 0) return 0;
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, rows, cols, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, accumulate);
   return (int)hipGetLastError();
 }
 
@@ -368,7 +372,7 @@ extern "C" int muse_embed_fwd(const int64_t* ids, const float* word, const float
   return (int)hipGetLastError();
 }
 
-#define EMB_SPLIT 8
+#define EMB_SPLIT 32
 // partial[split][v][:] = sum (in position order) of dout[t,:] over tokens t in this split with ids[t] == v
 __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
                                                                 float* __restrict__ partial, int ntok, int hidden, int vocab) {

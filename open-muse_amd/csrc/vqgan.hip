@@ -20,11 +20,18 @@ extern "C" int muse_conv2d_nhwc(const void* in, const void* weight, const float*
   p.M = batch * H * W; p.N = Cout; p.K = KS * KS * Cin;
   p.lda = 0; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
   p.zdiv = 1; p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
-  p.alpha = 1.0f; p.accumulate = 0; p.act = 0;
+  p.alpha = 1.0f; p.accumulate = 0; p.act = 0; p.split_k = 1;
   p.cH = H; p.cW = W; p.cCin = Cin; p.cKS = KS; p.cUps = upsample ? 1 : 0;
+  p.cCinShift = -1;
+  if ((Cin & (Cin - 1)) == 0) { int sh = 0; while ((1 << sh) < Cin) ++sh; p.cCinShift = sh; }
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MUSE_BF16) return launch_gemm<bf16_t, bf16_t, 0, 0, ConvLoader<bf16_t>, PlainLoader<bf16_t, 0>>(p, 1, s);
-  if (dtype == MUSE_F32) return launch_gemm<float, float, 0, 0, ConvLoader<float>, PlainLoader<float, 0>>(p, 1, s);
+  const bool big = use_bm256(p, 1);
+  if (dtype == MUSE_BF16)
+    return big ? launch_gemm<bf16_t, bf16_t, 0, 0, 256, ConvLoader<bf16_t, 256, 512>, PlainLoader<bf16_t, 0, 128, 512>>(p, 1, s)
+               : launch_gemm<bf16_t, bf16_t, 0, 0, 128, ConvLoader<bf16_t, 128, 256>, PlainLoader<bf16_t, 0, 128, 256>>(p, 1, s);
+  if (dtype == MUSE_F32)
+    return big ? launch_gemm<float, float, 0, 0, 256, ConvLoader<float, 256, 512>, PlainLoader<float, 0, 128, 512>>(p, 1, s)
+               : launch_gemm<float, float, 0, 0, 128, ConvLoader<float, 128, 256>, PlainLoader<float, 0, 128, 256>>(p, 1, s);
   return MUSE_ERR_BAD_ARG;
 }
 

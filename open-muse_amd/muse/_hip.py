@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
         ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("zdiv", c_int),
         ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ldr", c_i64),
         ("sA0", c_i64), ("sA1", c_i64), ("sB0", c_i64), ("sB1", c_i64), ("sC0", c_i64), ("sC1", c_i64),
-        ("alpha", c_float), ("accumulate", c_int), ("act", c_int),
+        ("alpha", c_float), ("accumulate", c_int), ("act", c_int), ("split_k", c_int),
     ]
 
 

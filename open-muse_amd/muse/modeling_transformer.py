@@ -464,7 +464,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         w_enc, w_dense = view(Wf, t0 + 0, (H,)), view(Wc, t0 + 1, (H, H))
         w_mln, w_log = view(Wf, t0 + 2, (H,)), view(Wc, t0 + 3, (V, H))
         # dW_logits[V,H] = dlog^T gl ; dgl[T,H] = dlog W_logits   (dlog rows are Vp wide, only V valid)
-        ops.gemm(dlog, sv["gl"], view(GW, t0 + 3, (V, H)), V, H, T, la=1, lb=1, lda=Vp, ldb=H, ldc=H, accumulate=acc[t0 + 3])
+        ops.linear_wgrad(dlog, sv["gl"], view(GW, t0 + 3, (V, H)), acc[t0 + 3], M=V, lda=Vp)
         dgl = torch.empty((T, H), dtype=cd, device=dev)
         ops.gemm(dlog, w_log, dgl, T, H, V, la=0, lb=1, lda=Vp, ldb=H, ldc=H)
         dg = ops.layernorm_bwd(dgl, sv["g"], w_mln, sv["mu_g"], sv["rs_g"], cd, view(GW, t0 + 2, (H,)), acc[t0 + 2])

@@ -373,3 +373,19 @@ def test_fused_attention_fwd_bwd(B, S, nh, hd):
     for i, nm in enumerate("qkv"):
         e = rel_err(dqkv[:, i * H:(i + 1) * H].float(), g[:, i * H:(i + 1) * H])
         assert e < 3e-2, (nm, e)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_split_k_wgrad(dtype):
+    """weight-gradient shape: short M,N, long K, k-major operands, K cut in slices summed with f32 atomics"""
+    ops = _ops()
+    T, N, K = 4100, 136, 200
+    dy, x = rnd((T, N), 110).to(dtype), rnd((T, K), 111).to(dtype)
+    ref = dy.double().t() @ x.double()
+    dw = torch.full((N, K), 3.0, device=DEV)
+    ops.gemm(dy.to(DEV), x.to(DEV), dw, N, K, T, la=1, lb=1, lda=N, ldb=K, ldc=K, accumulate=True, split_k=7)
+    assert rel_err(dw, ref + 3.0) < 1e-4
+    dw2 = torch.empty((N, K), device=DEV)
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw2, False)
+    assert rel_err(dw2, ref) < 1e-4
+    assert ops.wgrad_splits(768, 768, 16448, torch.bfloat16) > 1
