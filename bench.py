@@ -59,7 +59,7 @@ def cpu_baseline(cfg_name, bs=4):
     """the CPU oracle (port of the reference path) on this node's host cores, one full train step at bs=4"""
     import weights as W
     from oracle import maskgit_oracle as O
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), 32)  # torch CPU ops stop scaling (and oversubscribe) far below the 256 hw threads of the node
     torch.set_num_threads(cores)
     tcfg = dict(W.TRANSFORMER_A if cfg_name == "A" else W.TRANSFORMER_B)
     vsd = W.fill_state_dict(W.vqgan_shapes(W.VQGAN_F16), 1, "vqgan")
@@ -72,7 +72,7 @@ def cpu_baseline(cfg_name, bs=4):
     O.adamw_step(tsd[k], out["grads"][k], torch.zeros_like(tsd[k]), torch.zeros_like(tsd[k]), 1, 1e-4, 0.9, 0.999, 1e-8, 0.01)
     dt = time.time() - t0
     return {"value": round(bs / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 train step, config {cfg_name}, bs={bs}, f32, oracle/maskgit_oracle.py on {cores} host threads ({dt:.1f} s)"}
+            "sample": f"1 train step, config {cfg_name}, bs={bs}, f32, oracle/maskgit_oracle.py on {cores} of {os.cpu_count()} host threads ({dt:.1f} s)"}
 
 
 def main():
@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true", help="also time config A and the bf16 tokenizer (N=1 only)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary bf16-tokenizer timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,8 +156,9 @@ def main():
     extra = {"loss": round(lossv, 4), "algorithmic_gflop_per_image": gf_img,
              "step_tflops_per_gpu": round(gf_img * args.batch / ms, 1),
              "mfma_ms_in_instrumented_step": round(sum(v[1] for v in agg.values()), 2)}
-    if args.extra and world == 1:
-        for cfgn, vqd in (("B", "bf16"), ("A", "f32"), ("A", "bf16")):
+    if world == 1 and not args.no_extra:
+        variants = (("B", "bf16"), ("A", "f32"), ("A", "bf16")) if args.extra else ((args.config, "bf16"),)
+        for cfgn, vqd in variants:
             if (cfgn, vqd) == (args.config, args.vq_dtype):
                 continue
             e2, _, _ = run(cfgn, vqd, max(3, args.steps // 2), 2, profile=False)

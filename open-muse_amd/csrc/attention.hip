@@ -18,18 +18,20 @@ template <int HD> struct HeadCfg {
   static constexpr int HDP = (HD + 31) / 32 * 32;   // head dim padded to the MFMA K = 32
   static constexpr int KS = HDP / 32;               // k-steps of the (head-dim contracted) MFMAs
   static constexpr int ND = HD / 16;                // 16-wide output tiles over the head dim
-  static constexpr int RS = HDP * 2 + 32;           // LDS row stride in bytes (== 32 mod 64)
+  // LDS row stride in bytes, == 32 (mod 64): 96 B for hd 48 / 32, 160 B for hd 64, 32 B for hd 16.  Only HD columns are
+  // stored; the zero padding of the last 32-wide k-step (hd 48, 16) is produced in frag_hd instead of in LDS.
+  static constexpr int RS = ((HD * 2) % 64 == 32) ? HD * 2 : HD * 2 + 32;
 };
 
 // cooperative load of one head's [S][HD] slice (row stride ld elements) into an LDS image of SKP rows, zero padded
 template <int HD>
 __device__ __forceinline__ void load_head(unsigned char* img, const bf16_t* src, long ld, int S, int SKP) {
   using C = HeadCfg<HD>;
-  constexpr int CPR = C::HDP / 8;
+  constexpr int CPR = HD / 8;
   for (int c = threadIdx.x; c < SKP * CPR; c += blockDim.x) {
     const int row = c / CPR, col = (c % CPR) * 8;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < S && col < HD) v = *(const u32x4*)(src + (long)row * ld + col);
+    if (row < S) v = *(const u32x4*)(src + (long)row * ld + col);
     *(u32x4*)(img + row * C::RS + col * 2) = v;
   }
 }
@@ -37,7 +39,15 @@ __device__ __forceinline__ void load_head(unsigned char* img, const bf16_t* src,
 // B/A operand with k = head dim: rows [rowbase, +16) of an LDS image
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_hd(const unsigned char* img, int rowbase, int ks, int lane) {
-  return *(const bf16x8*)(img + (rowbase + (lane & 15)) * HeadCfg<HD>::RS + ks * 64 + (lane >> 4) * 16);
+  const int col = ks * 32 + (lane >> 4) * 8;
+  if constexpr (HD % 32 != 0) {
+    union { u32x4 u; bf16x8 v; } t;
+    t.u = u32x4{0u, 0u, 0u, 0u};
+    if (col < HD) t.v = *(const bf16x8*)(img + (rowbase + (lane & 15)) * HeadCfg<HD>::RS + col * 2);
+    return t.v;
+  } else {
+    return *(const bf16x8*)(img + (rowbase + (lane & 15)) * HeadCfg<HD>::RS + col * 2);
+  }
 }
 // the same operand straight from global memory (rows owned by this wave), zero outside [0,S) x [0,HD)
 template <int HD>

@@ -44,8 +44,8 @@ template <> struct TileCfg<bf16_t> {
   static constexpr int KC_STRIDE = 160;  // bytes per row, k-contiguous image (128 + 32)
 };
 template <> struct TileCfg<float> {
-  static constexpr int BK = 32, CH = 4;
-  static constexpr int KC_STRIDE = 160;  // 128 + 32
+  static constexpr int BK = 64, CH = 4;  // 8192 MFMA cycles per wave between barrier pairs (f32 MFMA is 16x slower per flop)
+  static constexpr int KC_STRIDE = 288;  // 256 + 32
 };
 // k-major image: [BK k-rows][ROWS] with a row stride of ROWS*sizeof(T) + pad, pad chosen so that the rows read together
 // by one half-wave fall on distinct banks (bf16 tr-reads: stride/4 == 8 mod 16 banks; f32 b32 reads: 4 rows -> +16 banks)
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(GemmParams p) {
       }
     } else {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < Cfg::BK / 16; ++ks) {
         f32x4 af[4], bf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

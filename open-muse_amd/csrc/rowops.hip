@@ -183,27 +183,29 @@ extern "C" int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* 
   return MUSE_ERR_BAD_ARG;
 }
 
-// out[c] (+)= sum_r in[r,c]; 64 columns x 4 row-groups per block, fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int acc) {
-  __shared__ float red[4][64];
+// out[c] (+)= sum_r in[r,c]; 64 columns x 16 row-groups per block, fixed summation order (deterministic)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int acc) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f;
   if (c < cols) {
     int r = w;
-    for (; r + 4 < rows; r += 8) { s0 += in[(long)r * cols + c]; s1 += in[(long)(r + 4) * cols + c]; }
+    for (; r + 16 < rows; r += 32) { s0 += in[(long)r * cols + c]; s1 += in[(long)(r + 16) * cols + c]; }
     if (r < rows) s0 += in[(long)r * cols + c];
   }
   red[w][lane] = s0 + s1;
   __syncthreads();
   if (w == 0 && c < cols) {
-    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][lane];
     out[c] = acc ? out[c] + s : s;
   }
 }
 extern "C" int muse_colsum(const float* in, float* out, int32_t rows, int32_t cols, int32_t accumulate, void* stream) {
   if (cols <= 0) return 0;
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, in, out, rows, cols, accumulate);
   return (int)hipGetLastError();
 }
 

@@ -20,6 +20,17 @@ if [[ $STAGE == all || $STAGE == bench ]]; then
   timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 ${BENCH_ARGS} > $O/bench.txt 2>&1; echo "bench exit $?" >> $O/bench.txt
   tail -5 $O/bench.txt
 fi
+if [[ $STAGE == perf ]]; then
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider > $O/pytest_kernels.txt 2>&1
+  echo "pytest exit $?" >> $O/pytest_kernels.txt; tail -15 $O/pytest_kernels.txt
+  for v in default bm256; do
+    if [[ $v == bm256 ]]; then export MUSE_BM256=1; else unset MUSE_BM256; fi
+    timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/bench_$v.txt 2>&1; echo "exit $?" >> $O/bench_$v.txt
+    tail -2 $O/bench_$v.txt | cut -c1-2600
+  done
+  unset MUSE_BM256
+  timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --vq-dtype bf16 > $O/bench_vqbf16.txt 2>&1; tail -1 $O/bench_vqbf16.txt | cut -c1-2600
+fi
 if [[ $STAGE == all || $STAGE == prof ]]; then
   rm -rf $O/prof
   timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o r1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $O/prof.txt 2>&1
