@@ -145,6 +145,12 @@ int muse_mask_sample(const int64_t* tokens, const int64_t* class_ids, const floa
 int muse_conv2d_nhwc(const void* in, const void* weight, const float* bias, const void* residual, void* out,
                      int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS,
                      int32_t upsample, void* stream);
+/* f32-class convolution on the bf16 matrix cores by hi/lo operand splitting (3 bf16 MFMAs per product, f32 accumulate,
+ * error <= 2^-16 |a||b| per product: tighter than the TF32 the reference's cuDNN path uses by PyTorch default).
+ * in / out / residual f32 NHWC, w_hi / w_lo bf16 [Cout][KS][KS][Cin] with w ~= w_hi + w_lo; Cin % 8 == 0. */
+int muse_conv2d_nhwc_split(const float* in, const void* w_hi, const void* w_lo, const float* bias, const float* residual,
+                           float* out, int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS,
+                           int32_t upsample, void* stream);
 /* GroupNorm(32, eps, affine) + SiLU (muse/modeling_maskgit_vqgan.py:61,73-78,186-187,236-237).
  * stats: partial [B, nchunk, G, 2] f64 -> apply.  `partial` needs B*nchunk*G*2 doubles (nchunk from _nchunk). */
 int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, const float* gamma, const float* beta,

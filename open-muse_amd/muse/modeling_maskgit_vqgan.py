@@ -138,10 +138,16 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
 
     # ---- weight packing: [Cout,Cin,k,k] -> [Cout,k,k,Cin_pad] in the compute dtype ------------------------------------
     def set_compute_dtype(self, dtype):
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        """torch.float32: exact-f32 MFMA convolutions (bit-level parity mode); "bf16x3": f32 activations, convolutions as
+        3 bf16 MFMAs per product (f32-class, tighter than the TF32 the reference's cuDNN path uses by default);
+        torch.bfloat16: bf16 activations and weights."""
+        if dtype not in (torch.float32, torch.bfloat16, "bf16x3"):
+            raise ValueError('compute dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
         self.compute_dtype = dtype
         return self
+
+    def _act_dtype(self):
+        return torch.bfloat16 if self.compute_dtype == torch.bfloat16 else torch.float32
 
     def _apply(self, fn, recurse=True):
         self._packed = {}
@@ -152,7 +158,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     def _cpad(self, c, cd):
-        q = 8 if cd == torch.bfloat16 else 4
+        q = 4 if cd == torch.float32 else 8
         return (c + q - 1) // q * q
 
     def _w(self, conv: _Conv, cd):
@@ -167,12 +173,16 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
             wp = wp.contiguous()
             if cd == torch.bfloat16:
                 wp = ops.cast_to_bf16(wp)
+            elif cd == "bf16x3":
+                wp = ops.split_bf16(wp)
             hit = (wp, cp, cout, k, None if conv.bias is None else conv.bias.data.float().contiguous())
             self._packed[key] = hit
         return hit
 
     def _conv(self, x, conv, B, H, W, cd, residual=None, upsample=False):
         wp, cp, cout, k, bias = self._w(conv, cd)
+        if cd == "bf16x3":
+            return ops.conv2d_nhwc_split(x, wp[0], wp[1], B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
         return ops.conv2d_nhwc(x, wp, B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
 
     def _gn(self, x, norm: _Norm, B, HW, C):
@@ -200,7 +210,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         cd = self.compute_dtype
         enc = self.encoder
         B, C, H, W = pixel_values.shape
-        x = ops.nchw_to_nhwc(pixel_values.float(), cd, self._cpad(C, cd))
+        x = ops.nchw_to_nhwc(pixel_values.float(), self._act_dtype(), self._cpad(C, cd))
         h = self._conv(x, enc.conv_in, B, H, W, cd)
         nres = self.config.num_resolutions
         for lvl, down in enumerate(enc.down):
@@ -261,7 +271,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         self._check(quantized_states)
         B, C, H, W = quantized_states.shape
         cd = self.compute_dtype
-        zq = ops.nchw_to_nhwc(quantized_states.float(), cd, C)
+        zq = ops.nchw_to_nhwc(quantized_states.float(), self._act_dtype(), C)
         return self._decode_nhwc(zq, B, H, W)
 
     @torch.no_grad()
@@ -269,7 +279,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         self._check(codebook_indices)
         B, T = codebook_indices.shape
         side = int(math.sqrt(T))
-        zq = ops.gather_rows(self._codebook(), codebook_indices.contiguous().view(-1), self.compute_dtype)
+        zq = ops.gather_rows(self._codebook(), codebook_indices.contiguous().view(-1), self._act_dtype())
         return self._decode_nhwc(zq.view(B, side, side, -1), B, side, side)
 
     @torch.no_grad()

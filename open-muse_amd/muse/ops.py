@@ -350,6 +350,24 @@ def conv2d_nhwc(x, w, B, H, W, Cin, Cout, KS, bias=None, residual=None, upsample
     return out
 
 
+def split_bf16(w):
+    """f32 -> (hi, lo) bf16 with w ~= hi + lo (weights of the bf16x3 convolution; one-time packing)"""
+    hi = cast_to_bf16(w.contiguous())
+    lo = cast_to_bf16((w - cast_to_f32(hi)).contiguous())
+    return hi, lo
+
+
+def conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=None, residual=None, upsample=False):
+    """f32 NHWC convolution as 3 bf16 MFMAs per product (see muse_conv2d_nhwc_split)"""
+    require_gpu(x, w_hi, w_lo)
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
+    check(lib().muse_conv2d_nhwc_split(x.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(), ptr(bias), ptr(residual), out.data_ptr(),
+                                       B, H, W, Cin, Cout, KS, 1 if upsample else 0, stream()), "muse_conv2d_nhwc_split")
+    _prof_end(e0, "conv_bf16x3", 2.0 * B * H * W * Cout * KS * KS * Cin)
+    return out
+
+
 def groupnorm_silu_nhwc(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, silu=True):
     require_gpu(x, gamma, beta)
     y = torch.empty_like(x)

@@ -23,13 +23,14 @@ fi
 if [[ $STAGE == perf ]]; then
   timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider > $O/pytest_kernels.txt 2>&1
   echo "pytest exit $?" >> $O/pytest_kernels.txt; tail -15 $O/pytest_kernels.txt
-  for v in default bm256; do
+  for v in default; do
     if [[ $v == bm256 ]]; then export MUSE_BM256=1; else unset MUSE_BM256; fi
     timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/bench_$v.txt 2>&1; echo "exit $?" >> $O/bench_$v.txt
     tail -2 $O/bench_$v.txt | cut -c1-2600
   done
   unset MUSE_BM256
-  timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --vq-dtype bf16 > $O/bench_vqbf16.txt 2>&1; tail -1 $O/bench_vqbf16.txt | cut -c1-2600
+  timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --vq-dtype bf16x3 > $O/bench_vqx3.txt 2>&1; tail -1 $O/bench_vqx3.txt | cut -c1-2600
+  timeout 600 python -m pytest tests/test_gpu_models.py -m gpu -q --tb=short -p no:cacheprovider -k "vqgan" > $O/pytest_vq.txt 2>&1; tail -15 $O/pytest_vq.txt
 fi
 if [[ $STAGE == all || $STAGE == prof ]]; then
   rm -rf $O/prof

@@ -389,3 +389,30 @@ def test_gemm_split_k_wgrad(dtype):
     ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw2, False)
     assert rel_err(dw2, ref) < 1e-4
     assert ops.wgrad_splits(768, 768, 16448, torch.bfloat16) > 1
+
+
+@pytest.mark.parametrize("Cin,Cout,KS,ups,bias,res", [(32, 64, 3, False, False, False), (64, 32, 1, False, False, True),
+                                                       (8, 40, 3, False, True, False), (32, 32, 3, True, True, False),
+                                                       (128, 130, 3, False, True, True)])
+def test_conv2d_split_bf16x3(Cin, Cout, KS, ups, bias, res):
+    """f32 convolution as 3 bf16 MFMAs per product: error bound 2^-16 per product -> 3e-5 relative on the output"""
+    ops = _ops()
+    B, H, W = 2, 12, 10
+    ih, iw = (H // 2, W // 2) if ups else (H, W)
+    x = rnd((B, Cin, ih, iw), 170)
+    w = rnd((Cout, Cin, KS, KS), 171) / math.sqrt(Cin * KS * KS)
+    bvec = rnd((Cout,), 172) if bias else None
+    rr = rnd((B, Cout, H, W), 173) if res else None
+    xr = x.double()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    p = KS - 1
+    ref = F.conv2d(F.pad(xr, [p // 2, p - p // 2, p // 2, p - p // 2]), w.double(), bvec.double() if bias else None)
+    if res:
+        ref = ref + rr.double()
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w_hi, w_lo = ops.split_bf16(w.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert rel_err(w_hi.float() + w_lo.float(), w.permute(0, 2, 3, 1)) < 2e-5
+    out = ops.conv2d_nhwc_split(xn, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=bvec.to(DEV) if bias else None,
+                                residual=rr.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None, upsample=ups)
+    assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < 3e-5, (Cin, Cout, KS, ups)

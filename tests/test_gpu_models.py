@@ -186,6 +186,16 @@ def test_vqgan_f16_256_vs_oracle():
     assert maxrel(v.decode_code(idx.to(DEV)), rec) < 1e-4
     # encode -> decode_code round trip is idempotent on the token grid: re-decoding the same codes is bit-identical
     assert torch.equal(v.decode_code(idx.to(DEV)), v.decode_code(idx.to(DEV)))
+    # bf16x3: f32-class convolutions on the bf16 matrix cores -> z within 1e-4, token indices equal up to f32 near-ties
+    v.set_compute_dtype("bf16x3")
+    z3, _ = v._encode_nhwc(px.to(DEV))
+    assert maxrel(z3.view(1, 16, 16, 256).permute(0, 3, 1, 2), z) < 1e-4
+    idx3 = v.get_code(px.to(DEV)).cpu()
+    for b, t in (idx3 != idx).nonzero().tolist():
+        d = dist[t]
+        assert abs(float(d[idx3[b, t]]) - float(d[idx[b, t]])) < 1e-4 * abs(float(d[idx[b, t]]))
+    assert int((idx3 != idx).sum()) <= 2
+    assert maxrel(v.decode_code(idx.to(DEV)), rec) < 2e-4
     v.set_compute_dtype(torch.bfloat16)
     idx_bf = v.get_code(px.to(DEV)).cpu()
     print("bf16 VQGAN token agreement with f32 oracle:", float((idx_bf == idx).float().mean()))
