@@ -145,7 +145,7 @@ def wgrad_splits(M, N, K, dtype):
     bk = 64 if dtype == torch.bfloat16 else 32
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     nk = (K + bk - 1) // bk
-    return max(1, min((512 + tiles - 1) // tiles, nk // 4, 64))
+    return max(1, min((768 + tiles - 1) // tiles, nk // 4, 64))   # ~3 resident blocks per CU (256 CUs)
 
 
 def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):

@@ -1,0 +1,49 @@
+"""micro-benchmark of the MFMA GEMM variants on the shapes of the config-B train step (for rocprofv3 --pmc runs)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+import torch
+from muse import ops
+
+dev = "cuda"
+T, H, I = 16448, 768, 3072
+reps = int(os.environ.get("REPS", "10"))
+which = os.environ.get("WHICH", "nn,nt,tt,conv").split(",")
+x = torch.randn(T, H, device=dev).to(torch.bfloat16)
+w01 = (torch.randn(2 * I, H, device=dev) * 0.03).to(torch.bfloat16)
+ab = torch.empty(T, 2 * I, dtype=torch.bfloat16, device=dev)
+dab = torch.randn(T, 2 * I, device=dev).to(torch.bfloat16)
+dx = torch.empty(T, H, dtype=torch.bfloat16, device=dev)
+dw = torch.zeros(2 * I, H, device=dev)
+
+
+def timeit(name, fn, flops):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"{name}: {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s", flush=True)
+
+
+if "nn" in which:
+    timeit("linear fwd  [16448x768]x[6144x768]^T", lambda: ops.linear(x, w01, out=ab), 2.0 * T * H * 2 * I)
+if "nt" in which:
+    timeit("linear dgrad [16448x6144]x[6144x768]", lambda: ops.linear_dgrad(dab, w01, out=dx), 2.0 * T * H * 2 * I)
+if "tt" in which:
+    timeit("linear wgrad [6144x16448]x[16448x768]", lambda: ops.linear_wgrad(dab, x, dw, True), 2.0 * T * H * 2 * I)
+if "conv" in which:
+    B, Hh, Ww, C = 64, 128, 128, 128
+    xi = torch.randn(B, Hh, Ww, C, device=dev)
+    w = torch.randn(C, 3, 3, C, device=dev) * 0.03
+    wh, wl = ops.split_bf16(w)
+    fl = 2.0 * B * Hh * Ww * C * 9 * C
+    timeit("conv bf16x3 64x128x128x128 3x3", lambda: ops.conv2d_nhwc_split(xi, wh, wl, B, Hh, Ww, C, C, 3), fl)
+    timeit("conv f32    64x128x128x128 3x3", lambda: ops.conv2d_nhwc(xi, w, B, Hh, Ww, C, C, 3), fl)
+    xb, wb = xi.to(torch.bfloat16), w.to(torch.bfloat16)
+    timeit("conv bf16   64x128x128x128 3x3", lambda: ops.conv2d_nhwc(xb, wb, B, Hh, Ww, C, C, 3), fl)
