@@ -54,8 +54,10 @@ typedef struct muse_gemm_desc {
   float alpha;
   int32_t accumulate; /* C += ...                                                          */
   int32_t act;        /* 0 none, 1 erf-GELU (F.gelu)                                       */
-  int32_t split_k;    /* > 1: K is cut into that many slices, each added to C (f32, no epilogue extras) with
-                         hardware f32 atomics; the caller pre-initialises C (zeros, or the value to accumulate into) */
+  int32_t split_k;    /* > 1: K is cut into that many slices (f32 output, no epilogue extras)                    */
+  int64_t split_stride; /* != 0: slice s stores its partial result at C + s*split_stride elements (workspace, plain
+                         stores; reduce with muse_sum_slices - deterministic); == 0: slices are added to C with hardware
+                         f32 atomics, the caller pre-initialises C (zeros, or the value to accumulate into)          */
 } muse_gemm_desc;
 int muse_gemm(const muse_gemm_desc* d, void* stream);
 
@@ -125,6 +127,8 @@ int muse_cross_entropy_bwd(const void* logits, int32_t dtype, const int64_t* lab
  * training/train_maskgit_imagenet.py:242-261,438); optionally refreshes the bf16 compute copy of the weights. */
 int muse_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+/* out[i] (+)= sum over s < nslices of ws[s*stride + i]: reduction of split-K partial results (n, stride % 4 == 0) */
+int muse_sum_slices(const float* ws, float* out, int32_t nslices, int64_t n, int64_t stride, int32_t accumulate, void* stream);
 int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 

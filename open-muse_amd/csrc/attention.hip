@@ -69,15 +69,15 @@ __device__ __forceinline__ bf16x8 frag_seq(const unsigned char* img, int r0, int
   return u.v;
 }
 __device__ __forceinline__ bf16x8 pack8(const float (&lo)[4], const float (&hi)[4]) {
-  union { unsigned short s[8]; bf16x8 v; } u;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { u.s[j] = f32_to_bf16(lo[j]); u.s[4 + j] = f32_to_bf16(hi[j]); }
+  union { uint32_t w[4]; bf16x8 v; } u;
+  u.w[0] = pack2_bf16(lo[0], lo[1]); u.w[1] = pack2_bf16(lo[2], lo[3]);
+  u.w[2] = pack2_bf16(hi[0], hi[1]); u.w[3] = pack2_bf16(hi[2], hi[3]);
   return u.v;
 }
 __device__ __forceinline__ void store4_bf16(bf16_t* p, const f32x4& v, float scale) {
   u32x2 t;
-  t[0] = (uint32_t)f32_to_bf16(v[0] * scale) | ((uint32_t)f32_to_bf16(v[1] * scale) << 16);
-  t[1] = (uint32_t)f32_to_bf16(v[2] * scale) | ((uint32_t)f32_to_bf16(v[3] * scale) << 16);
+  t[0] = pack2_bf16(v[0] * scale, v[1] * scale);
+  t[1] = pack2_bf16(v[2] * scale, v[3] * scale);
   *(u32x2*)p = t;
 }
 

@@ -14,12 +14,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserving (same rounding torch uses for .to(bfloat16))
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round-to-nearest-even (hardware v_cvt_pk_bf16_f32 on gfx950; same rounding torch uses for .to(bfloat16))
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){lo, hi}, bf16x2_));
 }
 
 template <typename T> struct Elem;

@@ -12,15 +12,11 @@
 #include "../../include/muse_hip.h"
 
 __device__ __forceinline__ void split4(const u32x4& v, u32x2& hi, u32x2& lo) {
-  unsigned short h[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float x = __uint_as_float(v[j]);
-    h[j] = f32_to_bf16(x);
-    l[j] = f32_to_bf16(x - bf16_to_f32(h[j]));
-  }
-  hi[0] = (uint32_t)h[0] | ((uint32_t)h[1] << 16); hi[1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-  lo[0] = (uint32_t)l[0] | ((uint32_t)l[1] << 16); lo[1] = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+  const float x0 = __uint_as_float(v[0]), x1 = __uint_as_float(v[1]), x2 = __uint_as_float(v[2]), x3 = __uint_as_float(v[3]);
+  hi[0] = pack2_bf16(x0, x1);
+  hi[1] = pack2_bf16(x2, x3);
+  lo[0] = pack2_bf16(x0 - __uint_as_float(hi[0] << 16), x1 - __uint_as_float(hi[0] & 0xffff0000u));
+  lo[1] = pack2_bf16(x2 - __uint_as_float(hi[1] << 16), x3 - __uint_as_float(hi[1] & 0xffff0000u));
 }
 
 struct SplitParams {
@@ -158,7 +154,7 @@ extern "C" int muse_conv2d_nhwc_split(const float* in, const void* w_hi, const v
   p.M = batch * H * W; p.N = Cout; p.K = KS * KS * Cin;
   p.lda = 0; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
   p.zdiv = 1; p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
-  p.alpha = 1.0f; p.accumulate = 0; p.act = 0; p.split_k = 1;
+  p.alpha = 1.0f; p.accumulate = 0; p.act = 0; p.split_k = 1; p.split_stride = 0;
   p.cH = H; p.cW = W; p.cCin = Cin; p.cKS = KS; p.cUps = upsample ? 1 : 0;
   p.cCinShift = -1;
   if ((Cin & (Cin - 1)) == 0) { int sh = 0; while ((1 << sh) < Cin) ++sh; p.cCinShift = sh; }

@@ -32,6 +32,7 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
   p.alpha = d->alpha; p.accumulate = d->accumulate; p.act = d->act;
   p.split_k = d->split_k > 1 ? d->split_k : 1;
+  p.split_stride = p.split_k > 1 ? d->split_stride : 0;
   if (p.split_k > 1 && (d->out_dtype != MUSE_F32 || d->bias || d->rowvec || d->residual || d->act)) return MUSE_ERR_BAD_ARG;
   p.cH = p.cW = p.cCin = p.cKS = p.cUps = 0; p.cCinShift = -1;
   const int batch = d->batch > 0 ? d->batch : 1;

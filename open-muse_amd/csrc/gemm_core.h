@@ -33,7 +33,9 @@ struct GemmParams {
   float alpha;
   int accumulate;  // C += result
   int act;         // 0 none, 1 erf-GELU
-  int split_k;     // > 1: blockIdx.y selects a K slice, partial results are added to C with f32 atomics (C pre-initialised)
+  int split_k;     // > 1: blockIdx.y selects a K slice
+  long split_stride;  // != 0: slice y stores its partial tile to C + y*split_stride (plain stores, reduced by
+                      // muse_sum_slices); == 0: slices are added to C with f32 atomics (C pre-initialised)
   // implicit-GEMM convolution geometry (conv A loader only)
   int cH, cW, cCin, cKS, cUps, cCinShift;
 };
@@ -61,39 +63,59 @@ template <typename T, int ROWS> struct TileBytes {
 __device__ __forceinline__ int km_phys_row_bf16(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // ---------------------------------------------------------------------------------------------------------------
-// global -> register tile loaders.  Each thread owns NCH 16-byte chunks of the 128 x BK operand tile.
+// global -> register tile loaders.  Each thread owns NCH 16-byte chunks of the ROWS x BK operand tile.
+// Loads are buffer_load_dwordx4 through a per-block (wave-uniform, SGPR) buffer descriptor: the chunk's byte offset inside
+// the operand lives in one VGPR computed once, the K advance is a scalar offset, and an invalid chunk (row outside the
+// matrix, k beyond K, conv tap in the zero padding) is redirected to an out-of-range offset, which the hardware
+// returns as zeros - no exec-mask branches and no 64-bit address arithmetic in the K loop.
 // ---------------------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+}
+
 template <typename T, int LAYOUT, int ROWS, int NT>
 struct PlainLoader {
   using Cfg = TileCfg<T>;
   static constexpr int NCH = ROWS * Cfg::BK * (int)sizeof(T) / 16 / NT;  // 16-byte chunks per thread
-  const T* base;
-  long ld;
-  int R, K, r0;
-  __device__ __forceinline__ void init(const void* ptr, long ld_, int R_, int K_, int r0_, const GemmParams&) {
-    base = (const T*)ptr; ld = ld_; R = R_; K = K_; r0 = r0_;
+  static constexpr int CPR = LAYOUT == 0 ? Cfg::BK / Cfg::CH : ROWS / Cfg::CH;
+  rsrc_t rs;
+  unsigned voff[NCH];  // byte offset of the chunk at k0 = 0 (or `oob` for a row outside the matrix)
+  unsigned oob, kstep;
+  int K;
+  __device__ __forceinline__ void init(const void* ptr, long ld, int R, int K_, int r0, const GemmParams&) {
+    constexpr int E = (int)sizeof(T);
+    K = K_;
+    const long cols = LAYOUT == 0 ? K : R, rows = LAYOUT == 0 ? R : K;
+    const unsigned bytes = (unsigned)(((rows - 1) * ld + (cols + Cfg::CH - 1) / Cfg::CH * Cfg::CH) * E);
+    rs = make_rsrc(ptr, bytes);
+    oob = (bytes + 15u) & ~15u;
+    kstep = LAYOUT == 0 ? (unsigned)E : (unsigned)(ld * E);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = threadIdx.x + NT * i;
+      if (LAYOUT == 0) {
+        const int row = r0 + c / CPR, col = (c % CPR) * Cfg::CH;
+        voff[i] = row < R ? (unsigned)(((long)row * ld + col) * E) : oob;
+      } else {
+        const int kr = c / CPR, r = r0 + (c % CPR) * Cfg::CH;
+        voff[i] = r < R ? (unsigned)(((long)kr * ld + r) * E) : oob;
+      }
+    }
   }
   __device__ __forceinline__ u32x4 load(int i, int k0) const {
     const int c = threadIdx.x + NT * i;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (LAYOUT == 0) {
-      constexpr int CPR = Cfg::BK / Cfg::CH;
-      const int row = r0 + c / CPR, k = k0 + (c % CPR) * Cfg::CH;
-      if (row < R && k < K) v = *(const u32x4*)(base + (long)row * ld + k);
-    } else {
-      constexpr int CPR = ROWS / Cfg::CH;
-      const int kr = k0 + c / CPR, r = r0 + (c % CPR) * Cfg::CH;
-      if (kr < K && r < R) v = *(const u32x4*)(base + (long)kr * ld + r);
-    }
-    return v;
+    const int kk = k0 + (LAYOUT == 0 ? (c % CPR) * Cfg::CH : c / CPR);  // first k of this chunk
+    return buf_load16(rs, kk < K ? voff[i] : oob, (unsigned)k0 * kstep);
   }
   static __device__ __forceinline__ int lds_off(int i) {
     const int c = threadIdx.x + NT * i;
     if (LAYOUT == 0) {
-      constexpr int CPR = Cfg::BK / Cfg::CH;
       return (c / CPR) * Cfg::KC_STRIDE + (c % CPR) * 16;
     } else {
-      constexpr int CPR = ROWS / Cfg::CH;
       int kr = c / CPR;
       if (sizeof(T) == 2) kr = km_phys_row_bf16(kr);
       return kr * KmCfg<T, ROWS>::STRIDE + (c % CPR) * 16;
@@ -103,44 +125,60 @@ struct PlainLoader {
 
 // implicit-GEMM A operand of an NHWC stride-1 SAME convolution:  m = (b, y, x),  k = (ky, kx, cin)
 // optional nearest x2 upsample of the input folded into the index math (decoder upsample_conv).
+// Per chunk: `center` = byte offset of the pixel's own (0,0)-tap data, `tapmask` bit t = tap t lies inside the image.
 template <typename T, int ROWS, int NT>
 struct ConvLoader {
   using Cfg = TileCfg<T>;
   static constexpr int CPR = Cfg::BK / Cfg::CH;
   static constexpr int NCH = ROWS * Cfg::BK * (int)sizeof(T) / 16 / NT;
-  const T* base;
-  int K, H, W, Cin, KS, ups, cshift;
-  int py[NCH], px[NCH];
-  long pb[NCH];
-  bool pv[NCH];
+  rsrc_t rs;
+  unsigned center[NCH], tapmask[NCH], pyx[NCH];
+  unsigned oob;
+  int W, iw, Cin, KS, ups, cshift;
   __device__ __forceinline__ void init(const void* ptr, long, int R_, int K_, int r0_, const GemmParams& p) {
-    base = (const T*)ptr; K = K_; H = p.cH; W = p.cW; Cin = p.cCin; KS = p.cKS; ups = p.cUps; cshift = p.cCinShift;
-    const int ih = ups ? (H >> 1) : H, iw = ups ? (W >> 1) : W;
+    constexpr int E = (int)sizeof(T);
+    const int H = p.cH;
+    W = p.cW; Cin = p.cCin; KS = p.cKS; ups = p.cUps; cshift = p.cCinShift;
+    const int ih = ups ? (H >> 1) : H;
+    iw = ups ? (W >> 1) : W;
+    const unsigned bytes = (unsigned)((long)(R_ / (H * W)) * ih * iw * Cin * E);
+    rs = make_rsrc(ptr, bytes);
+    oob = (bytes + 15u) & ~15u;
+    const int pad = (KS - 1) >> 1;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = threadIdx.x + NT * i;
       const int m = r0_ + c / CPR;
-      pv[i] = m < R_;
       const int b = m / (H * W), rem = m - b * (H * W);
-      py[i] = rem / W; px[i] = rem - py[i] * W;
-      pb[i] = (long)b * ih * iw;
+      const int y = rem / W, x = rem - y * W;
+      unsigned mask = 0;
+      if (m < R_) {
+        for (int t = 0; t < KS * KS; ++t) {
+          const int ky = t / KS, kx = t - ky * KS;
+          const int iy = y + ky - pad, ix = x + kx - pad;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) mask |= 1u << t;
+        }
+      }
+      tapmask[i] = mask;
+      pyx[i] = (unsigned)y | ((unsigned)x << 16);
+      center[i] = ups ? (unsigned)(b * ih * iw) : (unsigned)(((long)(b * H + y) * W + x) * Cin * E);
     }
   }
   __device__ __forceinline__ u32x4 load(int i, int k0) const {
+    constexpr int E = (int)sizeof(T);
     const int c = threadIdx.x + NT * i;
     const int k = k0 + (c % CPR) * Cfg::CH;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (pv[i] && k < K) {
-      const int kpos = cshift >= 0 ? (k >> cshift) : (k / Cin), ci = k - kpos * Cin;
-      const int ky = KS == 3 ? ((kpos * 11) >> 5) : 0, kx = kpos - ky * KS, pad = (KS - 1) >> 1;  // kpos < 9
-      int iy = py[i] + ky - pad, ix = px[i] + kx - pad;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-        int iw = W;
-        if (ups) { iy >>= 1; ix >>= 1; iw = W >> 1; }
-        v = *(const u32x4*)(base + (pb[i] + (long)iy * iw + ix) * Cin + ci);
-      }
+    const int kpos = cshift >= 0 ? (k >> cshift) : (k / Cin), ci = k - kpos * Cin;
+    const int ky = KS == 3 ? ((kpos * 11) >> 5) : 0, kx = kpos - ky * KS, pad = (KS - 1) >> 1;  // valid taps: kpos < 9
+    const bool ok = kpos < 9 && ((tapmask[i] >> kpos) & 1u);
+    unsigned off;
+    if (!ups) {
+      off = center[i] + (unsigned)((((ky - pad) * W + (kx - pad)) * Cin + ci) * E);
+    } else {
+      const int iy = ((int)(pyx[i] & 0xffffu) + ky - pad) >> 1, ix = ((int)(pyx[i] >> 16) + kx - pad) >> 1;
+      off = (unsigned)(((long)(center[i] + (unsigned)(iy * iw + ix)) * Cin + ci) * E);
     }
-    return v;
+    return buf_load16(rs, ok ? off : oob, 0u);
   }
   static __device__ __forceinline__ int lds_off(int i) {
     const int c = threadIdx.x + NT * i;
@@ -203,20 +241,23 @@ template <> struct OutVec<bf16_t> {
   }
   static __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
     u32x2 t;
-    t[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    t[0] = pack2_bf16(v[0], v[1]);
+    t[1] = pack2_bf16(v[2], v[3]);
     *(u32x2*)p = t;
   }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, typename TC, int AL, int BL, int BM, typename ALoader, typename BLoader>
+template <typename T, typename TC, int AL, int BL, int BM, int NSTAGE, typename ALoader, typename BLoader>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(GemmParams p) {
   using Cfg = TileCfg<T>;
   constexpr int TA_BYTES = TileBytes<T, BM>::VALUE, TB_BYTES = TileBytes<T, 128>::VALUE;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[TA_BYTES + TB_BYTES];
+  // bf16: two LDS stages + two register stages (K-tile t+2 in flight while t computes and t+1 is written to LDS);
+  // f32: one stage (its MFMA phase is 16x longer per byte and the tiles are twice as large).
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* tA = smem;
   unsigned char* tB = smem + TA_BYTES;
+  constexpr int STAGE_BYTES = TA_BYTES + TB_BYTES;
 
   // XCD-aware tile order: blocks b, b+8, b+16, ... (one XCD, one L2) get a contiguous range of tile ids ...
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + 127) >> 7, ntiles = ntm * ntn;
@@ -232,10 +273,19 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(GemmParams p) {
   const int z = blockIdx.z, zq = z / p.zdiv, zr = z - zq * p.zdiv;
   const T* Ap = (const T*)p.A + zq * p.sA0 + zr * p.sA1;
   const T* Bp = (const T*)p.B + zq * p.sB0 + zr * p.sB1;
-  TC* Cp = (TC*)p.C + zq * p.sC0 + zr * p.sC1;
+  TC* Cp = (TC*)p.C + zq * p.sC0 + zr * p.sC1 + (p.split_k > 1 ? (long)blockIdx.y * p.split_stride : 0L);
+  const bool atomic_out = p.split_k > 1 && p.split_stride == 0;
 
-  ALoader la; la.init(Ap, p.lda, p.M, p.K, m0, p);
-  BLoader lb; lb.init(Bp, p.ldb, p.N, p.K, n0, p);
+  int nk = (p.K + Cfg::BK - 1) / Cfg::BK, kt0 = 0;
+  if (p.split_k > 1) {
+    const int per = (nk + p.split_k - 1) / p.split_k;
+    kt0 = blockIdx.y * per;
+    nk = min(nk, kt0 + per);
+    if (kt0 >= nk) return;
+  }
+  const int kend = min(p.K, nk * Cfg::BK);  // K range of this block's slice: tiles past it load zeros
+  ALoader la; la.init(Ap, p.lda, p.M, kend, m0, p);
+  BLoader lb; lb.init(Bp, p.ldb, p.N, kend, n0, p);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;  // BM/64 x 2 waves, 64 x 64 each
@@ -246,40 +296,15 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[ALoader::NCH], rb[BLoader::NCH];
-  int nk = (p.K + Cfg::BK - 1) / Cfg::BK, kt0 = 0;
-  if (p.split_k > 1) {
-    const int per = (nk + p.split_k - 1) / p.split_k;
-    kt0 = blockIdx.y * per;
-    nk = min(nk, kt0 + per);
-    if (kt0 >= nk) return;
-  }
-#pragma unroll
-  for (int i = 0; i < ALoader::NCH; ++i) ra[i] = la.load(i, kt0 * Cfg::BK);
-#pragma unroll
-  for (int i = 0; i < BLoader::NCH; ++i) rb[i] = lb.load(i, kt0 * Cfg::BK);
-#pragma unroll
-  for (int i = 0; i < ALoader::NCH; ++i) *(u32x4*)(tA + ALoader::lds_off(i)) = ra[i];
-#pragma unroll
-  for (int i = 0; i < BLoader::NCH; ++i) *(u32x4*)(tB + BLoader::lds_off(i)) = rb[i];
-  __syncthreads();
-
-  for (int kt = kt0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < ALoader::NCH; ++i) ra[i] = la.load(i, (kt + 1) * Cfg::BK);
-#pragma unroll
-      for (int i = 0; i < BLoader::NCH; ++i) rb[i] = lb.load(i, (kt + 1) * Cfg::BK);
-    }
+  auto compute = [&](const unsigned char* cA, const unsigned char* cB) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 af[4], bf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          af[i] = frag_bf16<AL, BM>(tA, wr + i * 16, ks, lane);
-          bf[i] = frag_bf16<BL, 128>(tB, wc + i * 16, ks, lane);
+          af[i] = frag_bf16<AL, BM>(cA, wr + i * 16, ks, lane);
+          bf[i] = frag_bf16<BL, 128>(cB, wc + i * 16, ks, lane);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -293,8 +318,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(GemmParams p) {
         f32x4 af[4], bf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          af[i] = frag_f32<AL, BM>(tA, wr + i * 16, ks, lane);
-          bf[i] = frag_f32<BL, 128>(tB, wc + i * 16, ks, lane);
+          af[i] = frag_f32<AL, BM>(cA, wr + i * 16, ks, lane);
+          bf[i] = frag_f32<BL, 128>(cB, wc + i * 16, ks, lane);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -305,17 +330,159 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(GemmParams p) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
       }
     }
+  };
+
+  if constexpr (NSTAGE == 1) {
+    u32x4 ra[ALoader::NCH], rb[BLoader::NCH];
+#pragma unroll
+    for (int i = 0; i < ALoader::NCH; ++i) ra[i] = la.load(i, kt0 * Cfg::BK);
+#pragma unroll
+    for (int i = 0; i < BLoader::NCH; ++i) rb[i] = lb.load(i, kt0 * Cfg::BK);
+#pragma unroll
+    for (int i = 0; i < ALoader::NCH; ++i) *(u32x4*)(tA + ALoader::lds_off(i)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BLoader::NCH; ++i) *(u32x4*)(tB + BLoader::lds_off(i)) = rb[i];
     __syncthreads();
-    if (more) {
+    for (int kt = kt0; kt < nk; ++kt) {
+      const bool more = (kt + 1) < nk;
+      if (more) {
 #pragma unroll
-      for (int i = 0; i < ALoader::NCH; ++i) *(u32x4*)(tA + ALoader::lds_off(i)) = ra[i];
+        for (int i = 0; i < ALoader::NCH; ++i) ra[i] = la.load(i, (kt + 1) * Cfg::BK);
 #pragma unroll
-      for (int i = 0; i < BLoader::NCH; ++i) *(u32x4*)(tB + BLoader::lds_off(i)) = rb[i];
+        for (int i = 0; i < BLoader::NCH; ++i) rb[i] = lb.load(i, (kt + 1) * Cfg::BK);
+      }
+      compute(tA, tB);
+      __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < ALoader::NCH; ++i) *(u32x4*)(tA + ALoader::lds_off(i)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BLoader::NCH; ++i) *(u32x4*)(tB + BLoader::lds_off(i)) = rb[i];
+        __syncthreads();
+      }
+    }
+  } else {
+    // register sets r0 / r1 and LDS stages 0 / 1 alternate; the loop is unrolled by two so every index is static.
+    u32x4 ra0[ALoader::NCH], rb0[BLoader::NCH], ra1[ALoader::NCH], rb1[BLoader::NCH];
+    unsigned char* tA1 = tA + STAGE_BYTES;
+    unsigned char* tB1 = tB + STAGE_BYTES;
+#define MUSE_FETCH(RA, RB, KT)                                                          \
+  {                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < ALoader::NCH; ++i) RA[i] = la.load(i, (KT) * Cfg::BK); \
+    _Pragma("unroll") for (int i = 0; i < BLoader::NCH; ++i) RB[i] = lb.load(i, (KT) * Cfg::BK); \
+  }
+#define MUSE_STAGE(RA, RB, DA, DB)                                                      \
+  {                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < ALoader::NCH; ++i) *(u32x4*)((DA) + ALoader::lds_off(i)) = RA[i]; \
+    _Pragma("unroll") for (int i = 0; i < BLoader::NCH; ++i) *(u32x4*)((DB) + BLoader::lds_off(i)) = RB[i]; \
+  }
+    // The tile count is rounded up to even: a tile beyond K is all out-of-range chunks (zeros, no memory traffic), so the
+    // loop body is two symmetric, unconditional half-steps.
+    const int nk2 = kt0 + ((nk - kt0 + 1) & ~1);
+    MUSE_FETCH(ra0, rb0, kt0)
+    MUSE_FETCH(ra1, rb1, kt0 + 1)
+    MUSE_STAGE(ra0, rb0, tA, tB)
+    __syncthreads();
+    for (int kt = kt0; kt < nk2; kt += 2) {
+      // even half: compute stage 0 (tile kt); r1 holds tile kt+1 (issued one whole half-step ago); refill r0 with kt+2
+      MUSE_FETCH(ra0, rb0, kt + 2)
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch at the top of the half-step (a full step of latency cover)
+      compute(tA, tB);
+      MUSE_STAGE(ra1, rb1, tA1, tB1)
+      __syncthreads();
+      // odd half: compute stage 1 (tile kt+1); r0 holds tile kt+2; refill r1 with kt+3
+      MUSE_FETCH(ra1, rb1, kt + 3)
+      __builtin_amdgcn_sched_barrier(0);
+      compute(tA1, tB1);
+      MUSE_STAGE(ra0, rb0, tA, tB)
       __syncthreads();
     }
+#undef MUSE_FETCH
+#undef MUSE_STAGE
   }
 
   // ---- epilogue: lane holds C[m][n..n+3], m = m0+wr+16i+(lane&15), n = n0+wc+16j+4*(lane>>4) ----
+  // Fast path: the C tile goes through LDS (free now) so that global stores are whole 16-byte chunks of contiguous rows
+  // (a wave writes 1 KiB of full lines per instruction instead of sixteen 32-byte row fragments); residual / accumulate
+  // operands are read the same way.  Needs 16-byte-aligned rows; anything else takes the direct path below.
+  if constexpr (BM == 128) {
+    constexpr int EPC = 16 / (int)sizeof(TC);               // elements per 16-byte chunk
+    constexpr int CST = 128 * (int)sizeof(TC) + 16;         // LDS row stride of the staged tile
+    const bool fast = !atomic_out && (p.N % EPC) == 0 && (p.ldc % EPC) == 0 && ((((uintptr_t)Cp) & 15) == 0) &&
+                      (p.residual == nullptr || (((p.ldr % EPC) == 0) && ((((uintptr_t)p.residual) & 15) == 0)));
+    if (fast) {
+      // f32 tiles are staged 64 rows at a time so the epilogue never needs more LDS than the operand stages did
+      constexpr int NH = sizeof(TC) == 4 ? 2 : 1, RPP = 128 / NH;  // passes, rows per pass
+      constexpr int CPRo = 128 / EPC;                               // 16-byte chunks per tile row
+      const TC* Rq = (const TC*)p.residual;
+#pragma unroll
+      for (int half = 0; half < NH; ++half) {
+        __syncthreads();  // operand stages (first pass) / previous staged rows (second pass) are no longer read
+        if (wr / RPP == half) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ml = wr + i * 16 + (lane & 15);
+            const float rv = (p.rowvec && (m0 + ml) < p.M) ? p.rowvec[m0 + ml] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int nl = wc + j * 16 + 4 * (lane >> 4);
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float add = rv;
+                if (p.bias && (n0 + nl + r) < p.N) add += p.bias[n0 + nl + r];
+                float x = p.alpha * acc[i][j][r] + add;
+                if (p.act == 1) x = gelu_erf(x);
+                v[r] = x;
+              }
+              OutVec<TC>::store4((TC*)(smem + (ml - half * RPP) * CST) + nl, v);
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (RPP * CPRo) / 256; ++it) {
+          const int c = threadIdx.x + 256 * it;
+          const int row = c / CPRo, col = (c % CPRo) * EPC;
+          const int m = m0 + half * RPP + row, n = n0 + col;
+          if (m < p.M && n < p.N) {
+            u32x4 w = *(const u32x4*)(smem + row * CST + col * (int)sizeof(TC));
+            if (Rq || p.accumulate) {
+              float o[EPC];
+              if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __uint_as_float(w[e]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+              }
+              auto add16 = [&](const TC* src) {
+                const u32x4 t = *(const u32x4*)src;
+                if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) o[e] += __uint_as_float(t[e]);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) { o[2 * e] += __uint_as_float(t[e] << 16); o[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
+                }
+              };
+              if (Rq) add16(Rq + (long)m * p.ldr + n);
+              if (p.accumulate) add16(Cp + (long)m * p.ldc + n);
+              if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(o[e]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = pack2_bf16(o[2 * e], o[2 * e + 1]);
+              }
+            }
+            *(u32x4*)(Cp + (long)m * p.ldc + n) = w;
+          }
+        }
+      }
+      return;
+    }
+  }
   const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)Cp) & 15) == 0) &&
                       (p.residual == nullptr || (((p.ldr & 3) == 0) && ((((uintptr_t)p.residual) & 15) == 0)));
   const TC* Rp = (const TC*)p.residual;
@@ -339,7 +506,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(GemmParams p) {
       }
       TC* cptr = Cp + (long)m * p.ldc + n;
       if constexpr (sizeof(TC) == 4) {
-        if (p.split_k > 1) {  // partial sum of one K slice: hardware f32 atomics straight into C
+        if (atomic_out) {  // partial sum of one K slice: hardware f32 atomics straight into C
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if ((n + r) < p.N) unsafeAtomicAdd((float*)cptr + r, v[r]);
@@ -365,13 +532,38 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(GemmParams p) {
   }
 }
 
+template <typename T, typename TC, int AL, int BL, int BM, int NSTAGE, typename ALoader, typename BLoader>
+static inline int launch_gemm_st(const GemmParams& p, int batch, hipStream_t stream) {
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + 127) / 128;
+  dim3 grid(ntm * ntn, p.split_k > 1 ? p.split_k : 1, batch);
+  constexpr size_t tiles = (size_t)NSTAGE * (TileBytes<T, BM>::VALUE + TileBytes<T, 128>::VALUE);
+  constexpr size_t ctile = BM == 128 ? (size_t)(sizeof(TC) == 4 ? 64 : 128) * (128 * sizeof(TC) + 16) : 0;  // staged C rows
+  constexpr size_t lds = tiles > ctile ? tiles : ctile;
+  auto kern = gemm_kernel<T, TC, AL, BL, BM, NSTAGE, ALoader, BLoader>;
+  static bool attr_set = false;  // one flag per template instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(BM * 2), lds, stream, p);
+  return (int)hipGetLastError();
+}
+
+// bf16 operands: the k-contiguous x k-contiguous kernel runs one stage (3 blocks per CU beat the deeper prefetch:
+// 775 vs 650 TFLOP/s on [16448x768]x[6144x768]^T), kernels with a transposing (tr-read) operand run 2 LDS + 2 register
+// stages (592 vs 568 dgrad, 467 vs 432 wgrad).  MUSE_GEMM_STAGES=1|2 forces one choice.  f32 operands: always one stage.
+static inline int gemm_stages(int al, int bl) {
+  static const int st = [] { const char* e = getenv("MUSE_GEMM_STAGES"); return e ? (e[0] == '1' ? 1 : 2) : 0; }();
+  if (st) return st;
+  return (al == 0 && bl == 0) ? 1 : 2;
+}
 template <typename T, typename TC, int AL, int BL, int BM, typename ALoader, typename BLoader>
 static inline int launch_gemm(const GemmParams& p, int batch, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || batch <= 0) return 0;
-  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + 127) / 128;
-  dim3 grid(ntm * ntn, p.split_k > 1 ? p.split_k : 1, batch);
-  hipLaunchKernelGGL((gemm_kernel<T, TC, AL, BL, BM, ALoader, BLoader>), grid, dim3(BM * 2), 0, stream, p);
-  return (int)hipGetLastError();
+  if constexpr (sizeof(T) == 2) {
+    if (gemm_stages(AL, BL) == 2) return launch_gemm_st<T, TC, AL, BL, BM, 2, ALoader, BLoader>(p, batch, stream);
+  }
+  return launch_gemm_st<T, TC, AL, BL, BM, 1, ALoader, BLoader>(p, batch, stream);
 }
 
 // big-M problems use the 256 x 128 tile (8 waves): 25 % fewer operand bytes per flop through L2 / LDS

@@ -20,8 +20,8 @@ template <> struct V4<bf16_t> {
   }
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
     u32x2 t;
-    t[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    t[0] = pack2_bf16(v[0], v[1]);
+    t[1] = pack2_bf16(v[2], v[3]);
     *(u32x2*)p = t;
   }
 };
@@ -672,6 +672,29 @@ extern "C" int muse_mask_sample(const int64_t* tokens, const int64_t* class_ids,
   if (batch <= 0) return 0;
   hipLaunchKernelGGL(mask_sample_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, tokens, class_ids, timesteps, noise,
                      input_ids, labels, mask_prob, seq, mask_id, codebook_size, min_masking_rate);
+  return (int)hipGetLastError();
+}
+
+// out[i] (+)= sum_s ws[s*stride + i]   (deterministic reduction of split-K partial tiles), n % 4 == 0
+__global__ void sum_slices_kernel(const float* __restrict__ ws, float* __restrict__ out, int ns, long n, long stride, int acc) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (acc) V4<float>::load(out + i * 4, a);
+    for (int s = 0; s < ns; ++s) {
+      float t[4]; V4<float>::load(ws + s * stride + i * 4, t);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += t[j];
+    }
+    V4<float>::store(out + i * 4, a);
+  }
+}
+extern "C" int muse_sum_slices(const float* ws, float* out, int32_t nslices, int64_t n, int64_t stride, int32_t accumulate,
+                               void* stream) {
+  if (n <= 0) return 0;
+  if ((n & 3) || (stride & 3) || (((uintptr_t)ws) & 15) || (((uintptr_t)out) & 15)) return MUSE_ERR_ALIGN;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, ws, out, nslices, (long)n,
+                     (long)stride, accumulate);
   return (int)hipGetLastError();
 }
 

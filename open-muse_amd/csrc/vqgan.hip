@@ -20,7 +20,7 @@ extern "C" int muse_conv2d_nhwc(const void* in, const void* weight, const float*
   p.M = batch * H * W; p.N = Cout; p.K = KS * KS * Cin;
   p.lda = 0; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
   p.zdiv = 1; p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
-  p.alpha = 1.0f; p.accumulate = 0; p.act = 0; p.split_k = 1;
+  p.alpha = 1.0f; p.accumulate = 0; p.act = 0; p.split_k = 1; p.split_stride = 0;
   p.cH = H; p.cW = W; p.cCin = Cin; p.cKS = KS; p.cUps = upsample ? 1 : 0;
   p.cCinShift = -1;
   if ((Cin & (Cin - 1)) == 0) { int sh = 0; while ((1 << sh) < Cin) ++sh; p.cCinShift = sh; }
@@ -58,7 +58,7 @@ template <> __device__ __forceinline__ void storev<float, 4>(float* p, const flo
 template <> __device__ __forceinline__ void storev<bf16_t, 8>(bf16_t* p, const float (&v)[8]) {
   u32x4 t;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) t[j] = (uint32_t)f32_to_bf16(v[2 * j]) | ((uint32_t)f32_to_bf16(v[2 * j + 1]) << 16);
+  for (int j = 0; j < 4; ++j) t[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
   *(u32x4*)p = t;
 }
 

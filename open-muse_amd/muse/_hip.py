@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
         ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int), ("zdiv", c_int),
         ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ldr", c_i64),
         ("sA0", c_i64), ("sA1", c_i64), ("sB0", c_i64), ("sB1", c_i64), ("sC0", c_i64), ("sC1", c_i64),
-        ("alpha", c_float), ("accumulate", c_int), ("act", c_int), ("split_k", c_int),
+        ("alpha", c_float), ("accumulate", c_int), ("act", c_int), ("split_k", c_int), ("split_stride", c_i64),
     ]
 
 
@@ -61,6 +61,7 @@ SIGNATURES = {
                                c_i64, c_float, c_void_p],
     "muse_adamw_flat": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float,
                         c_float, c_int, c_float, c_void_p],
+    "muse_sum_slices": [c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_void_p],
     "muse_cast_f32_to_bf16": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_cast_bf16_to_f32": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_mask_sample": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64,

@@ -55,7 +55,8 @@ def _prof_end(e0, name, flops):
 
 
 def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, rowvec=None,
-         residual=None, ldr=0, batch=1, zdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), accumulate=False, act=0, split_k=1):
+         residual=None, ldr=0, batch=1, zdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), accumulate=False, act=0, split_k=1,
+         split_stride=0):
     """C[z] = epilogue(alpha * A[z] @ B[z]^T).  A/B/C_ are tensors, *_off element offsets of the (0,0) entry.
 
     la/lb = 0: operand(r,k) at base + r*ld + k;  1: at base + k*ld + r (see include/muse_hip.h).
@@ -86,6 +87,7 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     d.accumulate = 1 if accumulate else 0
     d.act = act
     d.split_k = split_k
+    d.split_stride = split_stride
     e0 = _prof_begin()
     check(lib().muse_gemm(C.byref(d), stream()), "muse_gemm")
     _prof_end(e0, f"gemm_{'bf16' if d.dtype == BF16 else 'f32'}_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
@@ -137,29 +139,42 @@ def linear_dgrad(dy, w, out=None):
 SPLIT_K = os.environ.get("MUSE_SPLIT_K", "1") != "0"   # MUSE_SPLIT_K=0: deterministic (no f32 atomics) weight gradients
 
 
-def wgrad_splits(M, N, K, dtype):
-    """K slices for a weight-gradient GEMM: the [N_out, K_in] output has few 128x128 tiles while K = tokens is long, so
-    the K loop is cut until >= ~2 blocks per CU exist (slices >= 4 K-tiles)."""
+def wgrad_splits(M, N, K, dtype, slots=512):
+    """K slices for a weight-gradient GEMM.  The [N_out, K_in] output has few 128x128 tiles while K = tokens is long, so
+    the K loop is cut; the slice count is the one that fills whole rounds of resident blocks best (2 blocks per CU of the
+    2-stage kernel = 512 slots), with at least 4 K-tiles per slice."""
     if not SPLIT_K:
         return 1
-    bk = 64 if dtype == torch.bfloat16 else 32
+    bk = 64 if dtype == torch.bfloat16 else 64
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     nk = (K + bk - 1) // bk
-    return max(1, min((768 + tiles - 1) // tiles, nk // 4, 64))   # ~3 resident blocks per CU (256 CUs)
+    best, best_eff = 1, 0.0
+    for s in range(1, max(1, min(nk // 4, 64)) + 1):
+        per = (nk + s - 1) // s
+        s_eff = (nk + per - 1) // per          # every slice must own at least one K-tile
+        blocks = tiles * s_eff
+        eff = blocks / (((blocks + slots - 1) // slots) * slots)
+        if eff > best_eff + 0.02:
+            best, best_eff = s_eff, eff
+    return best
 
 
 def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     """dw[N,K] (+)= dy[T,N]^T @ x[T,K]   (both operands k-major, f32 output into the flat grad buffer).
-    With split-K the slices are summed with f32 atomics, so dw is zeroed first unless it is accumulated into."""
+    Split-K slices write partial tiles to a workspace that muse_sum_slices folds into dw in a fixed order."""
     T_, N = dy.shape
     if M is not None:
         N = M
     K = x.shape[1]
-    sk = wgrad_splits(N, K, T_, dy.dtype) if dw.dtype == torch.float32 else 1
-    if sk > 1 and not accumulate:
-        dw.zero_()
-    return gemm(dy, x, dw, N, K, T_, la=1, lb=1, lda=lda or dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0),
-                accumulate=accumulate or sk > 1, split_k=sk)
+    sk = wgrad_splits(N, K, T_, dy.dtype) if (dw.dtype == torch.float32 and dw.is_contiguous() and (N * K) % 4 == 0) else 1
+    if sk <= 1:
+        return gemm(dy, x, dw, N, K, T_, la=1, lb=1, lda=lda or dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0),
+                    accumulate=accumulate)
+    ws = torch.empty((sk, N, K), dtype=torch.float32, device=dw.device)
+    gemm(dy, x, ws, N, K, T_, la=1, lb=1, lda=lda or dy.stride(0), ldb=x.stride(0), ldc=K, split_k=sk, split_stride=N * K)
+    check(lib().muse_sum_slices(ws.data_ptr(), dw.data_ptr(), sk, N * K, N * K, 1 if accumulate else 0, stream()),
+          "muse_sum_slices")
+    return dw
 
 
 def layernorm_fwd(x, w, eps, out_dtype, residual=None):

@@ -388,6 +388,12 @@ def test_gemm_split_k_wgrad(dtype):
     dw2 = torch.empty((N, K), device=DEV)
     ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw2, False)
     assert rel_err(dw2, ref) < 1e-4
+    dw3 = torch.full((N, K), 3.0, device=DEV)   # workspace split-K + deterministic slice reduction, accumulating
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw3, True)
+    assert rel_err(dw3, ref + 3.0) < 1e-4
+    dw4 = torch.empty((N, K), device=DEV)
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw4, False)
+    assert torch.equal(dw4, dw2)                 # run-to-run identical
     assert ops.wgrad_splits(768, 768, 16448, torch.bfloat16) > 1
 
 
