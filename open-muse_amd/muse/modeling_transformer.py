@@ -181,8 +181,10 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         self.direct_grad = True       # backward writes p.grad (views of the flat grad buffer) itself
         self.fused_attention = True   # bf16 compute: fused attention kernels (f32 parity mode keeps the reference algorithm)
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None  # (flat_begin, flat_end) after each segment
-        self._flat = self._flat_grad = self._flat_c = None
+        self._flat = self._flat_grad = self._flat_c = self._flat_ct = None
         self._shadow_fresh = False
+        self._shadow_version, self._ct_version = 0, -1
+        self.transposed_dgrad = True  # bf16 mode: keep W^T copies so dgrad uses the k-contiguous GEMM kernel
         self._build_flat()
         self._init_weights()
 
@@ -217,7 +219,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             p._muse_owner = weakref.ref(self)
         self._flat, self._offsets, self._flat_n = flat, offs, n
         self._flat_grad = None
-        self._flat_c = None
+        self._flat_c = self._flat_ct = None
         self._shadow_fresh = False
         self._grad_views = None
 
@@ -293,7 +295,34 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         if not self._shadow_fresh:
             ops.cast_to_bf16(self._flat, self._flat_c)
             self._shadow_fresh = True
+            self._shadow_version += 1
         return self._flat_c
+
+    def compute_weights_t(self, cd):
+        """bf16 compute mode: a second flat copy holding every Linear weight TRANSPOSED ([K_in, N_out]; the fused q|k|v and
+        wi_0|wi_1 blocks transposed as one [H, 3H] / [H, 2I] matrix), so that dX = dY W runs on the k-contiguous x
+        k-contiguous GEMM kernel (the fastest variant) instead of the transposing-read one.  Refreshed together with the
+        bf16 shadow (once per optimizer step)."""
+        if cd != torch.bfloat16 or not self.transposed_dgrad:
+            return None
+        Wc = self.compute_weights(cd)
+        if self._flat_ct is None or self._flat_ct.device != Wc.device:
+            self._flat_ct = torch.empty_like(Wc)
+            self._ct_version = -1
+        if self._ct_version != self._shadow_version:
+            H, I, V = self.hidden_size, self.intermediate_size, self.output_size
+            off = self._offsets
+            mats = []
+            for li in range(self.num_hidden_layers):
+                b0 = 2 + li * 11
+                mats += [(b0 + 1, 3 * H, H), (b0 + 4, H, H), (b0 + 7, 2 * I, H), (b0 + 10, H, I)]
+            t0 = 2 + self.num_hidden_layers * 11
+            mats += [(t0 + 1, H, H), (t0 + 3, V, H)]
+            for idx, n, k in mats:
+                o = off[idx]
+                ops.transpose(Wc[o:o + n * k].view(n, k), self._flat_ct[o:o + n * k].view(k, n))
+            self._ct_version = self._shadow_version
+        return self._flat_ct
 
     # ------------------------------------------------------------------------------------------------------------
     # forward / backward
@@ -443,6 +472,15 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         def to_cd(t):
             return t if cd == torch.float32 else ops.cast_to_bf16(t)
 
+        Wt = self.compute_weights_t(cd)
+
+        def dgrad(dy, w, idx):
+            """dx = dy @ w  (w = compute weights [N_out, K_in] at flat index idx)"""
+            if Wt is None:
+                return ops.linear_dgrad(dy, w)
+            n, k = w.shape
+            return ops.linear(dy, view(Wt, idx, (k, n)))
+
         def ready(i0, i1):
             if self.grad_ready_hook is not None and self.direct_grad:
                 end = off[i1] if i1 < len(off) else self._flat_n
@@ -466,11 +504,14 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         # dW_logits[V,H] = dlog^T gl ; dgl[T,H] = dlog W_logits   (dlog rows are Vp wide, only V valid)
         ops.linear_wgrad(dlog, sv["gl"], view(GW, t0 + 3, (V, H)), acc[t0 + 3], M=V, lda=Vp)
         dgl = torch.empty((T, H), dtype=cd, device=dev)
-        ops.gemm(dlog, w_log, dgl, T, H, V, la=0, lb=1, lda=Vp, ldb=H, ldc=H)
+        if Wt is not None and V % 8 == 0:
+            ops.gemm(dlog, view(Wt, t0 + 3, (H, V)), dgl, T, H, V, la=0, lb=0, lda=Vp, ldb=V, ldc=H)
+        else:
+            ops.gemm(dlog, w_log, dgl, T, H, V, la=0, lb=1, lda=Vp, ldb=H, ldc=H)
         dg = ops.layernorm_bwd(dgl, sv["g"], w_mln, sv["mu_g"], sv["rs_g"], cd, view(GW, t0 + 2, (H,)), acc[t0 + 2])
         dd = ops.gelu_bwd(sv["d"], dg)
         ops.linear_wgrad(dd, sv["xf"], view(GW, t0 + 1, (H, H)), acc[t0 + 1])
-        dxf = ops.linear_dgrad(dd, w_dense)
+        dxf = dgrad(dd, w_dense, t0 + 1)
         dx = ops.layernorm_bwd(dxf, sv["x_last"], w_enc, sv["mu_e"], sv["rs_e"], torch.float32, view(GW, t0 + 0, (H,)),
                                acc[t0 + 0])
         ready(t0, t0 + 4)
@@ -485,22 +526,22 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             # FFN
             dxc = to_cd(dx)
             ops.linear_wgrad(dxc, s["hm"], view(GW, b0 + 10, (H, I)), acc[b0 + 10])
-            dhm = ops.linear_dgrad(dxc, w_o2)
+            dhm = dgrad(dxc, w_o2, b0 + 10)
             dh = ops.layernorm_bwd(dhm, s["h"], w_mid, s["mu_m"], s["rs_m"], cd, view(GW, b0 + 9, (I,)), acc[b0 + 9])
             dab = ops.glu_bwd(s["ab"], dh)
             ops.linear_wgrad(dab, s["ln2"], view(GW, b0 + 7, (2 * I, H)), acc[b0 + 7])
-            dln2 = ops.linear_dgrad(dab, w_01)
+            dln2 = dgrad(dab, w_01, b0 + 7)
             dx1 = ops.layernorm_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], torch.float32, view(GW, b0 + 6, (H,)),
                                     acc[b0 + 6], dres=dx)
             # attention
             dao = ops.layernorm_bwd(dx1, s["ao"], w_post, s["mu_p"], s["rs_p"], cd, view(GW, b0 + 5, (H,)), acc[b0 + 5])
             ops.linear_wgrad(dao, s["ctx"], view(GW, b0 + 4, (H, H)), acc[b0 + 4])
-            dctx = ops.linear_dgrad(dao, w_out)
+            dctx = dgrad(dao, w_out, b0 + 4)
             qkv, P = s["qkv"], s["P"]
             if sv["fused"]:
                 dqkv = ops.attention_bwd(qkv, s["ctx"], dctx, P, B, S, nh, hd, alpha)
                 ops.linear_wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
-                dln1 = ops.linear_dgrad(dqkv, w_qkv)
+                dln1 = dgrad(dqkv, w_qkv, b0 + 1)
                 dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
                                        acc[b0 + 0], dres=dx1)
                 sv["layers"][li] = None
@@ -522,7 +563,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             ops.gemm(dP, qkv, dqkv, S, hd, S, la=1, lb=1, lda=Sp, ldb=3 * H, ldc=3 * H, b_off=0, c_off=H, alpha=alpha,
                      batch=B * nh, zdiv=nh, sA=sP_, sB=sQ, sC=sQ)
             ops.linear_wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
-            dln1 = ops.linear_dgrad(dqkv, w_qkv)
+            dln1 = dgrad(dqkv, w_qkv, b0 + 1)
             dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
                                    acc[b0 + 0], dres=dx1)
             sv["layers"][li] = None  # free activations as we go

@@ -177,6 +177,15 @@ def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     return dw
 
 
+def transpose(src, dst):
+    """dst[c, r] = src[r, c] for contiguous 2-D tensors of the same dtype"""
+    require_gpu(src, dst)
+    r, c = src.shape
+    check(lib().muse_transpose(src.data_ptr(), dst.data_ptr(), dt(src), r, c, src.stride(0), dst.stride(0), 1, 0, 0, stream()),
+          "muse_transpose")
+    return dst
+
+
 def layernorm_fwd(x, w, eps, out_dtype, residual=None):
     require_gpu(x, w)
     rows, cols = x.shape

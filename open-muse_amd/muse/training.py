@@ -87,6 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
         ops.adamw_flat(flat, g, self._m, self._v, shadow, lr, grp["betas"][0], grp["betas"][1], grp["eps"],
                        grp["weight_decay"], self._step)
         model._shadow_fresh = shadow is not None
+        model._shadow_version += 1   # transposed weight copies (dgrad) are rebuilt from the refreshed shadow
         return loss
 
     def state_dict(self):
