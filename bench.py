@@ -59,8 +59,8 @@ def synthetic_batch(bs, device, seed):
     return px.to(device), cls.to(device)
 
 
-def cpu_baseline(cfg_name, bs=4):
-    """the CPU oracle (port of the reference path) on this node's host cores, one full train step at bs=4"""
+def cpu_baseline(cfg_name, bs=16):
+    """the CPU oracle (port of the reference path) on this node's host cores, one full train step at bs=16 (~10-20 s)"""
     import weights as W
     from oracle import maskgit_oracle as O
     cores = min(os.cpu_count(), 32)  # torch CPU ops stop scaling (and oversubscribe) far below the 256 hw threads of the node
