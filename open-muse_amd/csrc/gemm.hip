@@ -1,5 +1,6 @@
 // Dense / strided-batched GEMM entry point of libmuse_hip (see include/muse_hip.h: muse_gemm).
 #include "gemm_core.h"
+#include "gemm256.h"
 #include "../../include/muse_hip.h"
 
 template <typename T, typename TC, int BM>
@@ -37,6 +38,10 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   p.cH = p.cW = p.cCin = p.cKS = p.cUps = 0; p.cCinShift = -1;
   const int batch = d->batch > 0 ? d->batch : 1;
   hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == MUSE_BF16 && d->layout_a == 0 && d->layout_b == 0 && gemm256_preferred(p, batch)) {
+    if (d->out_dtype == MUSE_BF16 && gemm256_ok<bf16_t>(p)) return launch_gemm256<bf16_t>(p, batch, s);
+    if (d->out_dtype == MUSE_F32 && gemm256_ok<float>(p)) return launch_gemm256<float>(p, batch, s);
+  }
   if (d->dtype == MUSE_BF16) {
     if (d->out_dtype == MUSE_BF16) return dispatch_layout<bf16_t, bf16_t>(p, d->layout_a, d->layout_b, batch, s);
     if (d->out_dtype == MUSE_F32) return dispatch_layout<bf16_t, float>(p, d->layout_a, d->layout_b, batch, s);

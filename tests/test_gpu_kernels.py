@@ -422,3 +422,25 @@ def test_conv2d_split_bf16x3(Cin, Cout, KS, ups, bias, res):
     out = ops.conv2d_nhwc_split(xn, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=bvec.to(DEV) if bias else None,
                                 residual=rr.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None, upsample=ups)
     assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < 3e-5, (Cin, Cout, KS, ups)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 200), (515, 256, 128), (2050, 776, 1544)])
+def test_gemm_256_tile_kernel(out_dtype, M, N, K):
+    """shapes eligible for the (experimental, MUSE_GEMM256=1|2) 256x256 kernel and, by default, the 128x128 one with its
+    LDS-staged epilogue: edges in M, N, K, every epilogue option"""
+    ops = _ops()
+    Kp = (K + 7) // 8 * 8
+    A = torch.zeros(M, Kp); A[:, :K] = rnd((M, K), 201)
+    B = torch.zeros(N, Kp); B[:, :K] = rnd((N, K), 202)
+    Ad, Bd = A.to(DEV, torch.bfloat16), B.to(DEV, torch.bfloat16)
+    ref = Ad.cpu().double()[:, :K] @ Bd.cpu().double()[:, :K].t()
+    C = torch.empty((M, N), dtype=out_dtype, device=DEV)
+    ops.gemm(Ad, Bd, C, M, N, K, lda=Kp, ldb=Kp, ldc=N, alpha=0.5)
+    tol = 1e-2 if out_dtype == torch.bfloat16 else 2e-5 * math.sqrt(K)
+    assert rel_err(C.float(), 0.5 * ref) < tol
+    bias, res = rnd((N,), 203).to(DEV), rnd((M, N), 204).to(DEV, out_dtype)
+    C2 = torch.ones((M, N), dtype=out_dtype, device=DEV)
+    ops.gemm(Ad, Bd, C2, M, N, K, lda=Kp, ldb=Kp, ldc=N, bias=bias, residual=res, ldr=N, act=1, accumulate=True)
+    ref2 = F.gelu(ref + bias.cpu().double()) + res.cpu().double() + 1.0
+    assert rel_err(C2.float(), ref2) < (2e-2 if out_dtype == torch.bfloat16 else 1e-4)
