@@ -101,6 +101,15 @@ int muse_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const
 /* GLU: h = gelu_erf(a) * b with ab = [rows, 2*inter] (a = first half).  muse/modeling_transformer.py:789-792. */
 int muse_glu_fwd(const void* ab, void* h, int32_t dtype, int64_t rows, int32_t inter, void* stream);
 int muse_glu_bwd(const void* ab, const void* dh, void* dab, int32_t dtype, int64_t rows, int32_t inter, void* stream);
+/* Fused middle of the NormFormer GLU MLP (muse/modeling_transformer.py:789-797), one pass over ab = [rows, 2*inter]:
+ *   fwd: h = gelu_erf(a) * b, hm = LayerNorm(h) * w (mean/rstd saved);
+ *   bwd: dh = LN'(dhm) never leaves the CU, dab = (dh*b*gelu'(a), dh*gelu(a)); dw_partial [ceil(rows/R), inter] f32 with
+ *        R = muse_ffn_mid_rows_per_block(), reduced by muse_colsum. */
+int muse_ffn_mid_rows_per_block(void);
+int muse_ffn_mid_fwd(const void* ab, const float* w, void* h, void* hm, float* mean, float* rstd, int32_t dtype,
+                     int32_t rows, int32_t inter, float eps, void* stream);
+int muse_ffn_mid_bwd(const void* dhm, const void* h, const void* ab, const float* w, const float* mean, const float* rstd,
+                     void* dab, float* dw_partial, int32_t dtype, int32_t rows, int32_t inter, void* stream);
 /* y = gelu_erf(x); dx = dy * gelu'(x).  muse/modeling_transformer.py:981. */
 int muse_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream);
 int muse_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, void* stream);

@@ -183,6 +183,177 @@ extern "C" int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* 
   return MUSE_ERR_BAD_ARG;
 }
 
+// =================================================================================================================
+// Fused middle of the NormFormer GLU MLP (muse/modeling_transformer.py:789-797):
+//   forward : h = gelu(a) * b ; hm = LayerNorm(h) * w          (ab = [rows, 2I], a first)   - one pass over ab
+//   backward: dh = LN'(dhm) ; dab = (dh * b * gelu'(a), dh * gelu(a)) ; dw partials          - dh never touches HBM
+// One 256-thread block per row at a time (NV chunks of 4 columns per thread), block reductions through LDS.
+// =================================================================================================================
+__device__ __forceinline__ float block_sum256(float v, float* red, int slot) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = v;
+  __syncthreads();
+  return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
+}
+
+#define FFN_ROWS 16
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ ab, const float* __restrict__ w,
+                                                          T* __restrict__ h, T* __restrict__ hm, float* __restrict__ mean_o,
+                                                          float* __restrict__ rstd_o, int rows, int inter, float eps) {
+  __shared__ float red[16];
+  float wv[NV][4];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (k * 256 + threadIdx.x) * 4;
+    if (c < inter) V4<float>::load(w + c, wv[k]);
+  }
+  const int r0 = blockIdx.x * FFN_ROWS;
+  for (int rr = 0; rr < FFN_ROWS; ++rr) {
+    const int row = r0 + rr;
+    if (row >= rows) break;
+    const T* abr = ab + (long)row * 2 * inter;
+    float hv[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) {
+        float a[4], b[4], o[4];
+        V4<T>::load(abr + c, a); V4<T>::load(abr + inter + c, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]) * b[j];
+        V4<T>::store(h + (long)row * inter + c, o);
+        if (sizeof(T) == 2) {  // LayerNorm sees the stored (bf16-rounded) h, exactly like the unfused path
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = bf16_to_f32(f32_to_bf16(o[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hv[k][j] = o[j]; s += o[j]; }
+      }
+    }
+    const float mean = block_sum256(s, red, 0) / (float)inter;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = hv[k][j] - mean; q = fmaf(d, d, q); }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum256(q, red, 1) / (float)inter + eps);
+    if (threadIdx.x == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (hv[k][j] - mean) * rstd * wv[k][j];
+        V4<T>::store(hm + (long)row * inter + c, o);
+      }
+    }
+    __syncthreads();  // red[] is reused by the next row
+  }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ dhm, const T* __restrict__ h,
+                                                          const T* __restrict__ ab, const float* __restrict__ w,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          T* __restrict__ dab, float* __restrict__ dwp, int rows, int inter) {
+  __shared__ float red[16];
+  float wv[NV][4], dwacc[NV][4];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (k * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dwacc[k][j] = 0.f;
+    if (c < inter) V4<float>::load(w + c, wv[k]);
+  }
+  const int r0 = blockIdx.x * FFN_ROWS;
+  for (int rr = 0; rr < FFN_ROWS; ++rr) {
+    const int row = r0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    float gk[NV][4], xh[NV][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) {
+        float d[4], x[4];
+        V4<T>::load(dhm + (long)row * inter + c, d); V4<T>::load(h + (long)row * inter + c, x);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[k][j] = (x[j] - mu) * rs;
+          gk[k][j] = d[j] * wv[k][j];
+          s1 += gk[k][j];
+          s2 = fmaf(gk[k][j], xh[k][j], s2);
+          dwacc[k][j] = fmaf(d[j], xh[k][j], dwacc[k][j]);
+        }
+      }
+    }
+    const float c1 = block_sum256(s1, red, 0) / (float)inter;
+    const float c2 = block_sum256(s2, red, 1) / (float)inter;
+    const T* abr = ab + (long)row * 2 * inter;
+    T* dr = dab + (long)row * 2 * inter;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) {
+        float a[4], b[4], da[4], db[4];
+        V4<T>::load(abr + c, a); V4<T>::load(abr + inter + c, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dh = rs * (gk[k][j] - c1 - xh[k][j] * c2);
+          da[j] = dh * b[j] * gelu_erf_grad(a[j]);
+          db[j] = dh * gelu_erf(a[j]);
+        }
+        V4<T>::store(dr + c, da); V4<T>::store(dr + inter + c, db);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (k * 256 + threadIdx.x) * 4;
+    if (c < inter) V4<float>::store(dwp + (long)blockIdx.x * inter + c, dwacc[k]);
+  }
+}
+
+extern "C" int muse_ffn_mid_rows_per_block(void) { return FFN_ROWS; }
+
+extern "C" int muse_ffn_mid_fwd(const void* ab, const float* w, void* h, void* hm, float* mean, float* rstd, int32_t dtype,
+                                int32_t rows, int32_t inter, float eps, void* stream) {
+  if (inter % 4 || inter > 4096) return MUSE_ERR_UNSUPPORTED;
+  if (rows <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((rows + FFN_ROWS - 1) / FFN_ROWS);
+  const int nv = (inter + 1023) / 1024;
+#define FF(T, NV) hipLaunchKernelGGL((ffn_mid_fwd_kernel<T, NV>), grid, dim3(256), 0, s, (const T*)ab, w, (T*)h, (T*)hm, mean, rstd, rows, inter, eps)
+  if (dtype == MUSE_F32) { if (nv == 1) FF(float, 1); else if (nv == 2) FF(float, 2); else if (nv == 3) FF(float, 3); else FF(float, 4); }
+  else { if (nv == 1) FF(bf16_t, 1); else if (nv == 2) FF(bf16_t, 2); else if (nv == 3) FF(bf16_t, 3); else FF(bf16_t, 4); }
+#undef FF
+  return (int)hipGetLastError();
+}
+
+extern "C" int muse_ffn_mid_bwd(const void* dhm, const void* h, const void* ab, const float* w, const float* mean,
+                                const float* rstd, void* dab, float* dw_partial, int32_t dtype, int32_t rows, int32_t inter,
+                                void* stream) {
+  if (inter % 4 || inter > 4096) return MUSE_ERR_UNSUPPORTED;
+  if (rows <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((rows + FFN_ROWS - 1) / FFN_ROWS);
+  const int nv = (inter + 1023) / 1024;
+#define FB(T, NV) hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, NV>), grid, dim3(256), 0, s, (const T*)dhm, (const T*)h, (const T*)ab, w, mean, rstd, (T*)dab, dw_partial, rows, inter)
+  if (dtype == MUSE_F32) { if (nv == 1) FB(float, 1); else if (nv == 2) FB(float, 2); else if (nv == 3) FB(float, 3); else FB(float, 4); }
+  else { if (nv == 1) FB(bf16_t, 1); else if (nv == 2) FB(bf16_t, 2); else if (nv == 3) FB(bf16_t, 3); else FB(bf16_t, 4); }
+#undef FB
+  return (int)hipGetLastError();
+}
+
 // out[c] (+)= sum_r in[r,c]; 64 columns x 16 row-groups per block, fixed summation order (deterministic)
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int acc) {
   __shared__ float red[16][64];

@@ -138,19 +138,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   __syncthreads();
   const int vpp = C / VEC;
   const int p0 = chunk * GN_PIX_PER_CHUNK, p1 = min(HW, p0 + GN_PIX_PER_CHUNK);
-  const long nv = (long)(p1 - p0) * vpp;
-  for (long i = threadIdx.x; i < nv; i += 256) {
-    const int p = p0 + (int)(i / vpp), vc = (int)(i % vpp);
-    const long off = ((long)b * HW + p) * C + vc * VEC;
-    float v[VEC];
-    loadv<T, VEC>(x + off, v);
+  if (vpp <= 256) {
+    // each thread keeps ONE channel vector (scale / shift in registers) and strides over pixels: no per-element index
+    // math or LDS lookups in the streaming loop
+    const int vc = threadIdx.x % vpp, ppi = 256 / vpp;
+    float scv[VEC], shv[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float t = v[j] * sc[vc * VEC + j] + sh[vc * VEC + j];
-      if (silu) t = t / (1.0f + expf(-t));
-      v[j] = t;
+    for (int j = 0; j < VEC; ++j) { scv[j] = sc[vc * VEC + j]; shv[j] = sh[vc * VEC + j]; }
+    for (int p = p0 + threadIdx.x / vpp; p < p1; p += ppi) {
+      const long off = ((long)b * HW + p) * C + vc * VEC;
+      float v[VEC];
+      loadv<T, VEC>(x + off, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = fmaf(v[j], scv[j], shv[j]);
+        if (silu) t = t * __frcp_rn(1.0f + __expf(-t));
+        v[j] = t;
+      }
+      storev<T, VEC>(y + off, v);
     }
-    storev<T, VEC>(y + off, v);
+  } else {
+    const long nv = (long)(p1 - p0) * vpp;
+    for (long i = threadIdx.x; i < nv; i += 256) {
+      const int p = p0 + (int)(i / vpp), vc = (int)(i % vpp);
+      const long off = ((long)b * HW + p) * C + vc * VEC;
+      float v[VEC];
+      loadv<T, VEC>(x + off, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = v[j] * sc[vc * VEC + j] + sh[vc * VEC + j];
+        if (silu) t = t * __frcp_rn(1.0f + __expf(-t));
+        v[j] = t;
+      }
+      storev<T, VEC>(y + off, v);
+    }
   }
 }
 

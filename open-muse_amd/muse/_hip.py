@@ -50,6 +50,10 @@ SIGNATURES = {
                            c_void_p],
     "muse_glu_fwd": [c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_glu_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
+    "muse_ffn_mid_rows_per_block": [],
+    "muse_ffn_mid_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
+    "muse_ffn_mid_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                         c_void_p],
     "muse_gelu_fwd": [c_void_p, c_void_p, c_int, c_i64, c_void_p],
     "muse_gelu_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p],
     "muse_embed_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

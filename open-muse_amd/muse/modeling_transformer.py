@@ -184,7 +184,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         self._flat = self._flat_grad = self._flat_c = self._flat_ct = None
         self._shadow_fresh = False
         self._shadow_version, self._ct_version = 0, -1
-        self.transposed_dgrad = True  # bf16 mode: keep W^T copies so dgrad uses the k-contiguous GEMM kernel
+        self.transposed_dgrad = False  # bf16 mode option: W^T copies so dgrad uses the k-contiguous GEMM kernel (measured: no net gain)
         self._build_flat()
         self._init_weights()
 
@@ -402,8 +402,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             x1, mu_p, rs_p = ops.layernorm_fwd(ao, w_post, eps, torch.float32, residual=x)   # x + LN(attn)  (:882-884)
             ln2, mu2, rs2 = ops.layernorm_fwd(x1, w_pre, eps, cd)
             ab = ops.linear(ln2, w_01)
-            h = ops.glu_fwd(ab)
-            hm, mu_m, rs_m = ops.layernorm_fwd(h, w_mid, eps, cd)
+            h, hm, mu_m, rs_m = ops.ffn_mid_fwd(ab, w_mid, eps)   # gelu(a)*b and the NormFormer mid-LN in one pass (:789-797)
             x2 = ops.linear(hm, w_o2, out_dtype=torch.float32, residual=x1)                  # x + FFN(x)    (:902-903)
             if need_grad:
                 saved["layers"].append(dict(x=x, mu1=mu1, rs1=rs1, ln1=ln1, qkv=qkv, P=P, ctx=ctx, ao=ao, mu_p=mu_p,
@@ -527,8 +526,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             dxc = to_cd(dx)
             ops.linear_wgrad(dxc, s["hm"], view(GW, b0 + 10, (H, I)), acc[b0 + 10])
             dhm = dgrad(dxc, w_o2, b0 + 10)
-            dh = ops.layernorm_bwd(dhm, s["h"], w_mid, s["mu_m"], s["rs_m"], cd, view(GW, b0 + 9, (I,)), acc[b0 + 9])
-            dab = ops.glu_bwd(s["ab"], dh)
+            dab = ops.ffn_mid_bwd(dhm, s["h"], s["ab"], w_mid, s["mu_m"], s["rs_m"], view(GW, b0 + 9, (I,)), acc[b0 + 9])
             ops.linear_wgrad(dab, s["ln2"], view(GW, b0 + 7, (2 * I, H)), acc[b0 + 7])
             dln2 = dgrad(dab, w_01, b0 + 7)
             dx1 = ops.layernorm_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], torch.float32, view(GW, b0 + 6, (H,)),

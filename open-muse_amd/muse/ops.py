@@ -269,6 +269,34 @@ def glu_bwd(ab, dh):
     return dab
 
 
+def ffn_mid_fwd(ab, w, eps):
+    """fused GLU + mid LayerNorm: ab [rows, 2I] -> (h, hm, mean, rstd)"""
+    require_gpu(ab, w)
+    rows, two_i = ab.shape
+    inter = two_i // 2
+    h = torch.empty((rows, inter), dtype=ab.dtype, device=ab.device)
+    hm = torch.empty_like(h)
+    mean = torch.empty(rows, dtype=torch.float32, device=ab.device)
+    rstd = torch.empty_like(mean)
+    check(lib().muse_ffn_mid_fwd(ab.data_ptr(), w.data_ptr(), h.data_ptr(), hm.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 dt(ab), rows, inter, eps, stream()), "muse_ffn_mid_fwd")
+    return h, hm, mean, rstd
+
+
+def ffn_mid_bwd(dhm, h, ab, w, mean, rstd, dw, accumulate):
+    """fused mid-LayerNorm backward + GLU backward: -> dab [rows, 2I]; dw (+)= column sums of dhm * xhat"""
+    require_gpu(dhm, h, ab, w)
+    rows, inter = h.shape
+    dab = torch.empty_like(ab)
+    rpb = lib().muse_ffn_mid_rows_per_block()
+    nblk = (rows + rpb - 1) // rpb
+    part = torch.empty((nblk, inter), dtype=torch.float32, device=h.device)
+    check(lib().muse_ffn_mid_bwd(dhm.data_ptr(), h.data_ptr(), ab.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 dab.data_ptr(), part.data_ptr(), dt(h), rows, inter, stream()), "muse_ffn_mid_bwd")
+    check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, inter, 1 if accumulate else 0, stream()), "muse_colsum")
+    return dab
+
+
 def gelu_fwd(x):
     require_gpu(x)
     y = torch.empty_like(x)

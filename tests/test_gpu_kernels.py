@@ -444,3 +444,28 @@ def test_gemm_256_tile_kernel(out_dtype, M, N, K):
     ops.gemm(Ad, Bd, C2, M, N, K, lda=Kp, ldb=Kp, ldc=N, bias=bias, residual=res, ldr=N, act=1, accumulate=True)
     ref2 = F.gelu(ref + bias.cpu().double()) + res.cpu().double() + 1.0
     assert rel_err(C2.float(), ref2) < (2e-2 if out_dtype == torch.bfloat16 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,inter", [(37, 64), (130, 3072), (50, 160), (20, 2048)])
+def test_ffn_mid_fused(dtype, rows, inter):
+    """fused GLU + mid-LayerNorm forward/backward vs F.gelu(a)*b -> F.layer_norm in f64"""
+    ops = _ops()
+    ab = rnd((rows, 2 * inter), 300).to(dtype)
+    w = 1 + 0.1 * rnd((inter,), 301)
+    eps = 1e-6
+    a = ab.double()[:, :inter].requires_grad_(True)
+    b = ab.double()[:, inter:].requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    h_ref = F.gelu(a) * b
+    hm_ref = F.layer_norm(h_ref, (inter,), wr, None, eps)
+    h, hm, mean, rstd = ops.ffn_mid_fwd(ab.to(DEV), w.to(DEV), eps)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(h.float(), h_ref.detach()) < (1e-6 if dtype == torch.float32 else 1e-2)
+    assert rel_err(hm.float(), hm_ref.detach()) < tol
+    dhm = rnd((rows, inter), 302).to(dtype)
+    hm_ref.backward(dhm.double())
+    dw = torch.empty(inter, device=DEV)
+    dab = ops.ffn_mid_bwd(dhm.to(DEV), h, ab.to(DEV), w.to(DEV), mean, rstd, dw, False)
+    assert rel_err(dab.float(), torch.cat([a.grad, b.grad], 1)) < (5e-5 if dtype == torch.float32 else 3e-2)
+    assert rel_err(dw, wr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
