@@ -59,6 +59,35 @@ def synthetic_batch(bs, device, seed):
     return px.to(device), cls.to(device)
 
 
+def vqgan_roundtrip(device, bs):
+    """BASELINE.json config 5: MaskGitVQGAN f16-256 encode -> decode_code throughput (315.3 GFLOP / image, algorithmic HBM
+    bytes 990.6 MB / image in f32: BASELINE.md section 3) for the f32-class (bf16x3) and exact-f32 tokenizer modes"""
+    import muse
+    import weights as W
+    out = {}
+    vq = muse.MaskGitVQGAN(**W.VQGAN_F16)
+    vq.load_state_dict(W.fill_state_dict(W.vqgan_shapes(W.VQGAN_F16), 1234, "vqgan"))
+    vq.to(device).eval()
+    px, _ = synthetic_batch(bs, device, seed=77)
+    for mode, name in (("bf16x3", "bf16x3"), (torch.float32, "f32")):
+        vq.set_compute_dtype(mode)
+        for _ in range(2):
+            vq.decode_code(vq.get_code(px))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            vq.decode_code(vq.get_code(px))
+        torch.cuda.synchronize()
+        ips = bs * n / (time.perf_counter() - t0)
+        out[f"vqgan_encode_decode_images_per_s_{name}"] = round(ips, 1)
+        out[f"vqgan_encode_decode_tflops_{name}"] = round(ips * 315.3 / 1e3, 1)
+        out[f"vqgan_encode_decode_algorithmic_GBps_{name}"] = round(ips * 990.6 / 1e3, 1)
+    del vq
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(cfg_name, bs=16):
     """the CPU oracle (port of the reference path) on this node's host cores, one full train step at bs=16 (~10-20 s)"""
     import weights as W
@@ -163,14 +192,17 @@ def main():
              "step_tflops_per_gpu": round(gf_img * args.batch / ms, 1),
              "mfma_ms_in_instrumented_step": round(sum(v[1] for v in agg.values()), 2)}
     if world == 1 and not args.no_extra:
-        variants = [(args.config, d) for d in ("f32", "bf16x3", "bf16") if d != args.vq_dtype]
+        other = "A" if args.config == "B" else "B"
+        variants = [(args.config, d) for d in ("f32", "bf16x3", "bf16") if d != args.vq_dtype] + [(other, args.vq_dtype)]
         if args.extra:
-            variants += [("A" if args.config == "B" else "B", d) for d in ("f32", "bf16x3", "bf16")]
+            variants += [(other, d) for d in ("f32", "bf16x3", "bf16") if d != args.vq_dtype]
         for cfgn, vqd in variants:
             if (cfgn, vqd) == (args.config, args.vq_dtype):
                 continue
             e2, _, _ = run(cfgn, vqd, max(3, args.steps // 2), 2, profile=False)
             extra[f"images_per_s_config{cfgn}_vq{vqd}"] = round(args.batch * max(3, args.steps // 2) / e2, 1)
+
+        extra.update(vqgan_roundtrip(device, args.batch))
 
     out = {
         "metric": "images/sec/node (MaskGit train step, 256^2, bs=64/GPU)", "value": round(value, 2), "unit": "images/s",

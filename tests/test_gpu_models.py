@@ -262,3 +262,29 @@ def test_pipeline_class_conditional():
     assert imgs.shape == (2, 16, 16, 3) and np.isfinite(imgs).all()
     ids = m.generate2(class_ids=torch.tensor([3], device=DEV), timesteps=3)
     assert ids.shape == (1, 16) and int(ids.max()) < 32
+
+
+def test_grad_reducer_on_rccl_single_rank(golden_dir):
+    """the N>1 path of bench.py on the real backend: RCCL ("nccl") process group of size 1, bucketed all-reduce of the flat
+    gradient buffer on the side stream fired from backward; gradients must equal the un-reduced reference golden"""
+    import torch.distributed as dist
+    import muse
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = W.TRANSFORMER_TINY
+        g = np.load(os.path.join(golden_dir, "transformer_tiny.npz"))
+        m, _ = _build_transformer(cfg, int(g["seed"]), torch.float32)
+        red = muse.GradReducer(m, bucket_bytes=32 * 1024)   # several buckets even for the tiny model
+        ids, labels = W.transformer_inputs(cfg, int(g["batch"]), int(g["seed"]) + 1)
+        _, loss = m(input_ids=ids.to(DEV), labels=labels.to(DEV))
+        loss.backward()
+        red.finish()
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            assert maxrel(p.grad, torch.from_numpy(g["grad." + k])) < 1e-3, k
+    finally:
+        dist.destroy_process_group()
