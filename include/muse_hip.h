@@ -60,6 +60,9 @@ typedef struct muse_gemm_desc {
                          f32 atomics, the caller pre-initialises C (zeros, or the value to accumulate into)          */
 } muse_gemm_desc;
 int muse_gemm(const muse_gemm_desc* d, void* stream);
+/* Block-tile edge muse_gemm will use for this descriptor: 256 (LDS-DMA kernel, one block per CU) or 128 (two / three
+ * blocks per CU); < 0 = the error muse_gemm would return.  Host code sizes split_k with it (ops.wgrad_splits). */
+int muse_gemm_tile(const muse_gemm_desc* d);
 
 /* 2-D transpose out[c, r] = in[r, c] (strided-batched); used only by the fallback that feeds k-major operands to
  * the k-contiguous GEMM path (MUSE_GEMM_TR=0). */

@@ -17,14 +17,13 @@ static int dispatch_layout(const GemmParams& p, int la, int lb, int batch, hipSt
   return use_bm256(p, batch) ? dispatch_bm<T, TC, 256>(p, la, lb, batch, s) : dispatch_bm<T, TC, 128>(p, la, lb, batch, s);
 }
 
-extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
+static int fill_params(const muse_gemm_desc* d, GemmParams& p) {
   if (!d || !d->A || !d->B || !d->C) return MUSE_ERR_BAD_ARG;
   const int esz = d->dtype == MUSE_BF16 ? 2 : 4;
   const int ch = 16 / esz;
   // 16-byte vector loads: leading dimensions and sub-matrix offsets must be multiples of one chunk
   if ((d->lda % ch) || (d->ldb % ch) || (((uintptr_t)d->A) & 15) || (((uintptr_t)d->B) & 15)) return MUSE_ERR_ALIGN;
   if ((d->sA0 % ch) || (d->sA1 % ch) || (d->sB0 % ch) || (d->sB1 % ch)) return MUSE_ERR_ALIGN;
-  GemmParams p;
   p.A = d->A; p.B = d->B; p.C = d->C;
   p.bias = (const float*)d->bias; p.rowvec = (const float*)d->rowvec; p.residual = d->residual;
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -36,11 +35,33 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   p.split_stride = p.split_k > 1 ? d->split_stride : 0;
   if (p.split_k > 1 && (d->out_dtype != MUSE_F32 || d->bias || d->rowvec || d->residual || d->act)) return MUSE_ERR_BAD_ARG;
   p.cH = p.cW = p.cCin = p.cKS = p.cUps = 0; p.cCinShift = -1;
+  return 0;
+}
+
+// does this descriptor go to the 256 x 256 LDS-DMA kernel (gemm256.h)?
+static bool takes_gemm256(const muse_gemm_desc* d, const GemmParams& p, int batch) {
+  if (d->dtype != MUSE_BF16 || !gemm256_preferred(p, d->layout_a, d->layout_b, batch)) return false;
+  if (d->out_dtype == MUSE_BF16) return gemm256_ok<bf16_t>(p, d->layout_a, d->layout_b);
+  if (d->out_dtype == MUSE_F32) return gemm256_ok<float>(p, d->layout_a, d->layout_b);
+  return false;
+}
+
+extern "C" int muse_gemm_tile(const muse_gemm_desc* d) {
+  GemmParams p;
+  const int rc = fill_params(d, p);
+  if (rc) return rc;
+  return takes_gemm256(d, p, d->batch > 0 ? d->batch : 1) ? 256 : 128;
+}
+
+extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
+  GemmParams p;
+  const int rc = fill_params(d, p);
+  if (rc) return rc;
   const int batch = d->batch > 0 ? d->batch : 1;
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == MUSE_BF16 && d->layout_a == 0 && d->layout_b == 0 && gemm256_preferred(p, batch)) {
-    if (d->out_dtype == MUSE_BF16 && gemm256_ok<bf16_t>(p)) return launch_gemm256<bf16_t>(p, batch, s);
-    if (d->out_dtype == MUSE_F32 && gemm256_ok<float>(p)) return launch_gemm256<float>(p, batch, s);
+  if (takes_gemm256(d, p, batch)) {
+    if (d->out_dtype == MUSE_BF16) return launch_gemm256<bf16_t>(p, d->layout_a, d->layout_b, batch, s);
+    return launch_gemm256<float>(p, d->layout_a, d->layout_b, batch, s);
   }
   if (d->dtype == MUSE_BF16) {
     if (d->out_dtype == MUSE_BF16) return dispatch_layout<bf16_t, bf16_t>(p, d->layout_a, d->layout_b, batch, s);

@@ -1,32 +1,218 @@
-// 256 x 256 x 64 bf16 GEMM kernel for the large k-contiguous x k-contiguous products (Linear forward, and dX through the
-// transposed weight copies).  Ablation of the 128 x 128 kernel on MI355X (scripts/exp/ablate_gemm.hip) showed that at
-// 128^2 the per-CU vector-memory path (64 B/clk) and the VGPR->LDS store path (~79 B/clk) each need as many cycles per tile
-// as the MFMAs do; a 256^2 tile moves half the bytes per flop through both.
+// 256 x 256 x 64 bf16 GEMM kernel with direct-to-LDS operand loads, for every operand layout (Linear forward, dX, dW).
 //
-//   8 waves (512 threads) as 2 (M) x 4 (N); each wave owns a 128 x 64 block = 8 x 4 MFMA 16x16 fragments (128 acc VGPRs).
-//   Operands: buffer_load_dwordx4 one K-tile ahead into 32 VGPRs, then ds_write_b128 into k-contiguous LDS images with the
-//   +32 B row pad (conflict-free ds_read_b128).  One 80 KiB stage, one block per CU (two waves per SIMD).
-//   Epilogue: alpha / bias / rowvec / GELU in registers, C staged through LDS in row passes, 16-byte row-contiguous global
-//   stores with residual / accumulate applied on the way out.
+// Why: ablation of the 128 x 128 kernel (scripts/exp/ablate_gemm.hip) showed the per-CU vector-memory return path and the
+// VGPR -> LDS store path each cost as many cycles per tile as the MFMAs.  Here operands never touch VGPRs on the way in:
 //
-// STATUS (round 1): correct (tests/test_gpu_kernels.py::test_gemm_256_tile_kernel with MUSE_GEMM256=1|2) but NOT the default:
-// with register staging there is room for only one K-tile of prefetch and one block per CU, so load latency is exposed
-// (500 TFLOP/s on [16448x768]x[6144x768]^T vs 810 for the 128^2 kernel; 811 vs 717 on the K=6144 dgrad).  It needs
-// direct-to-LDS loads (global_load_lds) with a counted-vmcnt multi-stage ring to pay off - the round-2 work item.
+//   * 8 waves (2 M x 4 N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 fragments (128 accumulator VGPRs), one block per CU.
+//   * Operand tiles arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, 8 per wave per K-tile)
+//     into two 64 KiB stages.  The LDS image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE offset:
+//       k-contiguous operand: [256 rows][128 B]; 16-byte chunk c of row r sits at chunk (c ^ ((r >> 1) & 7))
+//                             -> each 16-lane group of a ds_read_b128 fragment read covers all 64 banks once
+//       k-major operand:      [64 k-rows][512 B]; chunk c of k-row k sits at chunk (c ^ (s(k) << 1)), s(k) = k[1:0] | k[3] << 2
+//                             -> the 8 k-rows one half-wave of ds_read_b64_tr_b16 touches fall on 8 distinct 32-byte bank slots
+//     Rows outside the matrix and k beyond K are redirected to an out-of-range buffer offset (hardware returns zeros).
+//   * K loop, software-pipelined inside each wave (fragment registers double-buffered, reads issued by inline asm so the
+//     waits are counted by hand):  the ks=1 fragment reads run under the ks=0 MFMAs; then `vmcnt(0) lgkmcnt(0)` + ONE raw
+//     s_barrier per K-tile; right after it the DMA for tile t+2 goes into the stage just drained and the ks=0 fragment reads
+//     of tile t+1 run under the ks=1 MFMAs.  The DMA has a whole K-tile of MFMA time (>= 2048 cycles) to land.
+//   * Epilogue: alpha / bias / rowvec / GELU in registers, C staged through LDS in row passes, 16-byte row-contiguous
+//     global stores with residual / accumulate applied on the way out; split-K slices go to a workspace.
 #pragma once
 #include "gemm_core.h"
+#include <type_traits>
 
-template <typename TC>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
-  using T = bf16_t;
-  using Cfg = TileCfg<T>;
-  constexpr int BM = 256, BN = 256, NT = 512, MI = 8, NI = 4;
-  using ALoader = PlainLoader<T, 0, BM, NT>;  // 4 chunks / thread
-  using BLoader = PlainLoader<T, 0, BN, NT>;
-  constexpr int TA_BYTES = BM * Cfg::KC_STRIDE;  // 40960
+namespace g256 {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr int BM = 256, BN = 256, BK = 64, NT = 512, MI = 8, NI = 4;
+constexpr int TILE = 32768;                 // one operand tile of one stage
+constexpr int A_BASE = 0, B_BASE = 65536;   // stage s of an operand at BASE + s * TILE
+constexpr int LDS_BYTES = 131072;
+
+__device__ __forceinline__ int km_sw(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+
+template <int OFF> __device__ __forceinline__ void lds_read128(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void lds_read64_tr(u32x2& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- LDS-DMA of one operand (256 rows x 64 k) --------------------------------------------------------------------------
+// Each wave issues 4 pieces of 1 KiB per K-tile; piece q = wave * 4 + j lands at tile + q * 1024 (+ lane * 16 by hardware).
+template <int L>
+struct Dma {
+  rsrc_t rs;
+  unsigned voff[4];  // byte offset of this lane's chunk of piece j at K-tile 0 (or `oob`)
+  unsigned kk0;      // k (inside the tile) of this lane's chunk of piece 0
+  unsigned oob;
+  unsigned kstep;    // bytes per K-tile
+  int kend;
+  __device__ __forceinline__ void init(const bf16_t* ptr, long ld, int R, int K, int kend_, int r0, int wave, int lane) {
+    kend = kend_;
+    const long cols = L == 0 ? K : R, rows = L == 0 ? R : K;
+    const unsigned bytes = (unsigned)(((rows - 1) * ld + (cols + 7) / 8 * 8) * 2);
+    rs = make_rsrc(ptr, bytes);
+    oob = (bytes + 15u) & ~15u;
+    if constexpr (L == 0) {
+      const int r8 = lane >> 3, pc = lane & 7;
+      kstep = 128u;
+      kk0 = (unsigned)((pc ^ (r8 >> 1)) * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + r8;           // (row >> 1) & 7 == ((j & 1) << 2) | (r8 >> 1)
+        const int csrc = pc ^ ((row >> 1) & 7);
+        voff[j] = (r0 + row) < R ? (unsigned)(((long)(r0 + row) * ld + csrc * 8) * 2) : oob;
+      }
+    } else {
+      const int half = lane >> 5, pos = lane & 31;
+      kstep = (unsigned)(64 * ld * 2);
+      kk0 = (unsigned)(wave * 8 + half);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kr = wave * 8 + j * 2 + half;
+        const int csrc = pos ^ (km_sw(kr) << 1);
+        voff[j] = (r0 + csrc * 8) < R ? (unsigned)(((long)kr * ld + r0 + csrc * 8) * 2) : oob;
+      }
+    }
+  }
+  // k of this lane's chunk of piece j inside its tile
+  __device__ __forceinline__ unsigned kk(int j) const { return L == 0 ? (kk0 ^ ((unsigned)(j & 1) << 5)) : (kk0 + 2u * j); }
+  template <int LDS_OFF>
+  __device__ __forceinline__ void issue(unsigned char* smem, int kt, int wave) const {
+    const unsigned soff = (unsigned)kt * kstep;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned vo = ((unsigned)kt * 64u + kk(j)) < (unsigned)kend ? voff[j] : oob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + LDS_OFF + (wave * 4 + j) * 1024), 16, (int)vo, (int)soff, 0, 0);
+    }
+  }
+};
+
+// ---- LDS -> MFMA fragments of one operand: NF fragments of 16 rows; lane supplies row (lane & 15), k = 8 * (lane >> 4) .. +7 ---
+template <int L, int NF>
+struct Frags {
+  static constexpr int NADDR = L == 0 ? 2 : NF;
+  static constexpr int READS_PER_FRAG = L == 0 ? 1 : 2;
+  unsigned addr[NADDR];
+  __device__ __forceinline__ void init(int base, int wb, int lane) {
+    const int p = lane & 15, g = lane >> 4;
+    if constexpr (L == 0) {
+      const int sw = (p >> 1) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) addr[ks] = (unsigned)(base + (wb + p) * 128 + (((ks * 4 + g) ^ sw) << 4));
+    } else {
+      const int kr = 8 * g + (p >> 2), s = km_sw(kr);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int chunk = (wb >> 3) + 2 * f + ((p & 3) >> 1);
+        addr[f] = (unsigned)(base + kr * 512 + ((chunk ^ (s << 1)) << 4) + (p & 1) * 8);
+      }
+    }
+  }
+  // fragment F of K-group KS of stage STAGE
+  template <int STAGE, int KS, int F>
+  __device__ __forceinline__ void read(bf16x8& d) const {
+    if constexpr (L == 0) {
+      lds_read128<STAGE * TILE + F * 2048>(d, addr[KS]);
+    } else {
+      u32x2 h0, h1;
+      lds_read64_tr<STAGE * TILE + KS * 16384>(h0, addr[F]);
+      lds_read64_tr<STAGE * TILE + KS * 16384 + 2048>(h1, addr[F]);
+      const u32x4 w = {h0[0], h0[1], h1[0], h1[1]};
+      d = __builtin_bit_cast(bf16x8, w);
+    }
+  }
+  template <int STAGE, int KS, int F0, int F1>
+  __device__ __forceinline__ void read_range(bf16x8 (&d)[NF]) const {
+    if constexpr (F0 < F1) {
+      read<STAGE, KS, F0>(d[F0]);
+      read_range<STAGE, KS, F0 + 1, F1>(d);
+    }
+  }
+};
+
+// ---- the K loop: one wave's view ----------------------------------------------------------------------------------------
+// A K-tile is 16 MFMA "groups" g = ks * 8 + i (the 4 MFMAs of A-fragment row i against the 4 B fragments of K-group ks).
+// A fragments live in a ring of NSLOT registers and are read DIST groups ahead of their use; the B fragments of both
+// K-groups stay resident (read once per tile: ks=1 at group GB1, the next tile's ks=0 at group GBAR, right after the
+// barrier).  The barrier sits before group GBAR = 16 - DIST, the first group whose look-ahead read targets the next stage:
+//   wait vmcnt(0) lgkmcnt(0)   my DMA pieces of tile t+1 have landed, my reads of this stage are complete
+//   s_barrier                  ... and so have everyone's
+//   DMA tile t+2 -> this stage; fragment reads of tile t+1 begin, under the last DIST groups of MFMAs of tile t.
+// LDS reads return in order, so "fragment a(g) has arrived" == at most (reads issued after it) outstanding: waitN(g).
+template <int AL, int BL>
+struct Pipe {
+  static constexpr int RA = AL ? 2 : 1, RB = BL ? 2 : 1, NB = NI * RB;
+  static constexpr int NSLOT = 4, DIST = NSLOT - 1;
+  static constexpr int GB1 = 8 - DIST, GBAR = 16 - DIST;
+  Dma<AL> da;
+  Dma<BL> db;
+  Frags<AL, MI> fa;
+  Frags<BL, NI> fb;
+  f32x4 acc[MI][NI];
+  bf16x8 ring[NSLOT];
+  bf16x8 bk[2][NI];
+  unsigned char* smem;
+  int wave;
+
+  static constexpr int nB(int x) { x = ((x % 16) + 16) % 16; return (x == GB1 || x == GBAR) ? NB : 0; }
+  static constexpr int waitN(int g) {
+    int n = DIST * RA;
+    for (int x = g - DIST + 1; x <= g; ++x) n += nB(x);
+    return n > 15 ? 15 : n;
+  }
+  // A fragment of virtual group GA: 0..15 = this tile (stage S), 16.. = next tile (stage S ^ 1)
+  template <int S, int GA>
+  __device__ __forceinline__ void read_a() {
+    constexpr int st = GA < 16 ? S : (S ^ 1), g = GA & 15;
+    fa.template read<st, (g >> 3), (g & 7)>(ring[GA & (NSLOT - 1)]);
+  }
+  __device__ __forceinline__ void prologue(int kt0) {
+    da.template issue<A_BASE>(smem, kt0, wave);
+    db.template issue<B_BASE>(smem, kt0, wave);
+    da.template issue<A_BASE + TILE>(smem, kt0 + 1, wave);
+    db.template issue<B_BASE + TILE>(smem, kt0 + 1, wave);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    fb.template read_range<0, 0, 0, NI>(bk[0]);
+    prologue_a<0>();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <int G> __device__ __forceinline__ void prologue_a() {
+    if constexpr (G < DIST) { read_a<0, G>(); prologue_a<G + 1>(); }
+  }
+  template <int S, int G>
+  __device__ __forceinline__ void group(int kt, int kt_last) {
+    if constexpr (G == GBAR) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < kt_last) {
+        da.template issue<A_BASE + S * TILE>(smem, kt + 2, wave);
+        db.template issue<B_BASE + S * TILE>(smem, kt + 2, wave);
+      }
+      fb.template read_range<S ^ 1, 0, 0, NI>(bk[0]);  // (after the last tile: a stale stage, never used)
+    }
+    if constexpr (G == GB1) fb.template read_range<S, 1, 0, NI>(bk[1]);
+    read_a<S, G + DIST>();
+    wait_lgkm<waitN(G)>();
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      acc[G & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G + 1 < 16) group<S, G + 1>(kt, kt_last);
+  }
+};
+
+template <typename TC, int AL, int BL>
+__global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tA = smem;
-  unsigned char* tB = smem + TA_BYTES;
 
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
   const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
@@ -37,93 +223,76 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   const int m0 = (first_m + in_grp % gm) * BM, n0 = (in_grp / gm) * BN;
 
   const int z = blockIdx.z, zq = z / p.zdiv, zr = z - zq * p.zdiv;
-  const T* Ap = (const T*)p.A + zq * p.sA0 + zr * p.sA1;
-  const T* Bp = (const T*)p.B + zq * p.sB0 + zr * p.sB1;
-  TC* Cp = (TC*)p.C + zq * p.sC0 + zr * p.sC1;
+  const bf16_t* Ap = (const bf16_t*)p.A + zq * p.sA0 + zr * p.sA1;
+  const bf16_t* Bp = (const bf16_t*)p.B + zq * p.sB0 + zr * p.sB1;
+  TC* Cp = (TC*)p.C + zq * p.sC0 + zr * p.sC1 + (p.split_k > 1 ? (long)blockIdx.y * p.split_stride : 0L);
 
-  ALoader la; la.init(Ap, p.lda, p.M, p.K, m0, p);
-  BLoader lb; lb.init(Bp, p.ldb, p.N, p.K, n0, p);
+  int nk = (p.K + BK - 1) / BK, kt0 = 0;
+  if (p.split_k > 1) {
+    const int per = (nk + p.split_k - 1) / p.split_k;
+    kt0 = blockIdx.y * per;
+    nk = min(nk, kt0 + per);
+    if (kt0 >= nk) return;
+  }
+  const int kend = min(p.K, nk * BK);
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = (wave >> 2) * 128, wc = (wave & 3) * 64;
 
-  f32x4 acc[MI][NI];
+  Pipe<AL, BL> pp;
+  pp.smem = smem; pp.wave = wave;
+  pp.da.init(Ap, p.lda, p.M, p.K, kend, m0, wave, lane);
+  pp.db.init(Bp, p.ldb, p.N, p.K, kend, n0, wave, lane);
+  pp.fa.init(A_BASE, wr, lane);
+  pp.fb.init(B_BASE, wc, lane);
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) pp.acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[ALoader::NCH], rb[BLoader::NCH];
-  const int nk = (p.K + Cfg::BK - 1) / Cfg::BK;
-#pragma unroll
-  for (int i = 0; i < ALoader::NCH; ++i) ra[i] = la.load(i, 0);
-#pragma unroll
-  for (int i = 0; i < BLoader::NCH; ++i) rb[i] = lb.load(i, 0);
-#pragma unroll
-  for (int i = 0; i < ALoader::NCH; ++i) *(u32x4*)(tA + ALoader::lds_off(i)) = ra[i];
-#pragma unroll
-  for (int i = 0; i < BLoader::NCH; ++i) *(u32x4*)(tB + BLoader::lds_off(i)) = rb[i];
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < ALoader::NCH; ++i) ra[i] = la.load(i, (kt + 1) * Cfg::BK);
-#pragma unroll
-      for (int i = 0; i < BLoader::NCH; ++i) rb[i] = lb.load(i, (kt + 1) * Cfg::BK);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 bf[NI];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bf[j] = frag_bf16<0, BN>(tB, wc + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const bf16x8 af = frag_bf16<0, BM>(tA, wr + i * 16, ks, lane);
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af, acc[i][j], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < ALoader::NCH; ++i) *(u32x4*)(tA + ALoader::lds_off(i)) = ra[i];
-#pragma unroll
-      for (int i = 0; i < BLoader::NCH; ++i) *(u32x4*)(tB + BLoader::lds_off(i)) = rb[i];
-      __syncthreads();
-    }
+  // the tile count is rounded up to even (a tile beyond kend is all out-of-range chunks: zeros, no memory traffic)
+  const int kt_last = kt0 + ((nk - kt0 + 1) & ~1);
+  pp.prologue(kt0);
+  for (int kt = kt0; kt < kt_last; kt += 2) {
+    pp.template group<0, 0>(kt, kt_last);
+    pp.template group<1, 0>(kt + 1, kt_last);
   }
+  wait_lgkm<0>();  // the trailing (unused) fragment reads must not land in registers the epilogue reuses
+  auto& acc = pp.acc;
 
   // ---- epilogue: C staged through LDS, RPP rows per pass, 16-byte row-contiguous stores ----
+  // lane holds C[m][n..n+3], m = m0 + wr + 16 i + (lane & 15), n = n0 + wc + 16 j + 4 (lane >> 4)
+  // (kept small on purpose: 128 accumulator registers per lane make every per-element branch 128 copies of code, and a
+  //  one-block-per-CU kernel cannot hide an instruction-cache-missing epilogue behind another block)
   constexpr int EPC = 16 / (int)sizeof(TC);
   constexpr int CST = BN * (int)sizeof(TC) + 16;          // 528 (bf16) / 1040 (f32) bytes per staged row
   constexpr int RPP = sizeof(TC) == 2 ? 128 : 64;         // 67.6 KB / 66.6 KB per pass
-  constexpr int NPASS = BM / RPP;
+  constexpr int NPASS = BM / RPP, PPW = 128 / RPP, IPP = MI / PPW;  // passes, passes per wave row, fragment rows per pass
   constexpr int CPRo = BN / EPC;
   const TC* Rq = (const TC*)p.residual;
+  float bias_v[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wc + j * 16 + 4 * (lane >> 4) + r;
+      bias_v[j][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     __syncthreads();
+    if ((wave >> 2) == pass / PPW) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int rowblk = wr + i * 16;                     // wave-uniform
-      if (rowblk / RPP == pass) {
-        const int ml = rowblk + (lane & 15);
+      for (int ii = 0; ii < IPP; ++ii) {
+        const int i = (pass % PPW) * IPP + ii;
+        const int ml = wr + i * 16 + (lane & 15);
         const float rv = (p.rowvec && (m0 + ml) < p.M) ? p.rowvec[m0 + ml] : 0.f;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int nl = wc + j * 16 + 4 * (lane >> 4);
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float add = rv;
-            if (p.bias && (n0 + nl + r) < p.N) add += p.bias[n0 + nl + r];
-            float x = p.alpha * acc[i][j][r] + add;
-            if (p.act == 1) x = gelu_erf(x);
-            v[r] = x;
-          }
+          for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r] + (rv + bias_v[j][r]);
           OutVec<TC>::store4((TC*)(smem + (ml - pass * RPP) * CST) + nl, v);
         }
       }
@@ -171,42 +340,59 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
   }
 }
 
-// eligibility: bf16 k-contiguous operands, no split-K, 16-byte aligned output rows
+}  // namespace g256
+
+// eligibility: bf16 operands; 16-byte aligned output rows; whole 16-byte chunks along the contiguous operand dimension;
+// split-K only through the workspace (atomics stay with the 128^2 kernel)
 template <typename TC>
-static inline bool gemm256_ok(const GemmParams& p) {
+static inline bool gemm256_ok(const GemmParams& p, int la, int lb) {
   constexpr int EPC = 16 / (int)sizeof(TC);
-  return p.split_k <= 1 && (p.N % EPC) == 0 && (p.ldc % EPC) == 0 && ((((uintptr_t)p.C) & 15) == 0) &&
-         (p.sC0 % EPC) == 0 && (p.sC1 % EPC) == 0 &&
+  if (p.split_k > 1 && p.split_stride == 0) return false;
+  if (p.act != 0) return false;  // (GELU epilogue stays with the 128^2 kernel)
+  if ((la == 0 || lb == 0) && (p.K % 8)) return false;
+  if ((la == 1 && (p.M % 8)) || (lb == 1 && (p.N % 8))) return false;
+  return (p.N % EPC) == 0 && (p.ldc % EPC) == 0 && ((((uintptr_t)p.C) & 15) == 0) && (p.sC0 % EPC) == 0 &&
+         (p.sC1 % EPC) == 0 && (p.split_stride % EPC) == 0 &&
          (p.residual == nullptr || (((p.ldr % EPC) == 0) && ((((uintptr_t)p.residual) & 15) == 0)));
 }
 
-// Pick the tile by estimated time: rounds of resident blocks x per-block cost.  The 128^2 kernel keeps 3 blocks per CU
-// (768 slots), the 256^2 kernel 1 block per CU (256 slots) with 4x the work per block; R256/R128 is the measured
-// throughput ratio of fully occupied rounds.
-static inline bool gemm256_preferred(const GemmParams& p, int batch) {
-  static const int mode = [] { const char* e = getenv("MUSE_GEMM256"); return e ? (e[0] - '0') : 0; }();  // 0 off (default), 1 force, 2 auto
+// Pick the tile by estimated time (microseconds on MI355X, fitted to scripts/exp/gemm256g.hip and scripts/gemm_shapes.py):
+//   256^2: one block per CU (256 slots); a round costs nk * 1.8 + 6        (K loop ~1000 TFLOP/s + prologue / epilogue)
+//   128^2: 3 (k-contiguous x k-contiguous, one stage) or 2 blocks per CU; a round costs nk * 1.7 + 2.5 / nk * 1.25 + 2.5
+// MUSE_GEMM256 = 0 never, 1 whenever eligible, 2 (default) by the estimate.
+static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int batch) {
+  const char* e = getenv("MUSE_GEMM256");  // read per call (cheap) so tests can force either kernel
+  const int mode = e ? (e[0] - '0') : 2;
   if (mode == 0) return false;
-  if (p.K < 128 || p.M < 512 || p.N < 256) return false;
   if (mode == 1) return true;
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
-  const double rounds128 = (double)((t128 + 767) / 768), rounds256 = (double)((t256 + 255) / 256);
-  const double cost128 = rounds128 * 1.0, cost256 = rounds256 * (4.0 / 3.0) / 1.35;  // per-round time in 128^2-round units
+  if (p.K < 128 || p.M < 256 || p.N < 256) return false;
+  const long sk = p.split_k > 1 ? p.split_k : 1;
+  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch * sk;
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch * sk;
+  const double nk = (double)((p.K + 63) / 64) / (double)sk;
+  const bool nn = la == 0 && lb == 0;
+  const long slots128 = nn ? 768 : 512;
+  const double cost256 = (double)((t256 + 255) / 256) * (nk * 1.8 + 6.0);
+  const double cost128 = (double)((t128 + slots128 - 1) / slots128) * (nk * (nn ? 1.7 : 1.25) + 2.5);
   return cost256 < cost128;
 }
 
-template <typename TC>
-static inline int launch_gemm256(const GemmParams& p, int batch, hipStream_t stream) {
+template <typename TC, int AL, int BL>
+static inline int launch_gemm256_l(const GemmParams& p, int batch, hipStream_t stream) {
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
-  constexpr size_t tiles = 2 * 256 * TileCfg<bf16_t>::KC_STRIDE;
-  constexpr size_t ctile = (size_t)(sizeof(TC) == 2 ? 128 : 64) * (256 * sizeof(TC) + 16);
-  constexpr size_t lds = tiles > ctile ? tiles : ctile;
-  auto kern = gemm256_kernel<TC>;
+  auto kern = g256::kernel<TC, AL, BL>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn, 1, batch), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, p.split_k > 1 ? p.split_k : 1, batch), dim3(512), g256::LDS_BYTES, stream, p);
   return (int)hipGetLastError();
+}
+template <typename TC>
+static inline int launch_gemm256(const GemmParams& p, int la, int lb, int batch, hipStream_t stream) {
+  if (la == 0 && lb == 0) return launch_gemm256_l<TC, 0, 0>(p, batch, stream);
+  if (la == 0 && lb == 1) return launch_gemm256_l<TC, 0, 1>(p, batch, stream);
+  if (la == 1 && lb == 1) return launch_gemm256_l<TC, 1, 1>(p, batch, stream);
+  return launch_gemm256_l<TC, 1, 0>(p, batch, stream);
 }

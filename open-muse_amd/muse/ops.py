@@ -139,15 +139,14 @@ def linear_dgrad(dy, w, out=None):
 SPLIT_K = os.environ.get("MUSE_SPLIT_K", "1") != "0"   # MUSE_SPLIT_K=0: deterministic (no f32 atomics) weight gradients
 
 
-def wgrad_splits(M, N, K, dtype, slots=512):
-    """K slices for a weight-gradient GEMM.  The [N_out, K_in] output has few 128x128 tiles while K = tokens is long, so
-    the K loop is cut; the slice count is the one that fills whole rounds of resident blocks best (2 blocks per CU of the
-    2-stage kernel = 512 slots), with at least 4 K-tiles per slice."""
+def wgrad_splits(M, N, K, dtype, slots=512, tile=128):
+    """K slices for a weight-gradient GEMM.  The [N_out, K_in] output has few tiles while K = tokens is long, so the K
+    loop is cut; the slice count is the one that fills whole rounds of resident blocks best (128^2 kernel: 2 blocks per
+    CU = 512 slots; 256^2 LDS-DMA kernel: 1 block per CU = 256 slots), with at least 4 K-tiles per slice."""
     if not SPLIT_K:
         return 1
-    bk = 64 if dtype == torch.bfloat16 else 64
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    nk = (K + bk - 1) // bk
+    tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
+    nk = (K + 63) // 64
     best, best_eff = 1, 0.0
     for s in range(1, max(1, min(nk // 4, 64)) + 1):
         per = (nk + s - 1) // s
@@ -159,6 +158,31 @@ def wgrad_splits(M, N, K, dtype, slots=512):
     return best
 
 
+_WGRAD_PLAN = {}
+
+
+def _wgrad_plan(dy, x, N, K, T_, lda, ldb):
+    """(split_k) for dw[N,K] = dy^T x: sized for the 256^2 kernel when muse_gemm would take it (muse_gemm_tile), else for
+    the 128^2 one."""
+    key = (N, K, T_, dy.dtype, lda, ldb)
+    plan = _WGRAD_PLAN.get(key)
+    if plan is None:
+        plan = wgrad_splits(N, K, T_, dy.dtype, slots=512, tile=128)
+        if dy.dtype == torch.bfloat16:
+            sk = wgrad_splits(N, K, T_, dy.dtype, slots=256, tile=256)
+            d = GemmDesc()
+            d.A, d.B, d.C = dy.data_ptr(), x.data_ptr(), dy.data_ptr()   # (pointers only checked for alignment)
+            d.dtype, d.out_dtype, d.layout_a, d.layout_b = BF16, F32, 1, 1
+            d.M, d.N, d.K, d.batch, d.zdiv = N, K, T_, 1, 1
+            d.lda, d.ldb, d.ldc = lda, ldb, K
+            d.alpha = 1.0
+            d.split_k, d.split_stride = sk, (N * K if sk > 1 else 0)
+            if lib().muse_gemm_tile(C.byref(d)) == 256:
+                plan = sk
+        _WGRAD_PLAN[key] = plan
+    return plan
+
+
 def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     """dw[N,K] (+)= dy[T,N]^T @ x[T,K]   (both operands k-major, f32 output into the flat grad buffer).
     Split-K slices write partial tiles to a workspace that muse_sum_slices folds into dw in a fixed order."""
@@ -166,12 +190,13 @@ def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     if M is not None:
         N = M
     K = x.shape[1]
-    sk = wgrad_splits(N, K, T_, dy.dtype) if (dw.dtype == torch.float32 and dw.is_contiguous() and (N * K) % 4 == 0) else 1
+    lda = lda or dy.stride(0)
+    splittable = dw.dtype == torch.float32 and dw.is_contiguous() and (N * K) % 4 == 0
+    sk = _wgrad_plan(dy, x, N, K, T_, lda, x.stride(0)) if splittable else 1
     if sk <= 1:
-        return gemm(dy, x, dw, N, K, T_, la=1, lb=1, lda=lda or dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0),
-                    accumulate=accumulate)
+        return gemm(dy, x, dw, N, K, T_, la=1, lb=1, lda=lda, ldb=x.stride(0), ldc=dw.stride(0), accumulate=accumulate)
     ws = torch.empty((sk, N, K), dtype=torch.float32, device=dw.device)
-    gemm(dy, x, ws, N, K, T_, la=1, lb=1, lda=lda or dy.stride(0), ldb=x.stride(0), ldc=K, split_k=sk, split_stride=N * K)
+    gemm(dy, x, ws, N, K, T_, la=1, lb=1, lda=lda, ldb=x.stride(0), ldc=K, split_k=sk, split_stride=N * K)
     check(lib().muse_sum_slices(ws.data_ptr(), dw.data_ptr(), sk, N * K, N * K, 1 if accumulate else 0, stream()),
           "muse_sum_slices")
     return dw

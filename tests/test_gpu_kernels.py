@@ -425,25 +425,66 @@ def test_conv2d_split_bf16x3(Cin, Cout, KS, ups, bias, res):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("M,N,K", [(1000, 520, 200), (515, 256, 128), (2050, 776, 1544)])
-def test_gemm_256_tile_kernel(out_dtype, M, N, K):
-    """shapes eligible for the (experimental, MUSE_GEMM256=1|2) 256x256 kernel and, by default, the 128x128 one with its
-    LDS-staged epilogue: edges in M, N, K, every epilogue option"""
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (520, 264, 200), (1000, 520, 712), (264, 776, 64)])
+def test_gemm_256_tile_kernel(monkeypatch, out_dtype, la, lb, M, N, K):
+    """the 256x256 LDS-DMA kernel (gemm256.h), forced with MUSE_GEMM256=1: every operand layout, ragged M / N / K (tail
+    K-tile, odd tile counts), every epilogue option it handles (alpha, bias, rowvec, residual, accumulate); GELU falls back
+    to the 128x128 kernel and must agree too"""
     ops = _ops()
-    Kp = (K + 7) // 8 * 8
-    A = torch.zeros(M, Kp); A[:, :K] = rnd((M, K), 201)
-    B = torch.zeros(N, Kp); B[:, :K] = rnd((N, K), 202)
-    Ad, Bd = A.to(DEV, torch.bfloat16), B.to(DEV, torch.bfloat16)
-    ref = Ad.cpu().double()[:, :K] @ Bd.cpu().double()[:, :K].t()
+    monkeypatch.setenv("MUSE_GEMM256", "1")
+    A, B = rnd((M, K), 201).to(torch.bfloat16), rnd((N, K), 202).to(torch.bfloat16)
+    ref = A.double() @ B.double().t()
+    Ad = (A if la == 0 else A.t().contiguous()).to(DEV)
+    Bd = (B if lb == 0 else B.t().contiguous()).to(DEV)
+    lda, ldb = (K if la == 0 else M), (K if lb == 0 else N)
+    d = ops.GemmDesc()
+    d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), Ad.data_ptr()
+    d.dtype, d.out_dtype, d.layout_a, d.layout_b = 1, (1 if out_dtype == torch.bfloat16 else 0), la, lb
+    d.M, d.N, d.K, d.batch, d.zdiv, d.lda, d.ldb, d.ldc, d.alpha = M, N, K, 1, 1, lda, ldb, N, 1.0
+    assert ops.lib().muse_gemm_tile(ops.C.byref(d)) == 256
     C = torch.empty((M, N), dtype=out_dtype, device=DEV)
-    ops.gemm(Ad, Bd, C, M, N, K, lda=Kp, ldb=Kp, ldc=N, alpha=0.5)
+    ops.gemm(Ad, Bd, C, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=N, alpha=0.5)
     tol = 1e-2 if out_dtype == torch.bfloat16 else 2e-5 * math.sqrt(K)
     assert rel_err(C.float(), 0.5 * ref) < tol
-    bias, res = rnd((N,), 203).to(DEV), rnd((M, N), 204).to(DEV, out_dtype)
+    bias, rowvec = rnd((N,), 203).to(DEV), rnd((M,), 205).to(DEV)
+    res = rnd((M, N), 204).to(DEV, out_dtype)
     C2 = torch.ones((M, N), dtype=out_dtype, device=DEV)
-    ops.gemm(Ad, Bd, C2, M, N, K, lda=Kp, ldb=Kp, ldc=N, bias=bias, residual=res, ldr=N, act=1, accumulate=True)
-    ref2 = F.gelu(ref + bias.cpu().double()) + res.cpu().double() + 1.0
+    ops.gemm(Ad, Bd, C2, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=N, bias=bias, rowvec=rowvec, residual=res, ldr=N,
+             accumulate=True)
+    ref2 = ref + bias.cpu().double() + rowvec.cpu().double()[:, None] + res.cpu().double() + 1.0
     assert rel_err(C2.float(), ref2) < (2e-2 if out_dtype == torch.bfloat16 else 1e-4)
+    C3 = torch.empty((M, N), dtype=out_dtype, device=DEV)
+    ops.gemm(Ad, Bd, C3, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=N, bias=bias, act=1)
+    assert rel_err(C3.float(), F.gelu(ref + bias.cpu().double())) < (2e-2 if out_dtype == torch.bfloat16 else 1e-4)
+    if out_dtype == torch.float32:   # split-K through the workspace, slices reduced on the host
+        ws = torch.full((3, M, N), float("nan"), device=DEV)
+        ops.gemm(Ad, Bd, ws, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=N, split_k=3, split_stride=M * N)
+        nk = (K + 63) // 64
+        per = (nk + 2) // 3
+        used = (nk + per - 1) // per
+        assert rel_err(ws[:used].sum(0), ref) < tol
+
+
+def test_gemm_256_matches_128_on_model_shapes(monkeypatch):
+    """forward / dX / dW products of one transformer layer at T = 1028 tokens: the two kernels agree to bf16 rounding"""
+    ops = _ops()
+    T_, H, I = 1028, 768, 3072
+    x = rnd((T_, H), 210).to(DEV, torch.bfloat16)
+    w = (0.05 * rnd((2 * I, H), 211)).to(DEV, torch.bfloat16)
+    dy = rnd((T_, 2 * I), 212).to(DEV, torch.bfloat16)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MUSE_GEMM256", mode)
+        ops._WGRAD_PLAN.clear()
+        y = ops.linear(x, w)
+        dx = ops.linear_dgrad(dy, w)
+        dw = torch.zeros((2 * I, H), device=DEV)
+        ops.linear_wgrad(dy, x, dw, False)
+        outs[mode] = (y.float(), dx.float(), dw)
+    ops._WGRAD_PLAN.clear()
+    for a, b in zip(outs["0"], outs["1"]):
+        assert rel_err(a, b) < 1e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
