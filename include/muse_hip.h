@@ -167,12 +167,23 @@ int muse_conv2d_nhwc(const void* in, const void* weight, const float* bias, cons
 int muse_conv2d_nhwc_split(const float* in, const void* w_hi, const void* w_lo, const float* bias, const float* residual,
                            float* out, int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS,
                            int32_t upsample, void* stream);
+/* The same convolution for the 3x3 layers whose input comes out of GroupNorm+SiLU (conv1 / conv2 of every ResnetBlock
+ * :73-80, conv_out :189): the activation arrives pre-split as two bf16 NHWC planes (muse_groupnorm_silu_nhwc_split) and all
+ * operands go global -> LDS by DMA (csrc/conv_dma.hip).  Results are bit-identical to muse_conv2d_nhwc_split on the f32
+ * tensor hi + lo came from.  KS == 3, Cin % 32 == 0, Cout % 4 == 0, each plane < 4 GiB. */
+int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
+                            const float* residual, float* out, int32_t batch, int32_t H, int32_t W, int32_t Cin,
+                            int32_t Cout, int32_t KS, void* stream);
 /* GroupNorm(32, eps, affine) + SiLU (muse/modeling_maskgit_vqgan.py:61,73-78,186-187,236-237).
  * stats: partial [B, nchunk, G, 2] f64 -> apply.  `partial` needs B*nchunk*G*2 doubles (nchunk from _nchunk). */
 int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, const float* gamma, const float* beta,
                              double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
                              int32_t apply_silu, void* stream);
 int muse_groupnorm_nchunk(int32_t HW);
+/* f32 in; output as y_hi = bf16(y), y_lo = bf16(y - y_hi) (two [B, HW, C] bf16 planes) for muse_conv2d_nhwc_split2 */
+int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta,
+                                   double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
+                                   int32_t apply_silu, void* stream);
 int muse_avgpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t C,
                          void* stream); /* F.avg_pool2d(2,2), :112; H,W = input dims */
 /* layout / dtype conversion: NCHW f32 <-> NHWC (f32|bf16), channel padding with zeros up to Cpad */

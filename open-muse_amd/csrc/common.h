@@ -22,6 +22,15 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){lo, hi}, bf16x2_));
 }
 
+// bf16x3 operand split of 4 floats: hi = bf16(x), lo = bf16(x - hi)  (conv_split.hip / conv_dma.hip / GroupNorm split output)
+__device__ __forceinline__ void split4(const u32x4& v, u32x2& hi, u32x2& lo) {
+  const float x0 = __uint_as_float(v[0]), x1 = __uint_as_float(v[1]), x2 = __uint_as_float(v[2]), x3 = __uint_as_float(v[3]);
+  hi[0] = pack2_bf16(x0, x1);
+  hi[1] = pack2_bf16(x2, x3);
+  lo[0] = pack2_bf16(x0 - __uint_as_float(hi[0] << 16), x1 - __uint_as_float(hi[0] & 0xffff0000u));
+  lo[1] = pack2_bf16(x2 - __uint_as_float(hi[1] << 16), x3 - __uint_as_float(hi[1] & 0xffff0000u));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }

@@ -1,0 +1,253 @@
+// "bf16x3" 3x3 SAME convolution (see conv_split.hip for the numerics) as an LDS-DMA implicit GEMM: the activations arrive
+// PRE-SPLIT into two bf16 NHWC planes x_hi / x_lo (written by the GroupNorm+SiLU kernel that produces every 3x3 conv input
+// of the VQGAN - same bytes as one f32 plane), the weights as the usual w_hi / w_lo images, and all four operand images go
+// global -> LDS by `buffer_load_dwordx4 ... lds` with no VGPR staging, no in-kernel split and no ds_write.
+//
+//   tile 256 pixels x 128 output channels x 32 k; 8 waves (4 M x 2 N), wave tile 64 x 64 (4 x 4 MFMA fragments, 3 MFMAs per
+//   fragment pair: lo*hi, hi*lo, hi*hi in the order conv_split.hip uses -> bit-identical results).
+//   One stage = x_hi [256][64 B] + x_lo + w_hi [128][64 B] + w_lo = 48 KiB; three stages (144 KiB), one block per CU.
+//   64-byte LDS rows: 16-byte chunk c of row r sits at chunk c ^ s((r >> 2) & 3), s = {0,3,2,1}: every 16-lane group of a
+//   ds_read_b128 fragment read covers the 64 banks once (swizzle applied to the per-lane DMA source offset).
+//   im2col gather: K-tile kt is tap (ky,kx) = kt / (Cin/32), channels (kt % (Cin/32)) * 32 ..+31; a lane's DMA offset is
+//   center(pixel) + delta(tap) or an out-of-range offset (zero fill) when the tap falls in the SAME padding.
+//   Pipeline per K-tile t (registers double-buffered, stage = t % 3):
+//       wait vmcnt(6) lgkmcnt(0) ; s_barrier        tile t+1 has landed everywhere, tile t's fragments are in registers
+//       DMA tile t+3 -> stage t % 3 (just drained), 16 fragment reads of tile t+1, 48 MFMAs of tile t - interleaved
+//   so each DMA has two K-tiles of MFMA time to land and each fragment read one.
+#include "gemm256.h"
+#include "../../include/muse_hip.h"
+
+namespace cdma {
+using g256::lds_read128;
+using g256::lds_void_t;
+
+constexpr int BM = 256, BN = 128, BK = 32, NT = 512, MI = 4, NI = 4, NSTAGE = 3;
+constexpr int AH = 0, AL = 16384, BH = 32768, BL = 40960, STAGE = 49152, LDS_BYTES = NSTAGE * STAGE;
+
+struct Params {
+  const bf16_t *xh, *xl, *wh, *wl;
+  const float* bias;
+  const float* residual;
+  float* out;
+  int M, N, K, H, W, Cin;
+};
+
+__device__ __forceinline__ int sw4(int q) { return (4 - q) & 3; }
+
+struct Frag16 { bf16x8 ah[MI], al[MI], bh[NI], bl[NI]; };
+
+__global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+  const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int tid_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+  const int m0 = (tid_ / ntn) * BM, n0 = (tid_ % ntn) * BN;   // the N-tiles of one pixel block run side by side (shared L2 lines)
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int H = p.H, W = p.W, Cin = p.Cin;
+
+  // ---- DMA state ----
+  const unsigned bytesA = (unsigned)((long)p.M * Cin * 2);
+  const rsrc_t rs_xh = make_rsrc(p.xh, bytesA), rs_xl = make_rsrc(p.xl, bytesA);
+  const unsigned oobA = (bytesA + 15u) & ~15u;
+  const int srcchunk = (lane & 3) ^ sw4((lane >> 4) & 3);
+  unsigned centerA[2], maskA[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + (2 * wave + j) * 16 + (lane >> 2);
+    const int pix = m % (H * W), y = pix / W, x = pix - y * W;
+    unsigned mask = 0;
+    if (m < p.M) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) mask |= 1u << t;
+      }
+    }
+    maskA[j] = mask;
+    centerA[j] = (unsigned)(((long)m * Cin + srcchunk * 8) * 2);
+  }
+  const int img = wave >> 2;  // this wave's weight image: 0 = hi, 1 = lo
+  const unsigned bytesB = (unsigned)((long)p.N * p.K * 2);
+  const rsrc_t rs_w = make_rsrc(img ? p.wl : p.wh, bytesB);
+  const unsigned oobB = (bytesB + 15u) & ~15u;
+  unsigned voffB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + ((wave & 3) * 2 + j) * 16 + (lane >> 2);
+    voffB[j] = n < p.N ? (unsigned)(((long)n * p.K + srcchunk * 8) * 2) : oobB;
+  }
+  const unsigned kkB = (unsigned)(srcchunk * 8);
+  int tap = 0, cc = 0, kti = 0;   // next K-tile to issue: tap, first channel, index
+
+  auto issue_a = [&](int stage_off, int j) {
+    const int ty = (tap * 11) >> 5, tx = tap - ty * 3;
+    const unsigned delta = (unsigned)((((ty - 1) * W + (tx - 1)) * Cin + cc) * 2);
+    const bool ok = tap < 9 && ((maskA[j] >> tap) & 1u);
+    const unsigned vo = ok ? centerA[j] + delta : oobA;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (lds_void_t*)(smem + stage_off + AH + (2 * wave + j) * 1024), 16, (int)vo, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xl, (lds_void_t*)(smem + stage_off + AL + (2 * wave + j) * 1024), 16, (int)vo, 0, 0, 0);
+  };
+  auto issue_b = [&](int stage_off) {
+    const unsigned kb = (unsigned)kti * 32u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned vo = (kb + kkB) < (unsigned)p.K ? voffB[j] : oobB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + stage_off + BH + img * 8192 + ((wave & 3) * 2 + j) * 1024), 16,
+                                               (int)vo, (int)(kb * 2u), 0, 0);
+    }
+    cc += 32;
+    if (cc >= Cin) { cc = 0; ++tap; }
+    ++kti;
+  };
+
+  // ---- fragment addresses (one per stage: the immediate offset field cannot reach past 64 KiB) ----
+  unsigned addrA[NSTAGE], addrB[NSTAGE];
+  {
+    const int pr = lane & 15, g = lane >> 4, pos = g ^ sw4((pr >> 2) & 3);
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s) {
+      addrA[s] = (unsigned)(s * STAGE + AH + (wm * 64 + pr) * 64 + pos * 16);
+      addrB[s] = (unsigned)(s * STAGE + BH + (wn * 64 + pr) * 64 + pos * 16);
+    }
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Frag16 f0, f1;
+
+  // read #q (0..15) of the tile in stage S into F
+#define CDMA_READ(F, S, Q)                                                                    \
+  {                                                                                           \
+    if constexpr ((Q) < 4) lds_read128<((Q) & 3) * 1024>(F.ah[(Q) & 3], addrA[S]);            \
+    else if constexpr ((Q) < 8) lds_read128<16384 + ((Q) & 3) * 1024>(F.al[(Q) & 3], addrA[S]); \
+    else if constexpr ((Q) < 12) lds_read128<((Q) & 3) * 1024>(F.bh[(Q) & 3], addrB[S]);      \
+    else lds_read128<8192 + ((Q) & 3) * 1024>(F.bl[(Q) & 3], addrB[S]);                       \
+  }
+#define CDMA_PAIR(F, Q)                                                                                                        \
+  {                                                                                                                            \
+    constexpr int i_ = (Q) >> 2, j_ = (Q) & 3;                                                                                 \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bl[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.al[i_], acc[i_][j_], 0, 0, 0);                            \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
+  }
+  // one (MFMA pair, DMA part, fragment read) slot of tile t: compute from CUR, prefetch tile t+1 (stage SN) into NXT,
+  // DMA tile t+3 into stage S
+#define CDMA_SLOT(CUR, NXT, S, SN, Q)                          \
+  CDMA_PAIR(CUR, Q)                                            \
+  __builtin_amdgcn_sched_barrier(0);                           \
+  if constexpr ((Q) == 0) issue_a((S) * STAGE, 0);             \
+  if constexpr ((Q) == 1) issue_a((S) * STAGE, 1);             \
+  if constexpr ((Q) == 2) issue_b((S) * STAGE);                \
+  CDMA_READ(NXT, SN, Q)                                        \
+  __builtin_amdgcn_sched_barrier(0);
+#define CDMA_TILE(CUR, NXT, S, SN)                                                     \
+  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                          \
+  __builtin_amdgcn_s_barrier();                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  CDMA_SLOT(CUR, NXT, S, SN, 0) CDMA_SLOT(CUR, NXT, S, SN, 1) CDMA_SLOT(CUR, NXT, S, SN, 2) CDMA_SLOT(CUR, NXT, S, SN, 3)     \
+  CDMA_SLOT(CUR, NXT, S, SN, 4) CDMA_SLOT(CUR, NXT, S, SN, 5) CDMA_SLOT(CUR, NXT, S, SN, 6) CDMA_SLOT(CUR, NXT, S, SN, 7)     \
+  CDMA_SLOT(CUR, NXT, S, SN, 8) CDMA_SLOT(CUR, NXT, S, SN, 9) CDMA_SLOT(CUR, NXT, S, SN, 10) CDMA_SLOT(CUR, NXT, S, SN, 11)   \
+  CDMA_SLOT(CUR, NXT, S, SN, 12) CDMA_SLOT(CUR, NXT, S, SN, 13) CDMA_SLOT(CUR, NXT, S, SN, 14) CDMA_SLOT(CUR, NXT, S, SN, 15)
+
+  // prologue: tiles 0, 1, 2 in flight; tile 0's fragments into f0
+  issue_a(0 * STAGE, 0); issue_a(0 * STAGE, 1); issue_b(0 * STAGE);
+  issue_a(1 * STAGE, 0); issue_a(1 * STAGE, 1); issue_b(1 * STAGE);
+  issue_a(2 * STAGE, 0); issue_a(2 * STAGE, 1); issue_b(2 * STAGE);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  CDMA_READ(f0, 0, 0) CDMA_READ(f0, 0, 1) CDMA_READ(f0, 0, 2) CDMA_READ(f0, 0, 3)
+  CDMA_READ(f0, 0, 4) CDMA_READ(f0, 0, 5) CDMA_READ(f0, 0, 6) CDMA_READ(f0, 0, 7)
+  CDMA_READ(f0, 0, 8) CDMA_READ(f0, 0, 9) CDMA_READ(f0, 0, 10) CDMA_READ(f0, 0, 11)
+  CDMA_READ(f0, 0, 12) CDMA_READ(f0, 0, 13) CDMA_READ(f0, 0, 14) CDMA_READ(f0, 0, 15)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // K-tiles beyond K are DMA'd as zeros (out-of-range offsets), so the loop runs whole groups of 6 (3 stages x 2 register sets)
+  const int nkt = (p.K + BK - 1) / BK, ngroups = (nkt + 5) / 6;
+  for (int grp = 0; grp < ngroups; ++grp) {
+    CDMA_TILE(f0, f1, 0, 1)
+    CDMA_TILE(f1, f0, 1, 2)
+    CDMA_TILE(f0, f1, 2, 0)
+    CDMA_TILE(f1, f0, 0, 1)
+    CDMA_TILE(f0, f1, 1, 2)
+    CDMA_TILE(f1, f0, 2, 0)
+  }
+#undef CDMA_TILE
+#undef CDMA_SLOT
+#undef CDMA_PAIR
+#undef CDMA_READ
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing (zero) DMAs and fragment reads are done before LDS / registers are reused
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: + bias, staged through LDS (128 rows per pass), 16-byte row-contiguous stores with the residual added ----
+  constexpr int CST = BN * 4 + 16;  // 528 bytes per staged row
+  float bias_v[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4) + r;
+      bias_v[j][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if ((wm >> 1) == pass) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int lr = (wm & 1) * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int nl = wn * 64 + j * 16 + 4 * (lane >> 4);
+          const f32x4 v = {acc[i][j][0] + bias_v[j][0], acc[i][j][1] + bias_v[j][1], acc[i][j][2] + bias_v[j][2], acc[i][j][3] + bias_v[j][3]};
+          *(f32x4*)(smem + lr * CST + nl * 4) = v;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (128 * 32) / NT; ++it) {
+      const int c = threadIdx.x + NT * it;
+      const int row = c >> 5, col = (c & 31) * 4;
+      const int m = m0 + pass * 128 + row, n = n0 + col;
+      if (m < p.M && n < p.N) {
+        f32x4 w = *(const f32x4*)(smem + row * CST + col * 4);
+        if (p.residual) w += *(const f32x4*)(p.residual + (long)m * p.N + n);
+        *(f32x4*)(p.out + (long)m * p.N + n) = w;
+      }
+    }
+  }
+}
+
+}  // namespace cdma
+
+extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
+                                       const float* residual, float* out, int32_t batch, int32_t H, int32_t W, int32_t Cin,
+                                       int32_t Cout, int32_t KS, void* stream) {
+  if (KS != 3) return MUSE_ERR_UNSUPPORTED;
+  if ((Cin % 32) || (Cout % 4)) return MUSE_ERR_ALIGN;
+  if ((((uintptr_t)in_hi) | ((uintptr_t)in_lo) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)out) | ((uintptr_t)residual)) & 15)
+    return MUSE_ERR_ALIGN;
+  const long M = (long)batch * H * W;
+  if (M <= 0 || Cout <= 0) return 0;
+  // 32-bit buffer offsets: each plane / weight image must stay below 4 GiB (and M below 2^31)
+  if (M * Cin * 2 >= (1L << 32) - 64 || (long)Cout * 9 * Cin * 2 >= (1L << 32) - 64 || M >= (1L << 31) - 256) return MUSE_ERR_UNSUPPORTED;
+  cdma::Params p;
+  p.xh = (const bf16_t*)in_hi; p.xl = (const bf16_t*)in_lo; p.wh = (const bf16_t*)w_hi; p.wl = (const bf16_t*)w_lo;
+  p.bias = bias; p.residual = residual; p.out = out;
+  p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.H = H; p.W = W; p.Cin = Cin;
+  const int ntm = (p.M + cdma::BM - 1) / cdma::BM, ntn = (p.N + cdma::BN - 1) / cdma::BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)cdma::conv_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cdma::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cdma::conv_dma_kernel, dim3(ntm * ntn), dim3(512), cdma::LDS_BYTES, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}

@@ -11,14 +11,6 @@
 #include "gemm_core.h"
 #include "../../include/muse_hip.h"
 
-__device__ __forceinline__ void split4(const u32x4& v, u32x2& hi, u32x2& lo) {
-  const float x0 = __uint_as_float(v[0]), x1 = __uint_as_float(v[1]), x2 = __uint_as_float(v[2]), x3 = __uint_as_float(v[3]);
-  hi[0] = pack2_bf16(x0, x1);
-  hi[1] = pack2_bf16(x2, x3);
-  lo[0] = pack2_bf16(x0 - __uint_as_float(hi[0] << 16), x1 - __uint_as_float(hi[0] & 0xffff0000u));
-  lo[1] = pack2_bf16(x2 - __uint_as_float(hi[1] << 16), x3 - __uint_as_float(hi[1] & 0xffff0000u));
-}
-
 struct SplitParams {
   GemmParams g;      // A = f32 NHWC input, B = weight hi image, C = f32 output
   const void* Blo;   // weight lo image

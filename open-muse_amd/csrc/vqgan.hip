@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const double* __restrict__ partial,
-                                                       int HW, int C, int G, int nchunk, float eps, int silu) {
+                                                       int HW, int C, int G, int nchunk, float eps, int silu,
+                                                       bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo) {
   __shared__ float sc[2048], sh[2048];
   __shared__ float gmean[64], grstd[64];
   const int chunk = blockIdx.x, b = blockIdx.y;
@@ -155,6 +156,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         if (silu) t = t * __frcp_rn(1.0f + __expf(-t));
         v[j] = t;
       }
+      if constexpr (VEC == 4) {
+        if (y_hi) {  // bf16x3 operand planes for the LDS-DMA convolution (conv_dma.hip) instead of the f32 tensor
+          const u32x4 raw = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+          u32x2 hi, lo;
+          split4(raw, hi, lo);
+          *(u32x2*)(y_hi + off) = hi;
+          *(u32x2*)(y_lo + off) = lo;
+          continue;
+        }
+      }
       storev<T, VEC>(y + off, v);
     }
   } else {
@@ -189,12 +200,29 @@ extern "C" int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, c
   if (dtype == MUSE_F32) {
     hipLaunchKernelGGL((gn_stats_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, partial, HW, C, groups);
     hipLaunchKernelGGL((gn_apply_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, (float*)y, gamma, beta,
-                       (const double*)partial, HW, C, groups, nchunk, eps, apply_silu);
+                       (const double*)partial, HW, C, groups, nchunk, eps, apply_silu, (bf16_t*)nullptr, (bf16_t*)nullptr);
   } else {
     hipLaunchKernelGGL((gn_stats_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, partial, HW, C, groups);
     hipLaunchKernelGGL((gn_apply_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, gamma, beta,
-                       (const double*)partial, HW, C, groups, nchunk, eps, apply_silu);
+                       (const double*)partial, HW, C, groups, nchunk, eps, apply_silu, (bf16_t*)nullptr, (bf16_t*)nullptr);
   }
+  return (int)hipGetLastError();
+}
+
+// f32 input, output as the two bf16 planes y_hi = bf16(y), y_lo = bf16(y - y_hi) the bf16x3 LDS-DMA convolution reads
+extern "C" int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta,
+                                              double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
+                                              int32_t apply_silu, void* stream) {
+  if (groups > 64 || C > 1024 || (C % groups) || (C % 4)) return MUSE_ERR_UNSUPPORTED;
+  const int vpp = C / 4;
+  if (256 % vpp) return MUSE_ERR_UNSUPPORTED;  // (the split store lives in the one-vector-per-thread loop)
+  if (batch <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = muse_groupnorm_nchunk(HW);
+  dim3 grid(nchunk, batch);
+  hipLaunchKernelGGL((gn_stats_kernel<float, 4>), grid, dim3(256), 0, s, x, partial, HW, C, groups);
+  hipLaunchKernelGGL((gn_apply_kernel<float, 4>), grid, dim3(256), 0, s, x, (float*)nullptr, gamma, beta, (const double*)partial,
+                     HW, C, groups, nchunk, eps, apply_silu, (bf16_t*)y_hi, (bf16_t*)y_lo);
   return (int)hipGetLastError();
 }
 

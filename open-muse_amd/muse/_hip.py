@@ -75,6 +75,10 @@ SIGNATURES = {
                          c_int, c_int, c_void_p],
     "muse_conv2d_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_void_p],
+    "muse_conv2d_nhwc_split2": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_void_p],
+    "muse_groupnorm_silu_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_float, c_int, c_void_p],
     "muse_groupnorm_silu_nhwc": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_float, c_int, c_void_p],
     "muse_groupnorm_nchunk": [c_int],

@@ -134,6 +134,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         self.decoder = _Decoder(self.config)
         self.quantize = _Quantizer(num_embeddings, quantized_embed_dim)
         self.compute_dtype = torch.float32
+        self.dma_conv = True   # "bf16x3" mode: 3x3 convs after GroupNorm run as the LDS-DMA kernel on pre-split planes
         self._packed = {}
 
     # ---- weight packing: [Cout,Cin,k,k] -> [Cout,k,k,Cin_pad] in the compute dtype ------------------------------------
@@ -181,6 +182,8 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
 
     def _conv(self, x, conv, B, H, W, cd, residual=None, upsample=False):
         wp, cp, cout, k, bias = self._w(conv, cd)
+        if isinstance(x, tuple):   # (hi, lo) planes from _gn_for: the LDS-DMA bf16x3 convolution
+            return ops.conv2d_nhwc_split2(x[0], x[1], wp[0], wp[1], B, H, W, cp, cout, bias=bias, residual=residual)
         if cd == "bf16x3":
             return ops.conv2d_nhwc_split(x, wp[0], wp[1], B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
         return ops.conv2d_nhwc(x, wp, B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
@@ -188,13 +191,21 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
     def _gn(self, x, norm: _Norm, B, HW, C):
         return ops.groupnorm_silu_nhwc(x, norm.weight.data, norm.bias.data, B, HW, C, groups=32, eps=1e-6, silu=True)
 
+    def _gn_for(self, x, norm: _Norm, conv: _Conv, B, H, W, cd):
+        """GroupNorm+SiLU feeding `conv`: in "bf16x3" mode the result is written directly as the (hi, lo) bf16 operand
+        planes of the LDS-DMA convolution when the layer qualifies (3x3, Cin % 32 == 0)"""
+        cout, cin, k, _ = conv.weight.shape
+        if cd == "bf16x3" and self.dma_conv and ops.conv_split2_ok(B, H, W, cin, cout, k) and (256 % (cin // 4)) == 0:
+            return ops.groupnorm_silu_nhwc_split(x, norm.weight.data, norm.bias.data, B, H * W, cin, groups=32, eps=1e-6, silu=True)
+        return self._gn(x, norm, B, H * W, cin)
+
     def _res(self, x, blk: _Res, B, H, W, cd):
         cin = blk.conv1.weight.shape[1]
         cout = blk.conv1.weight.shape[0]
-        h = self._conv(self._gn(x, blk.norm1, B, H * W, cin), blk.conv1, B, H, W, cd)
+        h = self._conv(self._gn_for(x, blk.norm1, blk.conv1, B, H, W, cd), blk.conv1, B, H, W, cd)
         if cin == cout:
-            return self._conv(self._gn(h, blk.norm2, B, H * W, cout), blk.conv2, B, H, W, cd, residual=x)
-        h = self._conv(self._gn(h, blk.norm2, B, H * W, cout), blk.conv2, B, H, W, cd)
+            return self._conv(self._gn_for(h, blk.norm2, blk.conv2, B, H, W, cd), blk.conv2, B, H, W, cd, residual=x)
+        h = self._conv(self._gn_for(h, blk.norm2, blk.conv2, B, H, W, cd), blk.conv2, B, H, W, cd)
         # reference quirk (:82-85): the "shortcut" is a 1x1 conv of the conv2 output, out = h + nin(h)
         return self._conv(h, blk.nin_shortcut, B, H, W, cd, residual=h)
 
@@ -221,7 +232,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
                 H, W = H // 2, W // 2
         for blk in enc.mid:
             h = self._res(h, blk, B, H, W, cd)
-        h = self._gn(h, enc.norm_out, B, H * W, h.shape[-1])
+        h = self._gn_for(h, enc.norm_out, enc.conv_out, B, H, W, cd)
         z = self._conv(h, enc.conv_out, B, H, W, cd)
         z = z.view(B * H * W, -1)
         if z.dtype != torch.float32:
@@ -244,7 +255,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
             if lvl != 0:
                 H, W = H * 2, W * 2
                 h = self._conv(h, up.upsample_conv, B, H, W, cd, upsample=True)
-        h = self._gn(h, dec.norm_out, B, H * W, h.shape[-1])
+        h = self._gn_for(h, dec.norm_out, dec.conv_out, B, H, W, cd)
         out = self._conv(h, dec.conv_out, B, H, W, cd)
         return ops.nhwc_to_nchw(out, self.config.num_channels)
 

@@ -445,6 +445,36 @@ def conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=None, residual
     return out
 
 
+def conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=None, residual=None):
+    """3x3 bf16x3 convolution on pre-split activation planes, operands by LDS-DMA (see muse_conv2d_nhwc_split2)"""
+    require_gpu(x_hi, x_lo, w_hi, w_lo)
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x_hi.device)
+    e0 = _prof_begin()
+    check(lib().muse_conv2d_nhwc_split2(x_hi.data_ptr(), x_lo.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(), ptr(bias),
+                                        ptr(residual), out.data_ptr(), B, H, W, Cin, Cout, 3, stream()), "muse_conv2d_nhwc_split2")
+    _prof_end(e0, "conv_bf16x3_dma", 2.0 * B * H * W * Cout * 9 * Cin)
+    return out
+
+
+def conv_split2_ok(B, H, W, Cin, Cout, KS):
+    """shapes muse_conv2d_nhwc_split2 takes (the rest stay on muse_conv2d_nhwc_split)"""
+    M = B * H * W
+    return KS == 3 and Cin % 32 == 0 and Cout % 4 == 0 and M * Cin * 2 < (1 << 32) - 64 and M < (1 << 31) - 256
+
+
+def groupnorm_silu_nhwc_split(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, silu=True):
+    """GroupNorm + SiLU of an f32 NHWC tensor, returned as the (hi, lo) bf16 planes of the result"""
+    require_gpu(x, gamma, beta)
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    nchunk = lib().muse_groupnorm_nchunk(HW)
+    part = torch.empty(B * nchunk * groups * 2, dtype=torch.float64, device=x.device)
+    check(lib().muse_groupnorm_silu_nhwc_split(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                               part.data_ptr(), B, HW, C, groups, eps, 1 if silu else 0, stream()),
+          "muse_groupnorm_silu_nhwc_split")
+    return hi, lo
+
+
 def groupnorm_silu_nhwc(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, silu=True):
     require_gpu(x, gamma, beta)
     y = torch.empty_like(x)

@@ -44,6 +44,16 @@ if "conv" in which:
     wh, wl = ops.split_bf16(w)
     fl = 2.0 * B * Hh * Ww * C * 9 * C
     timeit("conv bf16x3 64x128x128x128 3x3", lambda: ops.conv2d_nhwc_split(xi, wh, wl, B, Hh, Ww, C, C, 3), fl)
+    xh, xl = ops.split_bf16(xi)
+    timeit("conv bf16x3 DMA 64x128x128x128 3x3", lambda: ops.conv2d_nhwc_split2(xh, xl, wh, wl, B, Hh, Ww, C, C), fl)
+    for (b2, h2, c2) in ((16, 256, 128), (64, 64, 256), (64, 16, 512)):
+        x2 = torch.randn(b2, h2, h2, c2, device=dev)
+        w2 = torch.randn(c2, 3, 3, c2, device=dev) * 0.03
+        w2h, w2l = ops.split_bf16(w2)
+        x2h, x2l = ops.split_bf16(x2)
+        fl2 = 2.0 * b2 * h2 * h2 * c2 * 9 * c2
+        timeit(f"conv bf16x3     {b2}x{h2}x{h2}x{c2}", lambda: ops.conv2d_nhwc_split(x2, w2h, w2l, b2, h2, h2, c2, c2, 3), fl2)
+        timeit(f"conv bf16x3 DMA {b2}x{h2}x{h2}x{c2}", lambda: ops.conv2d_nhwc_split2(x2h, x2l, w2h, w2l, b2, h2, h2, c2, c2), fl2)
     timeit("conv f32    64x128x128x128 3x3", lambda: ops.conv2d_nhwc(xi, w, B, Hh, Ww, C, C, 3), fl)
     xb, wb = xi.to(torch.bfloat16), w.to(torch.bfloat16)
     timeit("conv bf16   64x128x128x128 3x3", lambda: ops.conv2d_nhwc(xb, wb, B, Hh, Ww, C, C, 3), fl)

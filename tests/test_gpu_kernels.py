@@ -424,6 +424,42 @@ def test_conv2d_split_bf16x3(Cin, Cout, KS, ups, bias, res):
     assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < 3e-5, (Cin, Cout, KS, ups)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,bias,res", [
+    (2, 12, 10, 32, 64, True, False),      # one partial pixel tile, one partial channel tile
+    (1, 16, 16, 64, 36, False, True),      # exactly one pixel tile, ragged Cout
+    (3, 20, 24, 128, 128, True, True),     # several pixel tiles (last ragged), Cin = 128 -> 36 K-tiles (6 groups)
+    (2, 8, 8, 96, 260, True, False),       # Cin not a power of two, 27 K-tiles (padded to 30), three channel tiles
+    (1, 32, 32, 256, 256, False, True),
+])
+def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
+    """the LDS-DMA bf16x3 convolution on pre-split planes is BIT-identical to the register-staged bf16x3 kernel on the f32
+    tensor the planes came from (same products, same accumulation order), and the planes GroupNorm writes are the split
+    of the tensor GroupNorm writes"""
+    ops = _ops()
+    x = rnd((B, H, W, Cin), 180).to(DEV)
+    w = (rnd((Cout, 3, 3, Cin), 181) / math.sqrt(9 * Cin)).to(DEV)
+    w_hi, w_lo = ops.split_bf16(w)
+    x_hi, x_lo = ops.split_bf16(x)
+    bvec = rnd((Cout,), 182).to(DEV) if bias else None
+    rr = rnd((B, H, W, Cout), 183).to(DEV) if res else None
+    assert ops.conv_split2_ok(B, H, W, Cin, Cout, 3)
+    ref = ops.conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, 3, bias=bvec, residual=rr)
+    got = ops.conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=bvec, residual=rr)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    ref64 = F.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.cpu().double().permute(0, 3, 1, 2), bvec.cpu().double() if bias else None, padding=1)
+    if res:
+        ref64 = ref64 + rr.cpu().double().permute(0, 3, 1, 2)
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref64) < 3e-5
+    # GroupNorm + SiLU with split output == split of the f32 output
+    if 256 % (Cin // 4):
+        return   # (channel counts the GroupNorm kernel does not take)
+    gam, bet = (1 + 0.1 * rnd((Cin,), 184)).to(DEV), (0.1 * rnd((Cin,), 185)).to(DEV)
+    y = ops.groupnorm_silu_nhwc(x, gam, bet, B, H * W, Cin)
+    y_hi, y_lo = ops.groupnorm_silu_nhwc_split(x, gam, bet, B, H * W, Cin)
+    e_hi, e_lo = ops.split_bf16(y)
+    assert torch.equal(y_hi.view(torch.int16), e_hi.view(torch.int16)) and torch.equal(y_lo.view(torch.int16), e_lo.view(torch.int16))
+
+
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (520, 264, 200), (1000, 520, 712), (264, 776, 64)])
