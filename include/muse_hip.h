@@ -172,18 +172,23 @@ int muse_conv2d_nhwc_split(const float* in, const void* w_hi, const void* w_lo, 
  * operands go global -> LDS by DMA (csrc/conv_dma.hip).  Results are bit-identical to muse_conv2d_nhwc_split on the f32
  * tensor hi + lo came from.  KS == 3, Cin % 32 == 0, Cout % 4 == 0, each plane < 4 GiB. */
 int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
-                            const float* residual, float* out, int32_t batch, int32_t H, int32_t W, int32_t Cin,
-                            int32_t Cout, int32_t KS, void* stream);
+                            const float* residual, float* out, double* gn_partial, int32_t gn_groups, int32_t batch,
+                            int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, void* stream);
+/*   gn_partial != NULL: the epilogue also writes the GroupNorm(gn_groups) sum / sum-of-squares of its output (bias and
+ *   residual included) per (image, 256-pixel tile, group) as [B, H*W/256, gn_groups, 2] f64 - the statistics pass of the
+ *   GroupNorm that consumes this tensor (muse_groupnorm_silu_nhwc_split with stats_nchunk = H*W/256) then never reads it.
+ *   Needs H*W % 256 == 0 and Cout/gn_groups a power of two in [4, 128]. */
 /* GroupNorm(32, eps, affine) + SiLU (muse/modeling_maskgit_vqgan.py:61,73-78,186-187,236-237).
  * stats: partial [B, nchunk, G, 2] f64 -> apply.  `partial` needs B*nchunk*G*2 doubles (nchunk from _nchunk). */
 int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, const float* gamma, const float* beta,
                              double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
                              int32_t apply_silu, void* stream);
 int muse_groupnorm_nchunk(int32_t HW);
-/* f32 in; output as y_hi = bf16(y), y_lo = bf16(y - y_hi) (two [B, HW, C] bf16 planes) for muse_conv2d_nhwc_split2 */
+/* f32 in; output as y_hi = bf16(y), y_lo = bf16(y - y_hi) (two [B, HW, C] bf16 planes) for muse_conv2d_nhwc_split2.
+ * stats_nchunk == 0: statistics computed here into `partial`; > 0: `partial` = [B, stats_nchunk, G, 2] already filled. */
 int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta,
-                                   double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
-                                   int32_t apply_silu, void* stream);
+                                   double* partial, int32_t stats_nchunk, int32_t batch, int32_t HW, int32_t C,
+                                   int32_t groups, float eps, int32_t apply_silu, void* stream);
 int muse_avgpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t C,
                          void* stream); /* F.avg_pool2d(2,2), :112; H,W = input dims */
 /* layout / dtype conversion: NCHW f32 <-> NHWC (f32|bf16), channel padding with zeros up to Cpad */

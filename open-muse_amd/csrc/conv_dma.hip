@@ -29,6 +29,8 @@ struct Params {
   const float* bias;
   const float* residual;
   float* out;
+  double* gn_partial;  // optional: per (image, 256-pixel tile, group) sum / sum-of-squares of the output, for the next GroupNorm
+  int gn_cpg, gn_groups;
   int M, N, K, H, W, Cin;
 };
 
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
     else if constexpr ((Q) < 12) lds_read128<((Q) & 3) * 1024>(F.bh[(Q) & 3], addrB[S]);      \
     else lds_read128<8192 + ((Q) & 3) * 1024>(F.bl[(Q) & 3], addrB[S]);                       \
   }
+#ifndef CDMA_ABLATE_NO_MFMA
 #define CDMA_PAIR(F, Q)                                                                                                        \
   {                                                                                                                            \
     constexpr int i_ = (Q) >> 2, j_ = (Q) & 3;                                                                                 \
@@ -136,18 +139,29 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
     acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.al[i_], acc[i_][j_], 0, 0, 0);                            \
     acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
   }
+#else  // timing experiments only (scripts/exp): keep the fragment registers live, issue no MFMA
+#define CDMA_PAIR(F, Q) asm volatile("" ::"v"(F.ah[(Q) >> 2]), "v"(F.al[(Q) >> 2]), "v"(F.bh[(Q) & 3]), "v"(F.bl[(Q) & 3]));
+#endif
+#ifndef CDMA_ABLATE_NO_DMA
+#define CDMA_ISSUE(S, Q)                             \
+  if constexpr ((Q) == 0) issue_a((S) * STAGE, 0);   \
+  if constexpr ((Q) == 1) issue_a((S) * STAGE, 1);   \
+  if constexpr ((Q) == 2) issue_b((S) * STAGE);
+#define CDMA_TOP_WAIT "s_waitcnt vmcnt(6) lgkmcnt(0)"
+#else
+#define CDMA_ISSUE(S, Q)
+#define CDMA_TOP_WAIT "s_waitcnt vmcnt(0) lgkmcnt(0)"
+#endif
   // one (MFMA pair, DMA part, fragment read) slot of tile t: compute from CUR, prefetch tile t+1 (stage SN) into NXT,
   // DMA tile t+3 into stage S
 #define CDMA_SLOT(CUR, NXT, S, SN, Q)                          \
   CDMA_PAIR(CUR, Q)                                            \
   __builtin_amdgcn_sched_barrier(0);                           \
-  if constexpr ((Q) == 0) issue_a((S) * STAGE, 0);             \
-  if constexpr ((Q) == 1) issue_a((S) * STAGE, 1);             \
-  if constexpr ((Q) == 2) issue_b((S) * STAGE);                \
+  CDMA_ISSUE(S, Q)                                             \
   CDMA_READ(NXT, SN, Q)                                        \
   __builtin_amdgcn_sched_barrier(0);
 #define CDMA_TILE(CUR, NXT, S, SN)                                                     \
-  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                          \
+  asm volatile(CDMA_TOP_WAIT ::: "memory");                                            \
   __builtin_amdgcn_s_barrier();                                                        \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   CDMA_SLOT(CUR, NXT, S, SN, 0) CDMA_SLOT(CUR, NXT, S, SN, 1) CDMA_SLOT(CUR, NXT, S, SN, 2) CDMA_SLOT(CUR, NXT, S, SN, 3)     \
@@ -179,6 +193,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
     CDMA_TILE(f1, f0, 2, 0)
   }
 #undef CDMA_TILE
+#undef CDMA_ISSUE
+#undef CDMA_TOP_WAIT
 #undef CDMA_SLOT
 #undef CDMA_PAIR
 #undef CDMA_READ
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
       const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4) + r;
       bias_v[j][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
+  double gs = 0.0, gq = 0.0;   // GroupNorm statistics of this thread's column chunk (4 channels = part of one group)
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
@@ -220,6 +237,33 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
         f32x4 w = *(const f32x4*)(smem + row * CST + col * 4);
         if (p.residual) w += *(const f32x4*)(p.residual + (long)m * p.N + n);
         *(f32x4*)(p.out + (long)m * p.N + n) = w;
+        if (p.gn_partial) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gs += (double)w[e]; gq += (double)w[e] * (double)w[e]; }
+        }
+      }
+    }
+  }
+  // GroupNorm partials: the tile's 256 pixels belong to one image (host guarantees H*W % 256 == 0); thread t owns column
+  // chunk t & 31 in every iteration above -> fold the 16 threads per chunk, then the chunks of each group, in a fixed order.
+  if (p.gn_partial) {
+    gs += __shfl_xor(gs, 32, 64);
+    gq += __shfl_xor(gq, 32, 64);
+    __syncthreads();
+    double* red = (double*)smem;   // [8 waves][32 chunks][2]
+    if (lane < 32) { red[(wave * 32 + lane) * 2] = gs; red[(wave * 32 + lane) * 2 + 1] = gq; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      double cs = 0.0, cq = 0.0;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) { cs += red[(w8 * 32 + threadIdx.x) * 2]; cq += red[(w8 * 32 + threadIdx.x) * 2 + 1]; }
+      const int cpc = p.gn_cpg >> 2;   // column chunks per group (1, 2, 4, 8)
+      for (int o = 1; o < cpc; o <<= 1) { cs += __shfl_xor(cs, o, 64); cq += __shfl_xor(cq, o, 64); }
+      const int n = n0 + (int)threadIdx.x * 4;
+      if ((threadIdx.x & (cpc - 1)) == 0 && n < p.N) {
+        const int hw = p.H * p.W, b = m0 / hw, chunk = (m0 - b * hw) >> 8, nchunk = hw >> 8;
+        double* o2 = p.gn_partial + (((long)b * nchunk + chunk) * p.gn_groups + n / p.gn_cpg) * 2;
+        o2[0] = cs; o2[1] = cq;
       }
     }
   }
@@ -228,8 +272,8 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
 }  // namespace cdma
 
 extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
-                                       const float* residual, float* out, int32_t batch, int32_t H, int32_t W, int32_t Cin,
-                                       int32_t Cout, int32_t KS, void* stream) {
+                                       const float* residual, float* out, double* gn_partial, int32_t gn_groups, int32_t batch,
+                                       int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, void* stream) {
   if (KS != 3) return MUSE_ERR_UNSUPPORTED;
   if ((Cin % 32) || (Cout % 4)) return MUSE_ERR_ALIGN;
   if ((((uintptr_t)in_hi) | ((uintptr_t)in_lo) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)out) | ((uintptr_t)residual)) & 15)
@@ -241,6 +285,11 @@ extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, con
   cdma::Params p;
   p.xh = (const bf16_t*)in_hi; p.xl = (const bf16_t*)in_lo; p.wh = (const bf16_t*)w_hi; p.wl = (const bf16_t*)w_lo;
   p.bias = bias; p.residual = residual; p.out = out;
+  p.gn_partial = gn_partial; p.gn_groups = gn_groups; p.gn_cpg = gn_groups > 0 ? Cout / gn_groups : 0;
+  if (gn_partial) {  // fused GroupNorm statistics: whole 256-pixel tiles per image, groups of 4 * 2^k channels inside one 128-channel tile
+    const int cpg = p.gn_cpg;
+    if (gn_groups <= 0 || (Cout % gn_groups) || ((H * W) % 256) || cpg < 4 || cpg > 128 || (cpg & (cpg - 1))) return MUSE_ERR_UNSUPPORTED;
+  }
   p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.H = H; p.W = W; p.Cin = Cin;
   const int ntm = (p.M + cdma::BM - 1) / cdma::BM, ntn = (p.N + cdma::BN - 1) / cdma::BN;
   static bool attr_set = false;

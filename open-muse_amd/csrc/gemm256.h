@@ -193,24 +193,200 @@ struct Pipe {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+#ifndef G256_ABLATE_NO_DMA
       if (kt + 2 < kt_last) {
         da.template issue<A_BASE + S * TILE>(smem, kt + 2, wave);
         db.template issue<B_BASE + S * TILE>(smem, kt + 2, wave);
       }
+#endif
       fb.template read_range<S ^ 1, 0, 0, NI>(bk[0]);  // (after the last tile: a stale stage, never used)
     }
     if constexpr (G == GB1) fb.template read_range<S, 1, 0, NI>(bk[1]);
     read_a<S, G + DIST>();
     wait_lgkm<waitN(G)>();
+#ifndef G256_ABLATE_NO_MFMA
 #pragma unroll
     for (int j = 0; j < NI; ++j)
       acc[G & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j], 0, 0, 0);
+#else
+    asm volatile("" ::"v"(ring[G & (NSLOT - 1)]), "v"(bk[G >> 3][0]), "v"(bk[G >> 3][1]), "v"(bk[G >> 3][2]), "v"(bk[G >> 3][3]));
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (G + 1 < 16) group<S, G + 1>(kt, kt_last);
   }
 };
 
-template <typename TC, int AL, int BL>
+// =====================================================================================================================
+// BK = 32 variant with five 32 KiB stages (160 KiB of LDS): three K-tiles of DMA in flight instead of one.
+// Ablation of the BK = 64 / 2-stage pipeline (scripts/exp/ablate256.sh, [16384x3072]x[6144x3072]^T): 594 us full,
+// 467 us without the in-loop DMA, 342 us without the MFMAs, 153 us with neither - the DMA stream alone runs at 1.19 us per
+// 64-wide K-tile although its bytes need 0.52 us of the CU's vector-memory path: with one stage in flight it is bound by
+// issue -> landed latency (Little: 64 KiB in flight per CU vs ~75 KiB needed at MFMA speed).  Same wave tiling, same
+// ring, same waits; per K-tile: 8 MFMA groups, barrier before group 5, `vmcnt(8)` (tiles t+2, t+3 stay in flight).
+// 64-byte LDS rows for k-contiguous operands: chunk c of row r at chunk c ^ s4((r >> 2) & 3), s4 = {0,3,2,1}.
+// =====================================================================================================================
+constexpr int BK32 = 32, NST32 = 5, TILE32 = 16384, STAGE32 = 32768, LDS_BYTES32 = NST32 * STAGE32;
+__device__ __forceinline__ int sw4(int q) { return (4 - q) & 3; }
+
+template <int L>
+struct Dma32 {
+  rsrc_t rs;
+  unsigned voff[2];
+  unsigned kk0, oob, kstep;
+  int kend;
+  __device__ __forceinline__ void init(const bf16_t* ptr, long ld, int R, int K, int kend_, int r0, int wave, int lane) {
+    kend = kend_;
+    const long cols = L == 0 ? K : R, rows = L == 0 ? R : K;
+    const unsigned bytes = (unsigned)(((rows - 1) * ld + (cols + 7) / 8 * 8) * 2);
+    rs = make_rsrc(ptr, bytes);
+    oob = (bytes + 15u) & ~15u;
+    if constexpr (L == 0) {
+      const int csrc = (lane & 3) ^ sw4((lane >> 4) & 3);
+      kstep = 64u;
+      kk0 = (unsigned)(csrc * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + (lane >> 2);
+        voff[j] = (r0 + row) < R ? (unsigned)(((long)(r0 + row) * ld + csrc * 8) * 2) : oob;
+      }
+    } else {
+      const int half = lane >> 5, pos = lane & 31;
+      kstep = (unsigned)(32 * ld * 2);
+      kk0 = (unsigned)(wave * 4 + half);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kr = wave * 4 + j * 2 + half;
+        const int csrc = pos ^ (km_sw(kr) << 1);
+        voff[j] = (r0 + csrc * 8) < R ? (unsigned)(((long)kr * ld + r0 + csrc * 8) * 2) : oob;
+      }
+    }
+  }
+  __device__ __forceinline__ unsigned kk(int j) const { return L == 0 ? kk0 : (kk0 + 2u * j); }
+  // tile kt -> LDS byte offset `lds_off` (stage base + operand base; wave-uniform)
+  __device__ __forceinline__ void issue(unsigned char* smem, int lds_off, int kt, int wave) const {
+    const unsigned soff = (unsigned)kt * kstep;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned vo = ((unsigned)kt * 32u + kk(j)) < (unsigned)kend ? voff[j] : oob;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + lds_off + (wave * 2 + j) * 1024), 16, (int)vo, (int)soff, 0, 0);
+    }
+  }
+};
+
+template <int L, int NF>
+struct Frags32 {
+  static constexpr int NADDR = L == 0 ? 1 : NF;
+  static constexpr int READS_PER_FRAG = L == 0 ? 1 : 2;
+  unsigned base[NADDR];  // stage-0 addresses
+  unsigned cur[NADDR];   // addresses in the stage being read
+  __device__ __forceinline__ void init(int opbase, int wb, int lane) {
+    const int p = lane & 15, g = lane >> 4;
+    if constexpr (L == 0) {
+      base[0] = (unsigned)(opbase + (wb + p) * 64 + ((g ^ sw4((p >> 2) & 3)) << 4));
+    } else {
+      const int kr = 8 * g + (p >> 2), s = km_sw(kr);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int chunk = (wb >> 3) + 2 * f + ((p & 3) >> 1);
+        base[f] = (unsigned)(opbase + kr * 512 + ((chunk ^ (s << 1)) << 4) + (p & 1) * 8);
+      }
+    }
+  }
+  __device__ __forceinline__ void point_at(unsigned stage_off) {
+#pragma unroll
+    for (int f = 0; f < NADDR; ++f) cur[f] = base[f] + stage_off;
+  }
+  template <int F>
+  __device__ __forceinline__ void read(bf16x8& d) const {
+    if constexpr (L == 0) {
+      lds_read128<F * 1024>(d, cur[0]);
+    } else {
+      u32x2 h0, h1;
+      lds_read64_tr<0>(h0, cur[F]);
+      lds_read64_tr<2048>(h1, cur[F]);
+      const u32x4 w = {h0[0], h0[1], h1[0], h1[1]};
+      d = __builtin_bit_cast(bf16x8, w);
+    }
+  }
+  template <int F0, int F1>
+  __device__ __forceinline__ void read_range(bf16x8 (&d)[NF]) const {
+    if constexpr (F0 < F1) {
+      read<F0>(d[F0]);
+      read_range<F0 + 1, F1>(d);
+    }
+  }
+};
+
+template <int AL, int BL>
+struct Pipe32 {
+  static constexpr int RA = AL ? 2 : 1, RB = BL ? 2 : 1, NB = NI * RB;
+  static constexpr int NSLOT = 4, DIST = NSLOT - 1, GBAR = 8 - DIST;
+  Dma32<AL> da;
+  Dma32<BL> db;
+  Frags32<AL, MI> fa;
+  Frags32<BL, NI> fb;
+  f32x4 acc[MI][NI];
+  bf16x8 ring[NSLOT];
+  bf16x8 bk[2][NI];
+  unsigned char* smem;
+  int wave;
+  int so_next, so_issue, kt_issue;   // stage byte offsets of tile t+1 / of the next tile to DMA, and that tile's index
+
+  static constexpr int waitN(int g) {
+    int n = DIST * RA;
+    for (int x = g - DIST + 1; x <= g; ++x) n += (((x % 8) + 8) % 8 == GBAR) ? NB : 0;
+    return n > 15 ? 15 : n;
+  }
+  __device__ __forceinline__ void issue_next() {
+    da.issue(smem, so_issue, kt_issue, wave);
+    db.issue(smem, so_issue + TILE32, kt_issue, wave);
+    so_issue = so_issue + STAGE32 == LDS_BYTES32 ? 0 : so_issue + STAGE32;
+    ++kt_issue;
+  }
+  template <int G> __device__ __forceinline__ void prologue_a() {
+    if constexpr (G < DIST) { fa.template read<G>(ring[G]); prologue_a<G + 1>(); }
+  }
+  __device__ __forceinline__ void prologue(int kt0) {
+    so_issue = 0; kt_issue = kt0;
+    issue_next(); issue_next(); issue_next(); issue_next();
+    so_next = STAGE32;
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    fa.point_at(0u);
+    fb.point_at((unsigned)TILE32);
+    fb.template read_range<0, NI>(bk[0]);
+    prologue_a<0>();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // one K-tile whose B fragments sit in bk[P]; G = MFMA group (A fragment row)
+  template <int P, int G>
+  __device__ __forceinline__ void group() {
+    if constexpr (G == GBAR) {
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // tile t+1 landed (t+2, t+3 in flight); my reads of tile t done
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      issue_next();                                  // tile t+4 -> the stage tile t-1 used
+      fa.point_at((unsigned)so_next);
+      fb.point_at((unsigned)(so_next + TILE32));
+      so_next = so_next + STAGE32 == LDS_BYTES32 ? 0 : so_next + STAGE32;
+      fb.template read_range<0, NI>(bk[P ^ 1]);
+    }
+    fa.template read<((G + DIST) & 7)>(ring[(G + DIST) & (NSLOT - 1)]);
+    wait_lgkm<waitN(G)>();
+#ifndef G256_ABLATE_NO_MFMA
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      acc[G][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[P][j], ring[G & (NSLOT - 1)], acc[G][j], 0, 0, 0);
+#else
+    asm volatile("" ::"v"(ring[G & (NSLOT - 1)]), "v"(bk[P][0]), "v"(bk[P][1]), "v"(bk[P][2]), "v"(bk[P][3]));
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G + 1 < 8) group<P, G + 1>();
+  }
+};
+
+template <typename TC, int AL, int BL, int BKV>
 __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -227,24 +403,32 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   const bf16_t* Bp = (const bf16_t*)p.B + zq * p.sB0 + zr * p.sB1;
   TC* Cp = (TC*)p.C + zq * p.sC0 + zr * p.sC1 + (p.split_k > 1 ? (long)blockIdx.y * p.split_stride : 0L);
 
-  int nk = (p.K + BK - 1) / BK, kt0 = 0;
+  constexpr int BKc = BKV;
+  int nk = (p.K + BKc - 1) / BKc, kt0 = 0;
   if (p.split_k > 1) {
-    const int per = (nk + p.split_k - 1) / p.split_k;
-    kt0 = blockIdx.y * per;
-    nk = min(nk, kt0 + per);
-    if (kt0 >= nk) return;
+    const int nk64 = (p.K + 63) / 64;                 // slices are cut on 64-wide boundaries for either pipeline
+    const int per = (nk64 + p.split_k - 1) / p.split_k;
+    if (blockIdx.y * per >= nk64) return;
+    kt0 = blockIdx.y * per * (64 / BKc);
+    nk = min(nk, (blockIdx.y + 1) * per * (64 / BKc));
   }
-  const int kend = min(p.K, nk * BK);
+  const int kend = min(p.K, nk * BKc);
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = (wave >> 2) * 128, wc = (wave & 3) * 64;
 
-  Pipe<AL, BL> pp;
+  using PipeT = std::conditional_t<BKV == 64, Pipe<AL, BL>, Pipe32<AL, BL>>;
+  PipeT pp;
   pp.smem = smem; pp.wave = wave;
   pp.da.init(Ap, p.lda, p.M, p.K, kend, m0, wave, lane);
   pp.db.init(Bp, p.ldb, p.N, p.K, kend, n0, wave, lane);
-  pp.fa.init(A_BASE, wr, lane);
-  pp.fb.init(B_BASE, wc, lane);
+  if constexpr (BKV == 64) {
+    pp.fa.init(A_BASE, wr, lane);
+    pp.fb.init(B_BASE, wc, lane);
+  } else {
+    pp.fa.init(0, wr, lane);
+    pp.fb.init(0, wc, lane);
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -253,11 +437,20 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   // the tile count is rounded up to even (a tile beyond kend is all out-of-range chunks: zeros, no memory traffic)
   const int kt_last = kt0 + ((nk - kt0 + 1) & ~1);
   pp.prologue(kt0);
-  for (int kt = kt0; kt < kt_last; kt += 2) {
-    pp.template group<0, 0>(kt, kt_last);
-    pp.template group<1, 0>(kt + 1, kt_last);
+  if constexpr (BKV == 64) {
+    for (int kt = kt0; kt < kt_last; kt += 2) {
+      pp.template group<0, 0>(kt, kt_last);
+      pp.template group<1, 0>(kt + 1, kt_last);
+    }
+    wait_lgkm<0>();  // the trailing (unused) fragment reads must not land in registers the epilogue reuses
+  } else {
+    for (int kt = kt0; kt < kt_last; kt += 2) {
+      pp.template group<0, 0>();
+      pp.template group<1, 0>();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing zero-fill DMAs and look-ahead reads
+    __builtin_amdgcn_sched_barrier(0);
   }
-  wait_lgkm<0>();  // the trailing (unused) fragment reads must not land in registers the epilogue reuses
   auto& acc = pp.acc;
 
   // ---- epilogue: C staged through LDS, RPP rows per pass, 16-byte row-contiguous stores ----
@@ -356,6 +549,10 @@ static inline bool gemm256_ok(const GemmParams& p, int la, int lb) {
          (p.residual == nullptr || (((p.ldr % EPC) == 0) && ((((uintptr_t)p.residual) & 15) == 0)));
 }
 
+// Peeling a short ragged last row-tile (tokens = 64 * 257 = 64 full tiles + 64 rows) off to the 128 x 128 kernel was tried and
+// measured: the extra launch costs more (~20 us) than the round it saves on [16448x768]x[6144x768]^T (14 us) - not done.
+static inline bool gemm256_peel(const GemmParams&, int, int) { return false; }
+
 // Pick the tile by estimated time (microseconds on MI355X, fitted to scripts/exp/gemm256g.hip and scripts/gemm_shapes.py):
 //   256^2: one block per CU (256 slots); a round costs nk * 1.8 + 6        (K loop ~1000 TFLOP/s + prologue / epilogue)
 //   128^2: 3 (k-contiguous x k-contiguous, one stage) or 2 blocks per CU; a round costs nk * 1.7 + 2.5 / nk * 1.25 + 2.5
@@ -368,7 +565,7 @@ static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int ba
   if (p.K < 128 || p.M < 256 || p.N < 256) return false;
   const long sk = p.split_k > 1 ? p.split_k : 1;
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch * sk;
-  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch * sk;
+  const long t256 = (long)(gemm256_peel(p, la, batch) ? p.M / 256 : (p.M + 255) / 256) * ((p.N + 255) / 256) * batch * sk;
   const double nk = (double)((p.K + 63) / 64) / (double)sk;
   const bool nn = la == 0 && lb == 0;
   const long slots128 = nn ? 768 : 512;
@@ -377,17 +574,26 @@ static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int ba
   return cost256 < cost128;
 }
 
-template <typename TC, int AL, int BL>
-static inline int launch_gemm256_l(const GemmParams& p, int batch, hipStream_t stream) {
+template <typename TC, int AL, int BL, int BKV>
+static inline int launch_gemm256_lb(const GemmParams& p, int batch, hipStream_t stream) {
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
-  auto kern = g256::kernel<TC, AL, BL>;
+  constexpr int lds = BKV == 64 ? g256::LDS_BYTES : g256::LDS_BYTES32;
+  auto kern = g256::kernel<TC, AL, BL, BKV>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn, p.split_k > 1 ? p.split_k : 1, batch), dim3(512), g256::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, p.split_k > 1 ? p.split_k : 1, batch), dim3(512), lds, stream, p);
   return (int)hipGetLastError();
+}
+// MUSE_G256_BK = 64 (default): two 64 KiB stages of 64-wide K-tiles; 32: five 32 KiB stages of 32-wide K-tiles.  Measured
+// equal within 2-3 % (BK = 64 ahead: 574 vs 586 us on [16384x3072]x[6144x3072]^T): the LDS-DMA stream is throughput-bound
+// (~28 B/clk per CU whatever the depth), so more tiles in flight buy nothing and twice the barriers cost a little.
+template <typename TC, int AL, int BL>
+static inline int launch_gemm256_l(const GemmParams& p, int batch, hipStream_t stream) {
+  const char* e = getenv("MUSE_G256_BK");
+  return (e && e[0] == '3') ? launch_gemm256_lb<TC, AL, BL, 32>(p, batch, stream) : launch_gemm256_lb<TC, AL, BL, 64>(p, batch, stream);
 }
 template <typename TC>
 static inline int launch_gemm256(const GemmParams& p, int la, int lb, int batch, hipStream_t stream) {

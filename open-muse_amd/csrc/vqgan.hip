@@ -114,14 +114,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo) {
   __shared__ float sc[2048], sh[2048];
   __shared__ float gmean[64], grstd[64];
+  __shared__ double gs_[64], gq_[64];
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int cpg = C / G;
-  if (threadIdx.x < G) {
+  {
+    // fold the image's partials: 256 / G threads per group, each a strided subset in a fixed order, then a lane tree
+    const int tpg = 256 / G, g = threadIdx.x / tpg, sub = threadIdx.x % tpg;   // G in {32, 64}: tpg = 8 / 4 lanes of one wave
     double s = 0.0, q = 0.0;
-    for (int c = 0; c < nchunk; ++c) {
-      const double* o = partial + (((long)b * nchunk + c) * G + threadIdx.x) * 2;
+    for (int c = sub; c < nchunk; c += tpg) {
+      const double* o = partial + (((long)b * nchunk + c) * G + g) * 2;
       s += o[0]; q += o[1];
     }
+    for (int o = 1; o < tpg; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (sub == 0) { gs_[g] = s; gq_[g] = q; }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const double s = gs_[threadIdx.x], q = gq_[threadIdx.x];
     const double n = (double)HW * (double)cpg;
     const double mean = s / n;
     double var = q / n - mean * mean;
@@ -190,7 +199,7 @@ extern "C" int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, c
                                         double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
                                         int32_t apply_silu, void* stream) {
   const int vec = dtype == MUSE_BF16 ? 8 : 4;
-  if (groups > 64 || C > 2048 || (C % groups) || (C % vec)) return MUSE_ERR_UNSUPPORTED;
+  if ((groups != 32 && groups != 64) || C > 2048 || (C % groups) || (C % vec)) return MUSE_ERR_UNSUPPORTED;
   const int vpp = C / vec;
   if (vpp <= 256 && (256 % vpp)) return MUSE_ERR_UNSUPPORTED;
   if (batch <= 0) return 0;
@@ -209,20 +218,22 @@ extern "C" int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, c
   return (int)hipGetLastError();
 }
 
-// f32 input, output as the two bf16 planes y_hi = bf16(y), y_lo = bf16(y - y_hi) the bf16x3 LDS-DMA convolution reads
+// f32 input, output as the two bf16 planes y_hi = bf16(y), y_lo = bf16(y - y_hi) the bf16x3 LDS-DMA convolution reads.
+// stats_nchunk == 0: the statistics pass runs here; > 0: `partial` already holds [B, stats_nchunk, G, 2] sums written by the
+// producing convolution's epilogue (muse_conv2d_nhwc_split2 with gn_partial) and only the apply pass runs.
 extern "C" int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta,
-                                              double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
-                                              int32_t apply_silu, void* stream) {
-  if (groups > 64 || C > 1024 || (C % groups) || (C % 4)) return MUSE_ERR_UNSUPPORTED;
+                                              double* partial, int32_t stats_nchunk, int32_t batch, int32_t HW, int32_t C,
+                                              int32_t groups, float eps, int32_t apply_silu, void* stream) {
+  if ((groups != 32 && groups != 64) || C > 1024 || (C % groups) || (C % 4)) return MUSE_ERR_UNSUPPORTED;
   const int vpp = C / 4;
   if (256 % vpp) return MUSE_ERR_UNSUPPORTED;  // (the split store lives in the one-vector-per-thread loop)
   if (batch <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = muse_groupnorm_nchunk(HW);
   dim3 grid(nchunk, batch);
-  hipLaunchKernelGGL((gn_stats_kernel<float, 4>), grid, dim3(256), 0, s, x, partial, HW, C, groups);
+  if (stats_nchunk <= 0) hipLaunchKernelGGL((gn_stats_kernel<float, 4>), grid, dim3(256), 0, s, x, partial, HW, C, groups);
   hipLaunchKernelGGL((gn_apply_kernel<float, 4>), grid, dim3(256), 0, s, x, (float*)nullptr, gamma, beta, (const double*)partial,
-                     HW, C, groups, nchunk, eps, apply_silu, (bf16_t*)y_hi, (bf16_t*)y_lo);
+                     HW, C, groups, stats_nchunk > 0 ? stats_nchunk : nchunk, eps, apply_silu, (bf16_t*)y_hi, (bf16_t*)y_lo);
   return (int)hipGetLastError();
 }
 

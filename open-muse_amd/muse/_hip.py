@@ -13,7 +13,7 @@ import torch
 
 F32, BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmuse_hip.so")
+LIB_PATH = os.environ.get("MUSE_HIP_LIB") or os.path.join(_HERE, "libmuse_hip.so")   # (override: kernel experiments)
 _lib = None
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -75,10 +75,10 @@ SIGNATURES = {
                          c_int, c_int, c_void_p],
     "muse_conv2d_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_void_p],
-    "muse_conv2d_nhwc_split2": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                c_int, c_int, c_void_p],
+    "muse_conv2d_nhwc_split2": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_int, c_int, c_int, c_int, c_void_p],
     "muse_groupnorm_silu_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                       c_float, c_int, c_void_p],
+                                       c_int, c_float, c_int, c_void_p],
     "muse_groupnorm_silu_nhwc": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_float, c_int, c_void_p],
     "muse_groupnorm_nchunk": [c_int],

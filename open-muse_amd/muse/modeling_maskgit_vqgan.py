@@ -134,6 +134,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         self.decoder = _Decoder(self.config)
         self.quantize = _Quantizer(num_embeddings, quantized_embed_dim)
         self.compute_dtype = torch.float32
+        self.fuse_gn_stats = True   # ... and their epilogues produce the next GroupNorm's statistics
         self.dma_conv = True   # "bf16x3" mode: 3x3 convs after GroupNorm run as the LDS-DMA kernel on pre-split planes
         self._packed = {}
 
@@ -180,10 +181,11 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
             self._packed[key] = hit
         return hit
 
-    def _conv(self, x, conv, B, H, W, cd, residual=None, upsample=False):
+    def _conv(self, x, conv, B, H, W, cd, residual=None, upsample=False, gn_next=False):
         wp, cp, cout, k, bias = self._w(conv, cd)
         if isinstance(x, tuple):   # (hi, lo) planes from _gn_for: the LDS-DMA bf16x3 convolution
-            return ops.conv2d_nhwc_split2(x[0], x[1], wp[0], wp[1], B, H, W, cp, cout, bias=bias, residual=residual)
+            return ops.conv2d_nhwc_split2(x[0], x[1], wp[0], wp[1], B, H, W, cp, cout, bias=bias, residual=residual,
+                                          gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
         if cd == "bf16x3":
             return ops.conv2d_nhwc_split(x, wp[0], wp[1], B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
         return ops.conv2d_nhwc(x, wp, B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
@@ -196,15 +198,17 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         planes of the LDS-DMA convolution when the layer qualifies (3x3, Cin % 32 == 0)"""
         cout, cin, k, _ = conv.weight.shape
         if cd == "bf16x3" and self.dma_conv and ops.conv_split2_ok(B, H, W, cin, cout, k) and (256 % (cin // 4)) == 0:
-            return ops.groupnorm_silu_nhwc_split(x, norm.weight.data, norm.bias.data, B, H * W, cin, groups=32, eps=1e-6, silu=True)
+            return ops.groupnorm_silu_nhwc_split(x, norm.weight.data, norm.bias.data, B, H * W, cin, groups=32, eps=1e-6, silu=True,
+                                                 stats=getattr(x, "_gn_stats", None))
         return self._gn(x, norm, B, H * W, cin)
 
     def _res(self, x, blk: _Res, B, H, W, cd):
         cin = blk.conv1.weight.shape[1]
         cout = blk.conv1.weight.shape[0]
-        h = self._conv(self._gn_for(x, blk.norm1, blk.conv1, B, H, W, cd), blk.conv1, B, H, W, cd)
+        # gn_next: the convolution's epilogue also leaves the GroupNorm statistics of its output for the next norm layer
+        h = self._conv(self._gn_for(x, blk.norm1, blk.conv1, B, H, W, cd), blk.conv1, B, H, W, cd, gn_next=True)
         if cin == cout:
-            return self._conv(self._gn_for(h, blk.norm2, blk.conv2, B, H, W, cd), blk.conv2, B, H, W, cd, residual=x)
+            return self._conv(self._gn_for(h, blk.norm2, blk.conv2, B, H, W, cd), blk.conv2, B, H, W, cd, residual=x, gn_next=True)
         h = self._conv(self._gn_for(h, blk.norm2, blk.conv2, B, H, W, cd), blk.conv2, B, H, W, cd)
         # reference quirk (:82-85): the "shortcut" is a 1x1 conv of the conv2 output, out = h + nin(h)
         return self._conv(h, blk.nin_shortcut, B, H, W, cd, residual=h)

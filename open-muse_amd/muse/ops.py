@@ -141,20 +141,27 @@ SPLIT_K = os.environ.get("MUSE_SPLIT_K", "1") != "0"   # MUSE_SPLIT_K=0: determi
 
 def wgrad_splits(M, N, K, dtype, slots=512, tile=128):
     """K slices for a weight-gradient GEMM.  The [N_out, K_in] output has few tiles while K = tokens is long, so the K
-    loop is cut; the slice count is the one that fills whole rounds of resident blocks best (128^2 kernel: 2 blocks per
-    CU = 512 slots; 256^2 LDS-DMA kernel: 1 block per CU = 256 slots), with at least 4 K-tiles per slice."""
+    loop is cut.  128^2 kernel (2 blocks per CU = 512 slots): the slice count that fills whole rounds of resident blocks
+    best, with at least 4 K-tiles per slice.  256^2 LDS-DMA kernel (1 block per CU = 256 slots): the slice count with the
+    smallest modelled time = rounds x (K-tiles per slice x 1.8 us + 6 us) + workspace traffic of the slice reduction
+    ((slices + 1) x 4 M N bytes at ~4 TB/s)."""
     if not SPLIT_K:
         return 1
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     nk = (K + 63) // 64
-    best, best_eff = 1, 0.0
+    best, best_eff, best_cost = 1, 0.0, float("inf")
     for s in range(1, max(1, min(nk // 4, 64)) + 1):
         per = (nk + s - 1) // s
         s_eff = (nk + per - 1) // per          # every slice must own at least one K-tile
         blocks = tiles * s_eff
-        eff = blocks / (((blocks + slots - 1) // slots) * slots)
-        if eff > best_eff + 0.02:
-            best, best_eff = s_eff, eff
+        if tile == 256:
+            cost = ((blocks + slots - 1) // slots) * (per * 1.8 + 6.0) + ((s_eff + 1) * 4.0 * M * N / 4e6 if s_eff > 1 else 0.0)
+            if cost < best_cost - 1e-9:
+                best, best_cost = s_eff, cost
+        else:
+            eff = blocks / (((blocks + slots - 1) // slots) * slots)
+            if eff > best_eff + 0.02:
+                best, best_eff = s_eff, eff
     return best
 
 
@@ -445,14 +452,23 @@ def conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=None, residual
     return out
 
 
-def conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=None, residual=None):
-    """3x3 bf16x3 convolution on pre-split activation planes, operands by LDS-DMA (see muse_conv2d_nhwc_split2)"""
+def conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=None, residual=None, gn_groups=0):
+    """3x3 bf16x3 convolution on pre-split activation planes, operands by LDS-DMA (see muse_conv2d_nhwc_split2).
+    gn_groups > 0: the epilogue also produces the GroupNorm statistics of the output; they ride on the returned tensor as
+    `out._gn_stats = (partial, nchunk)` for groupnorm_silu_nhwc_split."""
     require_gpu(x_hi, x_lo, w_hi, w_lo)
     out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x_hi.device)
+    part, nchunk = None, 0
+    if gn_groups and conv_gn_stats_ok(H, W, Cout, gn_groups):
+        nchunk = (H * W) // 256
+        part = torch.empty(B * nchunk * gn_groups * 2, dtype=torch.float64, device=out.device)
     e0 = _prof_begin()
     check(lib().muse_conv2d_nhwc_split2(x_hi.data_ptr(), x_lo.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(), ptr(bias),
-                                        ptr(residual), out.data_ptr(), B, H, W, Cin, Cout, 3, stream()), "muse_conv2d_nhwc_split2")
+                                        ptr(residual), out.data_ptr(), ptr(part), gn_groups if part is not None else 0,
+                                        B, H, W, Cin, Cout, 3, stream()), "muse_conv2d_nhwc_split2")
     _prof_end(e0, "conv_bf16x3_dma", 2.0 * B * H * W * Cout * 9 * Cin)
+    if part is not None:
+        out._gn_stats = (part, nchunk)
     return out
 
 
@@ -462,15 +478,24 @@ def conv_split2_ok(B, H, W, Cin, Cout, KS):
     return KS == 3 and Cin % 32 == 0 and Cout % 4 == 0 and M * Cin * 2 < (1 << 32) - 64 and M < (1 << 31) - 256
 
 
-def groupnorm_silu_nhwc_split(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, silu=True):
-    """GroupNorm + SiLU of an f32 NHWC tensor, returned as the (hi, lo) bf16 planes of the result"""
+def conv_gn_stats_ok(H, W, Cout, groups):
+    cpg = Cout // groups if groups else 0
+    return groups in (32, 64) and Cout % groups == 0 and (H * W) % 256 == 0 and 4 <= cpg <= 128 and (cpg & (cpg - 1)) == 0
+
+
+def groupnorm_silu_nhwc_split(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, silu=True, stats=None):
+    """GroupNorm + SiLU of an f32 NHWC tensor, returned as the (hi, lo) bf16 planes of the result.
+    stats = (partial, nchunk) from the producing convolution's epilogue skips the statistics pass."""
     require_gpu(x, gamma, beta)
     hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    nchunk = lib().muse_groupnorm_nchunk(HW)
-    part = torch.empty(B * nchunk * groups * 2, dtype=torch.float64, device=x.device)
+    if stats is not None:
+        part, snc = stats
+    else:
+        nchunk = lib().muse_groupnorm_nchunk(HW)
+        part, snc = torch.empty(B * nchunk * groups * 2, dtype=torch.float64, device=x.device), 0
     check(lib().muse_groupnorm_silu_nhwc_split(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                               part.data_ptr(), B, HW, C, groups, eps, 1 if silu else 0, stream()),
+                                               part.data_ptr(), snc, B, HW, C, groups, eps, 1 if silu else 0, stream()),
           "muse_groupnorm_silu_nhwc_split")
     return hi, lo
 

@@ -30,7 +30,8 @@ static GemmParams make_params(const void* A, const void* B, void* C, int M, int 
 }
 
 template <typename TC> static void run(int M, int N, int K, int la, int lb, bool check, int split_k = 1) {
-  const long lda = la == 0 ? K : M, ldb = lb == 0 ? K : N;
+  static const int pad = getenv("PAD") ? atoi(getenv("PAD")) : 0;
+  const long lda = (la == 0 ? K : M) + pad, ldb = (lb == 0 ? K : N) + pad;
   const size_t na = (size_t)(la == 0 ? M : K) * lda, nb = (size_t)(lb == 0 ? N : K) * ldb;
   std::vector<unsigned short> hA(na), hB(nb);
   unsigned s = 12345;
@@ -78,7 +79,14 @@ template <typename TC> static void run(int M, int N, int K, int la, int lb, bool
 }
 
 int main(int argc, char** argv) {
-  const bool quick = argc > 1;
+  const bool quick = argc > 1 && argv[1][0] == 'q';
+  if (argc > 1 && argv[1][0] == 't') {  // timing only (ablation builds: results are wrong by construction)
+    run<bf16_t>(16384, 6144, 3072, 0, 0, false);
+    run<bf16_t>(16384, 6144, 768, 0, 0, false);
+    run<bf16_t>(16384, 768, 6144, 0, 1, false);
+    run<float>(6144, 768, 16448, 1, 1, false, 3);
+    return 0;
+  }
   for (int la = 0; la < 2; ++la)
     for (int lb = 0; lb < 2; ++lb) {
       run<bf16_t>(1000, 520, 512, la, lb, true);

@@ -34,7 +34,7 @@ if [[ $STAGE == perf ]]; then
 fi
 if [[ $STAGE == all || $STAGE == prof ]]; then
   rm -rf $O/prof
-  timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o r1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $O/prof.txt 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $O/prof.txt 2>&1
   echo "prof exit $?" >> $O/prof.txt
   find $O/prof -name "*kernel_stats*" | head; f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
   # keep only the small summaries (the trace itself can be large)

@@ -429,7 +429,9 @@ def test_conv2d_split_bf16x3(Cin, Cout, KS, ups, bias, res):
     (1, 16, 16, 64, 36, False, True),      # exactly one pixel tile, ragged Cout
     (3, 20, 24, 128, 128, True, True),     # several pixel tiles (last ragged), Cin = 128 -> 36 K-tiles (6 groups)
     (2, 8, 8, 96, 260, True, False),       # Cin not a power of two, 27 K-tiles (padded to 30), three channel tiles
-    (1, 32, 32, 256, 256, False, True),
+    (1, 32, 32, 256, 256, False, True),    # fused GroupNorm statistics: 8 channels per group, 4 pixel tiles
+    (2, 16, 16, 128, 128, True, True),     # ... 4 channels per group, one tile per image
+    (1, 16, 32, 64, 512, True, False),     # ... 16 channels per group, 4 channel tiles
 ])
 def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
     """the LDS-DMA bf16x3 convolution on pre-split planes is BIT-identical to the register-staged bf16x3 kernel on the f32
@@ -450,6 +452,21 @@ def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
     if res:
         ref64 = ref64 + rr.cpu().double().permute(0, 3, 1, 2)
     assert rel_err(got.cpu().permute(0, 3, 1, 2), ref64) < 3e-5
+    # GroupNorm statistics fused into the convolution epilogue: [B, HW/256, 32, 2] f64 sums of the (bias + residual) output
+    if ops.conv_gn_stats_ok(H, W, Cout, 32):
+        got2 = ops.conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=bvec, residual=rr, gn_groups=32)
+        assert torch.equal(got2, ref)
+        part, nchunk = got2._gn_stats
+        assert nchunk == H * W // 256
+        st = part.view(B, nchunk, 32, 2).sum(1).cpu()
+        o = ref.cpu().double().view(B, H * W, 32, Cout // 32)
+        assert rel_err(st[..., 0], o.sum((1, 3))) < 1e-12 and rel_err(st[..., 1], (o * o).sum((1, 3))) < 1e-12
+        gam2, bet2 = (1 + 0.1 * rnd((Cout,), 186)).to(DEV), (0.1 * rnd((Cout,), 187)).to(DEV)
+        if 256 % (Cout // 4) == 0:
+            a_hi, a_lo = ops.groupnorm_silu_nhwc_split(ref, gam2, bet2, B, H * W, Cout)
+            b_hi, b_lo = ops.groupnorm_silu_nhwc_split(got2, gam2, bet2, B, H * W, Cout, stats=got2._gn_stats)
+            ya, yb = a_hi.float() + a_lo.float(), b_hi.float() + b_lo.float()
+            assert rel_err(yb, ya) < 1e-6   # same statistics up to f64 summation order
     # GroupNorm + SiLU with split output == split of the f32 output
     if 256 % (Cin // 4):
         return   # (channel counts the GroupNorm kernel does not take)
@@ -503,15 +520,17 @@ def test_gemm_256_tile_kernel(monkeypatch, out_dtype, la, lb, M, N, K):
 
 
 def test_gemm_256_matches_128_on_model_shapes(monkeypatch):
-    """forward / dX / dW products of one transformer layer at T = 1028 tokens: the two kernels agree to bf16 rounding"""
+    """forward / dX / dW products of one transformer layer at T = 1028 tokens: the 128x128 kernel and both pipelines of the
+    256x256 kernel (MUSE_G256_BK = 64: two stages of 64-wide K-tiles, 32: five stages of 32-wide ones) agree to bf16 rounding"""
     ops = _ops()
     T_, H, I = 1028, 768, 3072
     x = rnd((T_, H), 210).to(DEV, torch.bfloat16)
     w = (0.05 * rnd((2 * I, H), 211)).to(DEV, torch.bfloat16)
     dy = rnd((T_, 2 * I), 212).to(DEV, torch.bfloat16)
     outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("MUSE_GEMM256", mode)
+    for mode in ("0", "1", "1/32"):
+        monkeypatch.setenv("MUSE_GEMM256", mode[0])
+        monkeypatch.setenv("MUSE_G256_BK", "32" if mode.endswith("/32") else "64")
         ops._WGRAD_PLAN.clear()
         y = ops.linear(x, w)
         dx = ops.linear_dgrad(dy, w)
@@ -519,8 +538,11 @@ def test_gemm_256_matches_128_on_model_shapes(monkeypatch):
         ops.linear_wgrad(dy, x, dw, False)
         outs[mode] = (y.float(), dx.float(), dw)
     ops._WGRAD_PLAN.clear()
-    for a, b in zip(outs["0"], outs["1"]):
-        assert rel_err(a, b) < 1e-2
+    for other in ("1", "1/32"):
+        for a, b in zip(outs["0"], outs[other]):
+            assert rel_err(a, b) < 1e-2
+    for a, b in zip(outs["1"], outs["1/32"]):   # same products, same accumulation order per output element
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
