@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing (zero) DMAs and fragment reads are done before LDS / registers are reused
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- epilogue: + bias, staged through LDS (128 rows per pass), 16-byte row-contiguous stores with the residual added ----
+  // ---- epilogue: + bias, staged through LDS, 16-byte row-contiguous stores with the residual added ----
   constexpr int CST = BN * 4 + 16;  // 528 bytes per staged row
   float bias_v[NI][4];
 #pragma unroll
@@ -212,30 +212,36 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
       bias_v[j][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
   double gs = 0.0, gq = 0.0;   // GroupNorm statistics of this thread's column chunk (4 channels = part of one group)
+  // the whole 256 x 128 f32 tile fits the (now idle) operand stages: one staging pass, every wave busy
+  __syncthreads();
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
-    if ((wm >> 1) == pass) {
+  for (int i = 0; i < MI; ++i) {
+    const int lr = wm * 64 + i * 16 + (lane & 15);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int lr = (wm & 1) * 64 + i * 16 + (lane & 15);
+    for (int j = 0; j < NI; ++j) {
+      const int nl = wn * 64 + j * 16 + 4 * (lane >> 4);
+      const f32x4 v = {acc[i][j][0] + bias_v[j][0], acc[i][j][1] + bias_v[j][1], acc[i][j][2] + bias_v[j][2], acc[i][j][3] + bias_v[j][3]};
+      *(f32x4*)(smem + lr * CST + nl * 4) = v;
+    }
+  }
+  __syncthreads();
+  constexpr int NIT = (BM * 32) / NT;   // 16 row-contiguous 16-byte chunks per thread
+  const int col = (threadIdx.x & 31) * 4, n = n0 + col, rbase = threadIdx.x >> 5;
+  if (n < p.N) {
+    f32x4 rv[NIT];
+    if (p.residual) {   // all residual loads in flight before the first store
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int nl = wn * 64 + j * 16 + 4 * (lane >> 4);
-          const f32x4 v = {acc[i][j][0] + bias_v[j][0], acc[i][j][1] + bias_v[j][1], acc[i][j][2] + bias_v[j][2], acc[i][j][3] + bias_v[j][3]};
-          *(f32x4*)(smem + lr * CST + nl * 4) = v;
-        }
+      for (int it = 0; it < NIT; ++it) {
+        const int m = m0 + rbase + 16 * it;
+        rv[it] = m < p.M ? *(const f32x4*)(p.residual + (long)m * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    __syncthreads();
 #pragma unroll
-    for (int it = 0; it < (128 * 32) / NT; ++it) {
-      const int c = threadIdx.x + NT * it;
-      const int row = c >> 5, col = (c & 31) * 4;
-      const int m = m0 + pass * 128 + row, n = n0 + col;
-      if (m < p.M && n < p.N) {
+    for (int it = 0; it < NIT; ++it) {
+      const int row = rbase + 16 * it, m = m0 + row;
+      if (m < p.M) {
         f32x4 w = *(const f32x4*)(smem + row * CST + col * 4);
-        if (p.residual) w += *(const f32x4*)(p.residual + (long)m * p.N + n);
+        if (p.residual) w += rv[it];
         *(f32x4*)(p.out + (long)m * p.N + n) = w;
         if (p.gn_partial) {
 #pragma unroll
