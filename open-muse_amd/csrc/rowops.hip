@@ -196,7 +196,7 @@ __device__ __forceinline__ float block_sum256(float v, float* red, int slot) {
   return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
 }
 
-#define FFN_ROWS 16
+#define FFN_ROWS 8
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ ab, const float* __restrict__ w,
                                                           T* __restrict__ h, T* __restrict__ hm, float* __restrict__ mean_o,
