@@ -354,29 +354,30 @@ extern "C" int muse_ffn_mid_bwd(const void* dhm, const void* h, const void* ab, 
   return (int)hipGetLastError();
 }
 
-// out[c] (+)= sum_r in[r,c]; 64 columns x 16 row-groups per block, fixed summation order (deterministic)
+// out[c] (+)= sum_r in[r,c]; 16 columns x 64 row-groups per block (cols/16 blocks: the partial-sum matrices are short and
+// wide, 64-column blocks left a dozen CUs doing a latency-bound row walk), fixed summation order (deterministic)
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int acc) {
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  __shared__ float red[64][17];
+  const int c16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + c16;
   float s0 = 0.f, s1 = 0.f;
   if (c < cols) {
-    int r = w;
-    for (; r + 16 < rows; r += 32) { s0 += in[(long)r * cols + c]; s1 += in[(long)(r + 16) * cols + c]; }
+    int r = rg;
+    for (; r + 64 < rows; r += 128) { s0 += in[(long)r * cols + c]; s1 += in[(long)(r + 64) * cols + c]; }
     if (r < rows) s0 += in[(long)r * cols + c];
   }
-  red[w][lane] = s0 + s1;
+  red[rg][c16] = s0 + s1;
   __syncthreads();
-  if (w == 0 && c < cols) {
+  if (rg == 0 && c < cols) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += red[k][lane];
+    for (int k = 0; k < 64; ++k) s += red[k][c16];
     out[c] = acc ? out[c] + s : s;
   }
 }
 extern "C" int muse_colsum(const float* in, float* out, int32_t rows, int32_t cols, int32_t accumulate, void* stream) {
   if (cols <= 0) return 0;
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, in, out, rows, cols, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 15) / 16), dim3(1024), 0, (hipStream_t)stream, in, out, rows, cols, accumulate);
   return (int)hipGetLastError();
 }
 
