@@ -110,3 +110,33 @@ def test_sampling_schedules():
     assert get_mask_chedule("cosine") is cosine_schedule
     with pytest.raises(ValueError):
         get_mask_chedule("nope")
+
+
+def test_host_side_plans():
+    """pure host logic around the C-ABI: split-K plan of the weight-gradient GEMMs and the eligibility predicates of the
+    LDS-DMA convolution / its fused GroupNorm statistics (no GPU, no library call)"""
+    from muse import ops
+    # config B, bs 64: T = 16448 tokens -> 257 K-tiles of 64.  256x256 tiles, 256 slots: few tiles -> many slices, but never
+    # more workspace traffic than the rounds it saves
+    plan = {(m, n): ops.wgrad_splits(m, n, 16448, torch.bfloat16, slots=256, tile=256)
+            for (m, n) in [(2304, 768), (768, 768), (6144, 768), (768, 3072)]}
+    assert plan == {(2304, 768): 9, (768, 768): 26, (6144, 768): 3, (768, 3072): 7}
+    for (m, n), s in plan.items():
+        tiles = -(-m // 256) * -(-n // 256)
+        per = -(-257 // s)
+        assert -(-257 // per) == s            # every slice owns at least one K-tile (no empty workspace slice)
+        assert tiles * s <= 2 * 256           # at most two rounds of resident blocks
+    # 128x128 kernel: efficiency rule, at least 4 K-tiles per slice
+    s128 = ops.wgrad_splits(6144, 768, 16448, torch.bfloat16)
+    assert 1 <= s128 <= 257 // 4
+    assert ops.wgrad_splits(6144, 768, 64, torch.bfloat16) == 1   # a single K-tile cannot be split
+    # LDS-DMA convolution: 3x3, Cin % 32 == 0, 32-bit buffer offsets
+    assert ops.conv_split2_ok(64, 256, 256, 128, 128, 3)
+    assert not ops.conv_split2_ok(64, 256, 256, 128, 128, 1)        # 1x1 layers stay on the register-staged kernel
+    assert not ops.conv_split2_ok(64, 256, 256, 8, 128, 3)          # RGB stem (padded to 8 channels)
+    assert not ops.conv_split2_ok(256, 256, 256, 128, 128, 3)       # plane of 4 GiB: offsets would not fit 32 bits
+    # fused GroupNorm statistics: whole 256-pixel tiles per image, 4 * 2^k channels per group
+    assert ops.conv_gn_stats_ok(256, 256, 128, 32) and ops.conv_gn_stats_ok(16, 16, 512, 32)
+    assert not ops.conv_gn_stats_ok(20, 24, 128, 32)                # 480 pixels per image
+    assert not ops.conv_gn_stats_ok(16, 16, 96, 32)                 # 3 channels per group
+    assert not ops.conv_gn_stats_ok(16, 16, 64, 32)                 # 2 channels per group: below one 4-channel chunk
