@@ -60,24 +60,8 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   const int batch = d->batch > 0 ? d->batch : 1;
   hipStream_t s = (hipStream_t)stream;
   if (takes_gemm256(d, p, batch)) {
-    const int tail = p.M % 256;
-    GemmParams pt = p;
-    const bool peel = gemm256_peel(p, d->layout_a, batch);
-    if (peel) {
-      const long mm = p.M - tail;
-      const int eo = d->out_dtype == MUSE_BF16 ? 2 : 4;
-      p.M = (int)mm;
-      pt.M = tail;
-      pt.A = (const char*)p.A + mm * p.lda * 2;
-      pt.C = (char*)p.C + mm * p.ldc * eo;
-      if (p.residual) pt.residual = (const char*)p.residual + mm * p.ldr * eo;
-      if (p.rowvec) pt.rowvec = p.rowvec + mm;
-    }
-    const int rc2 = d->out_dtype == MUSE_BF16 ? launch_gemm256<bf16_t>(p, d->layout_a, d->layout_b, batch, s)
-                                              : launch_gemm256<float>(p, d->layout_a, d->layout_b, batch, s);
-    if (rc2 || !peel) return rc2;
-    return d->out_dtype == MUSE_BF16 ? dispatch_layout<bf16_t, bf16_t>(pt, d->layout_a, d->layout_b, batch, s)
-                                     : dispatch_layout<bf16_t, float>(pt, d->layout_a, d->layout_b, batch, s);
+    if (d->out_dtype == MUSE_BF16) return launch_gemm256<bf16_t>(p, d->layout_a, d->layout_b, batch, s);
+    return launch_gemm256<float>(p, d->layout_a, d->layout_b, batch, s);
   }
   if (d->dtype == MUSE_BF16) {
     if (d->out_dtype == MUSE_BF16) return dispatch_layout<bf16_t, bf16_t>(p, d->layout_a, d->layout_b, batch, s);

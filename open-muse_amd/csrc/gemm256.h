@@ -549,10 +549,8 @@ static inline bool gemm256_ok(const GemmParams& p, int la, int lb) {
          (p.residual == nullptr || (((p.ldr % EPC) == 0) && ((((uintptr_t)p.residual) & 15) == 0)));
 }
 
-// Peeling a short ragged last row-tile (tokens = 64 * 257 = 64 full tiles + 64 rows) off to the 128 x 128 kernel was tried and
-// measured: the extra launch costs more (~20 us) than the round it saves on [16448x768]x[6144x768]^T (14 us) - not done.
-static inline bool gemm256_peel(const GemmParams&, int, int) { return false; }
-
+// (Peeling the short ragged last row-tile of M = 16448 = 64 * 256 + 64 off to the 128 x 128 kernel was tried and measured: the
+// extra launch costs more (~20 us) than the round it saves on [16448x768]x[6144x768]^T (14 us).)
 // Pick the tile by estimated time (microseconds on MI355X, fitted to scripts/exp/gemm256g.hip and scripts/gemm_shapes.py):
 //   256^2: one block per CU (256 slots); a round costs nk * 1.8 + 6        (K loop ~1000 TFLOP/s + prologue / epilogue)
 //   128^2: 3 (k-contiguous x k-contiguous, one stage) or 2 blocks per CU; a round costs nk * 1.7 + 2.5 / nk * 1.25 + 2.5
@@ -565,7 +563,7 @@ static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int ba
   if (p.K < 128 || p.M < 256 || p.N < 256) return false;
   const long sk = p.split_k > 1 ? p.split_k : 1;
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch * sk;
-  const long t256 = (long)(gemm256_peel(p, la, batch) ? p.M / 256 : (p.M + 255) / 256) * ((p.N + 255) / 256) * batch * sk;
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch * sk;
   const double nk = (double)((p.K + 63) / 64) / (double)sk;
   const bool nn = la == 0 && lb == 0;
   const long slots128 = nn ? 768 : 512;

@@ -1,5 +1,7 @@
-// MFMA GEMM core for gfx950, shared by the dense/batched GEMM entry points (gemm.hip) and the NHWC
-// implicit-GEMM convolution (conv.hip).
+// MFMA GEMM core for gfx950 (register-staged 128 x 128 tile), shared by the dense/batched GEMM entry point (gemm.hip), the
+// NHWC implicit-GEMM convolutions (vqgan.hip: exact f32 / bf16; conv_split.hip: bf16x3 on f32 input) and, for its loaders and
+// epilogue helpers, by the 256 x 256 LDS-DMA kernel (gemm256.h) that takes the large bf16 products.  This kernel keeps: f32
+// operands (exact-f32 MFMA), small / ragged / batched products, GELU epilogues, atomic split-K.
 //
 //   C[m,n] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
 //
