@@ -94,6 +94,60 @@ def golden_mask(name, batch, seq, seed, mask_id, codebook_size, min_rate):
     print(name, "masked per row", mask.sum(-1)[:8].tolist())
 
 
+UVIT_TINY = dict(hidden_size=32, use_bias=False, hidden_dropout=0.0, cond_embed_dim=16, micro_cond_encode_dim=8,
+                 micro_cond_embed_dim=40, encoder_hidden_size=24, vocab_size=40, codebook_size=32, in_channels=16,
+                 block_out_channels=(24,), num_res_blocks=2, force_down_up_sample=False, block_num_heads=2,
+                 num_hidden_layers=2, num_attention_heads=2, attention_dropout=0.0, intermediate_size=48,
+                 norm_type="rmsnorm", layer_norm_eps=1e-6, ln_elementwise_affine=True)
+
+
+def golden_uvit(name, cfg, batch, seq, text_len, seed):
+    """SURVEY.md section 8 row a12 (config 4): muse/modeling_transformer_v2.py:MaskGiTUViT_v2 on a tiny configuration.
+    The tensors the reference zero-initialises (AdaLN mappers, mlm_layer.conv1, GlobalResponseNorm gamma/beta - :209-223,
+    :744-745) are perturbed first: with them at zero the logits are identically 0 and nothing would be tested."""
+    from muse.modeling_transformer_v2 import MaskGiTUViT_v2
+    torch.manual_seed(seed)
+    model = MaskGiTUViT_v2(**cfg)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p_ in model.named_parameters():
+            if float(p_.abs().max()) == 0.0:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+            elif k.endswith("norm.weight") or k.endswith("layer_norm.weight"):
+                p_.add_(torch.randn(p_.shape, generator=g) * 0.1)     # norm gains away from exactly 1
+    model.train()
+    side = int(seq ** 0.5)
+    assert side * side == seq
+    V = cfg["codebook_size"]
+    input_ids = torch.randint(0, V, (batch, seq), generator=g)
+    masked = torch.rand(batch, seq, generator=g) < 0.5
+    labels = torch.where(masked, input_ids, torch.full_like(input_ids, -100))
+    input_ids = torch.where(masked, torch.full_like(input_ids, cfg["vocab_size"] - 1), input_ids)
+    enc = torch.randn(batch, text_len, cfg["encoder_hidden_size"], generator=g)
+    cond = torch.randn(batch, cfg["cond_embed_dim"], generator=g)
+    micro = torch.tensor([[256.0, 256.0, 0.0, 0.0, 6.0], [512.0, 384.0, 16.0, 8.0, 5.5]])[:batch]
+    loss_weight = torch.rand(batch, seq, generator=g) + 0.5
+    out = dict(input_ids=np_(input_ids), labels=np_(labels), encoder_hidden_states=np_(enc), cond_embeds=np_(cond),
+               micro_conds=np_(micro), loss_weight=np_(loss_weight), label_smoothing=np.float32(0.1))
+    for k, v in model.state_dict().items():
+        out["param." + k] = np_(v)
+    # (1) plain mean cross-entropy, all gradients
+    logits, loss = model(input_ids, enc, cond, micro, labels=labels)
+    loss.backward()
+    out["logits"], out["loss"] = np_(logits), np_(loss)
+    for k, p_ in model.named_parameters():
+        out["grad." + k] = np_(p_.grad)
+    # (2) label smoothing + per-token loss weights (training/train_muse.py:742-750)
+    model.zero_grad()
+    _, loss_w = model(input_ids, enc, cond, micro, labels=labels, label_smoothing=0.1, loss_weight=loss_weight)
+    out["loss_weighted"] = np_(loss_w)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    import json
+    with open(os.path.join(HERE, "config_" + name + ".json"), "w") as f:
+        json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, f, indent=1, sort_keys=True)
+    print(name, "loss", float(loss), "weighted", float(loss_w), "logits", tuple(logits.shape), "max|logit|", float(logits.abs().max()))
+
+
 if __name__ == "__main__":
     golden_transformer("transformer_tiny", W.TRANSFORMER_TINY, batch=3, seed=100, label_smoothing=0.0)
     golden_transformer("transformer_tiny_ls", W.TRANSFORMER_TINY, batch=2, seed=110, label_smoothing=0.1)
@@ -101,3 +155,4 @@ if __name__ == "__main__":
     golden_vqgan("vqgan_tiny", W.VQGAN_TINY, batch=2, seed=200)
     golden_mask("mask_b64", batch=64, seq=256, seed=300, mask_id=2047, codebook_size=1024, min_rate=0.0)
     golden_mask("mask_small", batch=5, seq=16, seed=310, mask_id=47, codebook_size=32, min_rate=0.3)
+    golden_uvit("uvit_tiny", UVIT_TINY, batch=2, seq=16, text_len=7, seed=400)

@@ -65,3 +65,34 @@ def test_mask_sampling(golden_dir, name):
     assert np.array_equal(ids.numpy(), g["input_ids"])      # bit-exact mask indices
     assert np.array_equal(labels.numpy(), g["labels"])
     np.testing.assert_array_equal(prob.numpy(), g["mask_prob"])
+
+
+def test_uvit_oracle_vs_reference_golden(golden_dir):
+    """SURVEY.md section 8 row a12 (MaskGiTUViT_v2, config 4): logits, plain / smoothed+weighted loss and EVERY parameter
+    gradient of the CPU restatement against the real reference (tests/golden/make_golden.py::golden_uvit)"""
+    import json
+    from oracle import uvit_oracle as U
+    g = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    sd = {k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}
+    args = [torch.from_numpy(g[k]) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    labels = torch.from_numpy(g["labels"])
+    logits, loss, grads = U.uvit_loss_and_grads(sd, cfg, *args, labels)
+    ref_logits = torch.from_numpy(g["logits"])
+    assert float(ref_logits.abs().max()) > 0.5          # the perturbed init really exercises the network
+    assert torch.allclose(logits, ref_logits, rtol=1e-5, atol=1e-5 * float(ref_logits.abs().max()))
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    checked = 0
+    for k in g.files:
+        if k.startswith("grad."):
+            ref = torch.from_numpy(g[k])
+            got = grads[k[len("grad."):]]
+            assert got.shape == ref.shape
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-9, k
+            checked += 1
+    assert checked == len(sd)                           # no bias-free buffers: every state-dict entry is a parameter
+    _, loss_w = U.uvit_forward(sd, cfg, *args, labels=labels, label_smoothing=float(g["label_smoothing"]),
+                               loss_weight=torch.from_numpy(g["loss_weight"]))
+    assert abs(float(loss_w) - float(g["loss_weighted"])) < 1e-5 * abs(float(g["loss_weighted"]))
+    # inference call signature: logits only
+    assert U.uvit_forward(sd, cfg, *args).shape == ref_logits.shape
