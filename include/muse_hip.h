@@ -208,6 +208,26 @@ int muse_gather_rows(const float* table, const int64_t* idx, void* out, int32_t 
  * out[lane*4 + j] for a 64-lane wave reading lds[i] = i (uint16) with per-lane byte address addr[lane]. */
 int muse_probe_tr16(const int32_t* addr, int32_t* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * MaskGiTUViT_v2 (muse/modeling_transformer_v2.py) - the kernels that model needs beyond the
+ * MaskGit ones.  f32, forward.  (csrc/uvit.hip)
+ * muse_norm_res_fwd: v = x (+ res); pre = v (optional); y = RMSNorm(v) * w (mode 0, unfused_rms_norm :673-691) or
+ *   LayerNorm(v) * w (mode 1, unfused_layer_norm :726-737); w may be NULL.  cols % 4 == 0.
+ * muse_adaln_fwd: AdaLNModulation :1025-1037, y[b,r,:] = x[b,r,:] * (1 + ss[b,:C]) + ss[b,C:], ss = mapper(silu(cond)).
+ * muse_dwconv3x3_nhwc: ResBlock.depthwise :596-603 (groups = C, padding 1), weight [C][3][3].
+ * muse_grn_fwd: GlobalResponseNorm :741-751 on [B, S, C]; scratch B*C floats.
+ * muse_sinusoidal_encode: sinusoidal_encode :59-76, out [n, dim].
+ * muse_weighted_mean: out[0] = sum(v*w) / sum(w)  (per-token loss weighting :311-316). */
+int muse_norm_res_fwd(const float* x, const float* res, const float* w, float* y, float* pre, int64_t rows, int32_t cols,
+                      float eps, int32_t mode, void* stream);
+int muse_adaln_fwd(const float* x, const float* ss, float* y, int32_t batch, int64_t rows_per_batch, int32_t C, void* stream);
+int muse_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+int muse_dwconv3x3_nhwc(const float* x, const float* w, float* y, int32_t batch, int32_t H, int32_t W, int32_t C, void* stream);
+int muse_grn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* scratch, int32_t batch, int64_t S,
+                 int32_t C, void* stream);
+int muse_sinusoidal_encode(const float* f, float* out, int64_t n, int32_t dim, float max_positions, void* stream);
+int muse_weighted_mean(const float* v, const float* w, float* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

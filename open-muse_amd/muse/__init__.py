@@ -2,16 +2,17 @@
 
 Same import surface as the reference package for the classes on the path (reference muse/__init__.py:18-25):
 MaskGitTransformer, MaskGitVQGAN, PipelineMuse, get_mask_chedule; everything computes through libmuse_hip.so
-(hand-written HIP kernels for gfx950).  Components the hot path does not touch (taming/MoVQ/Paella VQ models, EMA,
-U-ViT) are not part of this build.
+(hand-written HIP kernels for gfx950).  Components the hot path does not touch (taming/MoVQ/Paella VQ models, EMA)
+are not part of this build; MaskGiTUViT (config 4) is forward-only in round 1.
 """
 __version__ = "0.0.1"
 
 from .modeling_maskgit_vqgan import MaskGitVQGAN
 from .modeling_transformer import MaskGitTransformer
+from .modeling_transformer_v2 import MaskGiTUViT, MaskGiTUViT_v2
 from .pipeline_muse import PipelineMuse
 from .sampling import get_mask_chedule
 from .training import FusedAdamW, GradReducer, TrainStep, prepare_inputs_and_labels
 
-__all__ = ["MaskGitVQGAN", "MaskGitTransformer", "PipelineMuse", "get_mask_chedule", "FusedAdamW", "GradReducer",
+__all__ = ["MaskGitVQGAN", "MaskGitTransformer", "MaskGiTUViT", "MaskGiTUViT_v2", "PipelineMuse", "get_mask_chedule", "FusedAdamW", "GradReducer",
            "TrainStep", "prepare_inputs_and_labels"]

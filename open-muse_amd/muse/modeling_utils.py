@@ -120,11 +120,12 @@ class ConfigMixin:
             raise ValueError("Please make sure to provide a config as the first positional argument.")
         config = dict(config)
         init_keys = cls._get_init_keys() - {"self", "kwargs"}
+        kwargs_only = not init_keys   # `def __init__(self, **kwargs)` (MaskGiTUViT_v2): the reference passes the whole config (:908)
         init_dict, unused = {}, {}
         for k, v in {**config, **kwargs}.items():
             if k.startswith("_"):
                 continue
-            if k in init_keys:
+            if kwargs_only or k in init_keys:
                 init_dict[k] = v
             else:
                 unused[k] = v

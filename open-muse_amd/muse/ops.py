@@ -362,7 +362,7 @@ def embed_bwd(ids, dout, dword, dpos, accumulate):
                                V, 1 if accumulate else 0, stream()), "muse_embed_bwd")
 
 
-def cross_entropy_fwd(logits, labels, label_smoothing, vocab=None):
+def cross_entropy_fwd(logits, labels, label_smoothing, vocab=None, want_rows=False):
     """logits [rows, ld] with the first `vocab` columns valid; returns (loss_out[2] = (mean loss, n_valid), lse[rows])"""
     require_gpu(logits, labels)
     rows = logits.shape[0]
@@ -373,6 +373,8 @@ def cross_entropy_fwd(logits, labels, label_smoothing, vocab=None):
     check(lib().muse_cross_entropy_fwd(logits.data_ptr(), dt(logits), labels.data_ptr(), row_loss.data_ptr(), lse.data_ptr(),
                                        loss_out.data_ptr(), rows, V, logits.stride(0), label_smoothing, stream()),
           "muse_cross_entropy_fwd")
+    if want_rows:
+        return loss_out, lse, row_loss   # row_loss[r] = 0 for ignored rows (reduction="none" semantics)
     return loss_out, lse
 
 
@@ -560,6 +562,68 @@ def gather_rows(table, idx, out_dtype):
     cols = table.shape[1]
     out = torch.empty((rows, cols), dtype=out_dtype, device=table.device)
     check(lib().muse_gather_rows(table.data_ptr(), idx.data_ptr(), out.data_ptr(), dt(out), rows, cols, stream()), "muse_gather_rows")
+    return out
+
+
+# ---- MaskGiTUViT_v2 : f32 forward ops --------------------------------------------------------
+def norm_res_fwd(x, w, eps, mode, residual=None, want_pre=False):
+    """v = x (+ residual); y = RMSNorm(v) * w (mode 0) / LayerNorm(v) * w (mode 1); returns (y, v or None)"""
+    require_gpu(x)
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    pre = torch.empty_like(x) if want_pre else None
+    check(lib().muse_norm_res_fwd(x.data_ptr(), ptr(residual), ptr(w), y.data_ptr(), ptr(pre), rows, cols, eps, mode, stream()),
+          "muse_norm_res_fwd")
+    return y, pre
+
+
+def adaln_fwd(x, ss, batch):
+    """x [batch * rows, C], ss [batch, 2C] -> x * (1 + scale) + shift"""
+    require_gpu(x, ss)
+    rows, C_ = x.shape
+    y = torch.empty_like(x)
+    check(lib().muse_adaln_fwd(x.data_ptr(), ss.data_ptr(), y.data_ptr(), batch, rows // batch, C_, stream()), "muse_adaln_fwd")
+    return y
+
+
+def silu_fwd(x):
+    require_gpu(x)
+    y = torch.empty_like(x)
+    check(lib().muse_silu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), stream()), "muse_silu_fwd")
+    return y
+
+
+def dwconv3x3_nhwc(x, w, B, H, W, C_):
+    """x [B*H*W, C] (NHWC rows), w [C, 1, 3, 3] contiguous"""
+    require_gpu(x, w)
+    y = torch.empty_like(x)
+    check(lib().muse_dwconv3x3_nhwc(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, C_, stream()), "muse_dwconv3x3_nhwc")
+    return y
+
+
+def grn_fwd(x, gamma, beta, B, S):
+    """GlobalResponseNorm over the S pixels of each image; x [B*S, C]"""
+    require_gpu(x, gamma, beta)
+    C_ = x.shape[1]
+    y = torch.empty_like(x)
+    scratch = torch.empty(B * C_, dtype=torch.float32, device=x.device)
+    check(lib().muse_grn_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), scratch.data_ptr(), B, S, C_, stream()),
+          "muse_grn_fwd")
+    return y
+
+
+def sinusoidal_encode(features, dim, max_positions=10000.0):
+    require_gpu(features)
+    f = features.reshape(-1).float().contiguous()
+    out = torch.empty((f.numel(), dim), dtype=torch.float32, device=f.device)
+    check(lib().muse_sinusoidal_encode(f.data_ptr(), out.data_ptr(), f.numel(), dim, max_positions, stream()), "muse_sinusoidal_encode")
+    return out
+
+
+def weighted_mean(v, w):
+    require_gpu(v, w)
+    out = torch.empty(1, dtype=torch.float32, device=v.device)
+    check(lib().muse_weighted_mean(v.data_ptr(), w.data_ptr(), out.data_ptr(), v.numel(), stream()), "muse_weighted_mean")
     return out
 
 

@@ -1,0 +1,142 @@
+"""SURVEY.md section 8 row a12 — MaskGiTUViT_v2 (config 4) on the HIP path, forward only (round 1): the new row / elementwise
+kernels against plain torch, and the whole model against the real reference's golden (tiny config) and the pinned CPU oracle
+(mid config with the real text length 77).  f32 ("parity mode"): tolerances 1e-5-class on ops, 1e-4 on logits."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from muse import ops
+    return ops
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 32), (67, 768), (130, 1024), (3, 4100)])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_norm_with_residual_stream(rows, cols, mode, with_res):
+    ops = _ops()
+    x, r, w = rnd((rows, cols), 1, 2.0) + 0.3, rnd((rows, cols), 2), 1 + 0.1 * rnd((cols,), 3)
+    v = (x + r if with_res else x).double()
+    if mode == 0:
+        ref = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-6) * w.double()
+    else:
+        ref = F.layer_norm(v, (cols,), w.double(), None, 1e-6)
+    y, pre = ops.norm_res_fwd(x.to(DEV), w.to(DEV), 1e-6, mode, residual=r.to(DEV) if with_res else None, want_pre=True)
+    assert rel_err(y, ref) < 2e-6
+    assert torch.equal(pre.cpu(), (x + r) if with_res else x)
+    y2, none = ops.norm_res_fwd(x.to(DEV), None, 1e-6, mode, residual=r.to(DEV) if with_res else None)   # no gain vector
+    assert none is None and rel_err(y2, ref / w.double()) < 2e-6
+
+
+def test_adaln_silu_sinusoid_weighted_mean():
+    ops = _ops()
+    B, S, C = 3, 16, 24
+    x, ss = rnd((B * S, C), 10), rnd((B, 2 * C), 11)
+    ref = x.view(B, S, C) * (1 + ss[:, None, :C]) + ss[:, None, C:]
+    assert rel_err(ops.adaln_fwd(x.to(DEV), ss.to(DEV), B), ref.reshape(B * S, C)) < 1e-6
+    z = rnd((1000,), 12, 3.0)
+    assert rel_err(ops.silu_fwd(z.to(DEV)), F.silu(z.double())) < 1e-6
+    feats = torch.tensor([256.0, 256.0, 0.0, 0.0, 6.0, 512.0, 384.0, 16.0, 8.0, 5.5])
+    for dim in (16, 256, 9):
+        half = dim // 2
+        freq = torch.exp(torch.arange(half, dtype=torch.float32) * (-math.log(10000) / half))
+        ang = feats[:, None] * freq[None, :]
+        ref = torch.cat([ang.cos(), ang.sin()], dim=1)
+        if dim % 2:
+            ref = F.pad(ref, (0, 1))
+        got = ops.sinusoidal_encode(feats.to(DEV), dim).cpu()
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-4   # angles up to 512 rad in f32
+    v, w = rnd((777,), 13).abs(), torch.rand(777) + 0.5
+    assert abs(float(ops.weighted_mean(v.to(DEV), w.to(DEV))[0]) - float((v * w).sum() / w.sum())) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 24), (1, 16, 16, 96), (3, 5, 7, 8)])
+def test_depthwise_conv_and_grn(B, H, W, C):
+    ops = _ops()
+    x = rnd((B, H, W, C), 20)
+    w = rnd((C, 1, 3, 3), 21, 0.3)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, padding=1, groups=C).permute(0, 2, 3, 1)
+    got = ops.dwconv3x3_nhwc(x.reshape(-1, C).contiguous().to(DEV), w.to(DEV), B, H, W, C)
+    assert rel_err(got.view(B, H, W, C), ref) < 1e-6
+    gamma, beta = rnd((C,), 22), rnd((C,), 23)
+    xd = x.double()
+    gx = torch.norm(xd, p=2, dim=(1, 2), keepdim=True)
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    ref2 = gamma.double() * (xd * nx) + beta.double() + xd
+    got2 = ops.grn_fwd(x.reshape(-1, C).contiguous().to(DEV), gamma.to(DEV), beta.to(DEV), B, H * W)
+    assert rel_err(got2.view(B, H, W, C), ref2) < 2e-6
+
+
+def _load_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    sd = {k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}
+    return g, cfg, sd
+
+
+def test_uvit_forward_vs_reference_golden(golden_dir):
+    """logits and both losses of the real reference (tests/golden/make_golden.py::golden_uvit) on the tiny configuration"""
+    import muse
+    g, cfg, sd = _load_golden(golden_dir)
+    model = muse.MaskGiTUViT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV)
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    ref_logits = torch.from_numpy(g["logits"])
+    logits, loss = model(*args, labels=labels)
+    assert logits.shape == ref_logits.shape
+    assert rel_err(logits, ref_logits) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    _, loss_w = model(*args, labels=labels, label_smoothing=float(g["label_smoothing"]),
+                      loss_weight=torch.from_numpy(g["loss_weight"]).to(DEV))
+    assert abs(float(loss_w) - float(g["loss_weighted"])) < 1e-4 * abs(float(g["loss_weighted"]))
+    assert rel_err(model(*args), ref_logits) < 1e-4          # inference call: logits only
+
+
+def test_uvit_forward_vs_oracle_text77():
+    """a mid-size configuration with the real text length (77 CLIP tokens), 8 x 8 tokens, head dims 24 / 32, against the
+    pinned CPU oracle"""
+    import muse
+    from oracle import uvit_oracle as U
+    cfg = dict(hidden_size=128, cond_embed_dim=48, micro_cond_encode_dim=32, micro_cond_embed_dim=160, encoder_hidden_size=80,
+               vocab_size=264, codebook_size=256, in_channels=64, block_out_channels=(96,), num_res_blocks=2,
+               block_num_heads=4, num_hidden_layers=3, num_attention_heads=4, intermediate_size=192, layer_norm_eps=1e-6)
+    torch.manual_seed(7)
+    model = muse.MaskGiTUViT(**cfg)
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for _, p in model.named_parameters():
+            if float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)   # the zero-initialised tensors
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    B, S, L = 2, 64, 77
+    ids = torch.randint(0, cfg["vocab_size"], (B, S), generator=g)
+    labels = torch.where(torch.rand(B, S, generator=g) < 0.5, torch.randint(0, 256, (B, S), generator=g), torch.full((B, S), -100))
+    enc, cond = torch.randn(B, L, 80, generator=g), torch.randn(B, 48, generator=g)
+    micro = torch.tensor([[256.0, 256.0, 0.0, 0.0, 6.0], [512.0, 512.0, 32.0, 64.0, 4.5]])
+    ocfg = dict(model.config)
+    ref_logits, ref_loss = U.uvit_forward(sd, ocfg, ids, enc, cond, micro, labels=labels)
+    model.to(DEV)
+    logits, loss = model(ids.to(DEV), enc.to(DEV), cond.to(DEV), micro.to(DEV), labels=labels.to(DEV))
+    assert rel_err(logits, ref_logits) < 1e-4
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))

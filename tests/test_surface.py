@@ -140,3 +140,39 @@ def test_host_side_plans():
     assert not ops.conv_gn_stats_ok(20, 24, 128, 32)                # 480 pixels per image
     assert not ops.conv_gn_stats_ok(16, 16, 96, 32)                 # 3 channels per group
     assert not ops.conv_gn_stats_ok(16, 16, 64, 32)                 # 2 channels per group: below one 4-channel chunk
+
+
+def test_uvit_surface_and_roundtrip(golden_dir):
+    """row a12: muse.MaskGiTUViT keeps the reference's state-dict template, config handling and init (CPU side only)"""
+    import json
+    import numpy as np
+    import muse
+    from muse._hip import MuseHipError
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    g = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    ref_shapes = {k[len("param."):]: tuple(g[k].shape) for k in g.files if k.startswith("param.")}
+    torch.manual_seed(0)
+    m = muse.MaskGiTUViT(**cfg, some_unknown_legacy_key=123, block_num_heads_unused=None)   # unknown kwargs are dropped (:140-142)
+    assert muse.MaskGiTUViT is muse.MaskGiTUViT_v2
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == ref_shapes                  # the reference's 120-tensor template
+    assert m.config.mask_token_id == cfg["vocab_size"] - 1 and m.output_size == cfg["codebook_size"]
+    assert "some_unknown_legacy_key" not in m.config
+    # degenerate-at-init structure of the reference (:209-223)
+    assert float(sd["mlm_layer.conv1.weight"].abs().max()) == 0.0
+    assert all(float(v.abs().max()) == 0.0 for k, v in sd.items() if "adaLN_modulation.mapper" in k or k.endswith("adaLN_modulation.mapper.weight"))
+    assert torch.equal(sd["mlm_layer.conv2.weight"][:, :, 0, 0], sd["embed.embeddings.weight"][: cfg["codebook_size"]])
+    assert all(float((v - 1).abs().max()) == 0.0 for k, v in sd.items() if k.endswith("norm.weight"))
+    m.load_state_dict({k: torch.from_numpy(g["param." + k]) for k in ref_shapes}, strict=True)
+    with tempfile.TemporaryDirectory() as d:
+        m.save_pretrained(d)
+        m2 = muse.MaskGiTUViT.from_pretrained(d)
+        assert dict(m2.config)["block_out_channels"] == [24] and not m2.training
+        for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+            assert torch.equal(a, b)
+    with pytest.raises(MuseHipError):                                                # no CPU path
+        m(torch.zeros(1, 16, dtype=torch.long), torch.zeros(1, 7, 24), torch.zeros(1, 16), torch.zeros(1, 5))
+    with pytest.raises(NotImplementedError):
+        muse.MaskGiTUViT(**{**cfg, "norm_type": "layernorm"})
+    with pytest.raises(AssertionError):
+        m.generate()
