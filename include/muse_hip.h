@@ -210,12 +210,12 @@ int muse_probe_tr16(const int32_t* addr, int32_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * MaskGiTUViT_v2 (muse/modeling_transformer_v2.py) - the kernels that model needs beyond the
- * MaskGit ones.  f32, forward.  (csrc/uvit.hip)
+ * MaskGit ones.  f32.  (csrc/uvit.hip)
  * muse_norm_res_fwd: v = x (+ res); pre = v (optional); y = RMSNorm(v) * w (mode 0, unfused_rms_norm :673-691) or
  *   LayerNorm(v) * w (mode 1, unfused_layer_norm :726-737); w may be NULL.  cols % 4 == 0.
  * muse_adaln_fwd: AdaLNModulation :1025-1037, y[b,r,:] = x[b,r,:] * (1 + ss[b,:C]) + ss[b,C:], ss = mapper(silu(cond)).
  * muse_dwconv3x3_nhwc: ResBlock.depthwise :596-603 (groups = C, padding 1), weight [C][3][3].
- * muse_grn_fwd: GlobalResponseNorm :741-751 on [B, S, C]; scratch B*C floats.
+ * muse_grn_fwd: GlobalResponseNorm :741-751 on [B, S, C]; scratch 2*B*C floats, returns [G | N] for the backward.
  * muse_sinusoidal_encode: sinusoidal_encode :59-76, out [n, dim].
  * muse_weighted_mean: out[0] = sum(v*w) / sum(w)  (per-token loss weighting :311-316). */
 int muse_norm_res_fwd(const float* x, const float* res, const float* w, float* y, float* pre, int64_t rows, int32_t cols,
@@ -227,6 +227,24 @@ int muse_grn_fwd(const float* x, const float* gamma, const float* beta, float* y
                  int32_t C, void* stream);
 int muse_sinusoidal_encode(const float* f, float* out, int64_t n, int32_t dim, float max_positions, void* stream);
 int muse_weighted_mean(const float* v, const float* w, float* out, int64_t n, void* stream);
+/* backward of the above (f32).  v = the forward's pre-norm sum x (+ res); dv = dx = dres; dw_partial [nblk, cols] is folded
+ * with muse_colsum (nblk from _nblk; cols <= 4096).  muse_adaln_bwd: dx and dss [B, 2C] = (sum_r dy x | sum_r dy).
+ * muse_dwconv3x3_bwd: dx and dw_partial [nchunk, C*9] (muse_colsum -> dw [C][3][3]).  muse_grn_bwd: `stats` = the forward's
+ * scratch [G | N]; work 4*B*C floats, on return work[0:B*C] = per-image dbeta terms, work[B*C:2*B*C] = per-image dgamma terms
+ * (muse_colsum over the B rows).  muse_scale_rows: x[r, :cols] *= w[r] * num[0] / den[0] (weighted-loss gradient). */
+int muse_norm_res_bwd_nblk(int64_t rows);
+int muse_norm_res_bwd(const float* dy, const float* dpre, const float* v, const float* w, float* dv, float* dw_partial,
+                      int64_t rows, int32_t cols, float eps, int32_t mode, void* stream);
+int muse_adaln_bwd(const float* dy, const float* x, const float* ss, float* dx, float* dss, int32_t batch,
+                   int64_t rows_per_batch, int32_t C, void* stream);
+int muse_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+int muse_dwconv3x3_bwd_nchunk(int64_t pixels);
+int muse_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw_partial, int32_t batch, int32_t H,
+                       int32_t W, int32_t C, void* stream);
+int muse_grn_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* work,
+                 int32_t batch, int64_t S, int32_t C, void* stream);
+int muse_scale_rows(float* x, const float* w, const float* num, const float* den, int64_t rows, int32_t cols, int64_t ld,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // Row / elementwise kernels of MaskGiTUViT_v2 (muse/modeling_transformer_v2.py) that the MaskGit
 // path does not have: norm with a pre-norm residual stream (RMSNorm / LayerNorm), AdaLN modulation, SiLU, depthwise 3x3
-// convolution (NHWC), GlobalResponseNorm, sinusoidal micro-conditioning, weighted mean of per-token losses.  f32, forward.
+// convolution (NHWC), GlobalResponseNorm, sinusoidal micro-conditioning, weighted mean of per-token losses - forward and
+// backward, f32.
 // Everything else of that model (linears, attention, GLU, GELU, gather, cross-entropy) reuses the MaskGit kernels.
 #include "common.h"
 #include "../../include/muse_hip.h"
@@ -136,7 +137,7 @@ extern "C" int muse_dwconv3x3_nhwc(const float* x, const float* w, float* y, int
 
 // =================================================================================================================
 // GlobalResponseNorm (:741-751) on [B, S, C] (S = H*W pixels):  Gx[b,c] = ||x[b,:,c]||_2 ;  Nx = Gx / (mean_c Gx + 1e-6) ;
-// y = gamma * (x * Nx) + beta + x.   scratch: B*C floats.
+// y = gamma * (x * Nx) + beta + x.   scratch: 2*B*C floats, on return [G | N] (the backward's `stats`).
 // =================================================================================================================
 __global__ __launch_bounds__(256) void grn_colnorm_kernel(const float* __restrict__ x, float* __restrict__ gx, long S, int C) {
   __shared__ float red[4][64];
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void grn_colnorm_kernel(const float* __restric
   __syncthreads();
   if (wv == 0 && c < C) gx[b * C + c] = sqrtf((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
-__global__ __launch_bounds__(256) void grn_scale_kernel(float* __restrict__ gx, int C) {   // in place: Gx -> Nx, one block per image
+__global__ __launch_bounds__(256) void grn_scale_kernel(const float* __restrict__ gx, float* __restrict__ nx, int C) {   // N = G / (mean_c G + 1e-6), one block per image
   __shared__ float red[4];
   const long b = blockIdx.x;
   float s = 0.f;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void grn_scale_kernel(float* __restrict__ gx, 
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C;
-  for (int c = threadIdx.x; c < C; c += 256) gx[b * C + c] = gx[b * C + c] / (mean + 1e-6f);
+  for (int c = threadIdx.x; c < C; c += 256) nx[b * C + c] = gx[b * C + c] / (mean + 1e-6f);
 }
 __global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict__ x, const float* __restrict__ nx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -176,10 +177,11 @@ extern "C" int muse_grn_fwd(const float* x, const float* gamma, const float* bet
   const long n = (long)batch * S * C;
   if (n <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  float* nx = scratch + (long)batch * C;   // scratch = [G | N], both kept for the backward
   hipLaunchKernelGGL(grn_colnorm_kernel, dim3((C + 63) / 64, batch), dim3(256), 0, s, x, scratch, (long)S, C);
-  hipLaunchKernelGGL(grn_scale_kernel, dim3(batch), dim3(256), 0, s, scratch, C);
+  hipLaunchKernelGGL(grn_scale_kernel, dim3(batch), dim3(256), 0, s, (const float*)scratch, nx, C);
   long g = (n + 255) / 256; if (g > 65535) g = 65535;
-  hipLaunchKernelGGL(grn_apply_kernel, dim3((unsigned)g), dim3(256), 0, s, x, (const float*)scratch, gamma, beta, y, (long)S, C, n);
+  hipLaunchKernelGGL(grn_apply_kernel, dim3((unsigned)g), dim3(256), 0, s, x, (const float*)nx, gamma, beta, y, (long)S, C, n);
   return (int)hipGetLastError();
 }
 
@@ -228,5 +230,324 @@ __global__ __launch_bounds__(1024) void weighted_mean_kernel(const float* __rest
 extern "C" int muse_weighted_mean(const float* v, const float* w, float* out, int64_t n, void* stream) {
   if (n <= 0) return MUSE_ERR_BAD_ARG;
   hipLaunchKernelGGL(weighted_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, w, out, (long)n);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// ============================================  backward  =========================================================
+// =================================================================================================================
+
+// norm with residual stream, backward.  v = x (+ res) was saved by the forward (`pre`, or x itself when there was no residual).
+//   RMS : xhat = v r            dv = r (g - xhat mean(g xhat))                  g = dy w
+//   LN  : xhat = (v - mu) r     dv = r (g - mean(g) - xhat mean(g xhat))
+//   dv += dpre (gradient that reached the pre-norm residual output);  dx = dres = dv;  dw_partial[block] = sum_rows dy xhat
+// 16 rows per block (4 per wave); per-column dw partials live in registers, folded across the 4 waves through LDS in a fixed order.
+#define NRB_ROWS 16
+extern "C" int muse_norm_res_bwd_nblk(int64_t rows) { return (int)((rows + NRB_ROWS - 1) / NRB_ROWS); }
+
+template <int NIT>
+__global__ __launch_bounds__(256) void norm_res_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dpre,
+                                                           const float* __restrict__ v, const float* __restrict__ w,
+                                                           float* __restrict__ dv, float* __restrict__ dwp, long rows, int cols,
+                                                           float eps, int mode) {
+  __shared__ float red[4096];   // cols <= 4096
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dwacc[NIT][4];          // a wave covers 256 columns per step: NIT = ceil(cols / 256) rounded up to a power of two
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dwacc[it][j] = 0.f;
+  for (int rr = 0; rr < NRB_ROWS / 4; ++rr) {
+    const long row = (long)blockIdx.x * NRB_ROWS + wave * (NRB_ROWS / 4) + rr;
+    if (row >= rows) break;
+    const float* vr = v + row * cols;
+    const float* gr = dy + row * cols;
+    float s = 0.f, q = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+      const f32x4 t = *(const f32x4*)(vr + c);
+      s += (t[0] + t[1]) + (t[2] + t[3]);
+      q += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+    }
+    float mean = 0.f, rstd;
+    if (mode == 0) {
+      rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    } else {
+      mean = wave_sum(s) / (float)cols;
+      float d2 = 0.f;
+      for (int c = lane * 4; c < cols; c += 256) {
+        const f32x4 t = *(const f32x4*)(vr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = t[j] - mean; d2 = fmaf(d, d, d2); }
+      }
+      rstd = 1.0f / sqrtf(wave_sum(d2) / (float)cols + eps);
+    }
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = lane * 4 + 256 * it;
+      if (c < cols) {
+        const f32x4 t = *(const f32x4*)(vr + c), d = *(const f32x4*)(gr + c);
+        f32x4 g = d;
+        if (w) g *= *(const f32x4*)(w + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (t[j] - mean) * rstd;
+          sg += g[j];
+          sgx = fmaf(g[j], xh, sgx);
+          dwacc[it][j] = fmaf(d[j], xh, dwacc[it][j]);
+        }
+      }
+    }
+    const float mg = mode == 0 ? 0.f : wave_sum(sg) / (float)cols;
+    const float mgx = wave_sum(sgx) / (float)cols;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = lane * 4 + 256 * it;
+      if (c < cols) {
+        const f32x4 t = *(const f32x4*)(vr + c);
+        f32x4 g = *(const f32x4*)(gr + c);
+        if (w) g *= *(const f32x4*)(w + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (g[j] - mg - (t[j] - mean) * rstd * mgx);
+        if (dpre) o += *(const f32x4*)(dpre + row * cols + c);
+        *(f32x4*)(dv + row * cols + c) = o;
+      }
+    }
+  }
+  // fold the four waves' column partials in wave order
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = lane * 4 + 256 * it;
+        if (c < cols) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) red[c + j] = wv == 0 ? dwacc[it][j] : red[c + j] + dwacc[it][j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < cols; c += 256) dwp[(long)blockIdx.x * cols + c] = red[c];
+}
+extern "C" int muse_norm_res_bwd(const float* dy, const float* dpre, const float* v, const float* w, float* dv, float* dw_partial,
+                                 int64_t rows, int32_t cols, float eps, int32_t mode, void* stream) {
+  if (cols % 4 || cols > 4096 || (mode != 0 && mode != 1)) return MUSE_ERR_UNSUPPORTED;
+  if (rows <= 0) return 0;
+  const int nblk = muse_norm_res_bwd_nblk(rows), nit = (cols + 255) / 256;
+  hipStream_t s = (hipStream_t)stream;
+#define NRB(N) hipLaunchKernelGGL(norm_res_bwd_kernel<N>, dim3(nblk), dim3(256), 0, s, dy, dpre, v, w, dv, dw_partial, (long)rows, cols, eps, mode)
+  if (nit <= 1) NRB(1); else if (nit <= 2) NRB(2); else if (nit <= 4) NRB(4); else if (nit <= 8) NRB(8); else NRB(16);
+#undef NRB
+  return (int)hipGetLastError();
+}
+
+// AdaLN backward: dx = dy (1 + scale[b]);  dss[b, c] = sum_r dy x,  dss[b, C + c] = sum_r dy   (r over the rows of image b)
+__global__ __launch_bounds__(256) void adaln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ ss,
+                                                           float* __restrict__ dx, long rows_per_batch, int C, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long e = i * 4, row = e / C;
+    const int c = (int)(e - row * C);
+    const long b = row / rows_per_batch;
+    const f32x4 g = *(const f32x4*)(dy + e), sc = *(const f32x4*)(ss + b * 2 * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] * (1.0f + sc[j]);
+    *(f32x4*)(dx + e) = o;
+  }
+}
+__global__ __launch_bounds__(256) void adaln_bwd_ss_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dss, long S, int C) {
+  __shared__ float r0[4][64], r1[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long b = blockIdx.y;
+  float a = 0.f, s = 0.f;
+  if (c < C)
+    for (long r = wv; r < S; r += 4) { const float g = dy[(b * S + r) * C + c]; a = fmaf(g, x[(b * S + r) * C + c], a); s += g; }
+  r0[wv][lane] = a; r1[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    dss[b * 2 * C + c] = (r0[0][lane] + r0[1][lane]) + (r0[2][lane] + r0[3][lane]);
+    dss[b * 2 * C + C + c] = (r1[0][lane] + r1[1][lane]) + (r1[2][lane] + r1[3][lane]);
+  }
+}
+extern "C" int muse_adaln_bwd(const float* dy, const float* x, const float* ss, float* dx, float* dss, int32_t batch,
+                              int64_t rows_per_batch, int32_t C, void* stream) {
+  if (C % 4) return MUSE_ERR_UNSUPPORTED;
+  const long n4 = (long)batch * rows_per_batch * C / 4;
+  if (n4 <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  long g = (n4 + 255) / 256; if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(adaln_bwd_dx_kernel, dim3((unsigned)g), dim3(256), 0, s, dy, ss, dx, (long)rows_per_batch, C, n4);
+  hipLaunchKernelGGL(adaln_bwd_ss_kernel, dim3((C + 63) / 64, batch), dim3(256), 0, s, dy, x, dss, (long)rows_per_batch, C);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i], sg = 1.0f / (1.0f + expf(-v));
+    dx[i] = dy[i] * sg * (1.0f + v * (1.0f - sg));
+  }
+}
+extern "C" int muse_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  long g = (n + 255) / 256; if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)n);
+  return (int)hipGetLastError();
+}
+
+// depthwise 3x3 backward: dx = correlation of dy with the flipped taps;  dw[c][t] = sum_pixels dy[p] x[p + tap t]
+// dw partials: one block per 256 pixels -> dwp[chunk][c * 9 + t], folded by muse_colsum
+#define DW_PIX 256
+extern "C" int muse_dwconv3x3_bwd_nchunk(int64_t pixels) { return (int)((pixels + DW_PIX - 1) / DW_PIX); }
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                               float* __restrict__ dx, int H, int W, int C, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H);
+    const long b = t / H;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int oy = yy - (ky - 1);            // output pixel that read this input through tap (ky, kx)
+      if (oy < 0 || oy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ox = xx - (kx - 1);
+        if (ox < 0 || ox >= W) continue;
+        acc = fmaf(dy[((b * H + oy) * W + ox) * C + c], w[c * 9 + ky * 3 + kx], acc);
+      }
+    }
+    dx[i] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               float* __restrict__ dwp, int H, int W, int C, long pixels) {
+  __shared__ float red[4][64 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long p0 = (long)blockIdx.y * DW_PIX, p1 = min(pixels, p0 + DW_PIX);
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  if (c < C) {
+    for (long p = p0 + wv; p < p1; p += 4) {
+      const int xx = (int)(p % W), yy = (int)((p / W) % H);
+      const long b = p / ((long)W * H);
+      const float g = dy[p * C + c];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = xx + kx - 1;
+          if (ix < 0 || ix >= W) continue;
+          acc[ky * 3 + kx] = fmaf(g, x[((b * H + iy) * W + ix) * C + c], acc[ky * 3 + kx]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[wv][lane * 9 + t] = acc[t];
+  __syncthreads();
+  if (wv == 0 && c < C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      dwp[(long)blockIdx.y * C * 9 + (long)c * 9 + t] = (red[0][lane * 9 + t] + red[1][lane * 9 + t]) + (red[2][lane * 9 + t] + red[3][lane * 9 + t]);
+  }
+}
+extern "C" int muse_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw_partial, int32_t batch,
+                                  int32_t H, int32_t W, int32_t C, void* stream) {
+  const long pixels = (long)batch * H * W, n = pixels * C;
+  if (n <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  long g = (n + 255) / 256; if (g > 65535) g = 65535;
+  hipLaunchKernelGGL(dwconv3x3_bwd_dx_kernel, dim3((unsigned)g), dim3(256), 0, s, dy, w, dx, H, W, C, n);
+  hipLaunchKernelGGL(dwconv3x3_bwd_dw_kernel, dim3((C + 63) / 64, muse_dwconv3x3_bwd_nchunk(pixels)), dim3(256), 0, s, dy, x,
+                     dw_partial, H, W, C, pixels);
+  return (int)hipGetLastError();
+}
+
+// GlobalResponseNorm backward.  Saved by the forward: stats[0 : B*C] = G (column norms), stats[B*C : 2*B*C] = N = G / (mean_c G + 1e-6).
+//   S0[b,c] = sum_s dy,  S1[b,c] = sum_s dy x;   dbeta = sum_b S0,  dgamma = sum_b N S1
+//   dL/dN_c = gamma_c S1_c;  dL/dG_c = (dL/dN_c - mean_j(dL/dN_j N_j)) / (m + 1e-6);   dx = dy (gamma N + 1) + x dL/dG_c / G_c
+// work: 4 * B * C floats = [S0 | S1 -> N*S1 | K = dLdG / G | unused]
+__global__ __launch_bounds__(256) void grn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             float* __restrict__ s0, float* __restrict__ s1, long S, int C) {
+  __shared__ float r0[4][64], r1[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long b = blockIdx.y;
+  float a = 0.f, s = 0.f;
+  if (c < C)
+    for (long r = wv; r < S; r += 4) { const float g = dy[(b * S + r) * C + c]; s += g; a = fmaf(g, x[(b * S + r) * C + c], a); }
+  r0[wv][lane] = s; r1[wv][lane] = a;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    s0[b * C + c] = (r0[0][lane] + r0[1][lane]) + (r0[2][lane] + r0[3][lane]);
+    s1[b * C + c] = (r1[0][lane] + r1[1][lane]) + (r1[2][lane] + r1[3][lane]);
+  }
+}
+__global__ __launch_bounds__(256) void grn_bwd_coef_kernel(const float* __restrict__ G, const float* __restrict__ N,
+                                                           const float* __restrict__ gamma, float* __restrict__ s1,
+                                                           float* __restrict__ K, int C) {   // one block per image
+  __shared__ float red[4], redg[4];
+  const long b = blockIdx.x;
+  float t = 0.f, sg = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) { t = fmaf(gamma[c] * s1[b * C + c], N[b * C + c], t); sg += G[b * C + c]; }
+  t = wave_sum(t); sg = wave_sum(sg);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = t; redg[threadIdx.x >> 6] = sg; }
+  __syncthreads();
+  const float mean_an = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C;
+  const float denom = ((redg[0] + redg[1]) + (redg[2] + redg[3])) / (float)C + 1e-6f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float a = gamma[c] * s1[b * C + c], g = G[b * C + c];
+    K[b * C + c] = g > 0.f ? (a - mean_an) / denom / g : 0.f;
+    s1[b * C + c] = N[b * C + c] * s1[b * C + c];     // -> dgamma contribution of this image
+  }
+}
+__global__ __launch_bounds__(256) void grn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ N, const float* __restrict__ K,
+                                                         const float* __restrict__ gamma, float* __restrict__ dx, long S, int C, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long b = i / ((long)S * C);
+    dx[i] = dy[i] * (gamma[c] * N[b * C + c] + 1.0f) + x[i] * K[b * C + c];
+  }
+}
+extern "C" int muse_grn_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* work,
+                            int32_t batch, int64_t S, int32_t C, void* stream) {
+  const long n = (long)batch * S * C, bc = (long)batch * C;
+  if (n <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  float *s0 = work, *s1 = work + bc, *K = work + 2 * bc;
+  hipLaunchKernelGGL(grn_bwd_reduce_kernel, dim3((C + 63) / 64, batch), dim3(256), 0, s, dy, x, s0, s1, (long)S, C);
+  hipLaunchKernelGGL(grn_bwd_coef_kernel, dim3(batch), dim3(256), 0, s, stats, stats + bc, gamma, s1, K, C);
+  long g = (n + 255) / 256; if (g > 65535) g = 65535;
+  hipLaunchKernelGGL(grn_bwd_dx_kernel, dim3((unsigned)g), dim3(256), 0, s, dy, x, stats + bc, (const float*)K, gamma, dx, (long)S, C, n);
+  return (int)hipGetLastError();
+}
+
+// x[r, :] *= w[r] * scal[0] / scal[1]   (weighted cross-entropy backward: per-token weight, n_valid / sum of weights)
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ num,
+                                                         const float* __restrict__ den, long rows, int cols, long ld) {
+  const float k = num[0] / den[0];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * cols; i += (long)gridDim.x * 256) {
+    const long r = i / cols;
+    const int c = (int)(i - r * cols);
+    x[r * ld + c] *= w[r] * k;
+  }
+}
+extern "C" int muse_scale_rows(float* x, const float* w, const float* num, const float* den, int64_t rows, int32_t cols, int64_t ld,
+                               void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  long g = (rows * cols + 255) / 256; if (g > 65535) g = 65535;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, w, num, den, (long)rows, cols, (long)ld);
   return (int)hipGetLastError();
 }

@@ -3,7 +3,7 @@
 Same import surface as the reference package for the classes on the path (reference muse/__init__.py:18-25):
 MaskGitTransformer, MaskGitVQGAN, PipelineMuse, get_mask_chedule; everything computes through libmuse_hip.so
 (hand-written HIP kernels for gfx950).  Components the hot path does not touch (taming/MoVQ/Paella VQ models, EMA)
-are not part of this build; MaskGiTUViT (config 4) is forward-only in round 1.
+are not part of this build; MaskGiTUViT (config 4) runs in f32 (forward + backward) in round 1.
 """
 __version__ = "0.0.1"
 

@@ -95,6 +95,14 @@ SIGNATURES = {
     "muse_grn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_sinusoidal_encode": [c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p],
     "muse_weighted_mean": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
+    "muse_norm_res_bwd_nblk": [c_i64],
+    "muse_norm_res_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p],
+    "muse_adaln_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
+    "muse_silu_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
+    "muse_dwconv3x3_bwd_nchunk": [c_i64],
+    "muse_dwconv3x3_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "muse_grn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
+    "muse_scale_rows": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p],
     "muse_probe_tr16": [c_void_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"muse_embed_bwd_scratch_floats": c_i64}

@@ -1,9 +1,8 @@
 """muse.MaskGiTUViT_v2 / muse.MaskGiTUViT for MI355X — SURVEY.md §8 row a12 (config 4, reference
 muse/modeling_transformer_v2.py:150-319).
 
-STATUS (round 1): forward only (logits, plain / label-smoothed / per-token-weighted loss), f32 ("parity mode": exact-f32 MFMA
-GEMMs, materialised attention = the reference's algorithm).  No backward yet: ``loss.backward()`` is not supported and the
-returned loss carries no graph.  Same constructor kwargs (filtered like ``config_from_legacy_kwargs`` :127-147: unknown keys are
+STATUS (round 1): forward (logits, plain / label-smoothed / per-token-weighted loss) and the hand-written backward of the loss
+(every parameter gradient), f32 ("parity mode": exact-f32 MFMA GEMMs, materialised attention = the reference's algorithm).  Same constructor kwargs (filtered like ``config_from_legacy_kwargs`` :127-147: unknown keys are
 dropped), config keys, state_dict names / shapes and init as the reference.
 
 Everything computes through libmuse_hip.so on channels-last rows ``[B * S, C]``:
@@ -144,6 +143,33 @@ class _Mlm(nn.Module):
         self.conv2 = _Conv(cin, codebook, 1)
 
 
+class _UViTFn(torch.autograd.Function):
+    """one autograd node for the whole network: forward records a tape, backward runs the hand-written reverse pass and hands
+    the parameter gradients (state-dict order) back to autograd"""
+
+    @staticmethod
+    def forward(ctx, model, input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad, *params):
+        logits, loss, tape = model._run_forward(input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad)
+        ctx.model, ctx.tape = model, tape
+        ctx.set_materialize_grads(False)
+        if loss is None:
+            return logits
+        ctx.mark_non_differentiable(logits)
+        return logits, loss
+
+    @staticmethod
+    def backward(ctx, g_logits, g_loss=None):
+        if ctx.tape is None:
+            raise MuseHipError("backward called on a forward that ran without grad")
+        if g_loss is None:
+            raise MuseHipError("MaskGiTUViT_v2: only the loss is differentiable (pass labels)")
+        model = ctx.model
+        G = model._run_backward(ctx.tape, g_loss)
+        ctx.tape = None
+        grads = tuple(G.get(name) for name, _ in model.named_parameters())
+        return (None,) * 9 + grads
+
+
 class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
     def __init__(self, **kwargs):
         super().__init__()
@@ -198,60 +224,143 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             if isinstance(m, _AdaLN):
                 nn.init.constant_(m.mapper.weight, 0)
 
-    # ---- forward --------------------------------------------------------------------------------------------------------
+    # ---- forward / backward ---------------------------------------------------------------------------------------------
+    # Activations are channels-last rows [B * S, C].  Every helper returns (output, saved); the *_bwd twin consumes `saved`,
+    # stores parameter gradients in `G` (name -> tensor) and returns the input gradients.  f32 throughout.
     @staticmethod
     def _f(p):
         return p.data if p.dtype == torch.float32 else p.data.float()
 
+    def _lin(self, x, mod, residual=None):
+        return ops.linear(x, self._f(mod.weight).reshape(mod.weight.shape[0], -1), residual=residual)
+
+    def _lin_bwd(self, dy, x, mod, name, G, need_dx=True):
+        w2 = self._f(mod.weight).reshape(mod.weight.shape[0], -1)
+        dw = torch.empty_like(w2)
+        ops.linear_wgrad(dy, x, dw, False)
+        G[name + ".weight"] = dw.view(mod.weight.shape)
+        return ops.linear_dgrad(dy, w2) if need_dx else None
+
     def _norm(self, x, mod, mode=0, residual=None, want_pre=False):
-        return ops.norm_res_fwd(x, self._f(mod.weight), float(self.config.layer_norm_eps), mode, residual=residual, want_pre=want_pre)
+        y, pre = ops.norm_res_fwd(x, self._f(mod.weight), float(self.config.layer_norm_eps), mode, residual=residual,
+                                  want_pre=want_pre)
+        return y, pre
+
+    def _norm_bwd(self, dy, v, mod, name, G, mode=0, dpre=None):
+        """v = the tensor that was normalised (x + residual); returns d(x) = d(residual)"""
+        dv, dw = ops.norm_res_bwd(dy, v, self._f(mod.weight), float(self.config.layer_norm_eps), mode, dpre=dpre)
+        G[name + ".weight"] = dw
+        return dv
 
     def _attention(self, x, ctx, att: _Attn, B, Sq, Skv, nh, residual=None):
         """reference Attention :834-915, materialised: scores = alpha q k^T (batched per head), softmax, P v, out projection"""
         Cq = x.shape[1]
         hd = Cq // nh
-        q = ops.linear(x, self._f(att.query.weight))
-        k = ops.linear(ctx, self._f(att.key.weight))
-        v = ops.linear(ctx, self._f(att.value.weight))
+        q, k, v = self._lin(x, att.query), self._lin(ctx, att.key), self._lin(ctx, att.value)
         Sp = (Skv + 7) // 8 * 8
         P = torch.empty((B * nh, Sq, Sp), dtype=torch.float32, device=x.device)
         alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
-        ops.gemm(q, k, P, Sq, Skv, hd, la=0, lb=0, lda=Cq, ldb=Cq, ldc=Sp, alpha=alpha, batch=B * nh, zdiv=nh,
-                 sA=(Sq * Cq, hd), sB=(Skv * Cq, hd), sC=(nh * Sq * Sp, Sq * Sp))
+        sQ, sK, sP = (Sq * Cq, hd), (Skv * Cq, hd), (nh * Sq * Sp, Sq * Sp)
+        ops.gemm(q, k, P, Sq, Skv, hd, la=0, lb=0, lda=Cq, ldb=Cq, ldc=Sp, alpha=alpha, batch=B * nh, zdiv=nh, sA=sQ, sB=sK, sC=sP)
         ops.softmax_(P, B * nh * Sq, Skv, Sp)
         o = torch.empty((B * Sq, Cq), dtype=torch.float32, device=x.device)
-        ops.gemm(P, v, o, Sq, hd, Skv, la=0, lb=1, lda=Sp, ldb=Cq, ldc=Cq, batch=B * nh, zdiv=nh,
-                 sA=(nh * Sq * Sp, Sq * Sp), sB=(Skv * Cq, hd), sC=(Sq * Cq, hd))
-        return ops.linear(o, self._f(att.out.weight), residual=residual)
+        ops.gemm(P, v, o, Sq, hd, Skv, la=0, lb=1, lda=Sp, ldb=Cq, ldc=Cq, batch=B * nh, zdiv=nh, sA=sP, sB=sK, sC=sQ)
+        y = self._lin(o, att.out, residual=residual)
+        return y, dict(x=x, ctx=ctx, q=q, k=k, v=v, P=P, o=o, dims=(B, Sq, Skv, nh, hd, Cq, Sp, alpha))
+
+    def _attention_bwd(self, dy, sv, att: _Attn, name, G, self_attn=False):
+        """-> (dx, dctx); for self attention the two are already summed and returned as dx (dctx = None)"""
+        B, Sq, Skv, nh, hd, Cq, Sp, alpha = sv["dims"]
+        q, k, v, P = sv["q"], sv["k"], sv["v"], sv["P"]
+        sQ, sK, sP = (Sq * Cq, hd), (Skv * Cq, hd), (nh * Sq * Sp, Sq * Sp)
+        do = self._lin_bwd(dy, sv["o"], att.out, name + ".out", G)
+        dv = torch.empty_like(v)
+        ops.gemm(P, do, dv, Skv, hd, Sq, la=1, lb=1, lda=Sp, ldb=Cq, ldc=Cq, batch=B * nh, zdiv=nh, sA=sP, sB=sQ, sC=sK)   # dV = P^T dO
+        dP = torch.empty_like(P)
+        ops.gemm(do, v, dP, Sq, Skv, hd, la=0, lb=0, lda=Cq, ldb=Cq, ldc=Sp, batch=B * nh, zdiv=nh, sA=sQ, sB=sK, sC=sP)   # dP = dO V^T
+        ops.softmax_bwd_(P, dP, B * nh * Sq, Skv, Sp)                                                                     # dS in place
+        dq = torch.empty_like(q)
+        ops.gemm(dP, k, dq, Sq, hd, Skv, la=0, lb=1, lda=Sp, ldb=Cq, ldc=Cq, alpha=alpha, batch=B * nh, zdiv=nh, sA=sP, sB=sK, sC=sQ)
+        dk = torch.empty_like(k)
+        ops.gemm(dP, q, dk, Skv, hd, Sq, la=1, lb=1, lda=Sp, ldb=Cq, ldc=Cq, alpha=alpha, batch=B * nh, zdiv=nh, sA=sP, sB=sQ, sC=sK)
+        dx = self._lin_bwd(dq, sv["x"], att.query, name + ".query", G)
+        dctx = self._lin_bwd(dk, sv["ctx"], att.key, name + ".key", G)
+        wv = self._f(att.value.weight)
+        gv = torch.empty_like(wv)
+        ops.linear_wgrad(dv, sv["ctx"], gv, False)
+        G[name + ".value.weight"] = gv
+        # dctx += dv Wv ; for self attention query and context are the same tensor: everything lands in dx
+        ops.gemm(dv, wv, dctx, dv.shape[0], wv.shape[1], Cq, la=0, lb=1, lda=Cq, ldb=wv.shape[1], ldc=dctx.shape[1], accumulate=True)
+        if self_attn:
+            return dx.add_(dctx), None
+        return dx, dctx
 
     def _adaln(self, x, mod: _AdaLN, scond, B):
-        return ops.adaln_fwd(x, ops.linear(scond, self._f(mod.mapper.weight)), B)
+        ss = self._lin(scond, mod.mapper)
+        return ops.adaln_fwd(x, ss, B), dict(x=x, ss=ss)
+
+    def _adaln_bwd(self, dy, sv, mod: _AdaLN, name, G, scond, dscond, B):
+        dx, dss = ops.adaln_bwd(dy, sv["x"], sv["ss"], B)
+        d = self._lin_bwd(dss, scond, mod.mapper, name + ".mapper", G)
+        dscond.add_(d)            # every AdaLN reads the same silu(cond): sum of a [B, H] tensor (plumbing)
+        return dx
 
     def _res_block(self, h, blk: _ResBlock, scond, B, side):
         C = h.shape[1]
-        d = ops.dwconv3x3_nhwc(h, self._f(blk.depthwise.weight).contiguous(), B, side, side, C)
+        wdw = self._f(blk.depthwise.weight).contiguous()
+        d = ops.dwconv3x3_nhwc(h, wdw, B, side, side, C)
         n, _ = self._norm(d, blk.norm.norm)
-        a = ops.gelu_fwd(ops.linear(n, self._f(blk.channelwise["0"].weight)))
+        a = self._lin(n, blk.channelwise["0"])
+        ga = ops.gelu_fwd(a)
         grn = blk.channelwise["2"]
-        g = ops.grn_fwd(a, self._f(grn.gamma).reshape(-1).contiguous(), self._f(grn.beta).reshape(-1).contiguous(), B, side * side)
-        x = ops.linear(g, self._f(blk.channelwise["4"].weight), residual=h)          # + x_res (:616)
-        return self._adaln(x, blk.adaLN_modulation, scond, B)
+        gamma = self._f(grn.gamma).reshape(-1).contiguous()
+        g, stats = ops.grn_fwd(ga, gamma, self._f(grn.beta).reshape(-1).contiguous(), B, side * side, want_stats=True)
+        x = self._lin(g, blk.channelwise["4"], residual=h)                          # + x_res (:616)
+        y, sva = self._adaln(x, blk.adaLN_modulation, scond, B)
+        return y, dict(h=h, d=d, n=n, a=a, ga=ga, g=g, stats=stats, gamma=gamma, wdw=wdw, ada=sva, side=side)
+
+    def _res_block_bwd(self, dy, sv, blk: _ResBlock, name, G, scond, dscond, B):
+        C = sv["h"].shape[1]
+        side = sv["side"]
+        dx = self._adaln_bwd(dy, sv["ada"], blk.adaLN_modulation, name + ".adaLN_modulation", G, scond, dscond, B)
+        dg = self._lin_bwd(dx, sv["g"], blk.channelwise["4"], name + ".channelwise.4", G)      # dx also flows to h (residual)
+        dga, dgam, dbet = ops.grn_bwd(dg, sv["ga"], sv["gamma"], sv["stats"], B, side * side)
+        grn = blk.channelwise["2"]
+        G[name + ".channelwise.2.gamma"] = dgam.view(grn.gamma.shape)
+        G[name + ".channelwise.2.beta"] = dbet.view(grn.beta.shape)
+        da = ops.gelu_bwd(sv["a"], dga)
+        dn = self._lin_bwd(da, sv["n"], blk.channelwise["0"], name + ".channelwise.0", G)
+        dd = self._norm_bwd(dn, sv["d"], blk.norm.norm, name + ".norm.norm", G)
+        dh, dwdw = ops.dwconv3x3_bwd(dd, sv["h"], sv["wdw"], B, side, side, C)
+        G[name + ".depthwise.weight"] = dwdw
+        return dh.add_(dx)                                                           # + residual path
 
     def _attn_block(self, h, blk: _AttnBlock2D, enc, senc, B, S, L):
-        ctx = ops.linear(senc, self._f(blk.kv_mapper.weight)) if hasattr(blk, "kv_mapper") else enc   # :815-816
+        has_map = hasattr(blk, "kv_mapper")
+        ctx = self._lin(senc, blk.kv_mapper) if has_map else enc                      # :815-816
         nh = self.config.block_num_heads
         n1, _ = self._norm(h, blk.attn_layer_norm)                                    # residual = h (:819)
-        a1 = self._attention(n1, ctx, blk.attention, B, S, L, nh)
+        a1, s1 = self._attention(n1, ctx, blk.attention, B, S, L, nh)
         n2, res = self._norm(a1, blk.crossattn_layer_norm, residual=h, want_pre=True)  # :822
-        return self._attention(n2, ctx, blk.crossattention, B, S, L, nh, residual=res)  # + residual (:824)
+        y, s2 = self._attention(n2, ctx, blk.crossattention, B, S, L, nh, residual=res)  # + residual (:824)
+        return y, dict(h=h, res=res, s1=s1, s2=s2, has_map=has_map)
 
-    @torch.no_grad()
-    def forward(self, input_ids, encoder_hidden_states, cond_embeds, micro_conds, labels=None, label_smoothing=0.0,
-                loss_weight=None):
+    def _attn_block_bwd(self, dy, sv, blk: _AttnBlock2D, name, G, senc, denc, dsenc):
+        """accumulates the context gradient into denc (no kv_mapper) or dsenc (through kv_mapper); returns dh"""
+        dn2, dctx2 = self._attention_bwd(dy, sv["s2"], blk.crossattention, name + ".crossattention", G)
+        dv2 = self._norm_bwd(dn2, sv["res"], blk.crossattn_layer_norm, name + ".crossattn_layer_norm", G, dpre=dy)   # d(a1) = d(h)
+        dn1, dctx1 = self._attention_bwd(dv2, sv["s1"], blk.attention, name + ".attention", G)
+        dh = self._norm_bwd(dn1, sv["h"], blk.attn_layer_norm, name + ".attn_layer_norm", G, dpre=dv2)
+        dctx = dctx1.add_(dctx2)
+        if sv["has_map"]:
+            dsenc.add_(self._lin_bwd(dctx, senc, blk.kv_mapper, name + ".kv_mapper", G))
+        else:
+            denc.add_(dctx)
+        return dh
+
+    def _run_forward(self, input_ids, encoder_hidden_states, cond_embeds, micro_conds, labels, label_smoothing, loss_weight,
+                     need_grad):
         c = self.config
-        for t in (input_ids, encoder_hidden_states, cond_embeds, micro_conds):
-            if not t.is_cuda:
-                raise MuseHipError("MaskGiTUViT_v2 (MI355X build) has no CPU path: move the model and inputs to the GPU")
         B, S = input_ids.shape
         side = int(S ** 0.5)
         if side * side != S:
@@ -259,60 +368,185 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         L = encoder_hidden_states.shape[1]
         H, C = c.hidden_size, c.block_out_channels[0]
         f = self._f
+        T = {}                                                                        # the tape
         # text states :252-253
-        enc = ops.linear(encoder_hidden_states.reshape(B * L, -1).float().contiguous(), f(self.encoder_proj.weight))
-        enc, _ = self._norm(enc, self.encoder_proj_layer_norm)
+        enc_in = encoder_hidden_states.reshape(B * L, -1).float().contiguous()
+        enc0 = self._lin(enc_in, self.encoder_proj)
+        enc, _ = self._norm(enc0, self.encoder_proj_layer_norm)
         senc = ops.silu_fwd(enc) if C != H else None
         # conditioning :255-260
         micro = ops.sinusoidal_encode(micro_conds, c.micro_cond_encode_dim).reshape(B, -1)
-        cond = torch.cat([cond_embeds.float(), micro], dim=1).contiguous()
-        cond = ops.linear(ops.silu_fwd(ops.linear(cond, f(self.cond_embed["0"].weight))), f(self.cond_embed["2"].weight))
+        cond_in = torch.cat([cond_embeds.float(), micro], dim=1).contiguous()
+        c1 = self._lin(cond_in, self.cond_embed["0"])
+        sc1 = ops.silu_fwd(c1)
+        cond = self._lin(sc1, self.cond_embed["2"])
         scond = ops.silu_fwd(cond)                                                    # every AdaLN sees silu(cond) (:1032)
         # ConvEmbed :485-500
-        emb = ops.gather_rows(f(self.embed.embeddings.weight), input_ids.reshape(-1).contiguous(), torch.float32)
-        emb, _ = self._norm(emb, self.embed.layer_norm)
-        h = ops.linear(emb, f(self.embed.conv.weight).reshape(C, -1))
+        ids = input_ids.reshape(-1).contiguous()
+        emb0 = ops.gather_rows(f(self.embed.embeddings.weight), ids, torch.float32)
+        emb, _ = self._norm(emb0, self.embed.layer_norm)
+        h = self._lin(emb, self.embed.conv)
+        T["down"] = []
         blk = self.down_blocks[0]
         for i in range(c.num_res_blocks):
-            h = self._res_block(h, blk.res_blocks[i], scond, B, side)
-            h = self._attn_block(h, blk.attention_blocks[i], enc, senc, B, S, L)
+            h, sr = self._res_block(h, blk.res_blocks[i], scond, B, side)
+            h, sa = self._attn_block(h, blk.attention_blocks[i], enc, senc, B, S, L)
+            T["down"].append((sr, sa))
+        hd_in = h
         n, _ = self._norm(h, self.project_to_hidden_norm)
-        t = ops.linear(n, f(self.project_to_hidden.weight))
+        t = self._lin(n, self.project_to_hidden)
+        T["proj_in"] = dict(h=hd_in, n=n)
         res = None
         nh = c.num_attention_heads
+        T["layers"] = []
         for lyr in self.transformer_layers:                                           # TransformerLayer :757-792
-            n, res = self._norm(t, lyr.attn_layer_norm, residual=res, want_pre=True)
-            m = self._adaln(n, lyr.self_attn_adaLN_modulation, scond, B)
-            a = self._attention(m, m, lyr.attention, B, S, S, nh)
-            n, res = self._norm(a, lyr.crossattn_layer_norm, residual=res, want_pre=True)
-            m = self._adaln(n, lyr.cross_attn_adaLN_modulation, scond, B)
-            a = self._attention(m, enc, lyr.crossattention, B, S, L, nh)
-            n, res = self._norm(a, lyr.ffn.pre_mlp_layer_norm, mode=1, residual=res, want_pre=True)   # LayerNorm (:928)
-            m = self._adaln(n, lyr.ffn.adaLN_modulation, scond, B)
+            n1, res1 = self._norm(t, lyr.attn_layer_norm, residual=res, want_pre=True)
+            m1, a1s = self._adaln(n1, lyr.self_attn_adaLN_modulation, scond, B)
+            a, s1 = self._attention(m1, m1, lyr.attention, B, S, S, nh)
+            n2, res2 = self._norm(a, lyr.crossattn_layer_norm, residual=res1, want_pre=True)
+            m2, a2s = self._adaln(n2, lyr.cross_attn_adaLN_modulation, scond, B)
+            a2, s2 = self._attention(m2, enc, lyr.crossattention, B, S, L, nh)
+            n3, res3 = self._norm(a2, lyr.ffn.pre_mlp_layer_norm, mode=1, residual=res2, want_pre=True)   # LayerNorm (:928)
+            m3, a3s = self._adaln(n3, lyr.ffn.adaLN_modulation, scond, B)
             w01 = torch.cat([f(lyr.ffn.wi_0.weight), f(lyr.ffn.wi_1.weight)], dim=0)
-            t = ops.linear(ops.glu_fwd(ops.linear(m, w01)), f(lyr.ffn.wo.weight))
-        n, _ = self._norm(t, self.project_from_hidden_norm, residual=res)             # (t + residual) then norm (:288-290)
-        h = ops.linear(n, f(self.project_from_hidden.weight))
+            ab = ops.linear(m3, w01)
+            gl = ops.glu_fwd(ab)
+            t = self._lin(gl, lyr.ffn.wo)
+            T["layers"].append(dict(res1=res1, res2=res2, res3=res3, a1s=a1s, a2s=a2s, a3s=a3s, s1=s1, s2=s2, m3=m3, w01=w01, ab=ab,
+                                    gl=gl))
+            res = res3
+        vlast = None
+        n, vlast = self._norm(t, self.project_from_hidden_norm, residual=res, want_pre=True)   # (t + residual) then norm (:288-290)
+        h = self._lin(n, self.project_from_hidden)
+        T["proj_out"] = dict(v=vlast, n=n)
+        T["up"] = []
         blk = self.up_blocks[0]
         for i in range(c.num_res_blocks):
-            h = self._res_block(h, blk.res_blocks[i], scond, B, side)
-            h = self._attn_block(h, blk.attention_blocks[i], enc, senc, B, S, L)
+            h, sr = self._res_block(h, blk.res_blocks[i], scond, B, side)
+            h, sa = self._attn_block(h, blk.attention_blocks[i], enc, senc, B, S, L)
+            T["up"].append((sr, sa))
         # ConvMlmLayer :1002-1022
-        y = ops.linear(h, f(self.mlm_layer.conv1.weight).reshape(c.in_channels, C))
-        y, _ = self._norm(y, self.mlm_layer.layer_norm.norm)
+        y1 = self._lin(h, self.mlm_layer.conv1)
+        y2, _ = self._norm(y1, self.mlm_layer.layer_norm.norm)
         V = c.codebook_size
         Vp = (V + 7) // 8 * 8
-        logits_p = torch.empty((B * S, Vp), dtype=torch.float32, device=y.device)
-        ops.gemm(y, f(self.mlm_layer.conv2.weight).reshape(V, -1), logits_p, B * S, V, c.in_channels, lda=c.in_channels,
-                 ldb=c.in_channels, ldc=Vp)
+        w2 = f(self.mlm_layer.conv2.weight).reshape(V, -1)
+        logits_p = torch.empty((B * S, Vp), dtype=torch.float32, device=y2.device)
+        ops.gemm(y2, w2, logits_p, B * S, V, c.in_channels, lda=c.in_channels, ldb=c.in_channels, ldc=Vp)
         logits = logits_p.view(B, S, Vp) if Vp == V else logits_p[:, :V].contiguous().view(B, S, V)
-        if labels is None:
-            return logits
-        lab = labels.reshape(-1).contiguous()
-        loss_out, _, rows = ops.cross_entropy_fwd(logits_p, lab, float(label_smoothing), vocab=V, want_rows=True)
-        if loss_weight is None:
-            return logits, loss_out[0]
-        return logits, ops.weighted_mean(rows, loss_weight.reshape(-1).float().contiguous())[0]   # :311-316
+        loss = None
+        if labels is not None:
+            lab = labels.reshape(-1).contiguous()
+            loss_out, lse, rows = ops.cross_entropy_fwd(logits_p, lab, float(label_smoothing), vocab=V, want_rows=True)
+            lw = None
+            if loss_weight is None:
+                loss = loss_out[0]
+            else:
+                lw = loss_weight.reshape(-1).float().contiguous()
+                loss = ops.weighted_mean(rows, lw)[0]                                 # :311-316
+            T["ce"] = dict(lab=lab, lse=lse, loss_out=loss_out, lw=lw, ls=float(label_smoothing))
+        if not need_grad:
+            return logits, loss, None
+        T.update(B=B, S=S, L=L, side=side, enc_in=enc_in, enc0=enc0, enc=enc, senc=senc, cond_in=cond_in, c1=c1, sc1=sc1, cond=cond,
+                 scond=scond, ids=ids, emb0=emb0, emb=emb, h_mlm=h, y1=y1, y2=y2, logits_p=logits_p, V=V, Vp=Vp)
+        return logits, loss, T
+
+    def _run_backward(self, T, g_loss):
+        """gradients of every parameter for d(loss) = g_loss: {state-dict name: tensor}"""
+        c = self.config
+        B, S, L, V, Vp = T["B"], T["S"], T["L"], T["V"], T["Vp"]
+        H, C = c.hidden_size, c.block_out_channels[0]
+        G = {}
+        ce = T["ce"]
+        dev = T["logits_p"].device
+        go = g_loss.reshape(1).to(torch.float32).contiguous()
+        dl = ops.cross_entropy_bwd(T["logits_p"], ce["lab"], ce["lse"], ce["loss_out"], go, ce["ls"], torch.float32, vocab=V)
+        if ce["lw"] is not None:   # mean over valid rows -> weighted mean: row r scaled by w_r * n_valid / sum(w)
+            ops.scale_rows_(dl, ce["lw"], ce["loss_out"][1:2], ce["lw"].sum().reshape(1), V)
+        # ConvMlmLayer
+        w2 = self._f(self.mlm_layer.conv2.weight).reshape(V, -1)
+        gw2 = torch.empty_like(w2)
+        ops.linear_wgrad(dl, T["y2"], gw2, False, M=V, lda=Vp)
+        G["mlm_layer.conv2.weight"] = gw2.view(self.mlm_layer.conv2.weight.shape)
+        dy2 = torch.empty_like(T["y2"])
+        ops.gemm(dl, w2, dy2, B * S, w2.shape[1], V, la=0, lb=1, lda=Vp, ldb=w2.shape[1], ldc=w2.shape[1])
+        dy1 = self._norm_bwd(dy2, T["y1"], self.mlm_layer.layer_norm.norm, "mlm_layer.layer_norm.norm", G)
+        dh = self._lin_bwd(dy1, T["h_mlm"], self.mlm_layer.conv1, "mlm_layer.conv1", G)
+        scond, senc = T["scond"], T["senc"]
+        dscond = torch.zeros_like(scond)
+        denc = torch.zeros_like(T["enc"])
+        dsenc = torch.zeros_like(senc) if senc is not None else None
+        blk = self.up_blocks[0]
+        for i in reversed(range(c.num_res_blocks)):
+            sr, sa = T["up"][i]
+            dh = self._attn_block_bwd(dh, sa, blk.attention_blocks[i], f"up_blocks.0.attention_blocks.{i}", G, senc, denc, dsenc)
+            dh = self._res_block_bwd(dh, sr, blk.res_blocks[i], f"up_blocks.0.res_blocks.{i}", G, scond, dscond, B)
+        po = T["proj_out"]
+        dn = self._lin_bwd(dh, po["n"], self.project_from_hidden, "project_from_hidden", G)
+        dres = self._norm_bwd(dn, po["v"], self.project_from_hidden_norm, "project_from_hidden_norm", G)   # = dt = d(residual)
+        dt = dres
+        for li in reversed(range(c.num_hidden_layers)):
+            lyr, sv = self.transformer_layers[li], T["layers"][li]
+            nm = f"transformer_layers.{li}"
+            # feed-forward
+            dgl = self._lin_bwd(dt, sv["gl"], lyr.ffn.wo, nm + ".ffn.wo", G)
+            dab = ops.glu_bwd(sv["ab"], dgl)
+            gw01 = torch.empty_like(sv["w01"])
+            ops.linear_wgrad(dab, sv["m3"], gw01, False)
+            I = gw01.shape[0] // 2
+            G[nm + ".ffn.wi_0.weight"], G[nm + ".ffn.wi_1.weight"] = gw01[:I], gw01[I:]
+            dm3 = ops.linear_dgrad(dab, sv["w01"])
+            dn3 = self._adaln_bwd(dm3, sv["a3s"], lyr.ffn.adaLN_modulation, nm + ".ffn.adaLN_modulation", G, scond, dscond, B)
+            dv3 = self._norm_bwd(dn3, sv["res3"], lyr.ffn.pre_mlp_layer_norm, nm + ".ffn.pre_mlp_layer_norm", G, mode=1, dpre=dres)
+            # cross attention (dv3 = d(a2) = d(res2))
+            dm2, dctx = self._attention_bwd(dv3, sv["s2"], lyr.crossattention, nm + ".crossattention", G)
+            denc.add_(dctx)
+            dn2 = self._adaln_bwd(dm2, sv["a2s"], lyr.cross_attn_adaLN_modulation, nm + ".cross_attn_adaLN_modulation", G, scond,
+                                  dscond, B)
+            dv2 = self._norm_bwd(dn2, sv["res2"], lyr.crossattn_layer_norm, nm + ".crossattn_layer_norm", G, dpre=dv3)
+            # self attention (dv2 = d(a) = d(res1))
+            dm1, _ = self._attention_bwd(dv2, sv["s1"], lyr.attention, nm + ".attention", G, self_attn=True)
+            dn1 = self._adaln_bwd(dm1, sv["a1s"], lyr.self_attn_adaLN_modulation, nm + ".self_attn_adaLN_modulation", G, scond,
+                                  dscond, B)
+            dv1 = self._norm_bwd(dn1, sv["res1"], lyr.attn_layer_norm, nm + ".attn_layer_norm", G, dpre=dv2)
+            dt = dres = dv1                                                           # d(t_prev) = d(res_prev)
+        pi = T["proj_in"]
+        dn = self._lin_bwd(dt, pi["n"], self.project_to_hidden, "project_to_hidden", G)
+        dh = self._norm_bwd(dn, pi["h"], self.project_to_hidden_norm, "project_to_hidden_norm", G)
+        blk = self.down_blocks[0]
+        for i in reversed(range(c.num_res_blocks)):
+            sr, sa = T["down"][i]
+            dh = self._attn_block_bwd(dh, sa, blk.attention_blocks[i], f"down_blocks.0.attention_blocks.{i}", G, senc, denc, dsenc)
+            dh = self._res_block_bwd(dh, sr, blk.res_blocks[i], f"down_blocks.0.res_blocks.{i}", G, scond, dscond, B)
+        # ConvEmbed
+        demb = self._lin_bwd(dh, T["emb"], self.embed.conv, "embed.conv", G)
+        demb0 = self._norm_bwd(demb, T["emb0"], self.embed.layer_norm, "embed.layer_norm", G)
+        gemb = torch.zeros_like(self._f(self.embed.embeddings.weight))
+        dpos = torch.empty((S, gemb.shape[1]), dtype=torch.float32, device=dev)      # (position table of the shared kernel: unused here)
+        ops.embed_bwd(T["ids"].view(B, S), demb0, gemb, dpos, False)
+        G["embed.embeddings.weight"] = gemb
+        # conditioning: scond = silu(cond), cond = W2 silu(W0 cond_in)
+        dcond = ops.silu_bwd(T["cond"], dscond)
+        dsc1 = self._lin_bwd(dcond, T["sc1"], self.cond_embed["2"], "cond_embed.2", G)
+        dc1 = ops.silu_bwd(T["c1"], dsc1)
+        self._lin_bwd(dc1, T["cond_in"], self.cond_embed["0"], "cond_embed.0", G, need_dx=False)
+        # text states
+        if dsenc is not None:
+            denc.add_(ops.silu_bwd(T["enc"], dsenc))
+        denc0 = self._norm_bwd(denc, T["enc0"], self.encoder_proj_layer_norm, "encoder_proj_layer_norm", G)
+        self._lin_bwd(denc0, T["enc_in"], self.encoder_proj, "encoder_proj", G, need_dx=False)
+        return G
+
+    def forward(self, input_ids, encoder_hidden_states, cond_embeds, micro_conds, labels=None, label_smoothing=0.0,
+                loss_weight=None):
+        for t in (input_ids, encoder_hidden_states, cond_embeds, micro_conds):
+            if not t.is_cuda:
+                raise MuseHipError("MaskGiTUViT_v2 (MI355X build) has no CPU path: move the model and inputs to the GPU")
+        params = [p for _, p in self.named_parameters()]
+        need_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in params)
+        out = _UViTFn.apply(self, input_ids, encoder_hidden_states, cond_embeds, micro_conds, labels, label_smoothing, loss_weight,
+                            need_grad, *params)
+        return out
 
     def generate(self):
         raise AssertionError("generate() is not part of MaskGiTUViT_v2 (reference :327-328)")

@@ -601,15 +601,15 @@ def dwconv3x3_nhwc(x, w, B, H, W, C_):
     return y
 
 
-def grn_fwd(x, gamma, beta, B, S):
+def grn_fwd(x, gamma, beta, B, S, want_stats=False):
     """GlobalResponseNorm over the S pixels of each image; x [B*S, C]"""
     require_gpu(x, gamma, beta)
     C_ = x.shape[1]
     y = torch.empty_like(x)
-    scratch = torch.empty(B * C_, dtype=torch.float32, device=x.device)
-    check(lib().muse_grn_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), scratch.data_ptr(), B, S, C_, stream()),
+    stats = torch.empty(2 * B * C_, dtype=torch.float32, device=x.device)   # [G | N], kept for grn_bwd
+    check(lib().muse_grn_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, S, C_, stream()),
           "muse_grn_fwd")
-    return y
+    return (y, stats) if want_stats else y
 
 
 def sinusoidal_encode(features, dim, max_positions=10000.0):
@@ -625,6 +625,78 @@ def weighted_mean(v, w):
     out = torch.empty(1, dtype=torch.float32, device=v.device)
     check(lib().muse_weighted_mean(v.data_ptr(), w.data_ptr(), out.data_ptr(), v.numel(), stream()), "muse_weighted_mean")
     return out
+
+
+def colsum(part, out, accumulate=False):
+    """out[c] (+)= sum_r part[r, c]  (fixed order)"""
+    require_gpu(part, out)
+    rows, cols = part.shape
+    check(lib().muse_colsum(part.data_ptr(), out.data_ptr(), rows, cols, 1 if accumulate else 0, stream()), "muse_colsum")
+    return out
+
+
+def norm_res_bwd(dy, v, w, eps, mode, dpre=None, want_dw=True):
+    """backward of norm_res_fwd: returns (dv = dx = dres, dw or None).  v = the forward's pre-norm sum."""
+    require_gpu(dy, v)
+    rows, cols = v.shape
+    dv = torch.empty_like(v)
+    nblk = lib().muse_norm_res_bwd_nblk(rows)
+    part = torch.empty((nblk, cols), dtype=torch.float32, device=v.device)
+    check(lib().muse_norm_res_bwd(dy.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), dv.data_ptr(), part.data_ptr(), rows, cols, eps,
+                                  mode, stream()), "muse_norm_res_bwd")
+    dw = colsum(part, torch.empty(cols, dtype=torch.float32, device=v.device)) if want_dw else None
+    return dv, dw
+
+
+def adaln_bwd(dy, x, ss, batch):
+    """-> (dx, dss [batch, 2C])"""
+    require_gpu(dy, x, ss)
+    rows, C_ = x.shape
+    dx = torch.empty_like(x)
+    dss = torch.empty_like(ss)
+    check(lib().muse_adaln_bwd(dy.data_ptr(), x.data_ptr(), ss.data_ptr(), dx.data_ptr(), dss.data_ptr(), batch, rows // batch, C_,
+                               stream()), "muse_adaln_bwd")
+    return dx, dss
+
+
+def silu_bwd(x, dy):
+    require_gpu(x, dy)
+    dx = torch.empty_like(x)
+    check(lib().muse_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), stream()), "muse_silu_bwd")
+    return dx
+
+
+def dwconv3x3_bwd(dy, x, w, B, H, W, C_):
+    """-> (dx, dw [C, 1, 3, 3])"""
+    require_gpu(dy, x, w)
+    dx = torch.empty_like(x)
+    nchunk = lib().muse_dwconv3x3_bwd_nchunk(B * H * W)
+    part = torch.empty((nchunk, C_ * 9), dtype=torch.float32, device=x.device)
+    check(lib().muse_dwconv3x3_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), part.data_ptr(), B, H, W, C_, stream()),
+          "muse_dwconv3x3_bwd")
+    dw = colsum(part, torch.empty(C_ * 9, dtype=torch.float32, device=x.device)).view(C_, 1, 3, 3)
+    return dx, dw
+
+
+def grn_bwd(dy, x, gamma, stats, B, S):
+    """-> (dx, dgamma [C], dbeta [C])"""
+    require_gpu(dy, x, gamma, stats)
+    C_ = x.shape[1]
+    dx = torch.empty_like(x)
+    work = torch.empty(4 * B * C_, dtype=torch.float32, device=x.device)
+    check(lib().muse_grn_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(), work.data_ptr(), B, S, C_,
+                             stream()), "muse_grn_bwd")
+    dbeta = colsum(work[: B * C_].view(B, C_), torch.empty(C_, dtype=torch.float32, device=x.device))
+    dgamma = colsum(work[B * C_: 2 * B * C_].view(B, C_), torch.empty(C_, dtype=torch.float32, device=x.device))
+    return dx, dgamma, dbeta
+
+
+def scale_rows_(x, w, num, den, cols):
+    """x[r, :cols] *= w[r] * num[0] / den[0]  (in place; num / den are 1-element device tensors)"""
+    require_gpu(x, w, num, den)
+    check(lib().muse_scale_rows(x.data_ptr(), w.data_ptr(), num.data_ptr(), den.data_ptr(), x.shape[0], cols, x.stride(0), stream()),
+          "muse_scale_rows")
+    return x
 
 
 def probe_tr16(addr):

@@ -140,3 +140,103 @@ def test_uvit_forward_vs_oracle_text77():
     logits, loss = model(ids.to(DEV), enc.to(DEV), cond.to(DEV), micro.to(DEV), labels=labels.to(DEV))
     assert rel_err(logits, ref_logits) < 1e-4
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+
+
+# ---- backward --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols", [(5, 32), (67, 768), (33, 4096)])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("with_dpre", [False, True])
+def test_norm_backward(rows, cols, mode, with_dpre):
+    ops = _ops()
+    v = (rnd((rows, cols), 30, 2.0) + 0.3).double().requires_grad_(True)
+    w = (1 + 0.1 * rnd((cols,), 31)).double().requires_grad_(True)
+    dy, dpre = rnd((rows, cols), 32), rnd((rows, cols), 33)
+    if mode == 0:
+        y = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    else:
+        y = F.layer_norm(v, (cols,), w, None, 1e-6)
+    y.backward(dy.double())
+    ref_dv = v.grad + (dpre.double() if with_dpre else 0)
+    dv, dw = ops.norm_res_bwd(dy.to(DEV), v.detach().float().to(DEV), w.detach().float().to(DEV), 1e-6, mode,
+                              dpre=dpre.to(DEV) if with_dpre else None)
+    assert rel_err(dv, ref_dv) < 5e-6 and rel_err(dw, w.grad) < 5e-6
+
+
+def test_adaln_silu_scale_backward():
+    ops = _ops()
+    B, S, C = 3, 50, 24
+    x, ss, dy = rnd((B * S, C), 40), rnd((B, 2 * C), 41), rnd((B * S, C), 42)
+    dx, dss = ops.adaln_bwd(dy.to(DEV), x.to(DEV), ss.to(DEV), B)
+    assert rel_err(dx, (dy.view(B, S, C) * (1 + ss[:, None, :C])).reshape(B * S, C)) < 1e-6
+    ref = torch.cat([(dy * x).double().view(B, S, C).sum(1), dy.double().view(B, S, C).sum(1)], dim=1)
+    assert rel_err(dss, ref) < 2e-6
+    z = rnd((1000,), 43, 3.0).double().requires_grad_(True)
+    g = rnd((1000,), 44)
+    F.silu(z).backward(g.double())
+    assert rel_err(ops.silu_bwd(z.detach().float().to(DEV), g.to(DEV)), z.grad) < 2e-6
+    m = rnd((37, 40), 45).to(DEV)
+    w = (torch.rand(37) + 0.5).to(DEV)
+    num, den = torch.tensor([5.0], device=DEV), torch.tensor([2.5], device=DEV)
+    exp = m.clone()
+    exp[:, :32] *= (w * 2.0)[:, None]
+    assert rel_err(ops.scale_rows_(m, w, num, den, 32), exp) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 24), (1, 16, 16, 96), (3, 5, 7, 8)])
+def test_depthwise_conv_and_grn_backward(B, H, W, C):
+    ops = _ops()
+    x = rnd((B, H, W, C), 50).double().requires_grad_(True)
+    w = rnd((C, 1, 3, 3), 51, 0.3).double().requires_grad_(True)
+    dy = rnd((B, H, W, C), 52)
+    F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1, groups=C).permute(0, 2, 3, 1).backward(dy.double())
+    dx, dw = ops.dwconv3x3_bwd(dy.reshape(-1, C).contiguous().to(DEV), x.detach().float().reshape(-1, C).contiguous().to(DEV),
+                               w.detach().float().to(DEV), B, H, W, C)
+    assert rel_err(dx.view(B, H, W, C), x.grad) < 2e-6 and rel_err(dw, w.grad) < 5e-6
+    xg = rnd((B, H, W, C), 53).double().requires_grad_(True)
+    gamma, beta = rnd((C,), 54).double().requires_grad_(True), rnd((C,), 55).double().requires_grad_(True)
+    gx = torch.norm(xg, p=2, dim=(1, 2), keepdim=True)
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    (gamma * (xg * nx) + beta + xg).backward(dy.double())
+    xr = xg.detach().float().reshape(-1, C).contiguous().to(DEV)
+    _, stats = ops.grn_fwd(xr, gamma.detach().float().to(DEV), beta.detach().float().to(DEV), B, H * W, want_stats=True)
+    dxg, dgam, dbet = ops.grn_bwd(dy.reshape(-1, C).contiguous().to(DEV), xr, gamma.detach().float().to(DEV), stats, B, H * W)
+    assert rel_err(dxg.view(B, H, W, C), xg.grad) < 5e-6
+    assert rel_err(dgam, gamma.grad) < 5e-6 and rel_err(dbet, beta.grad) < 5e-6
+
+
+def _grad_check(model, ref_grads, tol):
+    worst = (0.0, None)
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        ref = ref_grads[name]
+        e = float((p.grad.detach().double().cpu().reshape(ref.shape) - ref.double()).abs().max() / (ref.double().abs().max() + 1e-12))
+        worst = max(worst, (e, name))
+    assert worst[0] < tol, worst
+
+
+def test_uvit_backward_vs_reference_golden(golden_dir):
+    """loss.backward() through the hand-written reverse pass: every one of the 120 parameter gradients against the real
+    reference (plain mean cross-entropy), then label smoothing + per-token loss weights against the pinned oracle"""
+    import muse
+    from oracle import uvit_oracle as U
+    g, cfg, sd = _load_golden(golden_dir)
+    model = muse.MaskGiTUViT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train()
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    logits, loss = model(*args, labels=labels)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    _grad_check(model, {k[len("grad."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad.")}, 5e-4)
+    model.zero_grad(set_to_none=True)
+    lw = torch.from_numpy(g["loss_weight"])
+    ls = float(g["label_smoothing"])
+    _, loss_w = model(*args, labels=labels, label_smoothing=ls, loss_weight=lw.to(DEV))
+    (2.0 * loss_w).backward()                                            # an upstream gradient other than 1
+    cpu_args = [torch.from_numpy(g[k]) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    _, lo, ref = U.uvit_loss_and_grads(sd, cfg, *cpu_args, torch.from_numpy(g["labels"]), ls, lw)
+    assert abs(float(loss_w) - float(lo)) < 1e-4 * abs(float(lo))
+    _grad_check(model, {k: 2.0 * v for k, v in ref.items()}, 5e-4)
+    with torch.no_grad():                                                # inference keeps working and records nothing
+        assert model(*args, labels=labels)[1].grad_fn is None
