@@ -22,6 +22,7 @@ from torch import nn
 from . import ops
 from ._hip import MuseHipError
 from .modeling_utils import ConfigMixin, ModelMixin
+from .sampling import cosine_schedule, mask_by_random_topk
 
 # reference dataclass MaskGiTUViT_v2Config :79-124 (field -> default)
 _DEFAULTS = dict(
@@ -550,6 +551,72 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
 
     def generate(self):
         raise AssertionError("generate() is not part of MaskGiTUViT_v2 (reference :327-328)")
+
+    @torch.no_grad()
+    def generate2(self, encoder_hidden_states, cond_embeds, micro_conds, empty_embeds, empty_cond_embeds, input_ids=None,
+                  negative_embeds=None, negative_cond_embeds=None, temperature=1.0, timesteps=18, guidance_scale=0,
+                  guidance_schedule=None, noise_schedule=cosine_schedule, generator=None, return_intermediate=False,
+                  seq_len=None, use_tqdm=None, topk_filter_thres=None, noise_type=None, predict_all_tokens=None):
+        """reference :330-479 — iterative parallel decoding with classifier-free guidance; the forward passes run on the HIP
+        path, the per-step sampling (multinomial, confidence masking with Gumbel noise) is the reference's torch code on the
+        GPU tensors.  (The reference leaves `model_input` undefined for guidance_scale == 0; here that case feeds input_ids.)"""
+        batch_size = encoder_hidden_states.shape[0]
+        seq_len = 256 if seq_len is None else seq_len
+        dev = encoder_hidden_states.device
+        mask_id = self.config.mask_token_id
+        V = self.config.codebook_size
+        temperatures = (torch.linspace(temperature[0], temperature[1], timesteps) if isinstance(temperature, tuple)
+                        else torch.linspace(temperature, 0.01, timesteps))
+        if input_ids is None:
+            input_ids = torch.full((batch_size, seq_len), mask_id, dtype=torch.long, device=dev)
+        intermediate = []
+        if guidance_schedule == "linear":
+            guidance_scales = torch.linspace(0, guidance_scale, timesteps)
+        elif guidance_schedule == "cosine":
+            guidance_scales = torch.tensor([float((cosine_schedule(torch.tensor(1 - (step + 1) / timesteps)) * guidance_scale).floor())
+                                            for step in range(timesteps)])
+        else:
+            guidance_scales = torch.ones(timesteps) * guidance_scale
+        if micro_conds.shape[0] == 1:
+            micro_conds = micro_conds.repeat(batch_size, 1).to(dev)
+        if guidance_scale > 0:
+            unc = empty_embeds if negative_embeds is None else negative_embeds
+            if unc.shape[0] == 1:
+                unc = unc.expand(batch_size, -1, -1)
+            encoder_hidden_states = torch.cat([encoder_hidden_states, unc])
+            unc_c = empty_cond_embeds if negative_cond_embeds is None else negative_cond_embeds
+            if unc_c.shape[0] == 1:
+                unc_c = unc_c.expand(batch_size, -1)
+            cond_embeds = torch.cat([cond_embeds, unc_c])
+            micro_conds = torch.cat([micro_conds, micro_conds], dim=0)
+        steps = range(timesteps)
+        if use_tqdm:
+            from tqdm.auto import tqdm
+            steps = tqdm(steps)
+        sampled_ids = input_ids
+        for step in steps:
+            model_input = torch.cat([input_ids] * 2) if guidance_scale > 0 else input_ids
+            out = self(model_input, encoder_hidden_states, cond_embeds, micro_conds)
+            if guidance_scale > 0:
+                cond_logits, uncond_logits = out.chunk(2)
+                logits = uncond_logits[..., :V] + float(guidance_scales[step]) * (cond_logits[..., :V] - uncond_logits[..., :V])
+            else:
+                logits = out[..., :V]
+            probs = logits.softmax(dim=-1)
+            sampled_ids = torch.multinomial(probs.reshape(-1, V), 1, generator=generator)[:, 0].view(batch_size, seq_len)
+            if return_intermediate:
+                intermediate.append(sampled_ids)
+            unknown_map = input_ids == mask_id
+            sampled_ids = torch.where(unknown_map, sampled_ids, input_ids)
+            ratio = 1.0 * (step + 1) / timesteps
+            mask_ratio = noise_schedule(torch.tensor(ratio))
+            mask_len = (seq_len * mask_ratio).floor().unsqueeze(0).to(dev)
+            mask_len = torch.max(torch.tensor([1], device=dev), torch.min(unknown_map.sum(dim=-1, keepdim=True) - 1, mask_len))
+            selected = torch.gather(probs, -1, sampled_ids.long()[..., None]).squeeze(-1)
+            selected = torch.where(unknown_map, selected, torch.finfo(selected.dtype).max)
+            masking = mask_by_random_topk(mask_len, selected, float(temperatures[step]), generator=generator)
+            input_ids = torch.where(masking, mask_id, sampled_ids)
+        return (sampled_ids, intermediate) if return_intermediate else sampled_ids
 
 
 MaskGiTUViT = MaskGiTUViT_v2

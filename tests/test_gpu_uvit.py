@@ -240,3 +240,32 @@ def test_uvit_backward_vs_reference_golden(golden_dir):
     _grad_check(model, {k: 2.0 * v for k, v in ref.items()}, 5e-4)
     with torch.no_grad():                                                # inference keeps working and records nothing
         assert model(*args, labels=labels)[1].grad_fn is None
+
+
+def test_uvit_generate2(golden_dir):
+    """reference :330-479 on the HIP forward: classifier-free guidance doubles the batch, every token ends up decoded (no
+    mask id left), given tokens are kept, and a fixed generator reproduces the sample"""
+    import muse
+    g, cfg, sd = _load_golden(golden_dir)
+    model = muse.MaskGiTUViT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).eval()
+    B, S, L = 2, 16, 7
+    enc = torch.from_numpy(g["encoder_hidden_states"]).to(DEV)
+    cond = torch.from_numpy(g["cond_embeds"]).to(DEV)
+    micro = torch.tensor([[256.0, 256.0, 0.0, 0.0, 6.0]], device=DEV)                       # broadcast over the batch (:383-384)
+    empty, empty_c = torch.zeros(1, L, cfg["encoder_hidden_size"], device=DEV), torch.zeros(1, cfg["cond_embed_dim"], device=DEV)
+    outs = []
+    for _ in range(2):
+        gen = torch.Generator(device=DEV).manual_seed(123)
+        ids, inter = model.generate2(enc, cond, micro, empty, empty_c, timesteps=4, guidance_scale=2.0, generator=gen, seq_len=S,
+                                     return_intermediate=True)
+        outs.append(ids)
+        assert ids.shape == (B, S) and ids.dtype == torch.long and len(inter) == 4
+        assert int(ids.min()) >= 0 and int(ids.max()) < cfg["codebook_size"]
+    assert torch.equal(outs[0], outs[1])
+    given = torch.full((B, S), cfg["vocab_size"] - 1, dtype=torch.long, device=DEV)
+    given[:, :5] = torch.arange(5, device=DEV)
+    ids = model.generate2(enc, cond, micro, empty, empty_c, input_ids=given, timesteps=3, guidance_scale=0, seq_len=S,
+                          generator=torch.Generator(device=DEV).manual_seed(5))
+    assert torch.equal(ids[:, :5], given[:, :5]) and int(ids.max()) < cfg["codebook_size"]
