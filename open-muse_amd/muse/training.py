@@ -41,12 +41,16 @@ def prepare_inputs_and_labels(vq_model, pixel_values, class_ids, mask_id, min_ma
 
 
 def _owner_of(params):
+    """the muse.MaskGitTransformer that owns all `params` in its flat buffer, or None when the parameters are ordinary tensors
+    (muse.MaskGiTUViT): those are stepped one launch per tensor with the same kernel"""
     owner = None
+    if all(getattr(p, "_muse_owner", None) is None for p in params):
+        return None
     for p in params:
         ref = getattr(p, "_muse_owner", None)
         m = ref() if ref is not None else None
         if m is None:
-            raise MuseHipError("FusedAdamW needs the parameters of a muse.MaskGitTransformer (flat parameter buffer)")
+            raise MuseHipError("FusedAdamW: either all or none of the parameters may live in a flat parameter buffer")
         if owner is None:
             owner = m
         elif owner is not m:
@@ -65,22 +69,25 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
             raise MuseHipError("FusedAdamW supports a single parameter group (the reference uses one: :257-263)")
-        self._model = weakref.ref(_owner_of(self.param_groups[0]["params"]))
+        owner = _owner_of(self.param_groups[0]["params"])
+        self._model = weakref.ref(owner) if owner is not None else None
         self._m = self._v = None
         self._step = 0
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        grp = self.param_groups[0]
+        if self._model is None:
+            return self._step_per_tensor(grp, loss)
         model = self._model()
         flat = model.flat_params()
-        if any(p.grad is None for p in self.param_groups[0]["params"]):
+        if any(p.grad is None for p in grp["params"]):
             return loss  # nothing to do before the first backward (torch skips None grads)
         g = model.flat_grads()
         if self._m is None or self._m.device != flat.device:
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
-        grp = self.param_groups[0]
         self._step += 1
         lr = float(grp["lr"])
         shadow = model._flat_c if model._flat_c is not None and model._flat_c.device == flat.device else None
@@ -90,14 +97,45 @@ class FusedAdamW(torch.optim.Optimizer):
         model._shadow_version += 1   # transposed weight copies (dgrad) are rebuilt from the refreshed shadow
         return loss
 
+    def _step_per_tensor(self, grp, loss):
+        """parameters that are ordinary (contiguous f32) tensors: muse_adamw_flat once per tensor.  torch.optim.AdamW
+        semantics: a parameter without a gradient is skipped and keeps its own state; the step count is shared (all
+        parameters of these models receive a gradient every step)."""
+        params = [p for p in grp["params"] if p.grad is not None]
+        if not params:
+            return loss
+        if self._m is None:
+            self._m, self._v = {}, {}
+        self._step += 1
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                raise MuseHipError("FusedAdamW: parameters and gradients must be contiguous float32 tensors")
+            k = id(p)
+            if k not in self._m or self._m[k].device != p.device:
+                self._m[k] = torch.zeros_like(p)
+                self._v[k] = torch.zeros_like(p)
+            ops.adamw_flat(p.data, p.grad, self._m[k], self._v[k], None, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
+                           grp["eps"], grp["weight_decay"], self._step)
+        return loss
+
     def state_dict(self):
-        return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v,
-                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+        groups = [{k: v for k, v in self.param_groups[0].items() if k != "params"}]
+        if self._model is None:   # per-tensor mode: moments in parameter order (None for a parameter that never had a gradient)
+            ps = self.param_groups[0]["params"]
+            m, v = self._m or {}, self._v or {}
+            return {"step": self._step, "exp_avg": [m.get(id(p)) for p in ps], "exp_avg_sq": [v.get(id(p)) for p in ps],
+                    "param_groups": groups}
+        return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v, "param_groups": groups}
 
     def load_state_dict(self, sd):
         self._step = int(sd["step"])
-        self._m = sd["exp_avg"]
-        self._v = sd["exp_avg_sq"]
+        if self._model is None:
+            ps = self.param_groups[0]["params"]
+            self._m = {id(p): t for p, t in zip(ps, sd["exp_avg"]) if t is not None}
+            self._v = {id(p): t for p, t in zip(ps, sd["exp_avg_sq"]) if t is not None}
+        else:
+            self._m = sd["exp_avg"]
+            self._v = sd["exp_avg_sq"]
         self.param_groups[0].update(sd["param_groups"][0])
 
 
