@@ -208,6 +208,7 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         self.project_from_hidden = _Lin(H, C)
         self.up_blocks = nn.ModuleList([_Block(C, H, c.num_res_blocks)])
         self.mlm_layer = _Mlm(C, cin, c.codebook_size)
+        self.compute_dtype = torch.float32
         self._init_weights()
 
     def _init_weights(self):
@@ -232,15 +233,47 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
     def _f(p):
         return p.data if p.dtype == torch.float32 else p.data.float()
 
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (default): exact-f32 MFMA everywhere (parity mode).  torch.bfloat16: the operands of every weight GEMM
+        (linears, 1x1 convs, their dX / dW) are rounded to bf16 and run on the bf16 MFMA kernels with f32 accumulation and f32
+        outputs - the reference's autocast regime; the residual stream, norms, AdaLN, GRN, depthwise conv, softmax / attention
+        core and the loss stay f32."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
+
+    def _c(self, t):
+        """GEMM operand in the compute dtype"""
+        return t if self.compute_dtype == torch.float32 else ops.cast_to_bf16(t.contiguous())
+
+    def _mm(self, x, w2, residual=None):
+        """x w2^T (+ residual) -> f32"""
+        return ops.linear(self._c(x), self._c(w2), out_dtype=torch.float32, residual=residual)
+
+    def _mm_dx(self, dy, w2, lda=None, out=None, accumulate=False):
+        """dy w2 -> f32 [rows, K] (optionally accumulated into `out`);  dy [rows, >= N] with row stride lda, w2 [N, K]"""
+        N, K = w2.shape
+        dyb = self._c(dy)
+        if out is None:
+            out = torch.empty((dy.shape[0], K), dtype=torch.float32, device=dy.device)
+        ops.gemm(dyb, self._c(w2), out, dy.shape[0], K, N, la=0, lb=1, lda=lda or dyb.stride(0), ldb=K, ldc=out.stride(0),
+                 accumulate=accumulate)
+        return out
+
+    def _mm_dw(self, dy, x, shape2, M=None, lda=None):
+        """dy^T x -> f32 [N, K]"""
+        dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
+        ops.linear_wgrad(self._c(dy), self._c(x), dw, False, M=M, lda=lda)
+        return dw
+
     def _lin(self, x, mod, residual=None):
-        return ops.linear(x, self._f(mod.weight).reshape(mod.weight.shape[0], -1), residual=residual)
+        return self._mm(x, self._f(mod.weight).reshape(mod.weight.shape[0], -1), residual=residual)
 
     def _lin_bwd(self, dy, x, mod, name, G, need_dx=True):
         w2 = self._f(mod.weight).reshape(mod.weight.shape[0], -1)
-        dw = torch.empty_like(w2)
-        ops.linear_wgrad(dy, x, dw, False)
-        G[name + ".weight"] = dw.view(mod.weight.shape)
-        return ops.linear_dgrad(dy, w2) if need_dx else None
+        G[name + ".weight"] = self._mm_dw(dy, x, w2.shape).view(mod.weight.shape)
+        return self._mm_dx(dy, w2) if need_dx else None
 
     def _norm(self, x, mod, mode=0, residual=None, want_pre=False):
         y, pre = ops.norm_res_fwd(x, self._f(mod.weight), float(self.config.layer_norm_eps), mode, residual=residual,
@@ -287,11 +320,9 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         dx = self._lin_bwd(dq, sv["x"], att.query, name + ".query", G)
         dctx = self._lin_bwd(dk, sv["ctx"], att.key, name + ".key", G)
         wv = self._f(att.value.weight)
-        gv = torch.empty_like(wv)
-        ops.linear_wgrad(dv, sv["ctx"], gv, False)
-        G[name + ".value.weight"] = gv
+        G[name + ".value.weight"] = self._mm_dw(dv, sv["ctx"], wv.shape)
         # dctx += dv Wv ; for self attention query and context are the same tensor: everything lands in dx
-        ops.gemm(dv, wv, dctx, dv.shape[0], wv.shape[1], Cq, la=0, lb=1, lda=Cq, ldb=wv.shape[1], ldc=dctx.shape[1], accumulate=True)
+        self._mm_dx(dv, wv, out=dctx, accumulate=True)
         if self_attn:
             return dx.add_(dctx), None
         return dx, dctx
@@ -410,7 +441,7 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             n3, res3 = self._norm(a2, lyr.ffn.pre_mlp_layer_norm, mode=1, residual=res2, want_pre=True)   # LayerNorm (:928)
             m3, a3s = self._adaln(n3, lyr.ffn.adaLN_modulation, scond, B)
             w01 = torch.cat([f(lyr.ffn.wi_0.weight), f(lyr.ffn.wi_1.weight)], dim=0)
-            ab = ops.linear(m3, w01)
+            ab = self._mm(m3, w01)
             gl = ops.glu_fwd(ab)
             t = self._lin(gl, lyr.ffn.wo)
             T["layers"].append(dict(res1=res1, res2=res2, res3=res3, a1s=a1s, a2s=a2s, a3s=a3s, s1=s1, s2=s2, m3=m3, w01=w01, ab=ab,
@@ -433,7 +464,7 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         Vp = (V + 7) // 8 * 8
         w2 = f(self.mlm_layer.conv2.weight).reshape(V, -1)
         logits_p = torch.empty((B * S, Vp), dtype=torch.float32, device=y2.device)
-        ops.gemm(y2, w2, logits_p, B * S, V, c.in_channels, lda=c.in_channels, ldb=c.in_channels, ldc=Vp)
+        ops.gemm(self._c(y2), self._c(w2), logits_p, B * S, V, c.in_channels, lda=c.in_channels, ldb=c.in_channels, ldc=Vp)
         logits = logits_p.view(B, S, Vp) if Vp == V else logits_p[:, :V].contiguous().view(B, S, V)
         loss = None
         if labels is not None:
@@ -466,11 +497,8 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             ops.scale_rows_(dl, ce["lw"], ce["loss_out"][1:2], ce["lw"].sum().reshape(1), V)
         # ConvMlmLayer
         w2 = self._f(self.mlm_layer.conv2.weight).reshape(V, -1)
-        gw2 = torch.empty_like(w2)
-        ops.linear_wgrad(dl, T["y2"], gw2, False, M=V, lda=Vp)
-        G["mlm_layer.conv2.weight"] = gw2.view(self.mlm_layer.conv2.weight.shape)
-        dy2 = torch.empty_like(T["y2"])
-        ops.gemm(dl, w2, dy2, B * S, w2.shape[1], V, la=0, lb=1, lda=Vp, ldb=w2.shape[1], ldc=w2.shape[1])
+        G["mlm_layer.conv2.weight"] = self._mm_dw(dl, T["y2"], w2.shape, M=V, lda=Vp).view(self.mlm_layer.conv2.weight.shape)
+        dy2 = self._mm_dx(dl, w2, lda=Vp)
         dy1 = self._norm_bwd(dy2, T["y1"], self.mlm_layer.layer_norm.norm, "mlm_layer.layer_norm.norm", G)
         dh = self._lin_bwd(dy1, T["h_mlm"], self.mlm_layer.conv1, "mlm_layer.conv1", G)
         scond, senc = T["scond"], T["senc"]
@@ -492,11 +520,10 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             # feed-forward
             dgl = self._lin_bwd(dt, sv["gl"], lyr.ffn.wo, nm + ".ffn.wo", G)
             dab = ops.glu_bwd(sv["ab"], dgl)
-            gw01 = torch.empty_like(sv["w01"])
-            ops.linear_wgrad(dab, sv["m3"], gw01, False)
+            gw01 = self._mm_dw(dab, sv["m3"], sv["w01"].shape)
             I = gw01.shape[0] // 2
             G[nm + ".ffn.wi_0.weight"], G[nm + ".ffn.wi_1.weight"] = gw01[:I], gw01[I:]
-            dm3 = ops.linear_dgrad(dab, sv["w01"])
+            dm3 = self._mm_dx(dab, sv["w01"])
             dn3 = self._adaln_bwd(dm3, sv["a3s"], lyr.ffn.adaLN_modulation, nm + ".ffn.adaLN_modulation", G, scond, dscond, B)
             dv3 = self._norm_bwd(dn3, sv["res3"], lyr.ffn.pre_mlp_layer_norm, nm + ".ffn.pre_mlp_layer_norm", G, mode=1, dpre=dres)
             # cross attention (dv3 = d(a2) = d(res2))

@@ -1,6 +1,6 @@
 """SURVEY.md section 8 row a12 at its real size: MaskGiTUViT_v2 of configs/cc12m_uvit_clip.yaml (+ block_num_heads 12 -> hd 64),
 256 tokens, 77 text tokens: time of forward + backward on the f32 path (random weights filled on the GPU, synthetic inputs).
-    python scripts/uvit_bench.py [batch] [steps]"""
+    python scripts/uvit_bench.py [batch] [steps] [f32|bf16]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
@@ -10,10 +10,12 @@ from muse import modeling_transformer_v2 as M
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+mode = sys.argv[3] if len(sys.argv) > 3 else "f32"
 M.MaskGiTUViT_v2._init_weights = lambda self: None          # 729 M parameters: fill them on the GPU instead
 t0 = time.time()
 model = muse.MaskGiTUViT(block_num_heads=12)
 model.to("cuda")
+model.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
 g = torch.Generator(device="cuda").manual_seed(0)
 with torch.no_grad():
     for n, p in model.named_parameters():
@@ -44,5 +46,5 @@ for _ in range(steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
-print(f"MaskGiTUViT_v2 f32 fwd+bwd: batch {B}, {dt*1e3:.1f} ms/step, {B/dt:.1f} img/s, {3*275.10*B/dt/1e3:.1f} TFLOP/s algorithmic, "
+print(f"MaskGiTUViT_v2 {mode} fwd+bwd: batch {B}, {dt*1e3:.1f} ms/step, {B/dt:.1f} img/s, {3*275.10*B/dt/1e3:.1f} TFLOP/s algorithmic, "
       f"loss {float(loss):.4f}, peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
