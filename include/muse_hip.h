@@ -91,11 +91,30 @@ int muse_softmax_fwd(const void* x, void* y, int32_t dtype, int64_t rows, int32_
 int muse_softmax_bwd(const void* p, const void* dp, void* ds, int32_t dtype, int64_t rows, int32_t cols, int64_t ld,
                      void* stream);
 
-/* Fused full-visibility attention (bf16 in/out, f32 softmax), S <= 288, head_dim in {16,32,48,64}: replaces
- * Attention.attention (muse/modeling_transformer.py:221-241) and the xformers seam (:206-210) without materialising the
- * S x S matrix.  qkv [B*S, 3*H] (q | k | v, H = heads*head_dim), ctx [B*S, H], lse / dsum [B*heads, seq_pad] f32
- * (seq_pad = muse_attention_seq_pad(seq)); dqkv [B*S, 3*H].  alpha = 1/sqrt(head_dim) (the baddbmm alpha, :168,:230). */
+/* Fused full-visibility attention (bf16 in/out, f32 softmax / accumulation), head_dim in {16,32,48,64}, any query and
+ * key length: replaces Attention.attention (muse/modeling_transformer.py:221-241: baddbmm -> softmax -> matmul), the
+ * xformers memory_efficient_attention seam (:206-210; muse/modeling_transformer_v2.py:881-889, self- and cross-attention)
+ * and their autograd backward, without materialising the S x S matrix.  K / V stream through LDS in tiles of <= 288 keys
+ * (online softmax across tiles), so seq 257 / 256 / 1024 and the 77-token text cross-attention run on the same kernels.
+ * Token t of image b, head h of tensor X lives at X + b*bsX + t*ldX + h*head_dim (elements); all strides multiples of 8.
+ * lse / dsum are f32 [batch*heads, muse_attention_seq_pad(seq_q)].  alpha = 1/sqrt(head_dim) (the baddbmm alpha, :168,:230). */
+typedef struct muse_attn_desc {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;                       /* forward output (ctx); read by the backward */
+  int64_t ldq, ldk, ldv, ldo;    /* elements between consecutive tokens        */
+  int64_t bsq, bsk, bsv, bso;    /* elements between consecutive images        */
+  int32_t batch, heads, head_dim, seq_q, seq_kv;
+  float alpha;
+} muse_attn_desc;
 int muse_attention_seq_pad(int32_t seq);
+int muse_attention_fwd_ex(const muse_attn_desc* d, float* lse, void* stream);
+/* backward: d_o = upstream gradient of o; writes dq / dk / dv (bf16, own strides) and the scratch row constants dsum */
+int muse_attention_bwd_ex(const muse_attn_desc* d, const void* d_o, int64_t lddo, int64_t bsdo, const float* lse, float* dsum,
+                          void* dq, int64_t lddq, int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv,
+                          int64_t bsdv, void* stream);
+/* packed self-attention: qkv [B*S, 3*H] (q | k | v, H = heads*head_dim: the fused QKV projection), ctx [B*S, H], dqkv [B*S, 3*H] */
 int muse_attention_fwd(const void* qkv, void* ctx, float* lse, int32_t batch, int32_t seq, int32_t heads,
                        int32_t head_dim, float alpha, void* stream);
 int muse_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dsum, void* dqkv,

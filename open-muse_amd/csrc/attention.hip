@@ -1,63 +1,147 @@
-// Fused full-visibility attention for the MaskGit sequence lengths (S <= 288, head_dim in {16,32,48,64}), bf16 in/out,
-// f32 softmax / accumulation.  Replaces Attention.attention (muse/modeling_transformer.py:221-241: baddbmm -> softmax ->
-// matmul) and the xformers memory_efficient_attention seam (:206-210) without ever materialising the S x S matrix in HBM.
+// Fused full-visibility attention, bf16 in/out, f32 softmax / accumulation, head_dim in {16,32,48,64}; any query / key
+// length (self-attention at S = 257 / 256 / 1024 and cross-attention against 77 text tokens are the shapes on the path).
+// Replaces Attention.attention (muse/modeling_transformer.py:221-241: baddbmm -> softmax -> matmul), the xformers
+// memory_efficient_attention seam (:206-210; muse/modeling_transformer_v2.py:881-889) and their autograd backward
+// without ever materialising the S x S matrix in HBM.
 //
-// One workgroup (4 waves) per (image, head).  The head's K and V (forward / dQ) or Q and dO (dK,dV) live in LDS as
-// [S][hd] bf16 images with a row stride == 32 (mod 64) bytes: the same image is conflict-free for ds_read_b128
-// (k = head-dim contiguous operand) and for ds_read_b64_tr_b16 (k = sequence operand, hardware transpose).
+// Structure (all three kernels): a workgroup owns one (image, head) and a chunk of its "stationary" rows (queries for
+// forward / dQ, keys for dK,dV); the other operand streams through LDS in tiles of <= 288 rows as [rows][hd] bf16
+// images with a row stride == 32 (mod 64) bytes: the same image is conflict-free for ds_read_b128 / b64 (k = head-dim
+// contiguous operand) and for ds_read_b64_tr_b16 (k = sequence operand, hardware transpose).  A tile is fetched with
+// ALL of a thread's 16-byte buffer loads in flight at once (out-of-range rows come back as zeros from the buffer
+// descriptor: no branches), then written to LDS; two or three workgroups per CU overlap one's fetch with another's math.
+// Each wave owns 16-row tiles of the stationary operand.  With more than one streamed tile (S_kv > 288) a wave owns exactly
+// one stationary tile and carries its state (online-softmax max / sum / O, or the dQ / dK,dV accumulators) across tiles.
+//
 // Trick that keeps P in registers: scores are produced TRANSPOSED (S^T = K Q^T, MFMA operands swapped), so a lane holds,
 // for its one query (lane & 15), the keys {16t + 4g + r}; two consecutive 16-key tiles therefore give exactly the 8
 // k-slots one lane must supply as the B operand of the next MFMA (O^T = V^T P^T) under the k-permutation
 // slot(g, j) <-> key 32s + 16*(j>>2) + 4g + (j&3), which the V^T operand reproduces through its tr-read row addresses.
+// head_dim 48 contracts as one K=32 MFMA plus one K=16 MFMA (v_mfma_f32_16x16x16_bf16) instead of two half-empty K=32 ones.
 #include "common.h"
 #include "../../include/muse_hip.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+#define ATT_OOB 0x7ffffff0u
 
 template <int HD> struct HeadCfg {
-  static constexpr int HDP = (HD + 31) / 32 * 32;   // head dim padded to the MFMA K = 32
-  static constexpr int KS = HDP / 32;               // k-steps of the (head-dim contracted) MFMAs
+  static constexpr int N32 = HD / 32;               // K = 32 steps of the head-dim contraction
+  static constexpr int TAIL = (HD % 32) != 0;       // + one K = 16 step (hd 16, 48)
   static constexpr int ND = HD / 16;                // 16-wide output tiles over the head dim
-  // LDS row stride in bytes, == 32 (mod 64): 96 B for hd 48 / 32, 160 B for hd 64, 32 B for hd 16.  Only HD columns are
-  // stored; the zero padding of the last 32-wide k-step (hd 48, 16) is produced in frag_hd instead of in LDS.
+  static constexpr int CPR = HD / 8;                // 16-byte chunks per row
+  // LDS row stride in bytes, == 32 (mod 64): 96 B for hd 48 / 32, 160 B for hd 64, 32 B for hd 16
   static constexpr int RS = ((HD * 2) % 64 == 32) ? HD * 2 : HD * 2 + 32;
 };
 
-// cooperative load of one head's [S][HD] slice (row stride ld elements) into an LDS image of SKP rows, zero padded
+// one 16-row operand of a head-dim contraction: lane (row = lane & 15, g = lane >> 4) holds columns 32*ks + 8g .. +7 of every
+// K = 32 step and columns 32*N32 + 4g .. +3 of the K = 16 tail
+template <int HD> struct FragHD {
+  bf16x8 f[HeadCfg<HD>::N32 > 0 ? HeadCfg<HD>::N32 : 1];
+  bf16x4 t;
+};
+
 template <int HD>
-__device__ __forceinline__ void load_head(unsigned char* img, const bf16_t* src, long ld, int S, int SKP) {
+__device__ __forceinline__ FragHD<HD> frag_lds(const unsigned char* img, int rowbase, int lane) {
   using C = HeadCfg<HD>;
-  constexpr int CPR = HD / 8;
-  for (int c = threadIdx.x; c < SKP * CPR; c += blockDim.x) {
-    const int row = c / CPR, col = (c % CPR) * 8;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < S) v = *(const u32x4*)(src + (long)row * ld + col);
-    *(u32x4*)(img + row * C::RS + col * 2) = v;
+  FragHD<HD> r;
+  const unsigned char* p = img + (rowbase + (lane & 15)) * C::RS;
+#pragma unroll
+  for (int ks = 0; ks < C::N32; ++ks) r.f[ks] = *(const bf16x8*)(p + (ks * 32 + (lane >> 4) * 8) * 2);
+  if constexpr (C::TAIL) r.t = *(const bf16x4*)(p + (C::N32 * 32 + (lane >> 4) * 4) * 2);
+  return r;
+}
+// the same operand straight from global memory through a buffer descriptor (rows outside the tensor read as zeros)
+template <int HD>
+__device__ __forceinline__ FragHD<HD> frag_global(rsrc_t rs, unsigned ld_bytes, int rowbase, int lane) {
+  using C = HeadCfg<HD>;
+  FragHD<HD> r;
+  const unsigned ro = (unsigned)(rowbase + (lane & 15)) * ld_bytes;
+#pragma unroll
+  for (int ks = 0; ks < C::N32; ++ks) {
+    union { u32x4 u; bf16x8 v; } t;
+    t.u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + (ks * 32 + (lane >> 4) * 8) * 2), 0, 0);
+    r.f[ks] = t.v;
+  }
+  if constexpr (C::TAIL) {
+    union { u32x2 u; bf16x4 v; } t;
+    t.u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(ro + (C::N32 * 32 + (lane >> 4) * 4) * 2), 0, 0);
+    r.t = t.v;
+  }
+  return r;
+}
+#ifndef ATT_TAIL_MODE
+#define ATT_TAIL_MODE 2
+#endif
+template <int HD>
+__device__ __forceinline__ f32x4 mma_hd(const FragHD<HD>& a, const FragHD<HD>& b, f32x4 acc) {
+  using C = HeadCfg<HD>;
+#pragma unroll
+  for (int ks = 0; ks < C::N32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.f[ks], b.f[ks], acc, 0, 0, 0);
+  if constexpr (C::TAIL) {
+    const s16x4 at = __builtin_bit_cast(s16x4, a.t), bt = __builtin_bit_cast(s16x4, b.t);
+#if ATT_TAIL_MODE == 0
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, acc, 0, 0, 0);
+#elif ATT_TAIL_MODE == 1
+    if constexpr (C::N32 > 0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, acc, 0, 0, 0);
+#else
+    // the K = 16 step accumulates into its own registers: a K = 16 MFMA chained onto a K = 32 MFMA's result through SrcC
+    // returned wrong sums on gfx950 (ROCm 7.2 emits the two back to back with no wait states)
+    if constexpr (C::N32 > 0) {
+      const f32x4 tl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      acc += tl;
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, acc, 0, 0, 0);
+    }
+#endif
+  }
+  return acc;
+}
+// sum over the head dim of a .* b for this lane's row (partial: the 4 lanes g = 0..3 of a row each hold a quarter)
+template <int HD>
+__device__ __forceinline__ float dot_hd(const FragHD<HD>& a, const FragHD<HD>& b) {
+  using C = HeadCfg<HD>;
+  float s = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < C::N32; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fmaf((float)a.f[ks][j], (float)b.f[ks][j], s);
+  if constexpr (C::TAIL)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s = fmaf((float)a.t[j], (float)b.t[j], s);
+  return s;
+}
+
+// Cooperative fetch of `rows` (multiple of 32, <= MAXROWS) rows starting at row0 of one head's [S][HD] slice into an LDS image.
+// Rows >= S lie beyond the descriptor's range and arrive as zeros.  All loads of a thread are issued before the first LDS write.
+template <int HD, int NT, int MAXROWS>
+__device__ __forceinline__ void load_tile(unsigned char* img, rsrc_t rs, unsigned ld_bytes, int row0, int rows) {
+  using C = HeadCfg<HD>;
+  constexpr int NCH = (MAXROWS * C::CPR + NT - 1) / NT;
+  u32x4 v[NCH];
+  const int total = rows * C::CPR;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = threadIdx.x + i * NT;
+    const int row = c / C::CPR, col = c - row * C::CPR;
+    const unsigned off = c < total ? (unsigned)(row0 + row) * ld_bytes + col * 16 : ATT_OOB;
+    v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = threadIdx.x + i * NT;
+    const int row = c / C::CPR, col = c - row * C::CPR;
+    if (c < total) *(u32x4*)(img + row * C::RS + col * 16) = v[i];
   }
 }
 
-// B/A operand with k = head dim: rows [rowbase, +16) of an LDS image
-template <int HD>
-__device__ __forceinline__ bf16x8 frag_hd(const unsigned char* img, int rowbase, int ks, int lane) {
-  const int col = ks * 32 + (lane >> 4) * 8;
-  if constexpr (HD % 32 != 0) {
-    union { u32x4 u; bf16x8 v; } t;
-    t.u = u32x4{0u, 0u, 0u, 0u};
-    if (col < HD) t.v = *(const bf16x8*)(img + (rowbase + (lane & 15)) * HeadCfg<HD>::RS + col * 2);
-    return t.v;
-  } else {
-    return *(const bf16x8*)(img + (rowbase + (lane & 15)) * HeadCfg<HD>::RS + col * 2);
-  }
-}
-// the same operand straight from global memory (rows owned by this wave), zero outside [0,S) x [0,HD)
-template <int HD>
-__device__ __forceinline__ bf16x8 frag_hd_global(const bf16_t* src, long ld, int rowbase, int ks, int S, int lane) {
-  const int row = rowbase + (lane & 15), col = ks * 32 + (lane >> 4) * 8;
-  union { u32x4 u; bf16x8 v; } t;
-  t.u = u32x4{0u, 0u, 0u, 0u};
-  if (row < S && col < HD) t.u = *(const u32x4*)(src + (long)row * ld + col);
-  return t.v;
-}
 // A operand with k = sequence (32 rows starting at r0, permuted as described above), i = 16 columns starting at c0
 template <int HD>
 __device__ __forceinline__ bf16x8 frag_seq(const unsigned char* img, int r0, int c0, int lane) {
@@ -68,7 +152,7 @@ __device__ __forceinline__ bf16x8 frag_seq(const unsigned char* img, int r0, int
   u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * HeadCfg<HD>::RS));
   return u.v;
 }
-__device__ __forceinline__ bf16x8 pack8(const float (&lo)[4], const float (&hi)[4]) {
+__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
   union { uint32_t w[4]; bf16x8 v; } u;
   u.w[0] = pack2_bf16(lo[0], lo[1]); u.w[1] = pack2_bf16(lo[2], lo[3]);
   u.w[2] = pack2_bf16(hi[0], hi[1]); u.w[3] = pack2_bf16(hi[2], hi[3]);
@@ -80,159 +164,352 @@ __device__ __forceinline__ void store4_bf16(bf16_t* p, const f32x4& v, float sca
   t[1] = pack2_bf16(v[2] * scale, v[3] * scale);
   *(u32x2*)p = t;
 }
+__device__ __forceinline__ float quad_g_sum(float v) {   // sum over the 4 lanes (g = 0..3) that share lane & 15
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float quad_g_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+struct AttnParams {
+  const bf16_t *q, *k, *v, *o, *d_o;       // o / d_o: forward output (read by backward), upstream gradient
+  bf16_t *out, *dq, *dk, *dv;              // out: forward ctx
+  float *lse, *dsum;                       // [batch*heads, sqp]
+  long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;   // elements between consecutive tokens
+  long bq, bk, bv, bo, bdo, bdq, bdk, bdv;           // elements between consecutive images
+  int nh, sq, skv, sqp;
+  int nchunk, chunk_rows;                  // stationary rows per workgroup (multiple of 16)
+  int tile_rows, ntile;                    // streamed rows per LDS tile (multiple of 32), number of tiles
+  float alpha;
+};
+
+// blockIdx -> logical work item such that consecutive logical items (chunks of one head) run on one XCD (block b runs on XCD b % 8)
+__device__ __forceinline__ int xcd_remap() {
+  const int nb = gridDim.x, id = blockIdx.x, xcd = id & 7, slot = id >> 3, q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
 
 // =================================================================================================================
-// forward: ctx[b, q, h, :] = softmax(alpha * Q K^T) V ; lse[b*nh + h, q] = log sum exp of the scaled scores
+// forward: out[b, q, h, :] = softmax(alpha * Q K^T) V ; lse[b*nh + h, q] = log sum exp of the scaled scores
 // =================================================================================================================
-template <int HD, int MAXT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                       float* __restrict__ lse, int S, int SKP, int nh, float alpha) {
+// MAXT = 16-key tiles per streamed K/V tile (the LDS images always hold MAXT * 16 rows; rows past the sequence end are zeros).
+// Keys past the sequence end are masked through the MFMA's C operand (-1e30 instead of 0), which costs nothing for the
+// tiles that cannot contain the end: with FULL = false only the last two 16-key tiles of a K/V tile can (the host picks
+// MAXT = 2 * ceil(S_kv / 32) for one-tile problems and S_kv % 256 == 0 or > 224 for streamed ones), FULL = true masks every tile.
+// waves per SIMD to keep the register allocation to: what `blocks` co-resident workgroups of NW waves need (2 by LDS where they fit)
+constexpr int fwd_waves_per_simd(int hd_rs, int maxt, int nw) {
+  const int lds = 2 * maxt * 16 * hd_rs;
+  const int blocks = 163840 / lds >= 2 ? 2 : 1;
+  return (blocks * nw + 3) / 4;
+}
+template <int HD, int MAXT, int NW, bool FULL>
+__global__ __launch_bounds__(NW * 64, fwd_waves_per_simd(HeadCfg<HD>::RS, MAXT, NW)) void attn_fwd_kernel(const AttnParams P) {
   using C = HeadCfg<HD>;
+  constexpr int NT = NW * 64;
+  constexpr int ROWS = MAXT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Kimg = smem;
-  unsigned char* Vimg = smem + SKP * C::RS;
-  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
-  const int H = nh * HD;
-  const long ld = 3L * H;
-  const bf16_t* base = qkv + (long)b * S * ld + h * HD;
-  load_head<HD>(Kimg, base + H, ld, S, SKP);
-  load_head<HD>(Vimg, base + 2 * H, ld, S, SKP);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int nt = SKP >> 4, nq = (S + 15) >> 4;
-  for (int qt = wave; qt < nq; qt += 4) {
-    bf16x8 qf[C::KS];
+  unsigned char* Vimg = smem + ROWS * C::RS;
+  const int item = xcd_remap();
+  const int bh = item / P.nchunk, chunk = item - bh * P.nchunk;
+  const int b = bh / P.nh, h = bh - b * P.nh;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+  const unsigned ldq_b = (unsigned)P.ldq * 2, ldk_b = (unsigned)P.ldk * 2, ldv_b = (unsigned)P.ldv * 2;
+  const rsrc_t rq = make_rsrc(P.q + b * P.bq + h * HD, (unsigned)((P.sq - 1) * P.ldq + HD) * 2);
+  const rsrc_t rk = make_rsrc(P.k + b * P.bk + h * HD, (unsigned)((P.skv - 1) * P.ldk + HD) * 2);
+  const rsrc_t rv = make_rsrc(P.v + b * P.bv + h * HD, (unsigned)((P.skv - 1) * P.ldv + HD) * 2);
+  const float c = P.alpha * LOG2E;
+  const int q_begin = chunk * P.chunk_rows;
+  const int q_end = min(P.sq, q_begin + P.chunk_rows);
+  const int ntq = (q_end - q_begin + 15) >> 4;
+
+  // per-q-tile state (streamed K/V: carried across the tiles; one tile: a single pass)
+  FragHD<HD> qf;
+  float m = -INFINITY, l = 0.f;
+  f32x4 oacc[C::ND];
+
+  // scores of this wave's q-tile against the LDS tile in sub-steps of CT 16-key tiles, each an online-softmax update
+  // (m, l, O rescale) followed by O += P V: keeps ~CT*4 score registers live instead of MAXT*4
+  constexpr int CT = 6;
+  auto step = [&](int kv0) {
+    const int kvalid = P.skv - kv0 - 4 * g;   // this lane's keys kv0 + 16 t + 4 g + r are real iff 16 t + r < kvalid
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) qf[ks] = frag_hd_global<HD>(base, ld, qt * 16, ks, S, lane);
-    f32x4 sacc[MAXT];
-    float m = -INFINITY;
+    for (int t0 = 0; t0 < MAXT; t0 += CT) {
+      if (t0) __builtin_amdgcn_sched_barrier(0);   // keep the next sub-step's LDS reads from being hoisted over this one (registers)
+      const int tn = (MAXT - t0) < CT ? (MAXT - t0) : CT;   // compile-time after unrolling
+      f32x4 sacc[CT];
+      float mt = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < nt) {
+      for (int u = 0; u < CT; ++u) {
+        if (u < tn) {
+          const int t = t0 + u;
+          f32x4 ci = {0.f, 0.f, 0.f, 0.f};
+          if (FULL || t >= MAXT - 2) {
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks)
-          sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_hd<HD>(Kimg, t * 16, ks, lane), qf[ks], sacc[t], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) ci[r] = (16 * t + r < kvalid) ? 0.f : -1e30f;
+          }
+          sacc[u] = mma_hd<HD>(frag_lds<HD>(Kimg, t * 16, lane), qf, ci);
+          mt = fmaxf(mt, fmaxf(fmaxf(sacc[u][0], sacc[u][1]), fmaxf(sacc[u][2], sacc[u][3])));
+        }
+      }
+      mt = quad_g_max(mt);
+      const float mn = fmaxf(m, mt);
+      const float scale = __builtin_amdgcn_exp2f((m - mn) * c);   // 0 on the first sub-step (m = -inf)
+      const float mc = mn * c;
+      m = mn;
+      float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = t * 16 + 4 * g + r;
-          sacc[t][r] = key < S ? sacc[t][r] * alpha : -INFINITY;
-          m = fmaxf(m, sacc[t][r]);
+      for (int u = 0; u < CT; ++u) {
+        if (u < tn) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { sacc[u][r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc)); ps += sacc[u][r]; }
+        }
+      }
+      l = l * scale + ps;
+#pragma unroll
+      for (int d = 0; d < C::ND; ++d) oacc[d] *= scale;
+#pragma unroll
+      for (int s = 0; s < CT / 2; ++s) {
+        if (2 * s < tn) {
+          const bf16x8 pb = pack8(sacc[2 * s], sacc[2 * s + 1]);
+#pragma unroll
+          for (int d = 0; d < C::ND; ++d)
+            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Vimg, 16 * t0 + 32 * s, 16 * d, lane), pb, oacc[d], 0, 0, 0);
         }
       }
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      if (t < nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { sacc[t][r] = __expf(sacc[t][r] - m); sum += sacc[t][r]; }
-      }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    f32x4 oacc[C::ND];
+  };
+  auto begin_tile = [&](const FragHD<HD>& qnext) {
+    qf = qnext;
+    m = -INFINITY; l = 0.f;
 #pragma unroll
     for (int d = 0; d < C::ND; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < MAXT / 2; ++s) {
-      if (2 * s < nt) {
-        float lo[4] = {sacc[2 * s][0], sacc[2 * s][1], sacc[2 * s][2], sacc[2 * s][3]};
-        float hi[4] = {sacc[2 * s + 1][0], sacc[2 * s + 1][1], sacc[2 * s + 1][2], sacc[2 * s + 1][3]};
-        const bf16x8 pb = pack8(lo, hi);
-#pragma unroll
-        for (int d = 0; d < C::ND; ++d)
-          oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Vimg, 32 * s, 16 * d, lane), pb, oacc[d], 0, 0, 0);
-      }
-    }
-    const int q = qt * 16 + (lane & 15);
-    if (q < S) {
-      const float inv = 1.0f / sum;
-      bf16_t* o = ctx + ((long)b * S + q) * H + h * HD + 4 * g;
+  };
+  auto finish_tile = [&](int qt) {
+    const int q = q_begin + qt * 16 + (lane & 15);
+    const float lsum = quad_g_sum(l);
+    if (q < q_end) {
+      const float inv = 1.0f / lsum;
+      bf16_t* o = P.out + b * P.bo + (long)q * P.ldo + h * HD + 4 * g;
 #pragma unroll
       for (int d = 0; d < C::ND; ++d) store4_bf16(o + 16 * d, oacc[d], inv);
-      if (g == 0) lse[(long)bh * SKP + q] = m + __logf(sum);
+      if (g == 0) P.lse[(long)bh * P.sqp + q] = m * P.alpha + __logf(lsum);
     }
+  };
+
+  if (P.ntile == 1) {
+    FragHD<HD> qn = frag_global<HD>(rq, ldq_b, q_begin + wave * 16, lane);   // in flight under the K/V fetch
+    load_tile<HD, NT, ROWS>(Kimg, rk, ldk_b, 0, ROWS);
+    load_tile<HD, NT, ROWS>(Vimg, rv, ldv_b, 0, ROWS);
+    __syncthreads();
+    for (int qt = wave; qt < ntq; qt += NW) {
+      begin_tile(qn);
+      qn = frag_global<HD>(rq, ldq_b, q_begin + (qt + NW) * 16, lane);     // next tile's Q (rows past the end read as zeros)
+      step(0);
+      finish_tile(qt);
+    }
+  } else {   // one q-tile per wave (chunk_rows == NW * 16), state carried over the streamed K/V tiles
+    const bool active = wave < ntq;
+    begin_tile(frag_global<HD>(rq, ldq_b, q_begin + wave * 16, lane));
+    for (int j = 0; j < P.ntile; ++j) {
+      const int kv0 = j * ROWS;
+      if (j) __syncthreads();
+      load_tile<HD, NT, ROWS>(Kimg, rk, ldk_b, kv0, ROWS);
+      load_tile<HD, NT, ROWS>(Vimg, rv, ldv_b, kv0, ROWS);
+      __syncthreads();
+      if (active) step(kv0);
+    }
+    if (active) finish_tile(wave);
   }
 }
 
-// dsum[bh, q] = sum_d dctx[b,q,h,d] * ctx[b,q,h,d]   (the softmax-backward row constant), zero for q in [S, SKP)
-template <int HD>
-__global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx, float* __restrict__ dsum,
-                                     int S, int SKP, int nh, long total) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (bh, q in SKP)
-  if (i >= total) return;
-  const int q = (int)(i % SKP);
-  const long bh = i / SKP;
-  const int b = (int)(bh / nh), h = (int)(bh - (long)b * nh);
-  float s = 0.f;
-  if (q < S) {
-    const long off = ((long)b * S + q) * (nh * HD) + h * HD;
-#pragma unroll
-    for (int c = 0; c < HD; c += 8) {
-      const u32x4 a = *(const u32x4*)(ctx + off + c), d = *(const u32x4*)(dctx + off + c);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s = fmaf(__uint_as_float(a[j] << 16), __uint_as_float(d[j] << 16), s);
-        s = fmaf(__uint_as_float(a[j] & 0xffff0000u), __uint_as_float(d[j] & 0xffff0000u), s);
-      }
-    }
-  }
-  dsum[i] = s;
-}
-
 // =================================================================================================================
-// backward, part 1: dK, dV.  Each wave owns 16-key tiles and walks all queries in pairs of 16-query tiles.
+// backward, part 1: dQ (+ the softmax-backward row constant dsum[q] = sum_d dO[q,d] O[q,d], written for part 2).
+// Each wave owns 16-query tiles and walks the keys in pairs of 16-key tiles.
 // =================================================================================================================
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
-                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                           bf16_t* __restrict__ dqkv, int S, int SKP, int nh, float alpha) {
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams P) {
   using C = HeadCfg<HD>;
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Qimg = smem;
-  unsigned char* Dimg = smem + SKP * C::RS;  // dO image
-  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
-  const int H = nh * HD;
-  const long ld = 3L * H;
-  const bf16_t* base = qkv + (long)b * S * ld + h * HD;
-  load_head<HD>(Qimg, base, ld, S, SKP);
-  load_head<HD>(Dimg, dctx + (long)b * S * H + h * HD, H, S, SKP);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int nkt = (S + 15) >> 4, npair = SKP >> 5;
-  const float* lrow = lse + (long)bh * SKP;
-  const float* drow = dsum + (long)bh * SKP;
-  for (int kt = wave; kt < nkt; kt += 4) {
-    bf16x8 kf[C::KS], vf[C::KS];
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + P.tile_rows * C::RS;
+  const int item = xcd_remap();
+  const int bh = item / P.nchunk, chunk = item - bh * P.nchunk;
+  const int b = bh / P.nh, h = bh - b * P.nh;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+  const unsigned ldk_b = (unsigned)P.ldk * 2, ldv_b = (unsigned)P.ldv * 2;
+  const rsrc_t rq = make_rsrc(P.q + b * P.bq + h * HD, (unsigned)((P.sq - 1) * P.ldq + HD) * 2);
+  const rsrc_t ro = make_rsrc(P.o + b * P.bo + h * HD, (unsigned)((P.sq - 1) * P.ldo + HD) * 2);
+  const rsrc_t rd = make_rsrc(P.d_o + b * P.bdo + h * HD, (unsigned)((P.sq - 1) * P.lddo + HD) * 2);
+  const rsrc_t rk = make_rsrc(P.k + b * P.bk + h * HD, (unsigned)((P.skv - 1) * P.ldk + HD) * 2);
+  const rsrc_t rv = make_rsrc(P.v + b * P.bv + h * HD, (unsigned)((P.skv - 1) * P.ldv + HD) * 2);
+  const float c = P.alpha * LOG2E;
+  const int q_begin = chunk * P.chunk_rows;
+  const int q_end = min(P.sq, q_begin + P.chunk_rows);
+  const int ntq = (q_end - q_begin + 15) >> 4;
+  const bool multi = P.ntile > 1;
+
+  FragHD<HD> qf, df;
+  float lq2 = 0.f, dsq = 0.f;   // lse * log2(e), dsum of this lane's query
+  f32x4 acc[C::ND];
+  struct QIn { FragHD<HD> q, d, o; float l; };   // what a q-tile needs from global memory (prefetched one tile ahead)
+
+  auto fetch_tile = [&](int qt) {
+    QIn t;
+    const int r0 = q_begin + qt * 16;
+    t.q = frag_global<HD>(rq, (unsigned)P.ldq * 2, r0, lane);
+    t.d = frag_global<HD>(rd, (unsigned)P.lddo * 2, r0, lane);
+    t.o = frag_global<HD>(ro, (unsigned)P.ldo * 2, r0, lane);
+    const int q = r0 + (lane & 15);
+    t.l = q < q_end ? P.lse[(long)bh * P.sqp + q] : 0.f;
+    return t;
+  };
+  auto begin_tile = [&](int qt, const QIn& t) {
+    qf = t.q; df = t.d;
+    const int q = q_begin + qt * 16 + (lane & 15);
+    dsq = quad_g_sum(dot_hd<HD>(t.d, t.o));
+    lq2 = t.l * LOG2E;
+    if (q < q_end && g == 0) P.dsum[(long)bh * P.sqp + q] = dsq;
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      kf[ks] = frag_hd_global<HD>(base + H, ld, kt * 16, ks, S, lane);
-      vf[ks] = frag_hd_global<HD>(base + 2 * H, ld, kt * 16, ks, S, lane);
-    }
-    const bool key_ok = (kt * 16 + (lane & 15)) < S;
-    f32x4 dv[C::ND], dk[C::ND];
-#pragma unroll
-    for (int d = 0; d < C::ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int d = 0; d < C::ND; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto step = [&](int qt, int kv0, int npair) {
+    const bool qok = (q_begin + qt * 16 + (lane & 15)) < q_end;
     for (int s = 0; s < npair; ++s) {
-      float pv[2][4], dsv[2][4];
+      f32x4 dsv[2];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const int q0 = 32 * s + 16 * half;
+        const int k0 = 32 * s + 16 * half;
         f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_hd<HD>(Qimg, q0, ks, lane), kf[ks], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_hd<HD>(Dimg, q0, ks, lane), vf[ks], dp, 0, 0, 0);
-        }
-        const f32x4 l4 = *(const f32x4*)(lrow + q0 + 4 * g);
-        const f32x4 d4 = *(const f32x4*)(drow + q0 + 4 * g);
+        sa = mma_hd<HD>(frag_lds<HD>(Kimg, k0, lane), qf, sa);
+        dp = mma_hd<HD>(frag_lds<HD>(Vimg, k0, lane), df, dp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = key_ok && (q0 + 4 * g + r) < S;
-          const float p = ok ? __expf(sa[r] * alpha - l4[r]) : 0.f;
+          const bool ok = qok && (kv0 + k0 + 4 * g + r) < P.skv;
+          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], c, -lq2)) : 0.f;
+          dsv[half][r] = p * (dp[r] - dsq);
+        }
+      }
+      const bf16x8 dsb = pack8(dsv[0], dsv[1]);
+#pragma unroll
+      for (int d = 0; d < C::ND; ++d)
+        acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Kimg, 32 * s, 16 * d, lane), dsb, acc[d], 0, 0, 0);
+    }
+  };
+  auto finish_tile = [&](int qt) {
+    const int q = q_begin + qt * 16 + (lane & 15);
+    if (q < q_end) {
+      bf16_t* o = P.dq + b * P.bdq + (long)q * P.lddq + h * HD + 4 * g;
+#pragma unroll
+      for (int d = 0; d < C::ND; ++d) store4_bf16(o + 16 * d, acc[d], P.alpha);
+    }
+  };
+
+  if (!multi) {
+    const int rows = P.tile_rows;
+    QIn tn = fetch_tile(wave);   // in flight under the K/V fetch
+    load_tile<HD, NT, 288>(Kimg, rk, ldk_b, 0, rows);
+    load_tile<HD, NT, 288>(Vimg, rv, ldv_b, 0, rows);
+    __syncthreads();
+    for (int qt = wave; qt < ntq; qt += NW) {
+      begin_tile(qt, tn);
+      tn = fetch_tile(qt + NW);
+      step(qt, 0, rows >> 5);
+      finish_tile(qt);
+    }
+  } else {
+    const bool active = wave < ntq;
+    begin_tile(wave, fetch_tile(wave));
+    for (int j = 0; j < P.ntile; ++j) {
+      const int kv0 = j * P.tile_rows;
+      const int rows = min(P.tile_rows, (P.skv - kv0 + 31) & ~31);
+      if (j) __syncthreads();
+      load_tile<HD, NT, 288>(Kimg, rk, ldk_b, kv0, rows);
+      load_tile<HD, NT, 288>(Vimg, rv, ldv_b, kv0, rows);
+      __syncthreads();
+      if (active) step(wave, kv0, rows >> 5);
+    }
+    if (active) finish_tile(wave);
+  }
+}
+
+// =================================================================================================================
+// backward, part 2: dK, dV.  Each wave owns 16-key tiles and walks the queries in pairs of 16-query tiles; the queries'
+// lse / dsum ride in LDS next to the Q and dO images.
+// =================================================================================================================
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams P) {
+  using C = HeadCfg<HD>;
+  constexpr int NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qimg = smem;
+  unsigned char* Dimg = smem + P.tile_rows * C::RS;  // dO image
+  float* Limg = (float*)(smem + 2 * P.tile_rows * C::RS);   // lse * log2(e) of the tile's queries
+  float* Simg = Limg + P.tile_rows;                        // dsum
+  const int item = xcd_remap();
+  const int bh = item / P.nchunk, chunk = item - bh * P.nchunk;
+  const int b = bh / P.nh, h = bh - b * P.nh;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4;
+  const unsigned ldq_b = (unsigned)P.ldq * 2, lddo_b = (unsigned)P.lddo * 2;
+  const rsrc_t rq = make_rsrc(P.q + b * P.bq + h * HD, (unsigned)((P.sq - 1) * P.ldq + HD) * 2);
+  const rsrc_t rd = make_rsrc(P.d_o + b * P.bdo + h * HD, (unsigned)((P.sq - 1) * P.lddo + HD) * 2);
+  const rsrc_t rk = make_rsrc(P.k + b * P.bk + h * HD, (unsigned)((P.skv - 1) * P.ldk + HD) * 2);
+  const rsrc_t rv = make_rsrc(P.v + b * P.bv + h * HD, (unsigned)((P.skv - 1) * P.ldv + HD) * 2);
+  const float c = P.alpha * LOG2E;
+  const int k_begin = chunk * P.chunk_rows;
+  const int k_end = min(P.skv, k_begin + P.chunk_rows);
+  const int ntk = (k_end - k_begin + 15) >> 4;
+  const bool multi = P.ntile > 1;
+  const float* lrow = P.lse + (long)bh * P.sqp;
+  const float* drow = P.dsum + (long)bh * P.sqp;
+
+  FragHD<HD> kf, vf;
+  f32x4 dv[C::ND], dk[C::ND];
+
+  auto load_q_tile = [&](int q0, int rows) {
+    load_tile<HD, NT, 288>(Qimg, rq, ldq_b, q0, rows);
+    load_tile<HD, NT, 288>(Dimg, rd, lddo_b, q0, rows);
+    for (int i = threadIdx.x; i < rows; i += NT) {
+      const bool ok = q0 + i < P.sq;
+      Limg[i] = ok ? lrow[q0 + i] * LOG2E : 0.f;
+      Simg[i] = ok ? drow[q0 + i] : 0.f;
+    }
+  };
+  struct KIn { FragHD<HD> k, v; };
+  auto fetch_tile = [&](int kt) {
+    KIn t;
+    t.k = frag_global<HD>(rk, (unsigned)P.ldk * 2, k_begin + kt * 16, lane);
+    t.v = frag_global<HD>(rv, (unsigned)P.ldv * 2, k_begin + kt * 16, lane);
+    return t;
+  };
+  auto begin_tile = [&](const KIn& t) {
+    kf = t.k; vf = t.v;
+#pragma unroll
+    for (int d = 0; d < C::ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  };
+  auto step = [&](int kt, int q0, int npair) {
+    const bool key_ok = (k_begin + kt * 16 + (lane & 15)) < k_end;
+    for (int s = 0; s < npair; ++s) {
+      f32x4 pv[2], dsv[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int r0 = 32 * s + 16 * half;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sa = mma_hd<HD>(frag_lds<HD>(Qimg, r0, lane), kf, sa);
+        dp = mma_hd<HD>(frag_lds<HD>(Dimg, r0, lane), vf, dp);
+        const f32x4 l4 = *(const f32x4*)(Limg + r0 + 4 * g);
+        const f32x4 d4 = *(const f32x4*)(Simg + r0 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = key_ok && (q0 + r0 + 4 * g + r) < P.sq;
+          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], c, -l4[r])) : 0.f;
           pv[half][r] = p;
           dsv[half][r] = p * (dp[r] - d4[r]);
         }
@@ -244,147 +521,244 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Qimg, 32 * s, 16 * d, lane), dsb, dk[d], 0, 0, 0);
       }
     }
-    const int key = kt * 16 + (lane & 15);
-    if (key < S) {
-      bf16_t* o = dqkv + ((long)b * S + key) * ld + h * HD + 4 * g;
+  };
+  auto finish_tile = [&](int kt) {
+    const int key = k_begin + kt * 16 + (lane & 15);
+    if (key < k_end) {
+      bf16_t* ok_ = P.dk + b * P.bdk + (long)key * P.lddk + h * HD + 4 * g;
+      bf16_t* ov_ = P.dv + b * P.bdv + (long)key * P.lddv + h * HD + 4 * g;
 #pragma unroll
       for (int d = 0; d < C::ND; ++d) {
-        store4_bf16(o + H + 16 * d, dk[d], alpha);
-        store4_bf16(o + 2 * H + 16 * d, dv[d], 1.0f);
+        store4_bf16(ok_ + 16 * d, dk[d], P.alpha);
+        store4_bf16(ov_ + 16 * d, dv[d], 1.0f);
       }
     }
-  }
-}
+  };
 
-// =================================================================================================================
-// backward, part 2: dQ.  Each wave owns 16-query tiles and walks all keys in pairs of 16-key tiles.
-// =================================================================================================================
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
-                                                          const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                          bf16_t* __restrict__ dqkv, int S, int SKP, int nh, float alpha) {
-  using C = HeadCfg<HD>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Kimg = smem;
-  unsigned char* Vimg = smem + SKP * C::RS;
-  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
-  const int H = nh * HD;
-  const long ld = 3L * H;
-  const bf16_t* base = qkv + (long)b * S * ld + h * HD;
-  load_head<HD>(Kimg, base + H, ld, S, SKP);
-  load_head<HD>(Vimg, base + 2 * H, ld, S, SKP);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int nq = (S + 15) >> 4, npair = SKP >> 5;
-  const bf16_t* dbase = dctx + (long)b * S * H + h * HD;
-  for (int qt = wave; qt < nq; qt += 4) {
-    bf16x8 qf[C::KS], df[C::KS];
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      qf[ks] = frag_hd_global<HD>(base, ld, qt * 16, ks, S, lane);
-      df[ks] = frag_hd_global<HD>(dbase, H, qt * 16, ks, S, lane);
+  if (!multi) {
+    const int rows = P.tile_rows;
+    KIn tn = fetch_tile(wave);   // in flight under the Q / dO fetch
+    load_q_tile(0, rows);
+    __syncthreads();
+    for (int kt = wave; kt < ntk; kt += NW) {
+      begin_tile(tn);
+      tn = fetch_tile(kt + NW);
+      step(kt, 0, rows >> 5);
+      finish_tile(kt);
     }
-    const int q = qt * 16 + (lane & 15);
-    const float lq = q < S ? lse[(long)bh * SKP + q] : 0.f;
-    const float dq_ = q < S ? dsum[(long)bh * SKP + q] : 0.f;
-    f32x4 acc[C::ND];
-#pragma unroll
-    for (int d = 0; d < C::ND; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < npair; ++s) {
-      float dsv[2][4];
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int k0 = 32 * s + 16 * half;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_hd<HD>(Kimg, k0, ks, lane), qf[ks], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_hd<HD>(Vimg, k0, ks, lane), df[ks], dp, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = (q < S) && (k0 + 4 * g + r) < S;
-          const float p = ok ? __expf(sa[r] * alpha - lq) : 0.f;
-          dsv[half][r] = p * (dp[r] - dq_);
-        }
-      }
-      const bf16x8 dsb = pack8(dsv[0], dsv[1]);
-#pragma unroll
-      for (int d = 0; d < C::ND; ++d)
-        acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Kimg, 32 * s, 16 * d, lane), dsb, acc[d], 0, 0, 0);
-    }
-    if (q < S) {
-      bf16_t* o = dqkv + ((long)b * S + q) * ld + h * HD + 4 * g;
-#pragma unroll
-      for (int d = 0; d < C::ND; ++d) store4_bf16(o + 16 * d, acc[d], alpha);
-    }
-  }
-}
-
-// =================================================================================================================
-template <int HD>
-static int attn_fwd_launch(const void* qkv, void* ctx, float* lse, int B, int S, int nh, float alpha, hipStream_t st) {
-  using C = HeadCfg<HD>;
-  const int SKP = (S + 31) / 32 * 32;
-  const size_t lds = 2 * (size_t)SKP * C::RS;
-  if (SKP <= 64) {
-    auto k = attn_fwd_kernel<HD, 4>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(B * nh), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, S, SKP, nh, alpha);
   } else {
-    auto k = attn_fwd_kernel<HD, 18>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(B * nh), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)ctx, lse, S, SKP, nh, alpha);
+    const bool active = wave < ntk;
+    begin_tile(fetch_tile(wave));
+    for (int j = 0; j < P.ntile; ++j) {
+      const int q0 = j * P.tile_rows;
+      const int rows = min(P.tile_rows, (P.sq - q0 + 31) & ~31);
+      if (j) __syncthreads();
+      load_q_tile(q0, rows);
+      __syncthreads();
+      if (active) step(wave, q0, rows >> 5);
+    }
+    if (active) finish_tile(wave);
   }
+}
+
+// =================================================================================================================
+// host side: work decomposition
+// =================================================================================================================
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// waves per workgroup for `tiles` 16-row tiles handled by one workgroup.  Only multiples of 4: a 6-wave workgroup (the balanced
+// count for 17 tiles) measured SLOWER than 4 or 8 (54 vs 48 / 40 us forward at 64 x 16 heads x 257): its waves land 2,2,1,1 on
+// the four SIMDs and a second workgroup is then not admitted next to it, leaving one workgroup per CU.
+static int pick_waves(int tiles) {
+  static const int force = getenv("MUSE_ATT_NW") ? atoi(getenv("MUSE_ATT_NW")) : 0;   // experiment switch
+  if (force) return force;
+  return tiles > 6 ? 8 : 4;
+}
+
+struct Plan { int nw, nchunk, chunk_rows, tile_rows, ntile; size_t lds; };
+
+// backward kernels: stationary = rows the waves own (sq for dQ, skv for dK,dV); streamed = rows that pass through LDS
+template <int HD>
+static Plan make_plan(int stationary, int streamed, bool extra_f32) {
+  using C = HeadCfg<HD>;
+  Plan p;
+  if (streamed <= 288) { p.tile_rows = round_up(streamed, 32); p.ntile = 1; }
+  else { p.tile_rows = 256; p.ntile = (streamed + 255) / 256; }
+  const int tiles = (stationary + 15) / 16;
+  if (p.ntile == 1 && tiles <= 24) {          // whole head in one workgroup
+    p.nw = pick_waves(tiles); p.nchunk = 1; p.chunk_rows = tiles * 16;
+  } else if (p.ntile == 1) {                   // long stationary side, short streamed side (cross-attention): 2 tiles per wave
+    p.nw = 8; p.chunk_rows = 256; p.nchunk = (stationary + 255) / 256;
+  } else {                                      // state carried across streamed tiles: one tile per wave
+    p.nw = 8; p.chunk_rows = 128; p.nchunk = (stationary + 127) / 128;
+  }
+  p.lds = 2 * (size_t)p.tile_rows * C::RS + (extra_f32 ? 2 * (size_t)p.tile_rows * 4 : 0);
+  return p;
+}
+
+template <int HD, int MAXT, int NW, bool FULL>
+static int fwd_launch_k(AttnParams P, int sq_tiles_per_chunk_rows, int nchunk, int ntile, int batch, hipStream_t st) {
+  using C = HeadCfg<HD>;
+  P.nchunk = nchunk; P.chunk_rows = sq_tiles_per_chunk_rows; P.tile_rows = MAXT * 16; P.ntile = ntile;
+  const size_t lds = 2 * (size_t)MAXT * 16 * C::RS;
+  auto k = attn_fwd_kernel<HD, MAXT, NW, FULL>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(batch * P.nh * nchunk), dim3(NW * 64), lds, st, P);
+  return (int)hipGetLastError();
+}
+// forward: the kernel variant is (16-key tiles per K/V tile, waves, mask mode)
+template <int HD>
+static int attn_fwd_launch(const AttnParams& P, int batch, hipStream_t st) {
+  const int qt = (P.sq + 15) / 16;                 // 16-query tiles per head
+  if (P.skv <= 288) {
+    const int nt = 2 * ((P.skv + 31) / 32);        // exactly the tiles the keys need: only the last two can hold the end
+    const bool whole = qt <= 24;                   // whole head in one workgroup, else 256-query chunks (2 tiles per wave)
+    const int rows = whole ? qt * 16 : 256, nchunk = whole ? 1 : (P.sq + 255) / 256;
+    const bool big = (whole ? qt : 16) > 6;        // 8 waves when there are q-tiles for them
+    switch (nt) {
+      case 2: return big ? fwd_launch_k<HD, 2, 8, false>(P, rows, nchunk, 1, batch, st) : fwd_launch_k<HD, 2, 4, false>(P, rows, nchunk, 1, batch, st);
+      case 4: return big ? fwd_launch_k<HD, 4, 8, false>(P, rows, nchunk, 1, batch, st) : fwd_launch_k<HD, 4, 4, false>(P, rows, nchunk, 1, batch, st);
+      case 6: return big ? fwd_launch_k<HD, 6, 8, false>(P, rows, nchunk, 1, batch, st) : fwd_launch_k<HD, 6, 4, false>(P, rows, nchunk, 1, batch, st);
+      case 16: return fwd_launch_k<HD, 16, 8, false>(P, rows, nchunk, 1, batch, st);
+      case 18: {
+        static const int force = getenv("MUSE_ATT_NW") ? atoi(getenv("MUSE_ATT_NW")) : 0;   // experiment switch
+        if (force == 4) return fwd_launch_k<HD, 18, 4, false>(P, rows, nchunk, 1, batch, st);
+        if (force == 8) return fwd_launch_k<HD, 18, 8, false>(P, rows, nchunk, 1, batch, st);
+        if (force == 6) return fwd_launch_k<HD, 18, 6, false>(P, rows, nchunk, 1, batch, st);
+        return fwd_launch_k<HD, 18, 8, false>(P, rows, nchunk, 1, batch, st);
+      }
+      default: return fwd_launch_k<HD, 16, 8, true>(P, rows, nchunk, 1, batch, st);   // 8..14 tiles: the 16-tile kernel, every tile masked
+    }
+  }
+  // streamed K/V (256 keys per tile), one q-tile per wave, 128-query chunks
+  const int ntile = (P.skv + 255) / 256, nchunk = (P.sq + 127) / 128;
+  const int tail = P.skv - (ntile - 1) * 256;      // keys in the last tile
+  if (tail > 224) return fwd_launch_k<HD, 16, 8, false>(P, 128, nchunk, ntile, batch, st);
+  return fwd_launch_k<HD, 16, 8, true>(P, 128, nchunk, ntile, batch, st);
+}
+
+template <int HD, int NW>
+static int bwd_launch_dq(const AttnParams& P, const Plan& pl, int items, hipStream_t st) {
+  auto k = attn_bwd_dq_kernel<HD, NW>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  hipLaunchKernelGGL(k, dim3(items), dim3(NW * 64), pl.lds, st, P);
+  return (int)hipGetLastError();
+}
+template <int HD, int NW>
+static int bwd_launch_dkv(const AttnParams& P, const Plan& pl, int items, hipStream_t st) {
+  auto k = attn_bwd_dkv_kernel<HD, NW>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  hipLaunchKernelGGL(k, dim3(items), dim3(NW * 64), pl.lds, st, P);
   return (int)hipGetLastError();
 }
 template <int HD>
-static int attn_bwd_launch(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dsum, void* dqkv,
-                           int B, int S, int nh, float alpha, hipStream_t st) {
-  using C = HeadCfg<HD>;
-  const int SKP = (S + 31) / 32 * 32;
-  const size_t lds = 2 * (size_t)SKP * C::RS;
-  const long total = (long)B * nh * SKP;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel<HD>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)ctx,
-                     (const bf16_t*)dctx, dsum, S, SKP, nh, total);
-  auto k1 = attn_bwd_dkv_kernel<HD>;
-  auto k2 = attn_bwd_dq_kernel<HD>;
-  (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k1, dim3(B * nh), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, (const float*)dsum,
-                     (bf16_t*)dqkv, S, SKP, nh, alpha);
-  hipLaunchKernelGGL(k2, dim3(B * nh), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dctx, lse, (const float*)dsum,
-                     (bf16_t*)dqkv, S, SKP, nh, alpha);
-  return (int)hipGetLastError();
+static int attn_bwd_launch(AttnParams P, int batch, hipStream_t st) {
+  const Plan plq = make_plan<HD>(P.sq, P.skv, false);   // dQ: queries stationary, keys streamed
+  const Plan plk = make_plan<HD>(P.skv, P.sq, true);    // dK,dV: keys stationary, queries streamed
+  AttnParams Pq = P, Pk = P;
+  Pq.nchunk = plq.nchunk; Pq.chunk_rows = plq.chunk_rows; Pq.tile_rows = plq.tile_rows; Pq.ntile = plq.ntile;
+  Pk.nchunk = plk.nchunk; Pk.chunk_rows = plk.chunk_rows; Pk.tile_rows = plk.tile_rows; Pk.ntile = plk.ntile;
+  const int iq = batch * P.nh * plq.nchunk, ik = batch * P.nh * plk.nchunk;
+  int rc;   // dQ first: it also produces dsum, which dK,dV consumes
+  switch (plq.nw) {
+    case 4: rc = bwd_launch_dq<HD, 4>(Pq, plq, iq, st); break;
+    case 6: rc = bwd_launch_dq<HD, 6>(Pq, plq, iq, st); break;
+    default: rc = bwd_launch_dq<HD, 8>(Pq, plq, iq, st); break;
+  }
+  if (rc) return rc;
+  switch (plk.nw) {
+    case 4: return bwd_launch_dkv<HD, 4>(Pk, plk, ik, st);
+    case 6: return bwd_launch_dkv<HD, 6>(Pk, plk, ik, st);
+    default: return bwd_launch_dkv<HD, 8>(Pk, plk, ik, st);
+  }
+}
+
+static int check_desc(const muse_attn_desc* d) {
+  if (!d || d->seq_q <= 0 || d->seq_kv <= 0 || d->heads <= 0) return MUSE_ERR_BAD_ARG;
+  if (d->head_dim != 16 && d->head_dim != 32 && d->head_dim != 48 && d->head_dim != 64) return MUSE_ERR_UNSUPPORTED;
+  const int64_t lds[] = {d->ldq, d->ldk, d->ldv, d->ldo, d->bsq, d->bsk, d->bsv, d->bso};
+  for (int64_t x : lds) if (x & 7) return MUSE_ERR_ALIGN;     // 16-byte rows
+  const void* ps[] = {d->q, d->k, d->v, d->o};
+  for (const void* p : ps) if (((uintptr_t)p) & 15) return MUSE_ERR_ALIGN;
+  // 32-bit byte offsets inside one image
+  if ((int64_t)d->seq_q * d->ldq * 2 >= (1LL << 31) || (int64_t)d->seq_kv * d->ldk * 2 >= (1LL << 31) ||
+      (int64_t)d->seq_kv * d->ldv * 2 >= (1LL << 31) || (int64_t)d->seq_q * d->ldo * 2 >= (1LL << 31)) return MUSE_ERR_UNSUPPORTED;
+  return 0;
+}
+static AttnParams base_params(const muse_attn_desc* d) {
+  AttnParams P = {};
+  P.q = (const bf16_t*)d->q; P.k = (const bf16_t*)d->k; P.v = (const bf16_t*)d->v;
+  P.ldq = d->ldq; P.ldk = d->ldk; P.ldv = d->ldv; P.ldo = d->ldo;
+  P.bq = d->bsq; P.bk = d->bsk; P.bv = d->bsv; P.bo = d->bso;
+  P.nh = d->heads; P.sq = d->seq_q; P.skv = d->seq_kv; P.sqp = muse_attention_seq_pad(d->seq_q);
+  P.alpha = d->alpha;
+  return P;
 }
 
 extern "C" int muse_attention_seq_pad(int32_t seq) { return (seq + 31) / 32 * 32; }
 
-extern "C" int muse_attention_fwd(const void* qkv, void* ctx, float* lse, int32_t batch, int32_t seq, int32_t heads,
-                                  int32_t head_dim, float alpha, void* stream) {
-  if (seq > 288 || seq <= 0) return MUSE_ERR_UNSUPPORTED;
-  if (batch <= 0) return 0;
+extern "C" int muse_attention_fwd_ex(const muse_attn_desc* d, float* lse, void* stream) {
+  const int rc = check_desc(d);
+  if (rc) return rc;
+  if (d->batch <= 0) return 0;
+  AttnParams P = base_params(d);
+  P.out = (bf16_t*)d->o; P.lse = lse;
   hipStream_t st = (hipStream_t)stream;
-  switch (head_dim) {
-    case 16: return attn_fwd_launch<16>(qkv, ctx, lse, batch, seq, heads, alpha, st);
-    case 32: return attn_fwd_launch<32>(qkv, ctx, lse, batch, seq, heads, alpha, st);
-    case 48: return attn_fwd_launch<48>(qkv, ctx, lse, batch, seq, heads, alpha, st);
-    case 64: return attn_fwd_launch<64>(qkv, ctx, lse, batch, seq, heads, alpha, st);
+  switch (d->head_dim) {
+    case 16: return attn_fwd_launch<16>(P, d->batch, st);
+    case 32: return attn_fwd_launch<32>(P, d->batch, st);
+    case 48: return attn_fwd_launch<48>(P, d->batch, st);
+    case 64: return attn_fwd_launch<64>(P, d->batch, st);
   }
   return MUSE_ERR_UNSUPPORTED;
 }
 
+extern "C" int muse_attention_bwd_ex(const muse_attn_desc* d, const void* d_o, int64_t lddo, int64_t bsdo, const float* lse,
+                                     float* dsum, void* dq, int64_t lddq, int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk,
+                                     void* dv, int64_t lddv, int64_t bsdv, void* stream) {
+  const int rc = check_desc(d);
+  if (rc) return rc;
+  if ((lddo | bsdo | lddq | bsdq | lddk | bsdk | lddv | bsdv) & 7) return MUSE_ERR_ALIGN;
+  if ((((uintptr_t)d_o) | ((uintptr_t)dq) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 7) return MUSE_ERR_ALIGN;
+  if ((int64_t)d->seq_q * lddo * 2 >= (1LL << 31)) return MUSE_ERR_UNSUPPORTED;
+  if (d->batch <= 0) return 0;
+  AttnParams P = base_params(d);
+  P.o = (const bf16_t*)d->o; P.d_o = (const bf16_t*)d_o; P.lddo = lddo; P.bdo = bsdo;
+  P.lse = (float*)lse; P.dsum = dsum;
+  P.dq = (bf16_t*)dq; P.lddq = lddq; P.bdq = bsdq;
+  P.dk = (bf16_t*)dk; P.lddk = lddk; P.bdk = bsdk;
+  P.dv = (bf16_t*)dv; P.lddv = lddv; P.bdv = bsdv;
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->head_dim) {
+    case 16: return attn_bwd_launch<16>(P, d->batch, st);
+    case 32: return attn_bwd_launch<32>(P, d->batch, st);
+    case 48: return attn_bwd_launch<48>(P, d->batch, st);
+    case 64: return attn_bwd_launch<64>(P, d->batch, st);
+  }
+  return MUSE_ERR_UNSUPPORTED;
+}
+
+// packed-qkv self-attention entry points (qkv [batch*seq, 3*heads*head_dim]: the fused QKV projection's output)
+static muse_attn_desc packed_desc(const void* qkv, void* ctx, int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, float alpha) {
+  const int64_t H = (int64_t)heads * head_dim;
+  muse_attn_desc d = {};
+  d.q = qkv; d.k = (const bf16_t*)qkv + H; d.v = (const bf16_t*)qkv + 2 * H; d.o = ctx;
+  d.ldq = d.ldk = d.ldv = 3 * H; d.ldo = H;
+  d.bsq = d.bsk = d.bsv = (int64_t)seq * 3 * H; d.bso = (int64_t)seq * H;
+  d.batch = batch; d.heads = heads; d.head_dim = head_dim; d.seq_q = seq; d.seq_kv = seq; d.alpha = alpha;
+  return d;
+}
+extern "C" int muse_attention_fwd(const void* qkv, void* ctx, float* lse, int32_t batch, int32_t seq, int32_t heads,
+                                  int32_t head_dim, float alpha, void* stream) {
+  const muse_attn_desc d = packed_desc(qkv, ctx, batch, seq, heads, head_dim, alpha);
+  return muse_attention_fwd_ex(&d, lse, stream);
+}
 extern "C" int muse_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* dsum,
                                   void* dqkv, int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, float alpha,
                                   void* stream) {
-  if (seq > 288 || seq <= 0) return MUSE_ERR_UNSUPPORTED;
-  if (batch <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  switch (head_dim) {
-    case 16: return attn_bwd_launch<16>(qkv, ctx, dctx, lse, dsum, dqkv, batch, seq, heads, alpha, st);
-    case 32: return attn_bwd_launch<32>(qkv, ctx, dctx, lse, dsum, dqkv, batch, seq, heads, alpha, st);
-    case 48: return attn_bwd_launch<48>(qkv, ctx, dctx, lse, dsum, dqkv, batch, seq, heads, alpha, st);
-    case 64: return attn_bwd_launch<64>(qkv, ctx, dctx, lse, dsum, dqkv, batch, seq, heads, alpha, st);
-  }
-  return MUSE_ERR_UNSUPPORTED;
+  const muse_attn_desc d = packed_desc(qkv, (void*)ctx, batch, seq, heads, head_dim, alpha);
+  const int64_t H = (int64_t)heads * head_dim;
+  bf16_t* g = (bf16_t*)dqkv;
+  return muse_attention_bwd_ex(&d, dctx, H, (int64_t)seq * H, lse, dsum, g, 3 * H, (int64_t)seq * 3 * H, g + H, 3 * H,
+                               (int64_t)seq * 3 * H, g + 2 * H, 3 * H, (int64_t)seq * 3 * H, stream);
 }

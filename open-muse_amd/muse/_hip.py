@@ -31,6 +31,16 @@ class GemmDesc(C.Structure):
     ]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
+        ("ldq", c_i64), ("ldk", c_i64), ("ldv", c_i64), ("ldo", c_i64),
+        ("bsq", c_i64), ("bsk", c_i64), ("bsv", c_i64), ("bso", c_i64),
+        ("batch", c_int), ("heads", c_int), ("head_dim", c_int), ("seq_q", c_int), ("seq_kv", c_int),
+        ("alpha", c_float),
+    ]
+
+
 # name -> argtypes (every function returns int unless listed in _RESTYPES)
 SIGNATURES = {
     "muse_version": [],
@@ -46,6 +56,9 @@ SIGNATURES = {
     "muse_softmax_fwd": [c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],
     "muse_softmax_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],
     "muse_attention_seq_pad": [c_int],
+    "muse_attention_fwd_ex": [C.POINTER(AttnDesc), c_void_p, c_void_p],
+    "muse_attention_bwd_ex": [C.POINTER(AttnDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p,
+                              c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p],
     "muse_attention_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "muse_attention_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                            c_void_p],

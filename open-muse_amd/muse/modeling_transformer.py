@@ -183,7 +183,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None  # (flat_begin, flat_end) after each segment
         self._flat = self._flat_grad = self._flat_c = self._flat_ct = None
         self._shadow_fresh = False
-        self._shadow_version, self._ct_version = 0, -1
+        self._shadow_version, self._ct_version, self._shadow_pversion = 0, -1, -1
         self.transposed_dgrad = False  # bf16 mode option: W^T copies so dgrad uses the k-contiguous GEMM kernel (measured: no net gain)
         self._build_flat()
         self._init_weights()
@@ -285,16 +285,40 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                                 for p, o in zip(self._param_order(), self._offsets)]
         return self._flat_grad
 
+    def _param_version(self) -> int:
+        """sum of the parameters' autograd version counters: changes whenever anything updates a parameter in place
+        (torch.optim.AdamW / Lion `p.add_()`, `p.copy_()`, ...).  Writes through `p.data` are invisible to it; those callers
+        (EMA copy_to / restore) are covered by train()/eval() transitions and by mark_weights_changed()."""
+        return sum(p._version for p in self._param_order())
+
+    def mark_weights_changed(self):
+        """call after writing the f32 master weights behind autograd's back (`p.data.copy_`, a raw kernel on flat_params())"""
+        self._shadow_fresh = False
+
+    def _note_shadow_refreshed(self, fresh: bool):
+        """FusedAdamW has just rewritten the master weights and (if `fresh`) the bf16 copy in the same kernel"""
+        self._shadow_fresh = bool(fresh)
+        self._shadow_pversion = self._param_version()
+        self._shadow_version += 1   # transposed weight copies (dgrad) are rebuilt from the refreshed shadow
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            self._shadow_fresh = False   # EMA copy_to()/restore() around evaluation write p.data (reference modeling_ema.py)
+        return super().train(mode)
+
     def compute_weights(self, cd) -> torch.Tensor:
-        """flat weights in the compute dtype (the f32 master itself, or its bf16 shadow)."""
+        """flat weights in the compute dtype (the f32 master itself, or its bf16 shadow).  The shadow is re-cast whenever
+        it is not PROVEN current: only FusedAdamW (same kernel writes both) and an unchanged parameter-version sum count."""
         if cd == torch.float32:
             return self._flat
         if self._flat_c is None or self._flat_c.device != self._flat.device:
             self._flat_c = torch.empty(self._flat_n, dtype=torch.bfloat16, device=self._flat.device)
             self._shadow_fresh = False
-        if not self._shadow_fresh:
+        pv = self._param_version()
+        if not self._shadow_fresh or pv != self._shadow_pversion:
             ops.cast_to_bf16(self._flat, self._flat_c)
             self._shadow_fresh = True
+            self._shadow_pversion = pv
             self._shadow_version += 1
         return self._flat_c
 
@@ -341,10 +365,6 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)  # (grad mode is off inside Function.forward)
         out = _MaskGitFn.apply(self, input_ids, labels, float(label_smoothing), need_grad, *params)
         return out
-
-    def _segments(self, L):
-        """flat-buffer views of the compute weights for layer L and the head (element offsets)."""
-        raise NotImplementedError
 
     def _run_forward(self, input_ids, labels, label_smoothing, need_grad):
         cd = self._resolve_cd()

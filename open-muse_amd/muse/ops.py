@@ -256,8 +256,56 @@ def softmax_bwd_(p, dp, rows, cols, ld):
     return dp
 
 
-def attention_supported(dtype, seq, head_dim):
-    return dtype == torch.bfloat16 and 0 < seq <= 288 and head_dim in (16, 32, 48, 64)
+def attention_supported(dtype, seq, head_dim, seq_kv=None):
+    """the fused attention kernels take bf16, head_dim 16/32/48/64 and any query / key length"""
+    return dtype == torch.bfloat16 and seq > 0 and (seq_kv is None or seq_kv > 0) and head_dim in (16, 32, 48, 64)
+
+
+def _row_view(t, heads_dim):
+    """(base tensor pointer, elements between tokens) of a [tokens, >= heads_dim] view with unit column stride"""
+    if t.dim() != 2 or t.stride(1) != 1 or t.shape[1] < heads_dim:
+        raise _hip.MuseHipError("attention operands are [tokens, features] views with contiguous features")
+    return t.data_ptr(), t.stride(0)
+
+
+def _attn_desc(q, k, v, o, B, Sq, Skv, nh, hd, alpha):
+    d = _hip.AttnDesc()
+    H = nh * hd
+    (d.q, d.ldq), (d.k, d.ldk), (d.v, d.ldv), (d.o, d.ldo) = _row_view(q, H), _row_view(k, H), _row_view(v, H), _row_view(o, H)
+    d.bsq, d.bsk, d.bsv, d.bso = Sq * d.ldq, Skv * d.ldk, Skv * d.ldv, Sq * d.ldo
+    d.batch, d.heads, d.head_dim, d.seq_q, d.seq_kv, d.alpha = B, nh, hd, Sq, Skv, alpha
+    return d
+
+
+def attention_fwd_ex(q, k, v, B, Sq, Skv, nh, hd, alpha, out=None):
+    """fused softmax(alpha q k^T) v for separate q [B*Sq, H], k / v [B*Skv, H] views (row strides free: slices of a packed
+    projection are fine); -> (ctx [B*Sq, H] bf16, lse [B*nh, seq_pad(Sq)] f32).  Self- and cross-attention."""
+    require_gpu(q, k, v)
+    H = nh * hd
+    ctx = out if out is not None else torch.empty((B * Sq, H), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B * nh, lib().muse_attention_seq_pad(Sq)), dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
+    e0 = _prof_begin()
+    check(lib().muse_attention_fwd_ex(C.byref(d), lse.data_ptr(), stream()), "muse_attention_fwd_ex")
+    _prof_end(e0, "attn_fwd_bf16", 4.0 * B * nh * Sq * Skv * hd)
+    return ctx, lse
+
+
+def attention_bwd_ex(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None, dk=None, dv=None):
+    """-> (dq [B*Sq, H], dk, dv [B*Skv, H]) bf16; dq / dk / dv may be views (e.g. the three column blocks of a packed gradient)"""
+    require_gpu(q, k, v, ctx, dctx, lse)
+    H = nh * hd
+    dq = dq if dq is not None else torch.empty((B * Sq, H), dtype=q.dtype, device=q.device)
+    dk = dk if dk is not None else torch.empty((B * Skv, H), dtype=q.dtype, device=q.device)
+    dv = dv if dv is not None else torch.empty((B * Skv, H), dtype=q.dtype, device=q.device)
+    dsum = torch.empty_like(lse)
+    d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
+    (pdo, lddo), (pdq, lddq), (pdk, lddk), (pdv, lddv) = _row_view(dctx, H), _row_view(dq, H), _row_view(dk, H), _row_view(dv, H)
+    e0 = _prof_begin()
+    check(lib().muse_attention_bwd_ex(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), dsum.data_ptr(), pdq, lddq, Sq * lddq,
+                                      pdk, lddk, Skv * lddk, pdv, lddv, Skv * lddv, stream()), "muse_attention_bwd_ex")
+    _prof_end(e0, "attn_bwd_bf16", 10.0 * B * nh * Sq * Skv * hd)
+    return dq, dk, dv
 
 
 def attention_fwd(qkv, B, S, nh, hd, alpha):

@@ -62,7 +62,9 @@ class FusedAdamW(torch.optim.Optimizer):
     """AdamW (decoupled weight decay, torch.optim.AdamW numerics) as ONE kernel launch over the model's flat f32
     parameter / gradient buffers; also refreshes the bf16 compute copy of the weights in the same pass.
 
-    Drop-in for `optimizer_cls(model.parameters(), lr=..., betas=..., weight_decay=..., eps=...)`."""
+    Drop-in for `optimizer_cls(model.parameters(), lr=..., betas=..., weight_decay=..., eps=...)`.  `state_dict()` /
+    `load_state_dict()` use torch.optim.AdamW's layout ({"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups"}),
+    so optimizer checkpoints written by the reference's `adamw` choice load here and vice versa."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         params = list(params)
@@ -71,8 +73,29 @@ class FusedAdamW(torch.optim.Optimizer):
             raise MuseHipError("FusedAdamW supports a single parameter group (the reference uses one: :257-263)")
         owner = _owner_of(self.param_groups[0]["params"])
         self._model = weakref.ref(owner) if owner is not None else None
+        if owner is not None:
+            mine, theirs = self.param_groups[0]["params"], owner._param_order()
+            if len(mine) != len(theirs) or any(a is not b for a, b in zip(mine, theirs)):
+                raise MuseHipError("FusedAdamW steps the model's whole flat parameter buffer: pass model.parameters() "
+                                   "(all of them, in order); for a subset use torch.optim.AdamW")
         self._m = self._v = None
         self._step = 0
+        self.grad_scale = 1.0   # multiplied into the gradient inside the kernel (GradReducer sets 1/world for SUM reductions)
+
+    def _flat_grad_checked(self, model, params):
+        """the flat gradient buffer, after making sure it really holds this step's gradients: every p.grad must be the
+        parameter's view of it (what backward writes with model.direct_grad); a gradient that lives elsewhere (autograd-
+        returned with direct_grad=False, or assigned by the user) is copied in."""
+        g = model.flat_grads()
+        for p, gv in zip(params, model._grad_views):
+            if not p.requires_grad:
+                raise MuseHipError("FusedAdamW steps the whole flat buffer: a frozen parameter (requires_grad=False) is not supported")
+            if p.grad.data_ptr() != gv.data_ptr():
+                if p.grad.shape != gv.shape:
+                    raise MuseHipError("FusedAdamW: gradient shape differs from its parameter")
+                gv.copy_(p.grad)
+                p.grad = gv
+        return g
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -81,21 +104,34 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._model is None:
             return self._step_per_tensor(grp, loss)
         model = self._model()
+        if model is None:
+            raise MuseHipError("FusedAdamW: the model that owned these parameters is gone")
+        if not model._flat_ok():
+            raise MuseHipError("FusedAdamW: the model's flat parameter buffer was rebuilt (model.to(...) / load after the "
+                               "optimizer was created is fine, replacing p.data is not)")
         flat = model.flat_params()
         if any(p.grad is None for p in grp["params"]):
-            return loss  # nothing to do before the first backward (torch skips None grads)
-        g = model.flat_grads()
-        if self._m is None or self._m.device != flat.device:
-            self._m = torch.zeros_like(flat)
-            self._v = torch.zeros_like(flat)
+            if all(p.grad is None for p in grp["params"]):
+                return loss  # nothing to do before the first backward (torch skips None grads)
+            raise MuseHipError("FusedAdamW: some parameters have no gradient; the flat step needs all of them")
+        g = self._flat_grad_checked(model, grp["params"])
+        self._ensure_flat_state(flat)
         self._step += 1
         lr = float(grp["lr"])
         shadow = model._flat_c if model._flat_c is not None and model._flat_c.device == flat.device else None
         ops.adamw_flat(flat, g, self._m, self._v, shadow, lr, grp["betas"][0], grp["betas"][1], grp["eps"],
-                       grp["weight_decay"], self._step)
-        model._shadow_fresh = shadow is not None
-        model._shadow_version += 1   # transposed weight copies (dgrad) are rebuilt from the refreshed shadow
+                       grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
+        model._note_shadow_refreshed(shadow is not None)
         return loss
+
+    def _ensure_flat_state(self, flat):
+        if self._m is None:
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
+        elif self._m.device != flat.device:       # the model moved after the state was created / loaded: follow it
+            self._m, self._v = self._m.to(flat.device), self._v.to(flat.device)
+        if self._m.shape != flat.shape:
+            raise MuseHipError("FusedAdamW: optimizer state does not match the model's flat parameter buffer")
 
     def _step_per_tensor(self, grp, loss):
         """parameters that are ordinary (contiguous f32) tensors: muse_adamw_flat once per tensor.  torch.optim.AdamW
@@ -111,32 +147,76 @@ class FusedAdamW(torch.optim.Optimizer):
             if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                 raise MuseHipError("FusedAdamW: parameters and gradients must be contiguous float32 tensors")
             k = id(p)
-            if k not in self._m or self._m[k].device != p.device:
+            if k not in self._m:
                 self._m[k] = torch.zeros_like(p)
                 self._v[k] = torch.zeros_like(p)
+            elif self._m[k].device != p.device:
+                self._m[k], self._v[k] = self._m[k].to(p.device), self._v[k].to(p.device)
             ops.adamw_flat(p.data, p.grad, self._m[k], self._v[k], None, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
-                           grp["eps"], grp["weight_decay"], self._step)
+                           grp["eps"], grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
         return loss
 
+    # ---- checkpointing in torch.optim.AdamW's layout ----------------------------------------------------------------
     def state_dict(self):
-        groups = [{k: v for k, v in self.param_groups[0].items() if k != "params"}]
-        if self._model is None:   # per-tensor mode: moments in parameter order (None for a parameter that never had a gradient)
-            ps = self.param_groups[0]["params"]
-            m, v = self._m or {}, self._v or {}
-            return {"step": self._step, "exp_avg": [m.get(id(p)) for p in ps], "exp_avg_sq": [v.get(id(p)) for p in ps],
-                    "param_groups": groups}
-        return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v, "param_groups": groups}
+        ps = self.param_groups[0]["params"]
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(ps)))
+        state = {}
+        if self._step > 0 and self._m is not None:
+            stepv = torch.tensor(float(self._step))
+            if self._model is None:
+                for i, p in enumerate(ps):
+                    if id(p) in self._m:
+                        state[i] = {"step": stepv.clone(), "exp_avg": self._m[id(p)], "exp_avg_sq": self._v[id(p)]}
+            else:
+                model = self._model()
+                for i, (p, o) in enumerate(zip(ps, model._offsets)):
+                    n = p.numel()
+                    state[i] = {"step": stepv.clone(), "exp_avg": self._m[o:o + n].view(p.shape),
+                                "exp_avg_sq": self._v[o:o + n].view(p.shape)}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self._step = int(sd["step"])
-        if self._model is None:
-            ps = self.param_groups[0]["params"]
-            self._m = {id(p): t for p, t in zip(ps, sd["exp_avg"]) if t is not None}
-            self._v = {id(p): t for p, t in zip(ps, sd["exp_avg_sq"]) if t is not None}
-        else:
-            self._m = sd["exp_avg"]
-            self._v = sd["exp_avg_sq"]
-        self.param_groups[0].update(sd["param_groups"][0])
+        if "state" not in sd or "param_groups" not in sd:
+            raise MuseHipError("FusedAdamW.load_state_dict expects torch.optim's layout {'state', 'param_groups'}")
+        ps = self.param_groups[0]["params"]
+        grp = sd["param_groups"][0]
+        ids = list(grp.get("params", range(len(ps))))
+        if len(ids) != len(ps):
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+        self.param_groups[0].update({k: v for k, v in grp.items() if k != "params"})
+        state = {ids.index(k) if k in ids else k: v for k, v in sd["state"].items()}
+        steps = {int(float(v["step"])) for v in state.values()}
+        if len(steps) > 1:
+            raise MuseHipError("FusedAdamW keeps one step count for all parameters; the checkpoint has several")
+        self._step = steps.pop() if steps else 0
+        if not state:
+            self._m = self._v = None
+            return
+        model = self._model() if self._model is not None else None
+        if model is None:
+            self._m, self._v = {}, {}
+            for i, st in state.items():
+                p = ps[i]
+                for name, store in (("exp_avg", self._m), ("exp_avg_sq", self._v)):
+                    t = st[name]
+                    if tuple(t.shape) != tuple(p.shape):
+                        raise ValueError(f"FusedAdamW.load_state_dict: {name} of parameter {i} has shape {tuple(t.shape)}, "
+                                         f"expected {tuple(p.shape)}")
+                    store[id(p)] = t.detach().to(device=p.device, dtype=torch.float32).contiguous().clone()
+            return
+        if len(state) != len(ps):
+            raise MuseHipError("FusedAdamW (flat): the checkpoint must carry state for every parameter")
+        flat = model.flat_params()
+        self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+        for i, (p, o) in enumerate(zip(ps, model._offsets)):
+            n = p.numel()
+            for name, buf in (("exp_avg", self._m), ("exp_avg_sq", self._v)):
+                t = state[i][name]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError(f"FusedAdamW.load_state_dict: {name} of parameter {i} has shape {tuple(t.shape)}, "
+                                     f"expected {tuple(p.shape)}")
+                buf[o:o + n].view(p.shape).copy_(t.detach().to(device=flat.device, dtype=torch.float32))
 
 
 class GradReducer:
@@ -144,16 +224,24 @@ class GradReducer:
     contiguous buckets (default 64 MiB; xGMI rings are per-link bound, so few large messages) as soon as backward has
     finished writing them, on a side stream, while backward keeps computing earlier layers.
 
+    The mean is taken by the collective itself (`ReduceOp.AVG`, one pass) on RCCL; on gloo (CPU tests), which has no
+    AVG, the bucket is pre-scaled.  `grad_dtype=torch.bfloat16` sends each bucket as bf16 (half the xGMI bytes:
+    SURVEY.md section 5 sizes config B at 1.5 ms instead of 3.0 ms per step) and expands the reduced bucket back to f32.
+
     torch.distributed's "nccl" backend is RCCL on ROCm; on CPU tensors (gloo) the same logic runs synchronously, which
     is how the world_size-2 tests cover it."""
 
-    def __init__(self, model, process_group=None, bucket_bytes: int = 64 << 20, broadcast_params: bool = True):
+    def __init__(self, model, process_group=None, bucket_bytes: int = 64 << 20, broadcast_params: bool = True,
+                 grad_dtype=torch.float32):
         if not dist.is_initialized():
             raise MuseHipError("GradReducer needs an initialised torch.distributed process group")
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype must be torch.float32 or torch.bfloat16")
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.grad_dtype = grad_dtype
         self._hi = self._lo = None
         self._handles = []
         self._stream = None
@@ -161,7 +249,25 @@ class GradReducer:
         model.grad_ready_hook = self._on_ready
         if broadcast_params:
             dist.broadcast(model.flat_params(), src=0, group=process_group)  # DDP's constructor sync (:305)
-            model._shadow_fresh = False
+            model.mark_weights_changed()
+
+    def _reduce(self, g, on_gpu):
+        """mean over ranks of one bucket (in place)"""
+        if self.grad_dtype == torch.bfloat16:
+            c = ops.cast_to_bf16(g) if on_gpu else g.to(torch.bfloat16)
+            if on_gpu:
+                dist.all_reduce(c, op=dist.ReduceOp.AVG, group=self.pg)
+                ops.cast_to_f32(c, g)
+            else:   # gloo: no AVG and no bf16 arithmetic guarantee: reduce the bf16-rounded values in f32
+                c = c.to(torch.float32).mul_(1.0 / self.world)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.pg)
+                g.copy_(c)
+            return None
+        if on_gpu:
+            return dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+        g.mul_(1.0 / self.world)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+        return None
 
     def _launch(self, lo, hi):
         g = self.model.flat_grads()[lo:hi]
@@ -170,11 +276,11 @@ class GradReducer:
                 self._stream = torch.cuda.Stream(priority=-1)
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                g.mul_(1.0 / self.world)
-                self._handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                h = self._reduce(g, True)
+                if h is not None:
+                    self._handles.append(h)
         else:
-            g.mul_(1.0 / self.world)
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+            self._reduce(g, False)
 
     def _on_ready(self, begin: int, end: int):
         """backward reports finished [begin, end) ranges of the flat grad buffer, from the end of the buffer downward"""
@@ -199,6 +305,18 @@ class GradReducer:
         self._handles = []
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+
+    def reduce_metrics(self, loss, mask_prob):
+        """The two logged scalars of the reference's loop (`accelerator.gather(loss.repeat(bs)).mean()` and
+        `accelerator.gather(mask_prob.repeat(bs)).mean()`, train_maskgit_imagenet.py:430-431) as ONE 2-float all-reduce
+        instead of two all-gathers of bs and bs^2 floats.  -> (mean loss, mean mask rate) over all ranks."""
+        v = torch.stack([loss.detach().float().reshape(()), mask_prob.detach().float().mean()])
+        if v.is_cuda:
+            dist.all_reduce(v, op=dist.ReduceOp.AVG, group=self.pg)
+        else:
+            v.mul_(1.0 / self.world)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.pg)
+        return v[0], v[1]
 
 
 class TrainStep:

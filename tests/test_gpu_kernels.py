@@ -375,6 +375,59 @@ def test_fused_attention_fwd_bwd(B, S, nh, hd):
         assert e < 3e-2, (nm, e)
 
 
+@pytest.mark.parametrize("B,Sq,Skv,nh,hd", [(2, 256, 77, 2, 64), (1, 1024, 77, 2, 64), (2, 40, 130, 2, 48), (1, 1024, 1024, 2, 64),
+                                             (1, 600, 300, 1, 48), (2, 256, 256, 3, 32), (1, 1025, 1025, 1, 16), (2, 50, 7, 2, 64)])
+def test_fused_attention_general_lengths(B, Sq, Skv, nh, hd):
+    """separate q / k / v with their own row strides (cross-attention against 77 text tokens, seq 1024 with K/V streamed
+    through LDS in 256-key tiles and an online softmax, lengths that end inside a tile) vs the f64 evaluation"""
+    ops = _ops()
+    H = nh * hd
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+    qp = rnd((B * Sq, H + 8), 120, 1.0).to(torch.bfloat16)            # q rows padded: stride H + 8
+    kvp = rnd((B * Skv, 2 * H), 121, 1.0).to(torch.bfloat16)          # k | v packed
+    dctx = rnd((B * Sq, H), 122).to(torch.bfloat16)
+    qd = qp[:, :H].double().view(B, Sq, nh, hd).transpose(1, 2).requires_grad_(True)
+    kd = kvp[:, :H].double().view(B, Skv, nh, hd).transpose(1, 2).requires_grad_(True)
+    vd = kvp[:, H:].double().view(B, Skv, nh, hd).transpose(1, 2).requires_grad_(True)
+    sc = qd @ kd.transpose(-1, -2) * alpha
+    ref = (torch.softmax(sc, dim=-1) @ vd).transpose(1, 2).reshape(B * Sq, H)
+    ref.backward(dctx.double())
+    qg, kvg = qp.to(DEV), kvp.to(DEV)
+    ctx, lse = ops.attention_fwd_ex(qg[:, :H], kvg[:, :H], kvg[:, H:], B, Sq, Skv, nh, hd, alpha)
+    assert rel_err(ctx.float(), ref.detach()) < 1.5e-2
+    assert rel_err(lse[:, :Sq], torch.logsumexp(sc, dim=-1).reshape(B * nh, Sq).detach()) < 1e-5
+    dkv = torch.full((B * Skv, 2 * H), 7.0, dtype=torch.bfloat16, device=DEV)
+    dq, dk, dv = ops.attention_bwd_ex(qg[:, :H], kvg[:, :H], kvg[:, H:], ctx, dctx.to(DEV), lse, B, Sq, Skv, nh, hd, alpha,
+                                      dk=dkv[:, :H], dv=dkv[:, H:])
+    for got, want, nm in ((dq, qd.grad, "q"), (dkv[:, :H], kd.grad, "k"), (dkv[:, H:], vd.grad, "v")):
+        want = want.transpose(1, 2).reshape(got.shape)
+        e = rel_err(got.float(), want)
+        assert e < 3e-2, (nm, e)
+
+
+def test_fused_attention_extreme_scores():
+    """rows whose scores are all very negative / whose maximum sits in a late K/V tile (the online-softmax rescale path), and a
+    head with one dominant key: no NaN / inf, results match f64"""
+    ops = _ops()
+    B, S, nh, hd = 1, 600, 1, 64
+    alpha = 0.125
+    q = rnd((S, hd), 130, 1.0)
+    k = rnd((S, hd), 131, 1.0)
+    v = rnd((S, hd), 132, 1.0)
+    u = torch.ones(hd) / math.sqrt(hd)
+    k += 4.0 * u                              # every key shares a component along u ...
+    q[5] = -200.0 * u                         # ... so row 5's scaled scores are all about -100 +- 25
+    k[550] = 6.0 * q[7].sign()                # key 550 (third K/V tile) dominates row 7
+    k[3] = 20.0 * q[9].sign()                 # key 3 dominates row 9 by a huge margin
+    qb, kb, vb = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    sc = qb.double() @ kb.double().t() * alpha
+    ref = torch.softmax(sc, -1) @ vb.double()
+    ctx, lse = ops.attention_fwd_ex(qb.to(DEV), kb.to(DEV), vb.to(DEV), B, S, S, nh, hd, alpha)
+    assert torch.isfinite(ctx.float()).all() and torch.isfinite(lse[:, :S]).all()
+    assert rel_err(ctx.float(), ref) < 1.5e-2
+    assert rel_err(lse[:, :S], torch.logsumexp(sc, -1).view(1, S)) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_split_k_wgrad(dtype):
     """weight-gradient shape: short M,N, long K, k-major operands, K cut in slices summed with f32 atomics"""

@@ -271,8 +271,6 @@ def test_uvit_generate2(golden_dir):
     assert torch.equal(ids[:, :5], given[:, :5]) and int(ids.max()) < cfg["codebook_size"]
 
 
-@pytest.mark.skipif(os.environ.get("MUSE_TEST_UNVERIFIED", "0") != "1",
-                    reason="written after the round's GPU budget was spent: not yet run on hardware (enable with MUSE_TEST_UNVERIFIED=1)")
 def test_uvit_train_step_with_fused_adamw(golden_dir):
     """FusedAdamW on a model without a flat parameter buffer: one muse_adamw_flat launch per tensor == torch.optim.AdamW"""
     import muse
@@ -297,8 +295,6 @@ def test_uvit_train_step_with_fused_adamw(golden_dir):
         assert rel_err(p, q) < 1e-5, name
 
 
-@pytest.mark.skipif(os.environ.get("MUSE_TEST_UNVERIFIED", "0") != "1",
-                    reason="written after the round's GPU budget was spent: not yet run on hardware (enable with MUSE_TEST_UNVERIFIED=1)")
 def test_uvit_bf16_mode_vs_reference_golden(golden_dir):
     """set_compute_dtype(torch.bfloat16): weight-GEMM operands rounded to bf16 (f32 accumulate / outputs), everything else f32.
     Expected from a CPU emulation of the same rounding: logits 8e-3, loss 1.3e-4, gradients <= 2.5e-2 (relative to max)."""
