@@ -76,31 +76,38 @@ __device__ __forceinline__ FragHD<HD> frag_global(rsrc_t rs, unsigned ld_bytes, 
   }
   return r;
 }
+// head_dim 48 / 16: a K = 16 MFMA and a K = 32 MFMA must not be chained back to back through SrcC, in either order: ROCm 7.2
+// emits them with no wait states in between and gfx950 then returns wrong sums (found by the parity tests on MI355X; the
+// hazard tables the compiler consults evidently do not cover the mixed pair).  ATT_TAIL_MODE 1 (default): K = 32 step(s)
+// first, 16 wait states, then the K = 16 step accumulates onto the result; 2: separate accumulator + VALU add (VALU is the
+// busier pipe of these kernels: 5-7 % slower backward); 3: K = 16 first - WRONG on hardware, kept only as the reproducer.
 #ifndef ATT_TAIL_MODE
-#define ATT_TAIL_MODE 2
+#define ATT_TAIL_MODE 1
 #endif
 template <int HD>
 __device__ __forceinline__ f32x4 mma_hd(const FragHD<HD>& a, const FragHD<HD>& b, f32x4 acc) {
   using C = HeadCfg<HD>;
-#pragma unroll
-  for (int ks = 0; ks < C::N32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.f[ks], b.f[ks], acc, 0, 0, 0);
-  if constexpr (C::TAIL) {
+  if constexpr (C::TAIL && C::N32 > 0) {
     const s16x4 at = __builtin_bit_cast(s16x4, a.t), bt = __builtin_bit_cast(s16x4, b.t);
-#if ATT_TAIL_MODE == 0
+#if ATT_TAIL_MODE == 3
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, acc, 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < C::N32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.f[ks], b.f[ks], acc, 0, 0, 0);
 #elif ATT_TAIL_MODE == 1
-    if constexpr (C::N32 > 0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
+#pragma unroll
+    for (int ks = 0; ks < C::N32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.f[ks], b.f[ks], acc, 0, 0, 0);
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
     acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, acc, 0, 0, 0);
 #else
-    // the K = 16 step accumulates into its own registers: a K = 16 MFMA chained onto a K = 32 MFMA's result through SrcC
-    // returned wrong sums on gfx950 (ROCm 7.2 emits the two back to back with no wait states)
-    if constexpr (C::N32 > 0) {
-      const f32x4 tl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      acc += tl;
-    } else {
-      acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, acc, 0, 0, 0);
-    }
+#pragma unroll
+    for (int ks = 0; ks < C::N32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.f[ks], b.f[ks], acc, 0, 0, 0);
+    acc += __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at, bt, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #endif
+  } else if constexpr (C::TAIL) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a.t), __builtin_bit_cast(s16x4, b.t), acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < C::N32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.f[ks], b.f[ks], acc, 0, 0, 0);
   }
   return acc;
 }
@@ -184,6 +191,7 @@ struct AttnParams {
   int nh, sq, skv, sqp;
   int nchunk, chunk_rows;                  // stationary rows per workgroup (multiple of 16)
   int tile_rows, ntile;                    // streamed rows per LDS tile (multiple of 32), number of tiles
+  int shared;                              // 1: the workgroup's last stationary tile is split over all waves (see below)
   float alpha;
 };
 
@@ -194,25 +202,93 @@ __device__ __forceinline__ int xcd_remap() {
 }
 
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1e30f;   // "minus infinity" that survives an MFMA accumulate and an fma without producing NaN
+
+// Work balance.  A head with 257 tokens has 17 16-row tiles; 8 waves would do 3,2,2,... of them.  Instead every wave takes
+// floor(tiles / NW) whole tiles and the one left over ("shared" tile) is split over all NW waves along the STREAMED dimension
+// (wave w takes the 32-row pairs w, w + NW, ...); the per-wave partial results meet in LDS (the K/V or Q/dO images are dead
+// by then and provide the space) and wave 0 combines them: softmax partials by the usual (max, sum, O) merge, gradient
+// partials by plain addition.
 
 // =================================================================================================================
 // forward: out[b, q, h, :] = softmax(alpha * Q K^T) V ; lse[b*nh + h, q] = log sum exp of the scaled scores
 // =================================================================================================================
-// MAXT = 16-key tiles per streamed K/V tile (the LDS images always hold MAXT * 16 rows; rows past the sequence end are zeros).
-// Keys past the sequence end are masked through the MFMA's C operand (-1e30 instead of 0), which costs nothing for the
-// tiles that cannot contain the end: with FULL = false only the last two 16-key tiles of a K/V tile can (the host picks
-// MAXT = 2 * ceil(S_kv / 32) for one-tile problems and S_kv % 256 == 0 or > 224 for streamed ones), FULL = true masks every tile.
+template <int HD> struct FwdAcc {
+  float m;                          // running row maximum of the raw scores
+  f32x4 l;                          // running row sum of P (all four entries equal: it comes out of an MFMA against ones)
+  f32x4 o[HeadCfg<HD>::ND];         // running P V
+};
+
+// One online-softmax update over TN consecutive 16-key tiles starting at tile t0 of the LDS images (TN even):
+// scores (keys at tile index >= MASK_FROM within the step get the -1e30 init where they lie past the sequence end),
+// row max, rescale, P = exp2(...), O += P V and l += P 1 (the row sum as one more MFMA against a ones operand: VALU is the
+// busy pipe of this kernel, the matrix pipe has room).
+template <int HD, int TN, int MASK_FROM>
+__device__ __forceinline__ void fwd_substep(const unsigned char* Kimg, const unsigned char* Vimg, int t0, const FragHD<HD>& qf,
+                                            float c, int kvalid, FwdAcc<HD>& A, int lane) {
+  using C = HeadCfg<HD>;
+  f32x4 sacc[TN];
+  float mt = NEG_BIG;
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    f32x4 ci = {0.f, 0.f, 0.f, 0.f};
+    if (u >= MASK_FROM) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ci[r] = (16 * (t0 + u) + r < kvalid) ? 0.f : NEG_BIG;
+    }
+    sacc[u] = mma_hd<HD>(frag_lds<HD>(Kimg, (t0 + u) * 16, lane), qf, ci);
+    mt = fmaxf(mt, fmaxf(fmaxf(sacc[u][0], sacc[u][1]), fmaxf(sacc[u][2], sacc[u][3])));
+  }
+  mt = quad_g_max(mt);
+  const float mn = fmaxf(A.m, mt);
+  const float scale = __builtin_amdgcn_exp2f((A.m - mn) * c);   // 0 on the first step (m = -1e30: exp2(-huge) = 0)
+  const float mc = mn * c;
+  A.m = mn;
+#pragma unroll
+  for (int u = 0; u < TN; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sacc[u][r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc));
+  A.l *= scale;
+#pragma unroll
+  for (int d = 0; d < C::ND; ++d) A.o[d] *= scale;
+  const s16x4 one4 = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  union { s16x4 h[2]; bf16x8 v; } ones;
+  ones.h[0] = one4; ones.h[1] = one4;
+#pragma unroll
+  for (int s = 0; s < TN / 2; ++s) {
+    const bf16x8 pb = pack8(sacc[2 * s], sacc[2 * s + 1]);
+    A.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pb, A.l, 0, 0, 0);
+#pragma unroll
+    for (int d = 0; d < C::ND; ++d)
+      A.o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Vimg, 16 * t0 + 32 * s, 16 * d, lane), pb, A.o[d], 0, 0, 0);
+  }
+}
+
+template <int HD>
+__device__ __forceinline__ void fwd_reset(FwdAcc<HD>& A) {
+  A.m = NEG_BIG;
+  A.l = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < HeadCfg<HD>::ND; ++d) A.o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // waves per SIMD to keep the register allocation to: what `blocks` co-resident workgroups of NW waves need (2 by LDS where they fit)
 constexpr int fwd_waves_per_simd(int hd_rs, int maxt, int nw) {
   const int lds = 2 * maxt * 16 * hd_rs;
   const int blocks = 163840 / lds >= 2 ? 2 : 1;
   return (blocks * nw + 3) / 4;
 }
+
+// MAXT = 16-key tiles per streamed K/V tile (the LDS images always hold MAXT * 16 rows; rows past the sequence end are zeros).
+// Keys past the sequence end are masked through the MFMA's C operand (-1e30 instead of 0), which costs nothing for the
+// tiles that cannot contain the end: with FULL = false only the last two 16-key tiles of a K/V tile can (the host picks
+// MAXT = 2 * ceil(S_kv / 32) for one-tile problems and S_kv % 256 == 0 or > 224 for streamed ones), FULL = true masks every tile.
 template <int HD, int MAXT, int NW, bool FULL>
 __global__ __launch_bounds__(NW * 64, fwd_waves_per_simd(HeadCfg<HD>::RS, MAXT, NW)) void attn_fwd_kernel(const AttnParams P) {
   using C = HeadCfg<HD>;
   constexpr int NT = NW * 64;
   constexpr int ROWS = MAXT * 16;
+  constexpr int CT = 6;                     // 16-key tiles per online-softmax step (register budget)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + ROWS * C::RS;
@@ -229,94 +305,86 @@ __global__ __launch_bounds__(NW * 64, fwd_waves_per_simd(HeadCfg<HD>::RS, MAXT, 
   const int q_end = min(P.sq, q_begin + P.chunk_rows);
   const int ntq = (q_end - q_begin + 15) >> 4;
 
-  // per-q-tile state (streamed K/V: carried across the tiles; one tile: a single pass)
   FragHD<HD> qf;
-  float m = -INFINITY, l = 0.f;
-  f32x4 oacc[C::ND];
+  FwdAcc<HD> A;
 
-  // scores of this wave's q-tile against the LDS tile in sub-steps of CT 16-key tiles, each an online-softmax update
-  // (m, l, O rescale) followed by O += P V: keeps ~CT*4 score registers live instead of MAXT*4
-  constexpr int CT = 6;
-  auto step = [&](int kv0) {
+  auto step = [&](int kv0) {   // this wave's q-tile against the whole LDS tile
     const int kvalid = P.skv - kv0 - 4 * g;   // this lane's keys kv0 + 16 t + 4 g + r are real iff 16 t + r < kvalid
 #pragma unroll
     for (int t0 = 0; t0 < MAXT; t0 += CT) {
-      if (t0) __builtin_amdgcn_sched_barrier(0);   // keep the next sub-step's LDS reads from being hoisted over this one (registers)
-      const int tn = (MAXT - t0) < CT ? (MAXT - t0) : CT;   // compile-time after unrolling
-      f32x4 sacc[CT];
-      float mt = -INFINITY;
-#pragma unroll
-      for (int u = 0; u < CT; ++u) {
-        if (u < tn) {
-          const int t = t0 + u;
-          f32x4 ci = {0.f, 0.f, 0.f, 0.f};
-          if (FULL || t >= MAXT - 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ci[r] = (16 * t + r < kvalid) ? 0.f : -1e30f;
-          }
-          sacc[u] = mma_hd<HD>(frag_lds<HD>(Kimg, t * 16, lane), qf, ci);
-          mt = fmaxf(mt, fmaxf(fmaxf(sacc[u][0], sacc[u][1]), fmaxf(sacc[u][2], sacc[u][3])));
-        }
-      }
-      mt = quad_g_max(mt);
-      const float mn = fmaxf(m, mt);
-      const float scale = __builtin_amdgcn_exp2f((m - mn) * c);   // 0 on the first sub-step (m = -inf)
-      const float mc = mn * c;
-      m = mn;
-      float ps = 0.f;
-#pragma unroll
-      for (int u = 0; u < CT; ++u) {
-        if (u < tn) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { sacc[u][r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], c, -mc)); ps += sacc[u][r]; }
-        }
-      }
-      l = l * scale + ps;
-#pragma unroll
-      for (int d = 0; d < C::ND; ++d) oacc[d] *= scale;
-#pragma unroll
-      for (int s = 0; s < CT / 2; ++s) {
-        if (2 * s < tn) {
-          const bf16x8 pb = pack8(sacc[2 * s], sacc[2 * s + 1]);
-#pragma unroll
-          for (int d = 0; d < C::ND; ++d)
-            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Vimg, 16 * t0 + 32 * s, 16 * d, lane), pb, oacc[d], 0, 0, 0);
-        }
+      if (t0) __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads from being hoisted over this one (registers)
+      if (MAXT - t0 >= CT) {
+        if (FULL) fwd_substep<HD, CT, 0>(Kimg, Vimg, t0, qf, c, kvalid, A, lane);
+        else if (MAXT - t0 == CT) fwd_substep<HD, CT, CT - 2>(Kimg, Vimg, t0, qf, c, kvalid, A, lane);
+        else fwd_substep<HD, CT, CT>(Kimg, Vimg, t0, qf, c, kvalid, A, lane);   // (MAXT and CT even: the end cannot be in here)
+      } else {
+        constexpr int TN = MAXT % CT ? MAXT % CT : 2;
+        fwd_substep<HD, TN, FULL ? 0 : TN - 2>(Kimg, Vimg, t0, qf, c, kvalid, A, lane);
       }
     }
   };
-  auto begin_tile = [&](const FragHD<HD>& qnext) {
-    qf = qnext;
-    m = -INFINITY; l = 0.f;
-#pragma unroll
-    for (int d = 0; d < C::ND; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto finish_tile = [&](int qt) {
+  auto finish = [&](int qt) {   // normalise and store this wave's q-tile
     const int q = q_begin + qt * 16 + (lane & 15);
-    const float lsum = quad_g_sum(l);
     if (q < q_end) {
-      const float inv = 1.0f / lsum;
+      const float inv = 1.0f / A.l[0];
       bf16_t* o = P.out + b * P.bo + (long)q * P.ldo + h * HD + 4 * g;
 #pragma unroll
-      for (int d = 0; d < C::ND; ++d) store4_bf16(o + 16 * d, oacc[d], inv);
-      if (g == 0) P.lse[(long)bh * P.sqp + q] = m * P.alpha + __logf(lsum);
+      for (int d = 0; d < C::ND; ++d) store4_bf16(o + 16 * d, A.o[d], inv);
+      if (g == 0) P.lse[(long)bh * P.sqp + q] = A.m * P.alpha + __logf(A.l[0]);
     }
   };
 
   if (P.ntile == 1) {
-    FragHD<HD> qn = frag_global<HD>(rq, ldq_b, q_begin + wave * 16, lane);   // in flight under the K/V fetch
+    const int nfull = P.shared ? ntq - 1 : ntq;                               // tiles handled whole, wave-strided
+    FragHD<HD> qn = frag_global<HD>(rq, ldq_b, q_begin + wave * 16, lane);    // in flight under the K/V fetch
     load_tile<HD, NT, ROWS>(Kimg, rk, ldk_b, 0, ROWS);
     load_tile<HD, NT, ROWS>(Vimg, rv, ldv_b, 0, ROWS);
     __syncthreads();
-    for (int qt = wave; qt < ntq; qt += NW) {
-      begin_tile(qn);
-      qn = frag_global<HD>(rq, ldq_b, q_begin + (qt + NW) * 16, lane);     // next tile's Q (rows past the end read as zeros)
+    for (int qt = wave; qt < nfull; qt += NW) {
+      qf = qn;
+      const int nxt = qt + NW < nfull ? qt + NW : ntq - 1;                    // next whole tile, or the shared one
+      qn = frag_global<HD>(rq, ldq_b, q_begin + nxt * 16, lane);
+      fwd_reset<HD>(A);
       step(0);
-      finish_tile(qt);
+      finish(qt);
+    }
+    if (P.shared) {   // wave w: key pairs w, w + NW, ... of the last q-tile, then merge through LDS
+      const int qs = ntq - 1;
+      qf = nfull > wave ? qn : frag_global<HD>(rq, ldq_b, q_begin + qs * 16, lane);
+      fwd_reset<HD>(A);
+      const int kvalid = P.skv - 4 * g;
+      for (int s = wave; s < MAXT / 2; s += NW) fwd_substep<HD, 2, 0>(Kimg, Vimg, 2 * s, qf, c, kvalid, A, lane);
+      __syncthreads();                                   // every wave is done with the K / V images
+      constexpr int PW = HD + 2;                         // floats per (wave, row): O | m | l
+      float* part = (float*)smem;
+      float* mine = part + ((wave * 16 + (lane & 15)) * PW);
+#pragma unroll
+      for (int d = 0; d < C::ND; ++d) *(f32x4*)(mine + 16 * d + 4 * g) = A.o[d];
+      if (g == 0) { mine[HD] = A.m; mine[HD + 1] = A.l[0]; }
+      __syncthreads();
+      if (wave == 0) {
+        float mg = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mg = fmaxf(mg, part[(w * 16 + (lane & 15)) * PW + HD]);
+        fwd_reset<HD>(A);
+        A.m = mg;
+        float lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const float* pw = part + (w * 16 + (lane & 15)) * PW;
+          const float f = __builtin_amdgcn_exp2f((pw[HD] - mg) * c);
+          lsum = fmaf(pw[HD + 1], f, lsum);
+#pragma unroll
+          for (int d = 0; d < C::ND; ++d) A.o[d] += *(const f32x4*)(pw + 16 * d + 4 * g) * f;
+        }
+        A.l = f32x4{lsum, lsum, lsum, lsum};
+        finish(qs);
+      }
     }
   } else {   // one q-tile per wave (chunk_rows == NW * 16), state carried over the streamed K/V tiles
     const bool active = wave < ntq;
-    begin_tile(frag_global<HD>(rq, ldq_b, q_begin + wave * 16, lane));
+    qf = frag_global<HD>(rq, ldq_b, q_begin + wave * 16, lane);
+    fwd_reset<HD>(A);
     for (int j = 0; j < P.ntile; ++j) {
       const int kv0 = j * ROWS;
       if (j) __syncthreads();
@@ -325,7 +393,7 @@ __global__ __launch_bounds__(NW * 64, fwd_waves_per_simd(HeadCfg<HD>::RS, MAXT, 
       __syncthreads();
       if (active) step(kv0);
     }
-    if (active) finish_tile(wave);
+    if (active) finish(wave);
   }
 }
 
@@ -333,6 +401,33 @@ __global__ __launch_bounds__(NW * 64, fwd_waves_per_simd(HeadCfg<HD>::RS, MAXT, 
 // backward, part 1: dQ (+ the softmax-backward row constant dsum[q] = sum_d dO[q,d] O[q,d], written for part 2).
 // Each wave owns 16-query tiles and walks the keys in pairs of 16-key tiles.
 // =================================================================================================================
+// one 32-key pair: dS for the wave's q-tile, acc += dS K.  MASK: keys past the sequence end (only the last pair of the last
+// streamed tile can hold them) get the -1e30 score init, so P = 0 there.
+template <int HD, bool MASK>
+__device__ __forceinline__ void dq_pair(const unsigned char* Kimg, const unsigned char* Vimg, int s, const FragHD<HD>& qf,
+                                        const FragHD<HD>& df, float c, float lq2, float dsq, int kvalid,
+                                        f32x4 (&acc)[HeadCfg<HD>::ND], int lane) {
+  using C = HeadCfg<HD>;
+  f32x4 dsv[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int k0 = 32 * s + 16 * half;
+    f32x4 ci = {0.f, 0.f, 0.f, 0.f};
+    if (MASK) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ci[r] = (k0 + r < kvalid) ? 0.f : NEG_BIG;
+    }
+    const f32x4 sa = mma_hd<HD>(frag_lds<HD>(Kimg, k0, lane), qf, ci);
+    const f32x4 dp = mma_hd<HD>(frag_lds<HD>(Vimg, k0, lane), df, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dsv[half][r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c, -lq2)) * (dp[r] - dsq);
+  }
+  const bf16x8 dsb = pack8(dsv[0], dsv[1]);
+#pragma unroll
+  for (int d = 0; d < C::ND; ++d)
+    acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Kimg, 32 * s, 16 * d, lane), dsb, acc[d], 0, 0, 0);
+}
+
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams P) {
   using C = HeadCfg<HD>;
@@ -354,7 +449,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams P
   const int q_begin = chunk * P.chunk_rows;
   const int q_end = min(P.sq, q_begin + P.chunk_rows);
   const int ntq = (q_end - q_begin + 15) >> 4;
-  const bool multi = P.ntile > 1;
 
   FragHD<HD> qf, df;
   float lq2 = 0.f, dsq = 0.f;   // lse * log2(e), dsum of this lane's query
@@ -371,37 +465,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams P
     t.l = q < q_end ? P.lse[(long)bh * P.sqp + q] : 0.f;
     return t;
   };
-  auto begin_tile = [&](int qt, const QIn& t) {
+  auto begin_tile = [&](int qt, const QIn& t, bool write_dsum) {
     qf = t.q; df = t.d;
     const int q = q_begin + qt * 16 + (lane & 15);
     dsq = quad_g_sum(dot_hd<HD>(t.d, t.o));
     lq2 = t.l * LOG2E;
-    if (q < q_end && g == 0) P.dsum[(long)bh * P.sqp + q] = dsq;
+    if (write_dsum && q < q_end && g == 0) P.dsum[(long)bh * P.sqp + q] = dsq;
 #pragma unroll
     for (int d = 0; d < C::ND; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto step = [&](int qt, int kv0, int npair) {
-    const bool qok = (q_begin + qt * 16 + (lane & 15)) < q_end;
-    for (int s = 0; s < npair; ++s) {
-      f32x4 dsv[2];
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int k0 = 32 * s + 16 * half;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sa = mma_hd<HD>(frag_lds<HD>(Kimg, k0, lane), qf, sa);
-        dp = mma_hd<HD>(frag_lds<HD>(Vimg, k0, lane), df, dp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = qok && (kv0 + k0 + 4 * g + r) < P.skv;
-          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], c, -lq2)) : 0.f;
-          dsv[half][r] = p * (dp[r] - dsq);
-        }
-      }
-      const bf16x8 dsb = pack8(dsv[0], dsv[1]);
-#pragma unroll
-      for (int d = 0; d < C::ND; ++d)
-        acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Kimg, 32 * s, 16 * d, lane), dsb, acc[d], 0, 0, 0);
-    }
+  auto step = [&](int kv0, int npair) {   // all pairs of the LDS tile; only the last one can hold the sequence end
+    const int kvalid = P.skv - kv0 - 4 * g;
+    for (int s = 0; s < npair - 1; ++s) dq_pair<HD, false>(Kimg, Vimg, s, qf, df, c, lq2, dsq, kvalid, acc, lane);
+    dq_pair<HD, true>(Kimg, Vimg, npair - 1, qf, df, c, lq2, dsq, kvalid, acc, lane);
   };
   auto finish_tile = [&](int qt) {
     const int q = q_begin + qt * 16 + (lane & 15);
@@ -412,21 +488,41 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams P
     }
   };
 
-  if (!multi) {
-    const int rows = P.tile_rows;
-    QIn tn = fetch_tile(wave);   // in flight under the K/V fetch
+  if (P.ntile == 1) {
+    const int rows = P.tile_rows, npair = rows >> 5;
+    const int nfull = P.shared ? ntq - 1 : ntq;
+    QIn tn = fetch_tile(wave < nfull ? wave : ntq - 1);   // in flight under the K/V fetch
     load_tile<HD, NT, 288>(Kimg, rk, ldk_b, 0, rows);
     load_tile<HD, NT, 288>(Vimg, rv, ldv_b, 0, rows);
     __syncthreads();
-    for (int qt = wave; qt < ntq; qt += NW) {
-      begin_tile(qt, tn);
-      tn = fetch_tile(qt + NW);
-      step(qt, 0, rows >> 5);
+    for (int qt = wave; qt < nfull; qt += NW) {
+      begin_tile(qt, tn, true);
+      tn = fetch_tile(qt + NW < nfull ? qt + NW : ntq - 1);
+      step(0, npair);
       finish_tile(qt);
+    }
+    if (P.shared) {   // wave w: key pairs w, w + NW, ... of the last q-tile; partial dQ summed through LDS
+      const int qs = ntq - 1;
+      begin_tile(qs, tn, wave == 0);
+      const int kvalid = P.skv - 4 * g;
+      for (int s = wave; s < npair; s += NW) dq_pair<HD, true>(Kimg, Vimg, s, qf, df, c, lq2, dsq, kvalid, acc, lane);
+      __syncthreads();                                   // every wave is done with the K / V images
+      float* part = (float*)smem;
+      float* mine = part + (wave * 16 + (lane & 15)) * HD;
+#pragma unroll
+      for (int d = 0; d < C::ND; ++d) *(f32x4*)(mine + 16 * d + 4 * g) = acc[d];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+#pragma unroll
+          for (int d = 0; d < C::ND; ++d) acc[d] += *(const f32x4*)(part + (w * 16 + (lane & 15)) * HD + 16 * d + 4 * g);
+        finish_tile(qs);
+      }
     }
   } else {
     const bool active = wave < ntq;
-    begin_tile(wave, fetch_tile(wave));
+    begin_tile(wave, fetch_tile(wave), true);
     for (int j = 0; j < P.ntile; ++j) {
       const int kv0 = j * P.tile_rows;
       const int rows = min(P.tile_rows, (P.skv - kv0 + 31) & ~31);
@@ -434,7 +530,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams P
       load_tile<HD, NT, 288>(Kimg, rk, ldk_b, kv0, rows);
       load_tile<HD, NT, 288>(Vimg, rv, ldv_b, kv0, rows);
       __syncthreads();
-      if (active) step(wave, kv0, rows >> 5);
+      if (active) step(kv0, rows >> 5);
     }
     if (active) finish_tile(wave);
   }
@@ -442,8 +538,37 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams P
 
 // =================================================================================================================
 // backward, part 2: dK, dV.  Each wave owns 16-key tiles and walks the queries in pairs of 16-query tiles; the queries'
-// lse / dsum ride in LDS next to the Q and dO images.
+// lse / dsum ride in LDS next to the Q and dO images (lse = +1e30 for rows past the sequence end, so their P is 0: no
+// per-element masks in this kernel; key rows past the end only produce output rows that are never stored).
 // =================================================================================================================
+template <int HD>
+__device__ __forceinline__ void dkv_pair(const unsigned char* Qimg, const unsigned char* Dimg, const float* Limg, const float* Simg,
+                                         int s, const FragHD<HD>& kf, const FragHD<HD>& vf, float c,
+                                         f32x4 (&dk)[HeadCfg<HD>::ND], f32x4 (&dv)[HeadCfg<HD>::ND], int lane) {
+  using C = HeadCfg<HD>;
+  const int g = lane >> 4;
+  f32x4 pv[2], dsv[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r0 = 32 * s + 16 * half;
+    const f32x4 sa = mma_hd<HD>(frag_lds<HD>(Qimg, r0, lane), kf, f32x4{0.f, 0.f, 0.f, 0.f});
+    const f32x4 dp = mma_hd<HD>(frag_lds<HD>(Dimg, r0, lane), vf, f32x4{0.f, 0.f, 0.f, 0.f});
+    const f32x4 l4 = *(const f32x4*)(Limg + r0 + 4 * g);
+    const f32x4 d4 = *(const f32x4*)(Simg + r0 + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pv[half][r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c, -l4[r]));
+      dsv[half][r] = pv[half][r] * (dp[r] - d4[r]);
+    }
+  }
+  const bf16x8 pb = pack8(pv[0], pv[1]), dsb = pack8(dsv[0], dsv[1]);
+#pragma unroll
+  for (int d = 0; d < C::ND; ++d) {
+    dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Dimg, 32 * s, 16 * d, lane), pb, dv[d], 0, 0, 0);
+    dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Qimg, 32 * s, 16 * d, lane), dsb, dk[d], 0, 0, 0);
+  }
+}
+
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams P) {
   using C = HeadCfg<HD>;
@@ -466,7 +591,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
   const int k_begin = chunk * P.chunk_rows;
   const int k_end = min(P.skv, k_begin + P.chunk_rows);
   const int ntk = (k_end - k_begin + 15) >> 4;
-  const bool multi = P.ntile > 1;
   const float* lrow = P.lse + (long)bh * P.sqp;
   const float* drow = P.dsum + (long)bh * P.sqp;
 
@@ -478,7 +602,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
     load_tile<HD, NT, 288>(Dimg, rd, lddo_b, q0, rows);
     for (int i = threadIdx.x; i < rows; i += NT) {
       const bool ok = q0 + i < P.sq;
-      Limg[i] = ok ? lrow[q0 + i] * LOG2E : 0.f;
+      Limg[i] = ok ? lrow[q0 + i] * LOG2E : 1e30f;
       Simg[i] = ok ? drow[q0 + i] : 0.f;
     }
   };
@@ -494,34 +618,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
 #pragma unroll
     for (int d = 0; d < C::ND; ++d) { dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   };
-  auto step = [&](int kt, int q0, int npair) {
-    const bool key_ok = (k_begin + kt * 16 + (lane & 15)) < k_end;
-    for (int s = 0; s < npair; ++s) {
-      f32x4 pv[2], dsv[2];
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int r0 = 32 * s + 16 * half;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sa = mma_hd<HD>(frag_lds<HD>(Qimg, r0, lane), kf, sa);
-        dp = mma_hd<HD>(frag_lds<HD>(Dimg, r0, lane), vf, dp);
-        const f32x4 l4 = *(const f32x4*)(Limg + r0 + 4 * g);
-        const f32x4 d4 = *(const f32x4*)(Simg + r0 + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = key_ok && (q0 + r0 + 4 * g + r) < P.sq;
-          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], c, -l4[r])) : 0.f;
-          pv[half][r] = p;
-          dsv[half][r] = p * (dp[r] - d4[r]);
-        }
-      }
-      const bf16x8 pb = pack8(pv[0], pv[1]), dsb = pack8(dsv[0], dsv[1]);
-#pragma unroll
-      for (int d = 0; d < C::ND; ++d) {
-        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Dimg, 32 * s, 16 * d, lane), pb, dv[d], 0, 0, 0);
-        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_seq<HD>(Qimg, 32 * s, 16 * d, lane), dsb, dk[d], 0, 0, 0);
-      }
-    }
-  };
   auto finish_tile = [&](int kt) {
     const int key = k_begin + kt * 16 + (lane & 15);
     if (key < k_end) {
@@ -535,16 +631,43 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
     }
   };
 
-  if (!multi) {
-    const int rows = P.tile_rows;
-    KIn tn = fetch_tile(wave);   // in flight under the Q / dO fetch
+  if (P.ntile == 1) {
+    const int rows = P.tile_rows, npair = rows >> 5;
+    const int nfull = P.shared ? ntk - 1 : ntk;
+    KIn tn = fetch_tile(wave < nfull ? wave : ntk - 1);   // in flight under the Q / dO fetch
     load_q_tile(0, rows);
     __syncthreads();
-    for (int kt = wave; kt < ntk; kt += NW) {
+    for (int kt = wave; kt < nfull; kt += NW) {
       begin_tile(tn);
-      tn = fetch_tile(kt + NW);
-      step(kt, 0, rows >> 5);
+      tn = fetch_tile(kt + NW < nfull ? kt + NW : ntk - 1);
+      for (int s = 0; s < npair; ++s) dkv_pair<HD>(Qimg, Dimg, Limg, Simg, s, kf, vf, c, dk, dv, lane);
       finish_tile(kt);
+    }
+    if (P.shared) {   // wave w: query pairs w, w + NW, ... against the last key tile; partial dK, dV summed through LDS
+      const int ks = ntk - 1;
+      begin_tile(tn);
+      for (int s = wave; s < npair; s += NW) dkv_pair<HD>(Qimg, Dimg, Limg, Simg, s, kf, vf, c, dk, dv, lane);
+      __syncthreads();                                   // every wave is done with the Q / dO images
+      float* part = (float*)smem;
+      float* mine = part + (wave * 16 + (lane & 15)) * (2 * HD);
+#pragma unroll
+      for (int d = 0; d < C::ND; ++d) {
+        *(f32x4*)(mine + 16 * d + 4 * g) = dk[d];
+        *(f32x4*)(mine + HD + 16 * d + 4 * g) = dv[d];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          const float* pw = part + (w * 16 + (lane & 15)) * (2 * HD);
+#pragma unroll
+          for (int d = 0; d < C::ND; ++d) {
+            dk[d] += *(const f32x4*)(pw + 16 * d + 4 * g);
+            dv[d] += *(const f32x4*)(pw + HD + 16 * d + 4 * g);
+          }
+        }
+        finish_tile(ks);
+      }
     }
   } else {
     const bool active = wave < ntk;
@@ -555,7 +678,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
       if (j) __syncthreads();
       load_q_tile(q0, rows);
       __syncthreads();
-      if (active) step(wave, q0, rows >> 5);
+      if (active) for (int s = 0; s < (rows >> 5); ++s) dkv_pair<HD>(Qimg, Dimg, Limg, Simg, s, kf, vf, c, dk, dv, lane);
     }
     if (active) finish_tile(wave);
   }
@@ -565,42 +688,45 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
 // host side: work decomposition
 // =================================================================================================================
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
 // waves per workgroup for `tiles` 16-row tiles handled by one workgroup.  Only multiples of 4: a 6-wave workgroup (the balanced
 // count for 17 tiles) measured SLOWER than 4 or 8 (54 vs 48 / 40 us forward at 64 x 16 heads x 257): its waves land 2,2,1,1 on
 // the four SIMDs and a second workgroup is then not admitted next to it, leaving one workgroup per CU.
-static int pick_waves(int tiles) {
-  static const int force = getenv("MUSE_ATT_NW") ? atoi(getenv("MUSE_ATT_NW")) : 0;   // experiment switch
-  if (force) return force;
-  return tiles > 6 ? 8 : 4;
-}
+static int pick_waves(int tiles) { return tiles > 6 ? 8 : 4; }
+// split the leftover tile over all waves when exactly one is left over and every wave also has whole tiles to do
+static int use_shared(int tiles, int nw) { return tiles > nw && tiles % nw == 1; }
 
-struct Plan { int nw, nchunk, chunk_rows, tile_rows, ntile; size_t lds; };
+struct Plan { int nw, nchunk, chunk_rows, tile_rows, ntile, shared; size_t lds; };
 
 // backward kernels: stationary = rows the waves own (sq for dQ, skv for dK,dV); streamed = rows that pass through LDS
+// part_floats = per-(wave,row) floats of the shared-tile exchange (HD for dQ, 2 HD for dK,dV)
 template <int HD>
-static Plan make_plan(int stationary, int streamed, bool extra_f32) {
+static Plan make_plan(int stationary, int streamed, bool extra_f32, int part_floats) {
   using C = HeadCfg<HD>;
   Plan p;
+  p.shared = 0;
   if (streamed <= 288) { p.tile_rows = round_up(streamed, 32); p.ntile = 1; }
   else { p.tile_rows = 256; p.ntile = (streamed + 255) / 256; }
   const int tiles = (stationary + 15) / 16;
   if (p.ntile == 1 && tiles <= 24) {          // whole head in one workgroup
-    p.nw = pick_waves(tiles); p.nchunk = 1; p.chunk_rows = tiles * 16;
+    p.nw = pick_waves(tiles); p.nchunk = 1; p.chunk_rows = tiles * 16; p.shared = use_shared(tiles, p.nw);
   } else if (p.ntile == 1) {                   // long stationary side, short streamed side (cross-attention): 2 tiles per wave
     p.nw = 8; p.chunk_rows = 256; p.nchunk = (stationary + 255) / 256;
   } else {                                      // state carried across streamed tiles: one tile per wave
     p.nw = 8; p.chunk_rows = 128; p.nchunk = (stationary + 127) / 128;
   }
   p.lds = 2 * (size_t)p.tile_rows * C::RS + (extra_f32 ? 2 * (size_t)p.tile_rows * 4 : 0);
+  if (p.shared) p.lds = max_sz(p.lds, (size_t)p.nw * 16 * part_floats * 4);
   return p;
 }
 
 template <int HD, int MAXT, int NW, bool FULL>
-static int fwd_launch_k(AttnParams P, int sq_tiles_per_chunk_rows, int nchunk, int ntile, int batch, hipStream_t st) {
+static int fwd_launch_k(AttnParams P, int chunk_rows, int nchunk, int ntile, int shared, int batch, hipStream_t st) {
   using C = HeadCfg<HD>;
-  P.nchunk = nchunk; P.chunk_rows = sq_tiles_per_chunk_rows; P.tile_rows = MAXT * 16; P.ntile = ntile;
-  const size_t lds = 2 * (size_t)MAXT * 16 * C::RS;
+  P.nchunk = nchunk; P.chunk_rows = chunk_rows; P.tile_rows = MAXT * 16; P.ntile = ntile; P.shared = shared;
+  size_t lds = 2 * (size_t)MAXT * 16 * C::RS;
+  if (shared) lds = max_sz(lds, (size_t)NW * 16 * (HD + 2) * 4);
   auto k = attn_fwd_kernel<HD, MAXT, NW, FULL>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(batch * P.nh * nchunk), dim3(NW * 64), lds, st, P);
@@ -615,26 +741,21 @@ static int attn_fwd_launch(const AttnParams& P, int batch, hipStream_t st) {
     const bool whole = qt <= 24;                   // whole head in one workgroup, else 256-query chunks (2 tiles per wave)
     const int rows = whole ? qt * 16 : 256, nchunk = whole ? 1 : (P.sq + 255) / 256;
     const bool big = (whole ? qt : 16) > 6;        // 8 waves when there are q-tiles for them
+    const int sh = whole ? use_shared(qt, big ? 8 : 4) : 0;
     switch (nt) {
-      case 2: return big ? fwd_launch_k<HD, 2, 8, false>(P, rows, nchunk, 1, batch, st) : fwd_launch_k<HD, 2, 4, false>(P, rows, nchunk, 1, batch, st);
-      case 4: return big ? fwd_launch_k<HD, 4, 8, false>(P, rows, nchunk, 1, batch, st) : fwd_launch_k<HD, 4, 4, false>(P, rows, nchunk, 1, batch, st);
-      case 6: return big ? fwd_launch_k<HD, 6, 8, false>(P, rows, nchunk, 1, batch, st) : fwd_launch_k<HD, 6, 4, false>(P, rows, nchunk, 1, batch, st);
-      case 16: return fwd_launch_k<HD, 16, 8, false>(P, rows, nchunk, 1, batch, st);
-      case 18: {
-        static const int force = getenv("MUSE_ATT_NW") ? atoi(getenv("MUSE_ATT_NW")) : 0;   // experiment switch
-        if (force == 4) return fwd_launch_k<HD, 18, 4, false>(P, rows, nchunk, 1, batch, st);
-        if (force == 8) return fwd_launch_k<HD, 18, 8, false>(P, rows, nchunk, 1, batch, st);
-        if (force == 6) return fwd_launch_k<HD, 18, 6, false>(P, rows, nchunk, 1, batch, st);
-        return fwd_launch_k<HD, 18, 8, false>(P, rows, nchunk, 1, batch, st);
-      }
-      default: return fwd_launch_k<HD, 16, 8, true>(P, rows, nchunk, 1, batch, st);   // 8..14 tiles: the 16-tile kernel, every tile masked
+      case 2: return big ? fwd_launch_k<HD, 2, 8, false>(P, rows, nchunk, 1, sh, batch, st) : fwd_launch_k<HD, 2, 4, false>(P, rows, nchunk, 1, sh, batch, st);
+      case 4: return big ? fwd_launch_k<HD, 4, 8, false>(P, rows, nchunk, 1, sh, batch, st) : fwd_launch_k<HD, 4, 4, false>(P, rows, nchunk, 1, sh, batch, st);
+      case 6: return big ? fwd_launch_k<HD, 6, 8, false>(P, rows, nchunk, 1, sh, batch, st) : fwd_launch_k<HD, 6, 4, false>(P, rows, nchunk, 1, sh, batch, st);
+      case 16: return fwd_launch_k<HD, 16, 8, false>(P, rows, nchunk, 1, big ? sh : 0, batch, st);
+      case 18: return fwd_launch_k<HD, 18, 8, false>(P, rows, nchunk, 1, big ? sh : 0, batch, st);
+      default: return fwd_launch_k<HD, 16, 8, true>(P, rows, nchunk, 1, big ? sh : 0, batch, st);   // 8..14 tiles: the 16-tile kernel, every tile masked
     }
   }
   // streamed K/V (256 keys per tile), one q-tile per wave, 128-query chunks
   const int ntile = (P.skv + 255) / 256, nchunk = (P.sq + 127) / 128;
   const int tail = P.skv - (ntile - 1) * 256;      // keys in the last tile
-  if (tail > 224) return fwd_launch_k<HD, 16, 8, false>(P, 128, nchunk, ntile, batch, st);
-  return fwd_launch_k<HD, 16, 8, true>(P, 128, nchunk, ntile, batch, st);
+  if (tail > 224) return fwd_launch_k<HD, 16, 8, false>(P, 128, nchunk, ntile, 0, batch, st);
+  return fwd_launch_k<HD, 16, 8, true>(P, 128, nchunk, ntile, 0, batch, st);
 }
 
 template <int HD, int NW>
@@ -653,24 +774,16 @@ static int bwd_launch_dkv(const AttnParams& P, const Plan& pl, int items, hipStr
 }
 template <int HD>
 static int attn_bwd_launch(AttnParams P, int batch, hipStream_t st) {
-  const Plan plq = make_plan<HD>(P.sq, P.skv, false);   // dQ: queries stationary, keys streamed
-  const Plan plk = make_plan<HD>(P.skv, P.sq, true);    // dK,dV: keys stationary, queries streamed
+  const Plan plq = make_plan<HD>(P.sq, P.skv, false, HD);       // dQ: queries stationary, keys streamed
+  const Plan plk = make_plan<HD>(P.skv, P.sq, true, 2 * HD);    // dK,dV: keys stationary, queries streamed
   AttnParams Pq = P, Pk = P;
-  Pq.nchunk = plq.nchunk; Pq.chunk_rows = plq.chunk_rows; Pq.tile_rows = plq.tile_rows; Pq.ntile = plq.ntile;
-  Pk.nchunk = plk.nchunk; Pk.chunk_rows = plk.chunk_rows; Pk.tile_rows = plk.tile_rows; Pk.ntile = plk.ntile;
+  Pq.nchunk = plq.nchunk; Pq.chunk_rows = plq.chunk_rows; Pq.tile_rows = plq.tile_rows; Pq.ntile = plq.ntile; Pq.shared = plq.shared;
+  Pk.nchunk = plk.nchunk; Pk.chunk_rows = plk.chunk_rows; Pk.tile_rows = plk.tile_rows; Pk.ntile = plk.ntile; Pk.shared = plk.shared;
   const int iq = batch * P.nh * plq.nchunk, ik = batch * P.nh * plk.nchunk;
-  int rc;   // dQ first: it also produces dsum, which dK,dV consumes
-  switch (plq.nw) {
-    case 4: rc = bwd_launch_dq<HD, 4>(Pq, plq, iq, st); break;
-    case 6: rc = bwd_launch_dq<HD, 6>(Pq, plq, iq, st); break;
-    default: rc = bwd_launch_dq<HD, 8>(Pq, plq, iq, st); break;
-  }
+  // dQ first: it also produces dsum, which dK,dV consumes
+  const int rc = plq.nw == 4 ? bwd_launch_dq<HD, 4>(Pq, plq, iq, st) : bwd_launch_dq<HD, 8>(Pq, plq, iq, st);
   if (rc) return rc;
-  switch (plk.nw) {
-    case 4: return bwd_launch_dkv<HD, 4>(Pk, plk, ik, st);
-    case 6: return bwd_launch_dkv<HD, 6>(Pk, plk, ik, st);
-    default: return bwd_launch_dkv<HD, 8>(Pk, plk, ik, st);
-  }
+  return plk.nw == 4 ? bwd_launch_dkv<HD, 4>(Pk, plk, ik, st) : bwd_launch_dkv<HD, 8>(Pk, plk, ik, st);
 }
 
 static int check_desc(const muse_attn_desc* d) {

@@ -241,11 +241,51 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
         self.compute_dtype = dtype
+        self._wcache = {}
         return self
+
+    def mark_weights_changed(self):
+        """call after writing parameters behind autograd's back (`p.data.copy_`, EMA swap): drops the cached bf16 weights"""
+        self._wcache = {}
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            self._wcache = {}        # EMA copy_to()/restore() around evaluation write p.data
+        return super().train(mode)
 
     def _c(self, t):
         """GEMM operand in the compute dtype"""
-        return t if self.compute_dtype == torch.float32 else ops.cast_to_bf16(t.contiguous())
+        if self.compute_dtype == torch.float32 or t.dtype == torch.bfloat16:
+            return t
+        return ops.cast_to_bf16(t.contiguous())
+
+    def _wb(self, *mods):
+        """bf16 compute copy of one Linear / 1x1-conv weight, or of several stacked along the output dim (q|k|v, k|v, wi_0|wi_1),
+        as [N_out_total, K_in].  Cached across steps: valid while no source parameter has been updated in place (autograd version
+        counters; muse.FusedAdamW refreshes the copies it is given inside its own kernel and keeps them valid)."""
+        key = tuple(id(m.weight) for m in mods)
+        ver = tuple(m.weight._version for m in mods)
+        hit = getattr(self, "_wcache", {}).get(key)
+        if hit is not None and hit[0] == ver and hit[1].device == mods[0].weight.device:
+            return hit[1]
+        ws = [self._f(m.weight).reshape(m.weight.shape[0], -1) for m in mods]
+        wb = ops.cast_to_bf16((ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)).contiguous())
+        if not hasattr(self, "_wcache"):
+            self._wcache = {}
+        self._wcache[key] = (ver, wb)
+        off = 0
+        for m in mods:   # muse.FusedAdamW writes each parameter's refreshed bf16 copy straight into its row block of the cached tensor
+            n = m.weight.shape[0]
+            m.weight._muse_shadow = wb[off:off + n]
+            off += n
+        return wb
+
+    def _w2(self, *mods):
+        """the weight(s) as the GEMM operand of the current compute mode: cached bf16 copy, or the f32 master (stacked on the fly)"""
+        if self.compute_dtype == torch.bfloat16:
+            return self._wb(*mods)
+        ws = [self._f(m.weight).reshape(m.weight.shape[0], -1) for m in mods]
+        return ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
 
     def _mm(self, x, w2, residual=None):
         """x w2^T (+ residual) -> f32"""
@@ -268,12 +308,13 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         return dw
 
     def _lin(self, x, mod, residual=None):
-        return self._mm(x, self._f(mod.weight).reshape(mod.weight.shape[0], -1), residual=residual)
+        return self._mm(x, self._w2(mod), residual=residual)
 
     def _lin_bwd(self, dy, x, mod, name, G, need_dx=True):
-        w2 = self._f(mod.weight).reshape(mod.weight.shape[0], -1)
-        G[name + ".weight"] = self._mm_dw(dy, x, w2.shape).view(mod.weight.shape)
-        return self._mm_dx(dy, w2) if need_dx else None
+        w2 = self._w2(mod)
+        dyc = self._c(dy)            # one cast feeds both the dW and the dX product
+        G[name + ".weight"] = self._mm_dw(dyc, x, w2.shape).view(mod.weight.shape)
+        return self._mm_dx(dyc, w2) if need_dx else None
 
     def _norm(self, x, mod, mode=0, residual=None, want_pre=False):
         y, pre = ops.norm_res_fwd(x, self._f(mod.weight), float(self.config.layer_norm_eps), mode, residual=residual,
@@ -287,9 +328,27 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         return dv
 
     def _attention(self, x, ctx, att: _Attn, B, Sq, Skv, nh, residual=None):
-        """reference Attention :834-915, materialised: scores = alpha q k^T (batched per head), softmax, P v, out projection"""
+        """reference Attention :834-915.  bf16 compute mode: fused attention kernel (S x S never materialised; self- and
+        cross-attention) on a packed q|k|v (self) or k|v (cross) projection.  f32 parity mode: the reference's algorithm
+        materialised: scores = alpha q k^T (batched per head), softmax, P v, out projection."""
         Cq = x.shape[1]
         hd = Cq // nh
+        if self.compute_dtype == torch.bfloat16 and ops.attention_supported(torch.bfloat16, Sq, hd, Skv):
+            alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+            xb = ops.cast_to_bf16(x.contiguous())
+            self_attn = ctx is x
+            if self_attn:
+                qkv = ops.linear(xb, self._wb(att.query, att.key, att.value))            # [B*Sq, 3C] bf16
+                q, k, v, cb = qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], xb
+            else:
+                cb = ops.cast_to_bf16(ctx.contiguous())
+                q = ops.linear(xb, self._wb(att.query))
+                qkv = ops.linear(cb, self._wb(att.key, att.value))                      # [B*Skv, 2C] bf16
+                k, v = qkv[:, :Cq], qkv[:, Cq:]
+            o, lse = ops.attention_fwd_ex(q, k, v, B, Sq, Skv, nh, hd, alpha)
+            y = ops.linear(o, self._wb(att.out), out_dtype=torch.float32, residual=residual)
+            return y, dict(fused=True, self_attn=self_attn, xb=xb, cb=cb, q=q, qkv=qkv, o=o, lse=lse,
+                           dims=(B, Sq, Skv, nh, hd, Cq, alpha))
         q, k, v = self._lin(x, att.query), self._lin(ctx, att.key), self._lin(ctx, att.value)
         Sp = (Skv + 7) // 8 * 8
         P = torch.empty((B * nh, Sq, Sp), dtype=torch.float32, device=x.device)
@@ -304,6 +363,8 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
 
     def _attention_bwd(self, dy, sv, att: _Attn, name, G, self_attn=False):
         """-> (dx, dctx); for self attention the two are already summed and returned as dx (dctx = None)"""
+        if sv.get("fused"):
+            return self._attention_bwd_fused(dy, sv, att, name, G, self_attn)
         B, Sq, Skv, nh, hd, Cq, Sp, alpha = sv["dims"]
         q, k, v, P = sv["q"], sv["k"], sv["v"], sv["P"]
         sQ, sK, sP = (Sq * Cq, hd), (Skv * Cq, hd), (nh * Sq * Sp, Sq * Sp)
@@ -319,10 +380,52 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         ops.gemm(dP, q, dk, Skv, hd, Sq, la=1, lb=1, lda=Sp, ldb=Cq, ldc=Cq, alpha=alpha, batch=B * nh, zdiv=nh, sA=sP, sB=sQ, sC=sK)
         dx = self._lin_bwd(dq, sv["x"], att.query, name + ".query", G)
         dctx = self._lin_bwd(dk, sv["ctx"], att.key, name + ".key", G)
-        wv = self._f(att.value.weight)
+        wv = self._w2(att.value)
         G[name + ".value.weight"] = self._mm_dw(dv, sv["ctx"], wv.shape)
         # dctx += dv Wv ; for self attention query and context are the same tensor: everything lands in dx
         self._mm_dx(dv, wv, out=dctx, accumulate=True)
+        if self_attn:
+            return dx.add_(dctx), None
+        return dx, dctx
+
+    def _attention_bwd_fused(self, dy, sv, att: _Attn, name, G, self_attn):
+        B, Sq, Skv, nh, hd, Cq, alpha = sv["dims"]
+        dev = dy.device
+        dyb = ops.cast_to_bf16(dy.contiguous())
+        wo = self._wb(att.out)
+        gw = torch.empty(att.out.weight.shape, dtype=torch.float32, device=dev)
+        ops.linear_wgrad(dyb, sv["o"], gw, False)
+        G[name + ".out.weight"] = gw
+        do = ops.linear_dgrad(dyb, wo)                                                     # bf16 [B*Sq, C]
+        q, qkv = sv["q"], sv["qkv"]
+        if sv["self_attn"]:
+            if not self_attn:
+                raise MuseHipError("self-attention tape replayed as cross-attention")
+            k, v = qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:]
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd_ex(q, k, v, sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq],
+                                 dv=dqkv[:, 2 * Cq:])
+            gqkv = torch.empty((3 * Cq, Cq), dtype=torch.float32, device=dev)
+            ops.linear_wgrad(dqkv, sv["xb"], gqkv, False)
+            G[name + ".query.weight"], G[name + ".key.weight"], G[name + ".value.weight"] = gqkv[:Cq], gqkv[Cq:2 * Cq], gqkv[2 * Cq:]
+            dx = torch.empty((B * Sq, Cq), dtype=torch.float32, device=dev)
+            ops.linear_dgrad(dqkv, self._wb(att.query, att.key, att.value), out=dx)      # d(x) through q, k and v in one GEMM
+            return dx, None
+        k, v = qkv[:, :Cq], qkv[:, Cq:]
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(qkv)
+        ops.attention_bwd_ex(q, k, v, sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:])
+        gq = torch.empty(att.query.weight.shape, dtype=torch.float32, device=dev)
+        ops.linear_wgrad(dq, sv["xb"], gq, False)
+        G[name + ".query.weight"] = gq
+        Ck = att.key.weight.shape[1]
+        gkv = torch.empty((2 * Cq, Ck), dtype=torch.float32, device=dev)
+        ops.linear_wgrad(dkv, sv["cb"], gkv, False)
+        G[name + ".key.weight"], G[name + ".value.weight"] = gkv[:Cq], gkv[Cq:]
+        dx = torch.empty((B * Sq, Cq), dtype=torch.float32, device=dev)
+        ops.linear_dgrad(dq, self._wb(att.query), out=dx)
+        dctx = torch.empty((B * Skv, Ck), dtype=torch.float32, device=dev)
+        ops.linear_dgrad(dkv, self._wb(att.key, att.value), out=dctx)
         if self_attn:
             return dx.add_(dctx), None
         return dx, dctx
@@ -440,7 +543,7 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             a2, s2 = self._attention(m2, enc, lyr.crossattention, B, S, L, nh)
             n3, res3 = self._norm(a2, lyr.ffn.pre_mlp_layer_norm, mode=1, residual=res2, want_pre=True)   # LayerNorm (:928)
             m3, a3s = self._adaln(n3, lyr.ffn.adaLN_modulation, scond, B)
-            w01 = torch.cat([f(lyr.ffn.wi_0.weight), f(lyr.ffn.wi_1.weight)], dim=0)
+            w01 = self._w2(lyr.ffn.wi_0, lyr.ffn.wi_1)
             ab = self._mm(m3, w01)
             gl = ops.glu_fwd(ab)
             t = self._lin(gl, lyr.ffn.wo)
@@ -462,9 +565,9 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         y2, _ = self._norm(y1, self.mlm_layer.layer_norm.norm)
         V = c.codebook_size
         Vp = (V + 7) // 8 * 8
-        w2 = f(self.mlm_layer.conv2.weight).reshape(V, -1)
+        w2 = self._w2(self.mlm_layer.conv2)
         logits_p = torch.empty((B * S, Vp), dtype=torch.float32, device=y2.device)
-        ops.gemm(self._c(y2), self._c(w2), logits_p, B * S, V, c.in_channels, lda=c.in_channels, ldb=c.in_channels, ldc=Vp)
+        ops.gemm(self._c(y2), w2, logits_p, B * S, V, c.in_channels, lda=c.in_channels, ldb=c.in_channels, ldc=Vp)
         logits = logits_p.view(B, S, Vp) if Vp == V else logits_p[:, :V].contiguous().view(B, S, V)
         loss = None
         if labels is not None:
@@ -496,9 +599,10 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         if ce["lw"] is not None:   # mean over valid rows -> weighted mean: row r scaled by w_r * n_valid / sum(w)
             ops.scale_rows_(dl, ce["lw"], ce["loss_out"][1:2], ce["lw"].sum().reshape(1), V)
         # ConvMlmLayer
-        w2 = self._f(self.mlm_layer.conv2.weight).reshape(V, -1)
-        G["mlm_layer.conv2.weight"] = self._mm_dw(dl, T["y2"], w2.shape, M=V, lda=Vp).view(self.mlm_layer.conv2.weight.shape)
-        dy2 = self._mm_dx(dl, w2, lda=Vp)
+        w2 = self._w2(self.mlm_layer.conv2)
+        dlc = self._c(dl)
+        G["mlm_layer.conv2.weight"] = self._mm_dw(dlc, T["y2"], w2.shape, M=V, lda=Vp).view(self.mlm_layer.conv2.weight.shape)
+        dy2 = self._mm_dx(dlc, w2, lda=Vp)
         dy1 = self._norm_bwd(dy2, T["y1"], self.mlm_layer.layer_norm.norm, "mlm_layer.layer_norm.norm", G)
         dh = self._lin_bwd(dy1, T["h_mlm"], self.mlm_layer.conv1, "mlm_layer.conv1", G)
         scond, senc = T["scond"], T["senc"]

@@ -152,7 +152,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._v[k] = torch.zeros_like(p)
             elif self._m[k].device != p.device:
                 self._m[k], self._v[k] = self._m[k].to(p.device), self._v[k].to(p.device)
-            ops.adamw_flat(p.data, p.grad, self._m[k], self._v[k], None, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
+            shadow = getattr(p, "_muse_shadow", None)   # the model's cached bf16 compute copy of this weight (MaskGiTUViT bf16 mode)
+            if shadow is not None and (shadow.numel() != p.numel() or shadow.device != p.device or not shadow.is_contiguous()):
+                shadow = None
+            ops.adamw_flat(p.data, p.grad, self._m[k], self._v[k], shadow, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
                            grp["eps"], grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
         return loss
 

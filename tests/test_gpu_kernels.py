@@ -367,7 +367,7 @@ def test_fused_attention_fwd_bwd(B, S, nh, hd):
     ctx, lse = ops.attention_fwd(qkv.to(DEV), B, S, nh, hd, alpha)
     assert rel_err(ctx.float(), ref.detach()) < 1.5e-2          # bf16 P and bf16 output
     lse_ref = torch.logsumexp(q @ k.transpose(-1, -2) * alpha, dim=-1).reshape(B * nh, S)
-    assert rel_err(lse[:, :S], lse_ref.detach()) < 1e-5
+    assert rel_err(lse[:, :S], lse_ref.detach()) < 1e-3   # the row sums are sums of the bf16-rounded P (they come out of an MFMA)
     dqkv = ops.attention_bwd(qkv.to(DEV), ctx, dctx.to(DEV), lse, B, S, nh, hd, alpha)
     g = x.grad.reshape(B * S, 3 * H)
     for i, nm in enumerate("qkv"):
@@ -395,7 +395,7 @@ def test_fused_attention_general_lengths(B, Sq, Skv, nh, hd):
     qg, kvg = qp.to(DEV), kvp.to(DEV)
     ctx, lse = ops.attention_fwd_ex(qg[:, :H], kvg[:, :H], kvg[:, H:], B, Sq, Skv, nh, hd, alpha)
     assert rel_err(ctx.float(), ref.detach()) < 1.5e-2
-    assert rel_err(lse[:, :Sq], torch.logsumexp(sc, dim=-1).reshape(B * nh, Sq).detach()) < 1e-5
+    assert rel_err(lse[:, :Sq], torch.logsumexp(sc, dim=-1).reshape(B * nh, Sq).detach()) < 1e-3
     dkv = torch.full((B * Skv, 2 * H), 7.0, dtype=torch.bfloat16, device=DEV)
     dq, dk, dv = ops.attention_bwd_ex(qg[:, :H], kvg[:, :H], kvg[:, H:], ctx, dctx.to(DEV), lse, B, Sq, Skv, nh, hd, alpha,
                                       dk=dkv[:, :H], dv=dkv[:, H:])
@@ -425,7 +425,7 @@ def test_fused_attention_extreme_scores():
     ctx, lse = ops.attention_fwd_ex(qb.to(DEV), kb.to(DEV), vb.to(DEV), B, S, S, nh, hd, alpha)
     assert torch.isfinite(ctx.float()).all() and torch.isfinite(lse[:, :S]).all()
     assert rel_err(ctx.float(), ref) < 1.5e-2
-    assert rel_err(lse[:, :S], torch.logsumexp(sc, -1).view(1, S)) < 1e-5
+    assert rel_err(lse[:, :S], torch.logsumexp(sc, -1).view(1, S)) < 1e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
