@@ -170,6 +170,42 @@ int muse_mask_sample(const int64_t* tokens, const int64_t* class_ids, const floa
                      int64_t* input_ids, int64_t* labels, float* mask_prob, int32_t batch, int32_t seq, int64_t mask_id,
                      int64_t codebook_size, float min_masking_rate, void* stream);
 
+/* One iteration of MaskGit parallel decoding on the device (muse/modeling_transformer.py:1409-1454, :generate2;
+ * muse/modeling_transformer_v2.py:434-474; muse/sampling.py:30-35 mask_by_random_topk): replaces ~10 ATen launches per step
+ * (softmax, multinomial, where, gather, log, sort, gather, compare, where).
+ *   the logits of image b, position s start at logits + b*img_stride + s*ld (f32; lets the caller skip a class-token row);
+ *   logits = uncond + guidance_scale * (cond - uncond) over the first `vocab` columns (uncond_logits NULL: logits = cond);
+ *   p = softmax(logits);  sampled = argmax_j p_j / q_j, q ~ Exp(1) (how torch.multinomial(num_samples = 1) draws), known
+ *   tokens (input_ids != mask_id) are kept;  confidence = log(clamp(p_sampled, 1e-20)) + temperature * gumbel(u) (FLT_MAX as p
+ *   for known tokens);  mask_len = max(1, min(#unknown - 1, sched_mask_len));  next_ids = mask_id where confidence < the
+ *   mask_len-th smallest confidence of the image (0-based), else the sampled id.
+ * noise_exp [batch*seq, vocab] / noise_u [batch, seq]: the caller's random draws (parity tests replay the reference's CPU
+ * generator); NULL: Philox4x32-10 keyed by (seed, step).  raw_sampled (may be NULL) receives the samples before known tokens
+ * are restored (the reference's `intermediate` list).  conf_scratch: f32 [batch*seq].  2 <= seq <= 4096. */
+int muse_sample_step(const float* cond_logits, const float* uncond_logits, float guidance_scale, int64_t img_stride, int64_t ld,
+                     int32_t vocab,
+                     const int64_t* input_ids, int64_t mask_id, const float* noise_exp, const float* noise_u, uint64_t seed,
+                     uint32_t step, float temperature, int32_t sched_mask_len, int32_t batch, int32_t seq, int64_t* raw_sampled,
+                     int64_t* sampled, int64_t* next_ids, float* conf_scratch, void* stream);
+
+/* training/train_muse.py:149-226 mask_or_random_replace_tokens on the device.  mask_prob = cos(pi/2 t) clipped to
+ * min_masking_rate (timesteps given) or mask_prob_in as is (the eval_mask_ratios branch); k = round(seq * mask_prob) >= 1;
+ * mask = argsort(noise) < k (noise given) or the rectangle rects[b] = (y0, x0, h, w) on the sqrt(seq) grid (contiguous-region
+ * branch, drawn on the host like the reference does); input_ids = mask_id where masked (the reference's `noise_type` test at
+ * :202 is always true, so "random_replace" also masks: kept); labels = tokens where masked else -100, or all tokens when
+ * all_labels (predict_all_tokens / random_replace), with loss_weight = 1 - (1 - mask) * (1 - mask_prob) * (1 - weight_min)
+ * (:145-146; loss_weight may be NULL). */
+int muse_mask_tokens(const int64_t* tokens, const float* timesteps, const float* mask_prob_in, const float* noise,
+                     const int32_t* rects, int64_t* input_ids, int64_t* labels, float* loss_weight, float* mask_prob,
+                     int32_t batch, int32_t seq, int64_t mask_id, float min_masking_rate, int32_t all_labels, float weight_min,
+                     void* stream);
+
+/* training/train_muse.py:715-731 conditioning dropout: keep_b = uniforms[b] < prob;  out = (x * keep != 0) ? x : empty
+ * (x [batch, per_image] f32, empty [per_image] f32) - the reference's expression verbatim. */
+int muse_cond_dropout(const float* x, const float* empty, const float* uniforms, float* out, int32_t batch, int64_t per_image,
+                      float prob, void* stream);
+
+
 /* ------------------------------------------------------------------------------------------------------------
  * MaskGitVQGAN kernels (NHWC activations).
  * muse_conv2d_nhwc: stride-1 SAME convolution (Conv2dSame, muse/modeling_maskgit_vqgan.py:33-45) as implicit GEMM

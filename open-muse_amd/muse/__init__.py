@@ -12,7 +12,8 @@ from .modeling_transformer import MaskGitTransformer
 from .modeling_transformer_v2 import MaskGiTUViT, MaskGiTUViT_v2
 from .pipeline_muse import PipelineMuse
 from .sampling import get_mask_chedule
-from .training import FusedAdamW, GradReducer, TrainStep, prepare_inputs_and_labels
+from .training import (FusedAdamW, GradReducer, TrainStep, cond_dropout, mask_or_random_replace_tokens,
+                       prepare_inputs_and_labels)
 
 __all__ = ["MaskGitVQGAN", "MaskGitTransformer", "MaskGiTUViT", "MaskGiTUViT_v2", "PipelineMuse", "get_mask_chedule", "FusedAdamW", "GradReducer",
-           "TrainStep", "prepare_inputs_and_labels"]
+           "TrainStep", "prepare_inputs_and_labels", "mask_or_random_replace_tokens", "cond_dropout"]

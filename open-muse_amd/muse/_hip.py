@@ -84,6 +84,11 @@ SIGNATURES = {
     "muse_cast_bf16_to_f32": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_mask_sample": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64,
                          c_i64, c_float, c_void_p],
+    "muse_sample_step": [c_void_p, c_void_p, c_float, c_i64, c_i64, c_int, c_void_p, c_i64, c_void_p, c_void_p, C.c_uint64, C.c_uint32,
+                         c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "muse_mask_tokens": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                         c_i64, c_float, c_int, c_float, c_void_p],
+    "muse_cond_dropout": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_float, c_void_p],
     "muse_conv2d_nhwc": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int, c_int, c_void_p],
     "muse_conv2d_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -26,7 +26,7 @@ from torch import nn
 from . import ops
 from ._hip import MuseHipError
 from .modeling_utils import ConfigMixin, ModelMixin, register_to_config
-from .sampling import cosine_schedule, mask_by_random_topk
+from .sampling import cosine_schedule, decode_seed, scheduled_mask_len, step_noise
 
 _ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the flat buffer
 
@@ -597,39 +597,38 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         return [view(GW, i, tuple(p.shape)) for i, p in enumerate(params)]
 
     # ------------------------------------------------------------------------------------------------------------
-    # sampling (reference :1363-1456).  Adjacent to the hot path ("next" row in SURVEY.md section 8f): the network
-    # forward runs on the HIP kernels, the per-step token bookkeeping uses torch ops on the GPU.
+    # MaskGit parallel decoding (reference :1363-1456, "next" row f2 of SURVEY.md section 8): per step one forward on the
+    # HIP kernels and ONE device call for everything token-level (libmuse_hip muse_sample_step: softmax, categorical
+    # sample, Gumbel-perturbed confidence, k-th-smallest threshold, re-mask).  Nothing in the loop reads the device.
     # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def generate2(self, input_ids=None, class_ids=None, encoder_hidden_states=None, negative_embeds=None, temperature=1.0,
-                  timesteps=18, guidance_scale=0, noise_schedule=cosine_schedule, generator=None, **kwargs):
+                  timesteps=18, guidance_scale=0, noise_schedule=cosine_schedule, generator=None, noise=None, **kwargs):
+        """-> sampled ids [B, num_vq_tokens].  `noise` (tests): per step a pair (exponential draws [B*S, codebook_size],
+        uniform draws [B, S]) replacing the in-kernel Philox stream, e.g. the draws the reference's CPU generator produced.
+        Like the reference, `class_ids` is shifted by codebook_size IN PLACE (:1388-1389) and the temperature compounds
+        across steps (:1451)."""
         if encoder_hidden_states is not None:
             raise NotImplementedError("text conditioning is outside the MI355X hot-path build")
-        mask_token_id = self.config.mask_token_id
-        seq_len = self.config.num_vq_tokens
-        batch_size = len(class_ids)
-        class_ids = class_ids + self.config.codebook_size  # (the reference mutates the caller's tensor in place)
+        cfg = self.config
+        mask_id, S, V = cfg.mask_token_id, cfg.num_vq_tokens, cfg.codebook_size
+        B = len(class_ids)
+        class_ids += V
         if input_ids is None:
-            input_ids = torch.full((batch_size, seq_len), mask_token_id, dtype=torch.long, device=self.device)
-        sampled_ids = input_ids
+            input_ids = torch.full((B, S), mask_id, dtype=torch.long, device=self.device)
+        seed = decode_seed(generator) if noise is None else 0
+        model_in = torch.empty((B, S + 1), dtype=torch.long, device=input_ids.device)
+        model_in[:, 0] = class_ids
+        sampled = input_ids
         for step in range(timesteps):
-            model_in = torch.cat([class_ids[:, None], input_ids], dim=1)
-            logits = self(model_in)[..., : self.config.codebook_size][:, 1:]
-            probs = logits.softmax(dim=-1)
-            sampled_ids = torch.multinomial(probs.reshape(-1, probs.size(-1)), 1, generator=generator)[:, 0].view(batch_size, seq_len)
-            unknown_map = input_ids == mask_token_id
-            sampled_ids = torch.where(unknown_map, sampled_ids, input_ids)
-            ratio = 1.0 * (step + 1) / timesteps
-            mask_ratio = noise_schedule(torch.tensor(ratio))
-            selected_probs = torch.gather(probs, -1, sampled_ids.long()[..., None]).squeeze(-1)
-            selected_probs = torch.where(unknown_map, selected_probs, torch.finfo(selected_probs.dtype).max)
-            mask_len = (seq_len * mask_ratio).floor().unsqueeze(0).to(logits.device)
-            mask_len = torch.max(torch.tensor([1], device=logits.device),
-                                 torch.min(unknown_map.sum(dim=-1, keepdim=True) - 1, mask_len))
-            temperature = temperature * (1.0 - ratio)
-            masking = mask_by_random_topk(mask_len, selected_probs, temperature, generator=generator)
-            input_ids = torch.where(masking, mask_token_id, sampled_ids)
-        return sampled_ids
+            model_in[:, 1:] = input_ids
+            logits = self(model_in)                                   # [B, S + 1, vocab] f32; row 0 of each image is the class token
+            temperature = temperature * (1.0 - 1.0 * (step + 1) / timesteps)
+            q, u = step_noise(noise, step)
+            sampled, input_ids, _ = ops.sample_step(logits[:, 1:], input_ids, mask_id, V, temperature,
+                                                    scheduled_mask_len(S, step, timesteps, noise_schedule), noise_exp=q, noise_u=u,
+                                                    seed=seed, step=step)
+        return sampled
 
     def generate(self, *args, **kwargs):
         raise NotImplementedError("use generate2 (the reference's generate() is broken: modeling_transformer.py:1307)")

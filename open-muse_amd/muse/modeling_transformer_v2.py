@@ -22,7 +22,7 @@ from torch import nn
 from . import ops
 from ._hip import MuseHipError
 from .modeling_utils import ConfigMixin, ModelMixin
-from .sampling import cosine_schedule, mask_by_random_topk
+from .sampling import cosine_schedule, decode_seed, scheduled_mask_len, step_noise
 
 # reference dataclass MaskGiTUViT_v2Config :79-124 (field -> default)
 _DEFAULTS = dict(
@@ -687,67 +687,54 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
     def generate2(self, encoder_hidden_states, cond_embeds, micro_conds, empty_embeds, empty_cond_embeds, input_ids=None,
                   negative_embeds=None, negative_cond_embeds=None, temperature=1.0, timesteps=18, guidance_scale=0,
                   guidance_schedule=None, noise_schedule=cosine_schedule, generator=None, return_intermediate=False,
-                  seq_len=None, use_tqdm=None, topk_filter_thres=None, noise_type=None, predict_all_tokens=None):
-        """reference :330-479 — iterative parallel decoding with classifier-free guidance; the forward passes run on the HIP
-        path, the per-step sampling (multinomial, confidence masking with Gumbel noise) is the reference's torch code on the
-        GPU tensors.  (The reference leaves `model_input` undefined for guidance_scale == 0; here that case feeds input_ids.)"""
-        batch_size = encoder_hidden_states.shape[0]
-        seq_len = 256 if seq_len is None else seq_len
+                  seq_len=None, use_tqdm=None, topk_filter_thres=None, noise_type=None, predict_all_tokens=None, noise=None):
+        """reference :330-479 — iterative parallel decoding with classifier-free guidance.  Per step: one forward on the HIP
+        path (batch doubled under guidance) and ONE device call for the guidance mix + everything token-level
+        (muse_sample_step).  `noise` (tests): per step (exponential draws [B*S, codebook], uniform draws [B, S]) replacing the
+        in-kernel Philox stream.  (The reference leaves `model_input` undefined for guidance_scale == 0; here that case feeds
+        input_ids.)"""
+        B = encoder_hidden_states.shape[0]
+        S = 256 if seq_len is None else seq_len
         dev = encoder_hidden_states.device
-        mask_id = self.config.mask_token_id
-        V = self.config.codebook_size
+        mask_id, V = self.config.mask_token_id, self.config.codebook_size
+        # host-side per-step scalars, float32 like the reference's 0-dim tensors
         temperatures = (torch.linspace(temperature[0], temperature[1], timesteps) if isinstance(temperature, tuple)
                         else torch.linspace(temperature, 0.01, timesteps))
-        if input_ids is None:
-            input_ids = torch.full((batch_size, seq_len), mask_id, dtype=torch.long, device=dev)
-        intermediate = []
         if guidance_schedule == "linear":
-            guidance_scales = torch.linspace(0, guidance_scale, timesteps)
+            scales = torch.linspace(0, guidance_scale, timesteps)
         elif guidance_schedule == "cosine":
-            guidance_scales = torch.tensor([float((cosine_schedule(torch.tensor(1 - (step + 1) / timesteps)) * guidance_scale).floor())
-                                            for step in range(timesteps)])
+            scales = torch.tensor([float((cosine_schedule(torch.tensor(1 - 1.0 * (i + 1) / timesteps)) * guidance_scale).floor())
+                                   for i in range(timesteps)])
         else:
-            guidance_scales = torch.ones(timesteps) * guidance_scale
+            scales = torch.ones(timesteps) * guidance_scale
+        if input_ids is None:
+            input_ids = torch.full((B, S), mask_id, dtype=torch.long, device=dev)
         if micro_conds.shape[0] == 1:
-            micro_conds = micro_conds.repeat(batch_size, 1).to(dev)
-        if guidance_scale > 0:
-            unc = empty_embeds if negative_embeds is None else negative_embeds
-            if unc.shape[0] == 1:
-                unc = unc.expand(batch_size, -1, -1)
-            encoder_hidden_states = torch.cat([encoder_hidden_states, unc])
-            unc_c = empty_cond_embeds if negative_cond_embeds is None else negative_cond_embeds
-            if unc_c.shape[0] == 1:
-                unc_c = unc_c.expand(batch_size, -1)
-            cond_embeds = torch.cat([cond_embeds, unc_c])
+            micro_conds = micro_conds.repeat(B, 1).to(dev)
+        guided = guidance_scale > 0
+        if guided:
+            def pair(x, y):   # conditional batch followed by the unconditional one (a single broadcastable entry is expanded)
+                return torch.cat([x, y.expand(B, *y.shape[1:]) if y.shape[0] == 1 else y])
+            encoder_hidden_states = pair(encoder_hidden_states, empty_embeds if negative_embeds is None else negative_embeds)
+            cond_embeds = pair(cond_embeds, empty_cond_embeds if negative_cond_embeds is None else negative_cond_embeds)
             micro_conds = torch.cat([micro_conds, micro_conds], dim=0)
-        steps = range(timesteps)
+        seed = decode_seed(generator) if noise is None else 0
+        order = range(timesteps)
         if use_tqdm:
             from tqdm.auto import tqdm
-            steps = tqdm(steps)
-        sampled_ids = input_ids
-        for step in steps:
-            model_input = torch.cat([input_ids] * 2) if guidance_scale > 0 else input_ids
-            out = self(model_input, encoder_hidden_states, cond_embeds, micro_conds)
-            if guidance_scale > 0:
-                cond_logits, uncond_logits = out.chunk(2)
-                logits = uncond_logits[..., :V] + float(guidance_scales[step]) * (cond_logits[..., :V] - uncond_logits[..., :V])
-            else:
-                logits = out[..., :V]
-            probs = logits.softmax(dim=-1)
-            sampled_ids = torch.multinomial(probs.reshape(-1, V), 1, generator=generator)[:, 0].view(batch_size, seq_len)
+            order = tqdm(order)
+        intermediate = []
+        sampled = input_ids
+        for step in order:
+            out = self(torch.cat([input_ids, input_ids]) if guided else input_ids, encoder_hidden_states, cond_embeds, micro_conds)
+            q, u = step_noise(noise, step)
+            sampled, input_ids, raw = ops.sample_step(out[:B], input_ids, mask_id, V, float(temperatures[step]),
+                                                      scheduled_mask_len(S, step, timesteps, noise_schedule),
+                                                      uncond_logits=out[B:] if guided else None, guidance_scale=float(scales[step]),
+                                                      noise_exp=q, noise_u=u, seed=seed, step=step, want_raw=return_intermediate)
             if return_intermediate:
-                intermediate.append(sampled_ids)
-            unknown_map = input_ids == mask_id
-            sampled_ids = torch.where(unknown_map, sampled_ids, input_ids)
-            ratio = 1.0 * (step + 1) / timesteps
-            mask_ratio = noise_schedule(torch.tensor(ratio))
-            mask_len = (seq_len * mask_ratio).floor().unsqueeze(0).to(dev)
-            mask_len = torch.max(torch.tensor([1], device=dev), torch.min(unknown_map.sum(dim=-1, keepdim=True) - 1, mask_len))
-            selected = torch.gather(probs, -1, sampled_ids.long()[..., None]).squeeze(-1)
-            selected = torch.where(unknown_map, selected, torch.finfo(selected.dtype).max)
-            masking = mask_by_random_topk(mask_len, selected, float(temperatures[step]), generator=generator)
-            input_ids = torch.where(masking, mask_id, sampled_ids)
-        return (sampled_ids, intermediate) if return_intermediate else sampled_ids
+                intermediate.append(raw)
+        return (sampled, intermediate) if return_intermediate else sampled
 
 
 MaskGiTUViT = MaskGiTUViT_v2

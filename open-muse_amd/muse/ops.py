@@ -472,6 +472,71 @@ def mask_sample(tokens, class_ids, timesteps, noise, mask_id, codebook_size, min
     return input_ids, labels, mask_prob
 
 
+def sample_step(cond_logits, input_ids, mask_id, vocab, temperature, sched_mask_len, *, uncond_logits=None, guidance_scale=0.0,
+                noise_exp=None, noise_u=None, seed=0, step=0, want_raw=False):
+    """one MaskGit decoding iteration (muse_sample_step): cond_logits [B, S, >= vocab] f32 view (last dim contiguous; a slice
+    that skips the class-token row is fine) -> (sampled [B,S], next_input_ids [B,S], raw samples or None)"""
+    require_gpu(cond_logits, input_ids)
+    B, S = input_ids.shape
+
+    def layout(t):
+        if t.dim() != 3 or t.shape[0] != B or t.shape[1] != S or t.stride(2) != 1 or t.dtype != torch.float32 or t.shape[2] < vocab:
+            raise _hip.MuseHipError("sample_step: logits must be a float32 [B, S, >= vocab] view with a contiguous last dim")
+        return t.stride(0), t.stride(1)
+
+    lay = layout(cond_logits)
+    if uncond_logits is not None and layout(uncond_logits) != lay:
+        raise _hip.MuseHipError("sample_step: cond / uncond logits must share a layout")
+    ids = input_ids.contiguous()
+    sampled, nxt = torch.empty_like(ids), torch.empty_like(ids)
+    raw = torch.empty_like(ids) if want_raw else None
+    conf = torch.empty(B * S, dtype=torch.float32, device=ids.device)
+    if noise_exp is not None:
+        noise_exp = noise_exp.reshape(B * S, vocab).to(device=ids.device, dtype=torch.float32).contiguous()
+    if noise_u is not None:
+        noise_u = noise_u.reshape(B * S).to(device=ids.device, dtype=torch.float32).contiguous()
+    check(lib().muse_sample_step(cond_logits.data_ptr(), ptr(uncond_logits), float(guidance_scale), lay[0], lay[1], int(vocab),
+                                 ids.data_ptr(), int(mask_id), ptr(noise_exp), ptr(noise_u), int(seed) & (2 ** 64 - 1), int(step),
+                                 float(temperature), int(sched_mask_len), B, S, ptr(raw), sampled.data_ptr(), nxt.data_ptr(),
+                                 conf.data_ptr(), stream()), "muse_sample_step")
+    return sampled, nxt, raw
+
+
+def mask_tokens(tokens, mask_id, *, timesteps=None, mask_prob=None, noise=None, rects=None, min_masking_rate=0.0, all_labels=False,
+                want_weight=False, weight_min=0.3):
+    """training/train_muse.py:149-226 on the device -> (input_ids, labels, loss_weight or None, mask_prob)"""
+    require_gpu(tokens)
+    B, S = tokens.shape
+    dev = tokens.device
+    tokens = tokens.contiguous()
+    input_ids, labels = torch.empty_like(tokens), torch.empty_like(tokens)
+    lw = torch.empty((B, S), dtype=torch.float32, device=dev) if want_weight else None
+    mp = torch.empty(B, dtype=torch.float32, device=dev)
+    f = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731
+    timesteps, mask_prob, noise = f(timesteps), f(mask_prob), f(noise)
+    if rects is not None:
+        rects = rects.to(device=dev, dtype=torch.int32).contiguous()
+    check(lib().muse_mask_tokens(tokens.data_ptr(), ptr(timesteps), ptr(mask_prob), ptr(noise), ptr(rects), input_ids.data_ptr(),
+                                 labels.data_ptr(), ptr(lw), mp.data_ptr(), B, S, int(mask_id), float(min_masking_rate),
+                                 1 if all_labels else 0, float(weight_min), stream()), "muse_mask_tokens")
+    return input_ids, labels, lw, mp
+
+
+def cond_dropout(x, empty, uniforms, prob):
+    """training/train_muse.py:715-731: x [B, ...] f32, empty [...] (one image's worth), uniforms [B]"""
+    require_gpu(x, empty, uniforms)
+    B = x.shape[0]
+    xc = x.float().contiguous()
+    per = xc.numel() // B
+    e = empty.float().contiguous()
+    if e.numel() != per:
+        raise _hip.MuseHipError("cond_dropout: the empty embedding must have the shape of one batch element")
+    out = torch.empty_like(xc)
+    check(lib().muse_cond_dropout(xc.data_ptr(), e.data_ptr(), uniforms.float().contiguous().data_ptr(), out.data_ptr(), B, per,
+                                  float(prob), stream()), "muse_cond_dropout")
+    return out
+
+
 # ---- VQGAN (NHWC) ----------------------------------------------------------------------------------------------
 def conv2d_nhwc(x, w, B, H, W, Cin, Cout, KS, bias=None, residual=None, upsample=False):
     """x: [B, Hin, Win, Cin] (Hin = H/2 if upsample), w: [Cout, KS, KS, Cin]; returns [B, H, W, Cout]."""

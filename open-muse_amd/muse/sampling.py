@@ -1,66 +1,76 @@
-"""Mask schedules and confidence-based re-masking (reference: muse/sampling.py).  Host-side scalar maths plus a few
-torch tensor ops used by generate2; cosine_schedule is also the schedule of the train-step mask sampler."""
+"""Mask-ratio schedules and the host side of MaskGit parallel decoding.
+
+The schedules are the reference's (muse/sampling.py:38-77: cosine / linear / pow<k> / sigmoid, looked up through
+`get_mask_chedule` — the reference's spelling is part of its import surface).  They are host-side scalar maths: a schedule
+is evaluated once per decoding step on a 0-dim CPU tensor.  Everything per token — softmax, categorical sampling, the
+Gumbel-perturbed confidence, the k-th-smallest threshold and the re-masking (muse/sampling.py:30-35 `mask_by_random_topk`
+and its callers) — runs in ONE device call per step (`ops.sample_step` -> libmuse_hip `muse_sample_step`), so the
+reference's tensor helpers (`gumbel_noise`, `gumbel_sample`, `top_k`, `mask_by_random_topk`) have no counterpart here.
+"""
+from __future__ import annotations
+
 import math
-from functools import partial
+from typing import Callable, Optional, Sequence, Tuple
 
 import torch
 
-
-def log(t, eps=1e-20):
-    return torch.log(t.clamp(min=eps))
-
-
-def gumbel_noise(t, generator=None):
-    u = torch.zeros_like(t).uniform_(0, 1, generator=generator)
-    return -log(-log(u))
-
-
-def gumbel_sample(t, temperature=1.0, dim=-1, generator=None):
-    return ((t / max(temperature, 1e-10)) + gumbel_noise(t, generator=generator)).argmax(dim=dim)
-
-
-def top_k(logits, thres=0.9):
-    k = math.ceil((1 - thres) * logits.shape[-1])
-    val, ind = logits.topk(k, dim=-1)
-    out = torch.full_like(logits, float("-inf"))
-    out.scatter_(2, ind, val)
-    return out
-
-
-def mask_by_random_topk(mask_len, probs, temperature=1.0, generator=None):
-    """mask the `mask_len` least confident positions (confidence = log p + T * gumbel)."""
-    confidence = log(probs) + temperature * gumbel_noise(probs, generator=generator)
-    cut_off = torch.gather(torch.sort(confidence, dim=-1).values, 1, mask_len.long())
-    return confidence < cut_off
+_HALF_PI = math.pi * 0.5
+_FLOOR = 1e-6   # lower clamp of the non-cosine schedules
 
 
 def cosine_schedule(t):
-    return torch.cos(t * math.pi * 0.5)
+    """mask ratio cos(pi/2 * t); also the schedule of the train-time mask sampler (training/train_maskgit_imagenet.py:376)"""
+    return torch.cos(t * _HALF_PI)
 
 
 def linear_schedule(t):
-    return (1 - t).clamp(min=1e-6, max=1.0)
+    return torch.clamp(1 - t, min=_FLOOR, max=1.0)
 
 
-def pow(t, method):
-    exponent = float(method.replace("pow", ""))
-    return (1.0 - t ** exponent).clamp(min=1e-6, max=1.0)
+def _pow_schedule(t, exponent: float):
+    return torch.clamp(1.0 - t ** exponent, min=_FLOOR, max=1.0)
 
 
-def sigmoid_schedule(t, start=-3, end=3, tau=1.0, clip_min=1e-6):
-    v_start = torch.sigmoid(torch.tensor(start / tau))
-    v_end = torch.sigmoid(torch.tensor(end / tau))
-    out = torch.sigmoid((t * (end - start) + start) / tau)
-    return torch.clip((v_end - out) / (v_end - v_start), clip_min, 1.0)
+def sigmoid_schedule(t, start=-3, end=3, tau=1.0, clip_min=_FLOOR):
+    lo, hi = (torch.sigmoid(torch.tensor(b / tau)) for b in (start, end))
+    mid = torch.sigmoid((t * (end - start) + start) / tau)
+    return torch.clip((hi - mid) / (hi - lo), clip_min, 1.0)
 
 
-def get_mask_chedule(method, **schedule_kwargs):
+def get_mask_chedule(method: str, **schedule_kwargs) -> Callable:
+    """name -> schedule ("cosine", "linear", "pow<exponent>", "sigmoid"); raises ValueError for anything else"""
     if method == "cosine":
         return cosine_schedule
     if method == "linear":
         return linear_schedule
     if "pow" in method:
-        return partial(pow, method=method)
+        exponent = float(method.replace("pow", ""))
+        return lambda t: _pow_schedule(t, exponent)
     if method == "sigmoid":
-        return partial(sigmoid_schedule, **schedule_kwargs)
+        return lambda t: sigmoid_schedule(t, **schedule_kwargs)
     raise ValueError("Unknown schedule method: {}".format(method))
+
+
+def scheduled_mask_len(seq_len: int, step: int, timesteps: int, noise_schedule: Callable = cosine_schedule) -> int:
+    """floor(seq_len * schedule((step + 1) / timesteps)) with the reference's float32 arithmetic (a 0-dim CPU tensor:
+    muse/modeling_transformer.py:1430-1440).  Can be -1 on the last step (cos(pi/2) is slightly negative in float32); the
+    device kernel then applies max(1, min(#unknown - 1, .)) per image."""
+    ratio = 1.0 * (step + 1) / timesteps
+    return int((seq_len * noise_schedule(torch.tensor(ratio))).floor())
+
+
+def decode_seed(generator: Optional[torch.Generator]) -> int:
+    """64-bit key for the in-kernel Philox stream of one generate2 call: two draws from `generator` (on its own device;
+    one host read per call), so a seeded generator reproduces the sample and successive calls differ; without a generator
+    the key comes from torch's global CPU generator"""
+    dev = generator.device if generator is not None else "cpu"
+    hi, lo = torch.randint(0, 2 ** 31, (2,), generator=generator, device=dev).tolist()
+    return (int(hi) << 32) | int(lo)
+
+
+def step_noise(noise: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]], step: int):
+    """(exponential draws [B*S, V], uniform draws [B, S]) of one step when the caller replays a recorded stream, else (None, None)"""
+    if noise is None:
+        return None, None
+    q, u = noise[step]
+    return q, u

@@ -40,6 +40,67 @@ def prepare_inputs_and_labels(vq_model, pixel_values, class_ids, mask_id, min_ma
     return input_ids, labels, None, mask_prob
 
 
+def mask_or_random_replace_tokens(image_tokens, mask_id, config, mask_schedule=None, is_train=True, *, timesteps=None, noise=None,
+                                  rects=None, generator=None):
+    """training/train_muse.py:149-226 on the device (muse_mask_tokens), same signature and return value
+    `(input_ids, labels, loss_weight, mask_prob)`; `config` is read like the reference reads its OmegaConf node
+    (`config.training.get(...)`, `config.training.min_masking_rate`).
+
+    Host-side randomness follows the reference: `random.choices` for eval_mask_ratios, `random.random()` /
+    `random.randint` for the contiguous-region coin and rectangle (which costs the reference - and this function - one
+    device read of the per-image mask counts); the two device draws (`timesteps` [B], `noise` [B, S]) can be passed in for
+    bit-reproducible masks.  The reference's `noise_type` test (:202) is always true, so "random_replace" also writes the mask
+    id; that is kept."""
+    import math
+    import random
+    tr = config.training
+    B, S = image_tokens.shape
+    dev = image_tokens.device
+    mask_prob_in = None
+    if not is_train and tr.get("eval_mask_ratios", None):
+        mask_prob_in = torch.tensor(random.choices(tr.eval_mask_ratios, k=B), device=dev)
+    elif timesteps is None:
+        timesteps = torch.rand(B, device=dev, generator=generator)
+    if mask_prob_in is None and mask_schedule is not None:
+        from .sampling import cosine_schedule
+        if mask_schedule is not cosine_schedule:       # any other schedule: evaluate it like the reference does (:160-161)
+            mask_prob_in = mask_schedule(timesteps.float()).clip(tr.min_masking_rate)
+    region_p = tr.get("mask_contiguous_region_prob", None)
+    region = region_p is not None and random.random() < region_p
+    if region and rects is None:
+        mp = mask_prob_in if mask_prob_in is not None else torch.cos(timesteps.float() * (math.pi * 0.5)).clip(tr.min_masking_rate)
+        counts = (S * mp).round().clamp(min=1).tolist()
+        res = int(S ** 0.5)
+        boxes = []
+        for n in counts:                                # :186-199, the reference's "a bit handwavy" rectangle
+            n = int(n)
+            h = min(random.randint(math.ceil(n / res), min(res, n)), res)
+            w = min(math.ceil(n / h), res)
+            boxes.append([random.randint(0, res - h), random.randint(0, res - w), h, w])
+        rects = torch.tensor(boxes, dtype=torch.int32)
+    if not region:
+        rects = None
+        if noise is None:
+            noise = torch.rand(B, S, device=dev, generator=generator)
+    all_labels = bool(tr.get("predict_all_tokens", False)) or tr.get("noise_type", "mask") == "random_replace"
+    input_ids, labels, loss_weight, mask_prob = ops.mask_tokens(
+        image_tokens, int(mask_id), timesteps=None if mask_prob_in is not None else timesteps, mask_prob=mask_prob_in, noise=noise,
+        rects=rects, min_masking_rate=float(tr.min_masking_rate), all_labels=all_labels, want_weight=all_labels)
+    return input_ids, labels, loss_weight, mask_prob
+
+
+def cond_dropout(encoder_hidden_states, clip_embeds, empty_embeds, empty_clip_embeds, cond_dropout_prob, uniforms=None,
+                 generator=None):
+    """training/train_muse.py:715-731: one uniform per image decides, for the text states and the pooled embedding alike,
+    whether the conditioning is kept (u < p) or replaced by the empty-prompt embedding -> (encoder_hidden_states, cond_embeds)"""
+    B = encoder_hidden_states.shape[0]
+    if uniforms is None:
+        uniforms = torch.rand(B, device=encoder_hidden_states.device, generator=generator)
+    enc = ops.cond_dropout(encoder_hidden_states, empty_embeds, uniforms, cond_dropout_prob).view(encoder_hidden_states.shape)
+    cond = ops.cond_dropout(clip_embeds, empty_clip_embeds, uniforms, cond_dropout_prob).view(clip_embeds.shape)
+    return enc, cond
+
+
 def _owner_of(params):
     """the muse.MaskGitTransformer that owns all `params` in its flat buffer, or None when the parameters are ordinary tensors
     (muse.MaskGiTUViT): those are stepped one launch per tensor with the same kernel"""

@@ -272,3 +272,98 @@ def train_step(vq_sd: SD, vq_cfg: dict, tr_sd: SD, tr_cfg: dict, pixel_values: T
     logits, loss, grads = transformer_loss_and_grads(tr_sd, tr_cfg, input_ids, labels, label_smoothing)
     return dict(tokens=tokens, input_ids=input_ids, labels=labels, mask_prob=mask_prob, logits=logits, loss=loss,
                 grads=grads)
+
+
+# ----------------------------------------------------------------------------------------------
+# MaskGit parallel decoding with explicit random draws  (muse/modeling_transformer.py:1363-1456, muse/sampling.py)
+# ----------------------------------------------------------------------------------------------
+def _clamp_log(t: Tensor, eps: float = 1e-20) -> Tensor:
+    # muse/sampling.py:9-10
+    return torch.log(t.clamp(min=eps))
+
+
+def sample_step(logits: Tensor, input_ids: Tensor, mask_id: int, temperature, sched_mask_len: int, q_exp: Tensor, u: Tensor):
+    """One decoding iteration on codebook-sliced logits [B, S, V] with the random draws made explicit:
+    q_exp [B*S, V] = the Exp(1) draws torch.multinomial(num_samples=1) makes internally (it returns argmax(probs / q):
+    ATen multinomial_out, "fast path for one sample"), u [B, S] = the uniform draws of gumbel_noise (muse/sampling.py:13-15).
+    muse/modeling_transformer.py:1425-1454; mask_by_random_topk muse/sampling.py:30-35.
+    -> (raw samples, sampled ids with known tokens restored, next input ids)"""
+    B, S, V = logits.shape
+    probs = logits.softmax(dim=-1)
+    raw = torch.argmax(probs.reshape(-1, V) / q_exp.reshape(-1, V), dim=-1).view(B, S)
+    unknown_map = input_ids == mask_id
+    sampled = torch.where(unknown_map, raw, input_ids)
+    selected = torch.gather(probs, -1, sampled.long()[..., None]).squeeze(-1)
+    selected = torch.where(unknown_map, selected, torch.finfo(selected.dtype).max)
+    mask_len = torch.tensor([[float(sched_mask_len)]])
+    mask_len = torch.max(torch.tensor([1]), torch.min(unknown_map.sum(dim=-1, keepdim=True) - 1, mask_len))
+    gumbel = -_clamp_log(-_clamp_log(u))
+    confidence = _clamp_log(selected) + temperature * gumbel
+    cut_off = torch.gather(torch.sort(confidence, dim=-1).values, 1, mask_len.long())
+    masking = confidence < cut_off
+    return raw, sampled, torch.where(masking, mask_id, sampled)
+
+
+def generate2(sd: SD, cfg: dict, class_ids: Tensor, timesteps: int, temperature: float, noise, input_ids: Optional[Tensor] = None):
+    """MaskGitTransformer.generate2 (class-conditional path, guidance off), muse/modeling_transformer.py:1363-1456.
+    noise[step] = (q_exp [B*S, codebook_size], u [B, S]).  -> (final sampled ids, list of the input_ids fed to each step)"""
+    mask_id, S, V = cfg["vocab_size"] - 1, cfg["num_vq_tokens"], cfg["codebook_size"]
+    B = len(class_ids)
+    cls = class_ids + V                                                      # :1388-1389
+    if input_ids is None:
+        input_ids = torch.full((B, S), mask_id, dtype=torch.long)            # :1392-1393
+    fed, sampled = [], input_ids
+    for step in range(timesteps):
+        fed.append(input_ids)
+        logits = transformer_forward(sd, cfg, torch.cat([cls[:, None], input_ids], dim=1))
+        logits = logits[..., :V][:, 1:]                                      # :1416-1421
+        ratio = 1.0 * (step + 1) / timesteps
+        mask_ratio = cosine_schedule(torch.tensor(ratio))
+        sched = int((S * mask_ratio).floor())
+        temperature = temperature * (1.0 - ratio)                            # :1451 (compounds across steps)
+        q, u = noise[step]
+        _, sampled, input_ids = sample_step(logits, input_ids, mask_id, temperature, sched, q, u)
+    return sampled, fed
+
+
+# ----------------------------------------------------------------------------------------------
+# training/train_muse.py: masking variants and conditioning dropout
+# ----------------------------------------------------------------------------------------------
+def mask_or_random_replace_tokens(image_tokens: Tensor, mask_id: int, min_masking_rate: float, *, timesteps: Optional[Tensor] = None,
+                                  mask_prob: Optional[Tensor] = None, noise: Optional[Tensor] = None, rects: Optional[Tensor] = None,
+                                  all_labels: bool = False):
+    """training/train_muse.py:149-226 with the draws explicit.  timesteps -> cosine schedule clipped to min_masking_rate
+    (:157-161), or mask_prob given directly (eval_mask_ratios, :152-154).  Random mask: argsort(noise) < k (:175-176);
+    contiguous region: rects [B, 4] = (y0, x0, h, w) on the sqrt(S) grid (:178-199; the reference draws them with `random`).
+    input_ids = mask_id where masked - the `noise_type` test at :202 is always true, so there is no random-replace branch.
+    all_labels (predict_all_tokens or noise_type == "random_replace", :212-217): labels = tokens and
+    loss_weight = 1 - (1 - mask) * ((1 - mask_prob) * (1 - 0.3)) (:145-146), else labels = -100 outside the mask, no weight."""
+    B, S = image_tokens.shape
+    if mask_prob is None:
+        mask_prob = cosine_schedule(timesteps).clip(min_masking_rate)
+    num_token_masked = (S * mask_prob).round().clamp(min=1)
+    if rects is None:
+        mask = noise.argsort(dim=-1) < num_token_masked.unsqueeze(-1)
+    else:
+        side = int(S ** 0.5)
+        mask = torch.zeros((B, side, side))
+        for b in range(B):
+            y0, x0, h, w = (int(v) for v in rects[b])
+            mask[b, y0:y0 + h, x0:x0 + w] = 1
+        mask = mask.reshape(B, S).to(torch.bool)
+    input_ids = torch.where(mask, mask_id, image_tokens)
+    if all_labels:
+        labels = image_tokens
+        loss_weight = 1 - (1 - mask.long()) * ((1 - mask_prob) * (1 - 0.3))[:, None]
+    else:
+        labels = torch.where(mask, image_tokens, -100)
+        loss_weight = None
+    return input_ids, labels, loss_weight, mask_prob
+
+
+def cond_dropout(x: Tensor, empty: Tensor, uniforms: Tensor, prob: float) -> Tensor:
+    """training/train_muse.py:715-731: mask = u < p, shaped to broadcast over one image's embedding; where (x * mask) is
+    non-zero keep x, else the empty embedding (so the conditioning survives with probability p, element-wise zeros excepted)."""
+    B = x.shape[0]
+    mask = (uniforms.reshape(B, *([1] * (x.dim() - 1))) < prob)
+    return torch.where((x * mask).bool(), x, empty.expand(B, *empty.shape[-(x.dim() - 1):]))

@@ -202,3 +202,42 @@ def uvit_loss_and_grads(sd: SD, cfg: dict, input_ids: Tensor, encoder_hidden_sta
                                 label_smoothing, loss_weight)
     loss.backward()
     return logits.detach(), loss.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+
+
+def generate2(sd: SD, cfg: dict, encoder_hidden_states: Tensor, cond_embeds: Tensor, micro_conds: Tensor, empty_embeds: Tensor,
+              empty_cond_embeds: Tensor, timesteps: int, temperature, guidance_scale: float, noise, seq_len: int):
+    """MaskGiTUViT_v2.generate2 (muse/modeling_transformer_v2.py:330-479), guidance_schedule None, cosine noise schedule, with
+    the random draws explicit: noise[step] = (q_exp [B*S, codebook], u [B, S]) (see maskgit_oracle.sample_step).
+    -> (final sampled ids, per-step raw samples = the reference's `intermediate`)"""
+    from .maskgit_oracle import cosine_schedule, sample_step
+    B, S, V = encoder_hidden_states.shape[0], seq_len, cfg["codebook_size"]
+    mask_id = cfg["vocab_size"] - 1
+    temperatures = (torch.linspace(temperature[0], temperature[1], timesteps) if isinstance(temperature, tuple)
+                    else torch.linspace(temperature, 0.01, timesteps))                       # :359-362
+    scales = torch.ones(timesteps) * guidance_scale                                          # :381
+    input_ids = torch.ones((B, S), dtype=torch.long) * mask_id
+    if micro_conds.shape[0] == 1:
+        micro_conds = micro_conds.repeat(B, 1)
+    if guidance_scale > 0:                                                                   # :386-412
+        enc = torch.cat([encoder_hidden_states, empty_embeds.expand(B, -1, -1) if empty_embeds.shape[0] == 1 else empty_embeds])
+        cond = torch.cat([cond_embeds, empty_cond_embeds.expand(B, -1) if empty_cond_embeds.shape[0] == 1 else empty_cond_embeds])
+        micro = torch.cat([micro_conds, micro_conds], dim=0)
+    else:
+        enc, cond, micro = encoder_hidden_states, cond_embeds, micro_conds
+    intermediate, sampled = [], input_ids
+    for step in range(timesteps):
+        model_input = torch.cat([input_ids] * 2) if guidance_scale > 0 else input_ids
+        out = uvit_forward(sd, cfg, model_input, enc, cond, micro)
+        out = out[0] if isinstance(out, tuple) else out
+        if guidance_scale > 0:
+            cond_logits, uncond_logits = out.chunk(2)
+            cond_logits, uncond_logits = cond_logits[..., :V], uncond_logits[..., :V]
+            logits = uncond_logits + scales[step] * (cond_logits - uncond_logits)           # :431-436
+        else:
+            logits = out[..., :V]
+        ratio = 1.0 * (step + 1) / timesteps
+        sched = int((S * cosine_schedule(torch.tensor(ratio))).floor())
+        q, u = noise[step]
+        raw, sampled, input_ids = sample_step(logits, input_ids, mask_id, temperatures[step], sched, q, u)
+        intermediate.append(raw)
+    return sampled, intermediate

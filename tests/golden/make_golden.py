@@ -148,6 +148,169 @@ def golden_uvit(name, cfg, batch, seq, text_len, seed):
     print(name, "loss", float(loss), "weighted", float(loss_w), "logits", tuple(logits.shape), "max|logit|", float(logits.abs().max()))
 
 
+def replay_decode_noise(seed, steps, rows, seq, vocab):
+    """the draws a reference generate2 call makes from torch.Generator().manual_seed(seed), per step: torch.multinomial(probs
+    [rows*seq, vocab], 1) fills an Exp(1) tensor of the probabilities' shape (ATen multinomial_out, one-sample fast path), then
+    gumbel_noise (muse/sampling.py:13-15) fills a uniform [rows, seq] tensor"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(steps):
+        q = torch.empty(rows * seq, vocab).exponential_(1, generator=g)
+        u = torch.zeros(rows, seq).uniform_(0, 1, generator=g)
+        out.append((q, u))
+    return out
+
+
+def golden_generate2(name, cfg, batch, seed, timesteps, temperature):
+    """MaskGitTransformer.generate2 of the real reference (muse/modeling_transformer.py:1363-1456) with a seeded CPU generator;
+    the file records the generator's draws (replayed, and checked against the reference's own output through the oracle)."""
+    from oracle import maskgit_oracle as O
+    model = ref_muse.MaskGitTransformer(**cfg)
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    rng = np.random.default_rng(seed + 1)
+    class_ids = torch.from_numpy(rng.integers(0, cfg["num_classes"], size=(batch,)).astype(np.int64))
+    with torch.no_grad():
+        ids = model.generate2(class_ids=class_ids.clone(), timesteps=timesteps, temperature=temperature,
+                              generator=torch.Generator().manual_seed(seed + 2))
+    S, V = cfg["num_vq_tokens"], cfg["codebook_size"]
+    noise = replay_decode_noise(seed + 2, timesteps, batch, S, V)
+    with torch.no_grad():
+        ids_o, fed = O.generate2(sd, cfg, class_ids, timesteps, temperature, noise)
+    assert torch.equal(ids, ids_o), "replayed draws do not reproduce the reference's sample"
+    out = dict(class_ids=np_(class_ids), ids=np_(ids), timesteps=np.int64(timesteps), temperature=np.float32(temperature),
+               seed=np.int64(seed), batch=np.int64(batch))
+    for i, (q, u) in enumerate(noise):
+        out[f"q{i}"], out[f"u{i}"], out[f"fed{i}"] = np_(q), np_(u), np_(fed[i])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ids", ids[0, :8].tolist(), "masked fed to last step", int((fed[-1] == cfg["vocab_size"] - 1).sum()))
+
+
+def golden_uvit_generate2(name, cfg, batch, seq, text_len, seed, timesteps, temperature, guidance_scale):
+    """MaskGiTUViT_v2.generate2 (muse/modeling_transformer_v2.py:330-479) of the real reference with classifier-free guidance,
+    on the parameters of uvit_tiny.npz; records the generator's draws and the per-step raw samples (`intermediate`)."""
+    from muse.modeling_transformer_v2 import MaskGiTUViT_v2
+    from oracle import uvit_oracle as UO
+    gold = np.load(os.path.join(HERE, "uvit_tiny.npz"))
+    model = MaskGiTUViT_v2(**cfg)
+    sd = {k[len("param."):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("param.")}
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    g = torch.Generator().manual_seed(seed)
+    enc = torch.randn(batch, text_len, cfg["encoder_hidden_size"], generator=g)
+    cond = torch.randn(batch, cfg["cond_embed_dim"], generator=g)
+    empty, empty_c = torch.randn(1, text_len, cfg["encoder_hidden_size"], generator=g), torch.randn(1, cfg["cond_embed_dim"], generator=g)
+    micro = torch.tensor([[256.0, 256.0, 0.0, 0.0, 6.0]])
+    with torch.no_grad():
+        ids, inter = model.generate2(enc, cond, micro, empty, empty_c, timesteps=timesteps, temperature=temperature,
+                                     guidance_scale=guidance_scale, generator=torch.Generator().manual_seed(seed + 1),
+                                     return_intermediate=True, seq_len=seq)
+    noise = replay_decode_noise(seed + 1, timesteps, batch, seq, cfg["codebook_size"])
+    ocfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}
+    with torch.no_grad():
+        ids_o, inter_o = UO.generate2(sd, ocfg, enc, cond, micro, empty, empty_c, timesteps, temperature, guidance_scale, noise, seq)
+    assert torch.equal(ids, ids_o) and all(torch.equal(a, b) for a, b in zip(inter, inter_o)), "replay != reference"
+    out = dict(encoder_hidden_states=np_(enc), cond_embeds=np_(cond), empty_embeds=np_(empty), empty_cond_embeds=np_(empty_c),
+               micro_conds=np_(micro), ids=np_(ids), timesteps=np.int64(timesteps), guidance_scale=np.float32(guidance_scale),
+               temperature=np.array(temperature, dtype=np.float32), seq=np.int64(seq))
+    for i, (q, u) in enumerate(noise):
+        out[f"q{i}"], out[f"u{i}"], out[f"raw{i}"] = np_(q), np_(u), np_(inter[i])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ids", ids[0, :8].tolist())
+
+
+def _reference_function(path, *names):
+    """compile selected top-level functions of a reference source file WITHOUT importing the module (training/train_muse.py
+    imports wandb / omegaconf / webdataset at module level, none of which exist in this container)"""
+    import ast
+    import math
+    import random
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch, "math": math, "random": random}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+class _Cfg(dict):
+    """attribute + .get access like the OmegaConf node the reference function receives"""
+    __getattr__ = dict.__getitem__
+
+
+def golden_mask_muse(name, seed, batch=6, seq=16, mask_id=47, codebook_size=32):
+    """training/train_muse.py:149-226 mask_or_random_replace_tokens of the real reference (function body compiled from the
+    file), its torch.rand draws replaced by recorded tensors, for every branch: default / predict_all_tokens / random_replace /
+    contiguous region / eval mask ratios."""
+    import random
+    ns = _reference_function("/root/reference/training/train_muse.py", "mask_or_random_replace_tokens", "get_loss_weight")
+    fn = ns["mask_or_random_replace_tokens"]
+    rng = np.random.default_rng(seed)
+    tokens = torch.from_numpy(rng.integers(0, codebook_size, size=(batch, seq)).astype(np.int64))
+    out = dict(tokens=np_(tokens), mask_id=np.int64(mask_id), codebook_size=np.int64(codebook_size))
+    cases = {
+        "default": dict(training=_Cfg(min_masking_rate=0.1)),
+        "predict_all": dict(training=_Cfg(min_masking_rate=0.0, predict_all_tokens=True)),
+        "random_replace": dict(training=_Cfg(min_masking_rate=0.25, noise_type="random_replace")),
+        "region": dict(training=_Cfg(min_masking_rate=0.0, mask_contiguous_region_prob=1.0)),
+        "eval_ratios": dict(training=_Cfg(min_masking_rate=0.0, eval_mask_ratios=[0.2, 0.55, 0.9])),
+    }
+    real_rand = torch.rand
+    for i, (cname, c) in enumerate(cases.items()):
+        cfg = _Cfg(model=_Cfg(codebook_size=codebook_size), **c)
+        draws = [W.uniforms((batch,), seed + 10 * i + 1), W.uniforms((batch, seq), seed + 10 * i + 2)]
+        queue = list(draws) if cname != "eval_ratios" else [draws[1]]   # (eval_mask_ratios draws mask_prob with random.choices)
+        torch.rand = lambda *a, **k: queue.pop(0)          # the function's torch.rand calls, in order (:157, :175)
+        random.seed(seed + i)
+        try:
+            ids, labels, lw, mp = fn(tokens, mask_id, cfg, cosine_schedule, is_train=(cname != "eval_ratios"))
+        finally:
+            torch.rand = real_rand
+        out[cname + ".input_ids"], out[cname + ".labels"], out[cname + ".mask_prob"] = np_(ids), np_(labels), np_(mp.float())
+        out[cname + ".timesteps"], out[cname + ".noise"] = np_(draws[0]), np_(draws[1])
+        out[cname + ".min_rate"] = np.float32(c["training"]["min_masking_rate"])
+        if lw is not None:
+            out[cname + ".loss_weight"] = np_(lw)
+        if cname == "region":   # the rectangle each image received: the bounding box of its mask
+            m = (ids == mask_id).view(batch, int(seq ** 0.5), -1)
+            rects = []
+            for b in range(batch):
+                ys, xs = torch.nonzero(m[b].any(1)).flatten(), torch.nonzero(m[b].any(0)).flatten()
+                rects.append([int(ys[0]), int(xs[0]), int(ys[-1] - ys[0] + 1), int(xs[-1] - xs[0] + 1)])
+                assert int(m[b].sum()) == rects[-1][2] * rects[-1][3]
+            out["region.rects"] = np.array(rects, dtype=np.int32)
+        print(name, cname, "masked per image", (ids == mask_id).sum(-1).tolist())
+    # conditioning dropout, training/train_muse.py:715-731: the statements themselves, executed on recorded tensors
+    lines = open("/root/reference/training/train_muse.py").read().split("\n")[715:731]     # `assert` .. `cond_embeds = ...`
+    import textwrap
+    g = torch.Generator().manual_seed(seed + 99)
+    B, L, D = 5, 3, 8
+    enc = torch.randn(B, L, D, generator=g)
+    enc[1, 0, :4] = 0.0                                    # exact zeros: they take the empty embedding's value even when kept
+    clip = torch.randn(B, D, generator=g)
+    empty, empty_clip = torch.randn(1, L, D, generator=g), torch.randn(1, D, generator=g)
+    u = W.uniforms((B,), seed + 98)
+
+    class _Z:   # torch.zeros(...).float().uniform_(0, 1) -> the recorded draws, shaped like the zeros tensor
+        def __init__(self, shape): self.shape = shape
+        def float(self): return self
+        def uniform_(self, a, b): return u.reshape(self.shape)
+    env = dict(torch=torch, config=_Cfg(training=_Cfg(cond_dropout_prob=0.6)), encoder_hidden_states=enc, clip_embeds=clip,
+               empty_embeds=empty, empty_clip_embeds=empty_clip)
+    real_zeros = torch.zeros
+    torch.zeros = lambda shape, device=None: _Z(shape)
+    try:
+        exec(textwrap.dedent("\n".join(lines)), env)
+    finally:
+        torch.zeros = real_zeros
+    out.update({"cd.enc": np_(enc), "cd.clip": np_(clip), "cd.empty": np_(empty), "cd.empty_clip": np_(empty_clip), "cd.u": np_(u),
+                "cd.prob": np.float32(0.6), "cd.enc_out": np_(env["encoder_hidden_states"]), "cd.clip_out": np_(env["cond_embeds"])})
+    print(name, "cond dropout kept", (u < 0.6).tolist())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 if __name__ == "__main__":
     golden_transformer("transformer_tiny", W.TRANSFORMER_TINY, batch=3, seed=100, label_smoothing=0.0)
     golden_transformer("transformer_tiny_ls", W.TRANSFORMER_TINY, batch=2, seed=110, label_smoothing=0.1)
@@ -156,3 +319,8 @@ if __name__ == "__main__":
     golden_mask("mask_b64", batch=64, seq=256, seed=300, mask_id=2047, codebook_size=1024, min_rate=0.0)
     golden_mask("mask_small", batch=5, seq=16, seed=310, mask_id=47, codebook_size=32, min_rate=0.3)
     golden_uvit("uvit_tiny", UVIT_TINY, batch=2, seq=16, text_len=7, seed=400)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))   # the repo root, for `oracle`
+    golden_generate2("generate2_tiny", W.TRANSFORMER_TINY, batch=3, seed=500, timesteps=6, temperature=4.5)
+    golden_uvit_generate2("uvit_generate2_tiny", UVIT_TINY, batch=2, seq=16, text_len=7, seed=520, timesteps=5, temperature=(2, 0),
+                          guidance_scale=3.0)
+    golden_mask_muse("mask_muse", seed=540)

@@ -1,0 +1,163 @@
+"""GPU (-m gpu): SURVEY.md section 8 "next" rows f2 / f3 on the HIP path:
+  * muse_sample_step (one MaskGit decoding iteration) against the CPU oracle with the same random draws, bit-exact ids;
+  * MaskGitTransformer.generate2 / MaskGiTUViT.generate2 against the REAL reference's output (tests/golden: the reference ran
+    with a seeded CPU generator, the golden records the generator's draws), bit-exact ids;
+  * muse_mask_tokens / muse_cond_dropout against the real reference's mask_or_random_replace_tokens / cond-dropout statements
+    (training/train_muse.py:149-226, :715-731), bit-exact.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from muse import ops
+    return ops
+
+
+def _noise(g, steps):
+    return [(torch.from_numpy(g[f"q{i}"]), torch.from_numpy(g[f"u{i}"])) for i in range(steps)]
+
+
+@pytest.mark.parametrize("B,S,V,ld,guided", [(3, 16, 32, 48, False), (4, 256, 1024, 2048, False), (2, 256, 8192, 8192, True),
+                                             (2, 1024, 8192, 8192, True)])
+def test_sample_step_vs_oracle(B, S, V, ld, guided):
+    """softmax -> categorical (exponential race) -> confidence + Gumbel -> k-th smallest -> re-mask, same draws as the oracle"""
+    from oracle import maskgit_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(1234 + S + V)
+    cond = torch.randn(B, S, ld, generator=g) * 2.0
+    unc = torch.randn(B, S, ld, generator=g) * 2.0 if guided else None
+    scale = 3.0
+    mask_id = V + 7
+    ids = torch.where(torch.rand(B, S, generator=g) < 0.7, torch.full((B, S), mask_id), torch.randint(0, V, (B, S), generator=g))
+    ids[0, :] = mask_id                                   # one image fully masked
+    q = torch.empty(B * S, V).exponential_(1, generator=g)
+    u = torch.rand(B, S, generator=g)
+    for temperature, sched in ((4.5, S // 2), (0.0, -1), (1.3, 3)):
+        logits = (unc + scale * (cond - unc)) if guided else cond
+        raw_o, samp_o, next_o = O.sample_step(logits[..., :V], ids, mask_id, temperature, sched, q, u)
+        samp, nxt, raw = ops.sample_step(cond.to(DEV), ids.to(DEV), mask_id, V, temperature, sched,
+                                         uncond_logits=unc.to(DEV) if guided else None, guidance_scale=scale,
+                                         noise_exp=q.to(DEV), noise_u=u.to(DEV), want_raw=True)
+        assert torch.equal(raw.cpu(), raw_o) and torch.equal(samp.cpu(), samp_o) and torch.equal(nxt.cpu(), next_o), (temperature, sched)
+
+
+def test_sample_step_device_rng():
+    """without supplied draws the kernel's Philox stream is used: reproducible for a seed, different per step / seed, and the
+    categorical frequencies follow the softmax"""
+    ops = _ops()
+    B, S, V = 64, 256, 16
+    logits = torch.log(torch.tensor([0.4, 0.2, 0.1, 0.1] + [0.2 / 12] * 12)).repeat(B, S, 1).contiguous().to(DEV)
+    ids = torch.full((B, S), 99, dtype=torch.long, device=DEV)
+    a, na, _ = ops.sample_step(logits, ids, 99, V, 1.0, S // 2, seed=42, step=3)
+    b, nb, _ = ops.sample_step(logits, ids, 99, V, 1.0, S // 2, seed=42, step=3)
+    c, _, _ = ops.sample_step(logits, ids, 99, V, 1.0, S // 2, seed=42, step=4)
+    d, _, _ = ops.sample_step(logits, ids, 99, V, 1.0, S // 2, seed=43, step=3)
+    assert torch.equal(a, b) and torch.equal(na, nb)
+    assert not torch.equal(a, c) and not torch.equal(a, d)
+    freq = torch.bincount(a.flatten().cpu(), minlength=V).double() / (B * S)
+    assert abs(float(freq[0]) - 0.4) < 0.02 and abs(float(freq[1]) - 0.2) < 0.02 and abs(float(freq[4:].sum()) - 0.2) < 0.02
+    assert int((na == 99).sum(-1).min()) == S // 2 and int((na == 99).sum(-1).max()) == S // 2   # exactly mask_len re-masked, no ties
+
+
+def test_generate2_vs_reference_golden(golden_dir):
+    """the reference's MaskGitTransformer.generate2 sample (6 steps, temperature 4.5, seeded generator) reproduced id for id"""
+    import muse
+    g = np.load(os.path.join(golden_dir, "generate2_tiny.npz"))
+    cfg = W.TRANSFORMER_TINY
+    m = muse.MaskGitTransformer(**cfg)
+    m.load_state_dict(W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer"))
+    m.to(DEV).eval().set_compute_dtype(torch.float32)
+    T = int(g["timesteps"])
+    cls = torch.from_numpy(g["class_ids"]).to(DEV)
+    ids = m.generate2(class_ids=cls, timesteps=T, temperature=float(g["temperature"]), noise=_noise(g, T))
+    assert torch.equal(ids.cpu(), torch.from_numpy(g["ids"]))
+    assert torch.equal(cls.cpu(), torch.from_numpy(g["class_ids"]) + cfg["codebook_size"])   # shifted in place like the reference
+    # production path (device RNG): valid ids, reproducible with a seeded generator, every token decoded
+    outs = [m.generate2(class_ids=torch.from_numpy(g["class_ids"]).to(DEV), timesteps=T, temperature=2.0,
+                        generator=torch.Generator(device=DEV).manual_seed(7)) for _ in range(2)]
+    assert torch.equal(outs[0], outs[1]) and int(outs[0].max()) < cfg["codebook_size"] and int(outs[0].min()) >= 0
+
+
+def test_uvit_generate2_vs_reference_golden(golden_dir):
+    """MaskGiTUViT_v2.generate2 of the reference with classifier-free guidance 3.0, temperature (2, 0), 5 steps: final ids and the
+    per-step raw samples (`intermediate`)"""
+    import muse
+    g = np.load(os.path.join(golden_dir, "uvit_generate2_tiny.npz"))
+    gp = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    m = muse.MaskGiTUViT(**cfg)
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(gp[k]) for k in gp.files if k.startswith("param.")}, strict=True)
+    m.to(DEV).eval()
+    T = int(g["timesteps"])
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("encoder_hidden_states", "cond_embeds", "micro_conds", "empty_embeds",
+                                                     "empty_cond_embeds")]
+    ids, inter = m.generate2(*args, timesteps=T, temperature=tuple(float(x) for x in g["temperature"]),
+                             guidance_scale=float(g["guidance_scale"]), return_intermediate=True, seq_len=int(g["seq"]),
+                             noise=_noise(g, T))
+    assert torch.equal(ids.cpu(), torch.from_numpy(g["ids"]))
+    for i in range(T):
+        assert torch.equal(inter[i].cpu(), torch.from_numpy(g[f"raw{i}"])), i
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+@pytest.mark.parametrize("case", ["default", "predict_all", "random_replace", "region", "eval_ratios"])
+def test_mask_or_random_replace_tokens_vs_reference(golden_dir, case):
+    """muse.mask_or_random_replace_tokens (device kernel + the reference's host-side `random` calls) == the reference function"""
+    import muse
+    g = np.load(os.path.join(golden_dir, "mask_muse.npz"))
+    tokens = torch.from_numpy(g["tokens"]).to(DEV)
+    tr = {"default": dict(min_masking_rate=0.1), "predict_all": dict(min_masking_rate=0.0, predict_all_tokens=True),
+          "random_replace": dict(min_masking_rate=0.25, noise_type="random_replace"),
+          "region": dict(min_masking_rate=0.0, mask_contiguous_region_prob=1.0),
+          "eval_ratios": dict(min_masking_rate=0.0, eval_mask_ratios=[0.2, 0.55, 0.9])}[case]
+    cfg = _Cfg(training=_Cfg(tr), model=_Cfg(codebook_size=int(g["codebook_size"])))
+    i = ["default", "predict_all", "random_replace", "region", "eval_ratios"].index(case)
+    random.seed(540 + i)                                  # the seed make_golden.py gave Python's `random` for this case
+    from muse.sampling import cosine_schedule
+    ids, labels, lw, mp = muse.mask_or_random_replace_tokens(
+        tokens, int(g["mask_id"]), cfg, cosine_schedule, is_train=case != "eval_ratios",
+        timesteps=torch.from_numpy(g[case + ".timesteps"]).to(DEV), noise=torch.from_numpy(g[case + ".noise"]).to(DEV))
+    assert torch.equal(ids.cpu(), torch.from_numpy(g[case + ".input_ids"])) and torch.equal(labels.cpu(), torch.from_numpy(g[case + ".labels"]))
+    # mask_prob is a logged float: the device evaluates cos() correctly rounded (f64), torch's CPU cosf may differ in the last ulp
+    assert torch.allclose(mp.cpu(), torch.from_numpy(g[case + ".mask_prob"]), rtol=3e-7, atol=0)
+    if case in ("predict_all", "random_replace"):
+        assert torch.allclose(lw.cpu(), torch.from_numpy(g[case + ".loss_weight"]), rtol=3e-7, atol=0)
+    else:
+        assert lw is None
+
+
+def test_mask_tokens_full_size_properties():
+    """seq 1024 (the 512^2 text-to-image regime), batch 64: every image has exactly round(S * cos(pi/2 t)) masked positions"""
+    ops = _ops()
+    B, S = 64, 1024
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randint(0, 8192, (B, S), generator=g)
+    t, nz = torch.rand(B, generator=g), torch.rand(B, S, generator=g)
+    ids, labels, lw, mp = ops.mask_tokens(tok.to(DEV), 8255, timesteps=t.to(DEV), noise=nz.to(DEV), min_masking_rate=0.05,
+                                          all_labels=True, want_weight=True)
+    k = (S * torch.cos(t * (np.pi * 0.5)).clip(0.05)).round().clamp(min=1).long()
+    assert torch.equal((ids.cpu() == 8255).sum(-1), k) and torch.equal(labels.cpu(), tok)
+    assert torch.equal(ids.cpu() == 8255, lw.cpu() == 1.0)
+    assert float(lw.min()) >= 0.3 - 1e-6
+
+
+def test_cond_dropout_vs_reference(golden_dir):
+    import muse
+    g = np.load(os.path.join(golden_dir, "mask_muse.npz"))
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)   # noqa: E731
+    enc, clip = muse.cond_dropout(t("cd.enc"), t("cd.clip"), t("cd.empty"), t("cd.empty_clip"), float(g["cd.prob"]), uniforms=t("cd.u"))
+    assert torch.equal(enc.cpu(), torch.from_numpy(g["cd.enc_out"])) and torch.equal(clip.cpu(), torch.from_numpy(g["cd.clip_out"]))

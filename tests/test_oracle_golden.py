@@ -96,3 +96,74 @@ def test_uvit_oracle_vs_reference_golden(golden_dir):
     assert abs(float(loss_w) - float(g["loss_weighted"])) < 1e-5 * abs(float(g["loss_weighted"]))
     # inference call signature: logits only
     assert U.uvit_forward(sd, cfg, *args).shape == ref_logits.shape
+
+
+# ---- "next" rows f2 / f3: decoding loop and train_muse masking, oracle vs the real reference -------------------------------
+def _noise(g, steps):
+    return [(torch.from_numpy(g[f"q{i}"]), torch.from_numpy(g[f"u{i}"])) for i in range(steps)]
+
+
+def test_generate2_oracle_vs_reference(golden_dir):
+    """MaskGitTransformer.generate2 of the real reference (seeded CPU generator) == the oracle fed with the replayed draws"""
+    g = _load(golden_dir, "generate2_tiny")
+    cfg = W.TRANSFORMER_TINY
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer")
+    T = int(g["timesteps"])
+    with torch.no_grad():
+        ids, fed = O.generate2(sd, cfg, torch.from_numpy(g["class_ids"]), T, float(g["temperature"]), _noise(g, T))
+    assert np.array_equal(ids.numpy(), g["ids"])
+    for i in range(T):
+        assert np.array_equal(fed[i].numpy(), g[f"fed{i}"])
+    mask_id = cfg["vocab_size"] - 1
+    masked = [int((g[f"fed{i}"] == mask_id).sum()) for i in range(T)]
+    assert masked[0] == g["ids"].size and all(a > b for a, b in zip(masked, masked[1:]))   # the schedule really unmasks step by step
+
+
+def test_uvit_generate2_oracle_vs_reference(golden_dir):
+    import json
+    from oracle import uvit_oracle as U
+    g = _load(golden_dir, "uvit_generate2_tiny")
+    gp = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    sd = {k[len("param."):]: torch.from_numpy(gp[k]) for k in gp.files if k.startswith("param.")}
+    T = int(g["timesteps"])
+    t = tuple(float(x) for x in g["temperature"])
+    with torch.no_grad():
+        ids, inter = U.generate2(sd, cfg, *(torch.from_numpy(g[k]) for k in ("encoder_hidden_states", "cond_embeds", "micro_conds",
+                                                                              "empty_embeds", "empty_cond_embeds")),
+                                 T, t, float(g["guidance_scale"]), _noise(g, T), int(g["seq"]))
+    assert np.array_equal(ids.numpy(), g["ids"])
+    for i in range(T):
+        assert np.array_equal(inter[i].numpy(), g[f"raw{i}"])
+
+
+@pytest.mark.parametrize("case", ["default", "predict_all", "random_replace", "region", "eval_ratios"])
+def test_mask_or_random_replace_tokens_oracle(golden_dir, case):
+    g = _load(golden_dir, "mask_muse")
+    tokens = torch.from_numpy(g["tokens"])
+    kw = dict(all_labels=case in ("predict_all", "random_replace"))
+    if case == "region":
+        kw.update(timesteps=torch.from_numpy(g[case + ".timesteps"]), rects=torch.from_numpy(g["region.rects"]))
+    elif case == "eval_ratios":
+        kw.update(mask_prob=torch.from_numpy(g[case + ".mask_prob"]), noise=torch.from_numpy(g[case + ".noise"]))
+    else:
+        kw.update(timesteps=torch.from_numpy(g[case + ".timesteps"]), noise=torch.from_numpy(g[case + ".noise"]))
+    ids, labels, lw, mp = O.mask_or_random_replace_tokens(tokens, int(g["mask_id"]), float(g[case + ".min_rate"]), **kw)
+    assert np.array_equal(ids.numpy(), g[case + ".input_ids"]) and np.array_equal(labels.numpy(), g[case + ".labels"])
+    np.testing.assert_array_equal(mp.numpy(), g[case + ".mask_prob"])
+    if kw["all_labels"]:
+        np.testing.assert_array_equal(lw.numpy(), g[case + ".loss_weight"])
+    else:
+        assert lw is None and (case + ".loss_weight") not in g.files
+
+
+def test_cond_dropout_oracle(golden_dir):
+    g = _load(golden_dir, "mask_muse")
+    u, p = torch.from_numpy(g["cd.u"]), float(g["cd.prob"])
+    enc = O.cond_dropout(torch.from_numpy(g["cd.enc"]), torch.from_numpy(g["cd.empty"]), u, p)
+    clip = O.cond_dropout(torch.from_numpy(g["cd.clip"]), torch.from_numpy(g["cd.empty_clip"]), u, p)
+    np.testing.assert_array_equal(enc.numpy(), g["cd.enc_out"])
+    np.testing.assert_array_equal(clip.numpy(), g["cd.clip_out"])
+    kept = (g["cd.u"] < p)
+    assert kept.any() and (~kept).any()
+    assert np.array_equal(g["cd.enc_out"][1, 0, :4], g["cd.empty"][0, 0, :4])    # kept image, exact-zero elements -> empty's values
