@@ -48,6 +48,24 @@ def golden_transformer(name, cfg, batch, seed, label_smoothing):
     print(name, "loss", float(loss), "logits", logits.shape)
 
 
+def golden_transformer_autocast(name, cfg, batch, seed):
+    """the same forward / backward under torch.autocast("cpu", bfloat16) - the regime accelerate's mixed_precision: bf16 puts the
+    reference in (training/train_maskgit_imagenet.py:152-158; SURVEY.md section 3.2 dtype flow).  It pins how far the reference's
+    OWN bf16 path sits from its f32 path, which is what the HIP bf16 mode's tolerances are derived from."""
+    model = ref_muse.MaskGitTransformer(**cfg)
+    model.load_state_dict(W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer"), strict=True)
+    model.train()
+    input_ids, labels = W.transformer_inputs(cfg, batch, seed + 1)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        logits, loss = model(input_ids=input_ids, labels=labels)
+    loss.float().backward()
+    out = dict(logits=np_(logits.float()), loss=np_(loss.float()), batch=np.int64(batch), seed=np.int64(seed))
+    for k, p in model.named_parameters():
+        out["grad." + k] = np_(p.grad.float())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", float(loss), "logits dtype", logits.dtype)
+
+
 def golden_vqgan(name, cfg, batch, seed):
     model = ref_muse.MaskGitVQGAN(**cfg)
     sd = W.fill_state_dict(W.vqgan_shapes(cfg), seed, "vqgan")
@@ -324,3 +342,5 @@ if __name__ == "__main__":
     golden_uvit_generate2("uvit_generate2_tiny", UVIT_TINY, batch=2, seq=16, text_len=7, seed=520, timesteps=5, temperature=(2, 0),
                           guidance_scale=3.0)
     golden_mask_muse("mask_muse", seed=540)
+    golden_transformer_autocast("transformer_tiny_bf16", W.TRANSFORMER_TINY, batch=3, seed=100)
+    golden_transformer_autocast("transformer_hd48_bf16", W.TRANSFORMER_HD48, batch=2, seed=120)
