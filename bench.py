@@ -12,12 +12,22 @@ autocast regime) and the frozen VQGAN tokenizer in its f32-class "bf16x3" mode: 
 as 3 bf16 MFMAs with f32 accumulation (error <= 2^-16 per product).  The reference keeps the VQGAN in f32 tensors, and
 its GPU path runs those convolutions in TF32 (torch.backends.cudnn.allow_tf32 defaults to True, configs/imagenet.yaml:86
 enable_tf32); gfx950 has no xf32 MFMA, bf16x3 is the tighter CDNA4 counterpart (token indices equal to the f32 oracle up
-to f32 near-ties: tests/test_gpu_models.py::test_vqgan_f16_256_vs_oracle).  At N=1 the line also carries, in `extra`, the
-same step with the exact-f32 MFMA tokenizer (`--vq-dtype f32`) and the pure-bf16 one; `--config A` = README-tiny model.
+to f32 near-ties: tests/test_gpu_models.py::test_vq_indices_over_bench_batch_vs_oracle; the count over this run's CPU-baseline
+images is in cpu_baseline.vq_index_mismatches).
+
+The line carries
+  roofline      the dominant kernel (live HIP-event timing of every launch of one instrumented step) against its roof; `traffic`
+                = HBM bytes per launch of that kernel from the committed PMC passes (profiles/r02_traffic.json, FETCH_SIZE x 2
+                + WRITE_SIZE as /opt/skills/guides/MI355X_MICROARCH.md prescribes), null when no such profile is in the tree
+  cpu_baseline  the CPU oracle (port of the reference path) on the node's host cores: warm-up + median of 3, per phase
+  extra         the north_star's own targets: transformer_mfma_frac (3 x forward GFLOP / transformer fwd+bwd time / 2.5 PF),
+                vqgan_hbm_frac (GroupNorm / pooling kernels vs 8 TB/s), the tokens-given step (pre-encoded tokens,
+                scripts/pre_encode.py regime), config 4 (MaskGiTUViT, seq 256 and 1024), config 5 (VQGAN encode -> decode), config A
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,9 +41,15 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8000.0                      # GB/s (spec; ~6300 achievable per the same guide)
 # algorithmic work per image, GFLOP
 GF_ENCODE = 128.63
 GF_FWD = {"A": 19.00, "B": 122.40}
+GF_UVIT_FWD = {256: 275.10, 1024: 1137.05}
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+# rocprof kernel name fragment of each instrumented kernel family (to look its counters up in TRAFFIC_JSON)
+KERNEL_OF = {"conv_bf16x3_dma": "cdma::conv_dma_kernel", "gemm_bf16_NN": "g256::kernel<unsigned short, 0, 0", "gemm_bf16_NT": "g256::kernel<unsigned short, 0, 1",
+             "gemm_bf16_TT": "g256::kernel<float, 1, 1", "conv_bf16x3": "conv_split_kernel", "attn_fwd_bf16": "attn_fwd_kernel"}
 
 
 def build_models(cfg_name, vq_dtype, device, seed):
@@ -88,8 +104,58 @@ def vqgan_roundtrip(device, bs):
     return out
 
 
-def cpu_baseline(cfg_name, bs=16):
-    """the CPU oracle (port of the reference path) on this node's host cores, one full train step at bs=16 (~10-20 s)"""
+def uvit_leg(device, batch, seq, steps=3):
+    """BASELINE.json config 4: configs/cc12m_uvit_clip.yaml MaskGiTUViT (729 M parameters, 22 layers, hidden 1024; block_num_heads
+    12 per SURVEY.md D3), synthetic CLIP states (77 x 768), tokens given, bf16 compute (fused self / cross attention, bf16 weight
+    copies refreshed inside the AdamW kernel): forward + backward + FusedAdamW"""
+    import muse
+    from muse import modeling_transformer_v2 as M
+    init = M.MaskGiTUViT_v2._init_weights
+    M.MaskGiTUViT_v2._init_weights = lambda self: None     # 729 M parameters: filled on the GPU below instead of on one CPU core
+    try:
+        model = muse.MaskGiTUViT(block_num_heads=12)
+    finally:
+        M.MaskGiTUViT_v2._init_weights = init
+    model.to(device).train().set_compute_dtype(torch.bfloat16)
+    g = torch.Generator(device=device).manual_seed(0)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.fill_(1.0) if n.endswith("norm.weight") else p.normal_(0.0, 0.02, generator=g)
+    opt = muse.FusedAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
+    ids = torch.randint(0, 8256, (batch, seq), device=device, generator=g)
+    labels = torch.where(torch.rand(batch, seq, device=device, generator=g) < 0.5,
+                         torch.randint(0, 8192, (batch, seq), device=device, generator=g), torch.full((batch, seq), -100, device=device))
+    enc = torch.randn(batch, 77, 768, device=device, generator=g)
+    cond = torch.randn(batch, 768, device=device, generator=g)
+    micro = torch.tensor([[256.0, 256.0, 0.0, 0.0, 6.0]], device=device).repeat(batch, 1)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        _, loss = model(ids, enc, cond, micro, labels=labels)
+        loss.backward()
+        opt.step()
+        return loss
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tf = 3 * GF_UVIT_FWD[seq] * batch / dt / 1e3
+    out = {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 1), "batch": batch, "seq_len": seq,
+           "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK["bf16"], 4), "loss": round(float(loss), 4),
+           "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(cfg_name, device, bs=4, reps=3):
+    """the CPU oracle (port of the reference path: BASELINE.json configs[0], bs = 4) on this node's host cores: one warm-up step,
+    then `reps` timed steps with per-phase times; median reported.  Each repetition tokenizes different images; the oracle's token
+    indices are compared with the HIP tokenizer's (the bench's bf16x3 mode) on the same images: vq_index_mismatches."""
+    import muse
     import weights as W
     from oracle import maskgit_oracle as O
     cores = min(os.cpu_count(), 32)  # torch CPU ops stop scaling (and oversubscribe) far below the 256 hw threads of the node
@@ -97,15 +163,51 @@ def cpu_baseline(cfg_name, bs=16):
     tcfg = dict(W.TRANSFORMER_A if cfg_name == "A" else W.TRANSFORMER_B)
     vsd = W.fill_state_dict(W.vqgan_shapes(W.VQGAN_F16), 1, "vqgan")
     tsd = W.fill_state_dict(W.transformer_shapes(tcfg), 2, "transformer")
-    px, cls = W.images(bs, 256, 3), torch.from_numpy(np.random.default_rng(4).integers(0, 1000, size=bs))
-    t, nz = W.uniforms((bs,), 5), W.uniforms((bs, 256), 6)
-    t0 = time.time()
-    out = O.train_step(vsd, W.VQGAN_F16, tsd, tcfg, px, cls, t, nz)
-    k = "mlm_layer.to_logits.weight"
-    O.adamw_step(tsd[k], out["grads"][k], torch.zeros_like(tsd[k]), torch.zeros_like(tsd[k]), 1, 1e-4, 0.9, 0.999, 1e-8, 0.01)
-    dt = time.time() - t0
-    return {"value": round(bs / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 train step, config {cfg_name}, bs={bs}, f32, oracle/maskgit_oracle.py on {cores} of {os.cpu_count()} host threads ({dt:.1f} s)"}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in tsd.items()}
+    vq = muse.MaskGitVQGAN(**W.VQGAN_F16)
+    vq.load_state_dict(vsd)
+    vq.to(device).eval().set_compute_dtype("bf16x3")
+    phases, mism, ntok = [], 0, 0
+    for r in range(reps + 1):
+        px, cls = W.images(bs, 256, 30 + r), torch.from_numpy(np.random.default_rng(40 + r).integers(0, 1000, size=bs))
+        t, nz = W.uniforms((bs,), 50 + r), W.uniforms((bs, 256), 60 + r)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            _, _, tokens = O.vqgan_encode(vsd, W.VQGAN_F16, px)
+            ids, labels, _ = O.prepare_inputs_and_labels(tokens, cls, t, nz, int(tcfg["vocab_size"]) - 1, 1024)
+        t1 = time.perf_counter()
+        leaf = {k: v.detach().clone().requires_grad_(True) for k, v in tsd.items()}
+        _, loss = O.transformer_forward(leaf, tcfg, ids, labels, 0.0)
+        t2 = time.perf_counter()
+        loss.backward()
+        t3 = time.perf_counter()
+        with torch.no_grad():
+            for k, p in tsd.items():
+                O.adamw_step(p, leaf[k].grad, mom[k][0], mom[k][1], r + 1, 1e-4, 0.9, 0.999, 1e-8, 0.01)
+        t4 = time.perf_counter()
+        if r:   # (r == 0 is the warm-up)
+            phases.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+        hip = vq.get_code(px.to(device)).cpu()
+        mism += int((hip != tokens).sum())
+        ntok += tokens.numel()
+    med = [statistics.median(p[i] for p in phases) for i in range(4)]
+    total = statistics.median(sum(p) for p in phases)
+    return {"value": round(bs / total, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"config {cfg_name} train step at bs={bs} (BASELINE.json configs[0]), f32, oracle/maskgit_oracle.py on {cores} of "
+                      f"{os.cpu_count()} host threads: 1 warm-up + median of {reps} steps ({total:.1f} s per step)",
+            "phase_s": {"vq_encode+mask": round(med[0], 2), "forward": round(med[1], 2), "backward": round(med[2], 2), "adamw": round(med[3], 2)},
+            "vq_index_mismatches": f"{mism} of {ntok} tokens (HIP bf16x3 tokenizer vs the f32 oracle, {reps + 1} x {bs} images)"}
+
+
+def traffic_of(kernel_family):
+    """HBM bytes per launch of a kernel family from the committed PMC passes (scripts/gpu_traffic_bench.sh -> profiles/r02_traffic.json)"""
+    if not os.path.exists(TRAFFIC_JSON) or kernel_family not in KERNEL_OF:
+        return None, None
+    t = json.load(open(TRAFFIC_JSON))
+    for name, v in t.get("kernels", {}).items():
+        if KERNEL_OF[kernel_family] in name:
+            return v["hbm_bytes_per_launch"], t.get("note")
+    return None, None
 
 
 def main():
@@ -116,9 +218,9 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B"])
     ap.add_argument("--vq-dtype", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="gradient all-reduce payload (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="also time config A and the bf16 tokenizer (N=1 only)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary bf16-tokenizer timing")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (config A / 4 / 5, tokenizer variants)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,104 +230,143 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torch.distributed.run (also with one rank)
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     import muse
     from muse import ops
 
-    def run(cfg_name, vq_dtype, steps, warmup, profile):
+    prof_bytes = {}
+
+    def run(cfg_name, vq_dtype, steps, warmup, profile=False, tokens_given=False):
         vq, model, opt, tcfg = build_models(cfg_name, vq_dtype, device, seed=1234)
-        reducer = muse.GradReducer(model) if world > 1 else None
+        reducer = muse.GradReducer(model, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32) if distributed else None
         step = muse.TrainStep(vq, model, opt, reducer)
         px, cls = synthetic_batch(args.batch, device, seed=1000 + rank)  # different data per rank (weak scaling)
+        toks = vq.get_code(px) if tokens_given else None
+
+        def one():
+            return step(None if tokens_given else px, cls, image_tokens=toks)
         loss = None
         for _ in range(warmup):
-            loss, _ = step(px, cls)
-        if world > 1:
+            loss, _ = one()
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            loss, _ = step(px, cls)
+            loss, mask_prob = one()
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if distributed:
             t = torch.tensor([el], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t)
-        prof = None
+            loss, _ = reducer.reduce_metrics(loss, mask_prob)     # the two logged scalars of the loop as one 2-float all-reduce
+        prof = tr_ms = None
         if profile:
             ops.profile_start()
-            step(px, cls)
-            prof = ops.profile_stop()
+            one()
+            prof = ops.profile_stop(with_kind=True)
+            prof_bytes.update(ops.PROF_BYTES)
+            # transformer forward + backward alone (tokens given, no optimizer): the north_star's "MaskGitTransformer step"
+            ids, labels, _, _ = muse.prepare_inputs_and_labels(vq, None, cls, model.config.mask_token_id, image_tokens=vq.get_code(px))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 3
+            for i in range(n + 1):
+                if i == 1:
+                    e0.record()
+                model.zero_grad(set_to_none=True)
+                _, l2 = model(input_ids=ids, labels=labels)
+                l2.backward()
+            e1.record()
+            torch.cuda.synchronize()
+            tr_ms = e0.elapsed_time(e1) / n
         lossv = float(loss)
         del step, vq, model, opt, reducer
         torch.cuda.empty_cache()
-        return el, lossv, prof
+        return el, lossv, prof, tr_ms
 
-    el, lossv, prof = run(args.config, args.vq_dtype, args.steps, args.warmup, profile=True)
+    el, lossv, prof, tr_ms = run(args.config, args.vq_dtype, args.steps, args.warmup, profile=True)
     ms = el / args.steps * 1e3
     value = args.batch * world * args.steps / el
 
-    # roofline of the dominant MFMA kernel, from live HIP-event timings of one instrumented step
+    # per-kernel roofline from live HIP-event timings of one instrumented step
     agg = {}
-    for name, fl, t in prof:
-        a = agg.setdefault(name, [0.0, 0.0, 0])
-        a[0] += fl; a[1] += t; a[2] += 1
-    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    for name, work, t, kind in prof:
+        a = agg.setdefault((name, kind), [0.0, 0.0, 0])
+        a[0] += work; a[1] += t; a[2] += 1
+    mfma = {k[0]: v for k, v in agg.items() if k[1] == "flop"}
+    hbm = {k[0]: v for k, v in agg.items() if k[1] == "byte"}
     kinds = {k: {"launches": v[2], "ms_total": round(v[1], 3), "avg_us": round(v[1] / v[2] * 1e3, 1),
-                 "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-    dname, (dfl, dms, dn) = dom
-    peak = PEAK["bf16" if "bf16" in dname else "f32"]
+                 "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][1])}
+    hbm_kinds = {k: {"launches": v[2], "ms_total": round(v[1], 3), "GBps": round(v[0] / (v[1] * 1e-3) / 1e9, 1),
+                     "frac_of_8TBps": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK, 3)} for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}
+    dname, (dfl, dms, dn) = max(mfma.items(), key=lambda kv: kv[1][1])
     x3 = dname.startswith("conv_bf16x3")
-    if x3:
-        peak = round(PEAK["bf16"] / 3.0, 1)  # three bf16 MFMAs per algorithmic f32 product
+    peak = round(PEAK["bf16"] / 3.0, 1) if x3 else PEAK["bf16" if "bf16" in dname else "f32"]
     ach = dfl / (dms * 1e-3) / 1e12
+    traffic, tnote = traffic_of(dname)
     roofline = {"bound": "mfma", "kernel": dname, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": dn, "avg_launch_us": round(dms / dn * 1e3, 1),
-                "peak_note": ("2500 dense bf16 MFMA TFLOP/s / 3: the bf16x3 algorithm issues three bf16 MFMAs per f32 product; "
-                              "achieved counts algorithmic flops (x3 = executed MFMA rate)") if x3 else "dense MFMA peak of the dtype",
+                "frac": round(ach / peak, 4), "traffic": traffic, "launches_per_step": dn, "avg_launch_us": round(dms / dn * 1e3, 1),
+                "peak_basis": ("issued bf16 MFMA / 3: 2500 dense bf16 TFLOP/s divided by the three bf16 MFMAs the bf16x3 algorithm issues "
+                               "per f32 product; `achieved` counts ALGORITHMIC flops (2*B*H*W*Cout*9*Cin), executed_mfma_tflops the issued "
+                               "ones; against the plain 2500 peak frac would be frac/3") if x3 else "dense MFMA peak of the operand dtype",
                 "executed_mfma_tflops": round(ach * (3 if x3 else 1), 1),
-                "per_kernel": kinds}
+                "algorithmic_bytes_per_launch": round(prof_bytes[dname] / dn) if dname in prof_bytes else None,
+                "traffic_source": tnote,
+                "per_kernel": kinds, "hbm_bound_kernels": hbm_kinds}
     gf_img = GF_ENCODE + 3 * GF_FWD[args.config]
-    extra = {"loss": round(lossv, 4), "algorithmic_gflop_per_image": gf_img,
+    tr_tf = 3 * GF_FWD[args.config] * args.batch / tr_ms   # GFLOP / ms = TFLOP/s
+    vq_hbm = [v for k, v in hbm.items() if k in ("groupnorm_silu", "avgpool2x2")]
+    vq_bytes, vq_ms = sum(v[0] for v in vq_hbm), sum(v[1] for v in vq_hbm)
+    extra = {"loss": round(lossv, 4), "algorithmic_gflop_per_image": round(gf_img, 2),
              "step_tflops_per_gpu": round(gf_img * args.batch / ms, 1),
-             "mfma_ms_in_instrumented_step": round(sum(v[1] for v in agg.values()), 2)}
+             "transformer_fwd_bwd_ms": round(tr_ms, 2), "transformer_tflops": round(tr_tf, 1),
+             "transformer_mfma_frac": round(tr_tf / PEAK["bf16"], 4),
+             "vqgan_hbm_GBps": round(vq_bytes / (vq_ms * 1e-3) / 1e9, 1) if vq_ms else None,
+             "vqgan_hbm_frac": round(vq_bytes / (vq_ms * 1e-3) / 1e9 / HBM_PEAK, 4) if vq_ms else None,
+             "vqgan_hbm_note": "GroupNorm+SiLU and 2x2 pooling kernels of the encoder: algorithmic bytes (each operand once) / their time / 8 TB/s",
+             "mfma_ms_in_instrumented_step": round(sum(v[1] for v in mfma.values()), 2),
+             "hbm_kernel_ms_in_instrumented_step": round(sum(v[1] for v in hbm.values()), 2)}
     if world == 1 and not args.no_extra:
+        n2 = max(3, args.steps // 2)
+        e2, _, _, _ = run(args.config, args.vq_dtype, n2, 2, tokens_given=True)
+        extra["images_per_s_tokens_given"] = round(args.batch * n2 / e2, 1)   # pre-encoded tokens (scripts/pre_encode.py regime)
         other = "A" if args.config == "B" else "B"
-        variants = [(args.config, d) for d in ("f32", "bf16x3", "bf16") if d != args.vq_dtype] + [(other, args.vq_dtype)]
-        if args.extra:
-            variants += [(other, d) for d in ("f32", "bf16x3", "bf16") if d != args.vq_dtype]
-        for cfgn, vqd in variants:
-            if (cfgn, vqd) == (args.config, args.vq_dtype):
-                continue
-            e2, _, _ = run(cfgn, vqd, max(3, args.steps // 2), 2, profile=False)
-            extra[f"images_per_s_config{cfgn}_vq{vqd}"] = round(args.batch * max(3, args.steps // 2) / e2, 1)
-
+        for cfgn, vqd in [(args.config, d) for d in ("f32", "bf16") if d != args.vq_dtype] + [(other, args.vq_dtype)]:
+            e2, _, _, _ = run(cfgn, vqd, n2, 2)
+            extra[f"images_per_s_config{cfgn}_vq{vqd}"] = round(args.batch * n2 / e2, 1)
         extra.update(vqgan_roundtrip(device, args.batch))
+        extra["config4_uvit_seq256"] = uvit_leg(device, 64, 256)
+        extra["config4_uvit_seq1024"] = uvit_leg(device, 16, 1024)
 
     out = {
         "metric": "images/sec/node (MaskGit train step, 256^2, bs=64/GPU)", "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": f"bf16 (transformer GEMM/attention operands; f32 accumulate, residual, norms, loss) + {args.vq_dtype} tokenizer"
+                 + (" (f32 activations, f32-class products as 3 bf16 MFMAs)" if args.vq_dtype == "bf16x3" else ""),
+        "data": "synthetic",
         "config": {"workload": f"MaskGit train step: MaskGitVQGAN f16-256 encode ({args.vq_dtype}) + cosine mask + "
                                f"MaskGitTransformer config {args.config} "
                                f"({'configs/imagenet.yaml: hidden 768, 24 layers, 16 heads, vocab 2048' if args.config == 'B' else 'README: hidden 512, 8 layers, 8 heads, vocab 2025'}"
                                f", seq 257) fwd+bwd (bf16 MFMA, f32 accum/residual) + AdamW",
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "resolution": 256, "seq_len": 257,
-                   "parallelism": f"dp{world}", "vqgan_dtype": args.vq_dtype, "random_init": True},
+                   "parallelism": f"dp{world}", "vqgan_dtype": args.vq_dtype, "random_init": True,
+                   "grad_allreduce_dtype": args.grad_dtype if world > 1 else None},
         "roofline": roofline,
         "extra": extra,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.config)
+        out["cpu_baseline"] = cpu_baseline(args.config, device)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -74,13 +74,14 @@ int muse_transpose(const void* in, void* out, int32_t dtype, int32_t rows, int32
  * muse_layernorm_fwd: y = LayerNorm(x) * w (+ residual), weight-only LN (muse/modeling_transformer.py:124-137 at
  *   :878,:883,:786,:796,:1269,:983) with the residual add of :884 / :903 fused.  mean/rstd [rows] f32 are saved.
  * muse_layernorm_bwd: dx = LN'(dy) (+ dres);  dw_partial [nblk, cols] f32 holds per-block column sums of dy*xhat,
- *   reduced into dw by muse_colsum (deterministic two-stage reduction).  Returns nblk via *nblk_out when dx==NULL.
+ *   reduced into dw by muse_colsum (deterministic two-stage reduction).  dx_bf16 (may be NULL): a second, bf16 copy of dx
+ *   for the GEMMs that consume it next (the f32 dx stays the residual-stream gradient).
  */
 int muse_layernorm_fwd(const void* x, int32_t x_dtype, const float* w, const float* residual, void* y, int32_t y_dtype,
                        float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream);
 int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* w,
                        const float* mean, const float* rstd, const float* dres, void* dx, int32_t dx_dtype,
-                       float* dw_partial, int32_t nblk, int32_t rows, int32_t cols, void* stream);
+                       void* dx_bf16, float* dw_partial, int32_t nblk, int32_t rows, int32_t cols, void* stream);
 int muse_layernorm_bwd_nblk(int32_t rows);
 /* out[c] (+)= sum_r in[r, c], f32 */
 int muse_colsum(const float* in, float* out, int32_t rows, int32_t cols, int32_t accumulate, void* stream);
@@ -199,6 +200,11 @@ int muse_mask_tokens(const int64_t* tokens, const float* timesteps, const float*
                      const int32_t* rects, int64_t* input_ids, int64_t* labels, float* loss_weight, float* mask_prob,
                      int32_t batch, int32_t seq, int64_t mask_id, float min_masking_rate, int32_t all_labels, float weight_min,
                      void* stream);
+
+/* nn.Dropout (muse/modeling_transformer.py:237 attention probabilities, :797 feed-forward, :956 embeddings): y = x * keep / (1 - p),
+ * keep_i = [Philox(seed, offset + i / 4) lane (i % 4) >= p]; in place capable.  There is no mask tensor: the backward pass applies
+ * the same call (same seed / offset) to the gradient. */
+int muse_dropout(const void* x, void* y, int32_t dtype, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
 /* training/train_muse.py:715-731 conditioning dropout: keep_b = uniforms[b] < prob;  out = (x * keep != 0) ? x : empty
  * (x [batch, per_image] f32, empty [per_image] f32) - the reference's expression verbatim. */

@@ -24,6 +24,12 @@ static int fill_params(const muse_gemm_desc* d, GemmParams& p) {
   // 16-byte vector loads: leading dimensions and sub-matrix offsets must be multiples of one chunk
   if ((d->lda % ch) || (d->ldb % ch) || (((uintptr_t)d->A) & 15) || (((uintptr_t)d->B) & 15)) return MUSE_ERR_ALIGN;
   if ((d->sA0 % ch) || (d->sA1 % ch) || (d->sB0 % ch) || (d->sB1 % ch)) return MUSE_ERR_ALIGN;
+  {  // the operand loaders address one batch slice with 32-bit byte offsets through a buffer descriptor: a slice of 4 GiB or more
+     // would wrap silently (e.g. f32 logits [131072, 8192] as a wgrad operand) - refuse it instead
+    const int64_t ra = d->layout_a == 0 ? d->M : d->K, ca = d->layout_a == 0 ? d->K : d->M;
+    const int64_t rb = d->layout_b == 0 ? d->N : d->K, cb = d->layout_b == 0 ? d->K : d->N;
+    if (((ra - 1) * d->lda + ca + ch) * esz >= (1LL << 32) || ((rb - 1) * d->ldb + cb + ch) * esz >= (1LL << 32)) return MUSE_ERR_UNSUPPORTED;
+  }
   p.A = d->A; p.B = d->B; p.C = d->C;
   p.bias = (const float*)d->bias; p.rowvec = (const float*)d->rowvec; p.residual = d->residual;
   p.M = d->M; p.N = d->N; p.K = d->K;

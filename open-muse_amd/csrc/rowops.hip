@@ -87,7 +87,8 @@ template <typename TDY, typename TX, typename TDX, int NIT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
-                                                     TDX* __restrict__ dx, float* __restrict__ dwp, int rows, int cols) {
+                                                     TDX* __restrict__ dx, bf16_t* __restrict__ dx2, float* __restrict__ dwp, int rows,
+                                                     int cols) {
   __shared__ float red[4][NIT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dwacc[NIT][4];
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] += r[j]; }
         V4<TDX>::store(dx + (long)row * cols + c, o);
+        if (dx2) V4<bf16_t>::store(dx2 + (long)row * cols + c, o);   // the bf16 copy the next GEMMs consume (saves a cast pass)
       }
     }
   }
@@ -148,9 +150,9 @@ extern "C" int muse_layernorm_bwd_nblk(int32_t rows) { return (rows + LN_BWD_ROW
 
 template <typename TDY, typename TX, typename TDX>
 static int ln_bwd_launch(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
-                         const float* dres, void* dx, float* dwp, int nblk, int rows, int cols, hipStream_t s) {
+                         const float* dres, void* dx, void* dx2, float* dwp, int nblk, int rows, int cols, hipStream_t s) {
 #define LNB(NIT) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, NIT>), dim3(nblk), dim3(256), 0, s, (const TDY*)dy, \
-                                    (const TX*)x, w, mean, rstd, dres, (TDX*)dx, dwp, rows, cols)
+                                    (const TX*)x, w, mean, rstd, dres, (TDX*)dx, (bf16_t*)dx2, dwp, rows, cols)
   if (cols <= 256) LNB(1);
   else if (cols <= 512) LNB(2);
   else if (cols <= 1024) LNB(4);
@@ -164,21 +166,21 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* w, const fl
 
 extern "C" int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* w,
                                   const float* mean, const float* rstd, const float* dres, void* dx, int32_t dx_dtype,
-                                  float* dw_partial, int32_t nblk, int32_t rows, int32_t cols, void* stream) {
+                                  void* dx_bf16, float* dw_partial, int32_t nblk, int32_t rows, int32_t cols, void* stream) {
   if (cols % 4) return MUSE_ERR_BAD_ARG;
   if (rows <= 0) return 0;
   if (nblk != muse_layernorm_bwd_nblk(rows)) return MUSE_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int key = dy_dtype * 4 + x_dtype * 2 + dx_dtype;
   switch (key) {
-    case 0: return ln_bwd_launch<float, float, float>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
-    case 1: return ln_bwd_launch<float, float, bf16_t>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
-    case 2: return ln_bwd_launch<float, bf16_t, float>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
-    case 3: return ln_bwd_launch<float, bf16_t, bf16_t>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
-    case 4: return ln_bwd_launch<bf16_t, float, float>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
-    case 5: return ln_bwd_launch<bf16_t, float, bf16_t>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
-    case 6: return ln_bwd_launch<bf16_t, bf16_t, float>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
-    case 7: return ln_bwd_launch<bf16_t, bf16_t, bf16_t>(dy, x, w, mean, rstd, dres, dx, dw_partial, nblk, rows, cols, s);
+    case 0: return ln_bwd_launch<float, float, float>(dy, x, w, mean, rstd, dres, dx, dx_bf16, dw_partial, nblk, rows, cols, s);
+    case 1: return ln_bwd_launch<float, float, bf16_t>(dy, x, w, mean, rstd, dres, dx, dx_bf16, dw_partial, nblk, rows, cols, s);
+    case 2: return ln_bwd_launch<float, bf16_t, float>(dy, x, w, mean, rstd, dres, dx, dx_bf16, dw_partial, nblk, rows, cols, s);
+    case 3: return ln_bwd_launch<float, bf16_t, bf16_t>(dy, x, w, mean, rstd, dres, dx, dx_bf16, dw_partial, nblk, rows, cols, s);
+    case 4: return ln_bwd_launch<bf16_t, float, float>(dy, x, w, mean, rstd, dres, dx, dx_bf16, dw_partial, nblk, rows, cols, s);
+    case 5: return ln_bwd_launch<bf16_t, float, bf16_t>(dy, x, w, mean, rstd, dres, dx, dx_bf16, dw_partial, nblk, rows, cols, s);
+    case 6: return ln_bwd_launch<bf16_t, bf16_t, float>(dy, x, w, mean, rstd, dres, dx, dx_bf16, dw_partial, nblk, rows, cols, s);
+    case 7: return ln_bwd_launch<bf16_t, bf16_t, bf16_t>(dy, x, w, mean, rstd, dres, dx, dx_bf16, dw_partial, nblk, rows, cols, s);
   }
   return MUSE_ERR_BAD_ARG;
 }
@@ -189,19 +191,24 @@ extern "C" int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* 
 //   backward: dh = LN'(dhm) ; dab = (dh * b * gelu'(a), dh * gelu(a)) ; dw partials          - dh never touches HBM
 // One 256-thread block per row at a time (NV chunks of 4 columns per thread), block reductions through LDS.
 // =================================================================================================================
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it (a plain
+// __syncthreads() drains vmcnt first, which would serialise the next row's prefetch behind every reduction)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float block_sum256(float v, float* red, int slot) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = v;
-  __syncthreads();
+  lds_barrier();
   return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
 }
 
+// The rows of a block are software-pipelined: the loads of row r+1 are issued before the reductions / stores of row r, so
+// each CU keeps about twice the bytes in flight (these kernels are bound by loads in flight, not by bandwidth or VALU).
 #define FFN_ROWS 8
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ ab, const float* __restrict__ w,
                                                           T* __restrict__ h, T* __restrict__ hm, float* __restrict__ mean_o,
                                                           float* __restrict__ rstd_o, int rows, int inter, float eps) {
-  __shared__ float red[16];
+  __shared__ float red[2][16];
   float wv[NV][4];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -209,20 +216,28 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
     if (c < inter) V4<float>::load(w + c, wv[k]);
   }
   const int r0 = blockIdx.x * FFN_ROWS;
+  float an[NV][4], bn[NV][4];   // the next row's operands
+  auto fetch = [&](int row) {
+    const T* abr = ab + (long)row * 2 * inter;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) { V4<T>::load(abr + c, an[k]); V4<T>::load(abr + inter + c, bn[k]); }
+    }
+  };
+  if (r0 < rows) fetch(r0);
   for (int rr = 0; rr < FFN_ROWS; ++rr) {
     const int row = r0 + rr;
     if (row >= rows) break;
-    const T* abr = ab + (long)row * 2 * inter;
     float hv[NV][4];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 256 + threadIdx.x) * 4;
       if (c < inter) {
-        float a[4], b[4], o[4];
-        V4<T>::load(abr + c, a); V4<T>::load(abr + inter + c, b);
+        float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]) * b[j];
+        for (int j = 0; j < 4; ++j) o[j] = gelu_erf(an[k][j]) * bn[k][j];
         V4<T>::store(h + (long)row * inter + c, o);
         if (sizeof(T) == 2) {  // LayerNorm sees the stored (bf16-rounded) h, exactly like the unfused path
 #pragma unroll
@@ -232,7 +247,9 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
         for (int j = 0; j < 4; ++j) { hv[k][j] = o[j]; s += o[j]; }
       }
     }
-    const float mean = block_sum256(s, red, 0) / (float)inter;
+    if (rr + 1 < FFN_ROWS && row + 1 < rows) fetch(row + 1);
+    float* rd = red[rr & 1];   // alternate scratch: the next row's first reduction cannot overtake this row's last read
+    const float mean = block_sum256(s, rd, 0) / (float)inter;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
         for (int j = 0; j < 4; ++j) { const float d = hv[k][j] - mean; q = fmaf(d, d, q); }
       }
     }
-    const float rstd = 1.0f / sqrtf(block_sum256(q, red, 1) / (float)inter + eps);
+    const float rstd = 1.0f / sqrtf(block_sum256(q, rd, 1) / (float)inter + eps);
     if (threadIdx.x == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -254,7 +271,6 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
         V4<T>::store(hm + (long)row * inter + c, o);
       }
     }
-    __syncthreads();  // red[] is reused by the next row
   }
 }
 
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
                                                           const T* __restrict__ ab, const float* __restrict__ w,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           T* __restrict__ dab, float* __restrict__ dwp, int rows, int inter) {
-  __shared__ float red[16];
+  __shared__ float red[2][16];
   float wv[NV][4], dwacc[NV][4];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -273,48 +289,60 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
     if (c < inter) V4<float>::load(w + c, wv[k]);
   }
   const int r0 = blockIdx.x * FFN_ROWS;
+  float dn[NV][4], xn[NV][4];   // the next row's dhm / h
+  auto fetch = [&](int row) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) { V4<T>::load(dhm + (long)row * inter + c, dn[k]); V4<T>::load(h + (long)row * inter + c, xn[k]); }
+    }
+  };
+  if (r0 < rows) fetch(r0);
   for (int rr = 0; rr < FFN_ROWS; ++rr) {
     const int row = r0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
-    float gk[NV][4], xh[NV][4];
+    float gk[NV][4], xh[NV][4], av[NV][4], bv[NV][4];
     float s1 = 0.f, s2 = 0.f;
+    const T* abr = ab + (long)row * 2 * inter;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {   // this row's GLU operands: needed only after the reductions, in flight across them
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) { V4<T>::load(abr + c, av[k]); V4<T>::load(abr + inter + c, bv[k]); }
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 256 + threadIdx.x) * 4;
       if (c < inter) {
-        float d[4], x[4];
-        V4<T>::load(dhm + (long)row * inter + c, d); V4<T>::load(h + (long)row * inter + c, x);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          xh[k][j] = (x[j] - mu) * rs;
-          gk[k][j] = d[j] * wv[k][j];
+          xh[k][j] = (xn[k][j] - mu) * rs;
+          gk[k][j] = dn[k][j] * wv[k][j];
           s1 += gk[k][j];
           s2 = fmaf(gk[k][j], xh[k][j], s2);
-          dwacc[k][j] = fmaf(d[j], xh[k][j], dwacc[k][j]);
+          dwacc[k][j] = fmaf(dn[k][j], xh[k][j], dwacc[k][j]);
         }
       }
     }
-    const float c1 = block_sum256(s1, red, 0) / (float)inter;
-    const float c2 = block_sum256(s2, red, 1) / (float)inter;
-    const T* abr = ab + (long)row * 2 * inter;
+    if (rr + 1 < FFN_ROWS && row + 1 < rows) fetch(row + 1);
+    float* rd = red[rr & 1];
+    const float c1 = block_sum256(s1, rd, 0) / (float)inter;
+    const float c2 = block_sum256(s2, rd, 1) / (float)inter;
     T* dr = dab + (long)row * 2 * inter;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 256 + threadIdx.x) * 4;
       if (c < inter) {
-        float a[4], b[4], da[4], db[4];
-        V4<T>::load(abr + c, a); V4<T>::load(abr + inter + c, b);
+        float da[4], db[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float dh = rs * (gk[k][j] - c1 - xh[k][j] * c2);
-          da[j] = dh * b[j] * gelu_erf_grad(a[j]);
-          db[j] = dh * gelu_erf(a[j]);
+          da[j] = dh * bv[k][j] * gelu_erf_grad(av[k][j]);
+          db[j] = dh * gelu_erf(av[k][j]);
         }
         V4<T>::store(dr + c, da); V4<T>::store(dr + inter + c, db);
       }
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -546,25 +574,34 @@ extern "C" int muse_embed_fwd(const int64_t* ids, const float* word, const float
   return (int)hipGetLastError();
 }
 
-#define EMB_SPLIT 32
+// Token splits of the word-embedding gradient.  partial[split][v][:] costs split * vocab * hidden floats of HBM traffic twice
+// (write + reduce), so the split count is bounded by a 64 MiB partial buffer: 8 for vocab 2048 x 768 (was a fixed 32: 201 MB
+// written and re-read, 765 us of the 80 ms step), 2 for vocab 8256 x 768, 32 for small tables.
+static inline int emb_splits(int hidden, int vocab) {
+  long s = (16L << 20) / ((long)hidden * vocab > 0 ? (long)hidden * vocab : 1);
+  int p = 1;
+  while (p * 2 <= s && p < 32) p *= 2;
+  return p;
+}
 // partial[split][v][:] = sum (in position order) of dout[t,:] over tokens t in this split with ids[t] == v
 __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
-                                                                float* __restrict__ partial, int ntok, int hidden, int vocab) {
+                                                                float* __restrict__ partial, int ntok, int hidden, int vocab, int nsplit) {
   const int v = blockIdx.x, sp = blockIdx.y;
-  const int per = (ntok + EMB_SPLIT - 1) / EMB_SPLIT;
+  const int per = (ntok + nsplit - 1) / nsplit;
   const int t0 = sp * per, t1 = min(ntok, t0 + per);
   __shared__ int hits[256];
   __shared__ int nhit;
+  __shared__ int wcnt[4];
   // up to 16 columns per thread (hidden <= 4096)
   float acc[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  const int ncol = (hidden - (int)threadIdx.x + 255) / 256;   // columns threadIdx.x + 256 j < hidden
   for (int base = t0; base < t1; base += 256) {
     const int t = base + threadIdx.x;
     const bool hit = (t < t1) && (ids[t] == (int64_t)v);
     // ordered compaction of this chunk's hits
     const unsigned long long bal = __ballot(hit);
-    __shared__ int wcnt[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) wcnt[wave] = __popcll(bal);
     __syncthreads();
@@ -574,10 +611,25 @@ __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t* _
     if (threadIdx.x == 0) nhit = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     __syncthreads();
     const int n = nhit;
-    for (int h = 0; h < n; ++h) {
+    int h = 0;
+    for (; h + 4 <= n; h += 4) {   // four rows in flight, added in position order
+      const float* s0 = dout + (long)hits[h] * hidden;
+      const float* s1 = dout + (long)hits[h + 1] * hidden;
+      const float* s2 = dout + (long)hits[h + 2] * hidden;
+      const float* s3 = dout + (long)hits[h + 3] * hidden;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < ncol) {
+          const int c = threadIdx.x + j * 256;
+          const float a0 = s0[c], a1 = s1[c], a2 = s2[c], a3 = s3[c];
+          acc[j] = (((acc[j] + a0) + a1) + a2) + a3;
+        }
+      }
+    }
+    for (; h < n; ++h) {
       const float* src = dout + (long)hits[h] * hidden;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { const int c = threadIdx.x + j * 256; if (c < hidden) acc[j] += src[c]; }
+      for (int j = 0; j < 16; ++j) if (j < ncol) acc[j] += src[threadIdx.x + j * 256];
     }
     __syncthreads();
   }
@@ -585,11 +637,10 @@ __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t* _
 #pragma unroll
   for (int j = 0; j < 16; ++j) { const int c = threadIdx.x + j * 256; if (c < hidden) dst[c] = acc[j]; }
 }
-__global__ void embed_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dword, long n, int acc) {
+__global__ void embed_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dword, long n, int acc, int nsplit) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
-#pragma unroll
-    for (int sp = 0; sp < EMB_SPLIT; ++sp) s += partial[(long)sp * n + i];
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * n + i];
     dword[i] = acc ? dword[i] + s : s;
   }
 }
@@ -607,13 +658,14 @@ extern "C" int muse_embed_bwd(const int64_t* ids, const float* dout, float* dwor
   if (hidden > 4096) return MUSE_ERR_UNSUPPORTED;
   if (batch * seq <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_bwd_partial_kernel, dim3(vocab, EMB_SPLIT), dim3(256), 0, s, ids, dout, scratch, batch * seq, hidden, vocab);
+  const int nsplit = emb_splits(hidden, vocab);
+  hipLaunchKernelGGL(embed_bwd_partial_kernel, dim3(vocab, nsplit), dim3(256), 0, s, ids, dout, scratch, batch * seq, hidden, vocab, nsplit);
   const long n = (long)vocab * hidden;
-  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)scratch, dword, n, accumulate);
+  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)scratch, dword, n, accumulate, nsplit);
   hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(seq), dim3(256), 0, s, dout, dpos, batch, seq, hidden, accumulate);
   return (int)hipGetLastError();
 }
-extern "C" int64_t muse_embed_bwd_scratch_floats(int32_t hidden, int32_t vocab) { return (int64_t)EMB_SPLIT * vocab * hidden; }
+extern "C" int64_t muse_embed_bwd_scratch_floats(int32_t hidden, int32_t vocab) { return (int64_t)emb_splits(hidden, vocab) * vocab * hidden; }
 
 // =================================================================================================================
 // Cross entropy (ignore_index = -100, label smoothing, mean over valid rows)

@@ -240,3 +240,34 @@ extern "C" int muse_cond_dropout(const float* x, const float* empty, const float
                      total, prob);
   return (int)hipGetLastError();
 }
+
+// =================================================================================================================
+// Dropout (nn.Dropout of muse/modeling_transformer.py:177,237 attention probabilities, :779,797 feed-forward, :933,956
+// embeddings): y = x * keep / (1 - p), keep_i = [u_i >= p], u_i the Philox stream (seed, offset + i).  No mask tensor: the
+// backward pass calls the same function on the gradient with the same (seed, offset).  One Philox block serves 4 elements.
+// =================================================================================================================
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, float p, float scale, uint64_t seed, uint64_t offset) {
+  const long n4 = (n + 3) >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const uint64_t c = offset + (uint64_t)i;
+    const u4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), 0x6D757365u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long e = i * 4 + j;
+      if (e < n) Elem<T>::store(y + e, u01_open_high(rr[j]) >= p ? Elem<T>::load(x + e) * scale : 0.0f);
+    }
+  }
+}
+extern "C" int muse_dropout(const void* x, void* y, int32_t dtype, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+  if (!x || !y || p < 0.0f || p >= 1.0f) return MUSE_ERR_BAD_ARG;
+  if (n <= 0) return 0;
+  const long n4 = (n + 3) / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  const float scale = 1.0f / (1.0f - p);
+  if (dtype == MUSE_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, (long)n, p, scale, seed, offset);
+  else if (dtype == MUSE_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)n, p, scale, seed, offset);
+  else return MUSE_ERR_BAD_ARG;
+  return (int)hipGetLastError();
+}

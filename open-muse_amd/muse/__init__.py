@@ -10,6 +10,7 @@ __version__ = "0.0.1"
 from .modeling_maskgit_vqgan import MaskGitVQGAN
 from .modeling_transformer import MaskGitTransformer
 from .modeling_transformer_v2 import MaskGiTUViT, MaskGiTUViT_v2
+from . import pre_encode
 from .pipeline_muse import PipelineMuse
 from .sampling import get_mask_chedule
 from .training import (FusedAdamW, GradReducer, TrainStep, cond_dropout, mask_or_random_replace_tokens,

@@ -50,7 +50,7 @@ SIGNATURES = {
     "muse_layernorm_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                            c_float, c_void_p],
     "muse_layernorm_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                           c_void_p, c_int, c_int, c_int, c_void_p],
+                           c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "muse_layernorm_bwd_nblk": [c_int],
     "muse_colsum": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "muse_softmax_fwd": [c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],
@@ -88,6 +88,7 @@ SIGNATURES = {
                          c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "muse_mask_tokens": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                          c_i64, c_float, c_int, c_float, c_void_p],
+    "muse_dropout": [c_void_p, c_void_p, c_int, c_i64, c_float, C.c_uint64, C.c_uint64, c_void_p],
     "muse_cond_dropout": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_float, c_void_p],
     "muse_conv2d_nhwc": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int, c_int, c_void_p],

@@ -355,8 +355,6 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 label_smoothing=0.0, cond_dropout_prob=0.0, **kwargs):
         if encoder_hidden_states is not None:
             raise NotImplementedError("text conditioning (encoder_hidden_states) is outside the MI355X hot-path build")
-        if self.training and (self.hidden_dropout > 0.0 or self.attention_dropout > 0.0):
-            raise NotImplementedError("dropout > 0 is not implemented (target configs use 0.0: configs/imagenet.yaml:41-42)")
         if not input_ids.is_cuda:
             raise MuseHipError("MaskGitTransformer (MI355X build) has no CPU path: move the model and inputs to the GPU")
         if not self._flat_ok():
@@ -389,8 +387,18 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             return t[o:o + n].view(shape)
 
         x = ops.embed_fwd(ids, self.embed.word_embeddings.weight.data, self.embed.position_embeddings.weight.data)
-        fused = self.fused_attention and ops.attention_supported(cd, S, hd)
-        saved = {"layers": [], "cd": cd, "ids": ids, "B": B, "S": S, "Sp": Sp, "fused": fused} if need_grad else None
+        # nn.Dropout sites of the reference (training mode only): embeddings :956, attention probabilities :237, feed-forward
+        # :797.  Masks are Philox streams (seed drawn per forward from torch's CPU generator, one offset range per site); the
+        # backward regenerates them.  Attention dropout needs the probabilities, so it runs on the materialised path.
+        pd_h = float(self.hidden_dropout) if self.training else 0.0
+        pd_a = float(self.attention_dropout) if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,))) if (pd_h > 0.0 or pd_a > 0.0) else 0
+        self._last_dropout = (seed, pd_h, pd_a)
+        site = lambda li, k: ((li * 2 + k + 1) << 40)   # noqa: E731  (k = 0 attention, 1 feed-forward; 0 = embeddings)
+        if pd_h > 0.0:
+            ops.dropout(x, pd_h, seed, 0, out=x)
+        fused = self.fused_attention and ops.attention_supported(cd, S, hd) and pd_a == 0.0
+        saved = {"layers": [], "cd": cd, "ids": ids, "B": B, "S": S, "Sp": Sp, "fused": fused, "drop": (seed, pd_h, pd_a)} if need_grad else None
 
         for li in range(self.num_hidden_layers):
             b0 = 2 + li * 11
@@ -414,17 +422,22 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 ops.gemm(qkv, qkv, P, S, S, hd, la=0, lb=0, lda=3 * H, ldb=3 * H, ldc=Sp, a_off=0, b_off=H, alpha=alpha,
                          batch=B * nh, zdiv=nh, sA=(S * 3 * H, hd), sB=(S * 3 * H, hd), sC=(nh * S * Sp, S * Sp))
                 ops.softmax_(P, B * nh * S, S, Sp)
+                Pd = ops.dropout(P, pd_a, seed, site(li, 0)) if pd_a > 0.0 else P    # (reference :237)
                 ctx = torch.empty((T, H), dtype=cd, device=dev)
                 # ctx[b,:,h] = P V                   (reference :238-240)
-                ops.gemm(P, qkv, ctx, S, hd, S, la=0, lb=1, lda=Sp, ldb=3 * H, ldc=H, b_off=2 * H, batch=B * nh, zdiv=nh,
+                ops.gemm(Pd, qkv, ctx, S, hd, S, la=0, lb=1, lda=Sp, ldb=3 * H, ldc=H, b_off=2 * H, batch=B * nh, zdiv=nh,
                          sA=(nh * S * Sp, S * Sp), sB=(S * 3 * H, hd), sC=(S * H, hd))
             ao = ops.linear(ctx, w_out)
             x1, mu_p, rs_p = ops.layernorm_fwd(ao, w_post, eps, torch.float32, residual=x)   # x + LN(attn)  (:882-884)
             ln2, mu2, rs2 = ops.layernorm_fwd(x1, w_pre, eps, cd)
             ab = ops.linear(ln2, w_01)
             h, hm, mu_m, rs_m = ops.ffn_mid_fwd(ab, w_mid, eps)   # gelu(a)*b and the NormFormer mid-LN in one pass (:789-797)
+            if pd_h > 0.0:
+                ops.dropout(hm, pd_h, seed, site(li, 1), out=hm)   # (:797) in place: only the dropped tensor is needed again (dW_o)
             x2 = ops.linear(hm, w_o2, out_dtype=torch.float32, residual=x1)                  # x + FFN(x)    (:902-903)
             if need_grad:
+                if not fused and pd_a > 0.0:
+                    P = (P, Pd)
                 saved["layers"].append(dict(x=x, mu1=mu1, rs1=rs1, ln1=ln1, qkv=qkv, P=P, ctx=ctx, ao=ao, mu_p=mu_p,
                                             rs_p=rs_p, x1=x1, mu2=mu2, rs2=rs2, ln2=ln2, ab=ab, h=h, mu_m=mu_m,
                                             rs_m=rs_m, hm=hm))
@@ -488,10 +501,9 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 n *= s
             return t[o:o + n].view(shape)
 
-        def to_cd(t):
-            return t if cd == torch.float32 else ops.cast_to_bf16(t)
-
         Wt = self.compute_weights_t(cd)
+        seed, pd_h, pd_a = sv["drop"]
+        site = lambda li, k: ((li * 2 + k + 1) << 40)   # noqa: E731
 
         def dgrad(dy, w, idx):
             """dx = dy @ w  (w = compute weights [N_out, K_in] at flat index idx)"""
@@ -531,8 +543,10 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         dd = ops.gelu_bwd(sv["d"], dg)
         ops.linear_wgrad(dd, sv["xf"], view(GW, t0 + 1, (H, H)), acc[t0 + 1])
         dxf = dgrad(dd, w_dense, t0 + 1)
+        bf = cd == torch.bfloat16   # bf16 mode: LayerNorm backward also writes the bf16 copy of dx the next layer's GEMMs read
         dx = ops.layernorm_bwd(dxf, sv["x_last"], w_enc, sv["mu_e"], sv["rs_e"], torch.float32, view(GW, t0 + 0, (H,)),
-                               acc[t0 + 0])
+                               acc[t0 + 0], also_bf16=bf)
+        dx, dxc = dx if bf else (dx, dx)
         ready(t0, t0 + 4)
 
         # ---- layers, last to first ----------------------------------------------------------------------------------
@@ -543,9 +557,10 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             w_post, w_pre = view(Wf, b0 + 5, (H,)), view(Wf, b0 + 6, (H,))
             w_01, w_mid, w_o2 = view(Wc, b0 + 7, (2 * I, H)), view(Wf, b0 + 9, (I,)), view(Wc, b0 + 10, (H, I))
             # FFN
-            dxc = to_cd(dx)
             ops.linear_wgrad(dxc, s["hm"], view(GW, b0 + 10, (H, I)), acc[b0 + 10])
             dhm = dgrad(dxc, w_o2, b0 + 10)
+            if pd_h > 0.0:
+                ops.dropout(dhm, pd_h, seed, site(li, 1), out=dhm)
             dab = ops.ffn_mid_bwd(dhm, s["h"], s["ab"], w_mid, s["mu_m"], s["rs_m"], view(GW, b0 + 9, (I,)), acc[b0 + 9])
             ops.linear_wgrad(dab, s["ln2"], view(GW, b0 + 7, (2 * I, H)), acc[b0 + 7])
             dln2 = dgrad(dab, w_01, b0 + 7)
@@ -561,19 +576,23 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 ops.linear_wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
                 dln1 = dgrad(dqkv, w_qkv, b0 + 1)
                 dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
-                                       acc[b0 + 0], dres=dx1)
+                                       acc[b0 + 0], dres=dx1, also_bf16=bf and li > 0)
+                dx, dxc = dx if (bf and li > 0) else (dx, dx)
                 sv["layers"][li] = None
                 ready(b0, b0 + 11)
                 continue
             dqkv = torch.empty((T, 3 * H), dtype=cd, device=dev)
             sQ, sP_, sX = (S * 3 * H, hd), (nh * S * Sp, S * Sp), (S * H, hd)
-            # dV = P^T dctx
-            ops.gemm(P, dctx, dqkv, S, hd, S, la=1, lb=1, lda=Sp, ldb=H, ldc=3 * H, c_off=2 * H, batch=B * nh, zdiv=nh,
+            P, Pd = P if isinstance(P, tuple) else (P, P)
+            # dV = P^T dctx   (the dropped probabilities, as the forward used them)
+            ops.gemm(Pd, dctx, dqkv, S, hd, S, la=1, lb=1, lda=Sp, ldb=H, ldc=3 * H, c_off=2 * H, batch=B * nh, zdiv=nh,
                      sA=sP_, sB=sX, sC=sQ)
             # dP = dctx V^T
             dP = torch.empty((B * nh, S, Sp), dtype=cd, device=dev)
             ops.gemm(dctx, qkv, dP, S, S, hd, la=0, lb=0, lda=H, ldb=3 * H, ldc=Sp, b_off=2 * H, batch=B * nh, zdiv=nh,
                      sA=sX, sB=sQ, sC=sP_)
+            if pd_a > 0.0:
+                ops.dropout(dP, pd_a, seed, site(li, 0), out=dP)
             ops.softmax_bwd_(P, dP, B * nh * S, S, Sp)   # dS in place
             # dQ = alpha dS K ; dK = alpha dS^T Q
             ops.gemm(dP, qkv, dqkv, S, hd, S, la=0, lb=1, lda=Sp, ldb=3 * H, ldc=3 * H, b_off=H, c_off=0, alpha=alpha,
@@ -583,10 +602,13 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             ops.linear_wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
             dln1 = dgrad(dqkv, w_qkv, b0 + 1)
             dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
-                                   acc[b0 + 0], dres=dx1)
+                                   acc[b0 + 0], dres=dx1, also_bf16=bf and li > 0)
+            dx, dxc = dx if (bf and li > 0) else (dx, dx)
             sv["layers"][li] = None  # free activations as we go
             ready(b0, b0 + 11)
 
+        if pd_h > 0.0:
+            ops.dropout(dx, pd_h, seed, 0, out=dx)
         ops.embed_bwd(sv["ids"], dx, view(GW, 0, tuple(params[0].shape)), view(GW, 1, tuple(params[1].shape)), acc[0])
         # position rows beyond S received no gradient this step
         if not acc[1] and S < self.max_position_embeddings:

@@ -26,17 +26,23 @@ def _esz(t):
 _PROF = None
 
 
+PROF_BYTES = {}   # kernel family -> algorithmic HBM bytes of the instrumented launches (each operand read / written once)
+
+
 def profile_start():
     global _PROF
     _PROF = []
+    PROF_BYTES.clear()
 
 
-def profile_stop():
-    """-> list of (kernel name, algorithmic flops, milliseconds) per launch"""
+def profile_stop(with_kind=False):
+    """-> list of (kernel name, algorithmic work, milliseconds) per launch; work = flops for the MFMA kernels.  with_kind adds
+    the HBM-bound kernels (work = algorithmic bytes: every operand read or written once) and a 4th field "flop" | "byte"."""
     global _PROF
     rec, _PROF = _PROF, None
     torch.cuda.synchronize()
-    return [(n, f, e0.elapsed_time(e1)) for n, f, e0, e1 in rec]
+    out = [(n, f, e0.elapsed_time(e1), k) for n, f, e0, e1, k in rec]
+    return out if with_kind else [(n, f, t) for n, f, t, k in out if k == "flop"]
 
 
 def _prof_begin():
@@ -47,11 +53,15 @@ def _prof_begin():
     return e0
 
 
-def _prof_end(e0, name, flops):
+def _prof_end(e0, name, work, kind="flop"):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        _PROF.append((name, flops, e0, e1))
+        _PROF.append((name, work, e0, e1, kind))
+
+
+def _nbytes(*tensors):
+    return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
 
 def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, rowvec=None,
@@ -224,23 +234,29 @@ def layernorm_fwd(x, w, eps, out_dtype, residual=None):
     y = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
     check(lib().muse_layernorm_fwd(x.data_ptr(), dt(x), w.data_ptr(), ptr(residual), y.data_ptr(), dt(y), mean.data_ptr(),
                                    rstd.data_ptr(), rows, cols, eps, stream()), "muse_layernorm_fwd")
+    _prof_end(e0, "layernorm_fwd", _nbytes(x, residual, y), "byte")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None):
-    """returns dx (= LN'(dy) + dres); dw (+)= column sums of dy * xhat."""
+def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None, also_bf16=False):
+    """returns dx (= LN'(dy) + dres); dw (+)= column sums of dy * xhat.  also_bf16: returns (dx, bf16 copy of dx) written in the
+    same pass."""
     require_gpu(dy, x, w)
     rows, cols = x.shape
     dx = torch.empty((rows, cols), dtype=dx_dtype, device=x.device)
+    dx2 = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if also_bf16 else None
     nblk = lib().muse_layernorm_bwd_nblk(rows)
     part = torch.empty((nblk, cols), dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
     check(lib().muse_layernorm_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), dt(x), w.data_ptr(), mean.data_ptr(),
-                                   rstd.data_ptr(), ptr(dres), dx.data_ptr(), dt(dx), part.data_ptr(), nblk, rows, cols,
+                                   rstd.data_ptr(), ptr(dres), dx.data_ptr(), dt(dx), ptr(dx2), part.data_ptr(), nblk, rows, cols,
                                    stream()), "muse_layernorm_bwd")
     check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, cols, 1 if accumulate else 0, stream()), "muse_colsum")
-    return dx
+    _prof_end(e0, "layernorm_bwd", _nbytes(dy, x, dres, dx, dx2), "byte")
+    return (dx, dx2) if also_bf16 else dx
 
 
 def softmax_(x, rows, cols, ld):
@@ -358,8 +374,10 @@ def ffn_mid_fwd(ab, w, eps):
     hm = torch.empty_like(h)
     mean = torch.empty(rows, dtype=torch.float32, device=ab.device)
     rstd = torch.empty_like(mean)
+    e0 = _prof_begin()
     check(lib().muse_ffn_mid_fwd(ab.data_ptr(), w.data_ptr(), h.data_ptr(), hm.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                  dt(ab), rows, inter, eps, stream()), "muse_ffn_mid_fwd")
+    _prof_end(e0, "ffn_mid_fwd", _nbytes(ab, h, hm), "byte")
     return h, hm, mean, rstd
 
 
@@ -371,9 +389,11 @@ def ffn_mid_bwd(dhm, h, ab, w, mean, rstd, dw, accumulate):
     rpb = lib().muse_ffn_mid_rows_per_block()
     nblk = (rows + rpb - 1) // rpb
     part = torch.empty((nblk, inter), dtype=torch.float32, device=h.device)
+    e0 = _prof_begin()
     check(lib().muse_ffn_mid_bwd(dhm.data_ptr(), h.data_ptr(), ab.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                  dab.data_ptr(), part.data_ptr(), dt(h), rows, inter, stream()), "muse_ffn_mid_bwd")
     check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, inter, 1 if accumulate else 0, stream()), "muse_colsum")
+    _prof_end(e0, "ffn_mid_bwd", _nbytes(dhm, h, ab, dab), "byte")
     return dab
 
 
@@ -440,8 +460,10 @@ def cross_entropy_bwd(logits, labels, lse, loss_out, grad_out, label_smoothing, 
 
 def adamw_flat(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     require_gpu(p, g, m, v)
+    e0 = _prof_begin()
     check(lib().muse_adamw_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(p_bf16), p.numel(), lr, beta1,
                                 beta2, eps, weight_decay, step, grad_scale, stream()), "muse_adamw_flat")
+    _prof_end(e0, "adamw", 28.0 * p.numel() + (2.0 * p.numel() if p_bf16 is not None else 0.0), "byte")
 
 
 def cast_to_bf16(src, dst=None):
@@ -522,6 +544,18 @@ def mask_tokens(tokens, mask_id, *, timesteps=None, mask_prob=None, noise=None, 
     return input_ids, labels, lw, mp
 
 
+def dropout(x, p, seed, offset, out=None):
+    """y = x * keep / (1 - p) with the Philox keep-mask of (seed, offset); the same call on a gradient is the backward.
+    `out` may be x (in place)."""
+    require_gpu(x)
+    if not x.is_contiguous():
+        raise _hip.MuseHipError("dropout expects a contiguous tensor")
+    y = out if out is not None else torch.empty_like(x)
+    check(lib().muse_dropout(x.data_ptr(), y.data_ptr(), dt(x), x.numel(), float(p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+                             stream()), "muse_dropout")
+    return y
+
+
 def cond_dropout(x, empty, uniforms, prob):
     """training/train_muse.py:715-731: x [B, ...] f32, empty [...] (one image's worth), uniforms [B]"""
     require_gpu(x, empty, uniforms)
@@ -582,6 +616,8 @@ def conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=None, re
                                         ptr(residual), out.data_ptr(), ptr(part), gn_groups if part is not None else 0,
                                         B, H, W, Cin, Cout, 3, stream()), "muse_conv2d_nhwc_split2")
     _prof_end(e0, "conv_bf16x3_dma", 2.0 * B * H * W * Cout * 9 * Cin)
+    if e0 is not None:
+        PROF_BYTES["conv_bf16x3_dma"] = PROF_BYTES.get("conv_bf16x3_dma", 0.0) + _nbytes(x_hi, x_lo, w_hi, w_lo, residual, out)
     if part is not None:
         out._gn_stats = (part, nchunk)
     return out
@@ -609,9 +645,11 @@ def groupnorm_silu_nhwc_split(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, sil
     else:
         nchunk = lib().muse_groupnorm_nchunk(HW)
         part, snc = torch.empty(B * nchunk * groups * 2, dtype=torch.float64, device=x.device), 0
+    e0 = _prof_begin()
     check(lib().muse_groupnorm_silu_nhwc_split(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                part.data_ptr(), snc, B, HW, C, groups, eps, 1 if silu else 0, stream()),
           "muse_groupnorm_silu_nhwc_split")
+    _prof_end(e0, "groupnorm_silu", _nbytes(x, hi, lo), "byte")
     return hi, lo
 
 
@@ -620,15 +658,19 @@ def groupnorm_silu_nhwc(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, silu=True
     y = torch.empty_like(x)
     nchunk = lib().muse_groupnorm_nchunk(HW)
     part = torch.empty(B * nchunk * groups * 2, dtype=torch.float64, device=x.device)
+    e0 = _prof_begin()
     check(lib().muse_groupnorm_silu_nhwc(x.data_ptr(), y.data_ptr(), dt(x), gamma.data_ptr(), beta.data_ptr(), part.data_ptr(),
                                          B, HW, C, groups, eps, 1 if silu else 0, stream()), "muse_groupnorm_silu_nhwc")
+    _prof_end(e0, "groupnorm_silu", _nbytes(x, y), "byte")
     return y
 
 
 def avgpool2x2_nhwc(x, B, H, W, C_):
     require_gpu(x)
     y = torch.empty((B, H // 2, W // 2, C_), dtype=x.dtype, device=x.device)
+    e0 = _prof_begin()
     check(lib().muse_avgpool2x2_nhwc(x.data_ptr(), y.data_ptr(), dt(x), B, H, W, C_, stream()), "muse_avgpool2x2_nhwc")
+    _prof_end(e0, "avgpool2x2", _nbytes(x, y), "byte")
     return y
 
 

@@ -26,39 +26,80 @@ class PipelineMuse:
         self.tokenizer = tokenizer
         self.device = "cpu"
 
-    def to(self, device="cpu", dtype=None):
-        if dtype is not None and dtype != torch.float32:
-            self.transformer.set_compute_dtype(dtype)
-            self.vae.set_compute_dtype(dtype if dtype == torch.bfloat16 else torch.float32)
+    def to(self, device="cpu", dtype=torch.float32):
+        """reference :55-64: transformer (and text encoder) to `dtype`, the VAE always stays in float32.  Here `dtype` selects the
+        transformer's COMPUTE mode (its master weights stay f32): bfloat16 and float16 both map to the bf16 MFMA path (the HIP
+        kernels have no f16 variant; bf16 has the wider exponent and the same 2x MFMA rate), float32 to the exact-f32 path.  The
+        VAE keeps its own f32-class mode (exact f32 or bf16x3), whatever `dtype` says."""
+        self.device = device
+        self.dtype = dtype
+        self.transformer.set_compute_dtype(torch.bfloat16 if dtype in (torch.bfloat16, torch.float16) else torch.float32)
+        if getattr(self.vae, "compute_dtype", None) == torch.bfloat16:
+            self.vae.set_compute_dtype("bf16x3")
         self.vae.to(device)
         self.transformer.to(device)
         if self.text_encoder is not None:
-            self.text_encoder.to(device)
-        self.device = device
+            self.text_encoder.to(device, dtype=dtype)
         return self
 
     @torch.no_grad()
-    def __call__(self, text: Optional[Union[str, List[str]]] = None, negative_text=None,
-                 class_ids: Optional[Union[int, List[int]]] = None, timesteps: int = 8, guidance_scale: float = 8.0,
-                 temperature: float = 1.0, topk_filter_thres: float = 0.9, num_images_per_prompt: int = 1,
-                 use_maskgit_generate: bool = True, generator: Optional[torch.Generator] = None, use_fp16: bool = False,
-                 output_type: str = "pil", **kwargs):
-        if text is not None or not self.is_class_conditioned:
-            raise NotImplementedError("text-conditioned generation needs a text encoder (outside the MI355X hot-path build)")
-        if class_ids is None:
-            raise ValueError("Either `text` or `class_ids` must be provided.")
-        if isinstance(class_ids, int):
-            class_ids = [class_ids]
-        class_ids = torch.tensor(class_ids, device=self.device, dtype=torch.long)
-        class_ids = class_ids.repeat_interleave(num_images_per_prompt, dim=0)
-        ids = self.transformer.generate2(class_ids=class_ids, timesteps=timesteps, temperature=temperature,
-                                         guidance_scale=guidance_scale, generator=generator)
-        images = self.vae.decode_code(ids)
-        images = torch.clamp(images, 0.0, 1.0).permute(0, 2, 3, 1).float().cpu().numpy()
+    def __call__(self, text: Optional[Union[str, List[str]]] = None, negative_text: Optional[Union[str, List[str]]] = "",
+                 prompt_embeds: Optional[torch.Tensor] = None, pooled_embeds: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds: Optional[torch.Tensor] = None, negative_pooled_embeds: Optional[torch.Tensor] = None,
+                 class_ids: Optional[Union[int, List[int]]] = None, timesteps: int = 16, noise_schedule: str = "cosine",
+                 guidance_scale: float = 10.0, guidance_schedule=None, temperature=(2, 0), topk_filter_thres: float = 0.9,
+                 num_images_per_prompt: int = 1, use_maskgit_generate: bool = True, generator: Optional[torch.Generator] = None,
+                 use_fp16: bool = False, noise_type="mask", predict_all_tokens=False, orig_size=(512, 512), crop_coords=(0, 0),
+                 aesthetic_score=6.0, return_intermediate: bool = False, use_tqdm=True, transformer_seq_len=None,
+                 clip_skip: int = None, output_type: str = "pil", empty_embeds: Optional[torch.Tensor] = None,
+                 empty_pooled_embeds: Optional[torch.Tensor] = None):
+        """reference :66-243, same argument names and defaults.  Two executable paths: class-conditional MaskGitTransformer
+        (`class_ids`), and MaskGiTUViT conditioned on PRE-COMPUTED text states (`prompt_embeds` [B, 77, D] + `pooled_embeds`
+        [B, D], with `empty_embeds` / `empty_pooled_embeds` or the negative_* pair for classifier-free guidance); running a text
+        encoder on `text` needs CLIP, which is outside the hot-path build.  `temperature` may be the reference's (start, end)
+        tuple: MaskGitTransformer.generate2 takes a float, so the tuple's first entry is used there."""
+        from .sampling import get_mask_chedule
+        if text is None and class_ids is None and prompt_embeds is None:
+            raise ValueError("Either text or class_ids must be provided.")
+        if text is not None and class_ids is not None:
+            raise ValueError("Only one of text or class_ids may be provided.")
+        if text is not None:
+            raise NotImplementedError("text-conditioned generation from raw text needs a text encoder (outside the MI355X hot-path "
+                                      "build): pass prompt_embeds / pooled_embeds instead")
+        schedule = get_mask_chedule(noise_schedule)
+        if class_ids is not None:
+            if isinstance(class_ids, int):
+                class_ids = [class_ids]
+            class_ids = torch.tensor(class_ids, device=self.device, dtype=torch.long).repeat_interleave(num_images_per_prompt, dim=0)
+            t0 = float(temperature[0]) if isinstance(temperature, (tuple, list)) else float(temperature)
+            ids = self.transformer.generate2(class_ids=class_ids, timesteps=timesteps, temperature=t0, guidance_scale=guidance_scale,
+                                             noise_schedule=schedule, generator=generator)
+            intermediate = None
+        else:
+            n = num_images_per_prompt
+            rep = lambda t: None if t is None else t.to(self.device).repeat_interleave(n, dim=0)   # noqa: E731
+            micro = torch.tensor([list(orig_size) + list(crop_coords) + [aesthetic_score]], device=self.device, dtype=torch.float32)
+            temp = tuple(temperature) if isinstance(temperature, (tuple, list)) else temperature
+            out = self.transformer.generate2(
+                rep(prompt_embeds), rep(pooled_embeds), micro,
+                None if empty_embeds is None else empty_embeds.to(self.device),
+                None if empty_pooled_embeds is None else empty_pooled_embeds.to(self.device),
+                negative_embeds=rep(negative_prompt_embeds), negative_cond_embeds=rep(negative_pooled_embeds), temperature=temp,
+                timesteps=timesteps, guidance_scale=guidance_scale, guidance_schedule=guidance_schedule, noise_schedule=schedule,
+                generator=generator, return_intermediate=return_intermediate, seq_len=transformer_seq_len,
+                use_tqdm=False if use_tqdm is None else use_tqdm and False)
+            ids, intermediate = out if return_intermediate else (out, None)
+        images = self._decode(ids, output_type)
+        if intermediate is not None:
+            return images, [self._decode(t, output_type) for t in intermediate]
+        return images
+
+    def _decode(self, ids, output_type):
+        images = torch.clamp(self.vae.decode_code(ids), 0.0, 1.0).permute(0, 2, 3, 1).float().cpu().numpy()
         if output_type == "np":
             return images
         from PIL import Image
-        return [Image.fromarray(np.uint8(np.round(im * 255.0))) for im in images]
+        return [Image.fromarray((255 * im).astype(np.uint8)).convert("RGB") for im in images]   # reference to_pil_image :245-252
 
     def save_pretrained(self, save_directory: Union[str, os.PathLike], push_to_hub: bool = False):
         self.vae.save_pretrained(os.path.join(save_directory, "vae"))
@@ -68,10 +109,15 @@ class PipelineMuse:
     def from_pretrained(cls, model_name_or_path: str = None, text_encoder_path: Optional[str] = None,
                         vae_path: Optional[str] = None, transformer_path: Optional[str] = None,
                         is_class_conditioned: bool = False, **kwargs):
+        def load_transformer(path, **kw):   # the class named in the checkpoint's config.json (reference :300-318)
+            from .modeling_transformer_v2 import MaskGiTUViT_v2
+            cfg = MaskGitTransformer.load_config(path, **kw)
+            klass = MaskGiTUViT_v2 if str(cfg.get("_class_name", "")).startswith("MaskGiTUViT") else MaskGitTransformer
+            return klass.from_pretrained(path, **kw)
         if model_name_or_path is not None:
             vae = MaskGitVQGAN.from_pretrained(model_name_or_path, subfolder="vae")
-            transformer = MaskGitTransformer.from_pretrained(model_name_or_path, subfolder="transformer")
+            transformer = load_transformer(model_name_or_path, subfolder="transformer")
         else:
             vae = MaskGitVQGAN.from_pretrained(vae_path)
-            transformer = MaskGitTransformer.from_pretrained(transformer_path)
+            transformer = load_transformer(transformer_path)
         return cls(vae=vae, transformer=transformer, is_class_conditioned=is_class_conditioned)

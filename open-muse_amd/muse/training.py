@@ -392,9 +392,12 @@ class TrainStep:
         self.vq_model, self.model, self.optimizer, self.reducer = vq_model, model, optimizer, reducer
         self.label_smoothing, self.min_masking_rate = label_smoothing, min_masking_rate
 
-    def __call__(self, pixel_values, class_ids, timesteps=None, noise=None):
+    def __call__(self, pixel_values, class_ids, timesteps=None, noise=None, image_tokens=None):
+        """image_tokens [B, S] int64: pre-encoded VQ tokens (muse.pre_encode; the reference's scripts/pre_encode.py regime) -
+        the tokenizer is then skipped and pixel_values may be None"""
         input_ids, labels, _, mask_prob = prepare_inputs_and_labels(
-            self.vq_model, pixel_values, class_ids, self.model.config.mask_token_id, self.min_masking_rate, timesteps, noise)
+            self.vq_model, pixel_values, class_ids, self.model.config.mask_token_id, self.min_masking_rate, timesteps, noise,
+            image_tokens=image_tokens)
         _, loss = self.model(input_ids=input_ids, labels=labels, label_smoothing=self.label_smoothing)
         loss.backward()
         if self.reducer is not None:

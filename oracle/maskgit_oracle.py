@@ -35,7 +35,12 @@ def _ln(x: Tensor, w: Tensor, eps: float) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), w, None, eps)
 
 
-def attention(x: Tensor, sd: SD, prefix: str, num_heads: int) -> Tensor:
+def _drop(t: Tensor, keep: Optional[Tensor], p: float) -> Tensor:
+    """nn.Dropout in training mode with the Bernoulli keep-mask made explicit: t * keep / (1 - p)"""
+    return t if keep is None else t * keep.to(t.dtype) / (1.0 - p)
+
+
+def attention(x: Tensor, sd: SD, prefix: str, num_heads: int, keep: Optional[Tensor] = None, p: float = 0.0) -> Tensor:
     """Full-visibility self attention.  muse/modeling_transformer.py:190-241 (non-xformers branch).
 
     scores = (q k^T) * (1/sqrt(hd)) via baddbmm alpha (:226-231), softmax over keys (:236), P@V (:238),
@@ -52,12 +57,12 @@ def attention(x: Tensor, sd: SD, prefix: str, num_heads: int) -> Tensor:
     # the reference divides by float32(sqrt(float32(hd))) through baddbmm's alpha
     alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
     scores = torch.matmul(q, k.transpose(-1, -2)) * alpha
-    probs = torch.softmax(scores, dim=-1)
+    probs = _drop(torch.softmax(scores, dim=-1), keep, p)                     # self.dropout(attn_weights) :237
     ctx = torch.matmul(probs, v).transpose(1, 2).reshape(B, S, H)
     return ctx @ sd[prefix + "out.weight"].t()
 
 
-def feed_forward(x: Tensor, sd: SD, prefix: str, eps: float) -> Tensor:
+def feed_forward(x: Tensor, sd: SD, prefix: str, eps: float, keep: Optional[Tensor] = None, p: float = 0.0) -> Tensor:
     """NormFormer GLU MLP.  muse/modeling_transformer.py:785-799.
 
     LN(H) -> gelu_erf(x W0^T) * (x W1^T) -> LN(I) -> Wo.
@@ -65,15 +70,18 @@ def feed_forward(x: Tensor, sd: SD, prefix: str, eps: float) -> Tensor:
     h = _ln(x, sd[prefix + "pre_mlp_layer_norm.weight"], eps)
     g = F.gelu(h @ sd[prefix + "wi_0.weight"].t())
     lin = h @ sd[prefix + "wi_1.weight"].t()
-    h = _ln(g * lin, sd[prefix + "mid_mlp_layer_norm.weight"], eps)
+    h = _drop(_ln(g * lin, sd[prefix + "mid_mlp_layer_norm.weight"], eps), keep, p)   # self.dropout(hidden_states) :797
     return h @ sd[prefix + "wo.weight"].t()
 
 
-def transformer_layer(x: Tensor, sd: SD, prefix: str, num_heads: int, eps: float) -> Tensor:
-    """Pre-LN + NormFormer block.  muse/modeling_transformer.py:875-904 (no cross attention)."""
-    a = attention(_ln(x, sd[prefix + "attn_layer_norm.weight"], eps), sd, prefix + "attention.", num_heads)
+def transformer_layer(x: Tensor, sd: SD, prefix: str, num_heads: int, eps: float, drop: Optional[dict] = None) -> Tensor:
+    """Pre-LN + NormFormer block.  muse/modeling_transformer.py:875-904 (no cross attention).
+    drop = {"attn": keep [B, nh, S, S], "ffn": keep [B, S, I], "p_attn", "p_hidden"} for training-mode dropout."""
+    d = drop or {}
+    a = attention(_ln(x, sd[prefix + "attn_layer_norm.weight"], eps), sd, prefix + "attention.", num_heads, d.get("attn"),
+                  d.get("p_attn", 0.0))
     x = x + _ln(a, sd[prefix + "post_attn_layer_norm.weight"], eps)
-    return x + feed_forward(x, sd, prefix + "ffn.", eps)
+    return x + feed_forward(x, sd, prefix + "ffn.", eps, d.get("ffn"), d.get("p_hidden", 0.0))
 
 
 def transformer_forward(
@@ -82,8 +90,11 @@ def transformer_forward(
     input_ids: Tensor,
     labels: Optional[Tensor] = None,
     label_smoothing: float = 0.0,
+    dropout: Optional[dict] = None,
 ):
     """MaskGitTransformer.forward.  muse/modeling_transformer.py:1224-1281.
+    dropout (training mode, hidden_dropout / attention_dropout > 0): {"p_hidden", "p_attn", "embed": keep [B, S, H],
+    "layers": [{"attn": keep, "ffn": keep}, ...]} - the Bernoulli masks nn.Dropout would draw, made explicit.
 
     Embed (:942-957) -> L x TransformerLayer -> encoder_layer_norm (:1268) -> MlmLayer (:979-985)
     -> F.cross_entropy(ignore_index=-100) (:1276-1279).  Dropout is the identity (p=0 / eval).
@@ -93,8 +104,11 @@ def transformer_forward(
     L = int(cfg["num_hidden_layers"])
     S = input_ids.shape[-1]
     x = sd["embed.word_embeddings.weight"][input_ids] + sd["embed.position_embeddings.weight"][:S][None]
+    if dropout is not None:
+        x = _drop(x, dropout.get("embed"), dropout.get("p_hidden", 0.0))         # Embed.dropout :956
     for i in range(L):
-        x = transformer_layer(x, sd, f"transformer_layers.{i}.", nh, eps)
+        dl = None if dropout is None else dict(dropout["layers"][i], p_hidden=dropout.get("p_hidden", 0.0), p_attn=dropout.get("p_attn", 0.0))
+        x = transformer_layer(x, sd, f"transformer_layers.{i}.", nh, eps, dl)
     x = _ln(x, sd["encoder_layer_norm.weight"], eps)
     h = F.gelu(x @ sd["mlm_layer.mlm_dense.weight"].t())
     h = _ln(h, sd["mlm_layer.mlm_ln.weight"], eps)
@@ -106,10 +120,11 @@ def transformer_forward(
     return logits, loss
 
 
-def transformer_loss_and_grads(sd: SD, cfg: dict, input_ids: Tensor, labels: Tensor, label_smoothing: float = 0.0):
+def transformer_loss_and_grads(sd: SD, cfg: dict, input_ids: Tensor, labels: Tensor, label_smoothing: float = 0.0,
+                               dropout: Optional[dict] = None):
     """loss.backward() of the forward above (train_maskgit_imagenet.py:426-433); returns (logits, loss, grads)."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
-    logits, loss = transformer_forward(leaf, cfg, input_ids, labels, label_smoothing)
+    logits, loss = transformer_forward(leaf, cfg, input_ids, labels, label_smoothing, dropout)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
     return logits.detach(), loss.detach(), grads

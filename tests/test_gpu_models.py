@@ -142,7 +142,7 @@ def test_transformer_config_b_full_depth_vs_oracle():
     seed, bs = 510, 2
     ids, labels = W.transformer_inputs(cfg, bs, seed + 1)
     sd = W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer")
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))   # (more threads than ~32 slow torch CPU ops down on the 256-thread GPU host)
     o_logits, o_loss, o_grads = O.transformer_loss_and_grads(sd, cfg, ids, labels, 0.0)
     keys = ["embed.word_embeddings.weight", "embed.position_embeddings.weight", "transformer_layers.0.attention.query.weight",
             "transformer_layers.0.attn_layer_norm.weight", "transformer_layers.11.ffn.wi_1.weight",
@@ -175,7 +175,7 @@ def test_vq_indices_over_bench_batch_vs_oracle():
     sd = W.fill_state_dict(W.vqgan_shapes(cfg), 600, "vqgan")
     B = 64
     px = W.images(B, 256, 611)
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))   # (more threads than ~32 slow torch CPU ops down on the 256-thread GPU host)
     idx_o, dist = [], []
     with torch.no_grad():
         for i in range(0, B, 8):                                   # 8 images at a time bounds the oracle's memory
@@ -207,7 +207,7 @@ def test_transformer_full_arch_vs_oracle(cfg_name, bs):
     seed = 500
     ids, labels = W.transformer_inputs(cfg, bs, seed + 1)
     sd = W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer")
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))   # (more threads than ~32 slow torch CPU ops down on the 256-thread GPU host)
     o_logits, o_loss, o_grads = O.transformer_loss_and_grads(sd, cfg, ids, labels, 0.0)
     for cd in (torch.float32, torch.bfloat16):
         m, _ = _build_transformer(cfg, seed, cd)
@@ -258,7 +258,7 @@ def test_vqgan_f16_256_vs_oracle():
     cfg = W.VQGAN_F16
     sd = W.fill_state_dict(W.vqgan_shapes(cfg), 600, "vqgan")
     px = W.images(1, 256, 601)
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))   # (more threads than ~32 slow torch CPU ops down on the 256-thread GPU host)
     with torch.no_grad():
         z, zq, idx = O.vqgan_encode(sd, cfg, px)
         rec = O.vqgan_decode_code(sd, cfg, idx)
@@ -340,6 +340,46 @@ def test_full_batch_properties_bf16():
         l2, loss2 = m(input_ids=ids[perm].to(DEV), labels=labels[perm].to(DEV))
     assert abs(float(loss2) - float(loss)) < 1e-4 * float(loss)
     assert torch.equal(l2[0], logits[perm[0]].detach())
+
+
+def test_transformer_dropout_vs_oracle_with_same_masks(golden_dir):
+    """hidden_dropout / attention_dropout > 0 (the reference's constructor DEFAULTS, muse/modeling_transformer.py:1095-1096) in
+    training mode: the Philox keep-masks of the forward are read back (dropout of a ones tensor with the same seed / offset) and
+    handed to the oracle, which applies nn.Dropout's formula with them at the reference's three sites (:956, :237, :797);
+    logits, loss and every gradient must agree.  eval() is dropout-free."""
+    import muse
+    from muse import ops
+    from oracle import maskgit_oracle as O
+    cfg = dict(W.TRANSFORMER_TINY, hidden_dropout=0.3, attention_dropout=0.2)
+    g = np.load(os.path.join(golden_dir, "transformer_tiny.npz"))
+    m, sd = _build_transformer(cfg, int(g["seed"]), torch.float32)
+    ids, labels = W.transformer_inputs(cfg, int(g["batch"]), int(g["seed"]) + 1)
+    B, S = ids.shape
+    H, I, nh, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_attention_heads"], cfg["num_hidden_layers"]
+    logits, loss = m(input_ids=ids.to(DEV), labels=labels.to(DEV))
+    loss.backward()
+    seed, ph, pa = m._last_dropout
+    assert (ph, pa) == (0.3, 0.2)
+    Sp = (S + 7) // 8 * 8
+    keep = lambda shape, p, off: (ops.dropout(torch.ones(shape, device=DEV), p, seed, off) > 0).cpu()   # noqa: E731
+    site = lambda li, k: ((li * 2 + k + 1) << 40)   # noqa: E731
+    drop = dict(p_hidden=ph, p_attn=pa, embed=keep((B * S, H), ph, 0).view(B, S, H),
+                layers=[dict(attn=keep((B * nh, S, Sp), pa, site(li, 0))[:, :, :S].reshape(B, nh, S, S),
+                             ffn=keep((B * S, I), ph, site(li, 1)).view(B, S, I)) for li in range(L)])
+    rate = float(drop["layers"][0]["ffn"].float().mean())
+    assert abs(rate - 0.7) < 0.05, rate
+    o_logits, o_loss, o_grads = O.transformer_loss_and_grads(sd, cfg, ids, labels, 0.0, dropout=drop)
+    assert maxrel(logits, o_logits) < 1e-3 and abs(float(loss) - float(o_loss)) < 1e-4 * float(o_loss)
+    assert maxrel(o_logits, torch.from_numpy(g["logits"])) > 5e-2        # the masks really changed the result
+    for k, p in m.named_parameters():
+        assert maxrel(p.grad, o_grads[k]) < 1e-3, k
+    m.eval()
+    with torch.no_grad():
+        assert maxrel(m(input_ids=ids.to(DEV)), torch.from_numpy(g["logits"])) < 1e-3
+    m.train().set_compute_dtype(torch.bfloat16)                           # bf16 mode: materialised attention, bf16 probabilities dropped
+    _, l2 = m(input_ids=ids.to(DEV), labels=labels.to(DEV))
+    l2.backward()
+    assert torch.isfinite(l2) and m._last_dropout[0] != seed              # a fresh seed per forward
 
 
 def test_pipeline_class_conditional():

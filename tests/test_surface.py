@@ -176,3 +176,24 @@ def test_uvit_surface_and_roundtrip(golden_dir):
         muse.MaskGiTUViT(**{**cfg, "norm_type": "layernorm"})
     with pytest.raises(AssertionError):
         m.generate()
+
+
+def test_pre_encoded_token_shards_roundtrip(tmp_path):
+    """token shards in the layout of scripts/pre_encode.py:54-56,225-241 / training/data.py:561-573:
+    a POSIX tar of `<key>.<checkpoint with '/' -> '.'>.pth` (torch.save) members + `<key>.json`"""
+    import tarfile
+    from muse import pre_encode as PE
+    vae, txt = "openMUSE/vqgan-f16-8192-laion", "openMUSE/CLIP-ViT-L-14-DataComp.XL-s13B-b90K-penultimate"
+    toks = torch.randint(0, 8192, (5, 256))
+    enc = torch.randn(5, 77, 8)
+    keys = [f"{i:09d}" for i in range(5)]
+    path = str(tmp_path / "00000.tar")
+    PE.write_token_shard(path, keys, toks, vae, encoder_hidden_states=enc, text_encoder_checkpoint=txt, metadata=[{"i": i} for i in range(5)])
+    names = tarfile.open(path).getnames()
+    assert names[:3] == ["000000000.openmuse.vqgan-f16-8192-laion.pth",
+                         "000000000.openmuse.clip-vit-l-14-datacomp.xl-s13b-b90k-penultimate.pth", "000000000.json"]
+    got = list(PE.read_token_shard(path, vae, txt))
+    assert [s["__key__"] for s in got] == keys
+    assert all(torch.equal(s["image_input_ids"], toks[i]) and torch.equal(s["encoder_hidden_states"], enc[i]) for i, s in enumerate(got))
+    batches = list(PE.token_batches([path], vae, 2, device="cpu"))
+    assert len(batches) == 2 and torch.equal(batches[1], toks[2:4])            # ragged tail dropped
