@@ -191,24 +191,22 @@ extern "C" int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* 
 //   backward: dh = LN'(dhm) ; dab = (dh * b * gelu'(a), dh * gelu(a)) ; dw partials          - dh never touches HBM
 // One 256-thread block per row at a time (NV chunks of 4 columns per thread), block reductions through LDS.
 // =================================================================================================================
-// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it (a plain
-// __syncthreads() drains vmcnt first, which would serialise the next row's prefetch behind every reduction)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (Measured and rejected, round 2: software-pipelining the rows of a block - next row's loads issued before this row's reductions,
+// LDS-only barriers - raised the kernels to 136-145 VGPRs and made them SLOWER on MI355X: ffn_mid_bwd 4.39 -> 4.91 ms,
+// ffn_mid_fwd 2.19 -> 2.40 ms per step.  Occupancy, not loads in flight per block, is what these kernels live on.)
 __device__ __forceinline__ float block_sum256(float v, float* red, int slot) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = v;
-  lds_barrier();
+  __syncthreads();
   return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
 }
 
-// The rows of a block are software-pipelined: the loads of row r+1 are issued before the reductions / stores of row r, so
-// each CU keeps about twice the bytes in flight (these kernels are bound by loads in flight, not by bandwidth or VALU).
 #define FFN_ROWS 8
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ ab, const float* __restrict__ w,
                                                           T* __restrict__ h, T* __restrict__ hm, float* __restrict__ mean_o,
                                                           float* __restrict__ rstd_o, int rows, int inter, float eps) {
-  __shared__ float red[2][16];
+  __shared__ float red[16];
   float wv[NV][4];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -216,28 +214,20 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
     if (c < inter) V4<float>::load(w + c, wv[k]);
   }
   const int r0 = blockIdx.x * FFN_ROWS;
-  float an[NV][4], bn[NV][4];   // the next row's operands
-  auto fetch = [&](int row) {
-    const T* abr = ab + (long)row * 2 * inter;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int c = (k * 256 + threadIdx.x) * 4;
-      if (c < inter) { V4<T>::load(abr + c, an[k]); V4<T>::load(abr + inter + c, bn[k]); }
-    }
-  };
-  if (r0 < rows) fetch(r0);
   for (int rr = 0; rr < FFN_ROWS; ++rr) {
     const int row = r0 + rr;
     if (row >= rows) break;
+    const T* abr = ab + (long)row * 2 * inter;
     float hv[NV][4];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 256 + threadIdx.x) * 4;
       if (c < inter) {
-        float o[4];
+        float a[4], b[4], o[4];
+        V4<T>::load(abr + c, a); V4<T>::load(abr + inter + c, b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = gelu_erf(an[k][j]) * bn[k][j];
+        for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]) * b[j];
         V4<T>::store(h + (long)row * inter + c, o);
         if (sizeof(T) == 2) {  // LayerNorm sees the stored (bf16-rounded) h, exactly like the unfused path
 #pragma unroll
@@ -247,9 +237,7 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
         for (int j = 0; j < 4; ++j) { hv[k][j] = o[j]; s += o[j]; }
       }
     }
-    if (rr + 1 < FFN_ROWS && row + 1 < rows) fetch(row + 1);
-    float* rd = red[rr & 1];   // alternate scratch: the next row's first reduction cannot overtake this row's last read
-    const float mean = block_sum256(s, rd, 0) / (float)inter;
+    const float mean = block_sum256(s, red, 0) / (float)inter;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -259,7 +247,7 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
         for (int j = 0; j < 4; ++j) { const float d = hv[k][j] - mean; q = fmaf(d, d, q); }
       }
     }
-    const float rstd = 1.0f / sqrtf(block_sum256(q, rd, 1) / (float)inter + eps);
+    const float rstd = 1.0f / sqrtf(block_sum256(q, red, 1) / (float)inter + eps);
     if (threadIdx.x == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -271,6 +259,7 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
         V4<T>::store(hm + (long)row * inter + c, o);
       }
     }
+    __syncthreads();  // red[] is reused by the next row
   }
 }
 
@@ -279,7 +268,7 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
                                                           const T* __restrict__ ab, const float* __restrict__ w,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           T* __restrict__ dab, float* __restrict__ dwp, int rows, int inter) {
-  __shared__ float red[2][16];
+  __shared__ float red[16];
   float wv[NV][4], dwacc[NV][4];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -289,60 +278,48 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
     if (c < inter) V4<float>::load(w + c, wv[k]);
   }
   const int r0 = blockIdx.x * FFN_ROWS;
-  float dn[NV][4], xn[NV][4];   // the next row's dhm / h
-  auto fetch = [&](int row) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int c = (k * 256 + threadIdx.x) * 4;
-      if (c < inter) { V4<T>::load(dhm + (long)row * inter + c, dn[k]); V4<T>::load(h + (long)row * inter + c, xn[k]); }
-    }
-  };
-  if (r0 < rows) fetch(r0);
   for (int rr = 0; rr < FFN_ROWS; ++rr) {
     const int row = r0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
-    float gk[NV][4], xh[NV][4], av[NV][4], bv[NV][4];
+    float gk[NV][4], xh[NV][4];
     float s1 = 0.f, s2 = 0.f;
-    const T* abr = ab + (long)row * 2 * inter;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {   // this row's GLU operands: needed only after the reductions, in flight across them
-      const int c = (k * 256 + threadIdx.x) * 4;
-      if (c < inter) { V4<T>::load(abr + c, av[k]); V4<T>::load(abr + inter + c, bv[k]); }
-    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 256 + threadIdx.x) * 4;
       if (c < inter) {
+        float d[4], x[4];
+        V4<T>::load(dhm + (long)row * inter + c, d); V4<T>::load(h + (long)row * inter + c, x);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          xh[k][j] = (xn[k][j] - mu) * rs;
-          gk[k][j] = dn[k][j] * wv[k][j];
+          xh[k][j] = (x[j] - mu) * rs;
+          gk[k][j] = d[j] * wv[k][j];
           s1 += gk[k][j];
           s2 = fmaf(gk[k][j], xh[k][j], s2);
-          dwacc[k][j] = fmaf(dn[k][j], xh[k][j], dwacc[k][j]);
+          dwacc[k][j] = fmaf(d[j], xh[k][j], dwacc[k][j]);
         }
       }
     }
-    if (rr + 1 < FFN_ROWS && row + 1 < rows) fetch(row + 1);
-    float* rd = red[rr & 1];
-    const float c1 = block_sum256(s1, rd, 0) / (float)inter;
-    const float c2 = block_sum256(s2, rd, 1) / (float)inter;
+    const float c1 = block_sum256(s1, red, 0) / (float)inter;
+    const float c2 = block_sum256(s2, red, 1) / (float)inter;
+    const T* abr = ab + (long)row * 2 * inter;
     T* dr = dab + (long)row * 2 * inter;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 256 + threadIdx.x) * 4;
       if (c < inter) {
-        float da[4], db[4];
+        float a[4], b[4], da[4], db[4];
+        V4<T>::load(abr + c, a); V4<T>::load(abr + inter + c, b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float dh = rs * (gk[k][j] - c1 - xh[k][j] * c2);
-          da[j] = dh * bv[k][j] * gelu_erf_grad(av[k][j]);
-          db[j] = dh * gelu_erf(av[k][j]);
+          da[j] = dh * b[j] * gelu_erf_grad(a[j]);
+          db[j] = dh * gelu_erf(a[j]);
         }
         V4<T>::store(dr + c, da); V4<T>::store(dr + inter + c, db);
       }
     }
+    __syncthreads();
   }
 #pragma unroll
   for (int k = 0; k < NV; ++k) {

@@ -150,7 +150,10 @@ class _UViTFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad, *params):
+        model.__dict__["_act_cache"] = {}
+        model.__dict__["_act_cache_on"] = bool(need_grad)
         logits, loss, tape = model._run_forward(input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad)
+        model.__dict__["_act_cache_on"] = False
         ctx.model, ctx.tape = model, tape
         ctx.set_materialize_grads(False)
         if loss is None:
@@ -167,6 +170,7 @@ class _UViTFn(torch.autograd.Function):
         model = ctx.model
         G = model._run_backward(ctx.tape, g_loss)
         ctx.tape = None
+        model.__dict__["_act_cache"] = {}
         grads = tuple(G.get(name) for name, _ in model.named_parameters())
         return (None,) * 9 + grads
 
@@ -257,7 +261,16 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         """GEMM operand in the compute dtype"""
         if self.compute_dtype == torch.float32 or t.dtype == torch.bfloat16:
             return t
-        return ops.cast_to_bf16(t.contiguous())
+        # an activation is a GEMM operand twice: in the forward product and in the backward dW product.  The bf16 copy made
+        # for the first use is kept (keyed by the tensor object, dropped when the step's backward has run) instead of casting again.
+        cache = self.__dict__.setdefault("_act_cache", {})
+        hit = cache.get(id(t))
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        tb = ops.cast_to_bf16(t.contiguous())
+        if self.__dict__.get("_act_cache_on", False):
+            cache[id(t)] = (t, tb)
+        return tb
 
     def _wb(self, *mods):
         """bf16 compute copy of one Linear / 1x1-conv weight, or of several stacked along the output dim (q|k|v, k|v, wi_0|wi_1),

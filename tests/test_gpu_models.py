@@ -419,3 +419,21 @@ def test_grad_reducer_on_rccl_single_rank(golden_dir):
             assert maxrel(p.grad, torch.from_numpy(g["grad." + k])) < 1e-3, k
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_under_torchrun_single_rank():
+    """the launch path the driver uses for N > 1 (torch.distributed.run, RANK / LOCAL_RANK / WORLD_SIZE from the env, RCCL process
+    group with device_id, GradReducer on the side stream, barrier-bracketed timing, metric all-reduce) with one rank"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29800 + os.getpid() % 100), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 100 and line["config"]["parallelism"] == "dp1" and line["roofline"]["frac"] > 0
