@@ -226,8 +226,11 @@ int muse_conv2d_nhwc(const void* in, const void* weight, const float* bias, cons
  * error <= 2^-16 |a||b| per product: tighter than the TF32 the reference's cuDNN path uses by PyTorch default).
  * in / out / residual f32 NHWC, w_hi / w_lo bf16 [Cout][KS][KS][Cin] with w ~= w_hi + w_lo; Cin % 8 == 0. */
 int muse_conv2d_nhwc_split(const float* in, const void* w_hi, const void* w_lo, const float* bias, const float* residual,
-                           float* out, int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS,
-                           int32_t upsample, void* stream);
+                           float* out, double* gn_partial, int32_t gn_groups, int32_t batch, int32_t H, int32_t W,
+                           int32_t Cin, int32_t Cout, int32_t KS, int32_t upsample, void* stream);
+/*   gn_partial != NULL (conv_in :168, the 1x1 nin_shortcut :82-85): GroupNorm(gn_groups) sum / sum-of-squares of the output
+ *   per (image, 128-pixel tile, group), [B, H*W/128, gn_groups, 2] f64, as for muse_conv2d_nhwc_split2 below.  Needs
+ *   H*W % 128 == 0 and Cout/gn_groups a power of two in [4, 32]. */
 /* The same convolution for the 3x3 layers whose input comes out of GroupNorm+SiLU (conv1 / conv2 of every ResnetBlock
  * :73-80, conv_out :189): the activation arrives pre-split as two bf16 NHWC planes (muse_groupnorm_silu_nhwc_split) and all
  * operands go global -> LDS by DMA (csrc/conv_dma.hip).  Results are bit-identical to muse_conv2d_nhwc_split on the f32
@@ -252,6 +255,10 @@ int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* y_lo, const
                                    int32_t groups, float eps, int32_t apply_silu, void* stream);
 int muse_avgpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t C,
                          void* stream); /* F.avg_pool2d(2,2), :112; H,W = input dims */
+/* f32 avg_pool2d(2,2) that also leaves the GroupNorm(groups) statistics of its OUTPUT in `partial`
+ * ([B, muse_groupnorm_nchunk(H/2*W/2), groups, 2] f64): the first norm of the next encoder level (:73) skips its own pass. */
+int muse_avgpool2x2_nhwc_stats(const float* x, float* y, double* partial, int32_t groups, int32_t batch, int32_t H, int32_t W,
+                               int32_t C, void* stream);
 /* layout / dtype conversion: NCHW f32 <-> NHWC (f32|bf16), channel padding with zeros up to Cpad */
 int muse_nchw_to_nhwc(const float* in, void* out, int32_t out_dtype, int32_t batch, int32_t C, int32_t HW, int32_t Cpad,
                       void* stream);

@@ -14,6 +14,8 @@
 struct SplitParams {
   GemmParams g;      // A = f32 NHWC input, B = weight hi image, C = f32 output
   const void* Blo;   // weight lo image
+  double* gn_partial;  // optional [B, H*W/128, gn_groups, 2] sum / sum-of-squares of the output (next GroupNorm's statistics)
+  int gn_groups, gn_cpg;
 };
 
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams sp) {
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams sp) {
   const float* Rp = (const float*)p.residual;
   const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)Cp) & 15) == 0) &&
                       (Rp == nullptr || (((p.ldr & 3) == 0) && ((((uintptr_t)Rp) & 15) == 0)));
+  double gs[4] = {0.0, 0.0, 0.0, 0.0}, gq[4] = {0.0, 0.0, 0.0, 0.0};   // per column fragment j: this lane's 4 channels x 4 rows
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wr + i * 16 + (lane & 15);
@@ -123,6 +126,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams sp) {
       if (vec_ok && (n + 3) < p.N) {
         if (Rp) { float t[4]; OutVec<float>::load4(Rp + (long)m * p.ldr + n, t); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
         OutVec<float>::store4(cptr, v);
+        if (sp.gn_partial) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { gs[j] += (double)v[r]; gq[j] += (double)v[r] * (double)v[r]; }
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -130,16 +137,56 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams sp) {
       }
     }
   }
+  // GroupNorm partials (host guarantees H*W % 128 == 0, N % 4 == 0, 4 | cpg: the tile's 128 pixels are one image and a lane's
+  // 4 channels one group).  Fold the 16 row-lanes of each 4-channel chunk, the two row-halves (waves) through LDS, then the
+  // chunks of each group -- all in a fixed order.
+  if (sp.gn_partial) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { gs[j] += __shfl_xor(gs[j], o, 64); gq[j] += __shfl_xor(gq[j], o, 64); }
+    double* red = (double*)smem;   // [2 row halves][32 chunks][2]; the operand stages are idle (loop ended on a barrier)
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int chunk = (wc >> 2) + j * 4 + (lane >> 4);
+        red[((wave >> 1) * 32 + chunk) * 2] = gs[j];
+        red[((wave >> 1) * 32 + chunk) * 2 + 1] = gq[j];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      double cs = red[threadIdx.x * 2] + red[(32 + threadIdx.x) * 2];
+      double cq = red[threadIdx.x * 2 + 1] + red[(32 + threadIdx.x) * 2 + 1];
+      const int cpc = sp.gn_cpg >> 2;   // column chunks per group (1, 2, 4, 8)
+      for (int o = 1; o < cpc; o <<= 1) { cs += __shfl_xor(cs, o, 64); cq += __shfl_xor(cq, o, 64); }
+      const int n = n0 + (int)threadIdx.x * 4;
+      if ((threadIdx.x & (cpc - 1)) == 0 && n < p.N) {
+        const int hw = p.cH * p.cW, b = m0 / hw, chunk = (m0 - b * hw) >> 7, nchunk = hw >> 7;
+        double* o2 = sp.gn_partial + (((long)b * nchunk + chunk) * sp.gn_groups + n / sp.gn_cpg) * 2;
+        o2[0] = cs; o2[1] = cq;
+      }
+    }
+  }
 }
 
 extern "C" int muse_conv2d_nhwc_split(const float* in, const void* w_hi, const void* w_lo, const float* bias,
-                                      const float* residual, float* out, int32_t batch, int32_t H, int32_t W, int32_t Cin,
-                                      int32_t Cout, int32_t KS, int32_t upsample, void* stream) {
+                                      const float* residual, float* out, double* gn_partial, int32_t gn_groups, int32_t batch,
+                                      int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t upsample,
+                                      void* stream) {
   if (Cin % 8) return MUSE_ERR_ALIGN;  // bf16 weight rows in 16-byte chunks
   if ((((uintptr_t)in) & 15) || (((uintptr_t)w_hi) & 15) || (((uintptr_t)w_lo) & 15)) return MUSE_ERR_ALIGN;
   if (KS != 1 && KS != 3) return MUSE_ERR_UNSUPPORTED;
   if (upsample && ((H | W) & 1)) return MUSE_ERR_BAD_ARG;
   SplitParams sp;
+  sp.gn_partial = nullptr; sp.gn_groups = 0; sp.gn_cpg = 0;
+  if (gn_partial) {   // output statistics for the next GroupNorm, [batch, H*W/128, gn_groups, 2] doubles
+    const int cpg = gn_groups > 0 ? Cout / gn_groups : 0;
+    if (gn_groups <= 0 || (Cout % gn_groups) || (cpg & 3) || cpg > 32 || (cpg & (cpg - 1)) || ((H * W) & 127) || (Cout & 3) ||
+        (((uintptr_t)out) & 15) || (((uintptr_t)residual) & 15))
+      return MUSE_ERR_UNSUPPORTED;
+    sp.gn_partial = gn_partial; sp.gn_groups = gn_groups; sp.gn_cpg = cpg;
+  }
   GemmParams& p = sp.g;
   p.A = in; p.B = w_hi; p.C = out; sp.Blo = w_lo;
   p.bias = bias; p.rowvec = nullptr; p.residual = residual;

@@ -282,6 +282,65 @@ extern "C" int muse_avgpool2x2_nhwc(const void* x, void* y, int32_t dtype, int32
   return (int)hipGetLastError();
 }
 
+// pooled output + its GroupNorm statistics: block (chunk, b) produces output pixels [chunk*1024, +1024) of image b; a thread
+// keeps one 4-channel vector and strides over pixels (same decomposition and partial layout as gn_stats_kernel)
+__global__ __launch_bounds__(256) void avgpool_stats_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            double* __restrict__ partial, int H, int W, int C, int G) {
+  __shared__ double gs[64], gq[64];
+  const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+  if (threadIdx.x < G) { gs[threadIdx.x] = 0.0; gq[threadIdx.x] = 0.0; }
+  __syncthreads();
+  const int oh = H >> 1, ow = W >> 1, oHW = oh * ow, vpp = C >> 2, cpg = C / G;
+  const int p0 = chunk * GN_PIX_PER_CHUNK, p1 = min(oHW, p0 + GN_PIX_PER_CHUNK);
+  const int vc = threadIdx.x % vpp, ppi = 256 / vpp;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int UN = 2;
+  for (int pb = p0 + threadIdx.x / vpp; pb < p1; pb += UN * ppi) {
+    float a[UN][4], c0[UN][4], c1[UN][4], c2[UN][4];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int p = pb + u * ppi;
+      if (p < p1) {
+        const int oy = p / ow, ox = p - oy * ow;
+        const float* src = x + (((long)b * H + 2 * oy) * W + 2 * ox) * C + vc * 4;
+        loadv<float, 4>(src, a[u]); loadv<float, 4>(src + C, c0[u]);
+        loadv<float, 4>(src + (long)W * C, c1[u]); loadv<float, 4>(src + (long)W * C + C, c2[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int p = pb + u * ppi;
+      if (p >= p1) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[u][j] = (((a[u][j] + c0[u][j]) + c1[u][j]) + c2[u][j]) * 0.25f;
+        s[j] += (double)a[u][j]; q[j] += (double)a[u][j] * (double)a[u][j];
+      }
+      storev<float, 4>(y + ((long)b * oHW + p) * C + vc * 4, a[u]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = (vc * 4 + j) / cpg;
+    atomicAdd(&gs[g], s[j]); atomicAdd(&gq[g], q[j]);
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    double* o = partial + (((long)b * nchunk + chunk) * G + threadIdx.x) * 2;
+    o[0] = gs[threadIdx.x]; o[1] = gq[threadIdx.x];
+  }
+}
+extern "C" int muse_avgpool2x2_nhwc_stats(const float* x, float* y, double* partial, int32_t groups, int32_t batch, int32_t H,
+                                          int32_t W, int32_t C, void* stream) {
+  if ((C % 4) || ((H | W) & 1)) return MUSE_ERR_BAD_ARG;
+  const int vpp = C / 4;
+  if ((groups != 32 && groups != 64) || (C % groups) || vpp > 256 || (256 % vpp)) return MUSE_ERR_UNSUPPORTED;
+  if (batch <= 0 || H <= 0 || W <= 0) return 0;
+  const int nchunk = muse_groupnorm_nchunk((H / 2) * (W / 2));
+  hipLaunchKernelGGL(avgpool_stats_kernel, dim3(nchunk, batch), dim3(256), 0, (hipStream_t)stream, x, y, partial, H, W, C, groups);
+  return (int)hipGetLastError();
+}
+
 // =================================================================================================================
 // layout conversion NCHW f32 <-> NHWC (f32 | bf16) with zero channel padding
 // =================================================================================================================

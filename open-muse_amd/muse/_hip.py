@@ -92,8 +92,8 @@ SIGNATURES = {
     "muse_cond_dropout": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_float, c_void_p],
     "muse_conv2d_nhwc": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int, c_int, c_void_p],
-    "muse_conv2d_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_int, c_void_p],
+    "muse_conv2d_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_int, c_void_p],
     "muse_conv2d_nhwc_split2": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_int, c_int, c_int, c_int, c_void_p],
     "muse_groupnorm_silu_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -102,6 +102,7 @@ SIGNATURES = {
                                  c_float, c_int, c_void_p],
     "muse_groupnorm_nchunk": [c_int],
     "muse_avgpool2x2_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "muse_avgpool2x2_nhwc_stats": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "muse_nchw_to_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "muse_nhwc_to_nchw": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "muse_argmin_rows": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p],

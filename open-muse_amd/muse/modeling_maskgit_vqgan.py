@@ -187,7 +187,8 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
             return ops.conv2d_nhwc_split2(x[0], x[1], wp[0], wp[1], B, H, W, cp, cout, bias=bias, residual=residual,
                                           gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
         if cd == "bf16x3":
-            return ops.conv2d_nhwc_split(x, wp[0], wp[1], B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
+            return ops.conv2d_nhwc_split(x, wp[0], wp[1], B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample,
+                                         gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
         return ops.conv2d_nhwc(x, wp, B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
 
     def _gn(self, x, norm: _Norm, B, HW, C):
@@ -211,7 +212,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
             return self._conv(self._gn_for(h, blk.norm2, blk.conv2, B, H, W, cd), blk.conv2, B, H, W, cd, residual=x, gn_next=True)
         h = self._conv(self._gn_for(h, blk.norm2, blk.conv2, B, H, W, cd), blk.conv2, B, H, W, cd)
         # reference quirk (:82-85): the "shortcut" is a 1x1 conv of the conv2 output, out = h + nin(h)
-        return self._conv(h, blk.nin_shortcut, B, H, W, cd, residual=h)
+        return self._conv(h, blk.nin_shortcut, B, H, W, cd, residual=h, gn_next=True)
 
     def _check(self, t):
         if not t.is_cuda:
@@ -226,13 +227,13 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         enc = self.encoder
         B, C, H, W = pixel_values.shape
         x = ops.nchw_to_nhwc(pixel_values.float(), self._act_dtype(), self._cpad(C, cd))
-        h = self._conv(x, enc.conv_in, B, H, W, cd)
+        h = self._conv(x, enc.conv_in, B, H, W, cd, gn_next=True)
         nres = self.config.num_resolutions
         for lvl, down in enumerate(enc.down):
             for blk in down.block:
                 h = self._res(h, blk, B, H, W, cd)
             if lvl != nres - 1:
-                h = ops.avgpool2x2_nhwc(h, B, H, W, h.shape[-1])
+                h = ops.avgpool2x2_nhwc(h, B, H, W, h.shape[-1], gn_groups=32 if (cd == "bf16x3" and self.fuse_gn_stats) else 0)
                 H, W = H // 2, W // 2
         for blk in enc.mid:
             h = self._res(h, blk, B, H, W, cd)
@@ -249,7 +250,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         cd = self.compute_dtype
         dec = self.decoder
         nres = self.config.num_resolutions
-        h = self._conv(zq, dec.conv_in, B, H, W, cd)
+        h = self._conv(zq, dec.conv_in, B, H, W, cd, gn_next=True)
         for blk in dec.mid:
             h = self._res(h, blk, B, H, W, cd)
         for lvl in reversed(range(nres)):
@@ -258,7 +259,7 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
                 h = self._res(h, blk, B, H, W, cd)
             if lvl != 0:
                 H, W = H * 2, W * 2
-                h = self._conv(h, up.upsample_conv, B, H, W, cd, upsample=True)
+                h = self._conv(h, up.upsample_conv, B, H, W, cd, upsample=True, gn_next=True)
         h = self._gn_for(h, dec.norm_out, dec.conv_out, B, H, W, cd)
         out = self._conv(h, dec.conv_out, B, H, W, cd)
         return ops.nhwc_to_nchw(out, self.config.num_channels)

@@ -590,14 +590,23 @@ def split_bf16(w):
     return hi, lo
 
 
-def conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=None, residual=None, upsample=False):
-    """f32 NHWC convolution as 3 bf16 MFMAs per product (see muse_conv2d_nhwc_split)"""
+def conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=None, residual=None, upsample=False, gn_groups=0):
+    """f32 NHWC convolution as 3 bf16 MFMAs per product (see muse_conv2d_nhwc_split).  gn_groups > 0: the epilogue also
+    leaves the GroupNorm statistics of the output on the returned tensor (`out._gn_stats = (partial, nchunk)`)."""
     require_gpu(x, w_hi, w_lo)
     out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    part, nchunk = None, 0
+    cpg = Cout // gn_groups if gn_groups else 0
+    if gn_groups and Cout % gn_groups == 0 and cpg in (4, 8, 16, 32) and (H * W) % 128 == 0:
+        nchunk = (H * W) // 128
+        part = torch.empty(B * nchunk * gn_groups * 2, dtype=torch.float64, device=out.device)
     e0 = _prof_begin()
     check(lib().muse_conv2d_nhwc_split(x.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(), ptr(bias), ptr(residual), out.data_ptr(),
-                                       B, H, W, Cin, Cout, KS, 1 if upsample else 0, stream()), "muse_conv2d_nhwc_split")
+                                       ptr(part), gn_groups if part is not None else 0, B, H, W, Cin, Cout, KS,
+                                       1 if upsample else 0, stream()), "muse_conv2d_nhwc_split")
     _prof_end(e0, "conv_bf16x3", 2.0 * B * H * W * Cout * KS * KS * Cin)
+    if part is not None:
+        out._gn_stats = (part, nchunk)
     return out
 
 
@@ -665,11 +674,21 @@ def groupnorm_silu_nhwc(x, gamma, beta, B, HW, C, groups=32, eps=1e-6, silu=True
     return y
 
 
-def avgpool2x2_nhwc(x, B, H, W, C_):
+def avgpool2x2_nhwc(x, B, H, W, C_, gn_groups=0):
+    """F.avg_pool2d(2, 2) on NHWC.  gn_groups > 0 (f32): the same pass also leaves the GroupNorm statistics of the pooled
+    tensor on it (`y._gn_stats`), so the next level's first norm does not re-read it."""
     require_gpu(x)
     y = torch.empty((B, H // 2, W // 2, C_), dtype=x.dtype, device=x.device)
     e0 = _prof_begin()
-    check(lib().muse_avgpool2x2_nhwc(x.data_ptr(), y.data_ptr(), dt(x), B, H, W, C_, stream()), "muse_avgpool2x2_nhwc")
+    vpp = C_ // 4
+    if gn_groups and x.dtype == torch.float32 and C_ % 4 == 0 and C_ % gn_groups == 0 and vpp <= 256 and 256 % vpp == 0:
+        nchunk = lib().muse_groupnorm_nchunk((H // 2) * (W // 2))
+        part = torch.empty(B * nchunk * gn_groups * 2, dtype=torch.float64, device=x.device)
+        check(lib().muse_avgpool2x2_nhwc_stats(x.data_ptr(), y.data_ptr(), part.data_ptr(), gn_groups, B, H, W, C_, stream()),
+              "muse_avgpool2x2_nhwc_stats")
+        y._gn_stats = (part, nchunk)
+    else:
+        check(lib().muse_avgpool2x2_nhwc(x.data_ptr(), y.data_ptr(), dt(x), B, H, W, C_, stream()), "muse_avgpool2x2_nhwc")
     _prof_end(e0, "avgpool2x2", _nbytes(x, y), "byte")
     return y
 

@@ -530,6 +530,59 @@ def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
     assert torch.equal(y_hi.view(torch.int16), e_hi.view(torch.int16)) and torch.equal(y_lo.view(torch.int16), e_lo.view(torch.int16))
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,KS,res,ups", [
+    (2, 16, 16, 8, 128, 3, False, False),    # conv_in shape: 3 (padded to 8) -> 128, 4 channels per group
+    (3, 16, 8, 128, 256, 1, True, False),    # nin_shortcut: 1x1, residual, 8 channels per group, one tile per image
+    (1, 32, 16, 64, 512, 3, False, True),    # upsample conv: 16 channels per group, 4 pixel x 4 channel tiles
+    (2, 16, 32, 32, 1024, 1, True, False),   # 32 channels per group
+])
+def test_conv2d_split_fused_groupnorm_stats(B, H, W, Cin, Cout, KS, res, ups):
+    """muse_conv2d_nhwc_split with gn_partial: same output bits, and [B, HW/128, 32, 2] f64 sums of that output"""
+    ops = _ops()
+    hin, win = (H // 2, W // 2) if ups else (H, W)
+    x = rnd((B, hin, win, Cin), 190).to(DEV)
+    w_hi, w_lo = ops.split_bf16((rnd((Cout, KS, KS, Cin), 191) / math.sqrt(KS * KS * Cin)).to(DEV))
+    bvec = rnd((Cout,), 192).to(DEV)
+    rr = rnd((B, H, W, Cout), 193).to(DEV) if res else None
+    ref = ops.conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=bvec, residual=rr, upsample=ups)
+    got = ops.conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=bvec, residual=rr, upsample=ups, gn_groups=32)
+    assert torch.equal(got, ref)
+    part, nchunk = got._gn_stats
+    assert nchunk == H * W // 128
+    st = part.view(B, nchunk, 32, 2).sum(1).cpu()
+    o = ref.cpu().double().view(B, H * W, 32, Cout // 32)
+    assert rel_err(st[..., 0], o.sum((1, 3))) < 1e-12 and rel_err(st[..., 1], (o * o).sum((1, 3))) < 1e-12
+    if 256 % (Cout // 4) == 0:
+        gam, bet = (1 + 0.1 * rnd((Cout,), 194)).to(DEV), (0.1 * rnd((Cout,), 195)).to(DEV)
+        a_hi, a_lo = ops.groupnorm_silu_nhwc_split(ref, gam, bet, B, H * W, Cout)
+        b_hi, b_lo = ops.groupnorm_silu_nhwc_split(got, gam, bet, B, H * W, Cout, stats=got._gn_stats)
+        assert rel_err(b_hi.float() + b_lo.float(), a_hi.float() + a_lo.float()) < 1e-6
+    # shapes the fused statistics do not take fall back to a plain call (no _gn_stats attribute)
+    odd = ops.conv2d_nhwc_split(x[:, :6].contiguous(), w_hi, w_lo, B, 12 if ups else 6, W, Cin, Cout, KS, bias=bvec, upsample=ups, gn_groups=32)
+    assert not hasattr(odd, "_gn_stats")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 128), (3, 16, 24, 256), (1, 8, 8, 512), (2, 90, 46, 128)])
+def test_avgpool_fused_groupnorm_stats(B, H, W, C):
+    """muse_avgpool2x2_nhwc_stats: the pooled tensor is bit-identical to muse_avgpool2x2_nhwc and the partials are the f64
+    group sums of it (several 1024-pixel chunks per image in the first case, a ragged last chunk in the last)"""
+    ops = _ops()
+    x = rnd((B, H, W, C), 196).to(DEV)
+    ref = ops.avgpool2x2_nhwc(x, B, H, W, C)
+    got = ops.avgpool2x2_nhwc(x, B, H, W, C, gn_groups=32)
+    assert torch.equal(got, ref)
+    part, nchunk = got._gn_stats
+    ohw = (H // 2) * (W // 2)
+    assert nchunk == (ohw + 1023) // 1024
+    st = part.view(B, nchunk, 32, 2).sum(1).cpu()
+    o = ref.cpu().double().view(B, ohw, 32, C // 32)
+    assert rel_err(st[..., 0], o.sum((1, 3))) < 1e-12 and rel_err(st[..., 1], (o * o).sum((1, 3))) < 1e-12
+    gam, bet = (1 + 0.1 * rnd((C,), 197)).to(DEV), (0.1 * rnd((C,), 198)).to(DEV)
+    a_hi, a_lo = ops.groupnorm_silu_nhwc_split(ref, gam, bet, B, ohw, C)
+    b_hi, b_lo = ops.groupnorm_silu_nhwc_split(got, gam, bet, B, ohw, C, stats=got._gn_stats)
+    assert rel_err(b_hi.float() + b_lo.float(), a_hi.float() + a_lo.float()) < 1e-6
+
+
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (520, 264, 200), (1000, 520, 712), (264, 776, 64)])
