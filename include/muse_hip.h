@@ -218,6 +218,10 @@ int muse_cond_dropout(const float* x, const float* empty, const float* uniforms,
  *   on MFMA; weight pre-permuted to [Cout][KS][KS][Cin]; optional bias (f32 [Cout]), optional residual add
  *   (ResnetBlock :85), optional nearest x2 upsample of the input folded into the gather (UpsamplingBlock :146-147).
  *   H, W are the OUTPUT spatial dims.  Cin must be a multiple of 16/elsize.
+ *   upsample: 0 = stride 1;  1 = input is [H/2, W/2], nearest x2 upsampled on the fly;  2 = input is [2H, 2W], stride-2
+ *   3x3 convolution over it zero-padded by one row / column at the bottom / right (taming-VQGAN Downsample,
+ *   muse/modeling_taming_vqgan.py:53-59: F.pad(0,1,0,1) + Conv2d(3, stride 2, padding 0)).  Same meaning in
+ *   muse_conv2d_nhwc_split.
  */
 int muse_conv2d_nhwc(const void* in, const void* weight, const float* bias, const void* residual, void* out,
                      int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS,

@@ -177,7 +177,8 @@ extern "C" int muse_conv2d_nhwc_split(const float* in, const void* w_hi, const v
   if (Cin % 8) return MUSE_ERR_ALIGN;  // bf16 weight rows in 16-byte chunks
   if ((((uintptr_t)in) & 15) || (((uintptr_t)w_hi) & 15) || (((uintptr_t)w_lo) & 15)) return MUSE_ERR_ALIGN;
   if (KS != 1 && KS != 3) return MUSE_ERR_UNSUPPORTED;
-  if (upsample && ((H | W) & 1)) return MUSE_ERR_BAD_ARG;
+  if (upsample < 0 || upsample > 2 || (upsample == 2 && KS != 3)) return MUSE_ERR_BAD_ARG;
+  if (upsample == 1 && ((H | W) & 1)) return MUSE_ERR_BAD_ARG;
   SplitParams sp;
   sp.gn_partial = nullptr; sp.gn_groups = 0; sp.gn_cpg = 0;
   if (gn_partial) {   // output statistics for the next GroupNorm, [batch, H*W/128, gn_groups, 2] doubles
@@ -194,7 +195,7 @@ extern "C" int muse_conv2d_nhwc_split(const float* in, const void* w_hi, const v
   p.lda = 0; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
   p.zdiv = 1; p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
   p.alpha = 1.0f; p.accumulate = 0; p.act = 0; p.split_k = 1; p.split_stride = 0;
-  p.cH = H; p.cW = W; p.cCin = Cin; p.cKS = KS; p.cUps = upsample ? 1 : 0;
+  p.cH = H; p.cW = W; p.cCin = Cin; p.cKS = KS; p.cUps = upsample;
   p.cCinShift = -1;
   if ((Cin & (Cin - 1)) == 0) { int sh = 0; while ((1 << sh) < Cin) ++sh; p.cCinShift = sh; }
   if (p.M <= 0 || p.N <= 0) return 0;

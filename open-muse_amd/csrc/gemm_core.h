@@ -125,9 +125,11 @@ struct PlainLoader {
   }
 };
 
-// implicit-GEMM A operand of an NHWC stride-1 SAME convolution:  m = (b, y, x),  k = (ky, kx, cin)
-// optional nearest x2 upsample of the input folded into the index math (decoder upsample_conv).
-// Per chunk: `center` = byte offset of the pixel's own (0,0)-tap data, `tapmask` bit t = tap t lies inside the image.
+// implicit-GEMM A operand of an NHWC convolution:  m = (b, y, x) over the OUTPUT pixels,  k = (ky, kx, cin).  cUps selects
+// the input geometry:  0 = stride 1, SAME padding;  1 = nearest x2 upsample of the input folded into the index math
+// (decoder upsample_conv);  2 = stride 2 over a (2H x 2W) input zero-padded by one row / column at the bottom / right
+// (taming Downsample: F.pad(0,1,0,1) + Conv2d(3, stride 2, padding 0), muse/modeling_taming_vqgan.py:53-59).
+// Per chunk: `center` = byte offset of the pixel's first-tap data, `tapmask` bit t = tap t lies inside the image.
 template <typename T, int ROWS, int NT>
 struct ConvLoader {
   using Cfg = TileCfg<T>;
@@ -136,17 +138,18 @@ struct ConvLoader {
   rsrc_t rs;
   unsigned center[NCH], tapmask[NCH], pyx[NCH];
   unsigned oob;
-  int W, iw, Cin, KS, ups, cshift;
+  int iw, Cin, KS, ups, cshift, padv;
   __device__ __forceinline__ void init(const void* ptr, long, int R_, int K_, int r0_, const GemmParams& p) {
     constexpr int E = (int)sizeof(T);
-    const int H = p.cH;
-    W = p.cW; Cin = p.cCin; KS = p.cKS; ups = p.cUps; cshift = p.cCinShift;
-    const int ih = ups ? (H >> 1) : H;
-    iw = ups ? (W >> 1) : W;
+    const int H = p.cH, W = p.cW;
+    Cin = p.cCin; KS = p.cKS; ups = p.cUps; cshift = p.cCinShift;
+    const int ih = ups == 1 ? (H >> 1) : ups == 2 ? (H << 1) : H;
+    iw = ups == 1 ? (W >> 1) : ups == 2 ? (W << 1) : W;
     const unsigned bytes = (unsigned)((long)(R_ / (H * W)) * ih * iw * Cin * E);
     rs = make_rsrc(ptr, bytes);
     oob = (bytes + 15u) & ~15u;
     const int pad = (KS - 1) >> 1;
+    padv = ups == 2 ? 0 : pad;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = threadIdx.x + NT * i;
@@ -157,13 +160,19 @@ struct ConvLoader {
       if (m < R_) {
         for (int t = 0; t < KS * KS; ++t) {
           const int ky = t / KS, kx = t - ky * KS;
-          const int iy = y + ky - pad, ix = x + kx - pad;
-          if (iy >= 0 && iy < H && ix >= 0 && ix < W) mask |= 1u << t;
+          if (ups == 2) {
+            if (2 * y + ky < ih && 2 * x + kx < iw) mask |= 1u << t;
+          } else {
+            const int iy = y + ky - pad, ix = x + kx - pad;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) mask |= 1u << t;
+          }
         }
       }
       tapmask[i] = mask;
       pyx[i] = (unsigned)y | ((unsigned)x << 16);
-      center[i] = ups ? (unsigned)(b * ih * iw) : (unsigned)(((long)(b * H + y) * W + x) * Cin * E);
+      center[i] = ups == 1 ? (unsigned)(b * ih * iw)
+                : ups == 2 ? (unsigned)(((long)(b * ih + 2 * y) * iw + 2 * x) * Cin * E)
+                           : (unsigned)(((long)(b * H + y) * W + x) * Cin * E);
     }
   }
   __device__ __forceinline__ u32x4 load(int i, int k0) const {
@@ -171,12 +180,13 @@ struct ConvLoader {
     const int c = threadIdx.x + NT * i;
     const int k = k0 + (c % CPR) * Cfg::CH;
     const int kpos = cshift >= 0 ? (k >> cshift) : (k / Cin), ci = k - kpos * Cin;
-    const int ky = KS == 3 ? ((kpos * 11) >> 5) : 0, kx = kpos - ky * KS, pad = (KS - 1) >> 1;  // valid taps: kpos < 9
+    const int ky = KS == 3 ? ((kpos * 11) >> 5) : 0, kx = kpos - ky * KS;  // valid taps: kpos < 9
     const bool ok = kpos < 9 && ((tapmask[i] >> kpos) & 1u);
     unsigned off;
-    if (!ups) {
-      off = center[i] + (unsigned)((((ky - pad) * W + (kx - pad)) * Cin + ci) * E);
+    if (ups != 1) {
+      off = center[i] + (unsigned)((((ky - padv) * iw + (kx - padv)) * Cin + ci) * E);
     } else {
+      const int pad = (KS - 1) >> 1;
       const int iy = ((int)(pyx[i] & 0xffffu) + ky - pad) >> 1, ix = ((int)(pyx[i] >> 16) + kx - pad) >> 1;
       off = (unsigned)(((long)(center[i] + (unsigned)(iy * iw + ix)) * Cin + ci) * E);
     }

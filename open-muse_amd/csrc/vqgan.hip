@@ -13,7 +13,8 @@ extern "C" int muse_conv2d_nhwc(const void* in, const void* weight, const float*
   if (Cin % ch) return MUSE_ERR_ALIGN;
   if ((((uintptr_t)in) & 15) || (((uintptr_t)weight) & 15)) return MUSE_ERR_ALIGN;
   if (KS != 1 && KS != 3) return MUSE_ERR_UNSUPPORTED;
-  if (upsample && ((H | W) & 1)) return MUSE_ERR_BAD_ARG;
+  if (upsample < 0 || upsample > 2 || (upsample == 2 && KS != 3)) return MUSE_ERR_BAD_ARG;
+  if (upsample == 1 && ((H | W) & 1)) return MUSE_ERR_BAD_ARG;
   GemmParams p;
   p.A = in; p.B = weight; p.C = out;
   p.bias = bias; p.rowvec = nullptr; p.residual = residual;
@@ -21,7 +22,7 @@ extern "C" int muse_conv2d_nhwc(const void* in, const void* weight, const float*
   p.lda = 0; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
   p.zdiv = 1; p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = 0;
   p.alpha = 1.0f; p.accumulate = 0; p.act = 0; p.split_k = 1; p.split_stride = 0;
-  p.cH = H; p.cW = W; p.cCin = Cin; p.cKS = KS; p.cUps = upsample ? 1 : 0;
+  p.cH = H; p.cW = W; p.cCin = Cin; p.cKS = KS; p.cUps = upsample;
   p.cCinShift = -1;
   if ((Cin & (Cin - 1)) == 0) { int sh = 0; while ((1 << sh) < Cin) ++sh; p.cCinShift = sh; }
   hipStream_t s = (hipStream_t)stream;

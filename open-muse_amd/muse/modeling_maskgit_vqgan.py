@@ -105,38 +105,20 @@ class _Quantizer(nn.Module):
         self.embedding.weight.data.uniform_(-1.0 / n, 1.0 / n)  # reference :265
 
 
-class MaskGitVQGAN(ModelMixin, ConfigMixin):
-    @register_to_config
-    def __init__(
-        self,
-        resolution: int = 256,
-        num_channels: int = 3,
-        hidden_channels: int = 128,
-        channel_mult: Tuple = (1, 1, 2, 2, 4),
-        num_res_blocks: int = 2,
-        attn_resolutions: int = (16,),
-        z_channels: int = 256,
-        num_embeddings: int = 1024,
-        quantized_embed_dim: int = 256,
-        dropout: float = 0.0,
-        resample_with_conv: bool = True,
-        commitment_cost: float = 0.25,
-    ):
-        super().__init__()
-        if dropout != 0.0:
-            raise NotImplementedError("dropout > 0 in the VQGAN is outside the MI355X hot-path build")
-        if z_channels != quantized_embed_dim:
-            raise ValueError("z_channels must equal quantized_embed_dim")
-        self.config.num_resolutions = len(channel_mult)
-        self.config.reduction_factor = 2 ** (self.config.num_resolutions - 1)
-        self.config.latent_size = resolution // self.config.reduction_factor
-        self.encoder = _Encoder(self.config)
-        self.decoder = _Decoder(self.config)
-        self.quantize = _Quantizer(num_embeddings, quantized_embed_dim)
+class _ConvEngine:
+    """What both tokenizers (MaskGitVQGAN here, the taming VQGANModel in modeling_taming_vqgan.py) share: NHWC activations,
+    packed convolution weights per compute dtype, the convolution / GroupNorm dispatch over libmuse_hip, and the rule that
+    there is no CPU path."""
+
+    def _init_engine(self):
         self.compute_dtype = torch.float32
-        self.fuse_gn_stats = True   # ... and their epilogues produce the next GroupNorm's statistics
-        self.dma_conv = True   # "bf16x3" mode: 3x3 convs after GroupNorm run as the LDS-DMA kernel on pre-split planes
+        self.fuse_gn_stats = True   # convolution / pooling epilogues produce the next GroupNorm's statistics
+        self.dma_conv = True        # "bf16x3" mode: 3x3 convs after GroupNorm run as the LDS-DMA kernel on pre-split planes
         self._packed = {}
+
+    def _check(self, t):
+        if not t.is_cuda:
+            raise MuseHipError(f"{type(self).__name__} (MI355X build) has no CPU path: move the model and inputs to the GPU")
 
     # ---- weight packing: [Cout,Cin,k,k] -> [Cout,k,k,Cin_pad] in the compute dtype ------------------------------------
     def set_compute_dtype(self, dtype):
@@ -191,8 +173,8 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
                                          gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
         return ops.conv2d_nhwc(x, wp, B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
 
-    def _gn(self, x, norm: _Norm, B, HW, C):
-        return ops.groupnorm_silu_nhwc(x, norm.weight.data, norm.bias.data, B, HW, C, groups=32, eps=1e-6, silu=True)
+    def _gn(self, x, norm: _Norm, B, HW, C, silu=True):
+        return ops.groupnorm_silu_nhwc(x, norm.weight.data, norm.bias.data, B, HW, C, groups=32, eps=1e-6, silu=silu)
 
     def _gn_for(self, x, norm: _Norm, conv: _Conv, B, H, W, cd):
         """GroupNorm+SiLU feeding `conv`: in "bf16x3" mode the result is written directly as the (hi, lo) bf16 operand
@@ -202,6 +184,37 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
             return ops.groupnorm_silu_nhwc_split(x, norm.weight.data, norm.bias.data, B, H * W, cin, groups=32, eps=1e-6, silu=True,
                                                  stats=getattr(x, "_gn_stats", None))
         return self._gn(x, norm, B, H * W, cin)
+
+
+class MaskGitVQGAN(_ConvEngine, ModelMixin, ConfigMixin):
+    @register_to_config
+    def __init__(
+        self,
+        resolution: int = 256,
+        num_channels: int = 3,
+        hidden_channels: int = 128,
+        channel_mult: Tuple = (1, 1, 2, 2, 4),
+        num_res_blocks: int = 2,
+        attn_resolutions: int = (16,),
+        z_channels: int = 256,
+        num_embeddings: int = 1024,
+        quantized_embed_dim: int = 256,
+        dropout: float = 0.0,
+        resample_with_conv: bool = True,
+        commitment_cost: float = 0.25,
+    ):
+        super().__init__()
+        if dropout != 0.0:
+            raise NotImplementedError("dropout > 0 in the VQGAN is outside the MI355X hot-path build")
+        if z_channels != quantized_embed_dim:
+            raise ValueError("z_channels must equal quantized_embed_dim")
+        self.config.num_resolutions = len(channel_mult)
+        self.config.reduction_factor = 2 ** (self.config.num_resolutions - 1)
+        self.config.latent_size = resolution // self.config.reduction_factor
+        self.encoder = _Encoder(self.config)
+        self.decoder = _Decoder(self.config)
+        self.quantize = _Quantizer(num_embeddings, quantized_embed_dim)
+        self._init_engine()
 
     def _res(self, x, blk: _Res, B, H, W, cd):
         cin = blk.conv1.weight.shape[1]
@@ -213,10 +226,6 @@ class MaskGitVQGAN(ModelMixin, ConfigMixin):
         h = self._conv(self._gn_for(h, blk.norm2, blk.conv2, B, H, W, cd), blk.conv2, B, H, W, cd)
         # reference quirk (:82-85): the "shortcut" is a 1x1 conv of the conv2 output, out = h + nin(h)
         return self._conv(h, blk.nin_shortcut, B, H, W, cd, residual=h, gn_next=True)
-
-    def _check(self, t):
-        if not t.is_cuda:
-            raise MuseHipError("MaskGitVQGAN (MI355X build) has no CPU path: move the model and inputs to the GPU")
 
     # ---- encoder / decoder ----------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -573,12 +573,13 @@ def cond_dropout(x, empty, uniforms, prob):
 
 # ---- VQGAN (NHWC) ----------------------------------------------------------------------------------------------
 def conv2d_nhwc(x, w, B, H, W, Cin, Cout, KS, bias=None, residual=None, upsample=False):
-    """x: [B, Hin, Win, Cin] (Hin = H/2 if upsample), w: [Cout, KS, KS, Cin]; returns [B, H, W, Cout]."""
+    """x: [B, Hin, Win, Cin], w: [Cout, KS, KS, Cin]; returns [B, H, W, Cout].  upsample: False / 0 = stride 1 (Hin = H);
+    True / 1 = nearest x2 upsample folded in (Hin = H/2);  2 = stride-2 3x3 over the bottom/right zero-padded input (Hin = 2H)."""
     require_gpu(x, w)
     out = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
     e0 = _prof_begin()
     check(lib().muse_conv2d_nhwc(x.data_ptr(), w.data_ptr(), ptr(bias), ptr(residual), out.data_ptr(), dt(x), B, H, W, Cin,
-                                 Cout, KS, 1 if upsample else 0, stream()), "muse_conv2d_nhwc")
+                                 Cout, KS, int(upsample), stream()), "muse_conv2d_nhwc")
     _prof_end(e0, f"conv_{'bf16' if x.dtype == torch.bfloat16 else 'f32'}", 2.0 * B * H * W * Cout * KS * KS * Cin)
     return out
 
@@ -603,7 +604,7 @@ def conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, KS, bias=None, residual
     e0 = _prof_begin()
     check(lib().muse_conv2d_nhwc_split(x.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(), ptr(bias), ptr(residual), out.data_ptr(),
                                        ptr(part), gn_groups if part is not None else 0, B, H, W, Cin, Cout, KS,
-                                       1 if upsample else 0, stream()), "muse_conv2d_nhwc_split")
+                                       int(upsample), stream()), "muse_conv2d_nhwc_split")
     _prof_end(e0, "conv_bf16x3", 2.0 * B * H * W * Cout * KS * KS * Cin)
     if part is not None:
         out._gn_stats = (part, nchunk)

@@ -86,6 +86,37 @@ def golden_vqgan(name, cfg, batch, seed):
     print(name, "z", z.shape, "idx", idx.shape, "rec", rec.shape, "min margin", float(out["margin"].min()))
 
 
+def golden_taming(name, cfg, batch, seed):
+    """the taming tokenizer of the text-to-image configs (muse/modeling_taming_vqgan.py:512-585, configs/cc12m_uvit_clip.yaml
+    :19-21): encoder latents, quant_conv output, indices, z_q, reconstruction, and the top-2 distance margin per token"""
+    from muse.modeling_taming_vqgan import VQGANModel
+    model = VQGANModel(**cfg)
+    sd = W.fill_state_dict(W.taming_shapes(cfg), seed, "vqgan")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    px = W.images(batch, cfg["resolution"], seed + 1)
+    with torch.no_grad():
+        enc = model.encoder(px)
+        z = model.quant_conv(enc)
+        z_q, idx = model.encode(px)
+        rec = model.decode_code(idx)
+        rec2 = model.decode(z_q)
+        code = model.get_code(px)
+        dist = model.quantize.compute_distances(z.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(code, idx)
+    # (decode_code feeds a permuted view, decode a contiguous tensor: same math, the CPU convolution may round differently)
+    print(name, "decode_code vs decode(z_q): max abs diff", float((rec - rec2).abs().max()))
+    top2 = torch.topk(dist, 2, dim=1, largest=False).values
+    out = dict(enc=np_(enc), z=np_(z), z_q=np_(z_q), indices=np_(idx), rec=np_(rec), rec_decode=np_(rec2),
+               margin=np_(top2[:, 1] - top2[:, 0]),
+               batch=np.int64(batch), seed=np.int64(seed))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    with open(os.path.join(HERE, "config_" + name + ".json"), "w") as f:
+        f.write(model.to_json_string())   # what the reference's save_pretrained writes as config.json
+    print(name, "z", z.shape, "idx", idx.shape, "rec", rec.shape, "min margin", float(out["margin"].min()),
+          "distinct codes", len(set(idx.flatten().tolist())))
+
+
 def golden_mask(name, batch, seq, seed, mask_id, codebook_size, min_rate):
     """training/train_maskgit_imagenet.py:371-394 executed line by line with supplied uniforms."""
     rng = np.random.default_rng(seed)
@@ -344,3 +375,5 @@ if __name__ == "__main__":
     golden_mask_muse("mask_muse", seed=540)
     golden_transformer_autocast("transformer_tiny_bf16", W.TRANSFORMER_TINY, batch=3, seed=100)
     golden_transformer_autocast("transformer_hd48_bf16", W.TRANSFORMER_HD48, batch=2, seed=120)
+    golden_taming("taming_tiny", W.TAMING_TINY, batch=2, seed=600)
+    golden_taming("taming_tiny_pool", W.TAMING_TINY_POOL, batch=3, seed=610)

@@ -25,6 +25,18 @@ VQGAN_TINY = dict(
     z_channels=16, num_embeddings=32, quantized_embed_dim=16,
 )
 
+# taming VQGANModel (muse/modeling_taming_vqgan.py:512-550): attention at resolution 8 (down level 2, up level 2) and in the mid
+# blocks, stride-2 conv downsampling, conv upsampling, quant_conv 24 -> 16 and back
+TAMING_TINY = dict(
+    resolution=32, num_channels=3, hidden_channels=32, channel_mult=(1, 2, 2), num_res_blocks=2, attn_resolutions=(8,),
+    no_attn_mid_block=False, z_channels=24, num_embeddings=40, quantized_embed_dim=16, resample_with_conv=True,
+)
+# ... and the other branches: avg-pool / plain nearest resampling, no mid attention, no level attention
+TAMING_TINY_POOL = dict(
+    resolution=16, num_channels=3, hidden_channels=32, channel_mult=(1, 2), num_res_blocks=1, attn_resolutions=(),
+    no_attn_mid_block=True, z_channels=16, num_embeddings=24, quantized_embed_dim=16, resample_with_conv=False,
+)
+
 # ---- full-size configs (SURVEY.md section 8 legend) --------------------------------------------------------------
 TRANSFORMER_A = dict(  # README.md:90-100 ("hidden=512, 8 layers" in BASELINE.json)
     vocab_size=2025, hidden_size=512, num_hidden_layers=8, num_attention_heads=8, intermediate_size=2048,
@@ -115,6 +127,81 @@ def vqgan_shapes(cfg: dict) -> dict:
     s["decoder.conv_out.weight"] = (cfg["num_channels"], hc * mult[0], 3, 3)
     s["decoder.conv_out.bias"] = (cfg["num_channels"],)
     s["quantize.embedding.weight"] = (cfg["num_embeddings"], cfg["quantized_embed_dim"])
+    return s
+
+
+def taming_shapes(cfg: dict) -> dict:
+    """state_dict template of the taming muse.VQGANModel (muse/modeling_taming_vqgan.py; every convolution has a bias)"""
+    hc, mult, nb = cfg["hidden_channels"], tuple(cfg["channel_mult"]), cfg["num_res_blocks"]
+    nres, attn_res, with_conv = len(mult), tuple(cfg.get("attn_resolutions", (16,))), cfg.get("resample_with_conv", True)
+    s = {}
+
+    def conv(prefix, cout, cin, k):
+        s[prefix + "weight"] = (cout, cin, k, k)
+        s[prefix + "bias"] = (cout,)
+
+    def norm(prefix, c):
+        s[prefix + "weight"] = (c,)
+        s[prefix + "bias"] = (c,)
+
+    def res(prefix, cin, cout):
+        norm(prefix + "norm1.", cin)
+        conv(prefix + "conv1.", cout, cin, 3)
+        norm(prefix + "norm2.", cout)
+        conv(prefix + "conv2.", cout, cout, 3)
+        if cin != cout:
+            conv(prefix + "nin_shortcut.", cout, cin, 1)
+
+    def attn(prefix, c):
+        norm(prefix + "norm.", c)
+        for n in ("q", "k", "v", "proj_out"):
+            conv(prefix + n + ".", c, c, 1)
+
+    def mid(prefix, c):
+        res(prefix + "block_1.", c, c)
+        if not cfg.get("no_attn_mid_block", False):
+            attn(prefix + "attn_1.", c)
+        res(prefix + "block_2.", c, c)
+
+    conv("encoder.conv_in.", hc, cfg["num_channels"], 3)
+    in_mult = (1,) + mult
+    cur = cfg["resolution"]
+    for lvl in range(nres):
+        cin, cout = hc * in_mult[lvl], hc * mult[lvl]
+        for b in range(nb):
+            res(f"encoder.down.{lvl}.block.{b}.", cin, cout)
+            cin = cout
+            if cur in attn_res:
+                attn(f"encoder.down.{lvl}.attn.{b}.", cout)
+        if lvl != nres - 1:
+            if with_conv:
+                conv(f"encoder.down.{lvl}.downsample.conv.", cout, cout, 3)
+            cur //= 2
+    m = hc * mult[-1]
+    mid("encoder.mid.", m)
+    norm("encoder.norm_out.", m)
+    conv("encoder.conv_out.", cfg["z_channels"], m, 3)
+
+    conv("decoder.conv_in.", m, cfg["z_channels"], 3)
+    mid("decoder.mid.", m)
+    cur = cfg["resolution"] // 2 ** (nres - 1)
+    for lvl in reversed(range(nres)):
+        cin = hc * mult[-1] if lvl == nres - 1 else hc * mult[lvl + 1]
+        cout = hc * mult[lvl]
+        for b in range(nb + 1):
+            res(f"decoder.up.{lvl}.block.{b}.", cin, cout)
+            cin = cout
+            if cur in attn_res:
+                attn(f"decoder.up.{lvl}.attn.{b}.", cout)
+        if lvl != 0:
+            if with_conv:
+                conv(f"decoder.up.{lvl}.upsample.conv.", cout, cout, 3)
+            cur *= 2
+    norm("decoder.norm_out.", hc * mult[0])
+    conv("decoder.conv_out.", cfg["num_channels"], hc * mult[0], 3)
+    s["quantize.embedding.weight"] = (cfg["num_embeddings"], cfg["quantized_embed_dim"])
+    conv("quant_conv.", cfg["quantized_embed_dim"], cfg["z_channels"], 1)
+    conv("post_quant_conv.", cfg["z_channels"], cfg["quantized_embed_dim"], 1)
     return s
 
 

@@ -530,6 +530,34 @@ def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
     assert torch.equal(y_hi.view(torch.int16), e_hi.view(torch.int16)) and torch.equal(y_lo.view(torch.int16), e_lo.view(torch.int16))
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 5, 7, 64, 40), (3, 16, 12, 128, 128), (1, 32, 32, 24, 256)])
+def test_conv2d_stride2_downsample(mode, B, H, W, Cin, Cout):
+    """upsample = 2: the taming Downsample (muse/modeling_taming_vqgan.py:55-59) = F.pad(x, (0,1,0,1)) + Conv2d(3, stride 2,
+    padding 0), gathered straight from the unpadded [2H, 2W] input (bottom / right taps of the last row / column read zeros);
+    H, W are the OUTPUT dims; odd / ragged tile shapes, bias and residual included"""
+    ops = _ops()
+    x = rnd((B, Cin, 2 * H, 2 * W), 210)
+    w = rnd((Cout, Cin, 3, 3), 211) / math.sqrt(9 * Cin)
+    bvec, rr = rnd((Cout,), 212), rnd((B, Cout, H, W), 213)
+    ref = F.conv2d(F.pad(x.double(), (0, 1, 0, 1)), w.double(), bvec.double(), stride=2) + rr.double()
+    xn, wn = x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rn = rr.permute(0, 2, 3, 1).contiguous().to(DEV)
+    if mode == "bf16x3":
+        w_hi, w_lo = ops.split_bf16(wn)
+        out = ops.conv2d_nhwc_split(xn, w_hi, w_lo, B, H, W, Cin, Cout, 3, bias=bvec.to(DEV), residual=rn, upsample=2)
+        tol = 3e-5
+    elif mode == "f32":
+        out = ops.conv2d_nhwc(xn, wn, B, H, W, Cin, Cout, 3, bias=bvec.to(DEV), residual=rn, upsample=2)
+        tol = 2e-6
+    else:
+        out = ops.conv2d_nhwc(ops.cast_to_bf16(xn), ops.cast_to_bf16(wn), B, H, W, Cin, Cout, 3, bias=bvec.to(DEV),
+                              residual=ops.cast_to_bf16(rn), upsample=2).float()
+        tol = 2e-2
+    assert tuple(out.shape) == (B, H, W, Cout)
+    assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < tol, (mode, B, H, W, Cin, Cout)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,KS,res,ups", [
     (2, 16, 16, 8, 128, 3, False, False),    # conv_in shape: 3 (padded to 8) -> 128, 4 channels per group
     (3, 16, 8, 128, 256, 1, True, False),    # nin_shortcut: 1x1, residual, 8 channels per group, one tile per image

@@ -56,6 +56,23 @@ def test_vqgan_encode_decode(golden_dir):
     np.testing.assert_allclose(rec.numpy(), g["rec"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("name,cfg", [("taming_tiny", W.TAMING_TINY), ("taming_tiny_pool", W.TAMING_TINY_POOL)])
+def test_taming_vqgan_encode_decode(golden_dir, name, cfg):
+    """the taming `VQGANModel` restatement (oracle/taming_oracle.py) against the real reference
+    (golden_taming): encoder output, quant_conv latents, bit-exact indices / z_q, both decode entry points"""
+    from oracle import taming_oracle as T
+    g = _load(golden_dir, name)
+    sd = W.fill_state_dict(W.taming_shapes(cfg), int(g["seed"]), "vqgan")
+    px = W.images(int(g["batch"]), cfg["resolution"], int(g["seed"]) + 1)
+    np.testing.assert_allclose(T.encoder(sd, cfg, px).numpy(), g["enc"], rtol=1e-5, atol=1e-5)
+    z, z_q, idx = T.encode(sd, cfg, px)
+    np.testing.assert_allclose(z.numpy(), g["z"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(idx.numpy(), g["indices"])
+    np.testing.assert_allclose(z_q.numpy(), g["z_q"], rtol=0, atol=0)
+    np.testing.assert_allclose(T.decode_code(sd, cfg, idx).numpy(), g["rec"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(T.decode(sd, cfg, z_q).numpy(), g["rec_decode"], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["mask_b64", "mask_small"])
 def test_mask_sampling(golden_dir, name):
     g = _load(golden_dir, name)

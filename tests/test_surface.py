@@ -70,6 +70,35 @@ def test_vqgan_surface(golden_dir):
     assert len(full.state_dict()) == 168
 
 
+@pytest.mark.parametrize("name,cfg", [("taming_tiny", W.TAMING_TINY), ("taming_tiny_pool", W.TAMING_TINY_POOL)])
+def test_taming_vqgan_surface(golden_dir, name, cfg):
+    """row f4: muse.VQGANModel keeps the reference's state-dict template (muse/modeling_taming_vqgan.py), writes the same
+    config.json, round-trips through save_pretrained / from_pretrained, and has no CPU path"""
+    import muse
+    from muse._hip import MuseHipError
+    v = muse.VQGANModel(**cfg)
+    sd = v.state_dict()
+    assert {k: tuple(t.shape) for k, t in sd.items()} == W.taming_shapes(cfg)
+    assert v.num_embeddings == cfg["num_embeddings"] and v.config.latent_size == cfg["resolution"] // 2 ** (len(cfg["channel_mult"]) - 1)
+    assert v.to_json_string() == open(os.path.join(golden_dir, f"config_{name}.json")).read()
+    with tempfile.TemporaryDirectory() as d:
+        v.save_pretrained(d)
+        v2 = muse.VQGANModel.from_pretrained(d)
+        assert not v2.training
+        for a, b in zip(sd.values(), v2.state_dict().values()):
+            assert torch.equal(a, b)
+    with pytest.raises(MuseHipError):
+        v.encode(torch.zeros(1, 3, cfg["resolution"], cfg["resolution"]))
+    with pytest.raises(NotImplementedError):
+        muse.VQGANModel(**{**cfg, "dropout": 0.1})
+
+
+def test_taming_vqgan_full_size_template():
+    import muse
+    full = muse.VQGANModel(num_embeddings=8192)   # openMUSE/vqgan-f16-8192-laion geometry (configs/cc12m_uvit_clip.yaml:19-21)
+    assert len(full.state_dict()) == 343 and full.num_parameters() == 73976707   # the reference's counts
+
+
 def test_no_cpu_fallback():
     import muse
     from muse._hip import MuseHipError
