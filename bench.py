@@ -104,6 +104,32 @@ def vqgan_roundtrip(device, bs):
     return out
 
 
+def taming_leg(device, bs):
+    """the tokenizer of the text-to-image configs (configs/cc12m_uvit_clip.yaml:19-21: taming VQGANModel f16, 8192 codes):
+    get_code throughput (what scripts/pre_encode.py:440-511 runs per batch) and encode -> decode_code, bf16x3 mode"""
+    import muse
+    import weights as W
+    cfg = dict(W.VQGAN_F16, num_embeddings=8192, attn_resolutions=(16,), no_attn_mid_block=False, resample_with_conv=True)
+    vq = muse.VQGANModel(**cfg)
+    vq.load_state_dict(W.fill_state_dict(W.taming_shapes(cfg), 4321, "vqgan"))
+    vq.to(device).eval().set_compute_dtype("bf16x3")
+    px, _ = synthetic_batch(bs, device, seed=78)
+    out = {}
+    for name, fn in (("encode", lambda: vq.get_code(px)), ("encode_decode", lambda: vq.decode_code(vq.get_code(px)))):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        out[f"taming_vqgan_f16_8192_{name}_images_per_s_bf16x3"] = round(bs * n / (time.perf_counter() - t0), 1)
+    del vq
+    torch.cuda.empty_cache()
+    return out
+
+
 def uvit_leg(device, batch, seq, steps=3):
     """BASELINE.json config 4: configs/cc12m_uvit_clip.yaml MaskGiTUViT (729 M parameters, 22 layers, hidden 1024; block_num_heads
     12 per SURVEY.md D3), synthetic CLIP states (77 x 768), tokens given, bf16 compute (fused self / cross attention, bf16 weight
@@ -342,6 +368,7 @@ def main():
             e2, _, _, _ = run(cfgn, vqd, n2, 2)
             extra[f"images_per_s_config{cfgn}_vq{vqd}"] = round(args.batch * n2 / e2, 1)
         extra.update(vqgan_roundtrip(device, args.batch))
+        extra.update(taming_leg(device, args.batch))
         extra["config4_uvit_seq256"] = uvit_leg(device, 64, 256)
         extra["config4_uvit_seq1024"] = uvit_leg(device, 16, 1024)
 

@@ -625,9 +625,12 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
     # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def generate2(self, input_ids=None, class_ids=None, encoder_hidden_states=None, negative_embeds=None, temperature=1.0,
-                  timesteps=18, guidance_scale=0, noise_schedule=cosine_schedule, generator=None, noise=None, **kwargs):
+                  timesteps=18, guidance_scale=0, noise_schedule=cosine_schedule, generator=None, noise=None, hip_graph=False,
+                  **kwargs):
         """-> sampled ids [B, num_vq_tokens].  `noise` (tests): per step a pair (exponential draws [B*S, codebook_size],
         uniform draws [B, S]) replacing the in-kernel Philox stream, e.g. the draws the reference's CPU generator produced.
+        hip_graph=True captures the forward once (fixed input buffer) and replays it every step: one graph launch instead of
+        ~12 kernel launches per layer - what small-batch decoding is bound by.
         Like the reference, `class_ids` is shifted by codebook_size IN PLACE (:1388-1389) and the temperature compounds
         across steps (:1451)."""
         if encoder_hidden_states is not None:
@@ -642,15 +645,40 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         model_in = torch.empty((B, S + 1), dtype=torch.long, device=input_ids.device)
         model_in[:, 0] = class_ids
         sampled = input_ids
+        graph = None
+        if hip_graph:
+            graph, model_in, logits = self._decode_graph(B, S + 1, input_ids.device)
+            model_in[:, 0] = class_ids
         for step in range(timesteps):
             model_in[:, 1:] = input_ids
-            logits = self(model_in)                                   # [B, S + 1, vocab] f32; row 0 of each image is the class token
+            if graph is None:
+                logits = self(model_in)                               # [B, S + 1, vocab] f32; row 0 of each image is the class token
+            else:
+                graph.replay()
             temperature = temperature * (1.0 - 1.0 * (step + 1) / timesteps)
             q, u = step_noise(noise, step)
             sampled, input_ids, _ = ops.sample_step(logits[:, 1:], input_ids, mask_id, V, temperature,
                                                     scheduled_mask_len(S, step, timesteps, noise_schedule), noise_exp=q, noise_u=u,
                                                     seed=seed, step=step)
         return sampled
+
+    def _decode_graph(self, B, S, device):
+        """(graph, input buffer [B, S], logits) of the forward captured as a HIP graph, kept across generate2 calls for as long
+        as the weight buffers, the compute dtype and the mode stay the same.  The graph reads the weights through their buffers:
+        in-place updates are seen; a stale bf16 shadow is re-cast here (host logic the replay does not run)."""
+        if not self._flat_ok():
+            self._build_flat()
+        cd = self._resolve_cd()
+        key = (B, S, str(cd), self.training, str(device), self._flat.data_ptr())
+        hit = getattr(self, "_decode_graphs", {}).get(key)
+        if hit is None:
+            model_in = torch.zeros((B, S), dtype=torch.long, device=device)
+            graph, logits = ops.capture_graph(lambda: self(model_in))
+            hit = (graph, model_in, logits)
+            self._decode_graphs = {key: hit}      # one live graph: a new shape / dtype / weight buffer replaces it
+        else:
+            self.compute_weights(cd)
+        return hit
 
     def generate(self, *args, **kwargs):
         raise NotImplementedError("use generate2 (the reference's generate() is broken: modeling_transformer.py:1307)")

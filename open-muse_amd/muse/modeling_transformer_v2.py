@@ -700,12 +700,13 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
     def generate2(self, encoder_hidden_states, cond_embeds, micro_conds, empty_embeds, empty_cond_embeds, input_ids=None,
                   negative_embeds=None, negative_cond_embeds=None, temperature=1.0, timesteps=18, guidance_scale=0,
                   guidance_schedule=None, noise_schedule=cosine_schedule, generator=None, return_intermediate=False,
-                  seq_len=None, use_tqdm=None, topk_filter_thres=None, noise_type=None, predict_all_tokens=None, noise=None):
+                  seq_len=None, use_tqdm=None, topk_filter_thres=None, noise_type=None, predict_all_tokens=None, noise=None,
+                  hip_graph=False):
         """reference :330-479 — iterative parallel decoding with classifier-free guidance.  Per step: one forward on the HIP
         path (batch doubled under guidance) and ONE device call for the guidance mix + everything token-level
         (muse_sample_step).  `noise` (tests): per step (exponential draws [B*S, codebook], uniform draws [B, S]) replacing the
         in-kernel Philox stream.  (The reference leaves `model_input` undefined for guidance_scale == 0; here that case feeds
-        input_ids.)"""
+        input_ids.)  hip_graph=True captures the forward once on a fixed input buffer and replays it every step."""
         B = encoder_hidden_states.shape[0]
         S = 256 if seq_len is None else seq_len
         dev = encoder_hidden_states.device
@@ -738,8 +739,18 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             order = tqdm(order)
         intermediate = []
         sampled = input_ids
+        graph = None
+        if hip_graph:
+            model_in = torch.cat([input_ids, input_ids]) if guided else input_ids.clone()
+            graph, out = ops.capture_graph(lambda: self(model_in, encoder_hidden_states, cond_embeds, micro_conds))
         for step in order:
-            out = self(torch.cat([input_ids, input_ids]) if guided else input_ids, encoder_hidden_states, cond_embeds, micro_conds)
+            if graph is None:
+                out = self(torch.cat([input_ids, input_ids]) if guided else input_ids, encoder_hidden_states, cond_embeds, micro_conds)
+            else:
+                model_in[:B] = input_ids
+                if guided:
+                    model_in[B:] = input_ids
+                graph.replay()
             q, u = step_noise(noise, step)
             sampled, input_ids, raw = ops.sample_step(out[:B], input_ids, mask_id, V, float(temperatures[step]),
                                                       scheduled_mask_len(S, step, timesteps, noise_schedule),

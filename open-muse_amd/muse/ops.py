@@ -64,6 +64,19 @@ def _nbytes(*tensors):
     return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
 
+def capture_graph(fn):
+    """Run fn() once eagerly (one-time packing / first-use work stays out of the graph), then capture a second run into a
+    HIP graph: every libmuse_hip launch inside goes to torch's capture stream (`stream()` is torch's current stream) and the
+    tensors fn allocates come from the graph's private pool.  -> (graph, fn's captured return value); graph.replay() re-runs
+    it on the inputs' current contents."""
+    fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fn()
+    return graph, out
+
+
 def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, rowvec=None,
          residual=None, ldr=0, batch=1, zdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), accumulate=False, act=0, split_k=1,
          split_stride=0):

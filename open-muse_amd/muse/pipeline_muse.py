@@ -114,10 +114,16 @@ class PipelineMuse:
             cfg = MaskGitTransformer.load_config(path, **kw)
             klass = MaskGiTUViT_v2 if str(cfg.get("_class_name", "")).startswith("MaskGiTUViT") else MaskGitTransformer
             return klass.from_pretrained(path, **kw)
+        def load_vae(path, **kw):           # likewise for the tokenizer (reference :320-329; MoVQ / Paella are not part of this build)
+            from .modeling_taming_vqgan import VQGANModel
+            name = str(MaskGitVQGAN.load_config(path, **kw).get("_class_name", "MaskGitVQGAN"))
+            if name not in ("MaskGitVQGAN", "VQGANModel"):
+                raise ValueError(f"Unknown VAE class: {name}")
+            return (VQGANModel if name == "VQGANModel" else MaskGitVQGAN).from_pretrained(path, **kw)
         if model_name_or_path is not None:
-            vae = MaskGitVQGAN.from_pretrained(model_name_or_path, subfolder="vae")
+            vae = load_vae(model_name_or_path, subfolder="vae")
             transformer = load_transformer(model_name_or_path, subfolder="transformer")
         else:
-            vae = MaskGitVQGAN.from_pretrained(vae_path)
+            vae = load_vae(vae_path)
             transformer = load_transformer(transformer_path)
         return cls(vae=vae, transformer=transformer, is_class_conditioned=is_class_conditioned)

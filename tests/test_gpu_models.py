@@ -462,6 +462,16 @@ def test_pipeline_class_conditional():
     assert imgs.shape == (2, 16, 16, 3) and np.isfinite(imgs).all()
     ids = m.generate2(class_ids=torch.tensor([3], device=DEV), timesteps=3)
     assert ids.shape == (1, 16) and int(ids.max()) < 32
+    # the taming tokenizer in the pipeline: save_pretrained -> from_pretrained resolves the VQ class from vae/config.json
+    import tempfile
+    tv = muse.VQGANModel(**W.TAMING_TINY)
+    tm = muse.MaskGitTransformer(**dict(tcfg, vocab_size=56, codebook_size=40, num_vq_tokens=64, max_position_embeddings=65))
+    with tempfile.TemporaryDirectory() as d:
+        muse.PipelineMuse(vae=tv, transformer=tm, is_class_conditioned=True).save_pretrained(d)
+        pipe2 = muse.PipelineMuse.from_pretrained(d, is_class_conditioned=True).to(DEV)
+    assert type(pipe2.vae) is muse.VQGANModel and type(pipe2.transformer) is muse.MaskGitTransformer
+    imgs = pipe2(class_ids=[0, 5, 9], timesteps=3, output_type="np")
+    assert imgs.shape == (3, 32, 32, 3) and np.isfinite(imgs).all()
 
 
 def test_grad_reducer_on_rccl_single_rank(golden_dir):
