@@ -277,6 +277,294 @@ __global__ __launch_bounds__(512, 2) void conv_dma_kernel(Params p) {
 
 }  // namespace cdma
 
+
+// =====================================================================================================================
+// "Patch-slab" variant (taken when H % 16 == 0, W % 16 == 0, Cin % 64 == 0): the same bf16x3 products, but the activation
+// side of the implicit GEMM is staged ONCE per 32-channel chunk instead of once per tap.
+//
+//   The kernel above DMAs 48 KiB per K-tile (x_hi/x_lo [256][32] + w_hi/w_lo [128][32]) for 1546 MFMA cycles: 31.8 B/clk/CU
+//   against the ~28 B/clk the LDS-DMA path sustains - its K loop is DMA-bound, and the nine taps
+//   re-load the same pixels nine times.  Here a block's 256 pixels are a 16 x 16 PATCH of one image and, per 32-channel
+//   chunk, the 18 x 18 halo'd patch ("slab", 324 rows of 64 B per plane) is DMA'd once and serves all nine taps: tap
+//   (ky,kx) of patch row py reads slab rows (py+ky)*18 + kx + 0..15.  DMA bytes per K-tile: 4.6 KiB of activations + 16 KiB
+//   of weights = 13.7 B/clk/CU; K order = (channel chunk, tap, channel) instead of (tap, channel).
+//
+//   LDS: slab buffer = hi plane [21 KiB] + lo plane [21 KiB], two buffers (chunk c+1 lands while chunk c computes), then a
+//   3-stage weight ring of 16 KiB (w_hi [128][64 B] + w_lo) = 132 KiB; the epilogue stages the f32 tile in the same bytes.
+//   Slab rows are read at ARBITRARY 16-row windows (kx shifts), so the bank swizzle has to be conflict-free for every start
+//   row: chunk c of row r sits at position c ^ ((r >> 1) & 2) (scripts/lds_swizzle_search.py enumerates the ds_read_b128
+//   lane groups of the guide for all alignments: 4 LDS cycles = no conflict for every window; the {0,3,2,1} swizzle of the
+//   aligned kernel costs 8 on unaligned ones).  Read address = (P + c') * 64 + pos with P = 72 * wm + (lane & 15) per lane
+//   and c' = (i + ky) * 18 + kx a compile-time constant: the swizzle bit depends on bit 2 of P + c', i.e. on c' & 3 (carry
+//   into bit 2) and bit 2 of c' - eight per-lane base registers, everything else is the instruction's immediate offset.
+//   Pipeline per tap t (one K-tile): wait for the weights of tap t+1, barrier, then 48 MFMAs of tap t interleaved with the
+//   16 fragment reads of tap t+1 and the DMA of the weights of tap t+3 (+ in taps 0-2 a third of the next chunk's slab).
+namespace cslab {
+using g256::lds_read128;
+using g256::lds_void_t;
+using cdma::Params;
+using cdma::sw4;
+
+constexpr int BM = 256, BN = 128, NT = 512, MI = 4, NI = 4;
+constexpr int PLANE = 21 * 1024;            // 324 slab rows x 64 B, rounded up to whole 1 KiB DMA pieces (21)
+constexpr int SLAB = 2 * PLANE;             // hi + lo
+constexpr int B_BASE = 2 * SLAB, BSTAGE = 16384;
+constexpr int CST = BN * 4 + 16;            // staged output row (epilogue)
+constexpr int LDS_BYTES = BM * CST;         // 135168 >= B_BASE + 3 * BSTAGE (135168)
+static_assert(B_BASE + 3 * BSTAGE <= LDS_BYTES, "LDS map");
+
+struct Frag16 { bf16x8 ah[MI], al[MI], bh[NI], bl[NI]; };
+
+__global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int H = p.H, W = p.W, Cin = p.Cin;
+  const int tpr = W >> 4, tpi = (H >> 4) * tpr;     // patches per image row / per image
+  const int ntm = p.M >> 8, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+  const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int tid_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+  const int mt = tid_ / ntn, n0 = (tid_ % ntn) * BN;
+  const int img = mt / tpi, prem = mt - img * tpi, ty = prem / tpr, tx = prem - ty * tpr;
+  const int y0 = ty << 4, x0 = tx << 4;
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- slab DMA: 21 pieces of 1 KiB per plane; wave w issues pieces w, w+8, w+16 of both planes (a piece index past 20
+  //      repeats the wave's previous piece: same bytes to the same place, keeps the per-wave DMA count uniform) ----
+  const unsigned bytesA = (unsigned)((long)p.M * Cin * 2);
+  const rsrc_t rs_xh = make_rsrc(p.xh, bytesA), rs_xl = make_rsrc(p.xl, bytesA);
+  const unsigned oobA = (bytesA + 15u) & ~15u;
+  unsigned slab_off[3];
+  int slab_piece[3];
+  {
+    const int srcchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int piece = wave + 8 * k;
+      if (piece > 20) piece -= 8;
+      slab_piece[k] = piece;
+      const int r = piece * 16 + (lane >> 2), sy = r / 18, sx = r - sy * 18;
+      const int y = y0 - 1 + sy, x = x0 - 1 + sx;
+      const bool ok = r < 324 && y >= 0 && y < H && x >= 0 && x < W;
+      slab_off[k] = ok ? (unsigned)((((long)img * H + y) * W + x) * Cin * 2 + srcchunk * 16) : oobA;
+    }
+  }
+  // third `k` of the slab of channel chunk `chunk` into buffer `buf`
+  auto issue_slab = [&](int buf, int k, int chunk) {
+    const unsigned vo = chunk * 32 < Cin ? slab_off[k] : oobA;
+    const int soff = chunk * 64;
+    unsigned char* dst = smem + buf * SLAB + slab_piece[k] * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (lds_void_t*)dst, 16, (int)vo, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xl, (lds_void_t*)(dst + PLANE), 16, (int)vo, soff, 0, 0);
+  };
+
+  // ---- weight DMA (as in cdma): waves 0-3 the hi image, 4-7 the lo image, two 16-row pieces each per K-tile ----
+  const int wimg = wave >> 2;
+  const unsigned bytesB = (unsigned)((long)p.N * p.K * 2);
+  const rsrc_t rs_w = make_rsrc(wimg ? p.wl : p.wh, bytesB);
+  const unsigned oobB = (bytesB + 15u) & ~15u;
+  unsigned voffB[2];
+  {
+    const int srcchunk = (lane & 3) ^ sw4((lane >> 4) & 3);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + ((wave & 3) * 2 + j) * 16 + (lane >> 2);
+      voffB[j] = n < p.N ? (unsigned)(((long)n * p.K + srcchunk * 8) * 2) : oobB;
+    }
+  }
+  // weights of (chunk, tap) into ring stage `stage`: k index = tap * Cin + chunk * 32
+  auto issue_b = [&](int stage, int chunk, int tap) {
+    const bool ok = chunk * 32 < Cin;
+    const int soff = (tap * Cin + chunk * 32) * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + B_BASE + stage * BSTAGE + wimg * 8192 + ((wave & 3) * 2 + j) * 1024),
+                                               16, (int)(ok ? voffB[j] : oobB), soff, 0, 0);
+  };
+
+  // ---- fragment read addresses ----
+  unsigned baseA[4][2], addrB;
+  {
+    const int pr = lane & 15, g = lane >> 4, P = 72 * wm + pr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int bit2 = ((P >> 2) & 1) ^ (((P & 3) + e) >> 2) ^ b;
+        baseA[e][b] = (unsigned)((P << 6) | ((g << 4) ^ (bit2 << 5)));
+      }
+    addrB = (unsigned)(B_BASE + (wn * 64 + pr) * 64 + ((g ^ sw4((pr >> 2) & 3)) << 4));
+  }
+
+  auto flip_base = [&](int d) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { baseA[e][0] += d; baseA[e][1] += d; }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Frag16 f0, f1;
+
+  // read #Q (0..15) of tap TAP (0..8) from the slab buffer baseA points into / weight stage ST into F.   A reads: c' = (i + ky) * 18 + kx.
+#define SLAB_CP(TAP, I) (((I) + (TAP) / 3) * 18 + (TAP) % 3)
+#define SLAB_READ(F, ST, TAP, Q)                                                                                             \
+  {                                                                                                                               \
+    constexpr int q_ = (Q) & 3;                                                                                                   \
+    constexpr int cp_ = SLAB_CP(TAP, q_);                                                                                         \
+    if constexpr ((Q) < 4) lds_read128<cp_ * 64>(F.ah[q_], baseA[cp_ & 3][(cp_ >> 2) & 1]);                                       \
+    else if constexpr ((Q) < 8) lds_read128<PLANE + cp_ * 64>(F.al[q_], baseA[cp_ & 3][(cp_ >> 2) & 1]);                          \
+    else if constexpr ((Q) < 12) lds_read128<(ST) * BSTAGE + q_ * 1024>(F.bh[q_], addrB);                                         \
+    else lds_read128<(ST) * BSTAGE + 8192 + q_ * 1024>(F.bl[q_], addrB);                                                          \
+  }
+#ifndef CDMA_ABLATE_NO_MFMA
+#define SLAB_PAIR(F, Q)                                                                                                        \
+  {                                                                                                                            \
+    constexpr int i_ = (Q) >> 2, j_ = (Q) & 3;                                                                                 \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bl[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.al[i_], acc[i_][j_], 0, 0, 0);                            \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
+  }
+#else
+#define SLAB_PAIR(F, Q) asm volatile("" ::"v"(F.ah[(Q) >> 2]), "v"(F.al[(Q) >> 2]), "v"(F.bh[(Q) & 3]), "v"(F.bl[(Q) & 3]));
+#endif
+  // slot Q of tap T (0..17 inside the two-chunk loop body; chunk parity CP = T / 9, tap TAP = T % 9) computing from CUR while
+  // prefetching the fragments of tap T+1 into NXT.  DMA: slot 0/1 = a third of the NEXT chunk's slab (taps 0..2 only), slot 2 =
+  // the weights of tap T+3.
+#ifndef CDMA_ABLATE_NO_DMA
+#define SLAB_ISSUE(T, Q)                                                                          \
+  if constexpr ((Q) == 0 && ((T) % 9) < 3) issue_slab(1 - (T) / 9, (T) % 9, chunk0 + (T) / 9 + 1);  \
+  if constexpr ((Q) == 2) issue_b(((T) + 3) % 3, chunk0 + ((T) + 3) / 9, ((T) + 3) % 9);
+#else
+#define SLAB_ISSUE(T, Q)
+#endif
+#define SLAB_SLOT(CUR, NXT, T, Q)                                                   \
+  SLAB_PAIR(CUR, Q)                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  SLAB_ISSUE(T, Q)                                                                  \
+  SLAB_READ(NXT, (((T) + 1) % 3), (((T) + 1) % 9), Q)                               \
+  __builtin_amdgcn_sched_barrier(0);
+  // top-of-tap wait: the weights of tap T+1 (issued in tap T-1... see header) have landed once at most the DMAs issued after
+  // them are outstanding: 2 (weights of T+2) + 2 more when tap T-1 also issued a slab third (T-1 in 0..2 of its chunk)
+#ifndef CDMA_ABLATE_NO_DMA
+#define SLAB_WAIT(T)                                                                     \
+  if constexpr (((T) % 9) >= 1 && ((T) % 9) <= 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); \
+  else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+#else
+#define SLAB_WAIT(T) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  // the base registers point into the slab buffer the NEXT tap's fragments come from: flipped when that tap starts a new chunk
+  // (ds_read immediates are 16 bits, the two buffers span 84 KiB)
+#define SLAB_TAP(CUR, NXT, T)                                                                         \
+  SLAB_WAIT(T)                                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                       \
+  if constexpr ((T) == 8) flip_base(SLAB);                                                            \
+  if constexpr ((T) == 17) flip_base(-SLAB);                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                  \
+  SLAB_SLOT(CUR, NXT, T, 0) SLAB_SLOT(CUR, NXT, T, 1) SLAB_SLOT(CUR, NXT, T, 2) SLAB_SLOT(CUR, NXT, T, 3)     \
+  SLAB_SLOT(CUR, NXT, T, 4) SLAB_SLOT(CUR, NXT, T, 5) SLAB_SLOT(CUR, NXT, T, 6) SLAB_SLOT(CUR, NXT, T, 7)     \
+  SLAB_SLOT(CUR, NXT, T, 8) SLAB_SLOT(CUR, NXT, T, 9) SLAB_SLOT(CUR, NXT, T, 10) SLAB_SLOT(CUR, NXT, T, 11)   \
+  SLAB_SLOT(CUR, NXT, T, 12) SLAB_SLOT(CUR, NXT, T, 13) SLAB_SLOT(CUR, NXT, T, 14) SLAB_SLOT(CUR, NXT, T, 15)
+
+  // prologue: slab of chunk 0 and the weights of taps 0, 1, 2 in flight; tap 0's fragments into f0
+  int chunk0 = 0;
+  issue_slab(0, 0, 0); issue_slab(0, 1, 0); issue_slab(0, 2, 0);
+  issue_b(0, 0, 0); issue_b(1, 0, 1); issue_b(2, 0, 2);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  SLAB_READ(f0, 0, 0, 0) SLAB_READ(f0, 0, 0, 1) SLAB_READ(f0, 0, 0, 2) SLAB_READ(f0, 0, 0, 3)
+  SLAB_READ(f0, 0, 0, 4) SLAB_READ(f0, 0, 0, 5) SLAB_READ(f0, 0, 0, 6) SLAB_READ(f0, 0, 0, 7)
+  SLAB_READ(f0, 0, 0, 8) SLAB_READ(f0, 0, 0, 9) SLAB_READ(f0, 0, 0, 10) SLAB_READ(f0, 0, 0, 11)
+  SLAB_READ(f0, 0, 0, 12) SLAB_READ(f0, 0, 0, 13) SLAB_READ(f0, 0, 0, 14) SLAB_READ(f0, 0, 0, 15)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // two channel chunks (18 taps) per iteration: slab buffer = chunk parity, weight stage = tap % 3, registers ping-pong
+  const int nchunks = Cin >> 5;
+  for (; chunk0 < nchunks; chunk0 += 2) {
+    SLAB_TAP(f0, f1, 0) SLAB_TAP(f1, f0, 1) SLAB_TAP(f0, f1, 2) SLAB_TAP(f1, f0, 3) SLAB_TAP(f0, f1, 4) SLAB_TAP(f1, f0, 5)
+    SLAB_TAP(f0, f1, 6) SLAB_TAP(f1, f0, 7) SLAB_TAP(f0, f1, 8) SLAB_TAP(f1, f0, 9) SLAB_TAP(f0, f1, 10) SLAB_TAP(f1, f0, 11)
+    SLAB_TAP(f0, f1, 12) SLAB_TAP(f1, f0, 13) SLAB_TAP(f0, f1, 14) SLAB_TAP(f1, f0, 15) SLAB_TAP(f0, f1, 16) SLAB_TAP(f1, f0, 17)
+  }
+#undef SLAB_TAP
+#undef SLAB_WAIT
+#undef SLAB_SLOT
+#undef SLAB_ISSUE
+#undef SLAB_PAIR
+#undef SLAB_READ
+#undef SLAB_CP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing (zero) DMAs and fragment reads done before LDS is reused
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: + bias, staged through LDS, 16-byte row-contiguous stores with the residual added (tile row = patch
+  //      pixel py * 16 + px), GroupNorm partials of the output ----
+  float bias_v[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4) + r;
+      bias_v[j][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+  double gs = 0.0, gq = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int lr = wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int nl = wn * 64 + j * 16 + 4 * (lane >> 4);
+      const f32x4 v = {acc[i][j][0] + bias_v[j][0], acc[i][j][1] + bias_v[j][1], acc[i][j][2] + bias_v[j][2], acc[i][j][3] + bias_v[j][3]};
+      *(f32x4*)(smem + lr * CST + nl * 4) = v;
+    }
+  }
+  __syncthreads();
+  constexpr int NIT = (BM * 32) / NT;   // 16 chunks of 16 bytes per thread: patch row `it`, pixel rbase
+  const int col = (threadIdx.x & 31) * 4, n = n0 + col, rbase = threadIdx.x >> 5;
+  const long pix0 = ((long)img * H + y0) * W + x0 + rbase;
+  if (n < p.N) {
+    f32x4 rv[NIT];
+    if (p.residual) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) rv[it] = *(const f32x4*)(p.residual + (pix0 + (long)it * W) * p.N + n);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      f32x4 w = *(const f32x4*)(smem + (rbase + 16 * it) * CST + col * 4);
+      if (p.residual) w += rv[it];
+      *(f32x4*)(p.out + (pix0 + (long)it * W) * p.N + n) = w;
+      if (p.gn_partial) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs += (double)w[e]; gq += (double)w[e] * (double)w[e]; }
+      }
+    }
+  }
+  if (p.gn_partial) {
+    gs += __shfl_xor(gs, 32, 64);
+    gq += __shfl_xor(gq, 32, 64);
+    __syncthreads();
+    double* red = (double*)smem;   // [8 waves][32 chunks][2]
+    if (lane < 32) { red[(wave * 32 + lane) * 2] = gs; red[(wave * 32 + lane) * 2 + 1] = gq; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      double cs = 0.0, cq = 0.0;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) { cs += red[(w8 * 32 + threadIdx.x) * 2]; cq += red[(w8 * 32 + threadIdx.x) * 2 + 1]; }
+      const int cpc = p.gn_cpg >> 2;
+      for (int o = 1; o < cpc; o <<= 1) { cs += __shfl_xor(cs, o, 64); cq += __shfl_xor(cq, o, 64); }
+      const int nn = n0 + (int)threadIdx.x * 4;
+      if ((threadIdx.x & (cpc - 1)) == 0 && nn < p.N) {
+        double* o2 = p.gn_partial + (((long)img * tpi + prem) * p.gn_groups + nn / p.gn_cpg) * 2;   // chunk = patch index in the image
+        o2[0] = cs; o2[1] = cq;
+      }
+    }
+  }
+}
+
+}  // namespace cslab
+
 extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
                                        const float* residual, float* out, double* gn_partial, int32_t gn_groups, int32_t batch,
                                        int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, void* stream) {
@@ -302,6 +590,16 @@ extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, con
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)cdma::conv_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cdma::LDS_BYTES);
     attr_set = true;
+  }
+  static const int use_slab = []() { const char* e = getenv("MUSE_CONV_SLAB"); return e ? atoi(e) : 1; }();
+  if (use_slab && (H % 16) == 0 && (W % 16) == 0 && (Cin % 64) == 0) {   // patch-slab kernel (K order: chunk, tap, channel)
+    static bool slab_attr = false;
+    if (!slab_attr) {
+      (void)hipFuncSetAttribute((const void*)cslab::conv_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cslab::LDS_BYTES);
+      slab_attr = true;
+    }
+    hipLaunchKernelGGL(cslab::conv_slab_kernel, dim3((p.M >> 8) * ntn), dim3(512), cslab::LDS_BYTES, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(cdma::conv_dma_kernel, dim3(ntm * ntn), dim3(512), cdma::LDS_BYTES, (hipStream_t)stream, p);
   return (int)hipGetLastError();

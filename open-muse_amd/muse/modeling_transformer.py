@@ -20,6 +20,8 @@ import math
 import weakref
 from typing import Callable, List, Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -184,6 +186,8 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         self._flat = self._flat_grad = self._flat_c = self._flat_ct = None
         self._shadow_fresh = False
         self._shadow_version, self._ct_version, self._shadow_pversion = 0, -1, -1
+        self.wgrad_stream = os.environ.get("MUSE_WGRAD_STREAM", "1") != "0"   # bf16 mode: weight-gradient GEMMs on a second HIP stream
+        self._side_stream = None
         self.transposed_dgrad = False  # bf16 mode option: W^T copies so dgrad uses the k-contiguous GEMM kernel (measured: no net gain)
         self._build_flat()
         self._init_weights()
@@ -305,6 +309,11 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         if mode != self.training:
             self._shadow_fresh = False   # EMA copy_to()/restore() around evaluation write p.data (reference modeling_ema.py)
         return super().train(mode)
+
+    def _wgrad_side_stream(self, dev):
+        if self._side_stream is None or self._side_stream.device != dev:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        return self._side_stream
 
     def compute_weights(self, cd) -> torch.Tensor:
         """flat weights in the compute dtype (the f32 master itself, or its bf16 shadow).  The shadow is re-cast whenever
@@ -512,10 +521,30 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             n, k = w.shape
             return ops.linear(dy, view(Wt, idx, (k, n)))
 
+        # Weight gradients are a side branch of the backward graph (nothing downstream reads them before the all-reduce /
+        # optimizer), so they run on a second HIP stream: the split-K dW GEMMs and their slice reductions fill the CUs the
+        # main chain leaves idle (dX GEMMs with 195 tiles on 256 CUs, kernel tails, the HBM-bound LayerNorm / GLU backward).
+        main = torch.cuda.current_stream(dev)
+        side = self._wgrad_side_stream(dev) if (self.wgrad_stream and cd == torch.bfloat16) else None
+
+        def wgrad(dy, x, dw, accumulate, **kw):
+            if side is None:
+                return ops.linear_wgrad(dy, x, dw, accumulate, **kw)
+            side.wait_stream(main)           # dy (and on the first use x) were produced on the main stream
+            with torch.cuda.stream(side):
+                ops.linear_wgrad(dy, x, dw, accumulate, **kw)
+            dy.record_stream(side)           # the caching allocator must not hand these blocks out while the side stream reads them
+            x.record_stream(side)
+
         def ready(i0, i1):
             if self.grad_ready_hook is not None and self.direct_grad:
                 end = off[i1] if i1 < len(off) else self._flat_n
-                self.grad_ready_hook(off[i0], end)
+                if side is None:
+                    self.grad_ready_hook(off[i0], end)
+                else:   # the range is complete once both streams have passed this point
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        self.grad_ready_hook(off[i0], end)
 
         # ---- loss / head ----------------------------------------------------------------------------------------
         dlog = None
@@ -533,7 +562,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         w_enc, w_dense = view(Wf, t0 + 0, (H,)), view(Wc, t0 + 1, (H, H))
         w_mln, w_log = view(Wf, t0 + 2, (H,)), view(Wc, t0 + 3, (V, H))
         # dW_logits[V,H] = dlog^T gl ; dgl[T,H] = dlog W_logits   (dlog rows are Vp wide, only V valid)
-        ops.linear_wgrad(dlog, sv["gl"], view(GW, t0 + 3, (V, H)), acc[t0 + 3], M=V, lda=Vp)
+        wgrad(dlog, sv["gl"], view(GW, t0 + 3, (V, H)), acc[t0 + 3], M=V, lda=Vp)
         dgl = torch.empty((T, H), dtype=cd, device=dev)
         if Wt is not None and V % 8 == 0:
             ops.gemm(dlog, view(Wt, t0 + 3, (H, V)), dgl, T, H, V, la=0, lb=0, lda=Vp, ldb=V, ldc=H)
@@ -541,7 +570,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             ops.gemm(dlog, w_log, dgl, T, H, V, la=0, lb=1, lda=Vp, ldb=H, ldc=H)
         dg = ops.layernorm_bwd(dgl, sv["g"], w_mln, sv["mu_g"], sv["rs_g"], cd, view(GW, t0 + 2, (H,)), acc[t0 + 2])
         dd = ops.gelu_bwd(sv["d"], dg)
-        ops.linear_wgrad(dd, sv["xf"], view(GW, t0 + 1, (H, H)), acc[t0 + 1])
+        wgrad(dd, sv["xf"], view(GW, t0 + 1, (H, H)), acc[t0 + 1])
         dxf = dgrad(dd, w_dense, t0 + 1)
         bf = cd == torch.bfloat16   # bf16 mode: LayerNorm backward also writes the bf16 copy of dx the next layer's GEMMs read
         dx = ops.layernorm_bwd(dxf, sv["x_last"], w_enc, sv["mu_e"], sv["rs_e"], torch.float32, view(GW, t0 + 0, (H,)),
@@ -557,23 +586,23 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             w_post, w_pre = view(Wf, b0 + 5, (H,)), view(Wf, b0 + 6, (H,))
             w_01, w_mid, w_o2 = view(Wc, b0 + 7, (2 * I, H)), view(Wf, b0 + 9, (I,)), view(Wc, b0 + 10, (H, I))
             # FFN
-            ops.linear_wgrad(dxc, s["hm"], view(GW, b0 + 10, (H, I)), acc[b0 + 10])
+            wgrad(dxc, s["hm"], view(GW, b0 + 10, (H, I)), acc[b0 + 10])
             dhm = dgrad(dxc, w_o2, b0 + 10)
             if pd_h > 0.0:
                 ops.dropout(dhm, pd_h, seed, site(li, 1), out=dhm)
             dab = ops.ffn_mid_bwd(dhm, s["h"], s["ab"], w_mid, s["mu_m"], s["rs_m"], view(GW, b0 + 9, (I,)), acc[b0 + 9])
-            ops.linear_wgrad(dab, s["ln2"], view(GW, b0 + 7, (2 * I, H)), acc[b0 + 7])
+            wgrad(dab, s["ln2"], view(GW, b0 + 7, (2 * I, H)), acc[b0 + 7])
             dln2 = dgrad(dab, w_01, b0 + 7)
             dx1 = ops.layernorm_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], torch.float32, view(GW, b0 + 6, (H,)),
                                     acc[b0 + 6], dres=dx)
             # attention
             dao = ops.layernorm_bwd(dx1, s["ao"], w_post, s["mu_p"], s["rs_p"], cd, view(GW, b0 + 5, (H,)), acc[b0 + 5])
-            ops.linear_wgrad(dao, s["ctx"], view(GW, b0 + 4, (H, H)), acc[b0 + 4])
+            wgrad(dao, s["ctx"], view(GW, b0 + 4, (H, H)), acc[b0 + 4])
             dctx = dgrad(dao, w_out, b0 + 4)
             qkv, P = s["qkv"], s["P"]
             if sv["fused"]:
                 dqkv = ops.attention_bwd(qkv, s["ctx"], dctx, P, B, S, nh, hd, alpha)
-                ops.linear_wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
+                wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
                 dln1 = dgrad(dqkv, w_qkv, b0 + 1)
                 dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
                                        acc[b0 + 0], dres=dx1, also_bf16=bf and li > 0)
@@ -599,7 +628,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                      batch=B * nh, zdiv=nh, sA=sP_, sB=sQ, sC=sQ)
             ops.gemm(dP, qkv, dqkv, S, hd, S, la=1, lb=1, lda=Sp, ldb=3 * H, ldc=3 * H, b_off=0, c_off=H, alpha=alpha,
                      batch=B * nh, zdiv=nh, sA=sP_, sB=sQ, sC=sQ)
-            ops.linear_wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
+            wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
             dln1 = dgrad(dqkv, w_qkv, b0 + 1)
             dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
                                    acc[b0 + 0], dres=dx1, also_bf16=bf and li > 0)
@@ -614,6 +643,8 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         if not acc[1] and S < self.max_position_embeddings:
             view(GW, 1, tuple(params[1].shape))[S:].zero_()
         ready(0, 2)
+        if side is not None:
+            main.wait_stream(side)   # the optimizer (and anything else on the main stream) sees every weight gradient
         if self.direct_grad:
             return [None] * len(params)
         return [view(GW, i, tuple(p.shape)) for i, p in enumerate(params)]

@@ -652,6 +652,13 @@ def conv_split2_ok(B, H, W, Cin, Cout, KS):
     return KS == 3 and Cin % 32 == 0 and Cout % 4 == 0 and M * Cin * 2 < (1 << 32) - 64 and M < (1 << 31) - 256
 
 
+def conv_slab_ok(H, W, Cin):
+    """shapes muse_conv2d_nhwc_split2 runs on its patch-slab kernel (16 x 16 pixel patches, K order chunk / tap / channel) unless
+    MUSE_CONV_SLAB=0; the others run on the tap-major kernel"""
+    import os
+    return H % 16 == 0 and W % 16 == 0 and Cin % 64 == 0 and os.environ.get("MUSE_CONV_SLAB", "1") != "0"
+
+
 def conv_gn_stats_ok(H, W, Cout, groups):
     cpg = Cout // groups if groups else 0
     return groups in (32, 64) and Cout % groups == 0 and (H * W) % 256 == 0 and 4 <= cpg <= 128 and (cpg & (cpg - 1)) == 0

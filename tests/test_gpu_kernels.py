@@ -485,11 +485,15 @@ def test_conv2d_split_bf16x3(Cin, Cout, KS, ups, bias, res):
     (1, 32, 32, 256, 256, False, True),    # fused GroupNorm statistics: 8 channels per group, 4 pixel tiles
     (2, 16, 16, 128, 128, True, True),     # ... 4 channels per group, one tile per image
     (1, 16, 32, 64, 512, True, False),     # ... 16 channels per group, 4 channel tiles
+    (2, 48, 32, 128, 128, True, True),     # patch-slab kernel: 6 patches per image (interior + every border kind), 4 channel chunks
+    (1, 64, 64, 192, 256, False, True),    # ... 16 patches, 6 channel chunks (3 loop iterations), two channel tiles
+    (3, 16, 16, 512, 64, True, False),     # ... one patch per image (all halo rows are padding), 16 channel chunks, ragged Cout tile
 ])
 def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
-    """the LDS-DMA bf16x3 convolution on pre-split planes is BIT-identical to the register-staged bf16x3 kernel on the f32
-    tensor the planes came from (same products, same accumulation order), and the planes GroupNorm writes are the split
-    of the tensor GroupNorm writes"""
+    """the LDS-DMA bf16x3 convolution on pre-split planes computes the same products as the register-staged bf16x3 kernel on
+    the f32 tensor the planes came from: BIT-identical where the K order is the same (tap-major kernel), within f32
+    summation-order noise for the patch-slab kernel (K order chunk, tap, channel; ops.conv_slab_ok); and the planes GroupNorm
+    writes are the split of the tensor GroupNorm writes"""
     ops = _ops()
     x = rnd((B, H, W, Cin), 180).to(DEV)
     w = (rnd((Cout, 3, 3, Cin), 181) / math.sqrt(9 * Cin)).to(DEV)
@@ -500,7 +504,11 @@ def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
     assert ops.conv_split2_ok(B, H, W, Cin, Cout, 3)
     ref = ops.conv2d_nhwc_split(x, w_hi, w_lo, B, H, W, Cin, Cout, 3, bias=bvec, residual=rr)
     got = ops.conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=bvec, residual=rr)
-    assert torch.equal(got, ref), float((got - ref).abs().max())
+    slab = ops.conv_slab_ok(H, W, Cin)
+    if slab:
+        assert rel_err(got, ref) < 2e-6, rel_err(got, ref)   # same 3 x 9 x Cin products per output, f32 accumulation in another order
+    else:
+        assert torch.equal(got, ref), float((got - ref).abs().max())
     ref64 = F.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.cpu().double().permute(0, 3, 1, 2), bvec.cpu().double() if bias else None, padding=1)
     if res:
         ref64 = ref64 + rr.cpu().double().permute(0, 3, 1, 2)
@@ -508,15 +516,15 @@ def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
     # GroupNorm statistics fused into the convolution epilogue: [B, HW/256, 32, 2] f64 sums of the (bias + residual) output
     if ops.conv_gn_stats_ok(H, W, Cout, 32):
         got2 = ops.conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=bvec, residual=rr, gn_groups=32)
-        assert torch.equal(got2, ref)
+        assert torch.equal(got2, got)
         part, nchunk = got2._gn_stats
         assert nchunk == H * W // 256
         st = part.view(B, nchunk, 32, 2).sum(1).cpu()
-        o = ref.cpu().double().view(B, H * W, 32, Cout // 32)
+        o = got.cpu().double().view(B, H * W, 32, Cout // 32)
         assert rel_err(st[..., 0], o.sum((1, 3))) < 1e-12 and rel_err(st[..., 1], (o * o).sum((1, 3))) < 1e-12
         gam2, bet2 = (1 + 0.1 * rnd((Cout,), 186)).to(DEV), (0.1 * rnd((Cout,), 187)).to(DEV)
         if 256 % (Cout // 4) == 0:
-            a_hi, a_lo = ops.groupnorm_silu_nhwc_split(ref, gam2, bet2, B, H * W, Cout)
+            a_hi, a_lo = ops.groupnorm_silu_nhwc_split(got, gam2, bet2, B, H * W, Cout)
             b_hi, b_lo = ops.groupnorm_silu_nhwc_split(got2, gam2, bet2, B, H * W, Cout, stats=got2._gn_stats)
             ya, yb = a_hi.float() + a_lo.float(), b_hi.float() + b_lo.float()
             assert rel_err(yb, ya) < 1e-6   # same statistics up to f64 summation order
