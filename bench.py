@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--vq-dtype", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="gradient all-reduce payload (N > 1)")
+    ap.add_argument("--no-prefetch", action="store_true", help="encode each batch inline instead of one step ahead on a second stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (config A / 4 / 5, tokenizer variants)")
     args = ap.parse_args()
@@ -273,8 +274,12 @@ def main():
         px, cls = synthetic_batch(args.batch, device, seed=1000 + rank)  # different data per rank (weak scaling)
         toks = vq.get_code(px) if tokens_given else None
 
+        prefetch = not args.no_prefetch and not tokens_given
+
         def one():
-            return step(None if tokens_given else px, cls, image_tokens=toks)
+            # prefetch: the NEXT batch's tokenizer pass is enqueued on a second stream before this batch's transformer step
+            # (TrainStep docstring); every timed step still runs one encode + one fwd/bwd + AdamW
+            return step(None if tokens_given else px, cls, image_tokens=toks, next_pixel_values=px if prefetch else None)
         loss = None
         for _ in range(warmup):
             loss, _ = one()
@@ -295,9 +300,14 @@ def main():
             loss, _ = reducer.reduce_metrics(loss, mask_prob)     # the two logged scalars of the loop as one 2-float all-reduce
         prof = tr_ms = None
         if profile:
+            # per-kernel timing needs the kernels one at a time: no token prefetch, weight gradients on the main stream
+            step._pf = None
+            ws, model.wgrad_stream = model.wgrad_stream, False
+            torch.cuda.synchronize()
             ops.profile_start()
-            one()
+            step(px, cls)
             prof = ops.profile_stop(with_kind=True)
+            model.wgrad_stream = ws
             prof_bytes.update(ops.PROF_BYTES)
             # transformer forward + backward alone (tokens given, no optimizer): the north_star's "MaskGitTransformer step"
             ids, labels, _, _ = muse.prepare_inputs_and_labels(vq, None, cls, model.config.mask_token_id, image_tokens=vq.get_code(px))
@@ -385,7 +395,8 @@ def main():
                                f", seq 257) fwd+bwd (bf16 MFMA, f32 accum/residual) + AdamW",
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "resolution": 256, "seq_len": 257,
                    "parallelism": f"dp{world}", "vqgan_dtype": args.vq_dtype, "random_init": True,
-                   "grad_allreduce_dtype": args.grad_dtype if world > 1 else None},
+                   "grad_allreduce_dtype": args.grad_dtype if world > 1 else None,
+                   "tokenizer_prefetch": not args.no_prefetch, "wgrad_stream": os.environ.get("MUSE_WGRAD_STREAM", "1") != "0"},
         "roofline": roofline,
         "extra": extra,
     }

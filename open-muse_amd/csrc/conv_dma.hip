@@ -563,6 +563,327 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent form of the patch-slab kernel: one block per CU walks its tiles, and the K loop's own look-ahead (next chunk's
+// slab in taps 0-2, weights three taps ahead, fragments one tap ahead) simply runs on INTO THE NEXT TILE: when a tile's last
+// tap retires, the next tile's first slab, its first three weight stages and its tap-0 fragments are already on chip.
+// What is left between two tiles is the epilogue alone - no block launch, no address set-up, no cold DMA round trip (the
+// non-persistent kernel spends ~13 us of a 43 us tile there).
+//   LDS map (bytes): slab buffer 0 [0, 43008) | weight stages 1, 2, 0 [43008, 92160) | slab buffer 1 [92160, 135168) | spare.
+//   At a tile boundary buffer 0 and the three weight stages hold the NEXT tile's operands; buffer 1 and the spare bytes behind
+//   it are free: the f32 output tile is staged there in two passes of 128 rows (67584 bytes, 159744 in all).
+//   vmcnt: the epilogue drains every load before its first store, so the stores are the only old entries in the queue when
+//   the next tile starts; taps 0 and 1 of a tile's first iteration need no vector-memory wait at all (their operands were
+//   waited for in the previous tile / the epilogue), from tap 2 on the counted waits of the K loop apply unchanged (loads
+//   and stores retire in order within their kind; a counted wait that still sees stores is merely conservative).
+constexpr int P_BUF1 = 92160, P_BBASE = 43008, P_STAGING = P_BUF1, P_HALF_ROWS = 128;
+constexpr int P_LDS_BYTES = P_STAGING + P_HALF_ROWS * CST;   // 159744
+__host__ __device__ constexpr int p_stage_off(int st) { return st == 0 ? 32768 : (st - 1) * 16384; }   // relative to P_BBASE
+static_assert(P_BBASE + 3 * BSTAGE == P_BUF1 && P_BUF1 + SLAB <= P_LDS_BYTES && P_LDS_BYTES <= 163840, "LDS map");
+
+__global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int H = p.H, W = p.W, Cin = p.Cin;
+  const int tpr = W >> 4, tpi = (H >> 4) * tpr;
+  const int ntm = p.M >> 8, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+  const int bq = ntiles >> 3, br = ntiles & 7;
+  const int nblocks = gridDim.x;
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const unsigned bytesA = (unsigned)((long)p.M * Cin * 2);
+  const rsrc_t rs_xh = make_rsrc(p.xh, bytesA), rs_xl = make_rsrc(p.xl, bytesA);
+  const unsigned oobA = (bytesA + 15u) & ~15u;
+  const int wimg = wave >> 2;
+  const unsigned bytesB = (unsigned)((long)p.N * p.K * 2);
+  const rsrc_t rs_w = make_rsrc(wimg ? p.wl : p.wh, bytesB);
+  const unsigned oobB = (bytesB + 15u) & ~15u;
+  const int nchunks = Cin >> 5;
+  const unsigned bytesO = (unsigned)((long)p.M * p.N * 4);   // < 4 GiB (host check)
+  const rsrc_t rs_out = make_rsrc(p.out, bytesO), rs_res = make_rsrc(p.residual ? (const void*)p.residual : (const void*)p.out, bytesO);
+
+  int slab_piece[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { int piece = wave + 8 * k; if (piece > 20) piece -= 8; slab_piece[k] = piece; }
+  const int srcchunkA = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+  const int srcchunkB = (lane & 3) ^ sw4((lane >> 4) & 3);
+
+  // geometry of virtual block v (the XCD-aware walk of the launch-per-tile kernels: v -> tile)
+  struct Geo { int img, prem, y0, x0, n0; };
+  auto geo_of = [&](int v) {
+    const int xcd = v & 7, bi = v >> 3;
+    const int tid_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+    const int mt = tid_ / ntn;
+    Geo g;
+    g.n0 = (tid_ - mt * ntn) * BN;
+    g.img = mt / tpi; g.prem = mt - g.img * tpi;
+    const int ty = g.prem / tpr, tx = g.prem - ty * tpr;
+    g.y0 = ty << 4; g.x0 = tx << 4;
+    return g;
+  };
+  auto offsets_of = [&](const Geo& g, bool valid, unsigned (&so)[3], unsigned (&vb)[2]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = slab_piece[k] * 16 + (lane >> 2), sy = r / 18, sx = r - sy * 18;
+      const int y = g.y0 - 1 + sy, x = g.x0 - 1 + sx;
+      const bool ok = valid && r < 324 && y >= 0 && y < H && x >= 0 && x < W;
+      so[k] = ok ? (unsigned)((((long)g.img * H + y) * W + x) * Cin * 2 + srcchunkA * 16) : oobA;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = g.n0 + ((wave & 3) * 2 + j) * 16 + (lane >> 2);
+      vb[j] = (valid && n < p.N) ? (unsigned)(((long)n * p.K + srcchunkB * 8) * 2) : oobB;
+    }
+  };
+
+  unsigned slab_off[3], voffB[2], slab_off_n[3], voffB_n[2];
+  // slab third k of chunk `chunk` of the current tile, or (chunk == nchunks) of chunk 0 of the next tile
+  auto issue_slab = [&](int buf, int k, int chunk) {
+    const bool cur = chunk < nchunks;
+    const unsigned vo = cur ? slab_off[k] : slab_off_n[k];
+    const int soff = cur ? chunk * 64 : 0;
+    unsigned char* dst = smem + (buf ? P_BUF1 : 0) + slab_piece[k] * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (lds_void_t*)dst, 16, (int)vo, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xl, (lds_void_t*)(dst + PLANE), 16, (int)vo, soff, 0, 0);
+  };
+  auto issue_b = [&](int stage_off, int chunk, int tap) {
+    const bool cur = chunk < nchunks;
+    const int soff = (tap * Cin + (cur ? chunk * 32 : 0)) * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + P_BBASE + stage_off + wimg * 8192 + ((wave & 3) * 2 + j) * 1024),
+                                               16, (int)(cur ? voffB[j] : voffB_n[j]), soff, 0, 0);
+  };
+
+  unsigned baseA[4][2], addrB;
+  {
+    const int pr = lane & 15, g = lane >> 4, P = 72 * wm + pr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int bit2 = ((P >> 2) & 1) ^ (((P & 3) + e) >> 2) ^ b;
+        baseA[e][b] = (unsigned)((P << 6) | ((g << 4) ^ (bit2 << 5)));
+      }
+    addrB = (unsigned)(P_BBASE + (wn * 64 + pr) * 64 + ((g ^ sw4((pr >> 2) & 3)) << 4));
+  }
+  auto flip_base = [&](int d) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { baseA[e][0] += d; baseA[e][1] += d; }
+  };
+
+  // LDS-only barrier: a full block barrier is also a fence for global memory, i.e. an `s_waitcnt vmcnt(0)` on the output
+  // stores still in flight - exactly the wait the persistent walk exists to avoid
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  f32x4 acc[MI][NI];
+  Frag16 f0, f1;
+
+#define SLAB_CP(TAP, I) (((I) + (TAP) / 3) * 18 + (TAP) % 3)
+#define SLAB_READ(F, ST, TAP, Q)                                                                                                  \
+  {                                                                                                                               \
+    constexpr int q_ = (Q) & 3;                                                                                                   \
+    constexpr int cp_ = SLAB_CP(TAP, q_);                                                                                         \
+    if constexpr ((Q) < 4) lds_read128<cp_ * 64>(F.ah[q_], baseA[cp_ & 3][(cp_ >> 2) & 1]);                                       \
+    else if constexpr ((Q) < 8) lds_read128<PLANE + cp_ * 64>(F.al[q_], baseA[cp_ & 3][(cp_ >> 2) & 1]);                          \
+    else if constexpr ((Q) < 12) lds_read128<p_stage_off(ST) + q_ * 1024>(F.bh[q_], addrB);                                       \
+    else lds_read128<p_stage_off(ST) + 8192 + q_ * 1024>(F.bl[q_], addrB);                                                        \
+  }
+#define SLAB_PAIR(F, Q)                                                                                                        \
+  {                                                                                                                            \
+    constexpr int i_ = (Q) >> 2, j_ = (Q) & 3;                                                                                 \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bl[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.al[i_], acc[i_][j_], 0, 0, 0);                            \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
+  }
+#define SLAB_ISSUE(T, Q)                                                                          \
+  if constexpr ((Q) == 0 && ((T) % 9) < 3) issue_slab(1 - (T) / 9, (T) % 9, chunk0 + (T) / 9 + 1);  \
+  if constexpr ((Q) == 2) issue_b(p_stage_off(((T) + 3) % 3), chunk0 + ((T) + 3) / 9, ((T) + 3) % 9);
+#define SLAB_SLOT(CUR, NXT, T, Q)                                                   \
+  SLAB_PAIR(CUR, Q)                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  SLAB_ISSUE(T, Q)                                                                  \
+  SLAB_READ(NXT, (((T) + 1) % 3), (((T) + 1) % 9), Q)                               \
+  __builtin_amdgcn_sched_barrier(0);
+#define SLAB_WAIT(T)                                                                                                        \
+  if constexpr ((T) < 2) {                                                                                                  \
+    if (first) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+    else if constexpr ((T) == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                               \
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                                        \
+  } else if constexpr (((T) % 9) >= 1 && ((T) % 9) <= 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");        \
+  else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+#define SLAB_TAP(CUR, NXT, T)                                                                         \
+  SLAB_WAIT(T)                                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                       \
+  if constexpr ((T) == 8) flip_base(P_BUF1);                                                          \
+  if constexpr ((T) == 17) flip_base(-P_BUF1);                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                                  \
+  SLAB_SLOT(CUR, NXT, T, 0) SLAB_SLOT(CUR, NXT, T, 1) SLAB_SLOT(CUR, NXT, T, 2) SLAB_SLOT(CUR, NXT, T, 3)     \
+  SLAB_SLOT(CUR, NXT, T, 4) SLAB_SLOT(CUR, NXT, T, 5) SLAB_SLOT(CUR, NXT, T, 6) SLAB_SLOT(CUR, NXT, T, 7)     \
+  SLAB_SLOT(CUR, NXT, T, 8) SLAB_SLOT(CUR, NXT, T, 9) SLAB_SLOT(CUR, NXT, T, 10) SLAB_SLOT(CUR, NXT, T, 11)   \
+  SLAB_SLOT(CUR, NXT, T, 12) SLAB_SLOT(CUR, NXT, T, 13) SLAB_SLOT(CUR, NXT, T, 14) SLAB_SLOT(CUR, NXT, T, 15)
+
+  // ---- first tile: its operands as the "next tile" of an empty predecessor ----
+  int v = blockIdx.x;
+  Geo g = geo_of(v);
+  offsets_of(g, true, slab_off_n, voffB_n);
+  {
+    issue_slab(0, 0, nchunks); issue_slab(0, 1, nchunks); issue_slab(0, 2, nchunks);
+    issue_b(p_stage_off(0), nchunks, 0); issue_b(p_stage_off(1), nchunks, 1); issue_b(p_stage_off(2), nchunks, 2);
+  }
+  // (Measured and rejected: starting the blocks in eight phases an eighth of a tile apart, to keep 256 CUs from writing their
+  //  32 MB of output at the same instant.  scripts/exp/conv_seam.py: T(Cin) = 13-15 us + 8.1 us per 32-channel chunk per tile
+  //  with or without the stagger, launch-per-tile or persistent - the ~13 us is not a chip-wide burst but the CU's own
+  //  vector-memory path moving 128 KiB of output (+ 128 KiB of residual) at ~14 B/clk; only stores issued INSIDE the next
+  //  tile's K loop would hide it, and a second 128 KiB staging area or accumulator set does not fit next to this pipeline.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  SLAB_READ(f0, 0, 0, 0) SLAB_READ(f0, 0, 0, 1) SLAB_READ(f0, 0, 0, 2) SLAB_READ(f0, 0, 0, 3)
+  SLAB_READ(f0, 0, 0, 4) SLAB_READ(f0, 0, 0, 5) SLAB_READ(f0, 0, 0, 6) SLAB_READ(f0, 0, 0, 7)
+  SLAB_READ(f0, 0, 0, 8) SLAB_READ(f0, 0, 0, 9) SLAB_READ(f0, 0, 0, 10) SLAB_READ(f0, 0, 0, 11)
+  SLAB_READ(f0, 0, 0, 12) SLAB_READ(f0, 0, 0, 13) SLAB_READ(f0, 0, 0, 14) SLAB_READ(f0, 0, 0, 15)
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (;;) {
+    // this tile's offsets are the ones prefetched as "next"; then look one tile ahead
+#pragma unroll
+    for (int k = 0; k < 3; ++k) slab_off[k] = slab_off_n[k];
+    voffB[0] = voffB_n[0]; voffB[1] = voffB_n[1];
+    const int vn = v + nblocks;
+    const bool has_next = vn < ntiles;
+    const Geo gn = geo_of(has_next ? vn : v);
+    offsets_of(gn, has_next, slab_off_n, voffB_n);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bool first = true;
+    for (int chunk0 = 0; chunk0 < nchunks; chunk0 += 2) {
+      SLAB_TAP(f0, f1, 0) SLAB_TAP(f1, f0, 1) SLAB_TAP(f0, f1, 2) SLAB_TAP(f1, f0, 3) SLAB_TAP(f0, f1, 4) SLAB_TAP(f1, f0, 5)
+      SLAB_TAP(f0, f1, 6) SLAB_TAP(f1, f0, 7) SLAB_TAP(f0, f1, 8) SLAB_TAP(f1, f0, 9) SLAB_TAP(f0, f1, 10) SLAB_TAP(f1, f0, 11)
+      SLAB_TAP(f0, f1, 12) SLAB_TAP(f1, f0, 13) SLAB_TAP(f0, f1, 14) SLAB_TAP(f1, f0, 15) SLAB_TAP(f0, f1, 16) SLAB_TAP(f1, f0, 17)
+      first = false;
+    }
+
+    // ---- epilogue of tile v.  (The tap-17 look-ahead reads already fetched the next tile's tap-0 fragments, but keeping them
+    //      live through the epilogue - 64 more registers next to the accumulators and the residual tile - made hipcc spill into
+    //      the store loop, and a spill reload is a `vmcnt(0)` behind every store.  They are re-read after the epilogue.) ----
+    const int n0 = g.n0;
+    constexpr int NITH = (P_HALF_ROWS * 32) / NT;   // 8 chunks of 16 bytes per thread and pass
+    const int col = (threadIdx.x & 31) * 4, n = n0 + col, rbase = threadIdx.x >> 5;
+    // output / residual through buffer descriptors: one 32-bit offset register per thread, the patch row as a scalar offset
+    const long pixp = ((long)g.img * H + g.y0) * W + g.x0;   // first pixel of the patch
+    const unsigned obase = (unsigned)(((pixp + rbase) * p.N + n) * 4);
+    const unsigned rowstep = (unsigned)((long)W * p.N * 4);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // look-ahead DMAs and the tap-17 fragment reads
+    __builtin_amdgcn_sched_barrier(0);
+    // residual: added to the accumulators in FRAGMENT layout (lane = pixel lane & 15 of patch row wm * 4 + i, four channels),
+    // one patch row ahead, so that every global load of the epilogue retires before its first store: a load waited for behind
+    // a store is a wait for that store's acknowledgement (reads and writes share vmcnt)
+    if (p.residual) {
+      const int nf = n0 + wn * 64 + 4 * (lane >> 4);
+      const unsigned fbase = (unsigned)((((pixp + (long)(wm * 4) * W + (lane & 15)) * p.N) + nf) * 4);
+      u32x4 rr[2][NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        rr[0][j] = (nf + j * 16) < p.N ? __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(fbase + j * 64), 0, 0) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (i + 1 < MI) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            rr[(i + 1) & 1][j] = (nf + j * 16) < p.N ? __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(fbase + j * 64), (int)(rowstep * (i + 1)), 0)
+                                                     : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] += __builtin_bit_cast(f32x4, rr[i & 1][j]);
+      }
+    }
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) bias4 = *(const f32x4*)(p.bias + n);
+    // nothing but loads in the queue: a cheap drain.  Written as the builtin plus a visible use of the last loaded value so
+    // that hipcc's own wait-count bookkeeping sees the drain here, in straight-line code - an inline-asm wait is invisible to
+    // it, and it would re-insert `vmcnt(0)` at the first use of bias4 inside each (exec-masked) store pass, i.e. behind the stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("" ::"v"(bias4));
+    __builtin_amdgcn_sched_barrier(0);
+    double gs = 0.0, gq = 0.0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      lds_barrier();   // the staging bytes are free (pass 0: everyone's fragment reads are done; pass 1: pass 0's rows are out)
+      if ((wm >> 1) == half) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int lr = (wm & 1) * 64 + i * 16 + (lane & 15);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int nl = wn * 64 + j * 16 + 4 * (lane >> 4);
+            *(f32x4*)(smem + P_STAGING + lr * CST + nl * 4) = acc[i][j];
+          }
+        }
+      }
+      lds_barrier();
+      if (n < p.N) {
+#pragma unroll
+        for (int it = 0; it < NITH; ++it) {
+          // (products + residual) + bias; the launch-per-tile kernels add (products + bias) + residual - same f32 class
+          const f32x4 w = *(const f32x4*)(smem + P_STAGING + (rbase + 16 * it) * CST + col * 4) + bias4;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), rs_out, (int)obase, (int)(rowstep * (half * NITH + it)), 0);
+          if (p.gn_partial) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gs += (double)w[e]; gq += (double)w[e] * (double)w[e]; }
+          }
+        }
+      }
+    }
+    if (p.gn_partial) {
+      gs += __shfl_xor(gs, 32, 64);
+      gq += __shfl_xor(gq, 32, 64);
+      lds_barrier();
+      double* red = (double*)(smem + P_STAGING);   // [8 waves][32 chunks][2]
+      if (lane < 32) { red[(wave * 32 + lane) * 2] = gs; red[(wave * 32 + lane) * 2 + 1] = gq; }
+      lds_barrier();
+      if (threadIdx.x < 32) {
+        double cs = 0.0, cq = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) { cs += red[(w8 * 32 + threadIdx.x) * 2]; cq += red[(w8 * 32 + threadIdx.x) * 2 + 1]; }
+        const int cpc = p.gn_cpg >> 2;
+        for (int o = 1; o < cpc; o <<= 1) { cs += __shfl_xor(cs, o, 64); cq += __shfl_xor(cq, o, 64); }
+        const int nn = n0 + (int)threadIdx.x * 4;
+        if ((threadIdx.x & (cpc - 1)) == 0 && nn < p.N) {
+          double* o2 = p.gn_partial + (((long)g.img * tpi + g.prem) * p.gn_groups + nn / p.gn_cpg) * 2;
+          o2[0] = cs; o2[1] = cq;
+        }
+      }
+    }
+    if (!has_next) break;
+    v = vn; g = gn;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    SLAB_READ(f0, 0, 0, 0) SLAB_READ(f0, 0, 0, 1) SLAB_READ(f0, 0, 0, 2) SLAB_READ(f0, 0, 0, 3)
+    SLAB_READ(f0, 0, 0, 4) SLAB_READ(f0, 0, 0, 5) SLAB_READ(f0, 0, 0, 6) SLAB_READ(f0, 0, 0, 7)
+    SLAB_READ(f0, 0, 0, 8) SLAB_READ(f0, 0, 0, 9) SLAB_READ(f0, 0, 0, 10) SLAB_READ(f0, 0, 0, 11)
+    SLAB_READ(f0, 0, 0, 12) SLAB_READ(f0, 0, 0, 13) SLAB_READ(f0, 0, 0, 14) SLAB_READ(f0, 0, 0, 15)
+    __builtin_amdgcn_sched_barrier(0);
+    // (the top-of-tap-0 wait + barrier of the next tile orders its first DMAs / fragment reads behind these staging reads)
+  }
+#undef SLAB_TAP
+#undef SLAB_WAIT
+#undef SLAB_SLOT
+#undef SLAB_ISSUE
+#undef SLAB_PAIR
+#undef SLAB_READ
+#undef SLAB_CP
+}
+
 }  // namespace cslab
 
 extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
@@ -598,7 +919,19 @@ extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, con
       (void)hipFuncSetAttribute((const void*)cslab::conv_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cslab::LDS_BYTES);
       slab_attr = true;
     }
-    hipLaunchKernelGGL(cslab::conv_slab_kernel, dim3((p.M >> 8) * ntn), dim3(512), cslab::LDS_BYTES, (hipStream_t)stream, p);
+    const int nslab = (p.M >> 8) * ntn;
+    if (use_slab >= 2 && (long)p.M * p.N * 4 < (1L << 32) - 64) {   // persistent: one block per CU walks its tiles (32-bit output offsets)
+      static int ncu = 0;
+      if (!ncu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MUSE_ERR_UNSUPPORTED;
+        ncu = prop.multiProcessorCount;
+        (void)hipFuncSetAttribute((const void*)cslab::conv_slab_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cslab::P_LDS_BYTES);
+      }
+      hipLaunchKernelGGL(cslab::conv_slab_persist_kernel, dim3(nslab < ncu ? nslab : ncu), dim3(512), cslab::P_LDS_BYTES, (hipStream_t)stream, p);
+      return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(cslab::conv_slab_kernel, dim3(nslab), dim3(512), cslab::LDS_BYTES, (hipStream_t)stream, p);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(cdma::conv_dma_kernel, dim3(ntm * ntn), dim3(512), cdma::LDS_BYTES, (hipStream_t)stream, p);

@@ -385,16 +385,51 @@ class GradReducer:
 
 class TrainStep:
     """One optimisation step exactly as the reference's loop body strings it together (:405-452):
-    VQ-encode -> mask -> forward(loss) -> backward (+ overlapped gradient all-reduce) -> AdamW -> zero_grad."""
+    VQ-encode -> mask -> forward(loss) -> backward (+ overlapped gradient all-reduce) -> AdamW -> zero_grad.
+
+    `next_pixel_values`: the following batch's images.  The tokenizer is frozen (`vq_model.requires_grad_(False)`, :283), so its
+    token ids do not depend on the optimizer state and the NEXT batch can be encoded while this one trains: the encode is
+    enqueued on a second HIP stream before this step's forward (the software analogue of the reference's dataloader workers
+    running ahead of the loop; the token ids are bit-identical to encoding inline).  The convolution blocks and the
+    transformer's GEMM / HBM-bound kernels then share the chip: each fills the CUs and memory cycles the other leaves idle
+    (tile seams, short grids).  The next call picks the tokens up when it is given the same tensor as `pixel_values`."""
 
     def __init__(self, vq_model, model, optimizer, reducer: Optional[GradReducer] = None, label_smoothing: float = 0.0,
                  min_masking_rate: float = 0.0):
         self.vq_model, self.model, self.optimizer, self.reducer = vq_model, model, optimizer, reducer
         self.label_smoothing, self.min_masking_rate = label_smoothing, min_masking_rate
+        self._pf = None          # (pixel tensor, tokens, ready event) of the prefetched batch
+        self._pf_stream = None
 
-    def __call__(self, pixel_values, class_ids, timesteps=None, noise=None, image_tokens=None):
+    @torch.no_grad()
+    def _prefetch(self, pixel_values):
+        if not pixel_values.is_cuda:
+            raise MuseHipError("TrainStep: next_pixel_values must be on the GPU")
+        main = torch.cuda.current_stream(pixel_values.device)
+        if self._pf_stream is None or self._pf_stream.device != pixel_values.device:
+            self._pf_stream = torch.cuda.Stream(device=pixel_values.device)
+        side = self._pf_stream
+        side.wait_stream(main)                      # the images (and the previous use of the tokenizer's buffers) are ready
+        with torch.cuda.stream(side):
+            tokens = self.vq_model.get_code(pixel_values)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        pixel_values.record_stream(side)
+        self._pf = (pixel_values, tokens, ev)
+
+    def __call__(self, pixel_values, class_ids, timesteps=None, noise=None, image_tokens=None, next_pixel_values=None):
         """image_tokens [B, S] int64: pre-encoded VQ tokens (muse.pre_encode; the reference's scripts/pre_encode.py regime) -
         the tokenizer is then skipped and pixel_values may be None"""
+        if image_tokens is None and self._pf is not None and self._pf[0] is pixel_values:
+            _, image_tokens, ev = self._pf
+            main = torch.cuda.current_stream(image_tokens.device)
+            main.wait_event(ev)
+            image_tokens.record_stream(main)
+        self._pf = None
+        if next_pixel_values is not None:
+            if image_tokens is None:   # first step of a run: this batch inline, then the next one on the side stream
+                image_tokens = self.vq_model.get_code(pixel_values)
+            self._prefetch(next_pixel_values)
         input_ids, labels, _, mask_prob = prepare_inputs_and_labels(
             self.vq_model, pixel_values, class_ids, self.model.config.mask_token_id, self.min_masking_rate, timesteps, noise,
             image_tokens=image_tokens)

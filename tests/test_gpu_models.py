@@ -391,6 +391,41 @@ def test_train_step_end_to_end_vs_oracle():
     assert losses[-1] < float(loss), (float(loss), losses)  # same batch every step: the loss must go down
 
 
+def test_train_step_streams_match_serial():
+    """The two concurrency features of the step change scheduling, not results: (a) next-batch token prefetch on a second stream
+    (TrainStep next_pixel_values) and (b) weight-gradient GEMMs on a side stream (MaskGitTransformer.wgrad_stream).  Three steps
+    over two alternating batches with both on == the same three steps run serially, bit for bit (bf16 compute mode, the mode
+    the side stream is used in)."""
+    import muse
+    vcfg, tcfg = W.VQGAN_TINY, dict(W.TRANSFORMER_TINY)
+    vsd = W.fill_state_dict(W.vqgan_shapes(vcfg), 700, "vqgan")
+    tsd = W.fill_state_dict(W.transformer_shapes(tcfg), 701, "transformer")
+    B = 4
+    pxs = [W.images(B, 16, 702 + i).to(DEV) for i in range(2)]
+    cls = torch.from_numpy(np.random.default_rng(703).integers(0, 10, size=B)).to(DEV)
+    t, nz = W.uniforms((B,), 704).to(DEV), W.uniforms((B, 16), 705).to(DEV)
+
+    def run(concurrent):
+        v = muse.MaskGitVQGAN(**vcfg); v.load_state_dict(vsd); v.to(DEV).eval()
+        m = muse.MaskGitTransformer(**tcfg); m.load_state_dict(tsd); m.to(DEV).train().set_compute_dtype(torch.bfloat16)
+        m.wgrad_stream = concurrent
+        opt = muse.FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
+        step = muse.TrainStep(v, m, opt)
+        losses = []
+        for i in range(3):
+            nxt = pxs[(i + 1) % 2] if concurrent else None
+            losses.append(step(pxs[i % 2], cls, t, nz, next_pixel_values=nxt)[0])
+            if concurrent:
+                assert step._pf is not None and step._pf[0] is pxs[(i + 1) % 2]
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), m.flat_params().clone().cpu()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+
+
 def test_full_batch_properties_bf16():
     """BASELINE config at full size (bs 64, S 257, imagenet.yaml transformer, bf16): properties that need no oracle."""
     import muse
