@@ -159,6 +159,12 @@ int muse_cross_entropy_bwd(const void* logits, int32_t dtype, const int64_t* lab
  * training/train_maskgit_imagenet.py:242-261,438); optionally refreshes the bf16 compute copy of the weights. */
 int muse_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+/* The same update for many separate f32 tensors in ONE launch (models whose parameters are ordinary tensors: MaskGiTUViT_v2,
+ * muse/modeling_transformer_v2.py; the reference reaches this through apex FusedAdam's multi_tensor_apply).  `table` (device):
+ * 6 x int64 per tensor {p, g, m, v, p_bf16 or 0, n}; `chunk_first` (device, num_tensors + 1 x int32): exclusive prefix sum of
+ * ceil(n / 4096); num_chunks = chunk_first[num_tensors]. */
+int muse_adamw_multi(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
 /* out[i] (+)= sum over s < nslices of ws[s*stride + i]: reduction of split-K partial results (n, stride % 4 == 0) */
 int muse_sum_slices(const float* ws, float* out, int32_t nslices, int64_t n, int64_t stride, int32_t accumulate, void* stream);
 int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);

@@ -328,6 +328,167 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// ---- bf16, inter % 1024 == 0: TWO waves per row, 16-byte accesses, every operand of the row in flight at once ------------------
+// The 256-threads-per-row kernels above move 8 bytes per lane per access in two dependent phases per row (3.3 TB/s backward,
+// 4.4 TB/s forward on MI355X).  Here a row belongs to a pair of waves (128 lanes x 8 elements = 1024 columns per step, NK steps),
+// the two pairs of a block work on different rows, all 4 NK (backward) / 2 NK (forward) loads of a row are issued before the
+// first use, and the only block barriers are the ones that carry the two-wave row reductions.  Partial-sum layout unchanged:
+// partial row i = rows [8 i, 8 i + 8) (a pair walks 8 consecutive rows).
+__device__ __forceinline__ void unpack8(const u32x4& t, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(t[j] << 16); v[2 * j + 1] = __uint_as_float(t[j] & 0xffff0000u); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+  return u32x4{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+}
+// sum over the 128 lanes of a wave pair; `slot` = one of 4 exchange cells of the pair (a cell is rewritten only two barriers later)
+__device__ __forceinline__ float pair_sum(float v, float (*red)[2], int slot, int pair, int wip) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[pair * 4 + slot][wip] = v;
+  __syncthreads();
+  return red[pair * 4 + slot][0] + red[pair * 4 + slot][1];
+}
+
+template <int NK>
+__global__ __launch_bounds__(256) void ffn_mid_fwd2_kernel(const bf16_t* __restrict__ ab, const float* __restrict__ w,
+                                                           bf16_t* __restrict__ h, bf16_t* __restrict__ hm, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, int rows, float eps) {
+  constexpr int inter = NK * 1024;
+  __shared__ float red[8][2];
+  const int pair = threadIdx.x >> 7, wip = (threadIdx.x >> 6) & 1, t = threadIdx.x & 127;
+  float wv[NK][8];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const f32x4 w0 = *(const f32x4*)(w + k * 1024 + t * 8), w1 = *(const f32x4*)(w + k * 1024 + t * 8 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wv[k][j] = w0[j]; wv[k][4 + j] = w1[j]; }
+  }
+  const int r0 = (blockIdx.x * 2 + pair) * FFN_ROWS;
+#pragma unroll 1
+  for (int rr = 0; rr < FFN_ROWS; ++rr) {
+    const int row = r0 + rr;
+    const bool live = row < rows;     // (both pairs keep taking the barriers)
+    const int rowc = live ? row : rows - 1;
+    const bf16_t* abr = ab + (long)rowc * 2 * inter;
+    u32x4 ra[NK], rb[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { ra[k] = *(const u32x4*)(abr + k * 1024 + t * 8); rb[k] = *(const u32x4*)(abr + inter + k * 1024 + t * 8); }
+    float hv[NK][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      float a[8], b[8];
+      unpack8(ra[k], a); unpack8(rb[k], b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[k][j] = gelu_erf(a[j]) * b[j];
+      const u32x4 o = pack8(hv[k]);
+      if (live) *(u32x4*)(h + (long)row * inter + k * 1024 + t * 8) = o;
+      unpack8(o, hv[k]);   // LayerNorm sees the stored (bf16-rounded) h, exactly like the unfused path
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += hv[k][j];
+    }
+    const float mean = pair_sum(s, red, (rr & 1) * 2, pair, wip) / (float)inter;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = hv[k][j] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(pair_sum(q, red, (rr & 1) * 2 + 1, pair, wip) / (float)inter + eps);
+    if (live) {
+      if (t == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (hv[k][j] - mean) * rstd * wv[k][j];
+        *(u32x4*)(hm + (long)row * inter + k * 1024 + t * 8) = pack8(o);
+      }
+    }
+  }
+}
+
+template <int NK>
+__global__ __launch_bounds__(256) void ffn_mid_bwd2_kernel(const bf16_t* __restrict__ dhm, const bf16_t* __restrict__ h,
+                                                           const bf16_t* __restrict__ ab, const float* __restrict__ w,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           bf16_t* __restrict__ dab, float* __restrict__ dwp, int rows) {
+  constexpr int inter = NK * 1024;
+  __shared__ float red[8][2];
+  const int pair = threadIdx.x >> 7, wip = (threadIdx.x >> 6) & 1, t = threadIdx.x & 127;
+  float wv[NK][8], dwacc[NK][8];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const f32x4 w0 = *(const f32x4*)(w + k * 1024 + t * 8), w1 = *(const f32x4*)(w + k * 1024 + t * 8 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wv[k][j] = w0[j]; wv[k][4 + j] = w1[j]; dwacc[k][j] = 0.f; dwacc[k][4 + j] = 0.f; }
+  }
+  const int prow = blockIdx.x * 2 + pair;     // partial row of this pair
+  const int r0 = prow * FFN_ROWS;
+#pragma unroll 1
+  for (int rr = 0; rr < FFN_ROWS; ++rr) {
+    const int row = r0 + rr;
+    const bool live = row < rows;
+    const int rowc = live ? row : rows - 1;
+    const float mu = mean[rowc], rs = rstd[rowc];
+    const bf16_t* abr = ab + (long)rowc * 2 * inter;
+    u32x4 rd[NK], rx[NK], ra[NK], rb[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const long c = (long)rowc * inter + k * 1024 + t * 8;
+      rd[k] = *(const u32x4*)(dhm + c); rx[k] = *(const u32x4*)(h + c);
+      ra[k] = *(const u32x4*)(abr + k * 1024 + t * 8); rb[k] = *(const u32x4*)(abr + inter + k * 1024 + t * 8);
+    }
+    float s1 = 0.f, s2 = 0.f;
+    float xh[NK][8], gk[NK][8];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      float d[8], x[8];
+      unpack8(rd[k], d); unpack8(rx[k], x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[k][j] = (x[j] - mu) * rs;
+        gk[k][j] = d[j] * wv[k][j];
+        s1 += gk[k][j];
+        s2 = fmaf(gk[k][j], xh[k][j], s2);
+        if (live) dwacc[k][j] = fmaf(d[j], xh[k][j], dwacc[k][j]);
+      }
+    }
+    const float c1 = pair_sum(s1, red, (rr & 1) * 2, pair, wip) / (float)inter;
+    const float c2 = pair_sum(s2, red, (rr & 1) * 2 + 1, pair, wip) / (float)inter;
+    if (live) {
+      bf16_t* dr = dab + (long)row * 2 * inter;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        float a[8], b[8], da[8], db[8];
+        unpack8(ra[k], a); unpack8(rb[k], b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dh = rs * (gk[k][j] - c1 - xh[k][j] * c2);
+          da[j] = dh * b[j] * gelu_erf_grad(a[j]);
+          db[j] = dh * gelu_erf(a[j]);
+        }
+        *(u32x4*)(dr + k * 1024 + t * 8) = pack8(da);
+        *(u32x4*)(dr + inter + k * 1024 + t * 8) = pack8(db);
+      }
+    }
+  }
+  if (r0 < rows) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      float* o = dwp + (long)prow * inter + k * 1024 + t * 8;
+      *(f32x4*)o = f32x4{dwacc[k][0], dwacc[k][1], dwacc[k][2], dwacc[k][3]};
+      *(f32x4*)(o + 4) = f32x4{dwacc[k][4], dwacc[k][5], dwacc[k][6], dwacc[k][7]};
+    }
+  }
+}
+
+// MUSE_FFN_MID_WIDE: bit 0 = forward, bit 1 = backward.  Measured on MI355X (config B, 24 layers): forward 2.24 -> 1.98 ms per
+// step; backward 4.45 -> 4.42 ms (199 VGPRs: two waves per SIMD eat what the wider accesses give) - default: forward only.
+static bool ffn_mid_wide_ok(int32_t dtype, int32_t inter, int bit) {
+  static const int on = []() { const char* e = getenv("MUSE_FFN_MID_WIDE"); return e ? atoi(e) : 1; }();
+  return ((on >> bit) & 1) && dtype == MUSE_BF16 && inter % 1024 == 0 && inter <= 4096;
+}
+
 extern "C" int muse_ffn_mid_rows_per_block(void) { return FFN_ROWS; }
 
 extern "C" int muse_ffn_mid_fwd(const void* ab, const float* w, void* h, void* hm, float* mean, float* rstd, int32_t dtype,
@@ -337,6 +498,13 @@ extern "C" int muse_ffn_mid_fwd(const void* ab, const float* w, void* h, void* h
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((rows + FFN_ROWS - 1) / FFN_ROWS);
   const int nv = (inter + 1023) / 1024;
+  if (ffn_mid_wide_ok(dtype, inter, 0) && !((((uintptr_t)ab) | ((uintptr_t)h) | ((uintptr_t)hm) | ((uintptr_t)w)) & 15)) {
+    const dim3 g2((grid.x + 1) / 2);
+#define FF2(NK) hipLaunchKernelGGL((ffn_mid_fwd2_kernel<NK>), g2, dim3(256), 0, s, (const bf16_t*)ab, w, (bf16_t*)h, (bf16_t*)hm, mean, rstd, rows, eps)
+    if (nv == 1) FF2(1); else if (nv == 2) FF2(2); else if (nv == 3) FF2(3); else FF2(4);
+#undef FF2
+    return (int)hipGetLastError();
+  }
 #define FF(T, NV) hipLaunchKernelGGL((ffn_mid_fwd_kernel<T, NV>), grid, dim3(256), 0, s, (const T*)ab, w, (T*)h, (T*)hm, mean, rstd, rows, inter, eps)
   if (dtype == MUSE_F32) { if (nv == 1) FF(float, 1); else if (nv == 2) FF(float, 2); else if (nv == 3) FF(float, 3); else FF(float, 4); }
   else { if (nv == 1) FF(bf16_t, 1); else if (nv == 2) FF(bf16_t, 2); else if (nv == 3) FF(bf16_t, 3); else FF(bf16_t, 4); }
@@ -352,6 +520,13 @@ extern "C" int muse_ffn_mid_bwd(const void* dhm, const void* h, const void* ab, 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((rows + FFN_ROWS - 1) / FFN_ROWS);
   const int nv = (inter + 1023) / 1024;
+  if (ffn_mid_wide_ok(dtype, inter, 1) && !((((uintptr_t)dhm) | ((uintptr_t)h) | ((uintptr_t)ab) | ((uintptr_t)dab) | ((uintptr_t)w) | ((uintptr_t)dw_partial)) & 15)) {
+    const dim3 g2((grid.x + 1) / 2);
+#define FB2(NK) hipLaunchKernelGGL((ffn_mid_bwd2_kernel<NK>), g2, dim3(256), 0, s, (const bf16_t*)dhm, (const bf16_t*)h, (const bf16_t*)ab, w, mean, rstd, (bf16_t*)dab, dw_partial, rows)
+    if (nv == 1) FB2(1); else if (nv == 2) FB2(2); else if (nv == 3) FB2(3); else FB2(4);
+#undef FB2
+    return (int)hipGetLastError();
+  }
 #define FB(T, NV) hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, NV>), grid, dim3(256), 0, s, (const T*)dhm, (const T*)h, (const T*)ab, w, mean, rstd, (T*)dab, dw_partial, rows, inter)
   if (dtype == MUSE_F32) { if (nv == 1) FB(float, 1); else if (nv == 2) FB(float, 2); else if (nv == 3) FB(float, 3); else FB(float, 4); }
   else { if (nv == 1) FB(bf16_t, 1); else if (nv == 2) FB(bf16_t, 2); else if (nv == 3) FB(bf16_t, 3); else FB(bf16_t, 4); }
@@ -797,6 +972,64 @@ extern "C" int muse_adamw_flat(float* p, const float* g, float* m, float* v, voi
   const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
                      (long)n, lr, beta1, beta2, eps, decay, omb1, omb2, step_size, bc2_sqrt, grad_scale);
+  return (int)hipGetLastError();
+}
+
+// Multi-tensor form: ONE launch over a device-side table of tensors (models whose parameters are ordinary tensors, not views of
+// a flat buffer: MaskGiTUViT has ~500, and 500 launches of 9 us each were 4 % of its step).  The table is 6 x int64 per tensor:
+// {p, g, m, v, p_bf16 or 0, n}; `chunk_first[t]` = index of tensor t's first 4096-element chunk (exclusive prefix sum, nt + 1
+// entries); block b owns chunk b: binary search -> (tensor, offset).  Same arithmetic, same order, as adamw_kernel.
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const long* __restrict__ table, const int* __restrict__ chunk_first, int nt,
+                                                          float b2, float eps, float decay, float omb1, float omb2,
+                                                          float step_size, float bc2_sqrt, float gscale) {
+  int lo = 0, hi = nt;                    // largest t with chunk_first[t] <= blockIdx.x
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const long* e = table + (long)lo * 6;
+  float* p = (float*)e[0]; const float* g = (const float*)e[1]; float* m = (float*)e[2]; float* v = (float*)e[3];
+  bf16_t* pb = (bf16_t*)e[4];
+  const long n = e[5], base = (long)((int)blockIdx.x - chunk_first[lo]) * 4096;
+  const long end = base + 4096 < n ? base + 4096 : n;
+  const bool vec = !((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) && !(((uintptr_t)pb) & 7);
+  if (vec) {
+    for (long i = base + threadIdx.x * 4; i + 3 < end; i += 1024) {
+      float pp[4], gg[4], mm[4], vv[4];
+      V4<float>::load(p + i, pp); V4<float>::load(g + i, gg); V4<float>::load(m + i, mm); V4<float>::load(v + i, vv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gr = gg[j] * gscale;
+        pp[j] = pp[j] * decay;
+        mm[j] = fmaf(omb1, gr - mm[j], mm[j]);
+        vv[j] = fmaf(omb2, gr * gr, vv[j] * b2);
+        const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+        pp[j] = pp[j] - step_size * (mm[j] / denom);
+      }
+      V4<float>::store(p + i, pp); V4<float>::store(m + i, mm); V4<float>::store(v + i, vv);
+      if (pb) V4<bf16_t>::store(pb + i, pp);
+    }
+  }
+  // scalar: the whole chunk when a pointer is unaligned, else the (n % 4) tail of the tensor's last chunk
+  const long s0 = vec ? base + ((end - base) & ~3L) : base;
+  for (long i = s0 + threadIdx.x; i < end; i += 256) {
+    const float gr = g[i] * gscale;
+    float pp = p[i] * decay;
+    const float mm = fmaf(omb1, gr - m[i], m[i]);
+    const float vv = fmaf(omb2, gr * gr, v[i] * b2);
+    pp = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (pb) pb[i] = f32_to_bf16(pp);
+  }
+}
+extern "C" int muse_adamw_multi(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+  if (num_tensors <= 0 || num_chunks <= 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(num_chunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, chunk_first, num_tensors,
+                     beta2, eps, decay, omb1, omb2, step_size, bc2_sqrt, grad_scale);
   return (int)hipGetLastError();
 }
 

@@ -13,6 +13,7 @@ Everything computes through libmuse_hip.so on channels-last rows ``[B * S, C]``:
 from __future__ import annotations
 
 import math
+import os
 from typing import Tuple
 
 import numpy as np
@@ -213,6 +214,8 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         self.up_blocks = nn.ModuleList([_Block(C, H, c.num_res_blocks)])
         self.mlm_layer = _Mlm(C, cin, c.codebook_size)
         self.compute_dtype = torch.float32
+        self.wgrad_stream = os.environ.get("MUSE_WGRAD_STREAM", "1") != "0"   # bf16 mode: weight-gradient GEMMs on a second HIP stream
+        self._side_stream = None
         self._init_weights()
 
     def _init_weights(self):
@@ -315,9 +318,26 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         return out
 
     def _mm_dw(self, dy, x, shape2, M=None, lda=None):
-        """dy^T x -> f32 [N, K]"""
-        dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
-        ops.linear_wgrad(self._c(dy), self._c(x), dw, False, M=M, lda=lda)
+        """dy^T x -> f32 [N, K].  bf16 mode: on a second HIP stream (weight gradients are leaves of the backward graph: the
+        split-K GEMM and its slice reduction fill CUs the dX / attention / norm chain leaves idle); _run_backward joins the
+        stream before it hands the gradients to autograd."""
+        dyc, xc = self._c(dy), self._c(x)
+        if not (self.wgrad_stream and self.compute_dtype == torch.bfloat16 and x.is_cuda):
+            dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
+            ops.linear_wgrad(dyc, xc, dw, False, M=M, lda=lda)
+            return dw
+        main = torch.cuda.current_stream(x.device)
+        if self._side_stream is None or self._side_stream.device != x.device:
+            self._side_stream = torch.cuda.Stream(device=x.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
+            ops.linear_wgrad(dyc, xc, dw, False, M=M, lda=lda)
+        dyc.record_stream(side)
+        xc.record_stream(side)
+        dw.record_stream(main)
+        self.__dict__["_side_busy"] = True
         return dw
 
     def _lin(self, x, mod, residual=None):
@@ -406,9 +426,7 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         dev = dy.device
         dyb = ops.cast_to_bf16(dy.contiguous())
         wo = self._wb(att.out)
-        gw = torch.empty(att.out.weight.shape, dtype=torch.float32, device=dev)
-        ops.linear_wgrad(dyb, sv["o"], gw, False)
-        G[name + ".out.weight"] = gw
+        G[name + ".out.weight"] = self._mm_dw(dyb, sv["o"], att.out.weight.shape)
         do = ops.linear_dgrad(dyb, wo)                                                     # bf16 [B*Sq, C]
         q, qkv = sv["q"], sv["qkv"]
         if sv["self_attn"]:
@@ -418,8 +436,7 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd_ex(q, k, v, sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq],
                                  dv=dqkv[:, 2 * Cq:])
-            gqkv = torch.empty((3 * Cq, Cq), dtype=torch.float32, device=dev)
-            ops.linear_wgrad(dqkv, sv["xb"], gqkv, False)
+            gqkv = self._mm_dw(dqkv, sv["xb"], (3 * Cq, Cq))
             G[name + ".query.weight"], G[name + ".key.weight"], G[name + ".value.weight"] = gqkv[:Cq], gqkv[Cq:2 * Cq], gqkv[2 * Cq:]
             dx = torch.empty((B * Sq, Cq), dtype=torch.float32, device=dev)
             ops.linear_dgrad(dqkv, self._wb(att.query, att.key, att.value), out=dx)      # d(x) through q, k and v in one GEMM
@@ -428,12 +445,9 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(qkv)
         ops.attention_bwd_ex(q, k, v, sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:])
-        gq = torch.empty(att.query.weight.shape, dtype=torch.float32, device=dev)
-        ops.linear_wgrad(dq, sv["xb"], gq, False)
-        G[name + ".query.weight"] = gq
+        G[name + ".query.weight"] = self._mm_dw(dq, sv["xb"], att.query.weight.shape)
         Ck = att.key.weight.shape[1]
-        gkv = torch.empty((2 * Cq, Ck), dtype=torch.float32, device=dev)
-        ops.linear_wgrad(dkv, sv["cb"], gkv, False)
+        gkv = self._mm_dw(dkv, sv["cb"], (2 * Cq, Ck))
         G[name + ".key.weight"], G[name + ".value.weight"] = gkv[:Cq], gkv[Cq:]
         dx = torch.empty((B * Sq, Cq), dtype=torch.float32, device=dev)
         ops.linear_dgrad(dq, self._wb(att.query), out=dx)
@@ -557,7 +571,12 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             n3, res3 = self._norm(a2, lyr.ffn.pre_mlp_layer_norm, mode=1, residual=res2, want_pre=True)   # LayerNorm (:928)
             m3, a3s = self._adaln(n3, lyr.ffn.adaLN_modulation, scond, B)
             w01 = self._w2(lyr.ffn.wi_0, lyr.ffn.wi_1)
-            ab = self._mm(m3, w01)
+            if self.compute_dtype == torch.bfloat16:
+                # the reference's autocast regime: the GLU input and output live in bf16 between the two GEMMs (no f32 round trip,
+                # no separate cast of the wo operand)
+                ab = ops.linear(self._c(m3), w01, out_dtype=torch.bfloat16)
+            else:
+                ab = self._mm(m3, w01)
             gl = ops.glu_fwd(ab)
             t = self._lin(gl, lyr.ffn.wo)
             T["layers"].append(dict(res1=res1, res2=res2, res3=res3, a1s=a1s, a2s=a2s, a3s=a3s, s1=s1, s2=s2, m3=m3, w01=w01, ab=ab,
@@ -635,7 +654,12 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             lyr, sv = self.transformer_layers[li], T["layers"][li]
             nm = f"transformer_layers.{li}"
             # feed-forward
-            dgl = self._lin_bwd(dt, sv["gl"], lyr.ffn.wo, nm + ".ffn.wo", G)
+            if self.compute_dtype == torch.bfloat16:   # bf16 GLU gradient chain (mirrors the forward)
+                wo2, dtb = self._w2(lyr.ffn.wo), self._c(dt)
+                G[nm + ".ffn.wo.weight"] = self._mm_dw(dtb, sv["gl"], wo2.shape).view(lyr.ffn.wo.weight.shape)
+                dgl = ops.linear_dgrad(dtb, wo2)
+            else:
+                dgl = self._lin_bwd(dt, sv["gl"], lyr.ffn.wo, nm + ".ffn.wo", G)
             dab = ops.glu_bwd(sv["ab"], dgl)
             gw01 = self._mm_dw(dab, sv["m3"], sv["w01"].shape)
             I = gw01.shape[0] // 2
@@ -680,6 +704,8 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             denc.add_(ops.silu_bwd(T["enc"], dsenc))
         denc0 = self._norm_bwd(denc, T["enc0"], self.encoder_proj_layer_norm, "encoder_proj_layer_norm", G)
         self._lin_bwd(denc0, T["enc_in"], self.encoder_proj, "encoder_proj", G, need_dx=False)
+        if self.__dict__.pop("_side_busy", False):
+            torch.cuda.current_stream(dev).wait_stream(self._side_stream)   # every weight gradient is complete before autograd sees it
         return G
 
     def forward(self, input_ids, encoder_hidden_states, cond_embeds, micro_conds, labels=None, label_smoothing=0.0,

@@ -479,6 +479,13 @@ def adamw_flat(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, gr
     _prof_end(e0, "adamw", 28.0 * p.numel() + (2.0 * p.numel() if p_bf16 is not None else 0.0), "byte")
 
 
+def adamw_multi(table, chunk_first, num_tensors, num_chunks, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """one AdamW launch over a device-side table of tensors (muse_adamw_multi; training.FusedAdamW builds the table)"""
+    require_gpu(table, chunk_first)
+    check(lib().muse_adamw_multi(table.data_ptr(), chunk_first.data_ptr(), int(num_tensors), int(num_chunks), lr, beta1, beta2, eps,
+                                 weight_decay, step, grad_scale, stream()), "muse_adamw_multi")
+
+
 def cast_to_bf16(src, dst=None):
     require_gpu(src)
     if dst is None:

@@ -141,6 +141,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                    "(all of them, in order); for a subset use torch.optim.AdamW")
         self._m = self._v = None
         self._step = 0
+        self._table = self._chunk_first = self._table_key = self._stage = None   # per-tensor mode: device table of muse_adamw_multi
         self.grad_scale = 1.0   # multiplied into the gradient inside the kernel (GradReducer sets 1/world for SUM reductions)
 
     def _flat_grad_checked(self, model, params):
@@ -195,7 +196,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise MuseHipError("FusedAdamW: optimizer state does not match the model's flat parameter buffer")
 
     def _step_per_tensor(self, grp, loss):
-        """parameters that are ordinary (contiguous f32) tensors: muse_adamw_flat once per tensor.  torch.optim.AdamW
+        """parameters that are ordinary (contiguous f32) tensors: one muse_adamw_multi launch over all of them.  torch.optim.AdamW
         semantics: a parameter without a gradient is skipped and keeps its own state; the step count is shared (all
         parameters of these models receive a gradient every step)."""
         params = [p for p in grp["params"] if p.grad is not None]
@@ -204,6 +205,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._m is None:
             self._m, self._v = {}, {}
         self._step += 1
+        rows = []
         for p in params:
             if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                 raise MuseHipError("FusedAdamW: parameters and gradients must be contiguous float32 tensors")
@@ -216,8 +218,38 @@ class FusedAdamW(torch.optim.Optimizer):
             shadow = getattr(p, "_muse_shadow", None)   # the model's cached bf16 compute copy of this weight (MaskGiTUViT bf16 mode)
             if shadow is not None and (shadow.numel() != p.numel() or shadow.device != p.device or not shadow.is_contiguous()):
                 shadow = None
-            ops.adamw_flat(p.data, p.grad, self._m[k], self._v[k], shadow, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
-                           grp["eps"], grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
+            rows.append((p.data.data_ptr(), p.grad.data_ptr(), self._m[k].data_ptr(), self._v[k].data_ptr(),
+                         shadow.data_ptr() if shadow is not None else 0, p.numel()))
+        # one launch for all tensors.  Gradients are fresh allocations every step, so the pointer table is rebuilt every step: ~500
+        # rows staged through two alternating PINNED host buffers and copied asynchronously (a pageable copy would make the host
+        # wait for the stream and lose its run-ahead into the next step)
+        dev = params[0].device
+        key = tuple(rows)
+        if self._table_key != key:
+            nt = len(rows)
+            if self._table is None or self._table.shape[0] < nt or self._table.device != dev:
+                self._table = torch.empty((nt, 6), dtype=torch.int64, device=dev)
+                self._chunk_first = torch.empty(nt + 1, dtype=torch.int32, device=dev)
+                self._stage = [(torch.empty((nt, 6), dtype=torch.int64).pin_memory(), torch.empty(nt + 1, dtype=torch.int32).pin_memory(),
+                                torch.cuda.Event()) for _ in range(2)]
+                self._stage_i = 0
+            ht, hf, ev = self._stage[self._stage_i]
+            self._stage_i ^= 1
+            ev.synchronize()      # the copy issued from this staging buffer two rebuilds ago has run
+            nchunks = 0
+            first = [0] * (nt + 1)
+            for i, r in enumerate(rows):
+                first[i] = nchunks
+                nchunks += (r[5] + 4095) // 4096
+            first[nt] = nchunks
+            ht[:nt].copy_(torch.tensor(rows, dtype=torch.int64))
+            hf[:nt + 1].copy_(torch.tensor(first, dtype=torch.int32))
+            self._table[:nt].copy_(ht[:nt], non_blocking=True)
+            self._chunk_first[:nt + 1].copy_(hf[:nt + 1], non_blocking=True)
+            ev.record(torch.cuda.current_stream(dev))
+            self._table_key, self._nchunks = key, nchunks
+        ops.adamw_multi(self._table, self._chunk_first, len(rows), self._nchunks, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
+                        grp["eps"], grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
         return loss
 
     # ---- checkpointing in torch.optim.AdamW's layout ----------------------------------------------------------------

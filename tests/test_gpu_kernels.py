@@ -688,7 +688,7 @@ def test_gemm_256_matches_128_on_model_shapes(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,inter", [(37, 64), (130, 3072), (50, 160), (20, 2048)])
+@pytest.mark.parametrize("rows,inter", [(37, 64), (130, 3072), (50, 160), (20, 2048), (7, 1024), (33, 4096)])
 def test_ffn_mid_fused(dtype, rows, inter):
     """fused GLU + mid-LayerNorm forward/backward vs F.gelu(a)*b -> F.layer_norm in f64"""
     ops = _ops()
