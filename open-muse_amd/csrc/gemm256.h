@@ -91,6 +91,12 @@ struct Dma {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + LDS_OFF + (wave * 4 + j) * 1024), 16, (int)vo, (int)soff, 0, 0);
     }
   }
+  // piece J alone (a tile at or beyond kend is all out-of-range chunks: zeros, no memory traffic)
+  template <int LDS_OFF, int J>
+  __device__ __forceinline__ void issue1(unsigned char* smem, int kt, int wave) const {
+    const unsigned vo = ((unsigned)kt * 64u + kk(J)) < (unsigned)kend ? voff[J] : oob;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + LDS_OFF + (wave * 4 + J) * 1024), 16, (int)vo, (int)((unsigned)kt * kstep), 0, 0);
+  }
 };
 
 // ---- LDS -> MFMA fragments of one operand: NF fragments of 16 rows; lane supplies row (lane & 15), k = 8 * (lane >> 4) .. +7 ---
@@ -145,7 +151,7 @@ struct Frags {
 //   s_barrier                  ... and so have everyone's
 //   DMA tile t+2 -> this stage; fragment reads of tile t+1 begin, under the last DIST groups of MFMAs of tile t.
 // LDS reads return in order, so "fragment a(g) has arrived" == at most (reads issued after it) outstanding: waitN(g).
-template <int AL, int BL>
+template <int AL, int BL, bool SPREAD = false>
 struct Pipe {
   static constexpr int RA = AL ? 2 : 1, RB = BL ? 2 : 1, NB = NI * RB;
   static constexpr int NSLOT = 4, DIST = NSLOT - 1;
@@ -172,12 +178,26 @@ struct Pipe {
     constexpr int st = GA < 16 ? S : (S ^ 1), g = GA & 15;
     fa.template read<st, (g >> 3), (g & 7)>(ring[GA & (NSLOT - 1)]);
   }
+  // SPREAD: the 8 DMA pieces of a tile are not issued in one burst behind the barrier but one per MFMA group - pieces 0..2 of tile
+  // t+2 in groups 13..15 of tile t (its stage is free from the barrier on), pieces 3..7 in groups 0..4 of tile t+1.  A burst of 8
+  // pieces costs each wave ~150 cycles of issue per piece with both waves of the SIMD doing the same thing at the same time
+  // (MI355X_MICROARCH.md: "LDS-DMA piece issue cost"); a single piece among MFMAs costs ~60 and the partner wave's MFMAs run under it.
+  template <int STAGE, int Q>
+  __device__ __forceinline__ void issue_piece(int kt) {
+    if constexpr (Q < 4) da.template issue1<A_BASE + STAGE * TILE, Q>(smem, kt, wave);
+    else db.template issue1<B_BASE + STAGE * TILE, Q - 4>(smem, kt, wave);
+  }
   __device__ __forceinline__ void prologue(int kt0) {
     da.template issue<A_BASE>(smem, kt0, wave);
     db.template issue<B_BASE>(smem, kt0, wave);
-    da.template issue<A_BASE + TILE>(smem, kt0 + 1, wave);
-    db.template issue<B_BASE + TILE>(smem, kt0 + 1, wave);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (SPREAD) {   // pieces 3..7 of the second tile follow in groups 0..4 of the first
+      issue_piece<1, 0>(kt0 + 1); issue_piece<1, 1>(kt0 + 1); issue_piece<1, 2>(kt0 + 1);
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      da.template issue<A_BASE + TILE>(smem, kt0 + 1, wave);
+      db.template issue<B_BASE + TILE>(smem, kt0 + 1, wave);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     fb.template read_range<0, 0, 0, NI>(bk[0]);
@@ -194,13 +214,21 @@ struct Pipe {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
 #ifndef G256_ABLATE_NO_DMA
-      if (kt + 2 < kt_last) {
-        da.template issue<A_BASE + S * TILE>(smem, kt + 2, wave);
-        db.template issue<B_BASE + S * TILE>(smem, kt + 2, wave);
+      if constexpr (!SPREAD) {
+        if (kt + 2 < kt_last) {
+          da.template issue<A_BASE + S * TILE>(smem, kt + 2, wave);
+          db.template issue<B_BASE + S * TILE>(smem, kt + 2, wave);
+        }
       }
 #endif
       fb.template read_range<S ^ 1, 0, 0, NI>(bk[0]);  // (after the last tile: a stale stage, never used)
     }
+#ifndef G256_ABLATE_NO_DMA
+    if constexpr (SPREAD) {   // (tiles at or beyond kend are zero-fill pieces: the piece count per tile stays uniform for the waits)
+      if constexpr (G >= GBAR) issue_piece<S, G - GBAR>(kt + 2);
+      else if constexpr (G < 8 - (16 - GBAR)) issue_piece<S ^ 1, G + (16 - GBAR)>(kt + 1);
+    }
+#endif
     if constexpr (G == GB1) fb.template read_range<S, 1, 0, NI>(bk[1]);
     read_a<S, G + DIST>();
     wait_lgkm<waitN(G)>();
@@ -386,7 +414,7 @@ struct Pipe32 {
   }
 };
 
-template <typename TC, int AL, int BL, int BKV>
+template <typename TC, int AL, int BL, int BKV, bool SPREAD = false>
 __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -417,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = (wave >> 2) * 128, wc = (wave & 3) * 64;
 
-  using PipeT = std::conditional_t<BKV == 64, Pipe<AL, BL>, Pipe32<AL, BL>>;
+  using PipeT = std::conditional_t<BKV == 64, Pipe<AL, BL, SPREAD>, Pipe32<AL, BL>>;
   PipeT pp;
   pp.smem = smem; pp.wave = wave;
   pp.da.init(Ap, p.lda, p.M, p.K, kend, m0, wave, lane);
@@ -443,6 +471,10 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
       pp.template group<1, 0>(kt + 1, kt_last);
     }
     wait_lgkm<0>();  // the trailing (unused) fragment reads must not land in registers the epilogue reuses
+    if constexpr (SPREAD) {   // ... nor the trailing zero-fill DMA pieces in the LDS bytes the epilogue stages C in
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
   } else {
     for (int kt = kt0; kt < kt_last; kt += 2) {
       pp.template group<0, 0>();
@@ -572,11 +604,11 @@ static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int ba
   return cost256 < cost128;
 }
 
-template <typename TC, int AL, int BL, int BKV>
+template <typename TC, int AL, int BL, int BKV, bool SPREAD = false>
 static inline int launch_gemm256_lb(const GemmParams& p, int batch, hipStream_t stream) {
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
   constexpr int lds = BKV == 64 ? g256::LDS_BYTES : g256::LDS_BYTES32;
-  auto kern = g256::kernel<TC, AL, BL, BKV>;
+  auto kern = g256::kernel<TC, AL, BL, BKV, SPREAD>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -591,7 +623,11 @@ static inline int launch_gemm256_lb(const GemmParams& p, int batch, hipStream_t 
 template <typename TC, int AL, int BL>
 static inline int launch_gemm256_l(const GemmParams& p, int batch, hipStream_t stream) {
   const char* e = getenv("MUSE_G256_BK");
-  return (e && e[0] == '3') ? launch_gemm256_lb<TC, AL, BL, 32>(p, batch, stream) : launch_gemm256_lb<TC, AL, BL, 64>(p, batch, stream);
+  if (e && e[0] == '3') return launch_gemm256_lb<TC, AL, BL, 32>(p, batch, stream);
+  // MUSE_G256_SPREAD (default 1): the DMA pieces of a K-tile issued one per MFMA group instead of as a burst behind the barrier
+  // (Pipe::SPREAD).  MI355X, [16448x768]x[6144x768]^T and its dX / dW: 874 -> 920, 873 -> 970, 869 -> 955 TFLOP/s; bit-identical.
+  static const int spread = []() { const char* s = getenv("MUSE_G256_SPREAD"); return s ? atoi(s) : 1; }();
+  return spread ? launch_gemm256_lb<TC, AL, BL, 64, true>(p, batch, stream) : launch_gemm256_lb<TC, AL, BL, 64>(p, batch, stream);
 }
 template <typename TC>
 static inline int launch_gemm256(const GemmParams& p, int la, int lb, int batch, hipStream_t stream) {
