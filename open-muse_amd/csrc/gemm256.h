@@ -489,40 +489,85 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   // lane holds C[m][n..n+3], m = m0 + wr + 16 i + (lane & 15), n = n0 + wc + 16 j + 4 (lane >> 4)
   // (kept small on purpose: 128 accumulator registers per lane make every per-element branch 128 copies of code, and a
   //  one-block-per-CU kernel cannot hide an instruction-cache-missing epilogue behind another block)
+  // Loads and stores share the in-order vmcnt queue, so any load consumed after a store waits for that store's acknowledgement,
+  // and __syncthreads() is a global-memory fence (vmcnt(0)) as well.  Hence: (1) everything that has to be READ - bias, row
+  // vector and, for f32 outputs, the residual and the old C of an accumulating product - is folded into the accumulators in
+  // fragment layout BEFORE the first store; (2) the staging passes synchronise with LDS-only barriers.  (A bf16 residual /
+  // accumulate keeps its loads in the store loop: 8-byte fragment accesses would waste half of every request.)
   constexpr int EPC = 16 / (int)sizeof(TC);
   constexpr int CST = BN * (int)sizeof(TC) + 16;          // 528 (bf16) / 1040 (f32) bytes per staged row
   constexpr int RPP = sizeof(TC) == 2 ? 128 : 64;         // 67.6 KB / 66.6 KB per pass
   constexpr int NPASS = BM / RPP, PPW = 128 / RPP, IPP = MI / PPW;  // passes, passes per wave row, fragment rows per pass
   constexpr int CPRo = BN / EPC;
   const TC* Rq = (const TC*)p.residual;
-  float bias_v[NI][4];
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    float bias_v[NI][4];
 #pragma unroll
-  for (int j = 0; j < NI; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wc + j * 16 + 4 * (lane >> 4) + r;
-      bias_v[j][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wc + j * 16 + 4 * (lane >> 4) + r;
+        bias_v[j][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wr + i * 16 + (lane & 15);
+      const float rv = (p.rowvec && m < p.M) ? p.rowvec[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = p.alpha * acc[i][j][r] + (rv + bias_v[j][r]);
     }
+  }
+  bool late_add = (Rq != nullptr) || p.accumulate;   // residual / old C still to be added in the store loop
+  if constexpr (sizeof(TC) == 4) {
+    if (late_add) {
+      // one fragment row (NI x 16 bytes per lane) in flight ahead of the one being added
+      const int nf = n0 + wc + 4 * (lane >> 4);
+      auto load_row = [&](int i, f32x4 (&dst)[NI], const float* src, long ld) {
+        const int m = m0 + wr + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          dst[j] = (m < p.M && (nf + j * 16) < p.N) ? *(const f32x4*)(src + (long)m * ld + nf + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      };
+      auto add_all = [&](const float* src, long ld) {
+        f32x4 rr[2][NI];
+        load_row(0, rr[0], src, ld);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (i + 1 < MI) load_row(i + 1, rr[(i + 1) & 1], src, ld);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] += rr[i & 1][j];
+        }
+      };
+      if (Rq) add_all((const float*)Rq, p.ldr);
+      if (p.accumulate) add_all((const float*)Cp, p.ldc);
+      late_add = false;
+    }
+  }
+  // every load so far has been consumed (the compiler waited for it at its use): from here on the f32 path only stores
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
-    __syncthreads();
+    lds_barrier();
     if ((wave >> 2) == pass / PPW) {
 #pragma unroll
       for (int ii = 0; ii < IPP; ++ii) {
         const int i = (pass % PPW) * IPP + ii;
         const int ml = wr + i * 16 + (lane & 15);
-        const float rv = (p.rowvec && (m0 + ml) < p.M) ? p.rowvec[m0 + ml] : 0.f;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int nl = wc + j * 16 + 4 * (lane >> 4);
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r] + (rv + bias_v[j][r]);
+          const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
           OutVec<TC>::store4((TC*)(smem + (ml - pass * RPP) * CST) + nl, v);
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int it = 0; it < (RPP * CPRo) / NT; ++it) {
       const int c = threadIdx.x + NT * it;
@@ -530,31 +575,18 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
       const int m = m0 + pass * RPP + row, n = n0 + col;
       if (m < p.M && n < p.N) {
         u32x4 w = *(const u32x4*)(smem + row * CST + col * (int)sizeof(TC));
-        if (Rq || p.accumulate) {
-          float o[EPC];
-          if constexpr (sizeof(TC) == 4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = __uint_as_float(w[e]);
-          } else {
+        if constexpr (sizeof(TC) == 2) {
+          if (late_add) {
+            float o[EPC];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
-          }
-          auto add16 = [&](const TC* src) {
-            const u32x4 t = *(const u32x4*)src;
-            if constexpr (sizeof(TC) == 4) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] += __uint_as_float(t[e]);
-            } else {
+            auto add16 = [&](const TC* src) {
+              const u32x4 t = *(const u32x4*)src;
 #pragma unroll
               for (int e = 0; e < 4; ++e) { o[2 * e] += __uint_as_float(t[e] << 16); o[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
-            }
-          };
-          if (Rq) add16(Rq + (long)m * p.ldr + n);
-          if (p.accumulate) add16(Cp + (long)m * p.ldc + n);
-          if constexpr (sizeof(TC) == 4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(o[e]);
-          } else {
+            };
+            if (Rq) add16(Rq + (long)m * p.ldr + n);
+            if (p.accumulate) add16(Cp + (long)m * p.ldc + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = pack2_bf16(o[2 * e], o[2 * e + 1]);
           }
