@@ -48,7 +48,7 @@ GF_FWD = {"A": 19.00, "B": 122.40}
 GF_UVIT_FWD = {256: 275.10, 1024: 1137.05}
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
 # rocprof kernel name fragment of each instrumented kernel family (to look its counters up in TRAFFIC_JSON)
-KERNEL_OF = {"conv_bf16x3_dma": "cdma::conv_dma_kernel", "gemm_bf16_NN": "g256::kernel<unsigned short, 0, 0", "gemm_bf16_NT": "g256::kernel<unsigned short, 0, 1",
+KERNEL_OF = {"conv_bf16x3_dma": "cslab::conv_slab_kernel", "gemm_bf16_NN": "g256::kernel<unsigned short, 0, 0", "gemm_bf16_NT": "g256::kernel<unsigned short, 0, 1",
              "gemm_bf16_TT": "g256::kernel<float, 1, 1", "conv_bf16x3": "conv_split_kernel", "attn_fwd_bf16": "attn_fwd_kernel"}
 
 

@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; O=gpurun_out; mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prefetch > $O/pmc_$c.log 2>&1
   echo "$c exit $?"
 done
 f=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)

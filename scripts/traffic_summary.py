@@ -22,7 +22,7 @@ for k in fetch:
         out[k[:120]] = {"launches_sampled": fetch[k][1], "fetch_size_KiB_per_launch": round(f, 1), "write_size_KiB_per_launch": round(w, 1),
                         "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
 top = dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:40])
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra`; "
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prefetch`; "
                    "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, averaged over all launches of the kernel in the run (scripts/gpu_traffic_bench.sh)",
            "kernels": top}, open(sys.argv[3], "w"), indent=1)
 for k, v in list(top.items())[:12]:
