@@ -299,6 +299,9 @@ int muse_probe_tr16(const int32_t* addr, int32_t* out, void* stream);
 int muse_norm_res_fwd(const float* x, const float* res, const float* w, float* y, float* pre, int64_t rows, int32_t cols,
                       float eps, int32_t mode, void* stream);
 int muse_adaln_fwd(const float* x, const float* ss, float* y, int32_t batch, int64_t rows_per_batch, int32_t C, void* stream);
+/* ... with the f32 result and / or its bf16 copy (the next GEMM's operand in the bf16 compute mode); either pointer may be null */
+int muse_adaln_fwd_ex(const float* x, const float* ss, float* y, void* y_bf16, int32_t batch, int64_t rows_per_batch, int32_t C,
+                      void* stream);
 int muse_silu_fwd(const float* x, float* y, int64_t n, void* stream);
 int muse_dwconv3x3_nhwc(const float* x, const float* w, float* y, int32_t batch, int32_t H, int32_t W, int32_t C, void* stream);
 int muse_grn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* scratch, int32_t batch, int64_t S,
@@ -313,6 +316,9 @@ int muse_weighted_mean(const float* v, const float* w, float* out, int64_t n, vo
 int muse_norm_res_bwd_nblk(int64_t rows);
 int muse_norm_res_bwd(const float* dy, const float* dpre, const float* v, const float* w, float* dv, float* dw_partial,
                       int64_t rows, int32_t cols, float eps, int32_t mode, void* stream);
+/* ... also writing a bf16 copy of dv (may be null) */
+int muse_norm_res_bwd_ex(const float* dy, const float* dpre, const float* v, const float* w, float* dv, void* dv_bf16,
+                         float* dw_partial, int64_t rows, int32_t cols, float eps, int32_t mode, void* stream);
 int muse_adaln_bwd(const float* dy, const float* x, const float* ss, float* dx, float* dss, int32_t batch,
                    int64_t rows_per_batch, int32_t C, void* stream);
 int muse_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);

@@ -65,7 +65,7 @@ extern "C" int muse_norm_res_fwd(const float* x, const float* res, const float* 
 // AdaLN modulation (:1025-1037): y[b, r, c] = x[b, r, c] * (1 + ss[b, c]) + ss[b, C + c],  ss = mapper(silu(cond)) [B, 2C]
 // =================================================================================================================
 __global__ __launch_bounds__(256) void adaln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ss,
-                                                        float* __restrict__ y, long rows_per_batch, int C, long n4) {
+                                                        float* __restrict__ y, bf16_t* __restrict__ yb, long rows_per_batch, int C, long n4) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const long e = i * 4, row = e / C;
     const int c = (int)(e - row * C);
@@ -75,16 +75,23 @@ __global__ __launch_bounds__(256) void adaln_fwd_kernel(const float* __restrict_
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = v[j] * (1.0f + sc[j]) + sh[j];
-    *(f32x4*)(y + e) = o;
+    if (y) *(f32x4*)(y + e) = o;
+    if (yb) *(u32x2*)(yb + e) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
   }
 }
-extern "C" int muse_adaln_fwd(const float* x, const float* ss, float* y, int32_t batch, int64_t rows_per_batch, int32_t C, void* stream) {
+// y (f32) and / or y_bf16 (the GEMM operand of the bf16 compute mode, written here instead of by a separate cast) may be null
+extern "C" int muse_adaln_fwd_ex(const float* x, const float* ss, float* y, void* y_bf16, int32_t batch, int64_t rows_per_batch,
+                                 int32_t C, void* stream) {
   if (C % 4) return MUSE_ERR_UNSUPPORTED;
   const long n4 = (long)batch * rows_per_batch * C / 4;
   if (n4 <= 0) return 0;
   long g = (n4 + 255) / 256; if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(adaln_fwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ss, y, (long)rows_per_batch, C, n4);
+  hipLaunchKernelGGL(adaln_fwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ss, y, (bf16_t*)y_bf16,
+                     (long)rows_per_batch, C, n4);
   return (int)hipGetLastError();
+}
+extern "C" int muse_adaln_fwd(const float* x, const float* ss, float* y, int32_t batch, int64_t rows_per_batch, int32_t C, void* stream) {
+  return muse_adaln_fwd_ex(x, ss, y, nullptr, batch, rows_per_batch, C, stream);
 }
 
 __global__ __launch_bounds__(256) void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
@@ -248,8 +255,8 @@ extern "C" int muse_norm_res_bwd_nblk(int64_t rows) { return (int)((rows + NRB_R
 template <int NIT>
 __global__ __launch_bounds__(256) void norm_res_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dpre,
                                                            const float* __restrict__ v, const float* __restrict__ w,
-                                                           float* __restrict__ dv, float* __restrict__ dwp, long rows, int cols,
-                                                           float eps, int mode) {
+                                                           float* __restrict__ dv, bf16_t* __restrict__ dvb, float* __restrict__ dwp,
+                                                           long rows, int cols, float eps, int mode) {
   __shared__ float red[4096];   // cols <= 4096
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dwacc[NIT][4];          // a wave covers 256 columns per step: NIT = ceil(cols / 256) rounded up to a power of two
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(256) void norm_res_bwd_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) o[j] = rstd * (g[j] - mg - (t[j] - mean) * rstd * mgx);
         if (dpre) o += *(const f32x4*)(dpre + row * cols + c);
         *(f32x4*)(dv + row * cols + c) = o;
+        if (dvb) *(u32x2*)(dvb + row * cols + c) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
       }
     }
   }
@@ -331,16 +339,21 @@ __global__ __launch_bounds__(256) void norm_res_bwd_kernel(const float* __restri
   }
   for (int c = threadIdx.x; c < cols; c += 256) dwp[(long)blockIdx.x * cols + c] = red[c];
 }
-extern "C" int muse_norm_res_bwd(const float* dy, const float* dpre, const float* v, const float* w, float* dv, float* dw_partial,
-                                 int64_t rows, int32_t cols, float eps, int32_t mode, void* stream) {
+// dv_bf16 (optional): a bf16 copy of dv written in the same pass - dv is the next GEMM's operand in the bf16 compute mode
+extern "C" int muse_norm_res_bwd_ex(const float* dy, const float* dpre, const float* v, const float* w, float* dv, void* dv_bf16,
+                                    float* dw_partial, int64_t rows, int32_t cols, float eps, int32_t mode, void* stream) {
   if (cols % 4 || cols > 4096 || (mode != 0 && mode != 1)) return MUSE_ERR_UNSUPPORTED;
   if (rows <= 0) return 0;
   const int nblk = muse_norm_res_bwd_nblk(rows), nit = (cols + 255) / 256;
   hipStream_t s = (hipStream_t)stream;
-#define NRB(N) hipLaunchKernelGGL(norm_res_bwd_kernel<N>, dim3(nblk), dim3(256), 0, s, dy, dpre, v, w, dv, dw_partial, (long)rows, cols, eps, mode)
+#define NRB(N) hipLaunchKernelGGL(norm_res_bwd_kernel<N>, dim3(nblk), dim3(256), 0, s, dy, dpre, v, w, dv, (bf16_t*)dv_bf16, dw_partial, (long)rows, cols, eps, mode)
   if (nit <= 1) NRB(1); else if (nit <= 2) NRB(2); else if (nit <= 4) NRB(4); else if (nit <= 8) NRB(8); else NRB(16);
 #undef NRB
   return (int)hipGetLastError();
+}
+extern "C" int muse_norm_res_bwd(const float* dy, const float* dpre, const float* v, const float* w, float* dv, float* dw_partial,
+                                 int64_t rows, int32_t cols, float eps, int32_t mode, void* stream) {
+  return muse_norm_res_bwd_ex(dy, dpre, v, w, dv, nullptr, dw_partial, rows, cols, eps, mode, stream);
 }
 
 // AdaLN backward: dx = dy (1 + scale[b]);  dss[b, c] = sum_r dy x,  dss[b, C + c] = sum_r dy   (r over the rows of image b)

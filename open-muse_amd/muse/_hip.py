@@ -111,6 +111,7 @@ SIGNATURES = {
     "muse_gather_rows": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_norm_res_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p],
     "muse_adaln_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
+    "muse_adaln_fwd_ex": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_silu_fwd": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_dwconv3x3_nhwc": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "muse_grn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
@@ -118,6 +119,7 @@ SIGNATURES = {
     "muse_weighted_mean": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "muse_norm_res_bwd_nblk": [c_i64],
     "muse_norm_res_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p],
+    "muse_norm_res_bwd_ex": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p],
     "muse_adaln_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_silu_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "muse_dwconv3x3_bwd_nchunk": [c_i64],

@@ -145,6 +145,10 @@ class _Mlm(nn.Module):
         self.conv2 = _Conv(cin, codebook, 1)
 
 
+# MUSE_UVIT_BF16_OPERANDS (experiments): bit 0 = AdaLN writes the bf16 GEMM operand, bit 1 = norm backward writes the bf16 copy of dv
+_BF16_OPERANDS = int(os.environ.get("MUSE_UVIT_BF16_OPERANDS", "3"))
+
+
 class _UViTFn(torch.autograd.Function):
     """one autograd node for the whole network: forward records a tape, backward runs the hand-written reverse pass and hands
     the parameter gradients (state-dict order) back to autograd"""
@@ -354,9 +358,15 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
                                   want_pre=want_pre)
         return y, pre
 
-    def _norm_bwd(self, dy, v, mod, name, G, mode=0, dpre=None):
-        """v = the tensor that was normalised (x + residual); returns d(x) = d(residual)"""
-        dv, dw = ops.norm_res_bwd(dy, v, self._f(mod.weight), float(self.config.layer_norm_eps), mode, dpre=dpre)
+    def _norm_bwd(self, dy, v, mod, name, G, mode=0, dpre=None, gemm_operand=False):
+        """v = the tensor that was normalised (x + residual); returns d(x) = d(residual).
+        gemm_operand (bf16 mode): dv is also the dY of the next weight GEMMs - the kernel writes its bf16 copy in the same pass
+        and _c(dv) finds it instead of launching a cast."""
+        if gemm_operand and self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 2:
+            dv, dw, dvb = ops.norm_res_bwd(dy, v, self._f(mod.weight), float(self.config.layer_norm_eps), mode, dpre=dpre, also_bf16=True)
+            self.__dict__.setdefault("_act_cache", {})[id(dv)] = (dv, dvb)
+        else:
+            dv, dw = ops.norm_res_bwd(dy, v, self._f(mod.weight), float(self.config.layer_norm_eps), mode, dpre=dpre)
         G[name + ".weight"] = dw
         return dv
 
@@ -368,13 +378,13 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         hd = Cq // nh
         if self.compute_dtype == torch.bfloat16 and ops.attention_supported(torch.bfloat16, Sq, hd, Skv):
             alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
-            xb = ops.cast_to_bf16(x.contiguous())
+            xb = self._c(x)                   # (already bf16 when it is an AdaLN output; cached otherwise)
             self_attn = ctx is x
             if self_attn:
                 qkv = ops.linear(xb, self._wb(att.query, att.key, att.value))            # [B*Sq, 3C] bf16
                 q, k, v, cb = qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], xb
             else:
-                cb = ops.cast_to_bf16(ctx.contiguous())
+                cb = self._c(ctx)             # the text states feed every layer: one cast per step
                 q = ops.linear(xb, self._wb(att.query))
                 qkv = ops.linear(cb, self._wb(att.key, att.value))                      # [B*Skv, 2C] bf16
                 k, v = qkv[:, :Cq], qkv[:, Cq:]
@@ -424,7 +434,7 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
     def _attention_bwd_fused(self, dy, sv, att: _Attn, name, G, self_attn):
         B, Sq, Skv, nh, hd, Cq, alpha = sv["dims"]
         dev = dy.device
-        dyb = ops.cast_to_bf16(dy.contiguous())
+        dyb = self._c(dy)
         wo = self._wb(att.out)
         G[name + ".out.weight"] = self._mm_dw(dyb, sv["o"], att.out.weight.shape)
         do = ops.linear_dgrad(dyb, wo)                                                     # bf16 [B*Sq, C]
@@ -457,9 +467,11 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             return dx.add_(dctx), None
         return dx, dctx
 
-    def _adaln(self, x, mod: _AdaLN, scond, B):
+    def _adaln(self, x, mod: _AdaLN, scond, B, gemm_operand=False):
+        """gemm_operand (bf16 mode): the modulated tensor is consumed only as a GEMM operand -> written as bf16 directly"""
         ss = self._lin(scond, mod.mapper)
-        return ops.adaln_fwd(x, ss, B), dict(x=x, ss=ss)
+        od = torch.bfloat16 if (gemm_operand and self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
+        return ops.adaln_fwd(x, ss, B, out_dtype=od), dict(x=x, ss=ss)
 
     def _adaln_bwd(self, dy, sv, mod: _AdaLN, name, G, scond, dscond, B):
         dx, dss = ops.adaln_bwd(dy, sv["x"], sv["ss"], B)
@@ -563,13 +575,13 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
         T["layers"] = []
         for lyr in self.transformer_layers:                                           # TransformerLayer :757-792
             n1, res1 = self._norm(t, lyr.attn_layer_norm, residual=res, want_pre=True)
-            m1, a1s = self._adaln(n1, lyr.self_attn_adaLN_modulation, scond, B)
+            m1, a1s = self._adaln(n1, lyr.self_attn_adaLN_modulation, scond, B, gemm_operand=True)
             a, s1 = self._attention(m1, m1, lyr.attention, B, S, S, nh)
             n2, res2 = self._norm(a, lyr.crossattn_layer_norm, residual=res1, want_pre=True)
-            m2, a2s = self._adaln(n2, lyr.cross_attn_adaLN_modulation, scond, B)
+            m2, a2s = self._adaln(n2, lyr.cross_attn_adaLN_modulation, scond, B, gemm_operand=True)
             a2, s2 = self._attention(m2, enc, lyr.crossattention, B, S, L, nh)
             n3, res3 = self._norm(a2, lyr.ffn.pre_mlp_layer_norm, mode=1, residual=res2, want_pre=True)   # LayerNorm (:928)
-            m3, a3s = self._adaln(n3, lyr.ffn.adaLN_modulation, scond, B)
+            m3, a3s = self._adaln(n3, lyr.ffn.adaLN_modulation, scond, B, gemm_operand=True)
             w01 = self._w2(lyr.ffn.wi_0, lyr.ffn.wi_1)
             if self.compute_dtype == torch.bfloat16:
                 # the reference's autocast regime: the GLU input and output live in bf16 between the two GEMMs (no f32 round trip,
@@ -648,7 +660,7 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             dh = self._res_block_bwd(dh, sr, blk.res_blocks[i], f"up_blocks.0.res_blocks.{i}", G, scond, dscond, B)
         po = T["proj_out"]
         dn = self._lin_bwd(dh, po["n"], self.project_from_hidden, "project_from_hidden", G)
-        dres = self._norm_bwd(dn, po["v"], self.project_from_hidden_norm, "project_from_hidden_norm", G)   # = dt = d(residual)
+        dres = self._norm_bwd(dn, po["v"], self.project_from_hidden_norm, "project_from_hidden_norm", G, gemm_operand=True)   # = dt = d(residual)
         dt = dres
         for li in reversed(range(c.num_hidden_layers)):
             lyr, sv = self.transformer_layers[li], T["layers"][li]
@@ -666,18 +678,19 @@ class MaskGiTUViT_v2(ModelMixin, ConfigMixin):
             G[nm + ".ffn.wi_0.weight"], G[nm + ".ffn.wi_1.weight"] = gw01[:I], gw01[I:]
             dm3 = self._mm_dx(dab, sv["w01"])
             dn3 = self._adaln_bwd(dm3, sv["a3s"], lyr.ffn.adaLN_modulation, nm + ".ffn.adaLN_modulation", G, scond, dscond, B)
-            dv3 = self._norm_bwd(dn3, sv["res3"], lyr.ffn.pre_mlp_layer_norm, nm + ".ffn.pre_mlp_layer_norm", G, mode=1, dpre=dres)
+            dv3 = self._norm_bwd(dn3, sv["res3"], lyr.ffn.pre_mlp_layer_norm, nm + ".ffn.pre_mlp_layer_norm", G, mode=1, dpre=dres,
+                                  gemm_operand=True)
             # cross attention (dv3 = d(a2) = d(res2))
             dm2, dctx = self._attention_bwd(dv3, sv["s2"], lyr.crossattention, nm + ".crossattention", G)
             denc.add_(dctx)
             dn2 = self._adaln_bwd(dm2, sv["a2s"], lyr.cross_attn_adaLN_modulation, nm + ".cross_attn_adaLN_modulation", G, scond,
                                   dscond, B)
-            dv2 = self._norm_bwd(dn2, sv["res2"], lyr.crossattn_layer_norm, nm + ".crossattn_layer_norm", G, dpre=dv3)
+            dv2 = self._norm_bwd(dn2, sv["res2"], lyr.crossattn_layer_norm, nm + ".crossattn_layer_norm", G, dpre=dv3, gemm_operand=True)
             # self attention (dv2 = d(a) = d(res1))
             dm1, _ = self._attention_bwd(dv2, sv["s1"], lyr.attention, nm + ".attention", G, self_attn=True)
             dn1 = self._adaln_bwd(dm1, sv["a1s"], lyr.self_attn_adaLN_modulation, nm + ".self_attn_adaLN_modulation", G, scond,
                                   dscond, B)
-            dv1 = self._norm_bwd(dn1, sv["res1"], lyr.attn_layer_norm, nm + ".attn_layer_norm", G, dpre=dv2)
+            dv1 = self._norm_bwd(dn1, sv["res1"], lyr.attn_layer_norm, nm + ".attn_layer_norm", G, dpre=dv2, gemm_operand=True)
             dt = dres = dv1                                                           # d(t_prev) = d(res_prev)
         pi = T["proj_in"]
         dn = self._lin_bwd(dt, pi["n"], self.project_to_hidden, "project_to_hidden", G)

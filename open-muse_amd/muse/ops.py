@@ -779,12 +779,14 @@ def norm_res_fwd(x, w, eps, mode, residual=None, want_pre=False):
     return y, pre
 
 
-def adaln_fwd(x, ss, batch):
-    """x [batch * rows, C], ss [batch, 2C] -> x * (1 + scale) + shift"""
+def adaln_fwd(x, ss, batch, out_dtype=torch.float32):
+    """AdaLN modulation; out_dtype=torch.bfloat16 writes the result directly as the bf16 GEMM operand (no f32 copy)"""
     require_gpu(x, ss)
     rows, C_ = x.shape
-    y = torch.empty_like(x)
-    check(lib().muse_adaln_fwd(x.data_ptr(), ss.data_ptr(), y.data_ptr(), batch, rows // batch, C_, stream()), "muse_adaln_fwd")
+    y = torch.empty((rows, C_), dtype=out_dtype, device=x.device)
+    f32 = out_dtype == torch.float32
+    check(lib().muse_adaln_fwd_ex(x.data_ptr(), ss.data_ptr(), y.data_ptr() if f32 else None, None if f32 else y.data_ptr(), batch,
+                                  rows // batch, C_, stream()), "muse_adaln_fwd_ex")
     return y
 
 
@@ -837,17 +839,18 @@ def colsum(part, out, accumulate=False):
     return out
 
 
-def norm_res_bwd(dy, v, w, eps, mode, dpre=None, want_dw=True):
-    """backward of norm_res_fwd: returns (dv = dx = dres, dw or None).  v = the forward's pre-norm sum."""
+def norm_res_bwd(dy, v, w, eps, mode, dpre=None, want_dw=True, also_bf16=False):
+    """backward of norm_res_fwd: returns (dv = dx = dres, dw or None[, bf16 copy of dv]).  v = the forward's pre-norm sum."""
     require_gpu(dy, v)
     rows, cols = v.shape
     dv = torch.empty_like(v)
+    dvb = torch.empty(v.shape, dtype=torch.bfloat16, device=v.device) if also_bf16 else None
     nblk = lib().muse_norm_res_bwd_nblk(rows)
     part = torch.empty((nblk, cols), dtype=torch.float32, device=v.device)
-    check(lib().muse_norm_res_bwd(dy.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), dv.data_ptr(), part.data_ptr(), rows, cols, eps,
-                                  mode, stream()), "muse_norm_res_bwd")
+    check(lib().muse_norm_res_bwd_ex(dy.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), dv.data_ptr(), ptr(dvb), part.data_ptr(), rows,
+                                     cols, eps, mode, stream()), "muse_norm_res_bwd_ex")
     dw = colsum(part, torch.empty(cols, dtype=torch.float32, device=v.device)) if want_dw else None
-    return dv, dw
+    return (dv, dw, dvb) if also_bf16 else (dv, dw)
 
 
 def adaln_bwd(dy, x, ss, batch):
