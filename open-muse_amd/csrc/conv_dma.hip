@@ -315,8 +315,17 @@ static_assert(B_BASE + 3 * BSTAGE <= LDS_BYTES, "LDS map");
 
 struct Frag16 { bf16x8 ah[MI], al[MI], bh[NI], bl[NI]; };
 
+#ifdef CDMA_TIMESTAMPS   // timing experiments (scripts/exp/conv_ts.py): per-block s_memtime stamps at the phase boundaries
+__device__ long* g_conv_ts = nullptr;
+#define CDMA_TS(IDX) if (g_conv_ts && threadIdx.x == 0) g_conv_ts[(long)blockIdx.x * 8 + (IDX)] = (long)__builtin_amdgcn_s_memtime();
+#define CDMA_TSV(V, IDX) if (g_conv_ts && threadIdx.x == 0) g_conv_ts[(long)(V) * 8 + (IDX)] = (long)__builtin_amdgcn_s_memtime();
+#else
+#define CDMA_TS(IDX)
+#define CDMA_TSV(V, IDX)
+#endif
 __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CDMA_TS(0)
   const int H = p.H, W = p.W, Cin = p.Cin;
   const int tpr = W >> 4, tpi = (H >> 4) * tpr;     // patches per image row / per image
   const int ntm = p.M >> 8, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
@@ -472,9 +481,11 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
   int chunk0 = 0;
   issue_slab(0, 0, 0); issue_slab(0, 1, 0); issue_slab(0, 2, 0);
   issue_b(0, 0, 0); issue_b(1, 0, 1); issue_b(2, 0, 2);
+  CDMA_TS(1)
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  CDMA_TS(2)
   SLAB_READ(f0, 0, 0, 0) SLAB_READ(f0, 0, 0, 1) SLAB_READ(f0, 0, 0, 2) SLAB_READ(f0, 0, 0, 3)
   SLAB_READ(f0, 0, 0, 4) SLAB_READ(f0, 0, 0, 5) SLAB_READ(f0, 0, 0, 6) SLAB_READ(f0, 0, 0, 7)
   SLAB_READ(f0, 0, 0, 8) SLAB_READ(f0, 0, 0, 9) SLAB_READ(f0, 0, 0, 10) SLAB_READ(f0, 0, 0, 11)
@@ -497,6 +508,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
 #undef SLAB_CP
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // trailing (zero) DMAs and fragment reads done before LDS is reused
   __builtin_amdgcn_sched_barrier(0);
+  CDMA_TS(3)
 
   // ---- epilogue: + bias, staged through LDS, 16-byte row-contiguous stores with the residual added (tile row = patch
   //      pixel py * 16 + px), GroupNorm partials of the output ----
@@ -521,6 +533,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
     }
   }
   __syncthreads();
+  CDMA_TS(4)
   constexpr int NIT = (BM * 32) / NT;   // 16 chunks of 16 bytes per thread: patch row `it`, pixel rbase
   const int col = (threadIdx.x & 31) * 4, n = n0 + col, rbase = threadIdx.x >> 5;
   const long pix0 = ((long)img * H + y0) * W + x0 + rbase;
@@ -534,7 +547,11 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
     for (int it = 0; it < NIT; ++it) {
       f32x4 w = *(const f32x4*)(smem + (rbase + 16 * it) * CST + col * 4);
       if (p.residual) w += rv[it];
+#ifndef CDMA_ABLATE_NO_STORE   // (timing experiments: scripts/exp/conv_seam.sh)
       *(f32x4*)(p.out + (pix0 + (long)it * W) * p.N + n) = w;
+#else
+      if (w[0] == 123.456f) p.out[0] = w[1];   // keeps the staged read alive, stores nothing
+#endif
       if (p.gn_partial) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { gs += (double)w[e]; gq += (double)w[e] * (double)w[e]; }
@@ -561,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
       }
     }
   }
+  CDMA_TS(5)
 }
 
 
@@ -765,6 +783,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    CDMA_TSV(v, 0)
     bool first = true;
     for (int chunk0 = 0; chunk0 < nchunks; chunk0 += 2) {
       SLAB_TAP(f0, f1, 0) SLAB_TAP(f1, f0, 1) SLAB_TAP(f0, f1, 2) SLAB_TAP(f1, f0, 3) SLAB_TAP(f0, f1, 4) SLAB_TAP(f1, f0, 5)
@@ -773,6 +792,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
       first = false;
     }
 
+    CDMA_TSV(v, 1)
     // ---- epilogue of tile v.  (The tap-17 look-ahead reads already fetched the next tile's tap-0 fragments, but keeping them
     //      live through the epilogue - 64 more registers next to the accumulators and the residual tile - made hipcc spill into
     //      the store loop, and a spill reload is a `vmcnt(0)` behind every store.  They are re-read after the epilogue.) ----
@@ -785,6 +805,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
     const unsigned rowstep = (unsigned)((long)W * p.N * 4);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // look-ahead DMAs and the tap-17 fragment reads
     __builtin_amdgcn_sched_barrier(0);
+    CDMA_TSV(v, 2)
     // residual: added to the accumulators in FRAGMENT layout (lane = pixel lane & 15 of patch row wm * 4 + i, four channels),
     // one patch row ahead, so that every global load of the epilogue retires before its first store: a load waited for behind
     // a store is a wait for that store's acknowledgement (reads and writes share vmcnt)
@@ -815,6 +836,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
     asm volatile("" ::"v"(bias4));
     __builtin_amdgcn_sched_barrier(0);
+    CDMA_TSV(v, 3)
     double gs = 0.0, gq = 0.0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -844,6 +866,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
         }
       }
     }
+    CDMA_TSV(v, 4)
     if (p.gn_partial) {
       gs += __shfl_xor(gs, 32, 64);
       gq += __shfl_xor(gq, 32, 64);
@@ -864,6 +887,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
         }
       }
     }
+    CDMA_TSV(v, 5)
     if (!has_next) break;
     v = vn; g = gn;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -886,6 +910,9 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
 
 }  // namespace cslab
 
+#ifdef CDMA_TIMESTAMPS
+extern "C" int muse_debug_conv_ts(long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(cslab::g_conv_ts), &buf, sizeof(buf)); }
+#endif
 extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
                                        const float* residual, float* out, double* gn_partial, int32_t gn_groups, int32_t batch,
                                        int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, void* stream) {
