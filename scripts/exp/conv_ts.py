@@ -44,3 +44,9 @@ for res, gn in ((False, False), (True, True)):
     for i, n in enumerate(names):
         print(f"    {n:34s} median {np.median(d[:, i]):8.0f}   p10 {np.percentile(d[:, i], 10):8.0f}   p90 {np.percentile(d[:, i], 90):8.0f}")
     print(f"    stamped span                       median {np.median(t[:, 5] - t[:, 0]):8.0f}")
+    if os.environ.get("MUSE_CONV_SLAB", "1") == "2":   # persistent: tile v + 256 follows tile v in the same block
+        nb = 256
+        gap = raw[nb:, 0] - raw[:-nb, 5]
+        per = raw[nb:, 0] - raw[:-nb, 0]
+        print(f"    end of epilogue -> next K loop     median {np.median(gap):8.0f}   p10 {np.percentile(gap, 10):8.0f}   p90 {np.percentile(gap, 90):8.0f}")
+        print(f"    tile period (stamp 0 to stamp 0)   median {np.median(per):8.0f}  -> {us / (ntile / 256) / np.median(per) * 1e3:.3f} ns per tick")
