@@ -432,6 +432,8 @@ class TrainStep:
         self.label_smoothing, self.min_masking_rate = label_smoothing, min_masking_rate
         self._pf = None          # (pixel tensor, tokens, ready event) of the prefetched batch
         self._pf_stream = None
+        self.compute_priority = -1   # stream priority of the step while a prefetch is in flight (None: stay on the caller's stream)
+        self._hp_stream, self._in_hp = None, False
 
     @torch.no_grad()
     def _prefetch(self, pixel_values):
@@ -452,6 +454,26 @@ class TrainStep:
     def __call__(self, pixel_values, class_ids, timesteps=None, noise=None, image_tokens=None, next_pixel_values=None):
         """image_tokens [B, S] int64: pre-encoded VQ tokens (muse.pre_encode; the reference's scripts/pre_encode.py regime) -
         the tokenizer is then skipped and pixel_values may be None"""
+        # With a tokenizer pass of the next batch in flight, the train step itself runs on a HIGH-priority stream: the hardware
+        # then serves its (latency-critical, serially dependent) kernels first and fits the tokenizer's blocks into what is left
+        # (62.3 -> 61.1 ms per step on MI355X; the reverse, a high-priority tokenizer stream, costs 1.5 ms).  The caller's stream is
+        # joined on entry and on return, so nothing changes for code around the step.
+        if next_pixel_values is not None and self.compute_priority is not None and class_ids.is_cuda and not self._in_hp:
+            dev = class_ids.device
+            if self._hp_stream is None or self._hp_stream.device != dev:
+                self._hp_stream = torch.cuda.Stream(device=dev, priority=self.compute_priority)
+            cur = torch.cuda.current_stream(dev)
+            self._hp_stream.wait_stream(cur)
+            self._in_hp = True
+            try:
+                with torch.cuda.stream(self._hp_stream):
+                    loss, mask_prob = self.__call__(pixel_values, class_ids, timesteps, noise, image_tokens, next_pixel_values)
+            finally:
+                self._in_hp = False
+            cur.wait_stream(self._hp_stream)
+            loss.record_stream(cur)
+            mask_prob.record_stream(cur)
+            return loss, mask_prob
         if image_tokens is None and self._pf is not None and self._pf[0] is pixel_values:
             _, image_tokens, ev = self._pf
             main = torch.cuda.current_stream(image_tokens.device)
