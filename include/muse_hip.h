@@ -145,6 +145,12 @@ int muse_embed_fwd(const int64_t* ids, const float* word, const float* pos, floa
 int muse_embed_bwd(const int64_t* ids, const float* dout, float* dword, float* dpos, float* scratch, int32_t batch,
                    int32_t seq, int32_t hidden, int32_t vocab, int32_t accumulate, void* stream);
 int64_t muse_embed_bwd_scratch_floats(int32_t hidden, int32_t vocab);
+/* The same gradients by a stable (token id, position) sort and segmented row sums (csrc/embed.hip): every gradient row is read
+ * once, rows with many hits (the mask token) are shared by several blocks, the summation order is fixed.  `scratch`: 256-byte
+ * aligned, muse_embed_bwd2_scratch_bytes(batch, seq, hidden, vocab) bytes.  Ids outside [0, vocab) are ignored. */
+int muse_embed_bwd2(const int64_t* ids, const float* dout, float* dword, float* dpos, void* scratch, int64_t scratch_bytes,
+                    int32_t batch, int32_t seq, int32_t hidden, int32_t vocab, int32_t accumulate, void* stream);
+int64_t muse_embed_bwd2_scratch_bytes(int32_t batch, int32_t seq, int32_t hidden, int32_t vocab);
 
 /* F.cross_entropy(logits, labels, ignore_index=-100, label_smoothing) (muse/modeling_transformer.py:1276-1279).
  * fwd: row_loss[r], lse[r] per row, then loss = sum(row_loss over valid) / n_valid into loss_out[0], n_valid into

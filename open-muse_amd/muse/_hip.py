@@ -73,6 +73,8 @@ SIGNATURES = {
     "muse_embed_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "muse_embed_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "muse_embed_bwd_scratch_floats": [c_int, c_int],
+    "muse_embed_bwd2": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "muse_embed_bwd2_scratch_bytes": [c_int, c_int, c_int, c_int],
     "muse_cross_entropy_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_float,
                                c_void_p],
     "muse_cross_entropy_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int,
@@ -128,7 +130,7 @@ SIGNATURES = {
     "muse_scale_rows": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p],
     "muse_probe_tr16": [c_void_p, c_void_p, c_void_p],
 }
-_RESTYPES = {"muse_embed_bwd_scratch_floats": c_i64}
+_RESTYPES = {"muse_embed_bwd_scratch_floats": c_i64, "muse_embed_bwd2_scratch_bytes": c_i64}
 
 
 class MuseHipError(RuntimeError):

@@ -433,10 +433,22 @@ def embed_fwd(ids, word, pos):
     return out
 
 
+EMBED_BWD_SORT = os.environ.get("MUSE_EMBED_BWD_SORT", "1") != "0"   # 0: the scan-per-row kernel (muse_embed_bwd)
+
+
 def embed_bwd(ids, dout, dword, dpos, accumulate):
+    """dword[v] (+)= sum of dout rows whose token id is v (position order), dpos[s] (+)= sum over the batch"""
     require_gpu(ids, dout, dword, dpos)
     B, S = ids.shape
     V, H = dword.shape
+    if EMBED_BWD_SORT:
+        nb = lib().muse_embed_bwd2_scratch_bytes(B, S, H, V)
+        if nb < 0:
+            raise _hip.MuseHipError("muse_embed_bwd2_scratch_bytes failed")
+        scratch = torch.empty(nb, dtype=torch.uint8, device=ids.device)   # (the caching allocator hands out 512-byte aligned blocks)
+        check(lib().muse_embed_bwd2(ids.data_ptr(), dout.data_ptr(), dword.data_ptr(), dpos.data_ptr(), scratch.data_ptr(), nb, B, S, H,
+                                    V, 1 if accumulate else 0, stream()), "muse_embed_bwd2")
+        return
     n = lib().muse_embed_bwd_scratch_floats(H, V)
     scratch = torch.empty(n, dtype=torch.float32, device=ids.device)
     check(lib().muse_embed_bwd(ids.data_ptr(), dout.data_ptr(), dword.data_ptr(), dpos.data_ptr(), scratch.data_ptr(), B, S, H,

@@ -205,19 +205,22 @@ def test_cross_entropy(ls, V, ld):
     assert torch.all(dl[:, V:] == 0)
 
 
-def test_embedding_fwd_bwd_deterministic():
+@pytest.mark.parametrize("B,S,H,V,heavy", [(6, 17, 32, 48, 6), (16, 257, 768, 3049, 120), (3, 5, 20, 7, 0)])
+def test_embedding_fwd_bwd_deterministic(B, S, H, V, heavy):
+    """embedding forward (bit-exact) and backward: the sort-based segmented sum (csrc/embed.hip) against an f64 index_add, incl. a row
+    hit by ~half of all tokens (several 64-row segments), rows without hits, accumulation and run-to-run determinism"""
     ops = _ops()
-    B, S, H, V = 6, 17, 32, 48
     rng = np.random.default_rng(40)
     ids = torch.from_numpy(rng.integers(0, V, size=(B, S)))
-    ids[:, 3:9] = V - 1  # heavy hitter (mask token)
-    word, pos = rnd((V, H), 41), rnd((24, H), 42)
+    ids[:, 3:3 + heavy] = V - 1  # heavy hitter (mask token)
+    P = S + 7
+    word, pos = rnd((V, H), 41), rnd((P, H), 42)
     out = ops.embed_fwd(ids.to(DEV), word.to(DEV), pos.to(DEV))
     ref = word[ids] + pos[:S][None]
     assert torch.equal(out.cpu().view(B, S, H), ref)  # one f32 add: bit-exact
     dout = rnd((B * S, H), 43)
     dword = torch.full((V, H), 5.0, device=DEV)
-    dpos = torch.full((24, H), 5.0, device=DEV)
+    dpos = torch.full((P, H), 5.0, device=DEV)
     ops.embed_bwd(ids.to(DEV), dout.to(DEV), dword, dpos, False)
     rw = torch.zeros(V, H, dtype=torch.float64).index_add_(0, ids.view(-1), dout.double())
     rp = dout.double().view(B, S, H).sum(0)
@@ -227,6 +230,8 @@ def test_embedding_fwd_bwd_deterministic():
     p2 = torch.empty_like(dpos)
     ops.embed_bwd(ids.to(DEV), dout.to(DEV), d2, p2, False)
     assert torch.equal(d2, dword)  # run-to-run deterministic (no float atomics)
+    ops.embed_bwd(ids.to(DEV), dout.to(DEV), d2, p2, True)   # accumulate: 2 x the gradient (rows without hits stay 0)
+    assert rel_err(d2, 2 * rw) < 1e-6 and rel_err(p2[:S], 2 * rp) < 1e-6
 
 
 def test_adamw_matches_torch():
