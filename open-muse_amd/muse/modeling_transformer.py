@@ -374,6 +374,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         return out
 
     def _run_forward(self, input_ids, labels, label_smoothing, need_grad):
+        ops.COLSUM_SINK = None   # (a backward that died half way must not leave column sums queued for ever)
         cd = self._resolve_cd()
         H, I, nh, V = self.hidden_size, self.intermediate_size, self.num_attention_heads, self.output_size
         hd = H // nh
@@ -532,6 +533,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 return ops.linear_wgrad(dy, x, dw, accumulate, **kw)
             side.wait_stream(main)           # dy (and on the first use x) were produced on the main stream
             with torch.cuda.stream(side):
+                ops.flush_colsums()          # LayerNorm / GLU weight-gradient column sums queued since the last call
                 ops.linear_wgrad(dy, x, dw, accumulate, **kw)
             dy.record_stream(side)           # the caching allocator must not hand these blocks out while the side stream reads them
             x.record_stream(side)
@@ -544,7 +546,10 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 else:   # the range is complete once both streams have passed this point
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
+                        ops.flush_colsums()
                         self.grad_ready_hook(off[i0], end)
+        if side is not None:
+            ops.COLSUM_SINK = []
 
         # ---- loss / head ----------------------------------------------------------------------------------------
         dlog = None
@@ -644,6 +649,10 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             view(GW, 1, tuple(params[1].shape))[S:].zero_()
         ready(0, 2)
         if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.flush_colsums()
+            ops.COLSUM_SINK = None
             main.wait_stream(side)   # the optimizer (and anything else on the main stream) sees every weight gradient
         if self.direct_grad:
             return [None] * len(params)

@@ -254,6 +254,30 @@ def layernorm_fwd(x, w, eps, out_dtype, residual=None):
     return y, mean, rstd
 
 
+# The column sums that finish a LayerNorm weight gradient (per-block partials -> dw) are leaves of the backward graph.  While
+# COLSUM_SINK is a list (the model's backward sets it when it runs weight gradients on a second stream) they are queued instead of
+# launched, and flush_colsums() launches the queue on whatever stream is current - the weight-gradient stream, off the dX chain.
+COLSUM_SINK = None
+
+
+def _colsum_or_defer(part, dw, nblk, cols, accumulate):
+    if COLSUM_SINK is not None:
+        COLSUM_SINK.append((part, dw, nblk, cols, accumulate))
+    else:
+        check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, cols, 1 if accumulate else 0, stream()), "muse_colsum")
+
+
+def flush_colsums():
+    """launch the queued column sums on the current stream (the caller has ordered it behind the kernels that wrote the partials)"""
+    if not COLSUM_SINK:
+        return
+    cur = torch.cuda.current_stream(COLSUM_SINK[0][0].device)
+    for part, dw, nblk, cols, accumulate in COLSUM_SINK:
+        check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, cols, 1 if accumulate else 0, stream()), "muse_colsum")
+        part.record_stream(cur)
+    COLSUM_SINK.clear()
+
+
 def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None, also_bf16=False):
     """returns dx (= LN'(dy) + dres); dw (+)= column sums of dy * xhat.  also_bf16: returns (dx, bf16 copy of dx) written in the
     same pass."""
@@ -267,7 +291,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None, als
     check(lib().muse_layernorm_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), dt(x), w.data_ptr(), mean.data_ptr(),
                                    rstd.data_ptr(), ptr(dres), dx.data_ptr(), dt(dx), ptr(dx2), part.data_ptr(), nblk, rows, cols,
                                    stream()), "muse_layernorm_bwd")
-    check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, cols, 1 if accumulate else 0, stream()), "muse_colsum")
+    _colsum_or_defer(part, dw, nblk, cols, accumulate)
     _prof_end(e0, "layernorm_bwd", _nbytes(dy, x, dres, dx, dx2), "byte")
     return (dx, dx2) if also_bf16 else dx
 
@@ -405,7 +429,7 @@ def ffn_mid_bwd(dhm, h, ab, w, mean, rstd, dw, accumulate):
     e0 = _prof_begin()
     check(lib().muse_ffn_mid_bwd(dhm.data_ptr(), h.data_ptr(), ab.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                  dab.data_ptr(), part.data_ptr(), dt(h), rows, inter, stream()), "muse_ffn_mid_bwd")
-    check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, inter, 1 if accumulate else 0, stream()), "muse_colsum")
+    _colsum_or_defer(part, dw, nblk, inter, accumulate)
     _prof_end(e0, "ffn_mid_bwd", _nbytes(dhm, h, ab, dab), "byte")
     return dab
 
