@@ -77,3 +77,7 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   }
   return MUSE_ERR_BAD_ARG;
 }
+
+#ifdef G256_TIMESTAMPS
+extern "C" int muse_debug_gemm_ts(long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g256::g_gemm_ts), &buf, sizeof(buf)); }
+#endif

@@ -414,9 +414,16 @@ struct Pipe32 {
   }
 };
 
+#ifdef G256_TIMESTAMPS   // timing experiments (scripts/exp/gemm_ts.py): s_memtime stamps per block - 0 entry, 1 prologue done, 2 K loop done, 3 exit
+__device__ long* g_gemm_ts = nullptr;
+#define G256_TS(IDX) if (g_gemm_ts && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_gemm_ts[(long)blockIdx.x * 4 + (IDX)] = (long)__builtin_amdgcn_s_memtime();
+#else
+#define G256_TS(IDX)
+#endif
 template <typename TC, int AL, int BL, int BKV, bool SPREAD = false>
 __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  G256_TS(0)
 
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
   const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
@@ -465,6 +472,7 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   // the tile count is rounded up to even (a tile beyond kend is all out-of-range chunks: zeros, no memory traffic)
   const int kt_last = kt0 + ((nk - kt0 + 1) & ~1);
   pp.prologue(kt0);
+  G256_TS(1)
   if constexpr (BKV == 64) {
     for (int kt = kt0; kt < kt_last; kt += 2) {
       pp.template group<0, 0>(kt, kt_last);
@@ -484,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
   }
   auto& acc = pp.acc;
+  G256_TS(2)
 
   // ---- epilogue: C staged through LDS, RPP rows per pass, 16-byte row-contiguous stores ----
   // lane holds C[m][n..n+3], m = m0 + wr + 16 i + (lane & 15), n = n0 + wc + 16 j + 4 (lane >> 4)
@@ -595,6 +604,7 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
       }
     }
   }
+  G256_TS(3)
 }
 
 }  // namespace g256
