@@ -560,6 +560,8 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
     }
   }
   // every load so far has been consumed (the compiler waited for it at its use): from here on the f32 path only stores
+  // (Measured, no gain: taking each pass's rows from both wave rows so that all eight waves write LDS in every pass - the
+  //  epilogue's 9.5-10.6 k cycles are the 128 KiB of stores going through the CU's vector-memory path, not the staging.)
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     lds_barrier();

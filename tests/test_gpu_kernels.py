@@ -234,6 +234,45 @@ def test_embedding_fwd_bwd_deterministic(B, S, H, V, heavy):
     assert rel_err(d2, 2 * rw) < 1e-6 and rel_err(p2[:S], 2 * rp) < 1e-6
 
 
+def test_adamw_multi_matches_flat():
+    """muse_adamw_multi (one launch over a device table of tensors) == muse_adamw_flat per tensor, bit for bit: sizes that are not
+    multiples of 4 or of the 4096-element chunk, a 4-byte-aligned (not 16-byte) view, with and without the bf16 shadow"""
+    ops = _ops()
+    sizes = [1, 3, 4096, 4097, 10007, 8192 * 3 + 2, 5]
+    rng_seed = 70
+    tensors = []
+    for i, n in enumerate(sizes):
+        off = 1 if i == 4 else 0     # one tensor starts 4 bytes into its allocation
+        def mk(seed, scale=1.0, positive=False):
+            t = torch.zeros(n + off, device=DEV)
+            v = rnd((n,), seed, scale).to(DEV)
+            t[off:] = v.abs() if positive else v
+            return t[off:]
+        p, g = mk(rng_seed + 4 * i), mk(rng_seed + 4 * i + 1, 0.1)
+        m, v = mk(rng_seed + 4 * i + 2, 0.01), mk(rng_seed + 4 * i + 3, 1e-4, positive=True)
+        sh = torch.zeros(n, dtype=torch.bfloat16, device=DEV) if i % 2 == 0 else None
+        tensors.append((p, g, m, v, sh))
+    ref = [tuple(None if t is None else t.clone() for t in tt) for tt in tensors]
+    hp = dict(lr=1e-3, beta1=0.9, beta2=0.99, eps=1e-8, weight_decay=0.05, step=3)
+    for p, g, m, v, sh in ref:
+        ops.adamw_flat(p, g, m, v, sh, hp["lr"], hp["beta1"], hp["beta2"], hp["eps"], hp["weight_decay"], hp["step"], grad_scale=0.5)
+    rows, first, nch = [], [], 0
+    for p, g, m, v, sh in tensors:
+        rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr() if sh is not None else 0, p.numel()))
+        first.append(nch)
+        nch += (p.numel() + 4095) // 4096
+    first.append(nch)
+    table = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    cf = torch.tensor(first, dtype=torch.int32).to(DEV)
+    ops.adamw_multi(table, cf, len(rows), nch, hp["lr"], hp["beta1"], hp["beta2"], hp["eps"], hp["weight_decay"], hp["step"], grad_scale=0.5)
+    for a, b in zip(tensors, ref):
+        for x, y in zip(a, b):
+            if x is not None and x.dtype != torch.bfloat16:
+                assert torch.equal(x, y)
+            elif x is not None:
+                assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
 def test_adamw_matches_torch():
     ops = _ops()
     n = 4099

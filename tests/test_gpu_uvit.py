@@ -272,7 +272,8 @@ def test_uvit_generate2(golden_dir):
 
 
 def test_uvit_train_step_with_fused_adamw(golden_dir):
-    """FusedAdamW on a model without a flat parameter buffer: one muse_adamw_flat launch per tensor == torch.optim.AdamW"""
+    """FusedAdamW on a model without a flat parameter buffer: ONE muse_adamw_multi launch over the device table of all 120 tensors ==
+    torch.optim.AdamW"""
     import muse
     g, cfg, sd = _load_golden(golden_dir)
     model = muse.MaskGiTUViT(**cfg)
