@@ -428,7 +428,15 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
     else if constexpr ((Q) < 12) lds_read128<(ST) * BSTAGE + q_ * 1024>(F.bh[q_], addrB);                                         \
     else lds_read128<(ST) * BSTAGE + 8192 + q_ * 1024>(F.bl[q_], addrB);                                                          \
   }
-#ifndef CDMA_ABLATE_NO_MFMA
+#if defined(CDMA_TWO_PRODUCTS)   // accuracy experiment (scripts/exp/conv_two_products.sh): drop one cross term of the bf16x3 product
+#define SLAB_PAIR(F, Q)                                                                                                        \
+  {                                                                                                                            \
+    constexpr int i_ = (Q) >> 2, j_ = (Q) & 3;                                                                                 \
+    if constexpr (CDMA_TWO_PRODUCTS == 1) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.al[i_], acc[i_][j_], 0, 0, 0);  /* w_lo dropped */ \
+    else acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bl[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                       /* x_lo dropped */ \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
+  }
+#elif !defined(CDMA_ABLATE_NO_MFMA)
 #define SLAB_PAIR(F, Q)                                                                                                        \
   {                                                                                                                            \
     constexpr int i_ = (Q) >> 2, j_ = (Q) & 3;                                                                                 \
