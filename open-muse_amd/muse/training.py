@@ -316,7 +316,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
 
 class GradReducer:
-    """Data-parallel gradient averaging for a muse.MaskGitTransformer: the flat gradient buffer is all-reduced in large
+    """Data-parallel gradient averaging.  muse.MaskGitTransformer: the flat gradient buffer is all-reduced in large
     contiguous buckets (default 64 MiB; xGMI rings are per-link bound, so few large messages) as soon as backward has
     finished writing them, on a side stream, while backward keeps computing earlier layers.
 
@@ -341,11 +341,73 @@ class GradReducer:
         self._hi = self._lo = None
         self._handles = []
         self._stream = None
-        model.direct_grad = True
-        model.grad_ready_hook = self._on_ready
-        if broadcast_params:
-            dist.broadcast(model.flat_params(), src=0, group=process_group)  # DDP's constructor sync (:305)
-            model.mark_weights_changed()
+        # Models with a flat gradient buffer (MaskGitTransformer) report finished ranges during backward.  Models whose
+        # parameters are ordinary tensors (MaskGiTUViT: one autograd node hands every gradient back at once) are reduced in
+        # finish(): gradients packed, in reverse parameter order, into the same large buckets.
+        self._flat_mode = hasattr(model, "flat_grads") and hasattr(model, "grad_ready_hook")
+        if self._flat_mode:
+            model.direct_grad = True
+            model.grad_ready_hook = self._on_ready
+            if broadcast_params:
+                dist.broadcast(model.flat_params(), src=0, group=process_group)  # DDP's constructor sync (:305)
+                model.mark_weights_changed()
+        else:
+            self._params = [p for p in model.parameters() if p.requires_grad]
+            if broadcast_params:
+                with torch.no_grad():
+                    for bucket in self._buckets([p.data for p in self._params]):
+                        flat = torch.cat([t.reshape(-1) for t in bucket])
+                        dist.broadcast(flat, src=0, group=process_group)
+                        o = 0
+                        for t in bucket:
+                            t.copy_(flat[o:o + t.numel()].view_as(t))
+                            o += t.numel()
+                if hasattr(model, "mark_weights_changed"):
+                    model.mark_weights_changed()
+
+    def _buckets(self, tensors):
+        """consecutive tensors grouped into buckets of >= bucket_elems elements (the last one may be smaller)"""
+        out, cur, n = [], [], 0
+        for t in tensors:
+            cur.append(t)
+            n += t.numel()
+            if n >= self.bucket_elems:
+                out.append(cur)
+                cur, n = [], 0
+        if cur:
+            out.append(cur)
+        return out
+
+    def _finish_tensor_list(self):
+        grads = [p.grad for p in reversed(self._params) if p.grad is not None]
+        if not grads:
+            return
+        on_gpu = grads[0].is_cuda
+        if on_gpu and self._stream is None:
+            self._stream = torch.cuda.Stream(priority=-1)
+        packed = []
+        for bucket in self._buckets(grads):
+            flat = torch.cat([g.reshape(-1) for g in bucket])        # pack (one pass); the collective then moves one large message
+            if on_gpu:
+                self._stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._stream):
+                    h = self._reduce(flat, True)
+                    if h is not None:
+                        self._handles.append(h)
+                flat.record_stream(self._stream)
+            else:
+                self._reduce(flat, False)
+            packed.append((bucket, flat))
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if on_gpu:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        for bucket, flat in packed:                                   # unpack into the .grad tensors the optimizer reads
+            o = 0
+            for g in bucket:
+                g.copy_(flat[o:o + g.numel()].view_as(g))
+                o += g.numel()
 
     def _reduce(self, g, on_gpu):
         """mean over ranks of one bucket (in place)"""
@@ -393,6 +455,8 @@ class GradReducer:
 
     def finish(self):
         """flush the last bucket and make the compute stream wait for every outstanding all-reduce"""
+        if not self._flat_mode:
+            return self._finish_tensor_list()
         if self._hi is not None:
             self._launch(self._lo, self._hi)
             self._hi = self._lo = None

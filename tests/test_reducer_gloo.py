@@ -60,3 +60,38 @@ def test_grad_reducer_world2(tmp_path):
     assert abs(float(r0["loss"]) - 1.5) < 1e-6 and abs(float(r0["rate"]) - 0.375) < 1e-6 and torch.equal(r0["loss"], r1["loss"])
     e16 = (torch.arange(n, dtype=torch.float32) % 251) * 1.5   # small integers and their 1.5 multiples are exact in bf16
     assert torch.equal(r0["g16"], r1["g16"]) and torch.allclose(r0["g16"], e16, rtol=8e-3)
+
+
+def _worker_list(rank, world, port, out):
+    """tensor-list mode (MaskGiTUViT: ordinary parameter tensors, every gradient arrives at once)"""
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    import muse
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(200 + rank)
+    m = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.Linear(13, 5, bias=False), torch.nn.LayerNorm(5))
+    red = muse.GradReducer(m, bucket_bytes=256)          # 64 elements per bucket: several buckets, one of them a single large tensor
+    p_after = [p.detach().clone() for p in m.parameters()]
+    for i, p in enumerate(m.parameters()):
+        p.grad = torch.full_like(p, float(i + 1)) * (rank + 1) + torch.arange(p.numel(), dtype=torch.float32).view_as(p)
+    list(m.parameters())[2].grad = None                   # a parameter without a gradient is skipped (its .grad stays None)
+    red.finish()
+    torch.save({"p": p_after, "g": [None if p.grad is None else p.grad.clone() for p in m.parameters()]}, os.path.join(out, f"l{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_tensor_list_world2(tmp_path):
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_list, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "l0.pt")
+    r1 = torch.load(tmp_path / "l1.pt")
+    for a, b in zip(r0["p"], r1["p"]):
+        assert torch.equal(a, b)                              # rank 0's parameters everywhere
+    for i, (a, b) in enumerate(zip(r0["g"], r1["g"])):
+        if i == 2:
+            assert a is None and b is None
+            continue
+        expect = torch.full_like(a, float(i + 1)) * 1.5 + torch.arange(a.numel(), dtype=torch.float32).view_as(a)   # mean over the ranks
+        assert torch.equal(a, b) and torch.allclose(a, expect)
