@@ -162,6 +162,7 @@ def uvit_leg(device, batch, seq, steps=3):
         opt.step()
         return loss
     step()
+    step()   # two warm-up steps: the first touch of tens of GB of fresh HBM (page tables, allocator growth) must not land in the timed ones
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
