@@ -127,7 +127,9 @@ int muse_glu_bwd(const void* ab, const void* dh, void* dab, int32_t dtype, int64
 /* Fused middle of the NormFormer GLU MLP (muse/modeling_transformer.py:789-797), one pass over ab = [rows, 2*inter]:
  *   fwd: h = gelu_erf(a) * b, hm = LayerNorm(h) * w (mean/rstd saved);
  *   bwd: dh = LN'(dhm) never leaves the CU, dab = (dh*b*gelu'(a), dh*gelu(a)); dw_partial [ceil(rows/R), inter] f32 with
- *        R = muse_ffn_mid_rows_per_block(), reduced by muse_colsum. */
+ *        R = muse_ffn_mid_rows_per_block(), reduced by muse_colsum.
+ * `h` may be NULL in both: the forward then does not write it and the backward recomputes gelu_erf(a) * b (rounded to the storage
+ * type, i.e. exactly the tensor the forward normalised) from ab. */
 int muse_ffn_mid_rows_per_block(void);
 int muse_ffn_mid_fwd(const void* ab, const float* w, void* h, void* hm, float* mean, float* rstd, int32_t dtype,
                      int32_t rows, int32_t inter, float eps, void* stream);

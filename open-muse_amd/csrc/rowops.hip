@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
         V4<T>::load(abr + c, a); V4<T>::load(abr + inter + c, b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]) * b[j];
-        V4<T>::store(h + (long)row * inter + c, o);
+        if (h) V4<T>::store(h + (long)row * inter + c, o);
         if (sizeof(T) == 2) {  // LayerNorm sees the stored (bf16-rounded) h, exactly like the unfused path
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = bf16_to_f32(f32_to_bf16(o[j]));
@@ -275,7 +275,10 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T, int NV>
+// RECOMP: h is not read but recomputed from ab exactly as the forward produced it (gelu_erf(a) * b, rounded to the storage type
+// - the value the forward's LayerNorm normalised): one tensor less to write in the forward and to read here (-17 % of this kernel's
+// bytes), the erf it needs is the one the GLU backward computes anyway.  erf(a / sqrt 2) is kept across the row reductions.
+template <typename T, int NV, bool RECOMP>
 __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ dhm, const T* __restrict__ h,
                                                           const T* __restrict__ ab, const float* __restrict__ w,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
     const int row = r0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
-    float gk[NV][4], xh[NV][4];
+    float gk[NV][4], xh[RECOMP ? 1 : NV][4], ev[RECOMP ? NV : 1][4];
     float s1 = 0.f, s2 = 0.f;
     const T* abr = ab + (long)row * 2 * inter;
     // the GLU operands of the second phase do not depend on the row reductions: their loads go out with the first phase's
@@ -310,14 +313,27 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
       const int c = (k * 256 + threadIdx.x) * 4;
       if (c < inter) {
         float d[4], x[4];
-        V4<T>::load(dhm + (long)row * inter + c, d); V4<T>::load(h + (long)row * inter + c, x);
+        V4<T>::load(dhm + (long)row * inter + c, d);
+        if constexpr (RECOMP) {
+          float a[4], b[4];
+          V4<T>::unpack(ra[k], a); V4<T>::unpack(rb[k], b);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ev[k][j] = erff(a[j] * 0.70710678118654752440f);
+            x[j] = 0.5f * a[j] * (1.0f + ev[k][j]) * b[j];           // == gelu_erf(a) * b, bit for bit
+            if (sizeof(T) == 2) x[j] = bf16_to_f32(f32_to_bf16(x[j]));
+          }
+        } else {
+          V4<T>::load(h + (long)row * inter + c, x);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          xh[k][j] = (x[j] - mu) * rs;
+          const float xhj = (x[j] - mu) * rs;
+          if constexpr (!RECOMP) xh[k][j] = xhj;
           gk[k][j] = d[j] * wv[k][j];
           s1 += gk[k][j];
-          s2 = fmaf(gk[k][j], xh[k][j], s2);
-          dwacc[k][j] = fmaf(d[j], xh[k][j], dwacc[k][j]);
+          s2 = fmaf(gk[k][j], xhj, s2);
+          dwacc[k][j] = fmaf(d[j], xhj, dwacc[k][j]);
         }
       }
     }
@@ -332,9 +348,19 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
         V4<T>::unpack(ra[k], a); V4<T>::unpack(rb[k], b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float dh = rs * (gk[k][j] - c1 - xh[k][j] * c2);
-          da[j] = dh * b[j] * gelu_erf_grad(a[j]);
-          db[j] = dh * gelu_erf(a[j]);
+          if constexpr (RECOMP) {
+            const float e = ev[k][j], g = 0.5f * a[j] * (1.0f + e);
+            float hq = g * b[j];
+            if (sizeof(T) == 2) hq = bf16_to_f32(f32_to_bf16(hq));
+            const float dh = rs * (gk[k][j] - c1 - ((hq - mu) * rs) * c2);
+            const float cdf = 0.5f * (1.0f + e), pdf = 0.39894228040143267794f * __expf(-0.5f * a[j] * a[j]);
+            da[j] = dh * b[j] * (cdf + a[j] * pdf);                  // == gelu_erf_grad(a)
+            db[j] = dh * g;
+          } else {
+            const float dh = rs * (gk[k][j] - c1 - xh[k][j] * c2);
+            da[j] = dh * b[j] * gelu_erf_grad(a[j]);
+            db[j] = dh * gelu_erf(a[j]);
+          }
         }
         V4<T>::store(dr + c, da); V4<T>::store(dr + inter + c, db);
       }
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
       for (int j = 0; j < 8; ++j) hv[k][j] = gelu_erf(a[j]) * b[j];
       const u32x4 o = pack8(hv[k]);
-      if (live) *(u32x4*)(h + (long)row * inter + k * 1024 + t * 8) = o;
+      if (live && h) *(u32x4*)(h + (long)row * inter + k * 1024 + t * 8) = o;   // (h == nullptr: the backward recomputes it)
       unpack8(o, hv[k]);   // LayerNorm sees the stored (bf16-rounded) h, exactly like the unfused path
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += hv[k][j];
@@ -518,7 +544,7 @@ extern "C" int muse_ffn_mid_fwd(const void* ab, const float* w, void* h, void* h
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((rows + FFN_ROWS - 1) / FFN_ROWS);
   const int nv = (inter + 1023) / 1024;
-  if (ffn_mid_wide_ok(dtype, inter, 0) && !((((uintptr_t)ab) | ((uintptr_t)h) | ((uintptr_t)hm) | ((uintptr_t)w)) & 15)) {
+  if (ffn_mid_wide_ok(dtype, inter, 0) && !((((uintptr_t)ab) | ((uintptr_t)h) | ((uintptr_t)hm) | ((uintptr_t)w)) & 15)) {   // (a null h is "aligned")
     const dim3 g2((grid.x + 1) / 2);
 #define FF2(NK) hipLaunchKernelGGL((ffn_mid_fwd2_kernel<NK>), g2, dim3(256), 0, s, (const bf16_t*)ab, w, (bf16_t*)h, (bf16_t*)hm, mean, rstd, rows, eps)
     if (nv == 1) FF2(1); else if (nv == 2) FF2(2); else if (nv == 3) FF2(3); else FF2(4);
@@ -540,14 +566,15 @@ extern "C" int muse_ffn_mid_bwd(const void* dhm, const void* h, const void* ab, 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((rows + FFN_ROWS - 1) / FFN_ROWS);
   const int nv = (inter + 1023) / 1024;
-  if (ffn_mid_wide_ok(dtype, inter, 1) && !((((uintptr_t)dhm) | ((uintptr_t)h) | ((uintptr_t)ab) | ((uintptr_t)dab) | ((uintptr_t)w) | ((uintptr_t)dw_partial)) & 15)) {
+  if (h && ffn_mid_wide_ok(dtype, inter, 1) && !((((uintptr_t)dhm) | ((uintptr_t)h) | ((uintptr_t)ab) | ((uintptr_t)dab) | ((uintptr_t)w) | ((uintptr_t)dw_partial)) & 15)) {
     const dim3 g2((grid.x + 1) / 2);
 #define FB2(NK) hipLaunchKernelGGL((ffn_mid_bwd2_kernel<NK>), g2, dim3(256), 0, s, (const bf16_t*)dhm, (const bf16_t*)h, (const bf16_t*)ab, w, mean, rstd, (bf16_t*)dab, dw_partial, rows)
     if (nv == 1) FB2(1); else if (nv == 2) FB2(2); else if (nv == 3) FB2(3); else FB2(4);
 #undef FB2
     return (int)hipGetLastError();
   }
-#define FB(T, NV) hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, NV>), grid, dim3(256), 0, s, (const T*)dhm, (const T*)h, (const T*)ab, w, mean, rstd, (T*)dab, dw_partial, rows, inter)
+#define FB(T, NV) do { if (h) hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, NV, false>), grid, dim3(256), 0, s, (const T*)dhm, (const T*)h, (const T*)ab, w, mean, rstd, (T*)dab, dw_partial, rows, inter); \
+                       else hipLaunchKernelGGL((ffn_mid_bwd_kernel<T, NV, true>), grid, dim3(256), 0, s, (const T*)dhm, (const T*)nullptr, (const T*)ab, w, mean, rstd, (T*)dab, dw_partial, rows, inter); } while (0)
   if (dtype == MUSE_F32) { if (nv == 1) FB(float, 1); else if (nv == 2) FB(float, 2); else if (nv == 3) FB(float, 3); else FB(float, 4); }
   else { if (nv == 1) FB(bf16_t, 1); else if (nv == 2) FB(bf16_t, 2); else if (nv == 3) FB(bf16_t, 3); else FB(bf16_t, 4); }
 #undef FB

@@ -441,7 +441,9 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             x1, mu_p, rs_p = ops.layernorm_fwd(ao, w_post, eps, torch.float32, residual=x)   # x + LN(attn)  (:882-884)
             ln2, mu2, rs2 = ops.layernorm_fwd(x1, w_pre, eps, cd)
             ab = ops.linear(ln2, w_01)
-            h, hm, mu_m, rs_m = ops.ffn_mid_fwd(ab, w_mid, eps)   # gelu(a)*b and the NormFormer mid-LN in one pass (:789-797)
+            # gelu(a)*b and the NormFormer mid-LN in one pass (:789-797); bf16 mode: the GLU product h is not kept for backward (it is
+            # recomputed there from ab with the erf the GLU backward evaluates anyway: 101 MB per layer neither written nor read)
+            h, hm, mu_m, rs_m = ops.ffn_mid_fwd(ab, w_mid, eps, keep_h=(cd != torch.bfloat16))
             if pd_h > 0.0:
                 ops.dropout(hm, pd_h, seed, site(li, 1), out=hm)   # (:797) in place: only the dropped tensor is needed again (dW_o)
             x2 = ops.linear(hm, w_o2, out_dtype=torch.float32, residual=x1)                  # x + FFN(x)    (:902-903)

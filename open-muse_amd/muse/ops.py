@@ -402,33 +402,35 @@ def glu_bwd(ab, dh):
     return dab
 
 
-def ffn_mid_fwd(ab, w, eps):
-    """fused GLU + mid LayerNorm: ab [rows, 2I] -> (h, hm, mean, rstd)"""
+def ffn_mid_fwd(ab, w, eps, keep_h=True):
+    """fused GLU + mid LayerNorm: ab [rows, 2I] -> (h, hm, mean, rstd).  keep_h=False: h = gelu(a) * b is not written (h is None);
+    ffn_mid_bwd then recomputes it from ab, bit for bit."""
     require_gpu(ab, w)
     rows, two_i = ab.shape
     inter = two_i // 2
-    h = torch.empty((rows, inter), dtype=ab.dtype, device=ab.device)
-    hm = torch.empty_like(h)
+    h = torch.empty((rows, inter), dtype=ab.dtype, device=ab.device) if keep_h else None
+    hm = torch.empty((rows, inter), dtype=ab.dtype, device=ab.device)
     mean = torch.empty(rows, dtype=torch.float32, device=ab.device)
     rstd = torch.empty_like(mean)
     e0 = _prof_begin()
-    check(lib().muse_ffn_mid_fwd(ab.data_ptr(), w.data_ptr(), h.data_ptr(), hm.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    check(lib().muse_ffn_mid_fwd(ab.data_ptr(), w.data_ptr(), ptr(h), hm.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                  dt(ab), rows, inter, eps, stream()), "muse_ffn_mid_fwd")
     _prof_end(e0, "ffn_mid_fwd", _nbytes(ab, h, hm), "byte")
     return h, hm, mean, rstd
 
 
 def ffn_mid_bwd(dhm, h, ab, w, mean, rstd, dw, accumulate):
-    """fused mid-LayerNorm backward + GLU backward: -> dab [rows, 2I]; dw (+)= column sums of dhm * xhat"""
-    require_gpu(dhm, h, ab, w)
-    rows, inter = h.shape
+    """fused mid-LayerNorm backward + GLU backward: -> dab [rows, 2I]; dw (+)= column sums of dhm * xhat.  h may be None (see
+    ffn_mid_fwd keep_h=False): it is then recomputed from ab."""
+    require_gpu(dhm, ab, w)
+    rows, inter = dhm.shape
     dab = torch.empty_like(ab)
     rpb = lib().muse_ffn_mid_rows_per_block()
     nblk = (rows + rpb - 1) // rpb
-    part = torch.empty((nblk, inter), dtype=torch.float32, device=h.device)
+    part = torch.empty((nblk, inter), dtype=torch.float32, device=dhm.device)
     e0 = _prof_begin()
-    check(lib().muse_ffn_mid_bwd(dhm.data_ptr(), h.data_ptr(), ab.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                 dab.data_ptr(), part.data_ptr(), dt(h), rows, inter, stream()), "muse_ffn_mid_bwd")
+    check(lib().muse_ffn_mid_bwd(dhm.data_ptr(), ptr(h), ab.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 dab.data_ptr(), part.data_ptr(), dt(dhm), rows, inter, stream()), "muse_ffn_mid_bwd")
     _colsum_or_defer(part, dw, nblk, inter, accumulate)
     _prof_end(e0, "ffn_mid_bwd", _nbytes(dhm, h, ab, dab), "byte")
     return dab
