@@ -83,6 +83,18 @@ int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t 
                        const float* mean, const float* rstd, const float* dres, void* dx, int32_t dx_dtype,
                        void* dx_bf16, float* dw_partial, int32_t nblk, int32_t rows, int32_t cols, void* stream);
 int muse_layernorm_bwd_nblk(int32_t rows);
+/* The two back-to-back LayerNorms of a NormFormer layer (muse/modeling_transformer.py:882-884 then :785-789) in one pass:
+ *   fwd: x1 = x + LN(ao) * w_post (f32) ; ln2 = LN(x1) * w_pre (bf16); statistics of both rows.   ao bf16 [rows, cols], cols <= 1024.
+ *   bwd: dx1 = LN_pre'(dln2) + dres (f32) ; dao = LN_post'(dx1) (bf16); dw partials [nblk, cols] for both weights
+ *        (nblk = muse_layernorm_bwd_nblk(rows), reduced by muse_colsum).
+ * Bit-identical to two muse_layernorm_fwd / _bwd calls; saves the write + re-read of x1 / dx1. */
+int muse_layernorm_pair_fwd(const void* ao, const float* x, const float* w_post, const float* w_pre, float* x1, void* ln2,
+                            float* mean_post, float* rstd_post, float* mean_pre, float* rstd_pre, int32_t rows, int32_t cols,
+                            float eps, void* stream);
+int muse_layernorm_pair_bwd(const void* dln2, const float* x1, const float* w_pre, const float* mean_pre, const float* rstd_pre,
+                            const float* dres, const void* ao, const float* w_post, const float* mean_post, const float* rstd_post,
+                            float* dx1, void* dao, float* dw_partial_pre, float* dw_partial_post, int32_t nblk, int32_t rows,
+                            int32_t cols, void* stream);
 /* out[c] (+)= sum_r in[r, c], f32 */
 int muse_colsum(const float* in, float* out, int32_t rows, int32_t cols, int32_t accumulate, void* stream);
 

@@ -198,6 +198,213 @@ extern "C" int muse_layernorm_bwd(const void* dy, int32_t dy_dtype, const void* 
 }
 
 // =================================================================================================================
+// The two back-to-back LayerNorms of a NormFormer layer (muse/modeling_transformer.py:882-884, :785-789) as ONE pass per direction:
+//   forward : x1 = x + LN(ao) * w_post ;  ln2 = LN(x1) * w_pre            (ao bf16, x / x1 f32, ln2 bf16)
+//   backward: dx1 = LN_pre'(dln2) + dres ;  dao = LN_post'(dx1)            (dx1 f32 stays the residual gradient, dao bf16)
+// Same arithmetic in the same order as two muse_layernorm_fwd / _bwd calls (bit-identical, tested); what goes away is the write of
+// x1 / dx1 followed by its immediate re-read by the second kernel (50 MB each way per layer at config B) and one launch each.
+// One wave per row with the row in registers (cols <= 256 * NIT).
+// =================================================================================================================
+template <int NIT>
+__global__ __launch_bounds__(256) void ln_pair_fwd_kernel(const bf16_t* __restrict__ ao, const float* __restrict__ x,
+                                                          const float* __restrict__ w_post, const float* __restrict__ w_pre,
+                                                          float* __restrict__ x1, bf16_t* __restrict__ ln2, float* __restrict__ mean_p,
+                                                          float* __restrict__ rstd_p, float* __restrict__ mean_2, float* __restrict__ rstd_2,
+                                                          int rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[NIT][4];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < cols) { V4<bf16_t>::load(ao + (long)row * cols + c, v[it]); s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]); }
+  }
+  float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[it][j] - mean; q = fmaf(d, d, q); }
+    }
+  }
+  float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+  if (lane == 0) { mean_p[row] = mean; rstd_p[row] = rstd; }
+  s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < cols) {
+      float g[4], r[4];
+      V4<float>::load(w_post + c, g); V4<float>::load(x + (long)row * cols + c, r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[it][j] = __fadd_rn((v[it][j] - mean) * rstd * g[j], r[j]);   // LN output rounded, THEN the residual (no fma): what ln_fwd_kernel and torch do
+      V4<float>::store(x1 + (long)row * cols + c, v[it]);
+      s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+    }
+  }
+  mean = wave_sum(s) / (float)cols;
+  q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[it][j] - mean; q = fmaf(d, d, q); }
+    }
+  }
+  rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+  if (lane == 0) { mean_2[row] = mean; rstd_2[row] = rstd; }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < cols) {
+      float g[4], o[4];
+      V4<float>::load(w_pre + c, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[it][j] - mean) * rstd * g[j];
+      V4<bf16_t>::store(ln2 + (long)row * cols + c, o);
+    }
+  }
+}
+
+template <int NIT>
+__global__ __launch_bounds__(256, 4) void ln_pair_bwd_kernel(const bf16_t* __restrict__ dln2, const float* __restrict__ x1,
+                                                          const float* __restrict__ w_pre, const float* __restrict__ mean_2,
+                                                          const float* __restrict__ rstd_2, const float* __restrict__ dres,
+                                                          const bf16_t* __restrict__ ao, const float* __restrict__ w_post,
+                                                          const float* __restrict__ mean_p, const float* __restrict__ rstd_p,
+                                                          float* __restrict__ dx1, bf16_t* __restrict__ dao, float* __restrict__ dwp_pre,
+                                                          float* __restrict__ dwp_post, int rows, int cols) {
+  __shared__ float red[4][NIT * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dw_pre[NIT][4], dw_post[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dw_pre[it][j] = 0.f; dw_post[it][j] = 0.f; }
+  const int rbeg = blockIdx.x * LN_BWD_ROWS + wave * (LN_BWD_ROWS / 4);
+#pragma unroll 1
+  for (int rr = 0; rr < LN_BWD_ROWS / 4; ++rr) {
+    const int row = rbeg + rr;
+    if (row >= rows) break;
+    float o[NIT][4];
+    {   // ---- dx1 = LN_pre'(dln2) + dres  (ln_bwd_kernel<bf16, float, float> with dres)
+      const float mu = mean_2[row], rs = rstd_2[row];
+      float s1 = 0.f, s2 = 0.f;
+      float gk[NIT][4], xh[NIT][4];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < cols) {
+          float d[4], v[4], g[4];
+          V4<bf16_t>::load(dln2 + (long)row * cols + c, d); V4<float>::load(x1 + (long)row * cols + c, v); V4<float>::load(w_pre + c, g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            xh[it][j] = (v[j] - mu) * rs;
+            gk[it][j] = d[j] * g[j];
+            s1 += gk[it][j];
+            s2 = fmaf(gk[it][j], xh[it][j], s2);
+            dw_pre[it][j] = fmaf(d[j], xh[it][j], dw_pre[it][j]);
+          }
+        }
+      }
+      const float c1 = wave_sum(s1) / (float)cols, c2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < cols) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[it][j] = rs * (gk[it][j] - c1 - xh[it][j] * c2);
+          if (dres) { float r[4]; V4<float>::load(dres + (long)row * cols + c, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[it][j] += r[j]; }
+          V4<float>::store(dx1 + (long)row * cols + c, o[it]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the second phase's loads out of the first one (136 -> fewer VGPRs: this kernel lives on occupancy)
+    {   // ---- dao = LN_post'(dx1)  (ln_bwd_kernel<float, bf16, bf16>, dy = the dx1 just computed)
+      const float mu = mean_p[row], rs = rstd_p[row];
+      float s1 = 0.f, s2 = 0.f;
+      float gk[NIT][4], xh[NIT][4];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < cols) {
+          float v[4], g[4];
+          V4<bf16_t>::load(ao + (long)row * cols + c, v); V4<float>::load(w_post + c, g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = o[it][j];
+            xh[it][j] = (v[j] - mu) * rs;
+            gk[it][j] = d * g[j];
+            s1 += gk[it][j];
+            s2 = fmaf(gk[it][j], xh[it][j], s2);
+            dw_post[it][j] = fmaf(d, xh[it][j], dw_post[it][j]);
+          }
+        }
+      }
+      const float c1 = wave_sum(s1) / (float)cols, c2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < cols) {
+          float r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[j] = rs * (gk[it][j] - c1 - xh[it][j] * c2);
+          V4<bf16_t>::store(dao + (long)row * cols + c, r);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave][it * 256 + lane * 4 + j] = pass ? dw_post[it][j] : dw_pre[it][j];
+    __syncthreads();
+    float* dwp = pass ? dwp_post : dwp_pre;
+    for (int c = threadIdx.x; c < cols; c += 256)
+      dwp[(long)blockIdx.x * cols + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  }
+}
+
+extern "C" int muse_layernorm_pair_fwd(const void* ao, const float* x, const float* w_post, const float* w_pre, float* x1, void* ln2,
+                                       float* mean_post, float* rstd_post, float* mean_pre, float* rstd_pre, int32_t rows,
+                                       int32_t cols, float eps, void* stream) {
+  if (cols % 4 || cols > 1024) return MUSE_ERR_UNSUPPORTED;
+  if (rows <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((rows + 3) / 4);
+#define LPF(N) hipLaunchKernelGGL(ln_pair_fwd_kernel<N>, grid, dim3(256), 0, s, (const bf16_t*)ao, x, w_post, w_pre, x1, (bf16_t*)ln2, \
+                                  mean_post, rstd_post, mean_pre, rstd_pre, rows, cols, eps)
+  if (cols <= 256) LPF(1); else if (cols <= 512) LPF(2); else if (cols <= 768) LPF(3); else LPF(4);
+#undef LPF
+  return (int)hipGetLastError();
+}
+
+extern "C" int muse_layernorm_pair_bwd(const void* dln2, const float* x1, const float* w_pre, const float* mean_pre,
+                                       const float* rstd_pre, const float* dres, const void* ao, const float* w_post,
+                                       const float* mean_post, const float* rstd_post, float* dx1, void* dao, float* dw_partial_pre,
+                                       float* dw_partial_post, int32_t nblk, int32_t rows, int32_t cols, void* stream) {
+  if (cols % 4 || cols > 1024) return MUSE_ERR_UNSUPPORTED;
+  if (rows <= 0) return 0;
+  if (nblk != (rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS) return MUSE_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+#define LPB(N) hipLaunchKernelGGL(ln_pair_bwd_kernel<N>, dim3(nblk), dim3(256), 0, s, (const bf16_t*)dln2, x1, w_pre, mean_pre, rstd_pre, \
+                                  dres, (const bf16_t*)ao, w_post, mean_post, rstd_post, dx1, (bf16_t*)dao, dw_partial_pre, dw_partial_post, rows, cols)
+  if (cols <= 256) LPB(1); else if (cols <= 512) LPB(2); else if (cols <= 768) LPB(3); else LPB(4);
+#undef LPB
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
 // Fused middle of the NormFormer GLU MLP (muse/modeling_transformer.py:789-797):
 //   forward : h = gelu(a) * b ; hm = LayerNorm(h) * w          (ab = [rows, 2I], a first)   - one pass over ab
 //   backward: dh = LN'(dhm) ; dab = (dh * b * gelu'(a), dh * gelu(a)) ; dw partials          - dh never touches HBM

@@ -52,6 +52,8 @@ SIGNATURES = {
     "muse_layernorm_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                            c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "muse_layernorm_bwd_nblk": [c_int],
+    "muse_layernorm_pair_fwd": [c_void_p] * 10 + [c_int, c_int, c_float, c_void_p],
+    "muse_layernorm_pair_bwd": [c_void_p] * 14 + [c_int, c_int, c_int, c_void_p],
     "muse_colsum": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "muse_softmax_fwd": [c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],
     "muse_softmax_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],

@@ -438,8 +438,11 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 ops.gemm(Pd, qkv, ctx, S, hd, S, la=0, lb=1, lda=Sp, ldb=3 * H, ldc=H, b_off=2 * H, batch=B * nh, zdiv=nh,
                          sA=(nh * S * Sp, S * Sp), sB=(S * 3 * H, hd), sC=(S * H, hd))
             ao = ops.linear(ctx, w_out)
-            x1, mu_p, rs_p = ops.layernorm_fwd(ao, w_post, eps, torch.float32, residual=x)   # x + LN(attn)  (:882-884)
-            ln2, mu2, rs2 = ops.layernorm_fwd(x1, w_pre, eps, cd)
+            if ops.layernorm_pair_ok(ao, x, cd, 1):   # both LayerNorms in one pass (bit-identical to the two calls below)
+                x1, mu_p, rs_p, ln2, mu2, rs2 = ops.layernorm_pair_fwd(ao, x, w_post, w_pre, eps)
+            else:
+                x1, mu_p, rs_p = ops.layernorm_fwd(ao, w_post, eps, torch.float32, residual=x)   # x + LN(attn)  (:882-884)
+                ln2, mu2, rs2 = ops.layernorm_fwd(x1, w_pre, eps, cd)
             ab = ops.linear(ln2, w_01)
             # gelu(a)*b and the NormFormer mid-LN in one pass (:789-797); bf16 mode: the GLU product h is not kept for backward (it is
             # recomputed there from ab with the erf the GLU backward evaluates anyway: 101 MB per layer neither written nor read)
@@ -600,10 +603,14 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             dab = ops.ffn_mid_bwd(dhm, s["h"], s["ab"], w_mid, s["mu_m"], s["rs_m"], view(GW, b0 + 9, (I,)), acc[b0 + 9])
             wgrad(dab, s["ln2"], view(GW, b0 + 7, (2 * I, H)), acc[b0 + 7])
             dln2 = dgrad(dab, w_01, b0 + 7)
-            dx1 = ops.layernorm_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], torch.float32, view(GW, b0 + 6, (H,)),
-                                    acc[b0 + 6], dres=dx)
-            # attention
-            dao = ops.layernorm_bwd(dx1, s["ao"], w_post, s["mu_p"], s["rs_p"], cd, view(GW, b0 + 5, (H,)), acc[b0 + 5])
+            if ops.layernorm_pair_ok(s["ao"], s["x1"], cd, 2) and dln2.dtype == torch.bfloat16:
+                dx1, dao = ops.layernorm_pair_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], dx, s["ao"], w_post, s["mu_p"], s["rs_p"],
+                                                  view(GW, b0 + 6, (H,)), acc[b0 + 6], view(GW, b0 + 5, (H,)), acc[b0 + 5])
+            else:
+                dx1 = ops.layernorm_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], torch.float32, view(GW, b0 + 6, (H,)),
+                                        acc[b0 + 6], dres=dx)
+                # attention
+                dao = ops.layernorm_bwd(dx1, s["ao"], w_post, s["mu_p"], s["rs_p"], cd, view(GW, b0 + 5, (H,)), acc[b0 + 5])
             wgrad(dao, s["ctx"], view(GW, b0 + 4, (H, H)), acc[b0 + 4])
             dctx = dgrad(dao, w_out, b0 + 4)
             qkv, P = s["qkv"], s["P"]

@@ -296,6 +296,50 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None, als
     return (dx, dx2) if also_bf16 else dx
 
 
+# bit 0: fused forward pair (ln_fwd 1.74 -> 1.30 ms per step), bit 1: fused backward pair (measured SLOWER: 128 VGPRs / 4 waves per
+# SIMD against 78 / 6 of ln_bwd_kernel - 2.96 -> 3.41 ms; kept for experiments, off by default)
+LN_PAIR = int(os.environ.get("MUSE_LN_PAIR", "1"))
+
+
+def layernorm_pair_ok(ao, x, cd, direction):
+    return bool(LN_PAIR & direction) and cd == torch.bfloat16 and ao.dtype == torch.bfloat16 and x.dtype == torch.float32 and \
+        x.shape[1] % 4 == 0 and x.shape[1] <= (1024 if direction == 1 else 768)
+
+
+def layernorm_pair_fwd(ao, x, w_post, w_pre, eps):
+    """x1 = x + LN(ao) * w_post ; ln2 = LN(x1) * w_pre  ->  (x1 f32, mean_post, rstd_post, ln2 bf16, mean_pre, rstd_pre)"""
+    require_gpu(ao, x, w_post, w_pre)
+    rows, cols = x.shape
+    x1 = torch.empty_like(x)
+    ln2 = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    st = torch.empty((4, rows), dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
+    check(lib().muse_layernorm_pair_fwd(ao.data_ptr(), x.data_ptr(), w_post.data_ptr(), w_pre.data_ptr(), x1.data_ptr(), ln2.data_ptr(),
+                                        st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), rows, cols, eps, stream()),
+          "muse_layernorm_pair_fwd")
+    _prof_end(e0, "layernorm_fwd", _nbytes(ao, x, x1, ln2), "byte")
+    return x1, st[0], st[1], ln2, st[2], st[3]
+
+
+def layernorm_pair_bwd(dln2, x1, w_pre, mean_pre, rstd_pre, dres, ao, w_post, mean_post, rstd_post, dw_pre, acc_pre, dw_post, acc_post):
+    """dx1 = LN_pre'(dln2) + dres ; dao = LN_post'(dx1)  ->  (dx1 f32, dao bf16); dw_pre / dw_post (+)= their weight gradients"""
+    require_gpu(dln2, x1, ao)
+    rows, cols = x1.shape
+    dx1 = torch.empty_like(x1)
+    dao = torch.empty((rows, cols), dtype=torch.bfloat16, device=x1.device)
+    nblk = lib().muse_layernorm_bwd_nblk(rows)
+    part = torch.empty((2, nblk, cols), dtype=torch.float32, device=x1.device)
+    e0 = _prof_begin()
+    check(lib().muse_layernorm_pair_bwd(dln2.data_ptr(), x1.data_ptr(), w_pre.data_ptr(), mean_pre.data_ptr(), rstd_pre.data_ptr(), ptr(dres),
+                                        ao.data_ptr(), w_post.data_ptr(), mean_post.data_ptr(), rstd_post.data_ptr(), dx1.data_ptr(),
+                                        dao.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), nblk, rows, cols, stream()),
+          "muse_layernorm_pair_bwd")
+    _colsum_or_defer(part[0], dw_pre, nblk, cols, acc_pre)
+    _colsum_or_defer(part[1], dw_post, nblk, cols, acc_post)
+    _prof_end(e0, "layernorm_bwd", _nbytes(dln2, x1, dres, ao, dx1, dao), "byte")
+    return dx1, dao
+
+
 def softmax_(x, rows, cols, ld):
     require_gpu(x)
     check(lib().muse_softmax_fwd(x.data_ptr(), x.data_ptr(), dt(x), rows, cols, ld, stream()), "muse_softmax_fwd")

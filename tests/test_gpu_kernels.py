@@ -731,6 +731,37 @@ def test_gemm_256_matches_128_on_model_shapes(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("rows,cols", [(37, 768), (130, 512), (5, 64), (64, 1024)])
+def test_layernorm_pair_matches_two_calls(rows, cols):
+    """the fused NormFormer LayerNorm pair (x1 = x + LN(ao) w_post ; ln2 = LN(x1) w_pre, and its backward) against the two
+    muse_layernorm_fwd / _bwd calls it replaces: same operations in the same order, results equal up to fma contraction"""
+    ops = _ops()
+    eps = 1e-5
+    ao = rnd((rows, cols), 320).to(torch.bfloat16).to(DEV)
+    x = rnd((rows, cols), 321).to(DEV)
+    w_post, w_pre = (1 + 0.1 * rnd((cols,), 322)).to(DEV), (1 + 0.1 * rnd((cols,), 323)).to(DEV)
+    x1r, mu_p, rs_p = ops.layernorm_fwd(ao, w_post, eps, torch.float32, residual=x)
+    ln2r, mu2, rs2 = ops.layernorm_fwd(x1r, w_pre, eps, torch.bfloat16)
+    x1, mp, rp, ln2, m2, r2 = ops.layernorm_pair_fwd(ao, x, w_post, w_pre, eps)
+    assert torch.equal(mp, mu_p) and torch.equal(rp, rs_p), "statistics of the first LayerNorm"
+    d1 = float((x1 - x1r).abs().max())
+    assert d1 <= 1e-6 * float(x1r.abs().max()), d1           # same operations; at most the last bit (fma contraction) apart
+    assert rel_err(m2, mu2) < 1e-6 and rel_err(r2, rs2) < 1e-6
+    assert rel_err(ln2.float(), ln2r.float()) < 8e-3          # bf16 outputs: at most one rounding step apart
+    print(f"ln pair fwd {rows}x{cols}: max |x1 - x1_ref| = {d1:.3e}, x1 bit-equal {torch.equal(x1, x1r)}, ln2 bit-equal {torch.equal(ln2.view(torch.int16), ln2r.view(torch.int16))}")
+    if cols > 768:
+        return   # (the backward pair is built for hidden sizes up to 768)
+    dln2 = rnd((rows, cols), 324).to(torch.bfloat16).to(DEV)
+    dres = rnd((rows, cols), 325).to(DEV)
+    dw_pre_r, dw_post_r = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    dx1r = ops.layernorm_bwd(dln2, x1r, w_pre, mu2, rs2, torch.float32, dw_pre_r, False, dres=dres)
+    daor = ops.layernorm_bwd(dx1r, ao, w_post, mu_p, rs_p, torch.bfloat16, dw_post_r, False)
+    dw_pre, dw_post = torch.full((cols,), 7.0, device=DEV), torch.full((cols,), 7.0, device=DEV)
+    dx1, dao = ops.layernorm_pair_bwd(dln2, x1, w_pre, m2, r2, dres, ao, w_post, mp, rp, dw_pre, False, dw_post, False)
+    assert rel_err(dx1, dx1r) < 1e-6 and rel_err(dao.float(), daor.float()) < 1e-2     # (fma contraction may differ in the last bit)
+    assert rel_err(dw_pre, dw_pre_r) < 1e-5 and rel_err(dw_post, dw_post_r) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,inter", [(37, 64), (130, 3072), (50, 160), (20, 2048), (7, 1024), (33, 4096)])
 def test_ffn_mid_fused(dtype, rows, inter):
