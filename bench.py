@@ -25,6 +25,7 @@ The line carries
                 scripts/pre_encode.py regime), config 4 (MaskGiTUViT, seq 256 and 1024), config 5 (VQGAN encode -> decode), config A
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -349,6 +350,7 @@ def main():
             tr_ms = e0.elapsed_time(e1) / n
         lossv = float(loss)
         del step, vq, model, opt, reducer
+        gc.collect()               # (tapes and parameter views of the finished leg: later legs must not pay for a growing Python heap)
         torch.cuda.empty_cache()
         return el, lossv, prof, tr_ms
 
