@@ -292,14 +292,14 @@ def main():
 
     prof_bytes = {}
 
-    def run(cfg_name, vq_dtype, steps, warmup, profile=False, tokens_given=False):
+    def run(cfg_name, vq_dtype, steps, warmup, profile=False, tokens_given=False, inline_tokenizer=False):
         vq, model, opt, tcfg = build_models(cfg_name, vq_dtype, device, seed=1234)
         reducer = muse.GradReducer(model, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32) if distributed else None
         step = muse.TrainStep(vq, model, opt, reducer)
         px, cls = synthetic_batch(args.batch, device, seed=1000 + rank)  # different data per rank (weak scaling)
         toks = vq.get_code(px) if tokens_given else None
 
-        prefetch = not args.no_prefetch and not tokens_given
+        prefetch = not args.no_prefetch and not tokens_given and not inline_tokenizer
 
         def one():
             # prefetch: the NEXT batch's tokenizer pass is enqueued on a second stream before this batch's transformer step
@@ -400,6 +400,9 @@ def main():
         n2 = max(3, args.steps // 2)
         e2, _, _, _ = run(args.config, args.vq_dtype, n2, 2, tokens_given=True)
         extra["images_per_s_tokens_given"] = round(args.batch * n2 / e2, 1)   # pre-encoded tokens (scripts/pre_encode.py regime)
+        if not args.no_prefetch:   # the same step with each batch encoded inline, in the reference loop's order (no second stream)
+            e2, _, _, _ = run(args.config, args.vq_dtype, n2, 2, inline_tokenizer=True)
+            extra["images_per_s_inline_tokenizer"] = round(args.batch * n2 / e2, 1)
         other = "A" if args.config == "B" else "B"
         for cfgn, vqd in [(args.config, d) for d in ("f32", "bf16") if d != args.vq_dtype] + [(other, args.vq_dtype)]:
             e2, _, _, _ = run(cfgn, vqd, n2, 2)
