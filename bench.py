@@ -105,6 +105,21 @@ def vqgan_roundtrip(device, bs):
     return out
 
 
+def leg_isolated(spec, fallback):
+    """One secondary leg in a process of its own (`bench.py --leg SPEC` prints a JSON dict).  Late in this long-lived process the same
+    legs measure 15-25 % slower than in a fresh one (tokens-given step: 46 ms here, 38.4 ms fresh - scripts/exp/host_bound.py); a
+    training job is a fresh process, so that is what each leg gets.  `fallback()` computes it in-process if the child fails."""
+    import subprocess
+    try:
+        torch.cuda.empty_cache()
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", spec] + (["--no-prefetch"] if "--no-prefetch" in sys.argv else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        return json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    except Exception:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
+        return fallback()
+
+
 def uvit_leg_isolated(device, batch, seq, steps):
     """uvit_leg in a fresh process.  The U-ViT step is ~4500 small launches; at the end of this long-lived process (allocator state,
     Python heap of all the earlier legs) the same leg measured 205 ms per step against 163 ms in a process of its own, which is what a
@@ -112,8 +127,9 @@ def uvit_leg_isolated(device, batch, seq, steps):
     import subprocess
     try:
         torch.cuda.empty_cache()
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--uvit-leg", f"{batch},{seq},{steps}"], capture_output=True, text=True,
-                           timeout=600)
+                           timeout=600, env=env)
         line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
@@ -268,6 +284,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (config A / 4 / 5, tokenizer variants)")
     ap.add_argument("--uvit-leg", default=None, help="internal: run one config-4 leg 'batch,seq,steps' and print its JSON")
+    ap.add_argument("--leg", default=None, help="internal: run one secondary leg ('run,<cfg>,<vq>,<mode>,<steps>,<batch>' | 'vqgan,<batch>' | "
+                                                "'taming,<batch>') and print its JSON")
     args = ap.parse_args()
     if args.uvit_leg:
         b, sq, st = (int(x) for x in args.uvit_leg.split(","))
@@ -354,6 +372,21 @@ def main():
         torch.cuda.empty_cache()
         return el, lossv, prof, tr_ms
 
+    def run_leg(cfgn, vqd, mode, n, batch):
+        e2, _, _, _ = run(cfgn, vqd, n, 2, tokens_given=(mode == "tokens"), inline_tokenizer=(mode == "inline"))
+        return {"images_per_s": round(batch * n / e2, 1)}
+
+    if args.leg:
+        f = args.leg.split(",")
+        if f[0] == "run":
+            args.batch = int(f[5])
+            print(json.dumps(run_leg(f[1], f[2], f[3], int(f[4]), args.batch)))
+        elif f[0] == "vqgan":
+            print(json.dumps(vqgan_roundtrip(device, int(f[1]))))
+        elif f[0] == "taming":
+            print(json.dumps(taming_leg(device, int(f[1]))))
+        return
+
     el, lossv, prof, tr_ms = run(args.config, args.vq_dtype, args.steps, args.warmup, profile=True)
     ms = el / args.steps * 1e3
     value = args.batch * world * args.steps / el
@@ -398,17 +431,17 @@ def main():
              "hbm_kernel_ms_in_instrumented_step": round(sum(v[1] for v in hbm.values()), 2)}
     if world == 1 and not args.no_extra:
         n2 = max(3, args.steps // 2)
-        e2, _, _, _ = run(args.config, args.vq_dtype, n2, 2, tokens_given=True)
-        extra["images_per_s_tokens_given"] = round(args.batch * n2 / e2, 1)   # pre-encoded tokens (scripts/pre_encode.py regime)
+
+        def leg(cfgn, vqd, mode):
+            return leg_isolated(f"run,{cfgn},{vqd},{mode},{n2},{args.batch}", lambda: run_leg(cfgn, vqd, mode, n2, args.batch))["images_per_s"]
+        extra["images_per_s_tokens_given"] = leg(args.config, args.vq_dtype, "tokens")   # pre-encoded tokens (scripts/pre_encode.py regime)
         if not args.no_prefetch:   # the same step with each batch encoded inline, in the reference loop's order (no second stream)
-            e2, _, _, _ = run(args.config, args.vq_dtype, n2, 2, inline_tokenizer=True)
-            extra["images_per_s_inline_tokenizer"] = round(args.batch * n2 / e2, 1)
+            extra["images_per_s_inline_tokenizer"] = leg(args.config, args.vq_dtype, "inline")
         other = "A" if args.config == "B" else "B"
         for cfgn, vqd in [(args.config, d) for d in ("f32", "bf16") if d != args.vq_dtype] + [(other, args.vq_dtype)]:
-            e2, _, _, _ = run(cfgn, vqd, n2, 2)
-            extra[f"images_per_s_config{cfgn}_vq{vqd}"] = round(args.batch * n2 / e2, 1)
-        extra.update(vqgan_roundtrip(device, args.batch))
-        extra.update(taming_leg(device, args.batch))
+            extra[f"images_per_s_config{cfgn}_vq{vqd}"] = leg(cfgn, vqd, "plain")
+        extra.update(leg_isolated(f"vqgan,{args.batch}", lambda: vqgan_roundtrip(device, args.batch)))
+        extra.update(leg_isolated(f"taming,{args.batch}", lambda: taming_leg(device, args.batch)))
         # config 4 at batch sizes that use the 288 GB (cc12m_uvit_clip.yaml trains 64 per GPU x 2 accumulation steps): the fixed
         # per-step cost (AdamW over 729 M parameters, ~500 small launches) is amortised - seq 256: 561 TF/s at 64, 641 at 128;
         # seq 1024: 512 TF/s at 16, 626 at 64 (159 GiB)
