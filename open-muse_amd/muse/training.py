@@ -9,6 +9,7 @@
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -142,6 +143,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._m = self._v = None
         self._step = 0
         self._table = self._chunk_first = self._table_key = self._stage = None   # per-tensor mode: device table of muse_adamw_multi
+        self._ranges_done = self._ranges_done_live = None                        # (step, [(begin, end), ...]) applied inside backward
         self.grad_scale = 1.0   # multiplied into the gradient inside the kernel (GradReducer sets 1/world for SUM reductions)
 
     def _flat_grad_checked(self, model, params):
@@ -179,12 +181,63 @@ class FusedAdamW(torch.optim.Optimizer):
         g = self._flat_grad_checked(model, grp["params"])
         self._ensure_flat_state(flat)
         self._step += 1
-        lr = float(grp["lr"])
         shadow = model._flat_c if model._flat_c is not None and model._flat_c.device == flat.device else None
-        ops.adamw_flat(flat, g, self._m, self._v, shadow, lr, grp["betas"][0], grp["betas"][1], grp["eps"],
-                       grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
+        done = self._ranges_done
+        self._ranges_done = None
+        if done is not None and done[0] == self._step:
+            # backward already applied this step's update range by range (begin_step_in_backward); cover what it did not report
+            covered = sorted(done[1])
+            pos = 0
+            for b, e in covered:
+                if b > pos:
+                    self._apply(model, pos, b, shadow)
+                pos = max(pos, e)
+            if pos < flat.numel():
+                self._apply(model, pos, flat.numel(), shadow)
+        else:
+            self._apply(model, 0, flat.numel(), shadow)
         model._note_shadow_refreshed(shadow is not None)
         return loss
+
+    def _apply(self, model, b, e, shadow):
+        grp = self.param_groups[0]
+        flat, g = model.flat_params(), model.flat_grads()
+        ops.adamw_flat(flat[b:e], g[b:e], self._m[b:e], self._v[b:e], None if shadow is None else shadow[b:e], float(grp["lr"]),
+                       grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], self._step_for_apply,
+                       grad_scale=float(self.grad_scale))
+
+    @property
+    def _step_for_apply(self):
+        d = self._ranges_done_live
+        return d[0] if d is not None else self._step
+
+    def begin_step_in_backward(self, model):
+        """Arm the optimizer to apply THIS step's update inside backward: every time backward reports a finished range of the flat
+        gradient buffer (model.grad_ready_hook) the AdamW kernel runs on that slice, on the stream the report comes from (the
+        weight-gradient stream) - the HBM-bound update hides behind the MFMA-bound dX chain of the earlier layers instead of
+        following backward.  Element-wise identical to one launch over the whole buffer.  The following step() only advances the
+        step count and covers ranges backward did not report.  Valid when nothing sits between backward and step(): no gradient
+        clipping, no gradient accumulation, no all-reduce (muse.TrainStep checks this and arms it)."""
+        flat = model.flat_params()
+        self._ensure_flat_state(flat)
+        if any((o * 4) % 16 for o in model._offsets):
+            return False                      # (slices must keep the kernel's 16-byte alignment)
+        self._ranges_done_live = (self._step + 1, [])
+        shadow = model.compute_weights(torch.bfloat16) if model._resolve_cd() == torch.bfloat16 else None
+
+        def hook(begin, end):
+            live = self._ranges_done_live
+            if live is None or end <= begin:
+                return
+            self._apply(model, begin, end, model._flat_c if shadow is not None else None)
+            live[1].append((begin, end))
+        model.direct_grad = True
+        model.grad_ready_hook = hook
+        return True
+
+    def end_step_in_backward(self, model):
+        model.grad_ready_hook = None
+        self._ranges_done, self._ranges_done_live = self._ranges_done_live, None
 
     def _ensure_flat_state(self, flat):
         if self._m is None:
@@ -497,6 +550,7 @@ class TrainStep:
         self._pf = None          # (pixel tensor, tokens, ready event) of the prefetched batch
         self._pf_stream = None
         self.compute_priority = -1   # stream priority of the step while a prefetch is in flight (None: stay on the caller's stream)
+        self.optimizer_in_backward = os.environ.get("MUSE_OPT_IN_BACKWARD", "1") != "0"
         self._hp_stream, self._in_hp = None, False
 
     @torch.no_grad()
@@ -552,7 +606,15 @@ class TrainStep:
             self.vq_model, pixel_values, class_ids, self.model.config.mask_token_id, self.min_masking_rate, timesteps, noise,
             image_tokens=image_tokens)
         _, loss = self.model(input_ids=input_ids, labels=labels, label_smoothing=self.label_smoothing)
-        loss.backward()
+        # AdamW inside backward (FusedAdamW.begin_step_in_backward): only when nothing sits between the two - no reducer here
+        armed = (self.optimizer_in_backward and self.reducer is None and isinstance(self.optimizer, FusedAdamW)
+                 and getattr(self.model, "wgrad_stream", False) and hasattr(self.model, "grad_ready_hook")
+                 and self.model._resolve_cd() == torch.bfloat16 and self.optimizer.begin_step_in_backward(self.model))
+        try:
+            loss.backward()
+        finally:
+            if armed:
+                self.optimizer.end_step_in_backward(self.model)
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()

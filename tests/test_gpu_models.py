@@ -393,7 +393,8 @@ def test_train_step_end_to_end_vs_oracle():
 
 def test_train_step_streams_match_serial():
     """The two concurrency features of the step change scheduling, not results: (a) next-batch token prefetch on a second stream
-    (TrainStep next_pixel_values) and (b) weight-gradient GEMMs on a side stream (MaskGitTransformer.wgrad_stream).  Three steps
+    (TrainStep next_pixel_values), (b) weight-gradient GEMMs on a side stream (MaskGitTransformer.wgrad_stream) and (c) the AdamW
+    update applied inside backward (FusedAdamW.begin_step_in_backward).  Three steps
     over two alternating batches with both on == the same three steps run serially, bit for bit (bf16 compute mode, the mode
     the side stream is used in)."""
     import muse
@@ -411,12 +412,14 @@ def test_train_step_streams_match_serial():
         m.wgrad_stream = concurrent
         opt = muse.FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
         step = muse.TrainStep(v, m, opt)
+        step.optimizer_in_backward = concurrent      # (c) AdamW applied range by range inside backward, on the weight-gradient stream
         losses = []
         for i in range(3):
             nxt = pxs[(i + 1) % 2] if concurrent else None
             losses.append(step(pxs[i % 2], cls, t, nz, next_pixel_values=nxt)[0])
             if concurrent:
                 assert step._pf is not None and step._pf[0] is pxs[(i + 1) % 2]
+                assert opt._ranges_done is None and opt._step == i + 1      # step() consumed the ranges backward had applied
         torch.cuda.synchronize()
         return torch.stack(losses).cpu(), m.flat_params().clone().cpu()
 
