@@ -116,7 +116,8 @@ def leg_isolated(spec, fallback):
         cmd = [sys.executable, os.path.abspath(__file__), "--leg", spec] + (["--no-prefetch"] if "--no-prefetch" in sys.argv else [])
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
         return json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
-    except Exception:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
+    except Exception as e:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
+        print(f"bench: leg {spec!r} fell back to this process ({type(e).__name__}: {e})", file=sys.stderr)
         return fallback()
 
 

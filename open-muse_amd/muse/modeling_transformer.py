@@ -374,7 +374,6 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         return out
 
     def _run_forward(self, input_ids, labels, label_smoothing, need_grad):
-        ops.COLSUM_SINK = None   # (a backward that died half way must not leave column sums queued for ever)
         cd = self._resolve_cd()
         H, I, nh, V = self.hidden_size, self.intermediate_size, self.num_attention_heads, self.output_size
         hd = H // nh
@@ -532,13 +531,14 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         # main chain leaves idle (dX GEMMs with 195 tiles on 256 CUs, kernel tails, the HBM-bound LayerNorm / GLU backward).
         main = torch.cuda.current_stream(dev)
         side = self._wgrad_side_stream(dev) if (self.wgrad_stream and cd == torch.bfloat16) else None
+        csq = [] if side is not None else None     # column sums of the LayerNorm / GLU weight gradients, launched on the side stream
 
         def wgrad(dy, x, dw, accumulate, **kw):
             if side is None:
                 return ops.linear_wgrad(dy, x, dw, accumulate, **kw)
             side.wait_stream(main)           # dy (and on the first use x) were produced on the main stream
             with torch.cuda.stream(side):
-                ops.flush_colsums()          # LayerNorm / GLU weight-gradient column sums queued since the last call
+                ops.flush_colsums(csq)       # LayerNorm / GLU weight-gradient column sums queued since the last call
                 ops.linear_wgrad(dy, x, dw, accumulate, **kw)
             dy.record_stream(side)           # the caching allocator must not hand these blocks out while the side stream reads them
             x.record_stream(side)
@@ -551,10 +551,8 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 else:   # the range is complete once both streams have passed this point
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        ops.flush_colsums()
+                        ops.flush_colsums(csq)
                         self.grad_ready_hook(off[i0], end)
-        if side is not None:
-            ops.COLSUM_SINK = []
 
         # ---- loss / head ----------------------------------------------------------------------------------------
         dlog = None
@@ -578,13 +576,13 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             ops.gemm(dlog, view(Wt, t0 + 3, (H, V)), dgl, T, H, V, la=0, lb=0, lda=Vp, ldb=V, ldc=H)
         else:
             ops.gemm(dlog, w_log, dgl, T, H, V, la=0, lb=1, lda=Vp, ldb=H, ldc=H)
-        dg = ops.layernorm_bwd(dgl, sv["g"], w_mln, sv["mu_g"], sv["rs_g"], cd, view(GW, t0 + 2, (H,)), acc[t0 + 2])
+        dg = ops.layernorm_bwd(dgl, sv["g"], w_mln, sv["mu_g"], sv["rs_g"], cd, view(GW, t0 + 2, (H,)), acc[t0 + 2], colsum_queue=csq)
         dd = ops.gelu_bwd(sv["d"], dg)
         wgrad(dd, sv["xf"], view(GW, t0 + 1, (H, H)), acc[t0 + 1])
         dxf = dgrad(dd, w_dense, t0 + 1)
         bf = cd == torch.bfloat16   # bf16 mode: LayerNorm backward also writes the bf16 copy of dx the next layer's GEMMs read
         dx = ops.layernorm_bwd(dxf, sv["x_last"], w_enc, sv["mu_e"], sv["rs_e"], torch.float32, view(GW, t0 + 0, (H,)),
-                               acc[t0 + 0], also_bf16=bf)
+                               acc[t0 + 0], also_bf16=bf, colsum_queue=csq)
         dx, dxc = dx if bf else (dx, dx)
         ready(t0, t0 + 4)
 
@@ -600,17 +598,17 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             dhm = dgrad(dxc, w_o2, b0 + 10)
             if pd_h > 0.0:
                 ops.dropout(dhm, pd_h, seed, site(li, 1), out=dhm)
-            dab = ops.ffn_mid_bwd(dhm, s["h"], s["ab"], w_mid, s["mu_m"], s["rs_m"], view(GW, b0 + 9, (I,)), acc[b0 + 9])
+            dab = ops.ffn_mid_bwd(dhm, s["h"], s["ab"], w_mid, s["mu_m"], s["rs_m"], view(GW, b0 + 9, (I,)), acc[b0 + 9], colsum_queue=csq)
             wgrad(dab, s["ln2"], view(GW, b0 + 7, (2 * I, H)), acc[b0 + 7])
             dln2 = dgrad(dab, w_01, b0 + 7)
             if ops.layernorm_pair_ok(s["ao"], s["x1"], cd, 2) and dln2.dtype == torch.bfloat16:
                 dx1, dao = ops.layernorm_pair_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], dx, s["ao"], w_post, s["mu_p"], s["rs_p"],
-                                                  view(GW, b0 + 6, (H,)), acc[b0 + 6], view(GW, b0 + 5, (H,)), acc[b0 + 5])
+                                                  view(GW, b0 + 6, (H,)), acc[b0 + 6], view(GW, b0 + 5, (H,)), acc[b0 + 5], colsum_queue=csq)
             else:
                 dx1 = ops.layernorm_bwd(dln2, s["x1"], w_pre, s["mu2"], s["rs2"], torch.float32, view(GW, b0 + 6, (H,)),
-                                        acc[b0 + 6], dres=dx)
+                                        acc[b0 + 6], dres=dx, colsum_queue=csq)
                 # attention
-                dao = ops.layernorm_bwd(dx1, s["ao"], w_post, s["mu_p"], s["rs_p"], cd, view(GW, b0 + 5, (H,)), acc[b0 + 5])
+                dao = ops.layernorm_bwd(dx1, s["ao"], w_post, s["mu_p"], s["rs_p"], cd, view(GW, b0 + 5, (H,)), acc[b0 + 5], colsum_queue=csq)
             wgrad(dao, s["ctx"], view(GW, b0 + 4, (H, H)), acc[b0 + 4])
             dctx = dgrad(dao, w_out, b0 + 4)
             qkv, P = s["qkv"], s["P"]
@@ -619,7 +617,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
                 wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
                 dln1 = dgrad(dqkv, w_qkv, b0 + 1)
                 dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
-                                       acc[b0 + 0], dres=dx1, also_bf16=bf and li > 0)
+                                       acc[b0 + 0], dres=dx1, also_bf16=bf and li > 0, colsum_queue=csq)
                 dx, dxc = dx if (bf and li > 0) else (dx, dx)
                 sv["layers"][li] = None
                 ready(b0, b0 + 11)
@@ -645,7 +643,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
             wgrad(dqkv, s["ln1"], view(GW, b0 + 1, (3 * H, H)), acc[b0 + 1])
             dln1 = dgrad(dqkv, w_qkv, b0 + 1)
             dx = ops.layernorm_bwd(dln1, s["x"], w_ln1, s["mu1"], s["rs1"], torch.float32, view(GW, b0 + 0, (H,)),
-                                   acc[b0 + 0], dres=dx1, also_bf16=bf and li > 0)
+                                   acc[b0 + 0], dres=dx1, also_bf16=bf and li > 0, colsum_queue=csq)
             dx, dxc = dx if (bf and li > 0) else (dx, dx)
             sv["layers"][li] = None  # free activations as we go
             ready(b0, b0 + 11)
@@ -660,8 +658,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                ops.flush_colsums()
-            ops.COLSUM_SINK = None
+                ops.flush_colsums(csq)
             main.wait_stream(side)   # the optimizer (and anything else on the main stream) sees every weight gradient
         if self.direct_grad:
             return [None] * len(params)

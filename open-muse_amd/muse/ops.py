@@ -254,31 +254,28 @@ def layernorm_fwd(x, w, eps, out_dtype, residual=None):
     return y, mean, rstd
 
 
-# The column sums that finish a LayerNorm weight gradient (per-block partials -> dw) are leaves of the backward graph.  While
-# COLSUM_SINK is a list (the model's backward sets it when it runs weight gradients on a second stream) they are queued instead of
-# launched, and flush_colsums() launches the queue on whatever stream is current - the weight-gradient stream, off the dX chain.
-COLSUM_SINK = None
-
-
-def _colsum_or_defer(part, dw, nblk, cols, accumulate):
-    if COLSUM_SINK is not None:
-        COLSUM_SINK.append((part, dw, nblk, cols, accumulate))
+# The column sums that finish a LayerNorm weight gradient (per-block partials -> dw) are leaves of the backward graph.  A caller that
+# runs weight gradients on a second stream passes `colsum_queue` (a list it owns): the sum is queued instead of launched, and
+# flush_colsums(queue) launches the queue on whatever stream is current - the weight-gradient stream, off the dX chain.
+def _colsum_or_defer(part, dw, nblk, cols, accumulate, queue):
+    if queue is not None:
+        queue.append((part, dw, nblk, cols, accumulate))
     else:
         check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, cols, 1 if accumulate else 0, stream()), "muse_colsum")
 
 
-def flush_colsums():
+def flush_colsums(queue):
     """launch the queued column sums on the current stream (the caller has ordered it behind the kernels that wrote the partials)"""
-    if not COLSUM_SINK:
+    if not queue:
         return
-    cur = torch.cuda.current_stream(COLSUM_SINK[0][0].device)
-    for part, dw, nblk, cols, accumulate in COLSUM_SINK:
+    cur = torch.cuda.current_stream(queue[0][0].device)
+    for part, dw, nblk, cols, accumulate in queue:
         check(lib().muse_colsum(part.data_ptr(), dw.data_ptr(), nblk, cols, 1 if accumulate else 0, stream()), "muse_colsum")
         part.record_stream(cur)
-    COLSUM_SINK.clear()
+    queue.clear()
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None, also_bf16=False):
+def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None, also_bf16=False, colsum_queue=None):
     """returns dx (= LN'(dy) + dres); dw (+)= column sums of dy * xhat.  also_bf16: returns (dx, bf16 copy of dx) written in the
     same pass."""
     require_gpu(dy, x, w)
@@ -291,7 +288,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx_dtype, dw, accumulate, dres=None, als
     check(lib().muse_layernorm_bwd(dy.data_ptr(), dt(dy), x.data_ptr(), dt(x), w.data_ptr(), mean.data_ptr(),
                                    rstd.data_ptr(), ptr(dres), dx.data_ptr(), dt(dx), ptr(dx2), part.data_ptr(), nblk, rows, cols,
                                    stream()), "muse_layernorm_bwd")
-    _colsum_or_defer(part, dw, nblk, cols, accumulate)
+    _colsum_or_defer(part, dw, nblk, cols, accumulate, colsum_queue)
     _prof_end(e0, "layernorm_bwd", _nbytes(dy, x, dres, dx, dx2), "byte")
     return (dx, dx2) if also_bf16 else dx
 
@@ -321,7 +318,8 @@ def layernorm_pair_fwd(ao, x, w_post, w_pre, eps):
     return x1, st[0], st[1], ln2, st[2], st[3]
 
 
-def layernorm_pair_bwd(dln2, x1, w_pre, mean_pre, rstd_pre, dres, ao, w_post, mean_post, rstd_post, dw_pre, acc_pre, dw_post, acc_post):
+def layernorm_pair_bwd(dln2, x1, w_pre, mean_pre, rstd_pre, dres, ao, w_post, mean_post, rstd_post, dw_pre, acc_pre, dw_post, acc_post,
+                       colsum_queue=None):
     """dx1 = LN_pre'(dln2) + dres ; dao = LN_post'(dx1)  ->  (dx1 f32, dao bf16); dw_pre / dw_post (+)= their weight gradients"""
     require_gpu(dln2, x1, ao)
     rows, cols = x1.shape
@@ -334,8 +332,8 @@ def layernorm_pair_bwd(dln2, x1, w_pre, mean_pre, rstd_pre, dres, ao, w_post, me
                                         ao.data_ptr(), w_post.data_ptr(), mean_post.data_ptr(), rstd_post.data_ptr(), dx1.data_ptr(),
                                         dao.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), nblk, rows, cols, stream()),
           "muse_layernorm_pair_bwd")
-    _colsum_or_defer(part[0], dw_pre, nblk, cols, acc_pre)
-    _colsum_or_defer(part[1], dw_post, nblk, cols, acc_post)
+    _colsum_or_defer(part[0], dw_pre, nblk, cols, acc_pre, colsum_queue)
+    _colsum_or_defer(part[1], dw_post, nblk, cols, acc_post, colsum_queue)
     _prof_end(e0, "layernorm_bwd", _nbytes(dln2, x1, dres, ao, dx1, dao), "byte")
     return dx1, dao
 
@@ -463,7 +461,7 @@ def ffn_mid_fwd(ab, w, eps, keep_h=True):
     return h, hm, mean, rstd
 
 
-def ffn_mid_bwd(dhm, h, ab, w, mean, rstd, dw, accumulate):
+def ffn_mid_bwd(dhm, h, ab, w, mean, rstd, dw, accumulate, colsum_queue=None):
     """fused mid-LayerNorm backward + GLU backward: -> dab [rows, 2I]; dw (+)= column sums of dhm * xhat.  h may be None (see
     ffn_mid_fwd keep_h=False): it is then recomputed from ab."""
     require_gpu(dhm, ab, w)
@@ -475,7 +473,7 @@ def ffn_mid_bwd(dhm, h, ab, w, mean, rstd, dw, accumulate):
     e0 = _prof_begin()
     check(lib().muse_ffn_mid_bwd(dhm.data_ptr(), ptr(h), ab.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                  dab.data_ptr(), part.data_ptr(), dt(dhm), rows, inter, stream()), "muse_ffn_mid_bwd")
-    _colsum_or_defer(part, dw, nblk, inter, accumulate)
+    _colsum_or_defer(part, dw, nblk, inter, accumulate, colsum_queue)
     _prof_end(e0, "ffn_mid_bwd", _nbytes(dhm, h, ab, dab), "byte")
     return dab
 
