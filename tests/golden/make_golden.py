@@ -86,6 +86,59 @@ def golden_vqgan(name, cfg, batch, seed):
     print(name, "z", z.shape, "idx", idx.shape, "rec", rec.shape, "min margin", float(out["margin"].min()))
 
 
+FULL_GRAD_KEYS = ["embed.word_embeddings.weight", "embed.position_embeddings.weight", "transformer_layers.0.attention.query.weight",
+                  "transformer_layers.0.attn_layer_norm.weight", "transformer_layers.11.ffn.wi_1.weight",
+                  "transformer_layers.12.attention.out.weight", "transformer_layers.23.ffn.wo.weight",
+                  "transformer_layers.23.post_attn_layer_norm.weight", "encoder_layer_norm.weight", "mlm_layer.to_logits.weight"]
+
+
+def golden_transformer_full(name, cfg, batch, seed, autocast=False):
+    """the BENCHED transformer (configs/imagenet.yaml: 24 layers, hidden 768, 16 heads of 48, vocab 2048, S = 257) run by the real
+    reference, f32 (and under CPU autocast-bf16).  Outputs are large (logits 2 x 257 x 2048, 230 M gradient elements), so the fixture
+    keeps the loss, per-tensor max|.| and L2 norm, and every k-th element (weights.subsample) of the logits and of ten gradients
+    spread over the depth of the stack."""
+    model = ref_muse.MaskGitTransformer(**cfg)
+    model.load_state_dict(W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer"), strict=True)
+    model.train()
+    input_ids, labels = W.transformer_inputs(cfg, batch, seed + 1)
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            logits, loss = model(input_ids=input_ids, labels=labels)
+        logits, loss = logits.float(), loss.float()
+    else:
+        logits, loss = model(input_ids=input_ids, labels=labels)
+    loss.backward()
+    out = dict(loss=np_(loss), batch=np.int64(batch), seed=np.int64(seed), logits=np_(W.subsample(logits, 16384)),
+               logits_absmax=np_(logits.abs().max()), logits_norm=np_(logits.double().norm()))
+    params = dict(model.named_parameters())
+    for k in FULL_GRAD_KEYS:
+        g = params[k].grad.float()
+        out["grad." + k] = np_(W.subsample(g))
+        out["absmax." + k] = np_(g.abs().max())
+        out["norm." + k] = np_(g.double().norm())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", float(loss), "logits absmax", float(logits.abs().max()))
+
+
+def golden_vqgan_full(name, cfg, seed):
+    """the f16-256 tokenizer (54.5 M parameters) run by the real reference on one 256 x 256 image: encoder output z (full), the 256
+    token ids, the two smallest distances per token (near-tie margins), and every k-th pixel of decode_code's reconstruction"""
+    model = ref_muse.MaskGitVQGAN(**cfg)
+    model.load_state_dict(W.fill_state_dict(W.vqgan_shapes(cfg), seed, "vqgan"), strict=True)
+    model.eval()
+    px = W.images(1, cfg["resolution"], seed + 1)
+    with torch.no_grad():
+        z = model.encoder(px)
+        z_q, idx = model.encode(px)
+        rec = model.decode_code(idx)
+        dist = model.quantize.compute_distances(z.permute(0, 2, 3, 1).contiguous())
+    top2 = torch.topk(dist, 2, dim=1, largest=False).values
+    out = dict(z=np_(z), indices=np_(idx), rec=np_(W.subsample(rec, 16384)), rec_absmax=np_(rec.abs().max()),
+               z_q=np_(W.subsample(z_q)), top2=np_(top2), seed=np.int64(seed))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "z", z.shape, "idx", idx.shape, "rec", rec.shape, "min margin", float((top2[:, 1] - top2[:, 0]).min()))
+
+
 def golden_taming(name, cfg, batch, seed):
     """the taming tokenizer of the text-to-image configs (muse/modeling_taming_vqgan.py:512-585, configs/cc12m_uvit_clip.yaml
     :19-21): encoder latents, quant_conv output, indices, z_q, reconstruction, and the top-2 distance margin per token"""
@@ -361,6 +414,12 @@ def golden_mask_muse(name, seed, batch=6, seq=16, mask_id=47, codebook_size=32):
 
 
 if __name__ == "__main__":
+    if "--skip-full" not in sys.argv:   # the benched geometries (about two minutes on one thread)
+        golden_vqgan_full("vqgan_f16_full", W.VQGAN_F16, seed=600)
+        golden_transformer_full("transformer_b_full", W.TRANSFORMER_B, batch=2, seed=510)
+        golden_transformer_full("transformer_b_full_bf16", W.TRANSFORMER_B, batch=2, seed=510, autocast=True)
+    if "--only-full" in sys.argv:
+        sys.exit(0)
     golden_transformer("transformer_tiny", W.TRANSFORMER_TINY, batch=3, seed=100, label_smoothing=0.0)
     golden_transformer("transformer_tiny_ls", W.TRANSFORMER_TINY, batch=2, seed=110, label_smoothing=0.1)
     golden_transformer("transformer_hd48", W.TRANSFORMER_HD48, batch=2, seed=120, label_smoothing=0.0)

@@ -259,3 +259,10 @@ def images(batch: int, res: int, seed: int) -> torch.Tensor:
 def uniforms(shape, seed: int) -> torch.Tensor:
     rng = np.random.default_rng(seed)
     return torch.from_numpy(rng.random(shape).astype(np.float32))
+
+
+def subsample(t, n: int = 4096):
+    """every k-th element of the flattened tensor (k = numel // n, at least 1): the compact form in which the full-size goldens
+    (make_golden.py::golden_transformer_full / golden_vqgan_full) store large outputs.  Works on torch tensors and numpy arrays."""
+    flat = t.reshape(-1)
+    return flat[:: max(1, flat.shape[0] // n)]

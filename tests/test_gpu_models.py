@@ -165,6 +165,63 @@ def test_transformer_config_b_full_depth_vs_oracle():
         torch.cuda.empty_cache()
 
 
+def test_transformer_config_b_full_depth_vs_reference_golden(golden_dir):
+    """the BENCHED transformer at batch 2 against the REAL reference's outputs (tests/golden/transformer_b_full*.npz, written by
+    make_golden.py::golden_transformer_full; no oracle in between): loss, sub-sampled logits and ten gradients over the depth.
+    bf16 mode is held to twice the gap the reference itself shows between its f32 and its CPU-autocast-bf16 run at this size
+    (logits 1.2e-2 of max|logit|, gradients 0.2e-2 .. 3.9e-2 of max|grad|, loss 1.9e-4)."""
+    g = np.load(os.path.join(golden_dir, "transformer_b_full.npz"))
+    gb = np.load(os.path.join(golden_dir, "transformer_b_full_bf16.npz"))
+    cfg = dict(W.TRANSFORMER_B)
+    seed, bs = int(g["seed"]), int(g["batch"])
+    ids, labels = W.transformer_inputs(cfg, bs, seed + 1)
+    keys = [f[5:] for f in g.files if f.startswith("grad.")]
+    ref_gap = max(float(np.abs(g["grad." + k] - gb["grad." + k]).max()) / float(g["absmax." + k]) for k in keys)
+    for cd in (torch.float32, torch.bfloat16):
+        m, _ = _build_transformer(cfg, seed, cd)
+        logits, loss = m(input_ids=ids.to(DEV), labels=labels.to(DEV))
+        loss.backward()
+        f32 = cd == torch.float32
+        el = float(np.abs(W.subsample(logits, 16384).cpu().numpy() - g["logits"]).max()) / float(g["logits_absmax"])
+        assert el < (1e-3 if f32 else 2.5e-2), (cd, el)
+        assert abs(float(loss) - float(g["loss"])) < (1e-4 if f32 else 1e-3) * float(g["loss"]), (cd, float(loss))
+        params = dict(m.named_parameters())
+        errs = {}
+        for k in keys:
+            gr = params[k].grad
+            errs[k] = float(np.abs(W.subsample(gr).cpu().numpy() - g["grad." + k]).max()) / float(g["absmax." + k])
+            assert abs(float(gr.double().norm()) - float(g["norm." + k])) < (1e-3 if f32 else 2e-2) * float(g["norm." + k]), (cd, k)
+        print(cd, "vs the reference: logits", f"{el:.2e}", "grads", {k.split("transformer_layers.")[-1]: f"{v:.1e}" for k, v in errs.items()},
+              "(reference f32 vs its own autocast: worst grad", f"{ref_gap:.1e})")
+        for k, e in errs.items():
+            assert e < (2e-3 if f32 else 8e-2), (cd, k, e)
+        del m
+        torch.cuda.empty_cache()
+
+
+def test_vqgan_f16_256_vs_reference_golden(golden_dir):
+    """the f16-256 tokenizer on one 256 x 256 image against the REAL reference's outputs (tests/golden/vqgan_f16_full.npz): encoder
+    output, token ids (bit-exact in f32 and bf16x3: the smallest top-2 distance margin of this image is 6.4e-3, far above either
+    mode's error), codes, reconstruction"""
+    import muse
+    g = np.load(os.path.join(golden_dir, "vqgan_f16_full.npz"))
+    cfg = W.VQGAN_F16
+    v = muse.MaskGitVQGAN(**cfg)
+    v.load_state_dict(W.fill_state_dict(W.vqgan_shapes(cfg), int(g["seed"]), "vqgan"))
+    v.to(DEV).eval()
+    px = W.images(1, 256, int(g["seed"]) + 1).to(DEV)
+    zref = torch.from_numpy(g["z"])
+    for mode in (torch.float32, "bf16x3"):
+        v.set_compute_dtype(mode)
+        z, _ = v._encode_nhwc(px)
+        assert maxrel(z.view(1, 16, 16, 256).permute(0, 3, 1, 2), zref) < 1e-4, mode
+        z_q, idx = v.encode(px)
+        assert np.array_equal(idx.cpu().numpy(), g["indices"]), mode
+        assert np.array_equal(W.subsample(z_q).cpu().numpy(), g["z_q"]), mode
+        rec = v.decode_code(idx)
+        assert float(np.abs(W.subsample(rec, 16384).cpu().numpy() - g["rec"]).max()) < 2e-4 * float(g["rec_absmax"]), mode
+
+
 def test_vq_indices_over_bench_batch_vs_oracle():
     """north_star: VQ token indices bit-exact.  The f16-256 tokenizer on a 64-image batch (the benched batch) in both the exact-f32
     and the bf16x3 (bench default) mode against oracle.vqgan_encode: the mismatch COUNT is reported and every mismatch must be an

@@ -184,3 +184,35 @@ def test_cond_dropout_oracle(golden_dir):
     kept = (g["cd.u"] < p)
     assert kept.any() and (~kept).any()
     assert np.array_equal(g["cd.enc_out"][1, 0, :4], g["cd.empty"][0, 0, :4])    # kept image, exact-zero elements -> empty's values
+
+
+def test_oracle_at_benched_geometry_vs_reference(golden_dir):
+    """The restatement against the REAL reference at the benched sizes (make_golden.py::golden_transformer_full / golden_vqgan_full):
+    configs/imagenet.yaml's 24-layer transformer at batch 2, S = 257 (loss, sub-sampled logits, ten gradients over the depth), and
+    the f16-256 tokenizer on one 256 x 256 image (encoder output, bit-exact token ids and codes, reconstruction)."""
+    torch.set_num_threads(min(8, os.cpu_count()))
+    try:
+        g = _load(golden_dir, "transformer_b_full")
+        cfg = dict(W.TRANSFORMER_B)
+        sd = W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer")
+        ids, labels = W.transformer_inputs(cfg, int(g["batch"]), int(g["seed"]) + 1)
+        logits, loss, grads = O.transformer_loss_and_grads(sd, cfg, ids, labels, 0.0)
+        np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-6)
+        assert float(np.abs(W.subsample(logits, 16384).numpy() - g["logits"]).max()) <= 1e-5 * float(g["logits_absmax"])
+        for k in [f[5:] for f in g.files if f.startswith("grad.")]:
+            e = float(np.abs(W.subsample(grads[k]).numpy() - g["grad." + k]).max())
+            assert e <= 2e-5 * float(g["absmax." + k]), (k, e)
+            assert abs(float(grads[k].double().norm()) - float(g["norm." + k])) <= 1e-5 * float(g["norm." + k]), k
+        del grads, logits, sd
+        gv = _load(golden_dir, "vqgan_f16_full")
+        sdv = W.fill_state_dict(W.vqgan_shapes(W.VQGAN_F16), int(gv["seed"]), "vqgan")
+        px = W.images(1, 256, int(gv["seed"]) + 1)
+        with torch.no_grad():
+            z, z_q, idx = O.vqgan_encode(sdv, W.VQGAN_F16, px)
+            rec = O.vqgan_decode_code(sdv, W.VQGAN_F16, idx)
+        np.testing.assert_allclose(z.numpy(), gv["z"], rtol=0, atol=2e-5)
+        assert np.array_equal(idx.numpy(), gv["indices"])                      # (smallest top-2 distance margin: 6.4e-3)
+        assert np.array_equal(W.subsample(z_q).numpy(), gv["z_q"])
+        assert float(np.abs(W.subsample(rec, 16384).numpy() - gv["rec"]).max()) <= 1e-4 * float(gv["rec_absmax"])
+    finally:
+        torch.set_num_threads(1)
