@@ -47,6 +47,15 @@ HBM_PEAK = 8000.0                      # GB/s (spec; ~6300 achievable per the sa
 GF_ENCODE = 128.63
 GF_FWD = {"A": 19.00, "B": 122.40}
 GF_UVIT_FWD = {256: 275.10, 1024: 1137.05}
+# BASELINE.json config 4: configs/cc12m_uvit_clip.yaml:29-54 `model.transformer` + block_num_heads=16;
+# 728 725 504 parameters - GF_UVIT_FWD above is THIS geometry's forward work (tests/test_surface.py keeps it equal to the golden config)
+UVIT_CC12M = dict(
+    vocab_size=8256, hidden_size=1024, intermediate_size=4096, num_hidden_layers=22, num_attention_heads=16,
+    max_position_embeddings=256, in_channels=512, block_out_channels=(1024,), num_res_blocks=3, patch_size=1,
+    encoder_hidden_size=768, add_cross_attention=True, project_encoder_hidden_states=False, codebook_size=8192, num_vq_tokens=256,
+    initializer_range=0.02, norm_type="rmsnorm", layer_norm_eps=1e-6, use_normformer=False, use_encoder_layernorm=True,
+    use_bias=False, hidden_dropout=0.0, attention_dropout=0.0, use_codebook_size_for_output=True, block_num_heads=16,
+)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
 # rocprof kernel name fragment of each instrumented kernel family (to look its counters up in TRAFFIC_JSON)
 KERNEL_OF = {"conv_bf16x3_dma": "cslab::conv_slab_kernel", "gemm_bf16_NN": "g256::kernel<unsigned short, 0, 0", "gemm_bf16_NT": "g256::kernel<unsigned short, 0, 1",
@@ -134,8 +143,13 @@ def uvit_leg_isolated(device, batch, seq, steps):
         line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
-        out = uvit_leg(device, batch, seq, steps)
-        out["note"] = f"in-process (subprocess failed: {type(e).__name__})"
+        print(f"bench: config-4 leg {batch},{seq} did not run in a subprocess ({type(e).__name__}); running it in-process", file=sys.stderr)
+        try:
+            out = uvit_leg(device, batch, seq, steps)
+            out["note"] = f"in-process (subprocess failed: {type(e).__name__})"
+        except Exception as e2:   # noqa: BLE001
+            torch.cuda.empty_cache()
+            out = {"error": f"{type(e2).__name__}: {str(e2)[:200]}", "batch": batch, "seq_len": seq}
         return out
 
 
@@ -166,17 +180,19 @@ def taming_leg(device, bs):
 
 
 def uvit_leg(device, batch, seq, steps=3):
-    """BASELINE.json config 4: configs/cc12m_uvit_clip.yaml MaskGiTUViT (729 M parameters, 22 layers, hidden 1024; block_num_heads
-    12 per SURVEY.md D3), synthetic CLIP states (77 x 768), tokens given, bf16 compute (fused self / cross attention, bf16 weight
-    copies refreshed inside the AdamW kernel): forward + backward + FusedAdamW"""
+    """BASELINE.json config 4: configs/cc12m_uvit_clip.yaml MaskGiTUViT (UVIT_CC12M: 728.7 M parameters, 22 layers, hidden 1024, GLU 4096,
+    1024-channel ResBlock / attention stages; block_num_heads 16 per SURVEY.md D3), synthetic CLIP states (77 x 768), tokens given,
+    bf16 compute (fused self / cross attention, bf16 weight copies refreshed inside the AdamW kernel): forward + backward + FusedAdamW"""
     import muse
     from muse import modeling_transformer_v2 as M
     init = M.MaskGiTUViT_v2._init_weights
     M.MaskGiTUViT_v2._init_weights = lambda self: None     # 729 M parameters: filled on the GPU below instead of on one CPU core
     try:
-        model = muse.MaskGiTUViT(block_num_heads=12)
+        model = muse.MaskGiTUViT(**UVIT_CC12M)
     finally:
         M.MaskGiTUViT_v2._init_weights = init
+    n_params = sum(p.numel() for p in model.parameters())
+    assert n_params == 728725504, n_params          # the geometry GF_UVIT_FWD was counted on
     model.to(device).train().set_compute_dtype(torch.bfloat16)
     g = torch.Generator(device=device).manual_seed(0)
     with torch.no_grad():
@@ -206,7 +222,7 @@ def uvit_leg(device, batch, seq, steps=3):
     dt = (time.perf_counter() - t0) / steps
     tf = 3 * GF_UVIT_FWD[seq] * batch / dt / 1e3
     out = {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 1), "batch": batch, "seq_len": seq,
-           "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK["bf16"], 4), "loss": round(float(loss), 4),
+           "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK["bf16"], 4), "loss": round(float(loss), 4), "parameters": n_params,
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     del model, opt
     torch.cuda.empty_cache()
@@ -444,10 +460,9 @@ def main():
         extra.update(leg_isolated(f"vqgan,{args.batch}", lambda: vqgan_roundtrip(device, args.batch)))
         extra.update(leg_isolated(f"taming,{args.batch}", lambda: taming_leg(device, args.batch)))
         # config 4 at batch sizes that use the 288 GB (cc12m_uvit_clip.yaml trains 64 per GPU x 2 accumulation steps): the fixed
-        # per-step cost (AdamW over 729 M parameters, ~500 small launches) is amortised - seq 256: 561 TF/s at 64, 641 at 128;
-        # seq 1024: 512 TF/s at 16, 626 at 64 (159 GiB)
+        # per-step cost (AdamW over 729 M parameters, ~500 small launches) is amortised over more tokens
         extra["config4_uvit_seq256"] = uvit_leg_isolated(device, 128, 256, 3)
-        extra["config4_uvit_seq1024"] = uvit_leg_isolated(device, 64, 1024, 2)
+        extra["config4_uvit_seq1024"] = uvit_leg_isolated(device, 48, 1024, 2)
 
     out = {
         "metric": "images/sec/node (MaskGit train step, 256^2, bs=64/GPU)", "value": round(value, 2), "unit": "images/s",

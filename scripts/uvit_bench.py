@@ -1,4 +1,4 @@
-"""SURVEY.md section 8 row a12 at its real size: MaskGiTUViT_v2 of configs/cc12m_uvit_clip.yaml (+ block_num_heads 12 -> hd 64),
+"""SURVEY.md section 8 row a12 at its real size: MaskGiTUViT_v2 of configs/cc12m_uvit_clip.yaml (+ block_num_heads 16 -> hd 64; bench.UVIT_CC12M),
 256 tokens, 77 text tokens: time of forward + backward on the f32 path (random weights filled on the GPU, synthetic inputs).
     python scripts/uvit_bench.py [batch] [steps] [f32|bf16]"""
 import os, sys, time
@@ -15,7 +15,9 @@ S = int(sys.argv[4]) if len(sys.argv) > 4 else 256          # 256 (configs/cc12m
 with_opt = len(sys.argv) > 5 and sys.argv[5] == "adamw"
 M.MaskGiTUViT_v2._init_weights = lambda self: None          # 729 M parameters: fill them on the GPU instead
 t0 = time.time()
-model = muse.MaskGiTUViT(block_num_heads=12)
+sys.path.insert(0, ROOT)
+from bench import UVIT_CC12M  # noqa: E402  (the geometry the 275.10 / 1137.05 GFLOP figures below were counted on)
+model = muse.MaskGiTUViT(**UVIT_CC12M)
 model.to("cuda")
 model.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
 g = torch.Generator(device="cuda").manual_seed(0)

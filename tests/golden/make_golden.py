@@ -139,6 +139,37 @@ def golden_vqgan_full(name, cfg, seed):
     print(name, "z", z.shape, "idx", idx.shape, "rec", rec.shape, "min margin", float((top2[:, 1] - top2[:, 0]).min()))
 
 
+def golden_uvit_full(name, batch, seq, text_len, seed, autocast=False):
+    """BASELINE.json config 4 (weights.UVIT_CC12M = configs/cc12m_uvit_clip.yaml's model.transformer + block_num_heads=16, SURVEY.md D3:
+    hidden 1024, 22 layers, GLU 4096, 3 + 3 ResBlock / attention stages of 1024 channels, in_channels 512, vocab 8256; 728.7 M
+    parameters) run by the real reference on one seeded batch, f32 and under CPU autocast-bf16.  Stored like golden_transformer_full: loss, per-tensor max|.| and
+    L2 norm, every k-th element of the logits and of eighteen gradients spread over the network."""
+    from muse.modeling_transformer_v2 import MaskGiTUViT_v2
+    model = MaskGiTUViT_v2(**W.UVIT_CC12M)
+    assert sum(p.numel() for p in model.parameters()) == 728725504
+    model.load_state_dict(W.fill_by_shapes({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed), strict=True)
+    model.train()
+    ids, enc, cond, micro, labels = W.uvit_inputs(batch, seq, text_len, seed + 1)
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            logits, loss = model(ids, enc, cond, micro, labels=labels)
+        logits, loss = logits.float(), loss.float()
+    else:
+        logits, loss = model(ids, enc, cond, micro, labels=labels)
+    loss.backward()
+    out = dict(loss=np_(loss), batch=np.int64(batch), seq=np.int64(seq), text_len=np.int64(text_len), seed=np.int64(seed),
+               logits=np_(W.subsample(logits, 16384)), logits_absmax=np_(logits.abs().max()), logits_norm=np_(logits.double().norm()),
+               logits_shape=np.array(logits.shape, dtype=np.int64))
+    params = dict(model.named_parameters())
+    for k in W.UVIT_FULL_GRAD_KEYS:
+        g = params[k].grad.float()
+        out["grad." + k] = np_(W.subsample(g))
+        out["absmax." + k] = np_(g.abs().max())
+        out["norm." + k] = np_(g.double().norm())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", float(loss), "logits", tuple(logits.shape), "absmax", float(logits.abs().max()))
+
+
 def golden_taming(name, cfg, batch, seed):
     """the taming tokenizer of the text-to-image configs (muse/modeling_taming_vqgan.py:512-585, configs/cc12m_uvit_clip.yaml
     :19-21): encoder latents, quant_conv output, indices, z_q, reconstruction, and the top-2 distance margin per token"""
@@ -418,6 +449,11 @@ if __name__ == "__main__":
         golden_vqgan_full("vqgan_f16_full", W.VQGAN_F16, seed=600)
         golden_transformer_full("transformer_b_full", W.TRANSFORMER_B, batch=2, seed=510)
         golden_transformer_full("transformer_b_full_bf16", W.TRANSFORMER_B, batch=2, seed=510, autocast=True)
+    if "--skip-full" not in sys.argv and "--skip-uvit-full" not in sys.argv:   # (729 M parameters: ~12 GB of host memory)
+        torch.set_num_threads(8)
+        golden_uvit_full("uvit_full", batch=2, seq=256, text_len=77, seed=700)
+        golden_uvit_full("uvit_full_bf16", batch=2, seq=256, text_len=77, seed=700, autocast=True)
+        torch.set_num_threads(1)
     if "--only-full" in sys.argv:
         sys.exit(0)
     golden_transformer("transformer_tiny", W.TRANSFORMER_TINY, batch=3, seed=100, label_smoothing=0.0)

@@ -56,6 +56,18 @@ VQGAN_F16 = dict(  # muse/modeling_maskgit_vqgan.py:352-367 defaults
 )
 
 
+# BASELINE.json config 4: configs/cc12m_uvit_clip.yaml:29-54 `model.transformer` + block_num_heads=16 (the YAML predates
+# MaskGiTUViT_v2, whose default 12 does not divide its 1024 block channels).  728 725 504 parameters; forward 275.10 GFLOP per
+# sample at 256 tokens, 1137.05 at 1024.  bench.py's config-4 legs build exactly this (tests/test_surface.py checks).
+UVIT_CC12M = dict(
+    vocab_size=8256, hidden_size=1024, intermediate_size=4096, num_hidden_layers=22, num_attention_heads=16,
+    max_position_embeddings=256, in_channels=512, block_out_channels=(1024,), num_res_blocks=3, patch_size=1,
+    encoder_hidden_size=768, add_cross_attention=True, project_encoder_hidden_states=False, codebook_size=8192, num_vq_tokens=256,
+    initializer_range=0.02, norm_type="rmsnorm", layer_norm_eps=1e-6, use_normformer=False, use_encoder_layernorm=True,
+    use_bias=False, hidden_dropout=0.0, attention_dropout=0.0, use_codebook_size_for_output=True, block_num_heads=16,
+)
+
+
 def transformer_shapes(cfg: dict) -> dict:
     """state_dict template of muse.MaskGitTransformer."""
     H, I, V, P = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["max_position_embeddings"]
@@ -266,3 +278,50 @@ def subsample(t, n: int = 4096):
     (make_golden.py::golden_transformer_full / golden_vqgan_full) store large outputs.  Works on torch tensors and numpy arrays."""
     flat = t.reshape(-1)
     return flat[:: max(1, flat.shape[0] // n)]
+
+
+def fill_by_shapes(shapes: dict, seed: int) -> dict:
+    """Seeded fp32 weights for ANY state-dict template {name: shape} (used for the full-size MaskGiTUViT, whose template is read off
+    the instantiated model), filled in sorted-key order: 1-D norm gains 1 + 0.1 N(0,1), GlobalResponseNorm gamma / beta 0.1 N(0,1),
+    every matrix / convolution / embedding N(0, 1 / fan_in) - also the tensors the reference zero-initialises (AdaLN mappers,
+    mlm_layer.conv1), so that the conditioning paths carry signal."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        x = rng.standard_normal(shp, dtype=np.float32)
+        if k.endswith("gamma") or k.endswith("beta"):
+            x *= 0.1
+        elif len(shp) == 1:
+            x = 1.0 + 0.1 * x
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            x *= np.float32(1.0 / np.sqrt(fan_in))
+        sd[k] = torch.from_numpy(np.ascontiguousarray(x.astype(np.float32)))
+    return sd
+
+
+UVIT_FULL_GRAD_KEYS = [
+    "embed.embeddings.weight", "embed.conv.weight", "cond_embed.0.weight", "encoder_proj.weight",
+    "down_blocks.0.res_blocks.0.depthwise.weight", "down_blocks.0.res_blocks.1.channelwise.2.gamma",
+    "down_blocks.0.res_blocks.2.adaLN_modulation.mapper.weight", "down_blocks.0.attention_blocks.0.crossattention.key.weight",
+    "project_to_hidden.weight", "transformer_layers.0.attention.query.weight", "transformer_layers.10.crossattention.value.weight",
+    "transformer_layers.10.ffn.adaLN_modulation.mapper.weight", "transformer_layers.21.ffn.wo.weight",
+    "transformer_layers.21.attn_layer_norm.weight", "up_blocks.0.res_blocks.2.channelwise.0.weight",
+    "up_blocks.0.attention_blocks.2.attention.out.weight", "mlm_layer.conv1.weight", "mlm_layer.conv2.weight",
+]
+
+
+def uvit_inputs(batch: int, seq: int, text_len: int, seed: int, vocab_size: int = 8256, codebook_size: int = 8192,
+                encoder_hidden_size: int = 768, cond_embed_dim: int = 768):
+    """seeded (input_ids, encoder_hidden_states, cond_embeds, micro_conds, labels) shaped like one train_muse.py batch"""
+    rng = np.random.default_rng(seed)
+    tokens = rng.integers(0, codebook_size, size=(batch, seq))
+    masked = rng.random((batch, seq)) < 0.5
+    input_ids = np.where(masked, vocab_size - 1, tokens).astype(np.int64)
+    labels = np.where(masked, tokens, -100).astype(np.int64)
+    enc = rng.standard_normal((batch, text_len, encoder_hidden_size), dtype=np.float32)
+    cond = rng.standard_normal((batch, cond_embed_dim), dtype=np.float32)
+    micro = np.tile(np.array([[256.0, 256.0, 0.0, 0.0, 6.0]], dtype=np.float32), (batch, 1))
+    micro[1:, 2] = 16.0
+    return tuple(torch.from_numpy(a) for a in (input_ids, enc, cond, micro, labels))

@@ -311,3 +311,48 @@ def test_uvit_bf16_mode_vs_reference_golden(golden_dir):
     assert abs(float(loss) - float(g["loss"])) < 2e-3 * abs(float(g["loss"]))
     loss.backward()
     _grad_check(model, {k[len("grad."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad.")}, 8e-2)
+
+
+def test_uvit_config4_vs_reference_golden(golden_dir):
+    """BASELINE.json config 4 at its real size (weights.UVIT_CC12M: 728.7 M parameters, 22 layers) on a 2 x 256-token batch with 77 text
+    tokens against the REAL reference's outputs (tests/golden/uvit_full*.npz, make_golden.py::golden_uvit_full): loss, sub-sampled
+    logits, eighteen gradients over the network (sub-sampled values and L2 norms).  f32 mode to 1e-3; bf16 mode is reported next to the
+    gap the reference itself shows between f32 and CPU-autocast-bf16 at this size (logits 1.7e-2, gradients up to 3.8e-2, loss 1.5e-4)."""
+    import weights as W
+    import muse
+    from muse import modeling_transformer_v2 as M
+    g = np.load(os.path.join(golden_dir, "uvit_full.npz"))
+    gb = np.load(os.path.join(golden_dir, "uvit_full_bf16.npz"))
+    init = M.MaskGiTUViT_v2._init_weights
+    M.MaskGiTUViT_v2._init_weights = lambda self: None      # (every tensor is loaded below)
+    try:
+        model = muse.MaskGiTUViT(**W.UVIT_CC12M)
+    finally:
+        M.MaskGiTUViT_v2._init_weights = init
+    model.load_state_dict(W.fill_by_shapes({k: tuple(v.shape) for k, v in model.state_dict().items()}, int(g["seed"])), strict=True)
+    model.to(DEV).train()
+    ids, enc, cond, micro, labels = (t.to(DEV) for t in W.uvit_inputs(int(g["batch"]), int(g["seq"]), int(g["text_len"]), int(g["seed"]) + 1))
+    keys = W.UVIT_FULL_GRAD_KEYS
+    ref_gap = max(float(np.abs(g["grad." + k] - gb["grad." + k]).max()) / float(g["absmax." + k]) for k in keys)
+    for cd in (torch.float32, torch.bfloat16):
+        model.set_compute_dtype(cd)
+        model.zero_grad(set_to_none=True)
+        logits, loss = model(ids, enc, cond, micro, labels=labels)
+        loss.backward()
+        f32 = cd == torch.float32
+        assert tuple(logits.shape) == tuple(g["logits_shape"])
+        el = float(np.abs(W.subsample(logits.float(), 16384).cpu().numpy() - g["logits"]).max()) / float(g["logits_absmax"])
+        lrel = abs(float(loss) - float(g["loss"])) / float(g["loss"])
+        params = dict(model.named_parameters())
+        errs, nerrs = {}, {}
+        for k in keys:
+            gr = params[k].grad.float()
+            errs[k] = float(np.abs(W.subsample(gr).cpu().numpy() - g["grad." + k]).max()) / float(g["absmax." + k])
+            nerrs[k] = abs(float(gr.double().norm()) - float(g["norm." + k])) / float(g["norm." + k])
+        print(cd, "config 4 vs the reference: logits", f"{el:.2e}", "loss", f"{lrel:.1e}", "worst grad", f"{max(errs.values()):.1e}",
+              "worst grad norm", f"{max(nerrs.values()):.1e}", f"(reference f32 vs its own autocast: worst grad {ref_gap:.1e})")
+        assert el < (1e-3 if f32 else 5e-2), (cd, el)
+        assert lrel < (1e-4 if f32 else 2e-3), (cd, lrel)
+        for k in keys:
+            assert errs[k] < (2e-3 if f32 else 1.5e-1), (cd, k, errs[k])
+            assert nerrs[k] < (1e-3 if f32 else 3e-2), (cd, k, nerrs[k])

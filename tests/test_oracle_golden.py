@@ -216,3 +216,32 @@ def test_oracle_at_benched_geometry_vs_reference(golden_dir):
         assert float(np.abs(W.subsample(rec, 16384).numpy() - gv["rec"]).max()) <= 1e-4 * float(gv["rec_absmax"])
     finally:
         torch.set_num_threads(1)
+
+
+def test_uvit_oracle_at_config4_vs_reference(golden_dir):
+    """the U-ViT restatement against the REAL reference at BASELINE config 4's size (728.7 M parameters; make_golden.py::
+    golden_uvit_full): loss, sub-sampled logits and the eighteen stored gradients of a 2 x 256-token batch (the restatement runs the
+    same torch CPU operators in the same order: measured difference 0)"""
+    from oracle import uvit_oracle as U
+    g = _load(golden_dir, "uvit_full")
+    torch.set_num_threads(min(8, os.cpu_count()))
+    try:
+        import muse
+        from muse import modeling_transformer_v2 as M
+        init = M.MaskGiTUViT_v2._init_weights
+        M.MaskGiTUViT_v2._init_weights = lambda self: None
+        try:
+            model = muse.MaskGiTUViT(**W.UVIT_CC12M)          # (only for the state-dict template and the config dict)
+        finally:
+            M.MaskGiTUViT_v2._init_weights = init
+        shapes, cfg = {k: tuple(v.shape) for k, v in model.state_dict().items()}, dict(model.config)
+        del model
+        sd = W.fill_by_shapes(shapes, int(g["seed"]))
+        ids, enc, cond, micro, labels = W.uvit_inputs(int(g["batch"]), int(g["seq"]), int(g["text_len"]), int(g["seed"]) + 1)
+        logits, loss, grads = U.uvit_loss_and_grads(sd, cfg, ids, enc, cond, micro, labels)
+        assert abs(float(loss) - float(g["loss"])) <= 1e-6 * float(g["loss"])
+        assert float(np.abs(W.subsample(logits, 16384).numpy() - g["logits"]).max()) <= 1e-5 * float(g["logits_absmax"])
+        for k in W.UVIT_FULL_GRAD_KEYS:
+            assert float(np.abs(W.subsample(grads[k]).numpy() - g["grad." + k]).max()) <= 2e-5 * float(g["absmax." + k]), k
+    finally:
+        torch.set_num_threads(1)

@@ -226,3 +226,24 @@ def test_pre_encoded_token_shards_roundtrip(tmp_path):
     assert all(torch.equal(s["image_input_ids"], toks[i]) and torch.equal(s["encoder_hidden_states"], enc[i]) for i, s in enumerate(got))
     batches = list(PE.token_batches([path], vae, 2, device="cpu"))
     assert len(batches) == 2 and torch.equal(batches[1], toks[2:4])            # ragged tail dropped
+
+
+def test_bench_config4_is_the_baseline_geometry():
+    """bench.py's config-4 legs must build the geometry BASELINE.md's row U counts its 275.10 / 1137.05 GFLOP on
+    (configs/cc12m_uvit_clip.yaml + block_num_heads=16: 728 725 504 parameters), the same one the full-size golden was generated with"""
+    import importlib.util
+    import weights as W
+    import muse
+    from muse import modeling_transformer_v2 as M
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.UVIT_CC12M == W.UVIT_CC12M
+    init = M.MaskGiTUViT_v2._init_weights
+    M.MaskGiTUViT_v2._init_weights = lambda self: None
+    try:
+        model = muse.MaskGiTUViT(**bench.UVIT_CC12M)
+    finally:
+        M.MaskGiTUViT_v2._init_weights = init
+    assert sum(p.numel() for p in model.parameters()) == 728725504
