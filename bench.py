@@ -380,6 +380,8 @@ def main():
                 model.zero_grad(set_to_none=True)
                 _, l2 = model(input_ids=ids, labels=labels)
                 l2.backward()
+                if reducer is not None:
+                    reducer.finish()
             e1.record()
             torch.cuda.synchronize()
             tr_ms = e0.elapsed_time(e1) / n

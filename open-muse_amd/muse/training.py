@@ -239,6 +239,33 @@ class FusedAdamW(torch.optim.Optimizer):
         model.grad_ready_hook = None
         self._ranges_done, self._ranges_done_live = self._ranges_done_live, None
 
+    def begin_step_in_reducer(self, model, reducer):
+        """The data-parallel form of begin_step_in_backward: the AdamW kernel runs on each gradient bucket right after its all-reduce,
+        on the reducer's stream (GradReducer.post_reduce), while backward is still computing the earlier layers and the next bucket is
+        being filled - instead of one pass over all parameters after the last all-reduce.  Same validity conditions; call
+        end_step_in_reducer after reducer.finish()."""
+        flat = model.flat_params()
+        self._ensure_flat_state(flat)
+        if any((o * 4) % 16 for o in model._offsets):
+            return False
+        self._ranges_done_live = (self._step + 1, [])
+        has_shadow = model._resolve_cd() == torch.bfloat16
+        if has_shadow:
+            model.compute_weights(torch.bfloat16)
+
+        def hook(begin, end):
+            live = self._ranges_done_live
+            if live is None or end <= begin:
+                return
+            self._apply(model, begin, end, model._flat_c if has_shadow else None)
+            live[1].append((begin, end))
+        reducer.post_reduce = hook
+        return True
+
+    def end_step_in_reducer(self, reducer):
+        reducer.post_reduce = None
+        self._ranges_done, self._ranges_done_live = self._ranges_done_live, None
+
     def _ensure_flat_state(self, flat):
         if self._m is None:
             self._m = torch.zeros_like(flat)
@@ -394,6 +421,7 @@ class GradReducer:
         self._hi = self._lo = None
         self._handles = []
         self._stream = None
+        self.post_reduce = None   # callable(lo, hi): runs on the reduction stream right after bucket [lo, hi) has been averaged
         # Models with a flat gradient buffer (MaskGitTransformer) report finished ranges during backward.  Models whose
         # parameters are ordinary tensors (MaskGiTUViT: one autograd node hands every gradient back at once) are reduced in
         # finish(): gradients packed, in reverse parameter order, into the same large buckets.
@@ -488,10 +516,16 @@ class GradReducer:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
                 h = self._reduce(g, True)
-                if h is not None:
+                if self.post_reduce is not None:
+                    if h is not None:
+                        h.wait()          # (a stream-side wait: the reduction stream continues behind the collective; the host does not block)
+                    self.post_reduce(lo, hi)
+                elif h is not None:
                     self._handles.append(h)
         else:
             self._reduce(g, False)
+            if self.post_reduce is not None:
+                self.post_reduce(lo, hi)
 
     def _on_ready(self, begin: int, end: int):
         """backward reports finished [begin, end) ranges of the flat grad buffer, from the end of the buffer downward"""
@@ -551,6 +585,7 @@ class TrainStep:
         self._pf_stream = None
         self.compute_priority = -1   # stream priority of the step while a prefetch is in flight (None: stay on the caller's stream)
         self.optimizer_in_backward = os.environ.get("MUSE_OPT_IN_BACKWARD", "1") != "0"
+        self.optimizer_in_reducer = os.environ.get("MUSE_OPT_IN_REDUCER", "1") != "0"
         self._hp_stream, self._in_hp = None, False
 
     @torch.no_grad()
@@ -610,13 +645,19 @@ class TrainStep:
         armed = (self.optimizer_in_backward and self.reducer is None and isinstance(self.optimizer, FusedAdamW)
                  and getattr(self.model, "wgrad_stream", False) and hasattr(self.model, "grad_ready_hook")
                  and self.model._resolve_cd() == torch.bfloat16 and self.optimizer.begin_step_in_backward(self.model))
+        # ... and with a reducer: AdamW on each bucket right behind its all-reduce, on the reducer's stream
+        armed_r = (not armed and self.optimizer_in_reducer and self.reducer is not None and getattr(self.reducer, "_flat_mode", False)
+                   and self.reducer.model is self.model and isinstance(self.optimizer, FusedAdamW) and loss.is_cuda
+                   and self.model._resolve_cd() == torch.bfloat16 and self.optimizer.begin_step_in_reducer(self.model, self.reducer))
         try:
             loss.backward()
+            if self.reducer is not None:
+                self.reducer.finish()
         finally:
             if armed:
                 self.optimizer.end_step_in_backward(self.model)
-        if self.reducer is not None:
-            self.reducer.finish()
+            if armed_r:
+                self.optimizer.end_step_in_reducer(self.reducer)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), mask_prob

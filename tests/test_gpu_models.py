@@ -595,6 +595,56 @@ def test_grad_reducer_on_rccl_single_rank(golden_dir):
         dist.destroy_process_group()
 
 
+def test_adamw_behind_each_reduced_bucket_matches_step_after_finish():
+    """data-parallel step on the real backend (RCCL group of size 1): FusedAdamW applied to every gradient bucket right behind its
+    all-reduce, on the reducer's stream (TrainStep.optimizer_in_reducer, FusedAdamW.begin_step_in_reducer), against the plain order
+    (all buckets reduced, then one AdamW pass): losses and parameters of three steps bit for bit, f32 and bf16 gradient buckets;
+    with one rank the averaged gradient is the local one, so the run without any reducer must agree as well"""
+    import torch.distributed as dist
+    import muse
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29500 + os.getpid() % 150)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    vcfg, tcfg = W.VQGAN_TINY, dict(W.TRANSFORMER_TINY)
+    vsd = W.fill_state_dict(W.vqgan_shapes(vcfg), 700, "vqgan")
+    tsd = W.fill_state_dict(W.transformer_shapes(tcfg), 701, "transformer")
+    B = 4
+    pxs = [W.images(B, 16, 702 + i).to(DEV) for i in range(2)]
+    cls = torch.from_numpy(np.random.default_rng(703).integers(0, 10, size=B)).to(DEV)
+    t, nz = W.uniforms((B,), 704).to(DEV), W.uniforms((B, 16), 705).to(DEV)
+
+    def run(mode, grad_dtype=torch.float32):
+        v = muse.MaskGitVQGAN(**vcfg); v.load_state_dict(vsd); v.to(DEV).eval()
+        m = muse.MaskGitTransformer(**tcfg); m.load_state_dict(tsd); m.to(DEV).train().set_compute_dtype(torch.bfloat16)
+        opt = muse.FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
+        red = muse.GradReducer(m, bucket_bytes=32 * 1024, grad_dtype=grad_dtype) if mode != "no_reducer" else None
+        step = muse.TrainStep(v, m, opt, red)
+        step.optimizer_in_reducer = mode == "behind_buckets"
+        step.optimizer_in_backward = False
+        losses = []
+        for i in range(3):
+            losses.append(step(pxs[i % 2], cls, t, nz, next_pixel_values=pxs[(i + 1) % 2])[0])
+            assert opt._ranges_done is None and opt._step == i + 1 and (red is None or red.post_reduce is None)
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), m.flat_params().clone().cpu()
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        l0, p0 = run("after_finish")
+        l1, p1 = run("behind_buckets")
+        assert torch.equal(l0, l1), (l0, l1)
+        assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+        l2, p2 = run("no_reducer")
+        assert torch.equal(l0, l2) and torch.equal(p0, p2), float((p0 - p2).abs().max())
+        lb0, pb0 = run("after_finish", torch.bfloat16)
+        lb1, pb1 = run("behind_buckets", torch.bfloat16)
+        assert torch.equal(lb0, lb1) and torch.equal(pb0, pb1), float((pb0 - pb1).abs().max())
+        assert float((pb0 - p0).abs().max()) < 1e-2        # bf16 buckets: a rounding of the gradient, not a different update
+    finally:
+        dist.destroy_process_group()
+
+
 def test_bench_under_torchrun_single_rank():
     """the launch path the driver uses for N > 1 (torch.distributed.run, RANK / LOCAL_RANK / WORLD_SIZE from the env, RCCL process
     group with device_id, GradReducer on the side stream, barrier-bracketed timing, metric all-reduce) with one rank"""

@@ -37,13 +37,29 @@ def _worker(rank, world, port, out):
     g_avg = g.clone()
     # the two logged scalars of the loop (train_maskgit_imagenet.py:430-431) as one 2-float all-reduce
     loss, rate = red.reduce_metrics(torch.tensor(1.0 + rank), torch.full((4,), 0.25 * (rank + 1)))
+    # post_reduce: the per-bucket callback FusedAdamW.begin_step_in_reducer hangs the optimizer update on.  It must see every
+    # element of the buffer exactly once, already averaged
+    g.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+    seen = []
+    red.post_reduce = lambda lo, hi: seen.append((lo, hi, g[lo:hi].clone()))
+    m.grad_ready_hook(off[t0], n)
+    for li in reversed(range(L)):
+        b0 = 2 + li * 11
+        m.grad_ready_hook(off[b0], off[b0 + 11])
+    m.grad_ready_hook(off[0], off[2])
+    red.finish()
+    red.post_reduce = None
+    seen.sort(key=lambda r: r[0])
+    tiles = len(seen) > 2 and seen[0][0] == 0 and seen[-1][1] == n and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    averaged = all(torch.allclose(v, torch.arange(lo, hi, dtype=torch.float32) * 1.5) for lo, hi, v in seen)
     # bf16 gradient buckets: same protocol, payload rounded to bf16
     red16 = muse.GradReducer(m, bucket_bytes=16 * 1024, broadcast_params=False, grad_dtype=torch.bfloat16)
     g16 = m.flat_grads()
     g16.copy_(torch.arange(n, dtype=torch.float32) % 251 * (rank + 1))
     m.grad_ready_hook(0, n)
     red16.finish()
-    torch.save({"p": p_after, "g": g_avg, "loss": loss, "rate": rate, "g16": g16.clone()}, os.path.join(out, f"r{rank}.pt"))
+    torch.save({"p": p_after, "g": g_avg, "loss": loss, "rate": rate, "g16": g16.clone(), "post_reduce_ok": bool(tiles and averaged)},
+               os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -58,6 +74,7 @@ def test_grad_reducer_world2(tmp_path):
     expect = torch.arange(n, dtype=torch.float32) * 1.5       # mean of (1x, 2x)
     assert torch.allclose(r0["g"], expect) and torch.equal(r0["g"], r1["g"])
     assert abs(float(r0["loss"]) - 1.5) < 1e-6 and abs(float(r0["rate"]) - 0.375) < 1e-6 and torch.equal(r0["loss"], r1["loss"])
+    assert r0["post_reduce_ok"] and r1["post_reduce_ok"]
     e16 = (torch.arange(n, dtype=torch.float32) % 251) * 1.5   # small integers and their 1.5 multiples are exact in bf16
     assert torch.equal(r0["g16"], r1["g16"]) and torch.allclose(r0["g16"], e16, rtol=8e-3)
 
