@@ -20,3 +20,8 @@ except Exception as ex:
     print("no bench line:", ex)
 PY
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/r2f2_smoke.txt 2>&1; echo "smoke exit $?" >> $O/r2f2_smoke.txt; tail -2 $O/r2f2_smoke.txt
+# (if box time is left) kernel ranking of one config-4 step on the cc12m geometry, for the next round
+rm -rf $O/prof_uvit
+timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_uvit -o uvit -- python bench.py --uvit-leg 64,256,2 > $O/r2f2_uvit_prof.txt 2>&1
+f=$(find $O/prof_uvit -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/r2f2_uvit_kernel_stats.csv && head -14 "$f" | cut -c1-150
+find $O/prof_uvit -name "*kernel_trace*" -delete
