@@ -223,6 +223,7 @@ def uvit_leg(device, batch, seq, steps=3):
     tf = 3 * GF_UVIT_FWD[seq] * batch / dt / 1e3
     out = {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 1), "batch": batch, "seq_len": seq,
            "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK["bf16"], 4), "loss": round(float(loss), 4), "parameters": n_params,
+           "dtype": "bf16 weight-GEMM / attention operands, f32 accumulate, residual stream, norms, loss (the yaml itself sets mixed_precision: no)",
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     del model, opt
     torch.cuda.empty_cache()
