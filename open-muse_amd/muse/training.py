@@ -144,6 +144,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self._table = self._chunk_first = self._table_key = self._stage = None   # per-tensor mode: device table of muse_adamw_multi
         self._ranges_done = self._ranges_done_live = None                        # (step, [(begin, end), ...]) applied inside backward
+        self._upd_stream, self._upd_used = None, False                           # stream of the per-bucket update (begin_step_in_reducer)
         self.grad_scale = 1.0   # multiplied into the gradient inside the kernel (GradReducer sets 1/world for SUM reductions)
 
     def _flat_grad_checked(self, model, params):
@@ -240,10 +241,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._ranges_done, self._ranges_done_live = self._ranges_done_live, None
 
     def begin_step_in_reducer(self, model, reducer):
-        """The data-parallel form of begin_step_in_backward: the AdamW kernel runs on each gradient bucket right after its all-reduce,
-        on the reducer's stream (GradReducer.post_reduce), while backward is still computing the earlier layers and the next bucket is
-        being filled - instead of one pass over all parameters after the last all-reduce.  Same validity conditions; call
-        end_step_in_reducer after reducer.finish()."""
+        """The data-parallel form of begin_step_in_backward: the AdamW kernel runs on each gradient bucket right after its all-reduce
+        (GradReducer.post_reduce), while backward is still computing the earlier layers and the next bucket is being filled - instead
+        of one pass over all parameters after the last all-reduce.  The kernel runs on the reducer's (high-priority) stream, behind
+        the bucket's collective.  MUSE_OPT_REDUCER_STREAM=own puts it on a normal-priority stream of its own instead (same results
+        bit for bit, but measured much slower at one rank: 69.6 vs 61.5 ms per step, profiles/r02_ab_dp1_updstream_*.json - the
+        low-priority update is starved until the end of the step and then serialises).  Same validity conditions as
+        begin_step_in_backward; call end_step_in_reducer after reducer.finish()."""
         flat = model.flat_params()
         self._ensure_flat_state(flat)
         if any((o * 4) % 16 for o in model._offsets):
@@ -252,18 +256,31 @@ class FusedAdamW(torch.optim.Optimizer):
         has_shadow = model._resolve_cd() == torch.bfloat16
         if has_shadow:
             model.compute_weights(torch.bfloat16)
+        own = flat.is_cuda and os.environ.get("MUSE_OPT_REDUCER_STREAM", "comm") == "own"
+        if own and (self._upd_stream is None or self._upd_stream.device != flat.device):
+            self._upd_stream = torch.cuda.Stream(device=flat.device)
+        self._upd_used = False
 
         def hook(begin, end):
             live = self._ranges_done_live
             if live is None or end <= begin:
                 return
-            self._apply(model, begin, end, model._flat_c if has_shadow else None)
+            if own:
+                self._upd_stream.wait_stream(torch.cuda.current_stream(flat.device))   # (the reducer's stream, behind the collective)
+                with torch.cuda.stream(self._upd_stream):
+                    self._apply(model, begin, end, model._flat_c if has_shadow else None)
+                self._upd_used = True
+            else:
+                self._apply(model, begin, end, model._flat_c if has_shadow else None)
             live[1].append((begin, end))
         reducer.post_reduce = hook
         return True
 
     def end_step_in_reducer(self, reducer):
         reducer.post_reduce = None
+        if self._upd_used:   # the caller's stream continues behind the last bucket's update
+            torch.cuda.current_stream(self._upd_stream.device).wait_stream(self._upd_stream)
+            self._upd_used = False
         self._ranges_done, self._ranges_done_live = self._ranges_done_live, None
 
     def _ensure_flat_state(self, flat):
