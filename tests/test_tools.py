@@ -1,0 +1,39 @@
+"""CPU: the profile-analysis tooling (scripts/overlap_report.py) on a hand-made kernel trace with known overlaps."""
+import importlib.util
+import io
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("overlap_report", os.path.join(ROOT, "scripts", "overlap_report.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_overlap_report_interval_arithmetic(tmp_path):
+    t = _tool()
+    ms = 1_000_000
+    # queue 1 / stream 1: two GEMMs [0,4) [5,9); queue 2 / stream 2: a conv [2,7); queue 2 / stream 3: AdamW [8,10); idle nowhere but [4,5) on q1
+    rows = [("g256::kernel<a>", 1, 1, 0, 4), ("g256::kernel<b>", 1, 1, 5, 9), ("cslab::conv_slab_kernel(x)", 2, 2, 2, 7),
+            ("adamw_kernel(y)", 2, 3, 8, 10)]
+    p = tmp_path / "t_kernel_trace.csv"
+    with open(p, "w") as f:
+        f.write('"Kind","Agent_Id","Queue_Id","Stream_Id","Kernel_Name","Start_Timestamp","End_Timestamp"\n')
+        for name, q, st, s, e in rows:
+            f.write(f'"KERNEL_DISPATCH","Agent 2",{q},{st},"{name}",{s * ms},{e * ms}\n')
+    out = io.StringIO()
+    r = t.report(t.load(str(p)), out=out)
+    assert abs(r["span_ms"] - 10.0) < 1e-9 and r["idle_ms"] == 0.0
+    fam = r["families"]
+    assert abs(fam["gemm"]["kernel_ms"] - 8.0) < 1e-9 and abs(fam["gemm"]["wall_ms"] - 8.0) < 1e-9
+    assert abs(fam["gemm"]["overlapped_ms"] - 5.0) < 1e-9      # conv over [2,4) and [5,7), AdamW over [8,9)
+    assert abs(fam["conv"]["overlapped_ms"] - 4.0) < 1e-9 and abs(fam["adamw"]["overlapped_ms"] - 1.0) < 1e-9
+    assert r["shared_queues"] == {"2": ["2", "3"]}             # two streams multiplexed onto hardware queue 2
+    hist = t.depth_histogram(t.load(str(p)))
+    assert hist[1] == 5 * ms and hist[2] == 5 * ms and hist[0] == 0
+    assert t.family("void ffn_mid_bwd_kernel<unsigned short, 3, true>") == "rows" and t.family("ncclDevKernel_AllReduce") == "collective"
+    # --last-ms keeps only the tail of the trace
+    assert len(t.load(str(p), last_ms=2.5)) == 1
