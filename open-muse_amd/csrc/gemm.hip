@@ -1,6 +1,7 @@
 // Dense / strided-batched GEMM entry point of libmuse_hip (see include/muse_hip.h: muse_gemm).
 #include "gemm_core.h"
 #include "gemm256.h"
+#include "gemm_p.h"
 #include "../../include/muse_hip.h"
 
 template <typename T, typename TC, int BM>
@@ -66,6 +67,11 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   const int batch = d->batch > 0 ? d->batch : 1;
   hipStream_t s = (hipStream_t)stream;
   if (takes_gemm256(d, p, batch)) {
+    // persistent tile-walking form first (gemm256p.h); -1 = no queue slot for this stream
+    if (gemm256p_takes(p, d->layout_a, d->layout_b, batch, d->out_dtype == MUSE_F32)) {
+      const int rp = launch_gemm256p(p, d->layout_a, d->layout_b, d->out_dtype == MUSE_F32, s);
+      if (rp != -1) return rp;
+    }
     if (d->out_dtype == MUSE_BF16) return launch_gemm256<bf16_t>(p, d->layout_a, d->layout_b, batch, s);
     return launch_gemm256<float>(p, d->layout_a, d->layout_b, batch, s);
   }

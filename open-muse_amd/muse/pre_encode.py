@@ -7,13 +7,14 @@ The reference's text-to-image configs never run the VQGAN inside the loop: scrip
 
 This module produces and consumes that layout with the tokenizer on the HIP kernels (`MaskGitVQGAN.get_code`) and plain `tarfile`
 (webdataset itself is not needed to write or read a POSIX tar of `<key>.<ext>` members): shards written here are readable by the
-reference's pipeline and vice versa.  `muse.TrainStep(...)(pixel_values=None, class_ids, image_tokens=tokens)` is the step that
+reference's pipeline and vice versa (member extensions are matched case-insensitively, as webdataset does).  `muse.TrainStep(...)(pixel_values=None, class_ids, image_tokens=tokens)` is the step that
 consumes the tokens.
 """
 from __future__ import annotations
 
 import io
 import json
+import os
 import tarfile
 from typing import Dict, Iterable, Iterator, Optional, Sequence
 
@@ -62,7 +63,11 @@ def read_token_shard(path: str, vae_checkpoint: str, text_encoder_checkpoint: Op
         for m in tar:
             if not m.isfile():
                 continue
-            key, _, ext = m.name.partition(".")     # webdataset: the key is everything before the first dot of the base name
+            # webdataset (base_plus_ext): the key is the directory part plus everything before the first dot of the BASE name, and
+            # the extension is lower-cased on read - the reference writes mixed-case members (`<key>.openMUSE.vqgan-....pth`)
+            dirname, base = os.path.split(m.name)
+            stem, _, ext = base.partition(".")
+            key, ext = (os.path.join(dirname, stem) if dirname else stem), ext.lower()
             if key != cur_key:
                 if cur_key is not None and "image_input_ids" in cur:
                     yield cur

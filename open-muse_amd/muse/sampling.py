@@ -4,8 +4,10 @@ The schedules are the reference's (muse/sampling.py:38-77: cosine / linear / pow
 `get_mask_chedule` — the reference's spelling is part of its import surface).  They are host-side scalar maths: a schedule
 is evaluated once per decoding step on a 0-dim CPU tensor.  Everything per token — softmax, categorical sampling, the
 Gumbel-perturbed confidence, the k-th-smallest threshold and the re-masking (muse/sampling.py:30-35 `mask_by_random_topk`
-and its callers) — runs in ONE device call per step (`ops.sample_step` -> libmuse_hip `muse_sample_step`), so the
-reference's tensor helpers (`gumbel_noise`, `gumbel_sample`, `top_k`, `mask_by_random_topk`) have no counterpart here.
+and its callers) — runs in ONE device call per step (`ops.sample_step` -> libmuse_hip `muse_sample_step`).  The
+reference's tensor helpers (`log`, `gumbel_noise`, `gumbel_sample`, `top_k`, `mask_by_random_topk`) stay importable from here
+for downstream code (the reference's own modules do `from .sampling import ...`); they are thin torch expressions that run
+on whatever device their inputs live on and are NOT on this package's decode path.
 """
 from __future__ import annotations
 
@@ -16,6 +18,33 @@ import torch
 
 _HALF_PI = math.pi * 0.5
 _FLOOR = 1e-6   # lower clamp of the non-cosine schedules
+
+
+# ---- import-surface helpers (muse/sampling.py:8-35); not used by generate2 here -------------------------------------------------
+def log(t, eps=1e-20):
+    return torch.log(t.clamp(min=eps))
+
+
+def gumbel_noise(t, generator=None):
+    u = torch.zeros_like(t).uniform_(0, 1, generator=generator)
+    return -log(-log(u))
+
+
+def gumbel_sample(t, temperature=1.0, dim=-1, generator=None):
+    return (t / max(temperature, 1e-10) + gumbel_noise(t, generator=generator)).argmax(dim=dim)
+
+
+def top_k(logits, thres=0.9):
+    keep = math.ceil((1 - thres) * logits.shape[-1])
+    val, ind = logits.topk(keep, dim=-1)
+    return torch.full_like(logits, float("-inf")).scatter_(2, ind, val)
+
+
+def mask_by_random_topk(mask_len, probs, temperature=1.0, generator=None):
+    """True where the Gumbel-perturbed log-confidence is below the mask_len-th smallest of its row"""
+    confidence = log(probs) + temperature * gumbel_noise(probs, generator=generator)
+    cut_off = torch.gather(torch.sort(confidence, dim=-1).values, 1, mask_len.long())
+    return confidence < cut_off
 
 
 def cosine_schedule(t):
@@ -29,6 +58,11 @@ def linear_schedule(t):
 
 def _pow_schedule(t, exponent: float):
     return torch.clamp(1.0 - t ** exponent, min=_FLOOR, max=1.0)
+
+
+def pow(t, method):
+    """reference spelling of the power schedule: method = "pow<exponent>" (muse/sampling.py:48-52)"""
+    return _pow_schedule(t, float(method.replace("pow", "")))
 
 
 def sigmoid_schedule(t, start=-3, end=3, tau=1.0, clip_min=_FLOOR):

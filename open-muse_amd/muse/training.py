@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import os
 import weakref
+import warnings
 from typing import Optional
 
 import torch
@@ -22,11 +23,16 @@ from ._hip import MuseHipError
 
 @torch.no_grad()
 def prepare_inputs_and_labels(vq_model, pixel_values, class_ids, mask_id, min_masking_rate: float = 0.0, timesteps=None,
-                              noise=None, generator=None, image_tokens=None):
+                              noise=None, generator=None, image_tokens=None, codebook_size=None):
     """-> (input_ids [B,S+1], labels [B,S+1], soft_targets=None, mask_prob [B]).
 
     `timesteps` [B] and `noise` [B,S] are the two torch.rand draws of the reference (:375, :381); pass them in for
-    bit-reproducible masks (parity tests), otherwise they are drawn on the GPU."""
+    bit-reproducible masks (parity tests), otherwise they are drawn on the GPU.  With pre-encoded `image_tokens` the
+    tokenizer is not touched: `vq_model` may be None when `codebook_size` (the class-token offset, :388) is given."""
+    if codebook_size is None:
+        if vq_model is None:
+            raise ValueError("prepare_inputs_and_labels: without a vq_model pass codebook_size (the class-token offset)")
+        codebook_size = vq_model.num_embeddings
     if image_tokens is None:
         image_tokens = vq_model.get_code(pixel_values)      # == vq_model.encode(pixel_values)[1] (:369) without the unused z_q
     B, S = image_tokens.shape
@@ -37,7 +43,7 @@ def prepare_inputs_and_labels(vq_model, pixel_values, class_ids, mask_id, min_ma
         noise = torch.rand(B, S, device=dev, generator=generator)
     input_ids, labels, mask_prob = ops.mask_sample(image_tokens.contiguous(), class_ids.contiguous(),
                                                    timesteps.float().contiguous(), noise.float().contiguous(), int(mask_id),
-                                                   int(vq_model.num_embeddings), float(min_masking_rate))
+                                                   int(codebook_size), float(min_masking_rate))
     return input_ids, labels, None, mask_prob
 
 
@@ -99,7 +105,8 @@ def cond_dropout(encoder_hidden_states, clip_embeds, empty_embeds, empty_clip_em
         uniforms = torch.rand(B, device=encoder_hidden_states.device, generator=generator)
     enc = ops.cond_dropout(encoder_hidden_states, empty_embeds, uniforms, cond_dropout_prob).view(encoder_hidden_states.shape)
     cond = ops.cond_dropout(clip_embeds, empty_clip_embeds, uniforms, cond_dropout_prob).view(clip_embeds.shape)
-    return enc, cond
+    # (the kernel works in f32; torch.where in the reference keeps the inputs' dtype)
+    return enc.to(encoder_hidden_states.dtype), cond.to(clip_embeds.dtype)
 
 
 def _owner_of(params):
@@ -164,6 +171,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        self._check_not_partial()
         loss = closure() if closure is not None else None
         grp = self.param_groups[0]
         if self._model is None:
@@ -219,11 +227,13 @@ class FusedAdamW(torch.optim.Optimizer):
         following backward.  Element-wise identical to one launch over the whole buffer.  The following step() only advances the
         step count and covers ranges backward did not report.  Valid when nothing sits between backward and step(): no gradient
         clipping, no gradient accumulation, no all-reduce (muse.TrainStep checks this and arms it)."""
+        self._check_not_partial()
         flat = model.flat_params()
         self._ensure_flat_state(flat)
         if any((o * 4) % 16 for o in model._offsets):
             return False                      # (slices must keep the kernel's 16-byte alignment)
         self._ranges_done_live = (self._step + 1, [])
+        self._direct_grad_before = model.direct_grad
         shadow = model.compute_weights(torch.bfloat16) if model._resolve_cd() == torch.bfloat16 else None
 
         def hook(begin, end):
@@ -236,9 +246,21 @@ class FusedAdamW(torch.optim.Optimizer):
         model.grad_ready_hook = hook
         return True
 
-    def end_step_in_backward(self, model):
+    def end_step_in_backward(self, model, failed=False):
+        """`failed`: backward raised.  Ranges it had already reported carry this step's update (weights changed, moments advanced)
+        while the step count has not: the step can be neither retried nor skipped, and every later call says so."""
         model.grad_ready_hook = None
+        model.direct_grad = getattr(self, "_direct_grad_before", model.direct_grad)
         self._ranges_done, self._ranges_done_live = self._ranges_done_live, None
+        if failed and self._ranges_done is not None and self._ranges_done[1]:
+            self._partial_step = True
+
+    def _check_not_partial(self):
+        if getattr(self, "_partial_step", False):
+            raise MuseHipError("FusedAdamW: an earlier step failed inside backward after AdamW had already been applied to part of "
+                               "the parameters (in-backward / behind-the-all-reduce update); the optimizer state is inconsistent - "
+                               "restore parameters and optimizer from a checkpoint (or set MUSE_OPT_IN_BACKWARD=0 / "
+                               "MUSE_OPT_IN_REDUCER=0 to keep the update out of backward)")
 
     def begin_step_in_reducer(self, model, reducer):
         """The data-parallel form of begin_step_in_backward: the AdamW kernel runs on each gradient bucket right after its all-reduce
@@ -649,6 +671,10 @@ class TrainStep:
             main = torch.cuda.current_stream(image_tokens.device)
             main.wait_event(ev)
             image_tokens.record_stream(main)
+        elif self._pf is not None and image_tokens is None:
+            # the prefetch is keyed by tensor IDENTITY: a different tensor object here means this batch is tokenised a second time
+            warnings.warn("TrainStep: the prefetched batch is discarded - `pixel_values` is not the tensor object that was passed as "
+                          "`next_pixel_values` to the previous call; this step encodes its images again", RuntimeWarning, stacklevel=2)
         self._pf = None
         if next_pixel_values is not None:
             if image_tokens is None:   # first step of a run: this batch inline, then the next one on the side stream
@@ -656,7 +682,8 @@ class TrainStep:
             self._prefetch(next_pixel_values)
         input_ids, labels, _, mask_prob = prepare_inputs_and_labels(
             self.vq_model, pixel_values, class_ids, self.model.config.mask_token_id, self.min_masking_rate, timesteps, noise,
-            image_tokens=image_tokens)
+            image_tokens=image_tokens,
+            codebook_size=None if self.vq_model is not None else self.model.config.codebook_size)
         _, loss = self.model(input_ids=input_ids, labels=labels, label_smoothing=self.label_smoothing)
         # AdamW inside backward (FusedAdamW.begin_step_in_backward): only when nothing sits between the two - no reducer here
         armed = (self.optimizer_in_backward and self.reducer is None and isinstance(self.optimizer, FusedAdamW)
