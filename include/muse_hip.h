@@ -63,6 +63,10 @@ int muse_gemm(const muse_gemm_desc* d, void* stream);
 /* Block-tile edge muse_gemm will use for this descriptor: 256 (LDS-DMA kernel, one block per CU) or 128 (two / three
  * blocks per CU); < 0 = the error muse_gemm would return.  Host code sizes split_k with it (ops.wgrad_splits). */
 int muse_gemm_tile(const muse_gemm_desc* d);
+/* Kernel form behind that tile: 128, 256 (launch-per-tile LDS-DMA kernel) or 257 (the persistent tile-walking form of the 256 kernel,
+ * csrc/gemm256p.h: bf16 operands, one batch, no split-K, no bias / activation; k-contiguous A); < 0 = muse_gemm's error.  Pure host
+ * logic (tests assert that the train step's products take the persistent form; MUSE_G256P=0 turns it off). */
+int muse_gemm_path(const muse_gemm_desc* d);
 
 /* 2-D transpose out[c, r] = in[r, c] (strided-batched); used only by the fallback that feeds k-major operands to
  * the k-contiguous GEMM path (MUSE_GEMM_TR=0). */

@@ -47,7 +47,10 @@ static int fill_params(const muse_gemm_desc* d, GemmParams& p) {
 
 // does this descriptor go to the 256 x 256 LDS-DMA kernel (gemm256.h)?
 static bool takes_gemm256(const muse_gemm_desc* d, const GemmParams& p, int batch) {
-  if (d->dtype != MUSE_BF16 || !gemm256_preferred(p, d->layout_a, d->layout_b, batch)) return false;
+  if (d->dtype != MUSE_BF16) return false;
+  const bool pers = (d->out_dtype == MUSE_BF16 || d->out_dtype == MUSE_F32) &&
+                    gemm256p_takes(p, d->layout_a, d->layout_b, batch, d->out_dtype == MUSE_F32);
+  if (!gemm256_preferred(p, d->layout_a, d->layout_b, batch, pers)) return false;
   if (d->out_dtype == MUSE_BF16) return gemm256_ok<bf16_t>(p, d->layout_a, d->layout_b);
   if (d->out_dtype == MUSE_F32) return gemm256_ok<float>(p, d->layout_a, d->layout_b);
   return false;
@@ -58,6 +61,15 @@ extern "C" int muse_gemm_tile(const muse_gemm_desc* d) {
   const int rc = fill_params(d, p);
   if (rc) return rc;
   return takes_gemm256(d, p, d->batch > 0 ? d->batch : 1) ? 256 : 128;
+}
+
+extern "C" int muse_gemm_path(const muse_gemm_desc* d) {
+  GemmParams p;
+  const int rc = fill_params(d, p);
+  if (rc) return rc;
+  const int batch = d->batch > 0 ? d->batch : 1;
+  if (!takes_gemm256(d, p, batch)) return 128;
+  return gemm256p_takes(p, d->layout_a, d->layout_b, batch, d->out_dtype == MUSE_F32) ? 257 : 256;
 }
 
 extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {

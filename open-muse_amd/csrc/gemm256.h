@@ -631,7 +631,7 @@ static inline bool gemm256_ok(const GemmParams& p, int la, int lb) {
 //   256^2: one block per CU (256 slots); a round costs nk * 1.8 + 6        (K loop ~1000 TFLOP/s + prologue / epilogue)
 //   128^2: 3 (k-contiguous x k-contiguous, one stage) or 2 blocks per CU; a round costs nk * 1.7 + 2.5 / nk * 1.25 + 2.5
 // MUSE_GEMM256 = 0 never, 1 whenever eligible, 2 (default) by the estimate.
-static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int batch) {
+static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int batch, bool persistent = false) {
   const char* e = getenv("MUSE_GEMM256");  // read per call (cheap) so tests can force either kernel
   const int mode = e ? (e[0] - '0') : 2;
   if (mode == 0) return false;
@@ -643,7 +643,10 @@ static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int ba
   const double nk = (double)((p.K + 63) / 64) / (double)sk;
   const bool nn = la == 0 && lb == 0;
   const long slots128 = nn ? 768 : 512;
-  const double cost256 = (double)((t256 + 255) / 256) * (nk * 1.8 + 6.0);
+  // persistent form (gemm256p.h): tiles are handed out dynamically and a tile change costs neither prologue nor a staged epilogue -
+  // rounds count fractionally beyond the first (MI355X: [16448x768]x[2048x768]^T 61.7 us against 70.5 us on the 128^2 kernel)
+  const double rounds = persistent ? (t256 <= 256 ? 1.0 : (double)t256 / 256.0) : (double)((t256 + 255) / 256);
+  const double cost256 = persistent ? rounds * (nk * 1.8 + 2.0) + 4.0 : rounds * (nk * 1.8 + 6.0);
   const double cost128 = (double)((t128 + slots128 - 1) / slots128) * (nk * (nn ? 1.7 : 1.25) + 2.5);
   return cost256 < cost128;
 }

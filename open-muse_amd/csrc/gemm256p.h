@@ -170,6 +170,7 @@ struct PipeP {
   unsigned tk;             // wave 0, lane 0: ticket drawn for the next tile
   int wave, lane, wr, wc, xcd, nbx;
   int kti;                 // K-tile index, relative to the tile the DMA currently targets
+  int nact;                // fragment rows of this wave that lie inside the matrix (current tile)
   int nm0, nn0;
   bool has_next, pend;
 
@@ -225,7 +226,10 @@ struct PipeP {
   }
 
   // one MFMA group (A-fragment row G & 7 against the 4 B fragments of K-group G >> 3) of the K-tile in stage S
-  template <int S, int G, int MODE>
+  // SKIP (tiles of the ragged last row strip): fragment rows outside the matrix are all zeros - leave their MFMAs out (nact =
+  // fragment rows of this wave that hold matrix rows; the reads, waits and barriers stay, the DMA pieces of those rows are
+  // out-of-range chunks that never touch memory)
+  template <int S, int G, int MODE, bool SKIP>
   __device__ __forceinline__ void group() {
     // the ticket for the tile after this one: behind the previous tile's stores when the barrier below lets them drain on (it
     // then has until the NEXT K-tile's barrier to return), else behind this K-tile's barrier
@@ -251,12 +255,22 @@ struct PipeP {
     if constexpr (G == GB1) fb.template read_range<S, 1, 0, NI>(bk[1]);
     read_a<S, G + DIST>();
     wait_lgkm<waitN(G)>();
+    if (!SKIP || (G & 7) < nact) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      acc[G & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j], 0, 0, 0);
+      for (int j = 0; j < NI; ++j)
+        acc[G & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (G + 1 < 16) group<S, G + 1, MODE>();
+    if constexpr (G + 1 < 16) group<S, G + 1, MODE, SKIP>();
     else ++kti;
+  }
+  template <int S, int MODE, bool SKIP>
+  __device__ __forceinline__ void ktile() {
+    group<S, 0, MODE, SKIP>();
+  }
+  __device__ __forceinline__ void set_nact(int m0) {
+    const int rows = M - m0 - wr;
+    nact = rows >= 16 * MI ? MI : (rows <= 0 ? 0 : (rows + 15) >> 4);
   }
 
   // accumulator start values: zero, or (f32 outputs) the residual / the old C, in fragment layout
@@ -267,16 +281,19 @@ struct PipeP {
         asm volatile("" : "+v"(ln));
         const int pr = ln & 15, g = ln >> 4;
         const int rowlim = M - m0 - wr - pr;
-        const unsigned soff = (unsigned)m0 * ldI * 4u + (unsigned)n0 * 4u;
-        const unsigned rowb = (unsigned)(wr + pr) * ldI * 4u + (unsigned)(wc + 4 * g) * 4u;
+        const unsigned soff = (unsigned)m0 * ldI * 4u + (unsigned)n0 * 4u, rstep = 16u * ldI * 4u;
+        const unsigned vbase = (unsigned)(wr + pr) * ldI * 4u + (unsigned)(wc + 4 * g) * 4u;
+        unsigned vb[NI];   // per fragment column: this lane's offset inside fragment row 0, or the out-of-range marker
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NI; ++j) vb[j] = (n0 + wc + 4 * g + 16 * j) < N ? vbase + (unsigned)j * 64u : oobI;
 #pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            const bool ok = (16 * i < rowlim) && (n0 + wc + 4 * g + 16 * j) < N;
-            const unsigned vo = ok ? rowb + (unsigned)i * 16u * ldI * 4u + (unsigned)j * 64u : oobI;
-            acc[i][j] = __builtin_bit_cast(f32x4, buf_load16(rsI, vo, soff));
-          }
+        for (int i = 0; i < MI; ++i) {
+          const bool rowok = 16 * i < rowlim;
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_bit_cast(f32x4, buf_load16(rsI, rowok ? vb[j] : oobI, soff + (unsigned)i * rstep));
+          __builtin_amdgcn_sched_barrier(0);   // (one fragment row's addresses at a time: 32 of them up front do not fit)
+        }
         return true;
       }
     }
@@ -286,7 +303,6 @@ struct PipeP {
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     return false;
   }
-
   // v_permlane16_swap in inline asm with its wait states inside the statement: two before (the operands come straight from
   // v_cvt_pk; hipcc pads only its own builtin) and four behind it - the instruction also rewrites its SOURCE operand, and a VALU
   // or store that read either register in the next issue slots got the old value on some waves of some launches (bring-up:
@@ -326,30 +342,40 @@ struct PipeP {
     const int pr = ln & 15, g = ln >> 4;
     const int rowlim = M - m0 - wr - pr;   // fragment row i lies inside the matrix iff 16 i < rowlim
     constexpr unsigned E = (unsigned)sizeof(TC);
-    const unsigned soff = (unsigned)m0 * ldc * E + (unsigned)n0 * E;
-    const unsigned rowb = (unsigned)(wr + pr) * ldc * E, rstep = 16u * ldc * E;
+    // fragment row i rides in the scalar offset; the lane's offset inside fragment row 0 (or the out-of-range marker for a column
+    // beyond N) is computed once per tile; a row beyond M swaps the marker in per store
+    const unsigned soff = (unsigned)m0 * ldc * E + (unsigned)n0 * E, rstep = 16u * ldc * E;
+    const unsigned rowb = (unsigned)(wr + pr) * ldc * E;
     if constexpr (F32OUT) {
       const int cb = wc + 4 * g;
+      unsigned vb[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int j = 0; j < NI; ++j) vb[j] = (n0 + cb + 16 * j) < N ? rowb + (unsigned)(cb + 16 * j) * 4u : oobC;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const bool ok = (16 * i < rowlim) && (n0 + cb + 16 * j) < N;
-          const unsigned vo = ok ? rowb + (unsigned)i * rstep + (unsigned)(cb + 16 * j) * 4u : oobC;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsC, (int)vo, (int)soff, 0);
-        }
+      for (int i = 0; i < MI; ++i) {
+        const bool rowok = 16 * i < rowlim;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsC, (int)(rowok ? vb[j] : oobC),
+                                                 (int)(soff + (unsigned)i * rstep), 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
-      if (epi == 0) {
+      if (epi == 0) {   // plain 8-byte stores (bring-up reference)
         const int cb = wc + 4 * g;
+        unsigned vb[NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NI; ++j) vb[j] = (n0 + cb + 16 * j) < N ? rowb + (unsigned)(cb + 16 * j) * 2u : oobC;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const bool rowok = 16 * i < rowlim;
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            const bool ok = (16 * i < rowlim) && (n0 + cb + 16 * j) < N;
-            const unsigned vo = ok ? rowb + (unsigned)i * rstep + (unsigned)(cb + 16 * j) * 2u : oobC;
             const u32x2 w = {pack2_bf16(acc[i][j][0], acc[i][j][1]), pack2_bf16(acc[i][j][2], acc[i][j][3])};
-            __builtin_amdgcn_raw_buffer_store_b64(w, rsC, (int)vo, (int)soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(w, rsC, (int)(rowok ? vb[j] : oobC), (int)(soff + (unsigned)i * rstep), 0);
           }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
         // lane (pr, g) holds columns 16 j + 4 g .. + 3 of row pr for j = 0..3 (8 bytes each).  v_permlane16_swap exchanges the odd
         // 16-lane rows of its first operand with the even rows of its second: with X = fragment 2q, Y = fragment 2q + 1,
@@ -359,17 +385,20 @@ struct PipeP {
         // wave's 64 columns.
         const int cg = 16 * (g & 1) + 8 * (g >> 1);
         if (epi == 1) {   // one chunk per store: the four lanes of a row cover 64 contiguous bytes
+          unsigned vb[2];
 #pragma unroll
-          for (int i = 0; i < MI; ++i)
+          for (int q = 0; q < 2; ++q) vb[q] = (n0 + wc + cg + 32 * q) < N ? rowb + (unsigned)(wc + cg + 32 * q) * 2u : oobC;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const bool rowok = 16 * i < rowlim;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
               u32x4 w;
               swapped_chunk(i, q, w);
-              const int col = wc + cg + 32 * q;
-              const bool ok = (16 * i < rowlim) && (n0 + col) < N;
-              const unsigned vo = ok ? rowb + (unsigned)i * rstep + (unsigned)col * 2u : oobC;
-              store16(w, vo, soff);
+              store16(w, rowok ? vb[q] : oobC, soff + (unsigned)i * rstep);
             }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         } else {
           // epi 2 - whole 128-byte lines per store: neighbouring lanes pr, pr ^ 1 (rows 2 t, 2 t + 1) trade a chunk through DPP
           // (quad_perm [1,0,3,2]): the even lane gives its chunk 1 and takes the odd lane's chunk 0.  Store 0 then writes row 2 t
@@ -377,8 +406,8 @@ struct PipeP {
           const int odd = pr & 1;
           const int col = wc + cg + 32 * odd;
           const int rl0 = rowlim + odd;            // row 16 i + (pr & ~1) inside the matrix  <=>  16 i < rl0
-          const unsigned rowb0 = rowb - (unsigned)odd * ldc * 2u;
-          const bool colok = (n0 + col) < N;
+          const unsigned vb0 = (n0 + col) < N ? rowb - (unsigned)odd * ldc * 2u + (unsigned)col * 2u : oobC;
+          const unsigned vb1 = (n0 + col) < N ? vb0 + ldc * 2u : oobC;
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             u32x4 c0, c1, d0, d1;
@@ -391,13 +420,38 @@ struct PipeP {
               d0[e] = odd ? from1 : c0[e];
               d1[e] = odd ? c1[e] : from0;
             }
-            const unsigned vo0 = (colok && 16 * i < rl0) ? rowb0 + (unsigned)i * rstep + (unsigned)col * 2u : oobC;
-            const unsigned vo1 = (colok && 16 * i + 1 < rl0) ? rowb0 + (unsigned)i * rstep + ldc * 2u + (unsigned)col * 2u : oobC;
-            store16(d0, vo0, soff);
-            store16(d1, vo1, soff);
+            store16(d0, 16 * i < rl0 ? vb0 : oobC, soff + (unsigned)i * rstep);
+            store16(d1, 16 * i + 1 < rl0 ? vb1 : oobC, soff + (unsigned)i * rstep);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
+    }
+  }
+
+  // the tile loop; SKIP = false returns true when the next tile is a ragged-strip tile (to be continued by tiles<true>)
+  template <bool SKIP>
+  __device__ __forceinline__ bool tiles(int& m0, int& n0) {
+    for (;;) {
+      ktile<0, M_FIRST, SKIP>();
+      ktile<1, M_PUBLISH, SKIP>();
+      for (int it = 2; it < nk2 - 2; it += 2) {
+        ktile<0, M_NORMAL, SKIP>();
+        ktile<1, M_NORMAL, SKIP>();
+      }
+      ktile<0, M_LAST, SKIP>();      // from its barrier on the DMA fetches the next tile
+      ktile<1, M_NORMAL, SKIP>();
+      // tile change: the rest of the next tile's second K-tile goes out ahead of the stores
+      issue_piece<1, 3>(1); issue_piece<1, 4>(1); issue_piece<1, 5>(1); issue_piece<1, 6>(1); issue_piece<1, 7>(1);
+      fence();
+      epilogue(m0, n0);
+      fence();
+      if (!has_next) return false;
+      m0 = nm0; n0 = nn0;
+      set_nact(m0);
+      const bool ld = init_acc(m0, n0);
+      fence();
+      pend = !ld && epi != 3;
     }
   }
 
@@ -430,26 +484,8 @@ struct PipeP {
     kti = 0;
     pend = false;
     has_next = false;
-    for (;;) {
-      group<0, 0, M_FIRST>();
-      group<1, 0, M_PUBLISH>();
-      for (int it = 2; it < nk2 - 2; it += 2) {
-        group<0, 0, M_NORMAL>();
-        group<1, 0, M_NORMAL>();
-      }
-      group<0, 0, M_LAST>();      // from its barrier on the DMA fetches the next tile
-      group<1, 0, M_NORMAL>();
-      // tile change: the rest of the next tile's second K-tile goes out ahead of the stores
-      issue_piece<1, 3>(1); issue_piece<1, 4>(1); issue_piece<1, 5>(1); issue_piece<1, 6>(1); issue_piece<1, 7>(1);
-      fence();
-      epilogue(m0, n0);
-      fence();
-      if (!has_next) break;
-      m0 = nm0; n0 = nn0;
-      const bool ld = init_acc(m0, n0);
-      fence();
-      pend = !ld && epi != 3;
-    }
+    set_nact(m0);
+    tiles<false>(m0, n0);
     // trailing zero-fill DMA pieces and look-ahead reads must not outlive the workgroup's LDS allocation
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }

@@ -2,6 +2,7 @@
 #include "gemm256p.h"
 #include "gemm_p.h"
 #include <mutex>
+#include <stdio.h>
 
 namespace {
 
@@ -39,20 +40,26 @@ unsigned* counters_for(hipStream_t s, int* cus) {
   return g_slots.base + (g_slots.n++) * 16;
 }
 
+// MUSE_G256P_DEBUG=1: say on stderr why a product does not take the persistent kernel
+#define P_REJECT(why) do { if (getenv("MUSE_G256P_DEBUG")) fprintf(stderr, "[g256p] %dx%dx%d la%d lb%d out%d: %s\n", p.M, p.N, p.K, la, lb, (int)sizeof(TC), why); return false; } while (0)
 template <typename TC>
 bool eligible(const GemmParams& p, int la, int lb, int batch) {
   constexpr long E = (long)sizeof(TC);
-  if (batch != 1 || p.split_k > 1 || p.act != 0 || p.bias || p.rowvec) return false;
-  if (p.K <= 128) return false;                                   // at least two K-tile pairs per output tile
-  if (sizeof(TC) == 2 && (p.residual || p.accumulate)) return false;
-  if (sizeof(TC) == 4 && ((p.residual && p.accumulate) || ((p.residual || p.accumulate) && p.alpha != 1.f))) return false;
-  if (!gemm256_ok<TC>(p, la, lb)) return false;
+  if (batch != 1 || p.split_k > 1 || p.act != 0 || p.bias || p.rowvec) P_REJECT("batch / split-K / activation / bias / row vector");
+  // instantiated forms: A k-contiguous; bf16 output with either B layout (Linear forward, dX), f32 output with B k-contiguous
+  // (forward into the f32 residual stream).  The other layout pairs compile with a few spilled registers and stay with the
+  // launch-per-tile kernel.
+  if (la != 0 || (sizeof(TC) == 4 && lb != 0)) P_REJECT("operand layout");
+  if (p.K <= 128) P_REJECT("K <= 128");                            // at least two K-tile pairs per output tile
+  if (sizeof(TC) == 2 && (p.residual || p.accumulate)) P_REJECT("bf16 residual / accumulate");
+  if (sizeof(TC) == 4 && ((p.residual && p.accumulate) || ((p.residual || p.accumulate) && p.alpha != 1.f))) P_REJECT("residual + accumulate / alpha");
+  if (!gemm256_ok<TC>(p, la, lb)) P_REJECT("gemm256_ok");
   // every tensor is addressed as (per-lane offset | out-of-range marker) + scalar tile offset, 32 bits, through a buffer descriptor:
   // keep each below 2 GiB so that marker + tile offset cannot wrap back into range
   const long ra = la == 0 ? p.M : p.K, rb = lb == 0 ? p.N : p.K;
-  if ((ra * p.lda + 16) * 2 >= (1L << 31) || (rb * p.ldb + 16) * 2 >= (1L << 31)) return false;
-  if (((long)p.M * p.ldc + 16) * E >= (1L << 31)) return false;
-  if (p.residual && ((long)p.M * p.ldr + 16) * E >= (1L << 31)) return false;
+  if ((ra * p.lda + 16) * 2 >= (1L << 31) || (rb * p.ldb + 16) * 2 >= (1L << 31)) P_REJECT("operand >= 2 GiB");
+  if (((long)p.M * p.ldc + 16) * E >= (1L << 31)) P_REJECT("C >= 2 GiB");
+  if (p.residual && ((long)p.M * p.ldr + 16) * E >= (1L << 31)) P_REJECT("residual >= 2 GiB");
   return true;
 }
 
@@ -60,7 +67,10 @@ template <typename TC, int AL, int BL>
 int launch(const GemmParams& p, hipStream_t stream) {
   int cus = 0;
   unsigned* counters = counters_for(stream, &cus);
-  if (!counters || cus < 8) return -1;
+  if (!counters || cus < 8) {
+    if (getenv("MUSE_G256P_DEBUG")) fprintf(stderr, "[g256p] no queue slot (counters %p, %d CUs)\n", (void*)counters, cus);
+    return -1;
+  }
   g256p::PArgs a;
   a.g = p;
   a.counters = counters;
@@ -92,23 +102,21 @@ int launch(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <typename TC>
-int launch_l(const GemmParams& p, int la, int lb, hipStream_t s) {
-  if (la == 0 && lb == 0) return launch<TC, 0, 0>(p, s);
-  if (la == 0 && lb == 1) return launch<TC, 0, 1>(p, s);
-  if (la == 1 && lb == 1) return launch<TC, 1, 1>(p, s);
-  return launch<TC, 1, 0>(p, s);
+int launch_l(const GemmParams& p, int la, int lb, bool f32_out, hipStream_t s) {
+  if (la != 0) return -1;
+  if (f32_out) return lb == 0 ? launch<float, 0, 0>(p, s) : -1;
+  return lb == 0 ? launch<bf16_t, 0, 0>(p, s) : launch<bf16_t, 0, 1>(p, s);
 }
 
 }  // namespace
 
 // MUSE_G256P = 0: never (launch-per-tile kernel), 1 (default): whenever eligible
 bool gemm256p_takes(const GemmParams& p, int la, int lb, int batch, bool f32_out) {
-  static const int mode = []() { const char* e = getenv("MUSE_G256P"); return e ? atoi(e) : 1; }();
-  if (!mode) return false;
+  const char* e = getenv("MUSE_G256P");   // read per call (cheap) so tests can compare both kernels in one process
+  if (e && e[0] == '0') return false;
   return f32_out ? eligible<float>(p, la, lb, batch) : eligible<bf16_t>(p, la, lb, batch);
 }
 
 int launch_gemm256p(const GemmParams& p, int la, int lb, bool f32_out, hipStream_t stream) {
-  return f32_out ? launch_l<float>(p, la, lb, stream) : launch_l<bf16_t>(p, la, lb, stream);
+  return launch_l(p, la, lb, f32_out, stream);
 }

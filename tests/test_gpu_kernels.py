@@ -731,6 +731,47 @@ def test_gemm_256_matches_128_on_model_shapes(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(520, 264, 200), (4360, 4104, 264), (16448, 776, 328)])
+def test_gemm_256_persistent_matches_launch_per_tile(monkeypatch, la, lb, M, N, K):
+    """the persistent tile-walking 256x256 kernel (csrc/gemm256p.h; MUSE_G256P=1, the default) against the launch-per-tile kernel
+    (MUSE_G256P=0): same products in the same order, so bf16 outputs must be BIT-identical - on a single-round grid, on a grid with
+    more tiles than CUs (18 x 17 = 306 tiles: per-XCD ticket queues, tile changes inside the K pipeline, the register epilogue
+    with its lane exchanges) and on the train step's ragged M = 64 x 257 (row strip with skipped MFMA groups); f32 outputs that
+    start the accumulators from a residual / the old C differ by the order of one addition; repeated launches are bit-identical
+    (race screen), and the f64 reference is met"""
+    ops = _ops()
+    monkeypatch.setenv("MUSE_GEMM256", "1")
+    A, B = rnd((M, K), 301).to(torch.bfloat16), rnd((N, K), 302).to(torch.bfloat16)
+    Ad = (A if la == 0 else A.t().contiguous()).to(DEV)
+    Bd = (B if lb == 0 else B.t().contiguous()).to(DEV)
+    lda, ldb = (K if la == 0 else M), (K if lb == 0 else N)
+    res = rnd((M, N), 303).to(DEV)
+    ref = (Ad.double() if la == 0 else Ad.double().t()) @ (Bd.double().t() if lb == 0 else Bd.double())
+
+    def run(persistent, out_dtype, **kw):
+        monkeypatch.setenv("MUSE_G256P", "1" if persistent else "0")
+        C = torch.full((M, N), 7.0, dtype=out_dtype, device=DEV)
+        ops.gemm(Ad, Bd, C, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=N, **kw)
+        return C
+    old_b, new_b = run(False, torch.bfloat16), run(True, torch.bfloat16)
+    assert torch.equal(old_b.view(torch.int16), new_b.view(torch.int16))
+    assert rel_err(new_b.float(), ref) < 1e-2
+    for _ in range(6):
+        assert torch.equal(run(True, torch.bfloat16).view(torch.int16), new_b.view(torch.int16))
+    old_s, new_s = run(False, torch.bfloat16, alpha=0.25), run(True, torch.bfloat16, alpha=0.25)
+    assert torch.equal(old_s.view(torch.int16), new_s.view(torch.int16))
+    old_f, new_f = run(False, torch.float32), run(True, torch.float32)
+    assert torch.equal(old_f, new_f)
+    tol = 2e-5 * math.sqrt(K)
+    new_r = run(True, torch.float32, residual=res, ldr=N)
+    assert rel_err(new_r, ref + res.double()) < tol and rel_err(new_r, run(False, torch.float32, residual=res, ldr=N)) < 1e-6
+    new_a = run(True, torch.float32, accumulate=True)
+    assert rel_err(new_a, ref + 7.0) < tol
+    for _ in range(3):
+        assert torch.equal(run(True, torch.float32, residual=res, ldr=N), new_r)
+
+
 @pytest.mark.parametrize("rows,cols", [(37, 768), (130, 512), (5, 64), (64, 1024)])
 def test_layernorm_pair_matches_two_calls(rows, cols):
     """the fused NormFormer LayerNorm pair (x1 = x + LN(ao) w_post ; ln2 = LN(x1) w_pre, and its backward) against the two
