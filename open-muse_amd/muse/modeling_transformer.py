@@ -28,6 +28,7 @@ from torch import nn
 from . import ops
 from ._hip import MuseHipError
 from .modeling_utils import ConfigMixin, ModelMixin, register_to_config
+from .maskgit_general import GeneralMaskGitEngine
 from .sampling import cosine_schedule, decode_seed, scheduled_mask_len, step_noise
 
 _ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the flat buffer
@@ -103,7 +104,7 @@ class _MaskGitFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
-class MaskGitTransformer(ModelMixin, ConfigMixin):
+class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
     _supports_gradient_checkpointing = True
 
     @register_to_config
@@ -138,20 +139,17 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         **kwargs,
     ):
         super().__init__()
-        unsupported = []
-        if add_cross_attention or project_encoder_hidden_states:
-            unsupported.append("cross attention (text conditioning)")
-        if norm_type != "layernorm":
-            unsupported.append(f"norm_type={norm_type}")
-        if not (use_normformer and use_encoder_layernorm and use_mlm_layer and use_mlm_layernorm):
-            unsupported.append("non-NormFormer / no-MLM-layer variants")
         if use_bias or use_conv_in_out:
-            unsupported.append("use_bias / use_conv_in_out")
-        if embedding_size not in (None, hidden_size):
-            unsupported.append("embedding_size != hidden_size")
-        if unsupported:
-            raise NotImplementedError("MI355X hot-path build covers the class-conditional MaskGit configs "
-                                      "(README example, configs/imagenet.yaml); unsupported here: " + ", ".join(unsupported))
+            raise NotImplementedError("MaskGitTransformer (MI355X build): use_bias / use_conv_in_out are not built (no configuration "
+                                      "of the reference sets them; ConvEmbed / ConvMlmLayer are only reachable through use_conv_in_out)")
+        if norm_type not in ("layernorm", "rmsnorm"):
+            raise ValueError(f"norm_type must be 'layernorm' or 'rmsnorm', got {norm_type}")
+        # (`embedding_size` is accepted and, as in the reference, unused: the constructor hands `hidden_size` to Embed for both widths,
+        #  modeling_transformer.py:1143-1152)
+        # the class-conditional NormFormer family (README example, configs/imagenet.yaml) runs on the flat-buffer engine below;
+        # everything else - text conditioning, RMSNorm, plain pre-LN layers, no MLM head - on the tape engine (maskgit_general.py)
+        self._general = bool(add_cross_attention or project_encoder_hidden_states or norm_type != "layernorm" or not use_normformer
+                             or not use_encoder_layernorm or not use_mlm_layer or not use_mlm_layernorm)
         if hidden_size % num_attention_heads:
             raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {hidden_size} and"
                              f" `num_heads`: {num_attention_heads}).")
@@ -170,6 +168,13 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         self.embedding_size = embedding_size or hidden_size
         self.register_to_config(mask_token_id=vocab_size - 1)
         self.output_size = codebook_size if use_codebook_size_for_output else vocab_size
+        self.gradient_checkpointing = False
+        self._flat = None
+        if self._general:
+            self.wgrad_stream = os.environ.get("MUSE_WGRAD_STREAM", "1") != "0"
+            self._cd_request = "auto"
+            self._gen_build()
+            return
 
         H, I, V = hidden_size, intermediate_size, vocab_size
         self.embed = _Embed(V, max_position_embeddings, H)
@@ -238,6 +243,9 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
+        if self._general:
+            self._wcache, self._wcache_owner = {}, {}
+            return out
         if self._flat is not None:
             p0 = self._param_order()[0]
             if p0.dtype != torch.float32:
@@ -247,6 +255,9 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        if self._general:
+            self._wcache, self._wcache_owner = {}, {}
+            return out
         if not self._flat_ok():
             self._build_flat()
         self._shadow_fresh = False
@@ -267,13 +278,17 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
     def set_compute_dtype(self, dtype):
         if dtype not in ("auto", torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be 'auto', torch.float32 or torch.bfloat16")
+        if self._general:
+            self._cd_request = dtype          # (the tape helpers read self.compute_dtype: resolved at every forward)
+            return self
         self.compute_dtype = dtype
         self._shadow_fresh = False
         return self
 
     def _resolve_cd(self):
-        if self.compute_dtype != "auto":
-            return self.compute_dtype
+        want = self._cd_request if self._general else self.compute_dtype
+        if want != "auto":
+            return want
         if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
             return torch.bfloat16
         return torch.float32
@@ -298,6 +313,7 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
     def mark_weights_changed(self):
         """call after writing the f32 master weights behind autograd's back (`p.data.copy_`, a raw kernel on flat_params())"""
         self._shadow_fresh = False
+        self._wcache, self._wcache_owner = {}, {}
 
     def _note_shadow_refreshed(self, fresh: bool):
         """FusedAdamW has just rewritten the master weights and (if `fresh`) the bf16 copy in the same kernel"""
@@ -308,7 +324,8 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
     def train(self, mode: bool = True):
         if mode != self.training:
             self._shadow_fresh = False   # EMA copy_to()/restore() around evaluation write p.data (reference modeling_ema.py)
-        return super().train(mode)
+            self._wcache, self._wcache_owner = {}, {}
+        return nn.Module.train(self, mode)
 
     def _wgrad_side_stream(self, dev):
         if self._side_stream is None or self._side_stream.device != dev:
@@ -362,8 +379,25 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
     # ------------------------------------------------------------------------------------------------------------
     def forward(self, input_ids, encoder_hidden_states=None, encoder_attention_mask=None, labels=None,
                 label_smoothing=0.0, cond_dropout_prob=0.0, **kwargs):
+        """reference :1224-1281.  Extra kwargs are accepted and ignored like the reference's **kwargs (train_muse.py passes
+        cond_embeds / loss_weight / micro_conds, :742-750); `cond_dropout_uniforms` [B] (tests) replaces the draw of
+        `prob_mask_like`.  `encoder_attention_mask` raises: the reference's own mask path fails with a TypeError
+        (`make_attention_mask(..., dtype=...)`, :214) and its fused-attention path refuses masks (:191-192)."""
+        if self.config.add_cross_attention and encoder_hidden_states is None:
+            raise ValueError("If `add_cross_attention` is True, `encoder_hidden_states` should be provided.")
+        if encoder_attention_mask is not None:
+            raise NotImplementedError("encoder_attention_mask is not supported (the reference's mask path is broken as well)")
+        if self._general:
+            cd = self._resolve_cd()
+            if cd != self.compute_dtype:
+                self.compute_dtype = cd
+                self._wcache, self._wcache_owner = {}, {}
+            if encoder_hidden_states is not None and not self.config.add_cross_attention:
+                encoder_hidden_states = None      # (layers without a cross-attention block: the reference would fail on a missing module)
+            return self._gen_call(input_ids, encoder_hidden_states, labels, label_smoothing, cond_dropout_prob,
+                                  kwargs.get("cond_dropout_uniforms"))
         if encoder_hidden_states is not None:
-            raise NotImplementedError("text conditioning (encoder_hidden_states) is outside the MI355X hot-path build")
+            raise ValueError("this model was built without cross attention (add_cross_attention=False)")
         if not input_ids.is_cuda:
             raise MuseHipError("MaskGitTransformer (MI355X build) has no CPU path: move the model and inputs to the GPU")
         if not self._flat_ok():
@@ -679,39 +713,53 @@ class MaskGitTransformer(ModelMixin, ConfigMixin):
         ~12 kernel launches per layer - what small-batch decoding is bound by.
         Like the reference, `class_ids` is shifted by codebook_size IN PLACE (:1388-1389) and the temperature compounds
         across steps (:1451)."""
-        if encoder_hidden_states is not None:
-            raise NotImplementedError("text conditioning is outside the MI355X hot-path build")
         cfg = self.config
         mask_id, S, V = cfg.mask_token_id, cfg.num_vq_tokens, cfg.codebook_size
-        B = len(class_ids)
-        class_ids += V
+        B = len(class_ids) if class_ids is not None else encoder_hidden_states.shape[0]
+        dev = class_ids.device if class_ids is not None else encoder_hidden_states.device
+        if class_ids is not None:
+            class_ids += V
         if input_ids is None:
-            input_ids = torch.full((B, S), mask_id, dtype=torch.long, device=self.device)
+            input_ids = torch.full((B, S), mask_id, dtype=torch.long, device=dev)
         seed = decode_seed(generator) if noise is None else 0
-        model_in = torch.empty((B, S + 1), dtype=torch.long, device=input_ids.device)
-        model_in[:, 0] = class_ids
+        # classifier-free guidance (:1394-1401): conditional batch followed by the unconditional one (zeros unless negative_embeds)
+        guided = encoder_hidden_states is not None and guidance_scale > 0
+        enc = encoder_hidden_states
+        if guided:
+            enc = torch.cat([encoder_hidden_states, torch.zeros_like(encoder_hidden_states) if negative_embeds is None else negative_embeds])
+        off = 1 if class_ids is not None else 0
+        rows = 2 * B if guided else B
+        model_in = torch.empty((rows, S + off), dtype=torch.long, device=dev)
+        if class_ids is not None:
+            model_in[:, 0] = class_ids.repeat(2) if guided else class_ids
         sampled = input_ids
         graph = None
-        if hip_graph:
-            graph, model_in, logits = self._decode_graph(B, S + 1, input_ids.device)
+        if hip_graph and enc is None:
+            graph, model_in, logits = self._decode_graph(B, S + 1, dev)
             model_in[:, 0] = class_ids
         for step in range(timesteps):
-            model_in[:, 1:] = input_ids
+            model_in[:B, off:] = input_ids
+            if guided:
+                model_in[B:, off:] = input_ids
             if graph is None:
-                logits = self(model_in)                               # [B, S + 1, vocab] f32; row 0 of each image is the class token
+                logits = self(model_in, encoder_hidden_states=enc)       # [rows, S + off, vocab] f32; row 0 of each image: the class token
             else:
                 graph.replay()
             temperature = temperature * (1.0 - 1.0 * (step + 1) / timesteps)
             q, u = step_noise(noise, step)
-            sampled, input_ids, _ = ops.sample_step(logits[:, 1:], input_ids, mask_id, V, temperature,
-                                                    scheduled_mask_len(S, step, timesteps, noise_schedule), noise_exp=q, noise_u=u,
-                                                    seed=seed, step=step)
+            sampled, input_ids, _ = ops.sample_step(logits[:B, off:], input_ids, mask_id, V, temperature,
+                                                    scheduled_mask_len(S, step, timesteps, noise_schedule),
+                                                    uncond_logits=logits[B:, off:] if guided else None,
+                                                    guidance_scale=float(guidance_scale) if guided else 0.0,
+                                                    noise_exp=q, noise_u=u, seed=seed, step=step)
         return sampled
 
     def _decode_graph(self, B, S, device):
         """(graph, input buffer [B, S], logits) of the forward captured as a HIP graph, kept across generate2 calls for as long
         as the weight buffers, the compute dtype and the mode stay the same.  The graph reads the weights through their buffers:
         in-place updates are seen; a stale bf16 shadow is re-cast here (host logic the replay does not run)."""
+        if self._general:
+            raise MuseHipError("hip_graph decoding is built for the class-conditional model only")
         if not self._flat_ok():
             self._build_flat()
         cd = self._resolve_cd()

@@ -53,8 +53,9 @@ class PipelineMuse:
                  aesthetic_score=6.0, return_intermediate: bool = False, use_tqdm=True, transformer_seq_len=None,
                  clip_skip: int = None, output_type: str = "pil", empty_embeds: Optional[torch.Tensor] = None,
                  empty_pooled_embeds: Optional[torch.Tensor] = None):
-        """reference :66-243, same argument names and defaults.  Two executable paths: class-conditional MaskGitTransformer
-        (`class_ids`), and MaskGiTUViT conditioned on PRE-COMPUTED text states (`prompt_embeds` [B, 77, D] + `pooled_embeds`
+        """reference :66-243, same argument names and defaults.  Three executable paths: class-conditional MaskGitTransformer
+        (`class_ids`), text-conditioned MaskGitTransformer on PRE-COMPUTED text states (`prompt_embeds`, `negative_prompt_embeds`),
+        and MaskGiTUViT conditioned on PRE-COMPUTED text states (`prompt_embeds` [B, 77, D] + `pooled_embeds`
         [B, D], with `empty_embeds` / `empty_pooled_embeds` or the negative_* pair for classifier-free guidance); running a text
         encoder on `text` needs CLIP, which is outside the hot-path build.  `temperature` may be the reference's (start, end)
         tuple: MaskGitTransformer.generate2 takes a float, so the tuple's first entry is used there."""
@@ -74,6 +75,17 @@ class PipelineMuse:
             t0 = float(temperature[0]) if isinstance(temperature, (tuple, list)) else float(temperature)
             ids = self.transformer.generate2(class_ids=class_ids, timesteps=timesteps, temperature=t0, guidance_scale=guidance_scale,
                                              noise_schedule=schedule, generator=generator)
+            intermediate = None
+        elif isinstance(self.transformer, MaskGitTransformer):
+            # text-conditioned MaskGitTransformer on pre-computed text states (reference :207-243 hands the same keyword set to
+            # every transformer class; MaskGitTransformer.generate2 takes the states, the negative states and a float temperature)
+            n = num_images_per_prompt
+            rep = lambda t: None if t is None else t.to(self.device).repeat_interleave(n, dim=0)   # noqa: E731
+            t0 = float(temperature[0]) if isinstance(temperature, (tuple, list)) else float(temperature)
+            neg = negative_prompt_embeds if negative_prompt_embeds is not None else empty_embeds
+            ids = self.transformer.generate2(encoder_hidden_states=rep(prompt_embeds), negative_embeds=rep(neg), timesteps=timesteps,
+                                             temperature=t0, guidance_scale=guidance_scale, noise_schedule=schedule,
+                                             generator=generator)
             intermediate = None
         else:
             n = num_images_per_prompt

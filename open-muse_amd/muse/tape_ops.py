@@ -1,0 +1,268 @@
+"""Hand-written forward / backward building blocks shared by the tape engines (muse.MaskGiTUViT_v2 and the general form of
+muse.MaskGitTransformer: text conditioning, RMSNorm, non-NormFormer layers).
+
+Activations are channels-last rows ``[B * S, C]``, f32 between blocks.  Every helper returns (output, saved); its *_bwd twin
+consumes `saved`, stores parameter gradients in `G` (state-dict name -> tensor) and returns the input gradients.  The host class
+provides: `compute_dtype` (torch.float32 = exact-f32 MFMA parity mode, torch.bfloat16 = bf16 GEMM operands with f32 accumulation,
+the reference's autocast regime), `config.layer_norm_eps`, `wgrad_stream`, `_side_stream`.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import ops
+from ._hip import MuseHipError
+
+# MUSE_UVIT_BF16_OPERANDS (experiments): bit 0 = AdaLN writes the bf16 GEMM operand, bit 1 = norm backward writes the bf16 copy of dv
+_BF16_OPERANDS = int(os.environ.get("MUSE_UVIT_BF16_OPERANDS", "3"))
+
+
+class TapeOps:
+    @staticmethod
+    def _f(p):
+        return p.data if p.dtype == torch.float32 else p.data.float()
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (default): exact-f32 MFMA everywhere (parity mode).  torch.bfloat16: the operands of every weight GEMM
+        (linears, 1x1 convs, their dX / dW) are rounded to bf16 and run on the bf16 MFMA kernels with f32 accumulation and f32
+        outputs - the reference's autocast regime; the residual stream, norms, AdaLN, GRN, depthwise conv, softmax / attention
+        core and the loss stay f32."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        self._wcache, self._wcache_owner = {}, {}
+        return self
+
+    def mark_weights_changed(self):
+        """call after writing parameters behind autograd's back (`p.data.copy_`, EMA swap): drops the cached bf16 weights"""
+        self._wcache, self._wcache_owner = {}, {}
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            self._wcache, self._wcache_owner = {}, {}        # EMA copy_to()/restore() around evaluation write p.data
+        return super().train(mode)
+
+    def _c(self, t):
+        """GEMM operand in the compute dtype"""
+        if self.compute_dtype == torch.float32 or t.dtype == torch.bfloat16:
+            return t
+        # an activation is a GEMM operand twice: in the forward product and in the backward dW product.  The bf16 copy made
+        # for the first use is kept (keyed by the tensor object, dropped when the step's backward has run) instead of casting again.
+        cache = self.__dict__.setdefault("_act_cache", {})
+        hit = cache.get(id(t))
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        tb = ops.cast_to_bf16(t.contiguous())
+        if self.__dict__.get("_act_cache_on", False):
+            cache[id(t)] = (t, tb)
+        return tb
+
+    def _wb(self, *mods):
+        """bf16 compute copy of one Linear / 1x1-conv weight, or of several stacked along the output dim (q|k|v, k|v, wi_0|wi_1),
+        as [N_out_total, K_in].  Cached across steps: valid while no source parameter has been updated in place (autograd version
+        counters; muse.FusedAdamW refreshes the copy it is given - `p._muse_shadow`, ONE pointer per parameter - inside its own
+        kernel without touching the counters).  A weight therefore lives in at most one cached stacking at a time: caching it in
+        another one (fused q|k|v against single q / k / v when `attention_supported` differs between sequence lengths, or a
+        generate2 call on a model left in train mode) drops the stacking that held it before, which would otherwise keep
+        passing the version check with stale bytes after the next optimizer step."""
+        key = tuple(id(m.weight) for m in mods)
+        ver = tuple(m.weight._version for m in mods)
+        cache = self.__dict__.setdefault("_wcache", {})
+        owner = self.__dict__.setdefault("_wcache_owner", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver and hit[1].device == mods[0].weight.device:
+            return hit[1]
+        ws = [self._f(m.weight).reshape(m.weight.shape[0], -1) for m in mods]
+        wb = ops.cast_to_bf16((ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)).contiguous())
+        for pid in key:
+            prev = owner.get(pid)
+            if prev is not None and prev != key:
+                cache.pop(prev, None)          # (its other members lose their shadow too: they are re-cast on their next use)
+                for q in prev:
+                    if owner.get(q) == prev:
+                        del owner[q]
+            owner[pid] = key
+        cache[key] = (ver, wb)
+        off = 0
+        for m in mods:   # muse.FusedAdamW writes each parameter's refreshed bf16 copy straight into its row block of the cached tensor
+            n = m.weight.shape[0]
+            m.weight._muse_shadow = wb[off:off + n]
+            off += n
+        return wb
+
+    def _w2(self, *mods):
+        """the weight(s) as the GEMM operand of the current compute mode: cached bf16 copy, or the f32 master (stacked on the fly)"""
+        if self.compute_dtype == torch.bfloat16:
+            return self._wb(*mods)
+        ws = [self._f(m.weight).reshape(m.weight.shape[0], -1) for m in mods]
+        return ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
+
+    def _mm(self, x, w2, residual=None):
+        """x w2^T (+ residual) -> f32"""
+        return ops.linear(self._c(x), self._c(w2), out_dtype=torch.float32, residual=residual)
+
+    def _mm_dx(self, dy, w2, lda=None, out=None, accumulate=False):
+        """dy w2 -> f32 [rows, K] (optionally accumulated into `out`);  dy [rows, >= N] with row stride lda, w2 [N, K]"""
+        N, K = w2.shape
+        dyb = self._c(dy)
+        if out is None:
+            out = torch.empty((dy.shape[0], K), dtype=torch.float32, device=dy.device)
+        ops.gemm(dyb, self._c(w2), out, dy.shape[0], K, N, la=0, lb=1, lda=lda or dyb.stride(0), ldb=K, ldc=out.stride(0),
+                 accumulate=accumulate)
+        return out
+
+    def _mm_dw(self, dy, x, shape2, M=None, lda=None):
+        """dy^T x -> f32 [N, K].  bf16 mode: on a second HIP stream (weight gradients are leaves of the backward graph: the
+        split-K GEMM and its slice reduction fill CUs the dX / attention / norm chain leaves idle); _run_backward joins the
+        stream before it hands the gradients to autograd."""
+        dyc, xc = self._c(dy), self._c(x)
+        if not (self.wgrad_stream and self.compute_dtype == torch.bfloat16 and x.is_cuda):
+            dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
+            ops.linear_wgrad(dyc, xc, dw, False, M=M, lda=lda)
+            return dw
+        main = torch.cuda.current_stream(x.device)
+        if self._side_stream is None or self._side_stream.device != x.device:
+            self._side_stream = torch.cuda.Stream(device=x.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
+            ops.linear_wgrad(dyc, xc, dw, False, M=M, lda=lda)
+        dyc.record_stream(side)
+        xc.record_stream(side)
+        dw.record_stream(main)
+        self.__dict__["_side_busy"] = True
+        return dw
+
+    def _lin(self, x, mod, residual=None):
+        return self._mm(x, self._w2(mod), residual=residual)
+
+    def _lin_bwd(self, dy, x, mod, name, G, need_dx=True):
+        w2 = self._w2(mod)
+        dyc = self._c(dy)            # one cast feeds both the dW and the dX product
+        G[name + ".weight"] = self._mm_dw(dyc, x, w2.shape).view(mod.weight.shape)
+        return self._mm_dx(dyc, w2) if need_dx else None
+
+    def _norm(self, x, mod, mode=0, residual=None, want_pre=False):
+        y, pre = ops.norm_res_fwd(x, self._f(mod.weight), float(self.config.layer_norm_eps), mode, residual=residual,
+                                  want_pre=want_pre)
+        return y, pre
+
+    def _norm_bwd(self, dy, v, mod, name, G, mode=0, dpre=None, gemm_operand=False):
+        """v = the tensor that was normalised (x + residual); returns d(x) = d(residual).
+        gemm_operand (bf16 mode): dv is also the dY of the next weight GEMMs - the kernel writes its bf16 copy in the same pass
+        and _c(dv) finds it instead of launching a cast."""
+        if gemm_operand and self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 2:
+            dv, dw, dvb = ops.norm_res_bwd(dy, v, self._f(mod.weight), float(self.config.layer_norm_eps), mode, dpre=dpre, also_bf16=True)
+            self.__dict__.setdefault("_act_cache", {})[id(dv)] = (dv, dvb)
+        else:
+            dv, dw = ops.norm_res_bwd(dy, v, self._f(mod.weight), float(self.config.layer_norm_eps), mode, dpre=dpre)
+        G[name + ".weight"] = dw
+        return dv
+
+    def _attention(self, x, ctx, att, B, Sq, Skv, nh, residual=None, drop=None):
+        """`drop` = (p, seed, offset): nn.Dropout on the attention probabilities (training mode of models with attention_dropout > 0;
+        needs the probabilities, so it runs on the materialised path whatever the compute dtype).
+        reference Attention :834-915.  bf16 compute mode: fused attention kernel (S x S never materialised; self- and
+        cross-attention) on a packed q|k|v (self) or k|v (cross) projection.  f32 parity mode: the reference's algorithm
+        materialised: scores = alpha q k^T (batched per head), softmax, P v, out projection."""
+        Cq = x.shape[1]
+        hd = Cq // nh
+        pdrop = drop[0] if drop is not None else 0.0
+        if self.compute_dtype == torch.bfloat16 and ops.attention_supported(torch.bfloat16, Sq, hd, Skv) and pdrop == 0.0:
+            alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+            xb = self._c(x)                   # (already bf16 when it is an AdaLN output; cached otherwise)
+            self_attn = ctx is x
+            if self_attn:
+                qkv = ops.linear(xb, self._wb(att.query, att.key, att.value))            # [B*Sq, 3C] bf16
+                q, k, v, cb = qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], xb
+            else:
+                cb = self._c(ctx)             # the text states feed every layer: one cast per step
+                q = ops.linear(xb, self._wb(att.query))
+                qkv = ops.linear(cb, self._wb(att.key, att.value))                      # [B*Skv, 2C] bf16
+                k, v = qkv[:, :Cq], qkv[:, Cq:]
+            o, lse = ops.attention_fwd_ex(q, k, v, B, Sq, Skv, nh, hd, alpha)
+            y = ops.linear(o, self._wb(att.out), out_dtype=torch.float32, residual=residual)
+            return y, dict(fused=True, self_attn=self_attn, xb=xb, cb=cb, q=q, qkv=qkv, o=o, lse=lse,
+                           dims=(B, Sq, Skv, nh, hd, Cq, alpha))
+        q, k, v = self._lin(x, att.query), self._lin(ctx, att.key), self._lin(ctx, att.value)
+        Sp = (Skv + 7) // 8 * 8
+        P = torch.empty((B * nh, Sq, Sp), dtype=torch.float32, device=x.device)
+        alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+        sQ, sK, sP = (Sq * Cq, hd), (Skv * Cq, hd), (nh * Sq * Sp, Sq * Sp)
+        ops.gemm(q, k, P, Sq, Skv, hd, la=0, lb=0, lda=Cq, ldb=Cq, ldc=Sp, alpha=alpha, batch=B * nh, zdiv=nh, sA=sQ, sB=sK, sC=sP)
+        ops.softmax_(P, B * nh * Sq, Skv, Sp)
+        Pd = ops.dropout(P, pdrop, drop[1], drop[2]) if pdrop > 0.0 else P
+        o = torch.empty((B * Sq, Cq), dtype=torch.float32, device=x.device)
+        ops.gemm(Pd, v, o, Sq, hd, Skv, la=0, lb=1, lda=Sp, ldb=Cq, ldc=Cq, batch=B * nh, zdiv=nh, sA=sP, sB=sK, sC=sQ)
+        y = self._lin(o, att.out, residual=residual)
+        return y, dict(x=x, ctx=ctx, q=q, k=k, v=v, P=P, Pd=Pd, drop=drop if pdrop > 0.0 else None, o=o,
+                       dims=(B, Sq, Skv, nh, hd, Cq, Sp, alpha))
+
+    def _attention_bwd(self, dy, sv, att, name, G, self_attn=False):
+        """-> (dx, dctx); for self attention the two are already summed and returned as dx (dctx = None)"""
+        if sv.get("fused"):
+            return self._attention_bwd_fused(dy, sv, att, name, G, self_attn)
+        B, Sq, Skv, nh, hd, Cq, Sp, alpha = sv["dims"]
+        q, k, v, P = sv["q"], sv["k"], sv["v"], sv["P"]
+        sQ, sK, sP = (Sq * Cq, hd), (Skv * Cq, hd), (nh * Sq * Sp, Sq * Sp)
+        do = self._lin_bwd(dy, sv["o"], att.out, name + ".out", G)
+        dv = torch.empty_like(v)
+        ops.gemm(sv.get("Pd", P), do, dv, Skv, hd, Sq, la=1, lb=1, lda=Sp, ldb=Cq, ldc=Cq, batch=B * nh, zdiv=nh, sA=sP, sB=sQ, sC=sK)   # dV = P^T dO
+        dP = torch.empty_like(P)
+        ops.gemm(do, v, dP, Sq, Skv, hd, la=0, lb=0, lda=Cq, ldb=Cq, ldc=Sp, batch=B * nh, zdiv=nh, sA=sQ, sB=sK, sC=sP)   # dP = dO V^T
+        if sv.get("drop") is not None:
+            ops.dropout(dP, sv["drop"][0], sv["drop"][1], sv["drop"][2], out=dP)
+        ops.softmax_bwd_(P, dP, B * nh * Sq, Skv, Sp)                                                                     # dS in place
+        dq = torch.empty_like(q)
+        ops.gemm(dP, k, dq, Sq, hd, Skv, la=0, lb=1, lda=Sp, ldb=Cq, ldc=Cq, alpha=alpha, batch=B * nh, zdiv=nh, sA=sP, sB=sK, sC=sQ)
+        dk = torch.empty_like(k)
+        ops.gemm(dP, q, dk, Skv, hd, Sq, la=1, lb=1, lda=Sp, ldb=Cq, ldc=Cq, alpha=alpha, batch=B * nh, zdiv=nh, sA=sP, sB=sQ, sC=sK)
+        dx = self._lin_bwd(dq, sv["x"], att.query, name + ".query", G)
+        dctx = self._lin_bwd(dk, sv["ctx"], att.key, name + ".key", G)
+        wv = self._w2(att.value)
+        G[name + ".value.weight"] = self._mm_dw(dv, sv["ctx"], wv.shape)
+        # dctx += dv Wv ; for self attention query and context are the same tensor: everything lands in dx
+        self._mm_dx(dv, wv, out=dctx, accumulate=True)
+        if self_attn:
+            return dx.add_(dctx), None
+        return dx, dctx
+
+    def _attention_bwd_fused(self, dy, sv, att, name, G, self_attn):
+        B, Sq, Skv, nh, hd, Cq, alpha = sv["dims"]
+        dev = dy.device
+        dyb = self._c(dy)
+        wo = self._wb(att.out)
+        G[name + ".out.weight"] = self._mm_dw(dyb, sv["o"], att.out.weight.shape)
+        do = ops.linear_dgrad(dyb, wo)                                                     # bf16 [B*Sq, C]
+        q, qkv = sv["q"], sv["qkv"]
+        if sv["self_attn"]:
+            if not self_attn:
+                raise MuseHipError("self-attention tape replayed as cross-attention")
+            k, v = qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:]
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd_ex(q, k, v, sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq],
+                                 dv=dqkv[:, 2 * Cq:])
+            gqkv = self._mm_dw(dqkv, sv["xb"], (3 * Cq, Cq))
+            G[name + ".query.weight"], G[name + ".key.weight"], G[name + ".value.weight"] = gqkv[:Cq], gqkv[Cq:2 * Cq], gqkv[2 * Cq:]
+            dx = torch.empty((B * Sq, Cq), dtype=torch.float32, device=dev)
+            ops.linear_dgrad(dqkv, self._wb(att.query, att.key, att.value), out=dx)      # d(x) through q, k and v in one GEMM
+            return dx, None
+        k, v = qkv[:, :Cq], qkv[:, Cq:]
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(qkv)
+        ops.attention_bwd_ex(q, k, v, sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:])
+        G[name + ".query.weight"] = self._mm_dw(dq, sv["xb"], att.query.weight.shape)
+        Ck = att.key.weight.shape[1]
+        gkv = self._mm_dw(dkv, sv["cb"], (2 * Cq, Ck))
+        G[name + ".key.weight"], G[name + ".value.weight"] = gkv[:Cq], gkv[Cq:]
+        dx = torch.empty((B * Sq, Cq), dtype=torch.float32, device=dev)
+        ops.linear_dgrad(dq, self._wb(att.query), out=dx)
+        dctx = torch.empty((B * Skv, Ck), dtype=torch.float32, device=dev)
+        ops.linear_dgrad(dkv, self._wb(att.key, att.value), out=dctx)
+        if self_attn:
+            return dx.add_(dctx), None
+        return dx, dctx
+

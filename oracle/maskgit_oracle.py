@@ -342,6 +342,120 @@ def generate2(sd: SD, cfg: dict, class_ids: Tensor, timesteps: int, temperature:
 
 
 # ----------------------------------------------------------------------------------------------
+# MaskGitTransformer, general form: text conditioning, RMSNorm, plain pre-LN layers, optional final norm / MLM head
+# ----------------------------------------------------------------------------------------------
+def _rms(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    # muse/modeling_transformer.py:75-100 (the pure-torch RMSNorm the reference falls back to without apex): f32 variance, no mean
+    variance = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+    return x * torch.rsqrt(variance + eps) * w
+
+
+def _norm_by_type(x: Tensor, w: Tensor, eps: float, cfg: dict) -> Tensor:
+    # norm_cls of muse/modeling_transformer.py:1128, :833, :775, :973
+    return _ln(x, w, eps) if cfg.get("norm_type", "layernorm") == "layernorm" else _rms(x, w, eps)
+
+
+def cross_attention(x: Tensor, ctx: Tensor, sd: SD, prefix: str, num_heads: int) -> Tensor:
+    """Attention.forward with encoder_hidden_states (muse/modeling_transformer.py:190-241): queries from x [B, S, H], keys and
+    values from the text states ctx [B, L, E]; no mask (the reference's encoder_attention_mask path raises, :214)."""
+    B, S, H = x.shape
+    L = ctx.shape[1]
+    hd = H // num_heads
+    q = (x @ sd[prefix + "query.weight"].t()).view(B, S, num_heads, hd).transpose(1, 2)
+    k = (ctx @ sd[prefix + "key.weight"].t()).view(B, L, num_heads, hd).transpose(1, 2)
+    v = (ctx @ sd[prefix + "value.weight"].t()).view(B, L, num_heads, hd).transpose(1, 2)
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+    probs = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * alpha, dim=-1)
+    out = torch.matmul(probs, v).transpose(1, 2).reshape(B, S, H)
+    return out @ sd[prefix + "out.weight"].t()
+
+
+def transformer_forward_general(sd: SD, cfg: dict, input_ids: Tensor, encoder_hidden_states: Optional[Tensor] = None,
+                                labels: Optional[Tensor] = None, label_smoothing: float = 0.0, cond_keep: Optional[Tensor] = None):
+    """MaskGitTransformer.forward for every configuration the constructor accepts without biases / conv embeddings
+    (muse/modeling_transformer.py:1224-1281; layer :875-904; feed-forward :785-799; MLM head :979-985).
+    cond_keep [B] bool = the mask prob_mask_like draws for condition dropout (:1243-1247), applied AFTER the projection."""
+    eps = float(cfg.get("layer_norm_eps", 1e-5))
+    nh, L = int(cfg["num_attention_heads"]), int(cfg["num_hidden_layers"])
+    nf = bool(cfg.get("use_normformer", True))
+    S = input_ids.shape[-1]
+    x = sd["embed.word_embeddings.weight"][input_ids] + sd["embed.position_embeddings.weight"][:S][None]
+    enc = encoder_hidden_states
+    if enc is not None and cfg.get("project_encoder_hidden_states", False):
+        enc = _norm_by_type(enc @ sd["encoder_proj.weight"].t(), sd["encoder_proj_layer_norm.weight"], eps, cfg)     # :1239-1241
+    if enc is not None and cond_keep is not None:
+        enc = enc * cond_keep.view(-1, 1, 1).to(enc.dtype)                                                            # :1243-1247
+    for i in range(L):
+        p = f"transformer_layers.{i}."
+        a = attention(_norm_by_type(x, sd[p + "attn_layer_norm.weight"], eps, cfg), sd, p + "attention.", nh)
+        if nf:
+            a = _norm_by_type(a, sd[p + "post_attn_layer_norm.weight"], eps, cfg)
+        x = x + a
+        if enc is not None and (p + "crossattention.query.weight") in sd:
+            a = cross_attention(_norm_by_type(x, sd[p + "crossattn_layer_norm.weight"], eps, cfg), enc, sd, p + "crossattention.", nh)
+            if nf:
+                a = _norm_by_type(a, sd[p + "post_crossattn_layer_norm.weight"], eps, cfg)
+            x = x + a
+        h = _ln(x, sd[p + "ffn.pre_mlp_layer_norm.weight"], eps)            # always a LayerNorm (:768-770)
+        h = F.gelu(h @ sd[p + "ffn.wi_0.weight"].t()) * (h @ sd[p + "ffn.wi_1.weight"].t())
+        if nf:
+            h = _norm_by_type(h, sd[p + "ffn.mid_mlp_layer_norm.weight"], eps, cfg)
+        x = x + h @ sd[p + "ffn.wo.weight"].t()
+    if cfg.get("use_encoder_layernorm", True):
+        x = _norm_by_type(x, sd["encoder_layer_norm.weight"], eps, cfg)
+    if cfg.get("use_mlm_layer", True):
+        h = F.gelu(x @ sd["mlm_layer.mlm_dense.weight"].t())
+        if cfg.get("use_mlm_layernorm", True):
+            h = _norm_by_type(h, sd["mlm_layer.mlm_ln.weight"], eps, cfg)
+        logits = h @ sd["mlm_layer.to_logits.weight"].t()
+    else:
+        logits = x @ sd["to_logits.weight"].t()
+    if labels is None:
+        return logits
+    V = logits.shape[-1]
+    return logits, F.cross_entropy(logits.view(-1, V), labels.view(-1), ignore_index=-100, label_smoothing=label_smoothing)
+
+
+def transformer_general_loss_and_grads(sd: SD, cfg: dict, input_ids: Tensor, labels: Tensor, encoder_hidden_states: Optional[Tensor] = None,
+                                       label_smoothing: float = 0.0, cond_keep: Optional[Tensor] = None):
+    """-> (logits, loss, parameter grads, gradient of the text states or None)"""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    enc = encoder_hidden_states.detach().clone().requires_grad_(True) if encoder_hidden_states is not None else None
+    logits, loss = transformer_forward_general(leaf, cfg, input_ids, enc, labels, label_smoothing, cond_keep)
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    return logits.detach(), loss.detach(), grads, (enc.grad if enc is not None else None)
+
+
+def generate2_text(sd: SD, cfg: dict, encoder_hidden_states: Tensor, timesteps: int, temperature: float, noise,
+                   guidance_scale: float = 0.0, negative_embeds: Optional[Tensor] = None):
+    """MaskGitTransformer.generate2 with text states and classifier-free guidance (muse/modeling_transformer.py:1394-1416):
+    conditional and unconditional (zeros unless negative_embeds) halves of one doubled batch, logits cut to the codebook, mixed as
+    uncond + scale * (cond - uncond).  -> final sampled ids"""
+    mask_id, S, V = cfg["vocab_size"] - 1, cfg["num_vq_tokens"], cfg["codebook_size"]
+    B = encoder_hidden_states.shape[0]
+    input_ids = torch.full((B, S), mask_id, dtype=torch.long)
+    guided = guidance_scale > 0
+    if guided:
+        un = torch.zeros_like(encoder_hidden_states) if negative_embeds is None else negative_embeds
+        cond = torch.cat([encoder_hidden_states, un])
+    sampled = input_ids
+    for step in range(timesteps):
+        if guided:
+            lo = transformer_forward_general(sd, cfg, torch.cat([input_ids] * 2), cond)
+            c, u_ = lo[:B, :, :V], lo[B:, :, :V]
+            logits = u_ + guidance_scale * (c - u_)
+        else:
+            logits = transformer_forward_general(sd, cfg, input_ids, encoder_hidden_states)[..., :V]
+        ratio = 1.0 * (step + 1) / timesteps
+        sched = int((S * cosine_schedule(torch.tensor(ratio))).floor())
+        temperature = temperature * (1.0 - ratio)
+        q, u = noise[step]
+        _, sampled, input_ids = sample_step(logits, input_ids, mask_id, temperature, sched, q, u)
+    return sampled
+
+
+# ----------------------------------------------------------------------------------------------
 # training/train_muse.py: masking variants and conditioning dropout
 # ----------------------------------------------------------------------------------------------
 def mask_or_random_replace_tokens(image_tokens: Tensor, mask_id: int, min_masking_rate: float, *, timesteps: Optional[Tensor] = None,

@@ -120,6 +120,144 @@ def golden_transformer_full(name, cfg, batch, seed, autocast=False):
     print(name, "loss", float(loss), "logits absmax", float(logits.abs().max()))
 
 
+def golden_transformer_full_chunked(name, cfg, batch, chunk, seed):
+    """the benched transformer at the BENCHED BATCH (64 images, T = 16448 rows: the weight-gradient split-K plans, the 1560-tile GEMM
+    grids and the ~8 k hits on the mask token's embedding row only exist at this size).  One reference pass at batch 64 needs more
+    host memory than the build container has (every layer keeps its f32 attention scores and GLU intermediates), so the real
+    reference runs the batch in chunks of `chunk` images: logits are per image; its loss is the mean over the masked positions, so
+    loss = sum_c n_c loss_c / N and grad = sum_c (n_c / N) grad_c, recombined here in f64 (differs from one batch-64 pass by f32
+    summation order only)."""
+    model = ref_muse.MaskGitTransformer(**cfg)
+    model.load_state_dict(W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer"), strict=True)
+    model.train()
+    input_ids, labels = W.transformer_inputs(cfg, batch, seed + 1)
+    n_total = int((labels != -100).sum())
+    params = dict(model.named_parameters())
+    acc = {k: torch.zeros(params[k].shape, dtype=torch.float64) for k in FULL_GRAD_KEYS}
+    loss_sum, logit_parts, sq, amax = 0.0, [], 0.0, 0.0
+    for c0 in range(0, batch, chunk):
+        ids_c, lab_c = input_ids[c0:c0 + chunk], labels[c0:c0 + chunk]
+        n_c = int((lab_c != -100).sum())
+        model.zero_grad(set_to_none=True)
+        logits, loss = model(input_ids=ids_c, labels=lab_c)
+        loss.backward()
+        loss_sum += float(loss.double()) * n_c
+        for k in FULL_GRAD_KEYS:
+            acc[k] += params[k].grad.double() * (n_c / n_total)
+        logit_parts.append(logits.detach().reshape(-1)[:: 4096].clone())      # every 4096-th logit of the chunk
+        sq += float(logits.double().pow(2).sum())
+        amax = max(amax, float(logits.abs().max()))
+        print(name, "chunk", c0 // chunk, "loss", float(loss), flush=True)
+    out = dict(loss=np.float64(loss_sum / n_total), batch=np.int64(batch), chunk=np.int64(chunk), seed=np.int64(seed),
+               n_masked=np.int64(n_total), logits=np_(torch.cat(logit_parts)), logits_stride=np.int64(4096),
+               logits_absmax=np.float64(amax), logits_norm=np.float64(sq ** 0.5))
+    for k in FULL_GRAD_KEYS:
+        g = acc[k]
+        out["grad." + k] = np_(W.subsample(g).float())
+        out["absmax." + k] = np_(g.abs().max())
+        out["norm." + k] = np_(g.norm())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", loss_sum / n_total, "masked", n_total)
+
+
+def golden_transformer_text(name, cfg, batch, text_len, seed, cond_p=0.5):
+    """the general form of the reference's MaskGitTransformer (text states through cross attention, RMSNorm, plain pre-LN layers,
+    optional projection / final norm / MLM head; muse/modeling_transformer.py:1083-1281) on seeded inputs: logits, loss, every
+    parameter gradient, the gradient of the text states, and a second pass with condition dropout (prob_mask_like's uniform draws
+    recorded: `uniform` of the reference module is replaced for that call)."""
+    import muse.modeling_transformer as ref_mt
+    model = ref_muse.MaskGitTransformer(**cfg)
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer")
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    text = bool(cfg.get("add_cross_attention", False))
+    if text:
+        input_ids, labels, enc = W.transformer_text_inputs(cfg, batch, text_len, seed + 1)
+        enc.requires_grad_(True)
+        logits, loss = model(input_ids=input_ids, encoder_hidden_states=enc, labels=labels)
+    else:
+        input_ids, labels = W.transformer_inputs(cfg, batch, seed + 1)
+        enc = None
+        logits, loss = model(input_ids=input_ids, labels=labels)
+    loss.backward()
+    out = dict(logits=np_(logits), loss=np_(loss), batch=np.int64(batch), seed=np.int64(seed), text_len=np.int64(text_len))
+    for k, p in model.named_parameters():
+        out["grad." + k] = np_(p.grad)
+    if text:
+        out["grad_enc"] = np_(enc.grad)
+        # condition dropout (:1243-1247) with label smoothing; the draws are the file's
+        u = torch.from_numpy(np.random.default_rng(seed + 2).random((batch, 1, 1)).astype(np.float32))
+        real_uniform = ref_mt.uniform
+        ref_mt.uniform = lambda shape, min=0, max=1, device=None: u.clone()
+        try:
+            model.zero_grad()
+            _, loss_d = model(input_ids=input_ids, encoder_hidden_states=enc.detach(), labels=labels, label_smoothing=0.1,
+                              cond_dropout_prob=cond_p)
+            loss_d.backward()
+        finally:
+            ref_mt.uniform = real_uniform
+        out.update(cd_u=np_(u.reshape(batch)), cd_p=np.float32(cond_p), cd_loss=np_(loss_d))
+        for k in ("transformer_layers.0.crossattention.key.weight", "transformer_layers.1.attention.out.weight" if cfg["num_hidden_layers"] > 1
+                  else "transformer_layers.0.attention.out.weight", "embed.word_embeddings.weight"):
+            out["cd_grad." + k] = np_(dict(model.named_parameters())[k].grad)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", float(loss), "logits", tuple(logits.shape))
+
+
+def golden_transformer_text_sub(name, cfg, batch, text_len, seed):
+    """the same at the width of configs/cc12m.yaml (2 of its 24 layers, 256 tokens, 77 text states of width 1024): loss, sub-sampled
+    logits and gradients with their norms, f32 and under CPU autocast-bf16"""
+    input_ids, labels, enc = W.transformer_text_inputs(cfg, batch, text_len, seed + 1)
+    for tag, autocast in (("", False), ("_bf16", True)):
+        model = ref_muse.MaskGitTransformer(**cfg)
+        model.load_state_dict(W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer"), strict=True)
+        model.train()
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                logits, loss = model(input_ids=input_ids, encoder_hidden_states=enc, labels=labels)
+            logits, loss = logits.float(), loss.float()
+        else:
+            logits, loss = model(input_ids=input_ids, encoder_hidden_states=enc, labels=labels)
+        loss.backward()
+        out = dict(loss=np_(loss), batch=np.int64(batch), seed=np.int64(seed), text_len=np.int64(text_len),
+                   logits=np_(W.subsample(logits, 16384)), logits_absmax=np_(logits.abs().max()))
+        for k, p in model.named_parameters():
+            if any(t in k for t in ("layers.0.crossattention", "layers.1.attention.query", "layers.1.ffn.wo", "layers.0.ffn.wi_0",
+                                    "layers.1.crossattn_layer_norm", "encoder_layer_norm", "word_embeddings", "mlm_layer.to_logits")):
+                g = p.grad.float()
+                out["grad." + k], out["absmax." + k], out["norm." + k] = np_(W.subsample(g)), np_(g.abs().max()), np_(g.double().norm())
+        np.savez_compressed(os.path.join(HERE, name + tag + ".npz"), **out)
+        print(name + tag, "loss", float(loss))
+
+
+def golden_generate2_text(name, cfg, batch, text_len, seed, timesteps, temperature, guidance_scale):
+    """MaskGitTransformer.generate2 of the real reference with text states and classifier-free guidance (:1394-1416), seeded CPU
+    generator; negative_embeds given for half of the cases (file `..._neg`)"""
+    from oracle import maskgit_oracle as O
+    model = ref_muse.MaskGitTransformer(**cfg)
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    _, _, enc = W.transformer_text_inputs(cfg, batch, text_len, seed + 1)
+    neg = torch.from_numpy(np.random.default_rng(seed + 3).standard_normal(tuple(enc.shape)).astype(np.float32))
+    S, V = cfg["num_vq_tokens"], cfg["codebook_size"]
+    out = dict(batch=np.int64(batch), seed=np.int64(seed), text_len=np.int64(text_len), timesteps=np.int64(timesteps),
+               temperature=np.float32(temperature), guidance_scale=np.float32(guidance_scale), negative_embeds=np_(neg))
+    for tag, negative in (("", None), ("_neg", neg)):
+        with torch.no_grad():
+            ids = model.generate2(encoder_hidden_states=enc, negative_embeds=negative, timesteps=timesteps, temperature=temperature,
+                                  guidance_scale=guidance_scale, generator=torch.Generator().manual_seed(seed + 7))
+        noise = replay_decode_noise(seed + 7, timesteps, batch, S, V)
+        ids_o = O.generate2_text(sd, cfg, enc, timesteps, temperature, noise, guidance_scale, negative)
+        assert torch.equal(ids, ids_o), "the recorded draws do not reproduce the reference's sample"
+        out["ids" + tag] = np_(ids)
+        if tag == "":
+            for i, (q, u) in enumerate(noise):
+                out[f"q{i}"], out[f"u{i}"] = np_(q), np_(u)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ids", out["ids"][0, :8], out["ids_neg"][0, :8])
+
+
 def golden_vqgan_full(name, cfg, seed):
     """the f16-256 tokenizer (54.5 M parameters) run by the real reference on one 256 x 256 image: encoder output z (full), the 256
     token ids, the two smallest distances per token (near-tie margins), and every k-th pixel of decode_code's reconstruction"""
@@ -445,10 +583,14 @@ def golden_mask_muse(name, seed, batch=6, seq=16, mask_id=47, codebook_size=32):
 
 
 if __name__ == "__main__":
-    if "--skip-full" not in sys.argv:   # the benched geometries (about two minutes on one thread)
+    if "--skip-full" not in sys.argv and "--bs64" not in sys.argv:   # the benched geometries (about two minutes on one thread)
         golden_vqgan_full("vqgan_f16_full", W.VQGAN_F16, seed=600)
         golden_transformer_full("transformer_b_full", W.TRANSFORMER_B, batch=2, seed=510)
         golden_transformer_full("transformer_b_full_bf16", W.TRANSFORMER_B, batch=2, seed=510, autocast=True)
+    if "--bs64" in sys.argv or ("--skip-full" not in sys.argv and "--skip-bs64" not in sys.argv):   # (~15 minutes on one thread)
+        golden_transformer_full_chunked("transformer_b_full_bs64", W.TRANSFORMER_B, batch=64, chunk=2, seed=510)
+        if "--bs64" in sys.argv:
+            sys.exit(0)
     if "--skip-full" not in sys.argv and "--skip-uvit-full" not in sys.argv:   # (729 M parameters: ~12 GB of host memory)
         torch.set_num_threads(8)
         golden_uvit_full("uvit_full", batch=2, seq=256, text_len=77, seed=700)
@@ -470,5 +612,14 @@ if __name__ == "__main__":
     golden_mask_muse("mask_muse", seed=540)
     golden_transformer_autocast("transformer_tiny_bf16", W.TRANSFORMER_TINY, batch=3, seed=100)
     golden_transformer_autocast("transformer_hd48_bf16", W.TRANSFORMER_HD48, batch=2, seed=120)
+    golden_transformer_text("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY, batch=3, text_len=7, seed=800)
+    golden_transformer_text("transformer_text_proj_tiny", W.TRANSFORMER_TEXT_PROJ_TINY, batch=2, text_len=5, seed=810)
+    golden_transformer_text("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY, batch=2, text_len=0, seed=820)
+    golden_generate2_text("generate2_text_tiny", W.TRANSFORMER_TEXT_TINY, batch=2, text_len=7, seed=830, timesteps=5, temperature=3.0,
+                          guidance_scale=2.5)
+    if "--skip-full" not in sys.argv:
+        torch.set_num_threads(8)
+        golden_transformer_text_sub("transformer_cc12m_2l", W.TRANSFORMER_CC12M_2L, batch=2, text_len=77, seed=840)
+        torch.set_num_threads(1)
     golden_taming("taming_tiny", W.TAMING_TINY, batch=2, seed=600)
     golden_taming("taming_tiny_pool", W.TAMING_TINY_POOL, batch=3, seed=610)

@@ -20,6 +20,36 @@ TRANSFORMER_HD48 = dict(
     max_position_embeddings=40, codebook_size=64, num_vq_tokens=36, num_classes=10,
     hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-6,
 )
+# ---- the general form of MaskGitTransformer (text conditioning, RMSNorm, plain pre-LN layers; oracle/ and muse/maskgit_general.py) ----
+# the shipped text-to-image family in small (configs/cc12m.yaml, imagenet_text2image.yaml: rmsnorm, no NormFormer, codebook-wide logits)
+TRANSFORMER_TEXT_TINY = dict(
+    vocab_size=48, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+    max_position_embeddings=16, codebook_size=32, num_vq_tokens=16, add_cross_attention=True, encoder_hidden_size=24,
+    project_encoder_hidden_states=False, norm_type="rmsnorm", use_normformer=False, use_codebook_size_for_output=True,
+    hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-6,
+)
+# the other branches: LayerNorm + NormFormer post-norms around both attentions, projected text states, MLM head without its norm
+TRANSFORMER_TEXT_PROJ_TINY = dict(
+    vocab_size=40, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=48,
+    max_position_embeddings=12, codebook_size=32, num_vq_tokens=12, add_cross_attention=True, encoder_hidden_size=20,
+    project_encoder_hidden_states=True, norm_type="layernorm", use_normformer=True, use_mlm_layernorm=False,
+    hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-5,
+)
+# ... RMSNorm with NormFormer, no final norm, bare `to_logits` head, no text (class token)
+TRANSFORMER_PLAIN_TINY = dict(
+    vocab_size=48, hidden_size=32, num_hidden_layers=1, num_attention_heads=4, intermediate_size=64,
+    max_position_embeddings=20, codebook_size=32, num_vq_tokens=16, num_classes=10, norm_type="rmsnorm", use_normformer=True,
+    use_encoder_layernorm=False, use_mlm_layer=False, hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-6,
+)
+# configs/cc12m.yaml:28-50 `model.transformer` with 2 of its 24 layers (T5-large states of width 1024, 77 tokens in the tests)
+TRANSFORMER_CC12M_2L = dict(
+    vocab_size=8256, max_position_embeddings=256, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16,
+    intermediate_size=4096, add_cross_attention=True, encoder_hidden_size=1024, project_encoder_hidden_states=False,
+    codebook_size=8192, num_vq_tokens=256, initializer_range=0.02, norm_type="rmsnorm", layer_norm_eps=1e-6, use_normformer=False,
+    use_encoder_layernorm=True, use_mlm_layer=True, use_mlm_layernorm=True, use_bias=False, hidden_dropout=0.0,
+    attention_dropout=0.0, use_codebook_size_for_output=True,
+)
+
 VQGAN_TINY = dict(
     resolution=16, num_channels=3, hidden_channels=32, channel_mult=(1, 2, 2), num_res_blocks=1,
     z_channels=16, num_embeddings=32, quantized_embed_dim=16,
@@ -69,24 +99,45 @@ UVIT_CC12M = dict(
 
 
 def transformer_shapes(cfg: dict) -> dict:
-    """state_dict template of muse.MaskGitTransformer."""
+    """state_dict template of muse.MaskGitTransformer (reference muse/modeling_transformer.py:1083-1200 for the
+    optional members: cross-attention blocks, text projection, NormFormer norms, final norm, MLM head)."""
     H, I, V, P = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["max_position_embeddings"]
+    cross, nf = bool(cfg.get("add_cross_attention", False)), bool(cfg.get("use_normformer", True))
+    kv = cfg.get("encoder_hidden_size", 1024)
+    out = cfg["codebook_size"] if cfg.get("use_codebook_size_for_output", False) else V
     s = {"embed.word_embeddings.weight": (V, H), "embed.position_embeddings.weight": (P, H)}
+    if cfg.get("project_encoder_hidden_states", False):
+        s["encoder_proj.weight"] = (H, kv)
+        s["encoder_proj_layer_norm.weight"] = (H,)
+        kv = H
     for i in range(cfg["num_hidden_layers"]):
         p = f"transformer_layers.{i}."
         s[p + "attn_layer_norm.weight"] = (H,)
         for n in ("query", "key", "value", "out"):
             s[p + f"attention.{n}.weight"] = (H, H)
-        s[p + "post_attn_layer_norm.weight"] = (H,)
+        if nf:
+            s[p + "post_attn_layer_norm.weight"] = (H,)
+        if cross:
+            s[p + "crossattn_layer_norm.weight"] = (H,)
+            for n, c in (("query", H), ("key", kv), ("value", kv), ("out", H)):
+                s[p + f"crossattention.{n}.weight"] = (H, c)
+            if nf:
+                s[p + "post_crossattn_layer_norm.weight"] = (H,)
         s[p + "ffn.pre_mlp_layer_norm.weight"] = (H,)
         s[p + "ffn.wi_0.weight"] = (I, H)
         s[p + "ffn.wi_1.weight"] = (I, H)
-        s[p + "ffn.mid_mlp_layer_norm.weight"] = (I,)
+        if nf:
+            s[p + "ffn.mid_mlp_layer_norm.weight"] = (I,)
         s[p + "ffn.wo.weight"] = (H, I)
-    s["encoder_layer_norm.weight"] = (H,)
-    s["mlm_layer.mlm_dense.weight"] = (H, H)
-    s["mlm_layer.mlm_ln.weight"] = (H,)
-    s["mlm_layer.to_logits.weight"] = (V, H)
+    if cfg.get("use_encoder_layernorm", True):
+        s["encoder_layer_norm.weight"] = (H,)
+    if cfg.get("use_mlm_layer", True):
+        s["mlm_layer.mlm_dense.weight"] = (H, H)
+        if cfg.get("use_mlm_layernorm", True):
+            s["mlm_layer.mlm_ln.weight"] = (H,)
+        s["mlm_layer.to_logits.weight"] = (out, H)
+    else:
+        s["to_logits.weight"] = (out, H)
     return s
 
 
@@ -259,6 +310,20 @@ def transformer_inputs(cfg: dict, batch: int, seed: int):
     input_ids = np.concatenate([cls, input_ids], axis=1)
     labels = np.concatenate([np.full((batch, 1), -100), labels], axis=1)
     return torch.from_numpy(input_ids.astype(np.int64)), torch.from_numpy(labels.astype(np.int64))
+
+
+def transformer_text_inputs(cfg: dict, batch: int, text_len: int, seed: int):
+    """Seeded (input_ids [B, S], labels [B, S], encoder_hidden_states [B, text_len, encoder_hidden_size]) of a text-conditioned
+    step: no class token (training/train_muse.py:685-750), labels only inside the codebook."""
+    rng = np.random.default_rng(seed)
+    S, cb, V = cfg["num_vq_tokens"], cfg["codebook_size"], cfg["vocab_size"]
+    tokens = rng.integers(0, cb, size=(batch, S))
+    mask = rng.random((batch, S)) < 0.55
+    mask[:, 0] = True
+    input_ids = np.where(mask, V - 1, tokens)
+    labels = np.where(mask, tokens, -100)
+    enc = rng.standard_normal((batch, text_len, cfg["encoder_hidden_size"])).astype(np.float32)
+    return (torch.from_numpy(input_ids.astype(np.int64)), torch.from_numpy(labels.astype(np.int64)), torch.from_numpy(enc))
 
 
 def images(batch: int, res: int, seed: int) -> torch.Tensor:

@@ -199,6 +199,141 @@ def test_transformer_config_b_full_depth_vs_reference_golden(golden_dir):
         torch.cuda.empty_cache()
 
 
+def test_transformer_config_b_benched_batch_vs_reference_golden(golden_dir):
+    """the BENCHED transformer at the BENCHED batch (64 images, T = 16448 rows) against the real reference
+    (tests/golden/transformer_b_full_bs64.npz = make_golden.py::golden_transformer_full_chunked: the reference run in 32 chunks of 2
+    images, loss and gradients recombined in f64 with the weights n_c / N of its masked-token mean).  Only at this size do the
+    weight-gradient split-K plans (K = 16448), the 1560 / 780 / 585-tile persistent GEMM grids with their ticket queues and ragged
+    row strip, and the ~9 k hits on the mask token's embedding row exist.  f32 mode: north_star's 1e-3; bf16 mode: the bounds of
+    the batch-2 test (the reference's own f32-vs-autocast gap at this geometry is 1.2e-2 on logits, up to 3.9e-2 on gradients)."""
+    g = np.load(os.path.join(golden_dir, "transformer_b_full_bs64.npz"))
+    cfg = dict(W.TRANSFORMER_B)
+    seed, bs = int(g["seed"]), int(g["batch"])
+    assert bs == 64
+    ids, labels = W.transformer_inputs(cfg, bs, seed + 1)
+    assert int((labels != -100).sum()) == int(g["n_masked"])
+    keys = [f[5:] for f in g.files if f.startswith("grad.")]
+    stride = int(g["logits_stride"])
+    for cd in (torch.float32, torch.bfloat16):
+        m, _ = _build_transformer(cfg, seed, cd)
+        logits, loss = m(input_ids=ids.to(DEV), labels=labels.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        f32 = cd == torch.float32
+        el = float(np.abs(logits.detach().reshape(-1)[::stride].cpu().numpy() - g["logits"]).max()) / float(g["logits_absmax"])
+        assert el < (1e-3 if f32 else 2.5e-2), (cd, el)
+        assert abs(float(loss) - float(g["loss"])) < (1e-4 if f32 else 1e-3) * float(g["loss"]), (cd, float(loss), float(g["loss"]))
+        params = dict(m.named_parameters())
+        errs = {}
+        for k in keys:
+            gr = params[k].grad
+            errs[k] = float(np.abs(W.subsample(gr.detach()).cpu().numpy() - g["grad." + k]).max()) / float(g["absmax." + k])
+            assert abs(float(gr.detach().double().norm()) - float(g["norm." + k])) < (1e-3 if f32 else 2e-2) * float(g["norm." + k]), (cd, k)
+        print(cd, "batch 64 vs the reference: loss", f"{float(loss):.6f} / {float(g['loss']):.6f}", "logits", f"{el:.2e}", "grads",
+              {k.split("transformer_layers.")[-1]: f"{v:.1e}" for k, v in errs.items()})
+        for k, e in errs.items():
+            assert e < (2e-3 if f32 else 8e-2), (cd, k, e)
+        del m, logits, loss
+        torch.cuda.empty_cache()
+
+
+def _build_general(cfg, seed, cd):
+    import muse
+    m = muse.MaskGitTransformer(**cfg)
+    m.load_state_dict(W.fill_state_dict(W.transformer_shapes(cfg), seed, "transformer"), strict=True)
+    m.to(DEV).train().set_compute_dtype(cd)
+    return m
+
+
+@pytest.mark.parametrize("name,cfg", [("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY),
+                                      ("transformer_text_proj_tiny", W.TRANSFORMER_TEXT_PROJ_TINY),
+                                      ("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY)])
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_transformer_general_vs_reference_golden(golden_dir, name, cfg, cd):
+    """the general form of muse.MaskGitTransformer (muse/maskgit_general.py: cross attention to text states, RMSNorm, plain pre-LN
+    layers, projected text states, optional final norm / MLM head) against the REAL reference's outputs on the same seeded
+    inputs: logits, loss, every parameter gradient, the gradient of the text states, and the condition-dropout pass with the
+    reference's recorded draws.  f32 mode: north_star's 1e-3; bf16 mode: the tiny-model bounds of the class-conditional tests."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    seed, B = int(g["seed"]), int(g["batch"])
+    m = _build_general(cfg, seed, cd)
+    f32 = cd == torch.float32
+    text = bool(cfg.get("add_cross_attention"))
+    if text:
+        ids, labels, enc = W.transformer_text_inputs(cfg, B, int(g["text_len"]), seed + 1)
+        enc = enc.to(DEV).requires_grad_(True)
+        logits, loss = m(input_ids=ids.to(DEV), encoder_hidden_states=enc, labels=labels.to(DEV))
+    else:
+        ids, labels = W.transformer_inputs(cfg, B, seed + 1)
+        enc = None
+        logits, loss = m(input_ids=ids.to(DEV), labels=labels.to(DEV))
+    loss.backward()
+    assert logits.shape == g["logits"].shape and logits.dtype == torch.float32
+    assert maxrel(logits, torch.from_numpy(g["logits"])) < (1e-3 if f32 else 2.5e-2)
+    assert abs(float(loss) - float(g["loss"])) < (1e-4 if f32 else 2e-3) * abs(float(g["loss"]))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        e = maxrel(p.grad, torch.from_numpy(g["grad." + k]))
+        worst = max(worst, e)
+        assert e < (1e-3 if f32 else 6e-2), (k, e)
+    if text:
+        assert maxrel(enc.grad, torch.from_numpy(g["grad_enc"])) < (1e-3 if f32 else 6e-2)
+        m.zero_grad(set_to_none=True)
+        _, loss_d = m(input_ids=ids.to(DEV), encoder_hidden_states=enc.detach(), labels=labels.to(DEV), label_smoothing=0.1,
+                      cond_dropout_prob=float(g["cd_p"]), cond_dropout_uniforms=torch.from_numpy(g["cd_u"]).to(DEV))
+        loss_d.backward()
+        assert abs(float(loss_d) - float(g["cd_loss"])) < (1e-4 if f32 else 2e-3) * abs(float(g["cd_loss"]))
+        params = dict(m.named_parameters())
+        for f in g.files:
+            if f.startswith("cd_grad."):
+                assert maxrel(params[f[8:]].grad, torch.from_numpy(g[f])) < (1e-3 if f32 else 6e-2), f
+    print(name, cd, "worst parameter-gradient error", f"{worst:.2e}")
+
+
+def test_transformer_text_cc12m_width_vs_reference_golden(golden_dir):
+    """two layers of configs/cc12m.yaml's text-conditioned transformer (hidden 1024, 16 heads of 64, GLU 4096, 256 tokens, 77 T5
+    states of width 1024, codebook 8192) against the real reference (f32 run; bf16 mode held to twice the reference's own
+    f32-vs-autocast gap, fused self / cross attention kernels at S = 256 / S_kv = 77), then three FusedAdamW steps in the
+    multi-tensor form with a falling loss"""
+    import muse
+    g = np.load(os.path.join(golden_dir, "transformer_cc12m_2l.npz"))
+    gb = np.load(os.path.join(golden_dir, "transformer_cc12m_2l_bf16.npz"))
+    cfg = W.TRANSFORMER_CC12M_2L
+    seed, B = int(g["seed"]), int(g["batch"])
+    ids, labels, enc = W.transformer_text_inputs(cfg, B, int(g["text_len"]), seed + 1)
+    keys = [f[5:] for f in g.files if f.startswith("grad.")]
+    gap_l = float(np.abs(g["logits"] - gb["logits"]).max()) / float(g["logits_absmax"])
+    gap_g = max(float(np.abs(g["grad." + k] - gb["grad." + k]).max()) / float(g["absmax." + k]) for k in keys)
+    for cd in (torch.float32, torch.bfloat16):
+        m = _build_general(cfg, seed, cd)
+        logits, loss = m(input_ids=ids.to(DEV), encoder_hidden_states=enc.to(DEV), labels=labels.to(DEV))
+        loss.backward()
+        f32 = cd == torch.float32
+        el = float(np.abs(W.subsample(logits.detach(), 16384).cpu().numpy() - g["logits"]).max()) / float(g["logits_absmax"])
+        assert el < (1e-3 if f32 else max(2.5e-2, 2 * gap_l)), (cd, el, gap_l)
+        assert abs(float(loss) - float(g["loss"])) < (1e-4 if f32 else 1e-3) * float(g["loss"])
+        params = dict(m.named_parameters())
+        errs = {k: float(np.abs(W.subsample(params[k].grad.detach()).cpu().numpy() - g["grad." + k]).max()) / float(g["absmax." + k])
+                for k in keys}
+        print(cd, "cc12m-width text transformer vs the reference: logits", f"{el:.2e}", "worst grad", f"{max(errs.values()):.2e}",
+              "(reference f32 vs its autocast: logits", f"{gap_l:.1e}", "grads", f"{gap_g:.1e})")
+        for k, e in errs.items():
+            assert e < (2e-3 if f32 else max(8e-2, 2 * gap_g)), (cd, k, e)
+        if not f32:
+            opt = muse.FusedAdamW(m.parameters(), lr=3e-4, weight_decay=0.01)
+            losses = [float(loss)]
+            for _ in range(3):
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                _, l2 = m(input_ids=ids.to(DEV), encoder_hidden_states=enc.to(DEV), labels=labels.to(DEV))
+                l2.backward()
+                losses.append(float(l2))
+            assert losses[-1] < losses[0] - 0.05, losses
+        del m
+        torch.cuda.empty_cache()
+
+
 def test_vqgan_f16_256_vs_reference_golden(golden_dir):
     """the f16-256 tokenizer on one 256 x 256 image against the REAL reference's outputs (tests/golden/vqgan_f16_full.npz): encoder
     output, token ids (bit-exact in f32 and bf16x3: the smallest top-2 distance margin of this image is 6.4e-3, far above either

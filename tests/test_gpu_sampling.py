@@ -89,6 +89,27 @@ def test_generate2_vs_reference_golden(golden_dir):
     assert torch.equal(outs[0], outs[1]) and int(outs[0].max()) < cfg["codebook_size"] and int(outs[0].min()) >= 0
 
 
+def test_generate2_text_guided_vs_reference_golden(golden_dir):
+    """text-conditioned MaskGitTransformer.generate2 with classifier-free guidance 2.5 (doubled batch; zeros or negative_embeds as
+    the unconditional half, reference :1394-1416): the real reference's ids from its recorded generator draws"""
+    import muse
+    g = np.load(os.path.join(golden_dir, "generate2_text_tiny.npz"))
+    cfg = W.TRANSFORMER_TEXT_TINY
+    m = muse.MaskGitTransformer(**cfg)
+    m.load_state_dict(W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer"))
+    m.to(DEV).eval().set_compute_dtype(torch.float32)
+    _, _, enc = W.transformer_text_inputs(cfg, int(g["batch"]), int(g["text_len"]), int(g["seed"]) + 1)
+    T = int(g["timesteps"])
+    for tag, neg in (("", None), ("_neg", torch.from_numpy(g["negative_embeds"]).to(DEV))):
+        ids = m.generate2(encoder_hidden_states=enc.to(DEV), negative_embeds=neg, timesteps=T, temperature=float(g["temperature"]),
+                          guidance_scale=float(g["guidance_scale"]), noise=_noise(g, T))
+        assert torch.equal(ids.cpu(), torch.from_numpy(g["ids" + tag])), tag
+    # unguided + device RNG: valid ids, reproducible
+    outs = [m.generate2(encoder_hidden_states=enc.to(DEV), timesteps=T, temperature=2.0, generator=torch.Generator(device=DEV).manual_seed(3))
+            for _ in range(2)]
+    assert torch.equal(outs[0], outs[1]) and int(outs[0].max()) < cfg["codebook_size"]
+
+
 def test_uvit_generate2_vs_reference_golden(golden_dir):
     """MaskGiTUViT_v2.generate2 of the reference with classifier-free guidance 3.0, temperature (2, 0), 5 steps: final ids and the
     per-step raw samples (`intermediate`)"""

@@ -32,6 +32,72 @@ def test_transformer_forward_backward(golden_dir, name, cfg):
         assert float(np.abs(v.numpy() - ref).max()) <= 2e-5 * scale + 1e-9, k
 
 
+@pytest.mark.parametrize("name,cfg", [("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY),
+                                      ("transformer_text_proj_tiny", W.TRANSFORMER_TEXT_PROJ_TINY),
+                                      ("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY)])
+def test_transformer_general_forward_backward(golden_dir, name, cfg):
+    """the general form of MaskGitTransformer (oracle.transformer_forward_general: cross attention to text states, RMSNorm, plain
+    pre-LN layers, projected text states, optional final norm / MLM head) against the REAL reference: logits, loss, every parameter
+    gradient, the gradient of the text states, and the condition-dropout pass with the reference's recorded draws"""
+    g = _load(golden_dir, name)
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer")
+    B = int(g["batch"])
+    if cfg.get("add_cross_attention"):
+        ids, labels, enc = W.transformer_text_inputs(cfg, B, int(g["text_len"]), int(g["seed"]) + 1)
+    else:
+        (ids, labels), enc = W.transformer_inputs(cfg, B, int(g["seed"]) + 1), None
+    logits, loss, grads, genc = O.transformer_general_loss_and_grads(sd, cfg, ids, labels, enc)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-6)
+    assert set("grad." + k for k in grads) == set(f for f in g.files if f.startswith("grad."))
+    for k, v in grads.items():
+        ref = g["grad." + k]
+        assert float(np.abs(v.numpy() - ref).max()) <= 2e-5 * max(float(np.abs(ref).max()), 1e-8) + 1e-9, k
+    if enc is not None:
+        assert float(np.abs(genc.numpy() - g["grad_enc"]).max()) <= 2e-5 * float(np.abs(g["grad_enc"]).max())
+        keep = torch.from_numpy(g["cd_u"]) < (1.0 - float(g["cd_p"]))       # prob_mask_like(.., 1 - p): uniform < 1 - p
+        assert 0 < int(keep.sum()) < B                                       # (the recorded draws exercise both branches)
+        _, loss_d, grads_d, _ = O.transformer_general_loss_and_grads(sd, cfg, ids, labels, enc, label_smoothing=0.1, cond_keep=keep)
+        np.testing.assert_allclose(loss_d.numpy(), g["cd_loss"], rtol=1e-6)
+        for f in g.files:
+            if f.startswith("cd_grad."):
+                ref = g[f]
+                assert float(np.abs(grads_d[f[8:]].numpy() - ref).max()) <= 2e-5 * float(np.abs(ref).max()) + 1e-9, f
+
+
+def test_transformer_text_cc12m_width_vs_reference(golden_dir):
+    """two layers of configs/cc12m.yaml's transformer (hidden 1024, 16 heads, GLU 4096, T5 states 77 x 1024, 256 tokens, codebook
+    8192) through the oracle against the real reference's sub-sampled outputs"""
+    torch.set_num_threads(8)
+    try:
+        g = _load(golden_dir, "transformer_cc12m_2l")
+        cfg = W.TRANSFORMER_CC12M_2L
+        sd = W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer")
+        ids, labels, enc = W.transformer_text_inputs(cfg, int(g["batch"]), int(g["text_len"]), int(g["seed"]) + 1)
+        logits, loss, grads, _ = O.transformer_general_loss_and_grads(sd, cfg, ids, labels, enc)
+        assert abs(float(loss) - float(g["loss"])) < 2e-6 * float(g["loss"])
+        assert float(np.abs(W.subsample(logits, 16384).numpy() - g["logits"]).max()) < 2e-5 * float(g["logits_absmax"])
+        for f in g.files:
+            if f.startswith("grad."):
+                assert float(np.abs(W.subsample(grads[f[5:]]).numpy() - g[f]).max()) < 5e-5 * float(g["absmax." + f[5:]]), f
+    finally:
+        torch.set_num_threads(1)
+
+
+def test_generate2_text_guided(golden_dir):
+    """oracle.generate2_text (classifier-free guidance over a doubled batch, with and without negative_embeds) reproduces the real
+    reference's generate2 ids from its recorded generator draws"""
+    g = _load(golden_dir, "generate2_text_tiny")
+    cfg = W.TRANSFORMER_TEXT_TINY
+    sd = W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer")
+    _, _, enc = W.transformer_text_inputs(cfg, int(g["batch"]), int(g["text_len"]), int(g["seed"]) + 1)
+    T = int(g["timesteps"])
+    noise = [(torch.from_numpy(g[f"q{i}"]), torch.from_numpy(g[f"u{i}"])) for i in range(T)]
+    for tag, neg in (("", None), ("_neg", torch.from_numpy(g["negative_embeds"]))):
+        ids = O.generate2_text(sd, cfg, enc, T, float(g["temperature"]), noise, float(g["guidance_scale"]), neg)
+        assert np.array_equal(ids.numpy(), g["ids" + tag]), tag
+
+
 def test_adamw_step(golden_dir):
     cfg = W.TRANSFORMER_TINY
     g = _load(golden_dir, "transformer_tiny")

@@ -113,9 +113,44 @@ def test_no_cpu_fallback():
 def test_unsupported_configs_fail_loudly():
     import muse
     with pytest.raises(NotImplementedError):
-        muse.MaskGitTransformer(vocab_size=48, hidden_size=32, num_attention_heads=2, add_cross_attention=True)
+        muse.MaskGitTransformer(vocab_size=48, hidden_size=32, num_attention_heads=2, use_bias=True)
+    with pytest.raises(NotImplementedError):
+        muse.MaskGitTransformer(vocab_size=48, hidden_size=32, num_attention_heads=2, use_conv_in_out=True)
     with pytest.raises(ValueError):
         muse.MaskGitTransformer(vocab_size=48, hidden_size=30, num_attention_heads=4)
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TEXT_TINY)
+    with pytest.raises(ValueError):                       # reference :1234-1235
+        m(torch.zeros(2, 16, dtype=torch.long))
+
+
+@pytest.mark.parametrize("name,cfg", [("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY),
+                                      ("transformer_text_proj_tiny", W.TRANSFORMER_TEXT_PROJ_TINY),
+                                      ("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY),
+                                      ("transformer_cc12m_2l", W.TRANSFORMER_CC12M_2L)])
+def test_general_transformer_surface_and_roundtrip(golden_dir, tmp_path, name, cfg):
+    """the general form of muse.MaskGitTransformer (text conditioning / RMSNorm / plain pre-LN layers): parameter names and shapes
+    are the REAL reference's (the goldens list its named_parameters), a state dict loads strictly, save_pretrained ->
+    from_pretrained round-trips config and weights"""
+    import muse
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = muse.MaskGitTransformer(**cfg)
+    shapes = W.transformer_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    ref_names = set(f[5:] for f in g.files if f.startswith("grad."))
+    if name != "transformer_cc12m_2l":                    # (the width-1024 golden keeps a subset of the gradients)
+        assert ref_names == set(shapes)
+    else:
+        assert ref_names <= set(shapes)
+    sd = W.fill_state_dict(shapes, 5, "transformer")
+    m.load_state_dict(sd, strict=True)
+    m.save_pretrained(str(tmp_path))
+    m2 = muse.MaskGitTransformer.from_pretrained(str(tmp_path))
+    assert m2.config.norm_type == cfg["norm_type"] and m2.config.mask_token_id == cfg["vocab_size"] - 1
+    assert m2.output_size == (cfg["codebook_size"] if cfg.get("use_codebook_size_for_output") else cfg["vocab_size"])
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    assert not m2.training and m._general and m2._general
 
 
 def test_library_exports_every_declared_symbol():
