@@ -94,22 +94,32 @@ class TapeOps:
 
     def _w2(self, *mods):
         """the weight(s) as the GEMM operand of the current compute mode: cached bf16 copy, or the f32 master (stacked on the fly)"""
-        if self.compute_dtype == torch.bfloat16:
+        k_in = mods[0].weight.numel() // mods[0].weight.shape[0]
+        if self.compute_dtype == torch.bfloat16 and k_in % 8 == 0:
             return self._wb(*mods)
+        # (bf16 rows must be whole 16-byte chunks: a weight whose input width is not a multiple of 8 - no shipped configuration -
+        #  keeps its products in exact f32, see _f32_pair)
         ws = [self._f(m.weight).reshape(m.weight.shape[0], -1) for m in mods]
         return ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
 
+    def _pair(self, a, w2):
+        """(activation, weight) as operands of one GEMM: the compute dtype, or both f32 when the weight stayed f32 (_w2)"""
+        if w2.dtype == torch.float32:
+            return (a if a.dtype == torch.float32 else ops.cast_to_f32(a.contiguous())), w2
+        return self._c(a), w2
+
     def _mm(self, x, w2, residual=None):
         """x w2^T (+ residual) -> f32"""
-        return ops.linear(self._c(x), self._c(w2), out_dtype=torch.float32, residual=residual)
+        xx, ww = self._pair(x, w2)
+        return ops.linear(xx, ww, out_dtype=torch.float32, residual=residual)
 
     def _mm_dx(self, dy, w2, lda=None, out=None, accumulate=False):
         """dy w2 -> f32 [rows, K] (optionally accumulated into `out`);  dy [rows, >= N] with row stride lda, w2 [N, K]"""
         N, K = w2.shape
-        dyb = self._c(dy)
+        dyb, ww = self._pair(dy, w2)
         if out is None:
             out = torch.empty((dy.shape[0], K), dtype=torch.float32, device=dy.device)
-        ops.gemm(dyb, self._c(w2), out, dy.shape[0], K, N, la=0, lb=1, lda=lda or dyb.stride(0), ldb=K, ldc=out.stride(0),
+        ops.gemm(dyb, ww, out, dy.shape[0], K, N, la=0, lb=1, lda=lda or dyb.stride(0), ldb=K, ldc=out.stride(0),
                  accumulate=accumulate)
         return out
 
@@ -117,7 +127,11 @@ class TapeOps:
         """dy^T x -> f32 [N, K].  bf16 mode: on a second HIP stream (weight gradients are leaves of the backward graph: the
         split-K GEMM and its slice reduction fill CUs the dX / attention / norm chain leaves idle); _run_backward joins the
         stream before it hands the gradients to autograd."""
-        dyc, xc = self._c(dy), self._c(x)
+        if shape2[-1] % 8 or (M if M is not None else shape2[0]) % 8:      # rows of the k-major bf16 operands would not be 16-byte chunks
+            dyc = dy if dy.dtype == torch.float32 else ops.cast_to_f32(dy.contiguous())
+            xc = x if x.dtype == torch.float32 else ops.cast_to_f32(x.contiguous())
+        else:
+            dyc, xc = self._c(dy), self._c(x)
         if not (self.wgrad_stream and self.compute_dtype == torch.bfloat16 and x.is_cuda):
             dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
             ops.linear_wgrad(dyc, xc, dw, False, M=M, lda=lda)
@@ -141,7 +155,7 @@ class TapeOps:
 
     def _lin_bwd(self, dy, x, mod, name, G, need_dx=True):
         w2 = self._w2(mod)
-        dyc = self._c(dy)            # one cast feeds both the dW and the dX product
+        dyc = dy if w2.dtype == torch.float32 else self._c(dy)            # one cast feeds both the dW and the dX product
         G[name + ".weight"] = self._mm_dw(dyc, x, w2.shape).view(mod.weight.shape)
         return self._mm_dx(dyc, w2) if need_dx else None
 
@@ -171,7 +185,8 @@ class TapeOps:
         Cq = x.shape[1]
         hd = Cq // nh
         pdrop = drop[0] if drop is not None else 0.0
-        if self.compute_dtype == torch.bfloat16 and ops.attention_supported(torch.bfloat16, Sq, hd, Skv) and pdrop == 0.0:
+        if (self.compute_dtype == torch.bfloat16 and ops.attention_supported(torch.bfloat16, Sq, hd, Skv) and pdrop == 0.0
+                and att.key.weight.shape[1] % 8 == 0):
             alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
             xb = self._c(x)                   # (already bf16 when it is an AdaLN output; cached otherwise)
             self_attn = ctx is x
