@@ -112,3 +112,92 @@ def test_grad_reducer_tensor_list_world2(tmp_path):
             continue
         expect = torch.full_like(a, float(i + 1)) * 1.5 + torch.arange(a.numel(), dtype=torch.float32).view_as(a)   # mean over the ranks
         assert torch.equal(a, b) and torch.allclose(a, expect)
+
+
+def _worker_opt_in_reducer(rank, world, port, out):
+    """the data-parallel optimizer protocol of muse.TrainStep (`optimizer_in_reducer`): FusedAdamW.begin_step_in_reducer hangs the
+    AdamW update of every gradient bucket behind that bucket's all-reduce; three steps, backward's report order replayed.  The HIP
+    AdamW kernel is replaced by its CPU restatement (oracle.adamw_step) - what is under test is the protocol: bucket boundaries
+    (a ragged last bucket, bucket size not dividing any layer), every element updated exactly once per step with the AVERAGED
+    gradient and the right step count, the uncovered remainder picked up by step()."""
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    sys.path.insert(0, ROOT)
+    import muse
+    import weights as W
+    from muse import ops
+    from oracle import maskgit_oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def adamw_cpu(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+        assert p_bf16 is None and grad_scale == 1.0
+        O.adamw_step(p, g, m, v, int(step), lr, beta1, beta2, eps, weight_decay)
+    ops.adamw_flat = adamw_cpu
+    torch.manual_seed(300 + rank)
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TINY)
+    m.set_compute_dtype(torch.float32)
+    red = muse.GradReducer(m, bucket_bytes=4 * 14000)              # 14000 elements: a bucket spans layers, the last one is ragged
+    opt = muse.FusedAdamW(m.parameters(), lr=1e-2, betas=(0.9, 0.99), weight_decay=0.05, eps=1e-8)
+    n = m.flat_params().numel()
+    p0 = m.flat_params().clone()
+    off, L = m._offsets, m.num_hidden_layers
+    t0 = 2 + L * 11
+    buckets = []
+    for step in range(3):
+        g = m.flat_grads()
+        g.copy_(torch.sin(torch.arange(n, dtype=torch.float32) * 0.01 * (step + 1)) * (rank + 1))
+        for p in m.parameters():
+            if p.grad is None:
+                p.grad = m._grad_views[[id(q) for q in m._param_order()].index(id(p))]
+        assert opt.begin_step_in_reducer(m, red)
+        seen = []
+        inner = red.post_reduce
+        red.post_reduce = lambda lo, hi: (seen.append((lo, hi)), inner(lo, hi))
+        m.grad_ready_hook(off[t0], n)
+        for li in reversed(range(L)):
+            if step == 1 and li == 0:
+                continue                                            # one layer unreported in step 1: step() must cover it
+            b0 = 2 + li * 11
+            m.grad_ready_hook(off[b0], off[b0 + 11])
+        if step != 1:
+            m.grad_ready_hook(off[0], off[2])
+        red.finish()
+        opt.end_step_in_reducer(red)
+        if step == 1:   # the unreported ranges still hold this rank's own gradient: average them the plain way before step()
+            lo, hi = 0, off[2 + 11]
+            g[lo:hi].mul_(1.0 / world)
+            dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
+        opt.step()
+        buckets.append(sorted(seen))
+    torch.save({"p0": p0, "p": m.flat_params().clone(), "buckets": buckets, "n": n}, os.path.join(out, f"o{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_optimizer_in_reducer_world4(tmp_path):
+    sys.path.insert(0, ROOT)
+    from oracle import maskgit_oracle as O
+    world = 4
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_opt_in_reducer, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"o{r}.pt") for r in range(world)]
+    n = rs[0]["n"]
+    for r in rs[1:]:
+        assert torch.equal(r["p"], rs[0]["p"])                     # every rank ends with the same parameters, bit for bit
+    # single-process reference: AdamW over the whole buffer with the rank-averaged gradient
+    p = rs[0]["p0"].clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(3):
+        g = torch.zeros(n)
+        for rank in range(world):
+            g += torch.sin(torch.arange(n, dtype=torch.float32) * 0.01 * (step + 1)) * (rank + 1) * (1.0 / world)
+        O.adamw_step(p, g, m, v, step + 1, 1e-2, 0.9, 0.99, 1e-8, 0.05)
+    assert torch.allclose(rs[0]["p"], p, rtol=0, atol=2e-6), float((rs[0]["p"] - p).abs().max())
+    sizes = [hi - lo for seen in rs[0]["buckets"] for lo, hi in seen]
+    assert any(z < 14000 for z in sizes) and any(z >= 14000 for z in sizes)     # full and ragged buckets
+    for step, seen in enumerate(rs[0]["buckets"]):
+        assert len(seen) >= (2 if step != 1 else 1)                 # several buckets ...
+        assert all(a[1] <= b[0] for a, b in zip(seen, seen[1:]))    # ... that never overlap
+        covered = sum(hi - lo for lo, hi in seen)
+        assert covered == n if step != 1 else covered < n
