@@ -170,7 +170,6 @@ struct PipeP {
   unsigned tk;             // wave 0, lane 0: ticket drawn for the next tile
   int wave, lane, wr, wc, xcd, nbx;
   int kti;                 // K-tile index, relative to the tile the DMA currently targets
-  int nact;                // fragment rows of this wave that lie inside the matrix (current tile)
   int nm0, nn0;
   bool has_next, pend;
 
@@ -226,10 +225,7 @@ struct PipeP {
   }
 
   // one MFMA group (A-fragment row G & 7 against the 4 B fragments of K-group G >> 3) of the K-tile in stage S
-  // SKIP (tiles of the ragged last row strip): fragment rows outside the matrix are all zeros - leave their MFMAs out (nact =
-  // fragment rows of this wave that hold matrix rows; the reads, waits and barriers stay, the DMA pieces of those rows are
-  // out-of-range chunks that never touch memory)
-  template <int S, int G, int MODE, bool SKIP>
+  template <int S, int G, int MODE>
   __device__ __forceinline__ void group() {
     // the ticket for the tile after this one: behind the previous tile's stores when the barrier below lets them drain on (it
     // then has until the NEXT K-tile's barrier to return), else behind this K-tile's barrier
@@ -255,22 +251,20 @@ struct PipeP {
     if constexpr (G == GB1) fb.template read_range<S, 1, 0, NI>(bk[1]);
     read_a<S, G + DIST>();
     wait_lgkm<waitN(G)>();
-    if (!SKIP || (G & 7) < nact) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        acc[G & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j], 0, 0, 0);
-    }
+    for (int j = 0; j < NI; ++j)
+      acc[G & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (G + 1 < 16) group<S, G + 1, MODE, SKIP>();
+    if constexpr (G + 1 < 16) group<S, G + 1, MODE>();
     else ++kti;
   }
-  template <int S, int MODE, bool SKIP>
+  // (Measured and dropped: skipping the MFMA groups of fragment rows outside the matrix on the tiles of the ragged last row strip
+  //  - M = 16448 leaves 64 rows in the 65th row tile - with a wave-uniform branch per group.  The strip tiles get ~2x cheaper and the
+  //  GEMM micro-benchmarks gain 2-5 %, but the branch costs every other tile a little and the train step, where other streams fill
+  //  the tail anyway, came out 0.15 ms SLOWER: 60.00 vs 59.85 ms, same box, profiles/r03_skip_ab.txt.)
+  template <int S, int MODE>
   __device__ __forceinline__ void ktile() {
-    group<S, 0, MODE, SKIP>();
-  }
-  __device__ __forceinline__ void set_nact(int m0) {
-    const int rows = M - m0 - wr;
-    nact = rows >= 16 * MI ? MI : (rows <= 0 ? 0 : (rows + 15) >> 4);
+    group<S, 0, MODE>();
   }
 
   // accumulator start values: zero, or (f32 outputs) the residual / the old C, in fragment layout
@@ -429,26 +423,24 @@ struct PipeP {
     }
   }
 
-  // the tile loop; SKIP = false returns true when the next tile is a ragged-strip tile (to be continued by tiles<true>)
-  template <bool SKIP>
-  __device__ __forceinline__ bool tiles(int& m0, int& n0) {
+  // the tile loop
+  __device__ __forceinline__ void tiles(int& m0, int& n0) {
     for (;;) {
-      ktile<0, M_FIRST, SKIP>();
-      ktile<1, M_PUBLISH, SKIP>();
+      ktile<0, M_FIRST>();
+      ktile<1, M_PUBLISH>();
       for (int it = 2; it < nk2 - 2; it += 2) {
-        ktile<0, M_NORMAL, SKIP>();
-        ktile<1, M_NORMAL, SKIP>();
+        ktile<0, M_NORMAL>();
+        ktile<1, M_NORMAL>();
       }
-      ktile<0, M_LAST, SKIP>();      // from its barrier on the DMA fetches the next tile
-      ktile<1, M_NORMAL, SKIP>();
+      ktile<0, M_LAST>();      // from its barrier on the DMA fetches the next tile
+      ktile<1, M_NORMAL>();
       // tile change: the rest of the next tile's second K-tile goes out ahead of the stores
       issue_piece<1, 3>(1); issue_piece<1, 4>(1); issue_piece<1, 5>(1); issue_piece<1, 6>(1); issue_piece<1, 7>(1);
       fence();
       epilogue(m0, n0);
       fence();
-      if (!has_next) return false;
+      if (!has_next) return;
       m0 = nm0; n0 = nn0;
-      set_nact(m0);
       const bool ld = init_acc(m0, n0);
       fence();
       pend = !ld && epi != 3;
@@ -484,8 +476,7 @@ struct PipeP {
     kti = 0;
     pend = false;
     has_next = false;
-    set_nact(m0);
-    tiles<false>(m0, n0);
+    tiles(m0, n0);
     // trailing zero-fill DMA pieces and look-ahead reads must not outlive the workgroup's LDS allocation
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }

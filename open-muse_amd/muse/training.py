@@ -278,8 +278,17 @@ class FusedAdamW(torch.optim.Optimizer):
         has_shadow = model._resolve_cd() == torch.bfloat16
         if has_shadow:
             model.compute_weights(torch.bfloat16)
-        own = flat.is_cuda and os.environ.get("MUSE_OPT_REDUCER_STREAM", "comm") == "own"
-        if own and (self._upd_stream is None or self._upd_stream.device != flat.device):
+        # where the per-bucket update runs: "comm" (default) = the reducer's high-priority stream right behind the collective;
+        # "side" = the model's weight-gradient stream, in order with the dW GEMMs still to come (the placement of the single-GPU
+        # in-backward update); "own" = a normal-priority stream of its own.  One-rank launch line on MI355X, per step
+        # (profiles/r03_dp1_update_placement.txt): comm 60.7 ms / side 62.2 ms with the default 4 hardware queues, 66.7 / 65.8 ms
+        # with GPU_MAX_HW_QUEUES=8 (plain single-GPU step on that box: 59.9 ms) - the 8-queue penalty is not the update's placement.
+        where = os.environ.get("MUSE_OPT_REDUCER_STREAM", "comm")
+        own = flat.is_cuda and where in ("own", "side")
+        if own and where == "side" and hasattr(model, "_wgrad_side_stream"):
+            self._upd_stream = model._wgrad_side_stream(flat.device)
+        elif own and (self._upd_stream is None or self._upd_stream.device != flat.device or
+                      self._upd_stream is getattr(model, "_side_stream", None)):
             self._upd_stream = torch.cuda.Stream(device=flat.device)
         self._upd_used = False
 
