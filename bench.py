@@ -131,7 +131,7 @@ def leg_isolated(spec, fallback):
         return fallback()
 
 
-def uvit_leg_isolated(device, batch, seq, steps):
+def uvit_leg_isolated(device, batch, seq, steps, f32=False):
     """uvit_leg in a fresh process.  The U-ViT step is ~4500 small launches; at the end of this long-lived process (allocator state,
     Python heap of all the earlier legs) the same leg measured 205 ms per step against 163 ms in a process of its own, which is what a
     training job is - so it gets one (GPU memory of this process has been released by then)."""
@@ -139,14 +139,14 @@ def uvit_leg_isolated(device, batch, seq, steps):
     try:
         torch.cuda.empty_cache()
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--uvit-leg", f"{batch},{seq},{steps}"], capture_output=True, text=True,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--uvit-leg", f"{batch},{seq},{steps}" + (",f32" if f32 else "")], capture_output=True, text=True,
                            timeout=600, env=env)
         line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
         print(f"bench: config-4 leg {batch},{seq} did not run in a subprocess ({type(e).__name__}); running it in-process", file=sys.stderr)
         try:
-            out = uvit_leg(device, batch, seq, steps)
+            out = uvit_leg(device, batch, seq, steps, f32)
             out["note"] = f"in-process (subprocess failed: {type(e).__name__})"
         except Exception as e2:   # noqa: BLE001
             torch.cuda.empty_cache()
@@ -257,7 +257,7 @@ def latency_leg(device, timesteps=12):
     return out
 
 
-def uvit_leg(device, batch, seq, steps=3):
+def uvit_leg(device, batch, seq, steps=3, f32=False):
     """BASELINE.json config 4: configs/cc12m_uvit_clip.yaml MaskGiTUViT (UVIT_CC12M: 728.7 M parameters, 22 layers, hidden 1024, GLU 4096,
     1024-channel ResBlock / attention stages; block_num_heads 16 per SURVEY.md D3), synthetic CLIP states (77 x 768), tokens given,
     bf16 compute (fused self / cross attention, bf16 weight copies refreshed inside the AdamW kernel): forward + backward + FusedAdamW"""
@@ -271,7 +271,7 @@ def uvit_leg(device, batch, seq, steps=3):
         M.MaskGiTUViT_v2._init_weights = init
     n_params = sum(p.numel() for p in model.parameters())
     assert n_params == 728725504, n_params          # the geometry GF_UVIT_FWD was counted on
-    model.to(device).train().set_compute_dtype(torch.bfloat16)
+    model.to(device).train().set_compute_dtype(torch.float32 if f32 else torch.bfloat16)
     g = torch.Generator(device=device).manual_seed(0)
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -300,8 +300,10 @@ def uvit_leg(device, batch, seq, steps=3):
     dt = (time.perf_counter() - t0) / steps
     tf = 3 * GF_UVIT_FWD[seq] * batch / dt / 1e3
     out = {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 1), "batch": batch, "seq_len": seq,
-           "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK["bf16"], 4), "loss": round(float(loss), 4), "parameters": n_params,
-           "dtype": "bf16 weight-GEMM / attention operands, f32 accumulate, residual stream, norms, loss (the yaml itself sets mixed_precision: no)",
+           "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK["f32" if f32 else "bf16"], 4), "loss": round(float(loss), 4), "parameters": n_params,
+           "dtype": ("exact f32 everywhere (f32-input MFMA, 157 TFLOP/s peak): at or above the precision of the yaml's mixed_precision: no + "
+                     "enable_tf32 (10-bit mantissa products); gfx950 has no xf32 MFMA") if f32 else
+                    "bf16 weight-GEMM / attention operands, f32 accumulate, residual stream, norms, loss (the yaml itself sets mixed_precision: no)",
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     del model, opt
     torch.cuda.empty_cache()
@@ -389,9 +391,10 @@ def main():
                                                 "'taming,<batch>') and print its JSON")
     args = ap.parse_args()
     if args.uvit_leg:
-        b, sq, st = (int(x) for x in args.uvit_leg.split(","))
+        parts = args.uvit_leg.split(",")
+        b, sq, st = (int(x) for x in parts[:3])
         torch.cuda.set_device(0)
-        print(json.dumps(uvit_leg(torch.device("cuda", 0), b, sq, st)))
+        print(json.dumps(uvit_leg(torch.device("cuda", 0), b, sq, st, f32=len(parts) > 3 and parts[3] == "f32")))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -551,6 +554,8 @@ def main():
         # per-step cost (AdamW over 729 M parameters, ~500 small launches) is amortised over more tokens
         extra["config4_uvit_seq256"] = uvit_leg_isolated(device, 128, 256, 3)
         extra["config4_uvit_seq1024"] = uvit_leg_isolated(device, 48, 1024, 2)
+        # ... and at the YAML's own precision class (cc12m_uvit_clip.yaml:102-103 mixed_precision "no" + TF32): exact f32 here
+        extra["config4_uvit_seq256_f32"] = uvit_leg_isolated(device, 32, 256, 2, f32=True)
         # the reference's PUBLISHED metric (its only published numbers): text-to-image pipeline latency, 12 steps, 256 x 256
         extra["inference_latency"] = leg_isolated("latency", lambda: latency_leg(device))
 

@@ -316,8 +316,9 @@ class MaskGitVQGAN(_ConvEngine, ModelMixin, ConfigMixin):
     def get_soft_code(self, pixel_values, temp=1.0, stochastic=False):
         z, (B, H, W) = self._encode_nhwc(pixel_values)
         cb = self._codebook()
-        dist = torch.cdist(z, cb).pow(2)  # adjacent feature (soft targets), torch op on the GPU
-        soft = F.softmax(-dist / temp, dim=-1)
+        soft = ops.vq_neg_distances_scaled(z, cb, 1.0 / float(temp))       # -distances / temp (:329-331) ...
+        ops.softmax_(soft, soft.shape[0], soft.shape[1], soft.shape[1])     # ... softmax over the codebook, in place
+        # stochastic: one categorical draw per token (torch's generator, like the reference :333); else the exact argmin of :335
         code = torch.multinomial(soft, 1) if stochastic else ops.vq_nearest(z, cb)
         return soft.view(B, H * W, -1), code.view(B, H * W)
 

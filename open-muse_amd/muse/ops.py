@@ -838,6 +838,22 @@ def vq_nearest(z_flat, codebook, en=None):
     return idx
 
 
+def vq_neg_distances_scaled(z_flat, codebook, inv_temp):
+    """-(|z|^2 + |e|^2 - 2 z.e) * inv_temp as one GEMM with its row / column vectors pre-scaled: the logits of
+    VectorQuantizer.get_soft_code (muse/modeling_maskgit_vqgan.py:327-331) -> f32 [N, Kc]"""
+    require_gpu(z_flat, codebook)
+    N, D = z_flat.shape
+    Kc = codebook.shape[0]
+    zn = torch.empty(N, dtype=torch.float32, device=z_flat.device)
+    en = torch.empty(Kc, dtype=torch.float32, device=z_flat.device)
+    check(lib().muse_row_sumsq(z_flat.data_ptr(), zn.data_ptr(), N, D, z_flat.stride(0), stream()), "muse_row_sumsq")
+    check(lib().muse_row_sumsq(codebook.data_ptr(), en.data_ptr(), Kc, D, codebook.stride(0), stream()), "muse_row_sumsq")
+    out = torch.empty((N, Kc), dtype=torch.float32, device=z_flat.device)
+    gemm(z_flat, codebook, out, N, Kc, D, la=0, lb=0, lda=z_flat.stride(0), ldb=codebook.stride(0), ldc=Kc, alpha=2.0 * inv_temp,
+         bias=en.mul_(-inv_temp), rowvec=zn.mul_(-inv_temp))
+    return out
+
+
 def gather_rows(table, idx, out_dtype):
     require_gpu(table, idx)
     rows = idx.numel()

@@ -22,11 +22,11 @@ for r in csv.DictReader(open(cc[0])):
     key = k[:70] + " grid=" + r["Grid_Size"]
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     agg[key]["_us"].append(dur.get(r["Dispatch_Id"], float("nan")))
-print("kernel | us (profiled) | GRBM_GUI_ACTIVE -> clock GHz | SQ_VALU_MFMA_BUSY_CYCLES / (GUI_ACTIVE * 1024 SIMDs) = matrix-pipe busy share")
+print("kernel | us (profiled) | GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration = clock GHz | SQ_VALU_MFMA_BUSY_CYCLES (summed over 1024 SIMDs) / 1024 / cycles = matrix-pipe busy share")
 for k, d in agg.items():
     med = lambda v: sorted(v)[len(v) // 2]
     us, gui, mf = med(d["_us"]), med(d.get("GRBM_GUI_ACTIVE", [0])), med(d.get("SQ_VALU_MFMA_BUSY_CYCLES", [0]))
-    print(f"{k}\n    {us:8.1f} us  gui_active {gui:.4g} -> {gui / us / 1e3:.3f} GHz   mfma_busy {mf:.4g} -> {mf / max(gui, 1) / 1024:.3f} of the matrix pipes"
+    print(f"{k}\n    {us:8.1f} us  gui_active {gui:.4g} -> {gui / 8 / us / 1e3:.3f} GHz   mfma_busy {mf:.4g} -> {mf / 1024 / max(gui / 8, 1):.3f} of the matrix-pipe cycles"
           f"   wave_cycles {med(d.get('SQ_WAVE_CYCLES', [0])):.4g}  busy_cycles {med(d.get('SQ_BUSY_CYCLES', [0])):.4g}")
 PY
 find $O/pmc_r3 -name "*.csv" -size +2M -delete

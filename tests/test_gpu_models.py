@@ -798,3 +798,24 @@ def test_bench_under_torchrun_single_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 100 and line["config"]["parallelism"] == "dp1" and line["roofline"]["frac"] > 0
+
+
+def test_get_soft_code_matches_oracle():
+    """VectorQuantizer.get_soft_code (muse/modeling_maskgit_vqgan.py:327-340): softmax(-distances / temp) over the codebook from the
+    HIP GEMM + softmax kernels against the oracle's distances; the hard code is the exact argmin; the stochastic draw is a valid id"""
+    import muse
+    from oracle import maskgit_oracle as O
+    cfg = W.VQGAN_TINY
+    v = muse.MaskGitVQGAN(**cfg)
+    sd = W.fill_state_dict(W.vqgan_shapes(cfg), 41, "vqgan")
+    v.load_state_dict(sd)
+    v.to(DEV).eval()
+    px = W.images(3, cfg["resolution"], 42).to(DEV)
+    soft, code = v.get_soft_code(px, temp=0.7)
+    z, _ = v._encode_nhwc(px)
+    dist = O.vq_distances(z.float().cpu(), sd["quantize.embedding.weight"])
+    ref = torch.softmax(-dist / 0.7, dim=-1).view(3, -1, cfg["num_embeddings"])
+    assert soft.shape == ref.shape and float((soft.cpu() - ref).abs().max()) < 2e-5
+    assert torch.equal(code, v.get_code(px))
+    _, drawn = v.get_soft_code(px, temp=0.7, stochastic=True)
+    assert drawn.shape == code.shape and int(drawn.min()) >= 0 and int(drawn.max()) < cfg["num_embeddings"]
