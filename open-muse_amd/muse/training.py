@@ -75,7 +75,10 @@ def mask_or_random_replace_tokens(image_tokens, mask_id, config, mask_schedule=N
     region_p = tr.get("mask_contiguous_region_prob", None)
     region = region_p is not None and random.random() < region_p
     if region and rects is None:
+        # ONE mask_prob for the rectangle sizes and for the kernel (which otherwise evaluates its own double-precision cosine: the two
+        # could disagree at a .5 rounding boundary): the f32 cosine of the reference (:160-161) is handed to muse_mask_tokens
         mp = mask_prob_in if mask_prob_in is not None else torch.cos(timesteps.float() * (math.pi * 0.5)).clip(tr.min_masking_rate)
+        mask_prob_in = mp
         counts = (S * mp).round().clamp(min=1).tolist()
         res = int(S ** 0.5)
         boxes = []
@@ -307,12 +310,14 @@ class FusedAdamW(torch.optim.Optimizer):
         reducer.post_reduce = hook
         return True
 
-    def end_step_in_reducer(self, reducer):
+    def end_step_in_reducer(self, reducer, failed=False):
         reducer.post_reduce = None
         if self._upd_used:   # the caller's stream continues behind the last bucket's update
             torch.cuda.current_stream(self._upd_stream.device).wait_stream(self._upd_stream)
             self._upd_used = False
         self._ranges_done, self._ranges_done_live = self._ranges_done_live, None
+        if failed and self._ranges_done is not None and self._ranges_done[1]:
+            self._partial_step = True
 
     def _ensure_flat_state(self, flat):
         if self._m is None:
@@ -702,15 +707,17 @@ class TrainStep:
         armed_r = (not armed and self.optimizer_in_reducer and self.reducer is not None and getattr(self.reducer, "_flat_mode", False)
                    and self.reducer.model is self.model and isinstance(self.optimizer, FusedAdamW) and loss.is_cuda
                    and self.model._resolve_cd() == torch.bfloat16 and self.optimizer.begin_step_in_reducer(self.model, self.reducer))
+        failed = True
         try:
             loss.backward()
             if self.reducer is not None:
                 self.reducer.finish()
+            failed = False
         finally:
             if armed:
-                self.optimizer.end_step_in_backward(self.model)
+                self.optimizer.end_step_in_backward(self.model, failed=failed)
             if armed_r:
-                self.optimizer.end_step_in_reducer(self.reducer)
+                self.optimizer.end_step_in_reducer(self.reducer, failed=failed)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), mask_prob

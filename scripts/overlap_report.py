@@ -11,7 +11,7 @@ import csv
 import sys
 from collections import defaultdict
 
-FAMILIES = (("conv", ("conv_slab", "conv_dma", "conv_split", "conv")), ("gemm", ("g256::", "gemm_kernel")),
+FAMILIES = (("conv", ("conv_slab", "conv_dma", "conv_split", "conv")), ("gemm", ("g256::", "g256p::", "gemm_kernel")),
             ("attention", ("attn_",)), ("adamw", ("adamw",)), ("groupnorm/pool", ("gn_", "avgpool")),
             ("rows", ("ln_", "ffn_mid", "norm_res", "adaln", "glu_", "gelu", "silu", "grn_", "dwconv")),
             ("reduce", ("sum_slices", "colsum")), ("copy/cast", ("copyBuffer", "cast_", "fillBuffer", "elementwise")),

@@ -819,3 +819,41 @@ def test_get_soft_code_matches_oracle():
     assert torch.equal(code, v.get_code(px))
     _, drawn = v.get_soft_code(px, temp=0.7, stochastic=True)
     assert drawn.shape == code.shape and int(drawn.min()) >= 0 and int(drawn.max()) < cfg["num_embeddings"]
+
+
+def test_train_step_on_pre_encoded_tokens_without_a_tokenizer():
+    """the pre-encoded regime (scripts/pre_encode.py shards) needs no tokenizer in the step: TrainStep(vq_model=None) takes
+    the class-token offset from the transformer's config and gives the loss of the step that was handed the same tokens by a tokenizer
+    object; a prefetched batch that is not picked up (another tensor object) warns instead of silently encoding twice; a failed
+    backward with the in-backward optimizer armed leaves the optimizer refusing further steps instead of double-applying ranges"""
+    import muse
+    from muse._hip import MuseHipError
+    tcfg = dict(W.TRANSFORMER_TINY)
+    vq = muse.MaskGitVQGAN(**W.VQGAN_TINY)
+    vq.load_state_dict(W.fill_state_dict(W.vqgan_shapes(W.VQGAN_TINY), 5, "vqgan"))
+    vq.to(DEV).eval()
+    px = W.images(4, 16, 6).to(DEV)
+    cls = torch.tensor([1, 2, 3, 4], device=DEV)
+    t, nz = W.uniforms((4,), 7).to(DEV), W.uniforms((4, 16), 8).to(DEV)
+    toks = vq.get_code(px)
+    losses = []
+    for tokenizer in (vq, None):
+        m = muse.MaskGitTransformer(**tcfg)
+        m.load_state_dict(W.fill_state_dict(W.transformer_shapes(tcfg), 9, "transformer"))
+        m.to(DEV).train().set_compute_dtype(torch.float32)
+        step = muse.TrainStep(tokenizer, m, muse.FusedAdamW(m.parameters(), lr=1e-3))
+        losses.append(float(step(None, cls, t, nz, image_tokens=toks)[0]))
+    assert losses[0] == losses[1]
+    step = muse.TrainStep(vq, m, muse.FusedAdamW(m.parameters(), lr=1e-3))
+    step(px, cls, t, nz, next_pixel_values=px)
+    with pytest.warns(RuntimeWarning, match="prefetched batch is discarded"):
+        step(px.clone(), cls, t, nz)
+    # partial-step guard
+    m2 = muse.MaskGitTransformer(**W.TRANSFORMER_B)
+    m2.to(DEV).train().set_compute_dtype(torch.bfloat16)
+    opt = muse.FusedAdamW(m2.parameters(), lr=1e-4)
+    assert opt.begin_step_in_backward(m2)
+    opt._ranges_done_live[1].append((0, 64))                   # (as if backward had reported - and updated - a first range)
+    opt.end_step_in_backward(m2, failed=True)
+    with pytest.raises(MuseHipError, match="failed inside backward"):
+        opt.step()

@@ -356,3 +356,32 @@ def test_uvit_config4_vs_reference_golden(golden_dir):
         for k in keys:
             assert errs[k] < (2e-3 if f32 else 1.5e-1), (cd, k, errs[k])
             assert nerrs[k] < (1e-3 if f32 else 3e-2), (cd, k, nerrs[k])
+
+
+def test_cached_bf16_weights_never_go_stale_across_stackings(golden_dir):
+    """the cached bf16 compute copies are validated by autograd version counters, which the raw FusedAdamW kernel does not
+    bump - it refreshes ONE copy per parameter (`p._muse_shadow`).  A weight cached first in the fused q|k|v stacking and then alone
+    (unfused attention at another sequence length, generate2 without eval()) must not leave a second, silently stale copy behind:
+    caching it in a new stacking drops the old one, so after an optimizer step every stacking equals the cast of the f32 master."""
+    import muse
+    from muse import ops
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    g = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    m = muse.MaskGiTUViT(**cfg)
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}, strict=True)
+    m.to(DEV).train().set_compute_dtype(torch.bfloat16)
+    att = m.transformer_layers[0].attention
+    fused = m._wb(att.query, att.key, att.value)
+    assert att.query.weight._muse_shadow.data_ptr() == fused.data_ptr()
+    alone = m._wb(att.query)                                   # the same weight in another stacking ...
+    key_fused = tuple(id(x.weight) for x in (att.query, att.key, att.value))
+    assert key_fused not in m._wcache                          # ... evicts the stacking that held it before
+    assert att.query.weight._muse_shadow.data_ptr() == alone.data_ptr()
+    opt = muse.FusedAdamW(m.parameters(), lr=1e-2)
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    _, loss = m(*args, labels=torch.from_numpy(g["labels"]).to(DEV))
+    loss.backward()
+    opt.step()                                                  # raw kernel: no version bump, refreshes the registered shadows
+    for mods in ((att.query,), (att.query, att.key, att.value), (att.key, att.value)):
+        want = ops.cast_to_bf16(torch.cat([x.weight.data.reshape(x.weight.shape[0], -1) for x in mods]).contiguous())
+        assert torch.equal(m._wb(*mods).view(torch.int16), want.view(torch.int16)), len(mods)

@@ -261,6 +261,25 @@ def test_pre_encoded_token_shards_roundtrip(tmp_path):
     assert all(torch.equal(s["image_input_ids"], toks[i]) and torch.equal(s["encoder_hidden_states"], enc[i]) for i, s in enumerate(got))
     batches = list(PE.token_batches([path], vae, 2, device="cpu"))
     assert len(batches) == 2 and torch.equal(batches[1], toks[2:4])            # ragged tail dropped
+    # a shard as the REFERENCE writes it (scripts/pre_encode.py:54-56: mixed-case member names, here inside a directory and with a
+    # dot in the directory name): webdataset lower-cases the extension on read and keys on the base name
+    import io
+    ref_path = str(tmp_path / "ref.tar")
+    with tarfile.open(ref_path, "w") as tar:
+        for i, key in enumerate(keys[:2]):
+            for ext, t in ((".openMUSE.vqgan-f16-8192-laion.pth", toks[i]), (".json", None)):
+                payload = io.BytesIO()
+                if t is None:
+                    payload.write(b"{}")
+                else:
+                    torch.save(t.clone(), payload)
+                info = tarfile.TarInfo(f"./shard.0/{key}{ext}")
+                info.size = payload.tell()
+                payload.seek(0)
+                tar.addfile(info, payload)
+    got = list(PE.read_token_shard(ref_path, vae))
+    assert [os.path.basename(s["__key__"]) for s in got] == keys[:2]
+    assert all(torch.equal(s["image_input_ids"], toks[i]) for i, s in enumerate(got))
 
 
 def test_bench_config4_is_the_baseline_geometry():
