@@ -101,6 +101,14 @@ int muse_layernorm_pair_bwd(const void* dln2, const float* x1, const float* w_pr
                             int32_t cols, void* stream);
 /* out[c] (+)= sum_r in[r, c], f32 */
 int muse_colsum(const float* in, float* out, int32_t rows, int32_t cols, int32_t accumulate, void* stream);
+/* Biases of `use_bias=True` models (muse/modeling_transformer.py:130 LayerNorm bias, :170-176 / :770-778 / :973-977 / :1155
+ * nn.Linear biases; the Linear bias itself rides in muse_gemm's `bias` epilogue):
+ *   muse_add_rowvec: x[r, c] += b[c], f32 in place (the LayerNorm bias behind muse_norm_res_fwd / muse_layernorm_fwd).
+ *   muse_bias_grad_partial: partial[k, c] = sum of dy[r, c] over the k-th chunk of muse_bias_grad_rows_per_block() rows (dy f32 or
+ *   bf16 with row stride ld); muse_colsum over the ceil(rows / R) partial rows gives d(bias), in a fixed order. */
+int muse_add_rowvec(float* x, const float* b, int64_t rows, int32_t cols, void* stream);
+int muse_bias_grad_rows_per_block(void);
+int muse_bias_grad_partial(const void* dy, int32_t dtype, float* partial, int64_t rows, int32_t cols, int64_t ld, void* stream);
 
 /* softmax over the last dim of [rows, ld] (first `cols` valid, pad columns written as 0), in place capable.
  * Replaces F.softmax at muse/modeling_transformer.py:236.  bwd: ds = p * (dp - sum(p*dp)). */

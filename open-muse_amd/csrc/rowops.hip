@@ -816,6 +816,41 @@ extern "C" int muse_colsum(const float* in, float* out, int32_t rows, int32_t co
 }
 
 // =================================================================================================================
+// biases of use_bias models (muse/modeling_transformer.py:130, :170-176): the LayerNorm bias added in place, and the first stage of
+// d(bias) = sum_r dy[r, :] (second stage: muse_colsum over the per-chunk partial rows; fixed order, no float atomics)
+// =================================================================================================================
+__global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ b, long n, int cols) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] += b[i % cols];
+}
+extern "C" int muse_add_rowvec(float* x, const float* b, int64_t rows, int32_t cols, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, b, n, cols);
+  return (int)hipGetLastError();
+}
+
+constexpr int kBiasGradRows = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const T* __restrict__ dy, float* __restrict__ part, long rows, int cols, long ld) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const long r0 = (long)blockIdx.y * kBiasGradRows;
+  const long r1 = r0 + kBiasGradRows < rows ? r0 + kBiasGradRows : rows;
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) s += Elem<T>::load(dy + r * ld + c);      // (a wave reads 64 consecutive columns of one row)
+  part[(long)blockIdx.y * cols + c] = s;
+}
+extern "C" int muse_bias_grad_rows_per_block(void) { return kBiasGradRows; }
+extern "C" int muse_bias_grad_partial(const void* dy, int32_t dtype, float* partial, int64_t rows, int32_t cols, int64_t ld, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (dtype != MUSE_F32 && dtype != MUSE_BF16) return MUSE_ERR_BAD_ARG;
+  const dim3 grid((cols + 255) / 256, (unsigned)((rows + kBiasGradRows - 1) / kBiasGradRows));
+  if (dtype == MUSE_F32) hipLaunchKernelGGL((bias_grad_partial_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, partial, (long)rows, cols, (long)ld);
+  else hipLaunchKernelGGL((bias_grad_partial_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, partial, (long)rows, cols, (long)ld);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
 // softmax over rows of [rows, ld] (cols valid); one wave per row, pad columns [cols, ld) written as 0
 // =================================================================================================================
 template <typename T>

@@ -56,6 +56,9 @@ SIGNATURES = {
     "muse_layernorm_pair_fwd": [c_void_p] * 10 + [c_int, c_int, c_float, c_void_p],
     "muse_layernorm_pair_bwd": [c_void_p] * 14 + [c_int, c_int, c_int, c_void_p],
     "muse_colsum": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "muse_add_rowvec": [c_void_p, c_void_p, c_i64, c_int, c_void_p],
+    "muse_bias_grad_rows_per_block": [],
+    "muse_bias_grad_partial": [c_void_p, c_int, c_void_p, c_i64, c_int, c_i64, c_void_p],
     "muse_softmax_fwd": [c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],
     "muse_softmax_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_i64, c_void_p],
     "muse_attention_seq_pad": [c_int],

@@ -29,40 +29,44 @@ from .tape_ops import TapeOps
 class _P(nn.Module):
     """leaf named like the reference's nn.Linear / nn.Embedding / norm module (`.weight`)"""
 
-    def __init__(self, *shape, ones=False):
+    def __init__(self, *shape, ones=False, bias=False):
         super().__init__()
         self.weight = nn.Parameter(torch.ones(*shape) if ones else torch.empty(*shape))
+        if bias:                     # `use_bias`: nn.Linear / LayerNorm bias, zero-initialised (reference :1203-1219)
+            self.bias = nn.Parameter(torch.zeros(shape[0]))
 
 
 class _GAttention(nn.Module):
-    def __init__(self, H, kv):
+    def __init__(self, H, kv, b):
         super().__init__()
-        self.query, self.key, self.value, self.out = _P(H, H), _P(H, kv), _P(H, kv), _P(H, H)
+        self.query, self.key, self.value, self.out = _P(H, H, bias=b), _P(H, kv, bias=b), _P(H, kv, bias=b), _P(H, H, bias=b)
 
 
 class _GFeedForward(nn.Module):
-    def __init__(self, H, I, normformer):
+    def __init__(self, H, I, normformer, b, nb):
         super().__init__()
-        self.pre_mlp_layer_norm = _P(H, ones=True)
-        self.wi_0, self.wi_1 = _P(I, H), _P(I, H)
+        self.pre_mlp_layer_norm = _P(H, ones=True, bias=b)      # a LayerNorm whatever norm_type says (:768-770): biased under use_bias
+        self.wi_0, self.wi_1 = _P(I, H, bias=b), _P(I, H, bias=b)
         if normformer:
-            self.mid_mlp_layer_norm = _P(I, ones=True)
-        self.wo = _P(H, I)
+            self.mid_mlp_layer_norm = _P(I, ones=True, bias=nb)
+        self.wo = _P(H, I, bias=b)
 
 
 class _GLayer(nn.Module):
-    def __init__(self, H, I, kv, cross, normformer):
+    """b: use_bias (every Linear);  nb: use_bias and norm_type == "layernorm" (norm_cls norms; RMSNorm has no bias)"""
+
+    def __init__(self, H, I, kv, cross, normformer, b, nb):
         super().__init__()
-        self.attn_layer_norm = _P(H, ones=True)
-        self.attention = _GAttention(H, H)
+        self.attn_layer_norm = _P(H, ones=True, bias=nb)
+        self.attention = _GAttention(H, H, b)
         if normformer:
-            self.post_attn_layer_norm = _P(H, ones=True)
-        self.ffn = _GFeedForward(H, I, normformer)
+            self.post_attn_layer_norm = _P(H, ones=True, bias=nb)
+        self.ffn = _GFeedForward(H, I, normformer, b, nb)
         if cross:
-            self.crossattn_layer_norm = _P(H, ones=True)
-            self.crossattention = _GAttention(H, kv)
+            self.crossattn_layer_norm = _P(H, ones=True, bias=nb)
+            self.crossattention = _GAttention(H, kv, b)
             if normformer:
-                self.post_crossattn_layer_norm = _P(H, ones=True)
+                self.post_crossattn_layer_norm = _P(H, ones=True, bias=nb)
 
 
 class _GEmbed(nn.Module):
@@ -72,12 +76,12 @@ class _GEmbed(nn.Module):
 
 
 class _GMlm(nn.Module):
-    def __init__(self, H, V, layernorm):
+    def __init__(self, H, V, layernorm, b, nb):
         super().__init__()
-        self.mlm_dense = _P(H, H)
+        self.mlm_dense = _P(H, H, bias=b)
         if layernorm:
-            self.mlm_ln = _P(H, ones=True)
-        self.to_logits = _P(V, H)
+            self.mlm_ln = _P(H, ones=True, bias=nb)
+        self.to_logits = _P(V, H, bias=b)
 
 
 class _GeneralFn(torch.autograd.Function):
@@ -120,18 +124,22 @@ class GeneralMaskGitEngine(TapeOps):
         H, I, V = c.hidden_size, c.intermediate_size, c.vocab_size
         cross = bool(c.add_cross_attention)
         kv = c.encoder_hidden_size
-        self.embed = _GEmbed(V, c.max_position_embeddings, H)
+        b = bool(c.use_bias)                              # a bias on every nn.Linear (:170-176, :770-778, :973-977, :1155, :1197) ...
+        nb = b and c.norm_type == "layernorm"             # ... and on every LayerNorm (:130); RMSNorm has none
+        self.__dict__["_use_bias"] = b
+        self.embed = _GEmbed(V, c.max_position_embeddings, H)   # (Embed gets no bias: its norm / projection are never built, :1143-1152)
         if c.add_cross_attention is not None and c.project_encoder_hidden_states:      # (:1143: `is not None`, as written)
-            self.encoder_proj = _P(H, c.encoder_hidden_size)
-            self.encoder_proj_layer_norm = _P(H, ones=True)
+            self.encoder_proj = _P(H, c.encoder_hidden_size, bias=b)
+            self.encoder_proj_layer_norm = _P(H, ones=True, bias=nb)
             kv = H
-        self.transformer_layers = nn.ModuleList([_GLayer(H, I, kv, cross, bool(c.use_normformer)) for _ in range(c.num_hidden_layers)])
+        self.transformer_layers = nn.ModuleList([_GLayer(H, I, kv, cross, bool(c.use_normformer), b, nb)
+                                                 for _ in range(c.num_hidden_layers)])
         if c.use_encoder_layernorm:
-            self.encoder_layer_norm = _P(H, ones=True)
+            self.encoder_layer_norm = _P(H, ones=True, bias=nb)
         if c.use_mlm_layer:
-            self.mlm_layer = _GMlm(H, self.output_size, bool(c.use_mlm_layernorm))
+            self.mlm_layer = _GMlm(H, self.output_size, bool(c.use_mlm_layernorm), b, nb)
         else:
-            self.to_logits = _P(self.output_size, H)
+            self.to_logits = _P(self.output_size, H, bias=b)
         self.compute_dtype = torch.float32
         self._side_stream = None
         for name, p in self.named_parameters():      # reference :1203-1219
@@ -144,6 +152,8 @@ class GeneralMaskGitEngine(TapeOps):
         eps = float(self.config.layer_norm_eps)
         if mode == 1:
             y, mean, rstd = ops.layernorm_fwd(a, self._f(mod.weight), eps, torch.float32, residual=x)
+            if getattr(mod, "bias", None) is not None:
+                ops.add_rowvec_(y, self._f(mod.bias))
             return y, dict(a=a, mean=mean, rstd=rstd)
         n, _ = ops.norm_res_fwd(a, self._f(mod.weight), eps, 0)
         return x + n, dict(a=a)            # (RMSNorm + NormFormer: no shipped config; one ATen add)
@@ -151,6 +161,8 @@ class GeneralMaskGitEngine(TapeOps):
     def _post_norm_add_bwd(self, dy, sv, mod, name, G, mode):
         """-> d(a); d(x) = dy"""
         eps = float(self.config.layer_norm_eps)
+        if getattr(mod, "bias", None) is not None:
+            G[name + ".bias"] = ops.bias_grad(dy)
         if mode == 1:
             dw = torch.empty_like(self._f(mod.weight))
             da = ops.layernorm_bwd(dy, sv["a"], self._f(mod.weight), sv["mean"], sv["rstd"], torch.float32, dw, False)
@@ -228,7 +240,8 @@ class GeneralMaskGitEngine(TapeOps):
             n3, _ = self._norm(x1, lyr.ffn.pre_mlp_layer_norm, 1)                    # always a LayerNorm (:768-770)
             w01 = self._w2(lyr.ffn.wi_0, lyr.ffn.wi_1)
             bf_chain = self.compute_dtype == torch.bfloat16 and not nf and pd_h == 0.0
-            ab = ops.linear(self._c(n3), w01, out_dtype=torch.bfloat16) if bf_chain else self._mm(n3, w01)
+            b01 = self._b(lyr.ffn.wi_0, lyr.ffn.wi_1)
+            ab = ops.linear(self._c(n3), w01, out_dtype=torch.bfloat16, bias=b01) if bf_chain else self._mm(n3, w01, bias=b01)
             g = ops.glu_fwd(ab)                                                       # gelu(wi_0 x) * (wi_1 x)  (:789-792)
             gm = g
             if nf:
@@ -254,7 +267,8 @@ class GeneralMaskGitEngine(TapeOps):
         Vp = (V + 7) // 8 * 8
         w2 = self._w2(head)
         logits_p = torch.empty((B * S, Vp), dtype=torch.float32, device=dev)
-        ops.gemm(self._c(gl), w2, logits_p, B * S, V, H, lda=H, ldb=H, ldc=Vp)
+        gl_op, w2 = self._pair(gl, w2)
+        ops.gemm(gl_op, w2, logits_p, B * S, V, H, lda=H, ldb=H, ldc=Vp, bias=self._b(head))
         logits = logits_p.view(B, S, Vp) if Vp == V else logits_p[:, :V].contiguous().view(B, S, V)
         loss = None
         if labels is not None:
@@ -284,6 +298,8 @@ class GeneralMaskGitEngine(TapeOps):
         w2 = self._w2(head)
         dlc = self._c(dl)
         G[hname + ".weight"] = self._mm_dw(dlc, T["gl"], w2.shape, M=V, lda=Vp).view(head.weight.shape)
+        if self._use_bias:
+            G[hname + ".bias"] = ops.bias_grad(dl, cols=V)
         dgl = self._mm_dx(dlc, w2, lda=Vp)
         if c.use_mlm_layer:
             dgd = self._norm_bwd(dgl, T["gd"], self.mlm_layer.mlm_ln, "mlm_layer.mlm_ln", G, mode=mode) if c.use_mlm_layernorm else dgl
@@ -300,6 +316,8 @@ class GeneralMaskGitEngine(TapeOps):
             if sv["ab"].dtype == torch.bfloat16:      # bf16 GLU chain (no mid norm, no dropout): mirrors the forward
                 wo2, dxb = self._w2(lyr.ffn.wo), self._c(dx)
                 G[nm + ".ffn.wo.weight"] = self._mm_dw(dxb, sv["gm"], wo2.shape).view(lyr.ffn.wo.weight.shape)
+                if self._use_bias:
+                    G[nm + ".ffn.wo.bias"] = ops.bias_grad(dx)
                 dg = ops.linear_dgrad(dxb, wo2)
             else:
                 dgm = self._lin_bwd(dx, sv["gm"], lyr.ffn.wo, nm + ".ffn.wo", G)
@@ -310,6 +328,9 @@ class GeneralMaskGitEngine(TapeOps):
             gw01 = self._mm_dw(dab, sv["n3"], sv["w01"].shape)
             I = gw01.shape[0] // 2
             G[nm + ".ffn.wi_0.weight"], G[nm + ".ffn.wi_1.weight"] = gw01[:I], gw01[I:]
+            if self._use_bias:
+                gb01 = ops.bias_grad(dab)
+                G[nm + ".ffn.wi_0.bias"], G[nm + ".ffn.wi_1.bias"] = gb01[:I], gb01[I:]
             dn3 = self._mm_dx(dab, sv["w01"])
             dx1 = self._norm_bwd(dn3, sv["x1"], lyr.ffn.pre_mlp_layer_norm, nm + ".ffn.pre_mlp_layer_norm", G, mode=1, dpre=dx)
             if sv["s2"] is not None:

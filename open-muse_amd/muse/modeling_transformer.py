@@ -139,17 +139,17 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
         **kwargs,
     ):
         super().__init__()
-        if use_bias or use_conv_in_out:
-            raise NotImplementedError("MaskGitTransformer (MI355X build): use_bias / use_conv_in_out are not built (no configuration "
-                                      "of the reference sets them; ConvEmbed / ConvMlmLayer are only reachable through use_conv_in_out)")
+        if use_conv_in_out:
+            raise NotImplementedError("MaskGitTransformer (MI355X build): use_conv_in_out is not built (no configuration of the "
+                                      "reference sets it; ConvEmbed / ConvMlmLayer are only reachable through it)")
         if norm_type not in ("layernorm", "rmsnorm"):
             raise ValueError(f"norm_type must be 'layernorm' or 'rmsnorm', got {norm_type}")
         # (`embedding_size` is accepted and, as in the reference, unused: the constructor hands `hidden_size` to Embed for both widths,
         #  modeling_transformer.py:1143-1152)
         # the class-conditional NormFormer family (README example, configs/imagenet.yaml) runs on the flat-buffer engine below;
-        # everything else - text conditioning, RMSNorm, plain pre-LN layers, no MLM head - on the tape engine (maskgit_general.py)
+        # everything else - text conditioning, RMSNorm, plain pre-LN layers, no MLM head, biases - on the tape engine (maskgit_general.py)
         self._general = bool(add_cross_attention or project_encoder_hidden_states or norm_type != "layernorm" or not use_normformer
-                             or not use_encoder_layernorm or not use_mlm_layer or not use_mlm_layernorm)
+                             or not use_encoder_layernorm or not use_mlm_layer or not use_mlm_layernorm or use_bias)
         if hidden_size % num_attention_heads:
             raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {hidden_size} and"
                              f" `num_heads`: {num_attention_heads}).")

@@ -935,6 +935,29 @@ def colsum(part, out, accumulate=False):
     return out
 
 
+def add_rowvec_(x, b):
+    """x[r, :] += b, f32 in place (LayerNorm bias of a use_bias model)"""
+    require_gpu(x, b)
+    if x.dtype != torch.float32 or b.dtype != torch.float32 or not x.is_contiguous():
+        raise _hip.MuseHipError("add_rowvec_: contiguous f32 rows and an f32 vector")
+    check(lib().muse_add_rowvec(x.data_ptr(), b.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], stream()), "muse_add_rowvec")
+    return x
+
+
+def bias_grad(dy, cols=None):
+    """d(bias)[c] = sum_r dy[r, c] for the first `cols` columns of dy [rows, >= cols] (f32 or bf16, any row stride): two fixed-order
+    stages (per-chunk partial rows, then muse_colsum)"""
+    require_gpu(dy)
+    rows = dy.shape[0]
+    cols = dy.shape[1] if cols is None else cols
+    if dy.stride(1) != 1:
+        raise _hip.MuseHipError("bias_grad: unit column stride")
+    R = lib().muse_bias_grad_rows_per_block()
+    part = torch.empty(((rows + R - 1) // R, cols), dtype=torch.float32, device=dy.device)
+    check(lib().muse_bias_grad_partial(dy.data_ptr(), dt(dy), part.data_ptr(), rows, cols, dy.stride(0), stream()), "muse_bias_grad_partial")
+    return colsum(part, torch.empty(cols, dtype=torch.float32, device=dy.device))
+
+
 def norm_res_bwd(dy, v, w, eps, mode, dpre=None, want_dw=True, also_bf16=False):
     """backward of norm_res_fwd: returns (dv = dx = dres, dw or None[, bf16 copy of dv]).  v = the forward's pre-norm sum."""
     require_gpu(dy, v)

@@ -108,10 +108,18 @@ class TapeOps:
             return (a if a.dtype == torch.float32 else ops.cast_to_f32(a.contiguous())), w2
         return self._c(a), w2
 
-    def _mm(self, x, w2, residual=None):
-        """x w2^T (+ residual) -> f32"""
+    def _b(self, *mods):
+        """f32 bias of one Linear, or of several stacked along the output dim like their weights; None for a model without biases
+        (`use_bias=False`, every shipped configuration)"""
+        if not self.__dict__.get("_use_bias", False):
+            return None
+        bs = [self._f(m.bias) for m in mods]
+        return bs[0] if len(bs) == 1 else torch.cat(bs)
+
+    def _mm(self, x, w2, residual=None, bias=None):
+        """x w2^T (+ bias) (+ residual) -> f32"""
         xx, ww = self._pair(x, w2)
-        return ops.linear(xx, ww, out_dtype=torch.float32, residual=residual)
+        return ops.linear(xx, ww, out_dtype=torch.float32, residual=residual, bias=bias)
 
     def _mm_dx(self, dy, w2, lda=None, out=None, accumulate=False):
         """dy w2 -> f32 [rows, K] (optionally accumulated into `out`);  dy [rows, >= N] with row stride lda, w2 [N, K]"""
@@ -151,10 +159,12 @@ class TapeOps:
         return dw
 
     def _lin(self, x, mod, residual=None):
-        return self._mm(x, self._w2(mod), residual=residual)
+        return self._mm(x, self._w2(mod), residual=residual, bias=self._b(mod))
 
     def _lin_bwd(self, dy, x, mod, name, G, need_dx=True):
         w2 = self._w2(mod)
+        if self.__dict__.get("_use_bias", False):
+            G[name + ".bias"] = ops.bias_grad(dy)
         dyc = dy if w2.dtype == torch.float32 else self._c(dy)            # one cast feeds both the dW and the dX product
         G[name + ".weight"] = self._mm_dw(dyc, x, w2.shape).view(mod.weight.shape)
         return self._mm_dx(dyc, w2) if need_dx else None
@@ -162,12 +172,16 @@ class TapeOps:
     def _norm(self, x, mod, mode=0, residual=None, want_pre=False):
         y, pre = ops.norm_res_fwd(x, self._f(mod.weight), float(self.config.layer_norm_eps), mode, residual=residual,
                                   want_pre=want_pre)
+        if getattr(mod, "bias", None) is not None and self.__dict__.get("_use_bias", False):
+            ops.add_rowvec_(y, self._f(mod.bias))           # LayerNorm bias (reference :130-137; RMSNorm never has one)
         return y, pre
 
     def _norm_bwd(self, dy, v, mod, name, G, mode=0, dpre=None, gemm_operand=False):
         """v = the tensor that was normalised (x + residual); returns d(x) = d(residual).
         gemm_operand (bf16 mode): dv is also the dY of the next weight GEMMs - the kernel writes its bf16 copy in the same pass
         and _c(dv) finds it instead of launching a cast."""
+        if getattr(mod, "bias", None) is not None and self.__dict__.get("_use_bias", False):
+            G[name + ".bias"] = ops.bias_grad(dy)
         if gemm_operand and self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 2:
             dv, dw, dvb = ops.norm_res_bwd(dy, v, self._f(mod.weight), float(self.config.layer_norm_eps), mode, dpre=dpre, also_bf16=True)
             self.__dict__.setdefault("_act_cache", {})[id(dv)] = (dv, dvb)
@@ -191,15 +205,15 @@ class TapeOps:
             xb = self._c(x)                   # (already bf16 when it is an AdaLN output; cached otherwise)
             self_attn = ctx is x
             if self_attn:
-                qkv = ops.linear(xb, self._wb(att.query, att.key, att.value))            # [B*Sq, 3C] bf16
+                qkv = ops.linear(xb, self._wb(att.query, att.key, att.value), bias=self._b(att.query, att.key, att.value))  # [B*Sq, 3C] bf16
                 q, k, v, cb = qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], xb
             else:
                 cb = self._c(ctx)             # the text states feed every layer: one cast per step
-                q = ops.linear(xb, self._wb(att.query))
-                qkv = ops.linear(cb, self._wb(att.key, att.value))                      # [B*Skv, 2C] bf16
+                q = ops.linear(xb, self._wb(att.query), bias=self._b(att.query))
+                qkv = ops.linear(cb, self._wb(att.key, att.value), bias=self._b(att.key, att.value))   # [B*Skv, 2C] bf16
                 k, v = qkv[:, :Cq], qkv[:, Cq:]
             o, lse = ops.attention_fwd_ex(q, k, v, B, Sq, Skv, nh, hd, alpha)
-            y = ops.linear(o, self._wb(att.out), out_dtype=torch.float32, residual=residual)
+            y = ops.linear(o, self._wb(att.out), out_dtype=torch.float32, residual=residual, bias=self._b(att.out))
             return y, dict(fused=True, self_attn=self_attn, xb=xb, cb=cb, q=q, qkv=qkv, o=o, lse=lse,
                            dims=(B, Sq, Skv, nh, hd, Cq, alpha))
         q, k, v = self._lin(x, att.query), self._lin(ctx, att.key), self._lin(ctx, att.value)
@@ -239,6 +253,8 @@ class TapeOps:
         dctx = self._lin_bwd(dk, sv["ctx"], att.key, name + ".key", G)
         wv = self._w2(att.value)
         G[name + ".value.weight"] = self._mm_dw(dv, sv["ctx"], wv.shape)
+        if self.__dict__.get("_use_bias", False):
+            G[name + ".value.bias"] = ops.bias_grad(dv)
         # dctx += dv Wv ; for self attention query and context are the same tensor: everything lands in dx
         self._mm_dx(dv, wv, out=dctx, accumulate=True)
         if self_attn:
@@ -251,6 +267,9 @@ class TapeOps:
         dyb = self._c(dy)
         wo = self._wb(att.out)
         G[name + ".out.weight"] = self._mm_dw(dyb, sv["o"], att.out.weight.shape)
+        ub = self.__dict__.get("_use_bias", False)
+        if ub:
+            G[name + ".out.bias"] = ops.bias_grad(dy)
         do = ops.linear_dgrad(dyb, wo)                                                     # bf16 [B*Sq, C]
         q, qkv = sv["q"], sv["qkv"]
         if sv["self_attn"]:
@@ -262,6 +281,9 @@ class TapeOps:
                                  dv=dqkv[:, 2 * Cq:])
             gqkv = self._mm_dw(dqkv, sv["xb"], (3 * Cq, Cq))
             G[name + ".query.weight"], G[name + ".key.weight"], G[name + ".value.weight"] = gqkv[:Cq], gqkv[Cq:2 * Cq], gqkv[2 * Cq:]
+            if ub:
+                gb = ops.bias_grad(dqkv)
+                G[name + ".query.bias"], G[name + ".key.bias"], G[name + ".value.bias"] = gb[:Cq], gb[Cq:2 * Cq], gb[2 * Cq:]
             dx = torch.empty((B * Sq, Cq), dtype=torch.float32, device=dev)
             ops.linear_dgrad(dqkv, self._wb(att.query, att.key, att.value), out=dx)      # d(x) through q, k and v in one GEMM
             return dx, None
@@ -273,6 +295,9 @@ class TapeOps:
         Ck = att.key.weight.shape[1]
         gkv = self._mm_dw(dkv, sv["cb"], (2 * Cq, Ck))
         G[name + ".key.weight"], G[name + ".value.weight"] = gkv[:Cq], gkv[Cq:]
+        if ub:
+            gb = ops.bias_grad(dkv)
+            G[name + ".query.bias"], G[name + ".key.bias"], G[name + ".value.bias"] = ops.bias_grad(dq), gb[:Cq], gb[Cq:]
         dx = torch.empty((B * Sq, Cq), dtype=torch.float32, device=dev)
         ops.linear_dgrad(dq, self._wb(att.query), out=dx)
         dctx = torch.empty((B * Skv, Ck), dtype=torch.float32, device=dev)

@@ -30,9 +30,16 @@ SD = Dict[str, Tensor]
 # ----------------------------------------------------------------------------------------------
 # MaskGitTransformer  (muse/modeling_transformer.py)
 # ----------------------------------------------------------------------------------------------
-def _ln(x: Tensor, w: Tensor, eps: float) -> Tensor:
-    # weight-only LayerNorm: muse/modeling_transformer.py:124-137
-    return F.layer_norm(x, (x.shape[-1],), w, None, eps)
+def _ln(x: Tensor, w: Tensor, eps: float, b: Optional[Tensor] = None) -> Tensor:
+    # LayerNorm, weight-only unless use_bias: muse/modeling_transformer.py:124-137
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def _linear(x: Tensor, sd: SD, name: str) -> Tensor:
+    """nn.Linear `name` of the state dict: x W^T (+ bias when the model was built with use_bias, muse/modeling_transformer.py:170-176)"""
+    y = x @ sd[name + ".weight"].t()
+    b = sd.get(name + ".bias")
+    return y if b is None else y + b
 
 
 def _drop(t: Tensor, keep: Optional[Tensor], p: float) -> Tensor:
@@ -44,13 +51,13 @@ def attention(x: Tensor, sd: SD, prefix: str, num_heads: int, keep: Optional[Ten
     """Full-visibility self attention.  muse/modeling_transformer.py:190-241 (non-xformers branch).
 
     scores = (q k^T) * (1/sqrt(hd)) via baddbmm alpha (:226-231), softmax over keys (:236), P@V (:238),
-    heads re-assembled side by side (:240), then the bias-free ``out`` projection (:218).
+    heads re-assembled side by side (:240), then the ``out`` projection (:218).
     """
     B, S, H = x.shape
     hd = H // num_heads
-    q = x @ sd[prefix + "query.weight"].t()
-    k = x @ sd[prefix + "key.weight"].t()
-    v = x @ sd[prefix + "value.weight"].t()
+    q = _linear(x, sd, prefix + "query")
+    k = _linear(x, sd, prefix + "key")
+    v = _linear(x, sd, prefix + "value")
     q = q.view(B, S, num_heads, hd).transpose(1, 2)
     k = k.view(B, S, num_heads, hd).transpose(1, 2)
     v = v.view(B, S, num_heads, hd).transpose(1, 2)
@@ -59,7 +66,7 @@ def attention(x: Tensor, sd: SD, prefix: str, num_heads: int, keep: Optional[Ten
     scores = torch.matmul(q, k.transpose(-1, -2)) * alpha
     probs = _drop(torch.softmax(scores, dim=-1), keep, p)                     # self.dropout(attn_weights) :237
     ctx = torch.matmul(probs, v).transpose(1, 2).reshape(B, S, H)
-    return ctx @ sd[prefix + "out.weight"].t()
+    return _linear(ctx, sd, prefix + "out")
 
 
 def feed_forward(x: Tensor, sd: SD, prefix: str, eps: float, keep: Optional[Tensor] = None, p: float = 0.0) -> Tensor:
@@ -350,9 +357,10 @@ def _rms(x: Tensor, w: Tensor, eps: float) -> Tensor:
     return x * torch.rsqrt(variance + eps) * w
 
 
-def _norm_by_type(x: Tensor, w: Tensor, eps: float, cfg: dict) -> Tensor:
-    # norm_cls of muse/modeling_transformer.py:1128, :833, :775, :973
-    return _ln(x, w, eps) if cfg.get("norm_type", "layernorm") == "layernorm" else _rms(x, w, eps)
+def _norm_by_type(x: Tensor, sd: SD, name: str, eps: float, cfg: dict) -> Tensor:
+    # norm_cls of muse/modeling_transformer.py:1128, :833, :775, :973: LayerNorm (with a bias under use_bias) or RMSNorm (never one)
+    w = sd[name + ".weight"]
+    return _ln(x, w, eps, sd.get(name + ".bias")) if cfg.get("norm_type", "layernorm") == "layernorm" else _rms(x, w, eps)
 
 
 def cross_attention(x: Tensor, ctx: Tensor, sd: SD, prefix: str, num_heads: int) -> Tensor:
@@ -361,18 +369,19 @@ def cross_attention(x: Tensor, ctx: Tensor, sd: SD, prefix: str, num_heads: int)
     B, S, H = x.shape
     L = ctx.shape[1]
     hd = H // num_heads
-    q = (x @ sd[prefix + "query.weight"].t()).view(B, S, num_heads, hd).transpose(1, 2)
-    k = (ctx @ sd[prefix + "key.weight"].t()).view(B, L, num_heads, hd).transpose(1, 2)
-    v = (ctx @ sd[prefix + "value.weight"].t()).view(B, L, num_heads, hd).transpose(1, 2)
+    q = _linear(x, sd, prefix + "query").view(B, S, num_heads, hd).transpose(1, 2)
+    k = _linear(ctx, sd, prefix + "key").view(B, L, num_heads, hd).transpose(1, 2)
+    v = _linear(ctx, sd, prefix + "value").view(B, L, num_heads, hd).transpose(1, 2)
     alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
     probs = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * alpha, dim=-1)
     out = torch.matmul(probs, v).transpose(1, 2).reshape(B, S, H)
-    return out @ sd[prefix + "out.weight"].t()
+    return _linear(out, sd, prefix + "out")
 
 
 def transformer_forward_general(sd: SD, cfg: dict, input_ids: Tensor, encoder_hidden_states: Optional[Tensor] = None,
                                 labels: Optional[Tensor] = None, label_smoothing: float = 0.0, cond_keep: Optional[Tensor] = None):
-    """MaskGitTransformer.forward for every configuration the constructor accepts without biases / conv embeddings
+    """MaskGitTransformer.forward for every configuration the constructor accepts without conv embeddings (use_bias: every
+    nn.Linear and every LayerNorm carries a bias, :130, :170-176, :770-778, :973-977, :1155; RMSNorm never does)
     (muse/modeling_transformer.py:1224-1281; layer :875-904; feed-forward :785-799; MLM head :979-985).
     cond_keep [B] bool = the mask prob_mask_like draws for condition dropout (:1243-1247), applied AFTER the projection."""
     eps = float(cfg.get("layer_norm_eps", 1e-5))
@@ -382,34 +391,34 @@ def transformer_forward_general(sd: SD, cfg: dict, input_ids: Tensor, encoder_hi
     x = sd["embed.word_embeddings.weight"][input_ids] + sd["embed.position_embeddings.weight"][:S][None]
     enc = encoder_hidden_states
     if enc is not None and cfg.get("project_encoder_hidden_states", False):
-        enc = _norm_by_type(enc @ sd["encoder_proj.weight"].t(), sd["encoder_proj_layer_norm.weight"], eps, cfg)     # :1239-1241
+        enc = _norm_by_type(_linear(enc, sd, "encoder_proj"), sd, "encoder_proj_layer_norm", eps, cfg)                # :1239-1241
     if enc is not None and cond_keep is not None:
         enc = enc * cond_keep.view(-1, 1, 1).to(enc.dtype)                                                            # :1243-1247
     for i in range(L):
         p = f"transformer_layers.{i}."
-        a = attention(_norm_by_type(x, sd[p + "attn_layer_norm.weight"], eps, cfg), sd, p + "attention.", nh)
+        a = attention(_norm_by_type(x, sd, p + "attn_layer_norm", eps, cfg), sd, p + "attention.", nh)
         if nf:
-            a = _norm_by_type(a, sd[p + "post_attn_layer_norm.weight"], eps, cfg)
+            a = _norm_by_type(a, sd, p + "post_attn_layer_norm", eps, cfg)
         x = x + a
         if enc is not None and (p + "crossattention.query.weight") in sd:
-            a = cross_attention(_norm_by_type(x, sd[p + "crossattn_layer_norm.weight"], eps, cfg), enc, sd, p + "crossattention.", nh)
+            a = cross_attention(_norm_by_type(x, sd, p + "crossattn_layer_norm", eps, cfg), enc, sd, p + "crossattention.", nh)
             if nf:
-                a = _norm_by_type(a, sd[p + "post_crossattn_layer_norm.weight"], eps, cfg)
+                a = _norm_by_type(a, sd, p + "post_crossattn_layer_norm", eps, cfg)
             x = x + a
-        h = _ln(x, sd[p + "ffn.pre_mlp_layer_norm.weight"], eps)            # always a LayerNorm (:768-770)
-        h = F.gelu(h @ sd[p + "ffn.wi_0.weight"].t()) * (h @ sd[p + "ffn.wi_1.weight"].t())
+        h = _ln(x, sd[p + "ffn.pre_mlp_layer_norm.weight"], eps, sd.get(p + "ffn.pre_mlp_layer_norm.bias"))   # always a LayerNorm (:768-770)
+        h = F.gelu(_linear(h, sd, p + "ffn.wi_0")) * _linear(h, sd, p + "ffn.wi_1")
         if nf:
-            h = _norm_by_type(h, sd[p + "ffn.mid_mlp_layer_norm.weight"], eps, cfg)
-        x = x + h @ sd[p + "ffn.wo.weight"].t()
+            h = _norm_by_type(h, sd, p + "ffn.mid_mlp_layer_norm", eps, cfg)
+        x = x + _linear(h, sd, p + "ffn.wo")
     if cfg.get("use_encoder_layernorm", True):
-        x = _norm_by_type(x, sd["encoder_layer_norm.weight"], eps, cfg)
+        x = _norm_by_type(x, sd, "encoder_layer_norm", eps, cfg)
     if cfg.get("use_mlm_layer", True):
-        h = F.gelu(x @ sd["mlm_layer.mlm_dense.weight"].t())
+        h = F.gelu(_linear(x, sd, "mlm_layer.mlm_dense"))
         if cfg.get("use_mlm_layernorm", True):
-            h = _norm_by_type(h, sd["mlm_layer.mlm_ln.weight"], eps, cfg)
-        logits = h @ sd["mlm_layer.to_logits.weight"].t()
+            h = _norm_by_type(h, sd, "mlm_layer.mlm_ln", eps, cfg)
+        logits = _linear(h, sd, "mlm_layer.to_logits")
     else:
-        logits = x @ sd["to_logits.weight"].t()
+        logits = _linear(x, sd, "to_logits")
     if labels is None:
         return logits
     V = logits.shape[-1]

@@ -583,6 +583,11 @@ def golden_mask_muse(name, seed, batch=6, seq=16, mask_id=47, codebook_size=32):
 
 
 if __name__ == "__main__":
+    if "--bias" in sys.argv:
+        # use_bias=True (a bias on every nn.Linear and LayerNorm; no shipped config sets it, the constructor accepts it)
+        golden_transformer_text("transformer_text_bias_tiny", W.TRANSFORMER_TEXT_BIAS_TINY, batch=2, text_len=5, seed=869)
+        golden_transformer_text("transformer_rms_bias_tiny", W.TRANSFORMER_RMS_BIAS_TINY, batch=3, text_len=6, seed=870)
+        sys.exit(0)
     if "--skip-full" not in sys.argv and "--bs64" not in sys.argv:   # the benched geometries (about two minutes on one thread)
         golden_vqgan_full("vqgan_f16_full", W.VQGAN_F16, seed=600)
         golden_transformer_full("transformer_b_full", W.TRANSFORMER_B, batch=2, seed=510)
@@ -615,6 +620,8 @@ if __name__ == "__main__":
     golden_transformer_text("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY, batch=3, text_len=7, seed=800)
     golden_transformer_text("transformer_text_proj_tiny", W.TRANSFORMER_TEXT_PROJ_TINY, batch=2, text_len=5, seed=810)
     golden_transformer_text("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY, batch=2, text_len=0, seed=820)
+    golden_transformer_text("transformer_text_bias_tiny", W.TRANSFORMER_TEXT_BIAS_TINY, batch=2, text_len=5, seed=869)
+    golden_transformer_text("transformer_rms_bias_tiny", W.TRANSFORMER_RMS_BIAS_TINY, batch=3, text_len=6, seed=870)
     golden_generate2_text("generate2_text_tiny", W.TRANSFORMER_TEXT_TINY, batch=2, text_len=7, seed=830, timesteps=5, temperature=3.0,
                           guidance_scale=2.5)
     if "--skip-full" not in sys.argv:

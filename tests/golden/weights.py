@@ -41,6 +41,20 @@ TRANSFORMER_PLAIN_TINY = dict(
     max_position_embeddings=20, codebook_size=32, num_vq_tokens=16, num_classes=10, norm_type="rmsnorm", use_normformer=True,
     use_encoder_layernorm=False, use_mlm_layer=False, hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-6,
 )
+# use_bias=True: biases on every Linear and LayerNorm - once with LayerNorm + NormFormer + projected text states + the full MLM head,
+# once with RMSNorm (no norm bias except the feed-forward's always-LayerNorm pre norm) and a bare to_logits head
+TRANSFORMER_TEXT_BIAS_TINY = dict(
+    vocab_size=40, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=48,
+    max_position_embeddings=12, codebook_size=32, num_vq_tokens=12, add_cross_attention=True, encoder_hidden_size=24,
+    project_encoder_hidden_states=True, norm_type="layernorm", use_normformer=True, use_bias=True,
+    hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-5,
+)
+TRANSFORMER_RMS_BIAS_TINY = dict(
+    vocab_size=48, hidden_size=32, num_hidden_layers=2, num_attention_heads=4, intermediate_size=64,
+    max_position_embeddings=16, codebook_size=32, num_vq_tokens=16, add_cross_attention=True, encoder_hidden_size=24,
+    project_encoder_hidden_states=False, norm_type="rmsnorm", use_normformer=False, use_mlm_layer=False, use_bias=True,
+    use_codebook_size_for_output=True, hidden_dropout=0.0, attention_dropout=0.0, layer_norm_eps=1e-6,
+)
 # configs/cc12m.yaml:28-50 `model.transformer` with 2 of its 24 layers (T5-large states of width 1024, 77 tokens in the tests)
 TRANSFORMER_CC12M_2L = dict(
     vocab_size=8256, max_position_embeddings=256, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16,
@@ -138,6 +152,15 @@ def transformer_shapes(cfg: dict) -> dict:
         s["mlm_layer.to_logits.weight"] = (out, H)
     else:
         s["to_logits.weight"] = (out, H)
+    if cfg.get("use_bias", False):
+        # every nn.Linear and every LayerNorm gets a bias (muse/modeling_transformer.py:130, :170-176, :770-778, :973-977, :1155);
+        # RMSNorm has none, and the feed-forward's pre_mlp_layer_norm is a LayerNorm whatever norm_type says (:768-770)
+        ln = cfg.get("norm_type", "layernorm") == "layernorm"
+        for k, shp in list(s.items()):
+            if k.startswith("embed."):
+                continue
+            if len(shp) == 2 or ln or "pre_mlp_layer_norm" in k:
+                s[k[:-len("weight")] + "bias"] = (shp[0],)
     return s
 
 

@@ -835,3 +835,25 @@ def test_ffn_mid_fused(dtype, rows, inter):
         assert torch.equal(dab0, dab) and torch.equal(dw0, dw)
     else:                         # f32: without the store the compiler fuses g * b - mean into one fma: last-bit differences
         assert rel_err(dab0, dab) < 1e-5 and rel_err(dw0, dw) < 1e-5
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(1, 8, 8), (130, 40, 48), (16448, 768, 768), (4112, 2304, 2304), (257, 33, 40)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_grad_and_add_rowvec(rows, cols, ld, dtype):
+    """the two kernels behind `use_bias` (muse/modeling_transformer.py:130, :170-176): d(bias) = sum over rows (two fixed-order
+    stages; f32 and bf16 dy, padded row stride, ragged last chunk) and the in-place LayerNorm bias add.  f32 sums of <= 16448 terms
+    against float64: 1e-5 relative to the largest column sum of |dy|."""
+    ops = _ops()
+    dy = rnd((rows, ld), 77 + rows, 1.0).to(dtype)
+    d = dy.to(DEV)
+    got = ops.bias_grad(d, cols=cols)
+    ref = dy.double()[:, :cols].sum(0)
+    scale = float(dy.double()[:, :cols].abs().sum(0).max())
+    assert got.dtype == torch.float32 and got.shape == (cols,)
+    assert float((got.double().cpu() - ref).abs().max()) <= 1e-5 * scale
+    assert torch.equal(got, ops.bias_grad(d, cols=cols))                      # fixed summation order
+    if dtype == torch.float32 and ld == cols:
+        b = rnd((cols,), 5)
+        x = dy.clone().to(DEV)
+        ops.add_rowvec_(x, b.to(DEV))
+        assert torch.equal(x.cpu(), dy + b)                                  # one f32 add per element: exact

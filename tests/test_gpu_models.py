@@ -247,7 +247,9 @@ def _build_general(cfg, seed, cd):
 
 @pytest.mark.parametrize("name,cfg", [("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY),
                                       ("transformer_text_proj_tiny", W.TRANSFORMER_TEXT_PROJ_TINY),
-                                      ("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY)])
+                                      ("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY),
+                                      ("transformer_text_bias_tiny", W.TRANSFORMER_TEXT_BIAS_TINY),      # use_bias=True
+                                      ("transformer_rms_bias_tiny", W.TRANSFORMER_RMS_BIAS_TINY)])
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
 def test_transformer_general_vs_reference_golden(golden_dir, name, cfg, cd):
     """the general form of muse.MaskGitTransformer (muse/maskgit_general.py: cross attention to text states, RMSNorm, plain pre-LN
@@ -276,6 +278,12 @@ def test_transformer_general_vs_reference_golden(golden_dir, name, cfg, cd):
     worst = 0.0
     for k, p in m.named_parameters():
         assert p.grad is not None, k
+        if k.endswith(".key.bias"):
+            # zero in exact arithmetic (a key bias shifts all scores of a query row alike; softmax does not see it): round-off on
+            # both sides, bounded against the value bias next to it
+            floor = (1e-5 if f32 else 2e-2) * float(np.abs(g["grad." + k.replace(".key.", ".value.")]).max())
+            assert float(p.grad.abs().max()) <= floor and float(np.abs(g["grad." + k]).max()) <= floor, k
+            continue
         e = maxrel(p.grad, torch.from_numpy(g["grad." + k]))
         worst = max(worst, e)
         assert e < (1e-3 if f32 else 1.2e-1), (k, e)
@@ -291,6 +299,31 @@ def test_transformer_general_vs_reference_golden(golden_dir, name, cfg, cd):
             if f.startswith("cd_grad."):
                 assert maxrel(params[f[8:]].grad, torch.from_numpy(g[f])) < (1e-3 if f32 else 1.2e-1), f
     print(name, cd, "worst parameter-gradient error", f"{worst:.2e}")
+
+
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_biased_transformer_trains(cd):
+    """a `use_bias=True` model under muse.FusedAdamW: every bias (zero-initialised, like the reference's, :1203-1219) receives a
+    gradient, moves, and the loss on a repeated batch falls"""
+    import muse
+    cfg = W.TRANSFORMER_TEXT_BIAS_TINY
+    torch.manual_seed(3)
+    m = muse.MaskGitTransformer(**cfg).to(DEV).train().set_compute_dtype(cd)
+    biases = {k: p for k, p in m.named_parameters() if k.endswith(".bias")}
+    assert len(biases) == 40 and all(float(p.abs().max()) == 0.0 for p in biases.values())
+    ids, labels, enc = W.transformer_text_inputs(cfg, 4, 5, 11)
+    opt = muse.FusedAdamW(m.parameters(), lr=3e-3, weight_decay=0.0)
+    losses = []
+    for _ in range(8):
+        _, loss = m(input_ids=ids.to(DEV), encoder_hidden_states=enc.to(DEV), labels=labels.to(DEV))
+        loss.backward()
+        assert all(p.grad is not None for p in biases.values())
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 0.2, losses
+    moved = [k for k, p in biases.items() if float(p.abs().max()) > 0.0]
+    assert len(moved) == len(biases), sorted(set(biases) - set(moved))
 
 
 def test_transformer_text_cc12m_width_vs_reference_golden(golden_dir):

@@ -34,7 +34,9 @@ def test_transformer_forward_backward(golden_dir, name, cfg):
 
 @pytest.mark.parametrize("name,cfg", [("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY),
                                       ("transformer_text_proj_tiny", W.TRANSFORMER_TEXT_PROJ_TINY),
-                                      ("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY)])
+                                      ("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY),
+                                      ("transformer_text_bias_tiny", W.TRANSFORMER_TEXT_BIAS_TINY),      # use_bias=True
+                                      ("transformer_rms_bias_tiny", W.TRANSFORMER_RMS_BIAS_TINY)])
 def test_transformer_general_forward_backward(golden_dir, name, cfg):
     """the general form of MaskGitTransformer (oracle.transformer_forward_general: cross attention to text states, RMSNorm, plain
     pre-LN layers, projected text states, optional final norm / MLM head) against the REAL reference: logits, loss, every parameter
@@ -52,6 +54,12 @@ def test_transformer_general_forward_backward(golden_dir, name, cfg):
     assert set("grad." + k for k in grads) == set(f for f in g.files if f.startswith("grad."))
     for k, v in grads.items():
         ref = g["grad." + k]
+        if k.endswith(".key.bias"):
+            # exactly zero in exact arithmetic (a key bias shifts every score of a query row by the same q.b: softmax does not see
+            # it); both sides hold round-off only, measured against the value bias next to it
+            floor = 1e-5 * float(np.abs(g["grad." + k.replace(".key.", ".value.")]).max())
+            assert float(np.abs(ref).max()) <= floor and float(np.abs(v.numpy()).max()) <= floor, k
+            continue
         assert float(np.abs(v.numpy() - ref).max()) <= 2e-5 * max(float(np.abs(ref).max()), 1e-8) + 1e-9, k
     if enc is not None:
         assert float(np.abs(genc.numpy() - g["grad_enc"]).max()) <= 2e-5 * float(np.abs(g["grad_enc"]).max())

@@ -113,8 +113,6 @@ def test_no_cpu_fallback():
 def test_unsupported_configs_fail_loudly():
     import muse
     with pytest.raises(NotImplementedError):
-        muse.MaskGitTransformer(vocab_size=48, hidden_size=32, num_attention_heads=2, use_bias=True)
-    with pytest.raises(NotImplementedError):
         muse.MaskGitTransformer(vocab_size=48, hidden_size=32, num_attention_heads=2, use_conv_in_out=True)
     with pytest.raises(ValueError):
         muse.MaskGitTransformer(vocab_size=48, hidden_size=30, num_attention_heads=4)
@@ -126,6 +124,8 @@ def test_unsupported_configs_fail_loudly():
 @pytest.mark.parametrize("name,cfg", [("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY),
                                       ("transformer_text_proj_tiny", W.TRANSFORMER_TEXT_PROJ_TINY),
                                       ("transformer_plain_tiny", W.TRANSFORMER_PLAIN_TINY),
+                                      ("transformer_text_bias_tiny", W.TRANSFORMER_TEXT_BIAS_TINY),
+                                      ("transformer_rms_bias_tiny", W.TRANSFORMER_RMS_BIAS_TINY),
                                       ("transformer_cc12m_2l", W.TRANSFORMER_CC12M_2L)])
 def test_general_transformer_surface_and_roundtrip(golden_dir, tmp_path, name, cfg):
     """the general form of muse.MaskGitTransformer (text conditioning / RMSNorm / plain pre-LN layers): parameter names and shapes
