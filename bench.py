@@ -59,7 +59,7 @@ UVIT_CC12M = dict(
 TRAFFIC_JSON = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_traffic.json", "r02_traffic.json")) if os.path.exists(f)),
                     os.path.join(ROOT, "profiles", "r03_traffic.json"))
 # rocprof kernel name fragment of each instrumented kernel family (to look its counters up in TRAFFIC_JSON)
-KERNEL_OF = {"conv_bf16x3_dma": "cslab::conv_slab_kernel", "gemm_bf16_NN": "g256p::kernel<unsigned short, 0, 0", "gemm_bf16_NT": "g256p::kernel<unsigned short, 0, 1",
+KERNEL_OF = {"conv_bf16x3_dma": "cslab::conv_slab_kernel<true>", "gemm_bf16_NN": "g256p::kernel<unsigned short, 0, 0", "gemm_bf16_NT": "g256p::kernel<unsigned short, 0, 1",
              "gemm_bf16_TT": "g256::kernel<float, 1, 1", "conv_bf16x3": "conv_split_kernel", "attn_fwd_bf16": "attn_fwd_kernel"}
 
 

@@ -290,6 +290,19 @@ int muse_groupnorm_silu_nhwc(const void* x, void* y, int32_t dtype, const float*
                              double* partial, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps,
                              int32_t apply_silu, void* stream);
 int muse_groupnorm_nchunk(int32_t HW);
+/* GroupNorm(groups) + SiLU of the INPUT fused into the 3x3 bf16x3 convolution (muse/modeling_maskgit_vqgan.py:73-80 norm1 -> swish
+ * -> conv1, norm2 -> swish -> conv2; :186-189 norm_out -> swish -> conv_out): `x` is the f32 NHWC activation, gn_scale / gn_shift
+ * [batch][Cin] f32 the affine form of its normalisation (muse_groupnorm_scale_shift: rstd * gamma, beta - rstd * gamma * mean from
+ * the [B, nchunk, groups, 2] f64 partial sums a producer's epilogue left).  The kernel normalises, activates and splits the
+ * activation into the hi / lo bf16 operands while it stages them in LDS: bit-identical to muse_groupnorm_silu_nhwc_split followed
+ * by muse_conv2d_nhwc_split2, without the write and re-read of the two planes.  Shapes: muse_conv2d_nhwc_gn_split2_ok (3x3, H and W
+ * multiples of 16, Cin a multiple of 64); others return MUSE_ERR_UNSUPPORTED.  bias / residual / gn_partial as for _split2. */
+int muse_conv2d_nhwc_gn_split2_ok(int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS);
+int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale, const float* gn_shift, const void* w_hi, const void* w_lo,
+                               const float* bias, const float* residual, float* out, double* gn_partial, int32_t gn_groups,
+                               int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, void* stream);
+int muse_groupnorm_scale_shift(const double* partial, int32_t nchunk, const float* gamma, const float* beta, float* scale,
+                               float* shift, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps, void* stream);
 /* f32 in; output as y_hi = bf16(y), y_lo = bf16(y - y_hi) (two [B, HW, C] bf16 planes) for muse_conv2d_nhwc_split2.
  * stats_nchunk == 0: statistics computed here into `partial`; > 0: `partial` = [B, stats_nchunk, G, 2] already filled. */
 int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta,

@@ -22,6 +22,11 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){lo, hi}, bf16x2_));
 }
 
+// SiLU behind a GroupNorm: the ONE expression the GroupNorm kernels (vqgan.hip) and the convolution that applies the norm itself
+// (conv_dma.hip) share, so both routes produce the same bits.  Hardware reciprocal (v_rcp_f32, 1 ulp): the correctly rounded division
+// is eleven VALU instructions per element, which the fused convolution could not hide under its MFMAs.
+__device__ __forceinline__ float gn_silu(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
+
 // bf16x3 operand split of 4 floats: hi = bf16(x), lo = bf16(x - hi)  (conv_split.hip / conv_dma.hip / GroupNorm split output)
 __device__ __forceinline__ void split4(const u32x4& v, u32x2& hi, u32x2& lo) {
   const float x0 = __uint_as_float(v[0]), x1 = __uint_as_float(v[1]), x2 = __uint_as_float(v[2]), x3 = __uint_as_float(v[3]);

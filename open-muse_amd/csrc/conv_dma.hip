@@ -32,6 +32,9 @@ struct Params {
   double* gn_partial;  // optional: per (image, 256-pixel tile, group) sum / sum-of-squares of the output, for the next GroupNorm
   int gn_cpg, gn_groups;
   int M, N, K, H, W, Cin;
+  // conv_slab_kernel<true>: the f32 activation and the GroupNorm scale / shift [batch][Cin] applied (with SiLU and the hi / lo
+  // split) while the slab is staged; xh / xl are unused then
+  const float *xf, *gsc, *gsh;
 };
 
 __device__ __forceinline__ int sw4(int q) { return (4 - q) & 3; }
@@ -323,6 +326,13 @@ __device__ long* g_conv_ts = nullptr;
 #define CDMA_TS(IDX)
 #define CDMA_TSV(V, IDX)
 #endif
+// GN = true: GroupNorm + SiLU + the bf16x3 split of the INPUT happen here (muse/modeling_maskgit_vqgan.py:73-80: norm -> swish ->
+// conv).  The slab thirds are loaded as f32 into registers (same two vector-memory operations per third as the two plane DMAs,
+// so the counted waits keep their meaning; issued in taps 0 / 2 / 4 instead of 0 / 1 / 2), transformed two taps later - the
+// top-of-tap wait of tap s+2 leaves only tap s+1's operations outstanding - with the arithmetic of gn_apply_split8_kernel
+// (vqgan.hip; same bits) spread over that tap's MFMA slots, and written to the slab buffer in the layout the plane DMA produces.
+// Saves the write and the re-read of both planes (8 of the 12 bytes per element the unfused pair moves) and a launch.
+template <bool GN>
 __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   CDMA_TS(0)
@@ -340,13 +350,14 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
 
   // ---- slab DMA: 21 pieces of 1 KiB per plane; wave w issues pieces w, w+8, w+16 of both planes (a piece index past 20
   //      repeats the wave's previous piece: same bytes to the same place, keeps the per-wave DMA count uniform) ----
-  const unsigned bytesA = (unsigned)((long)p.M * Cin * 2);
-  const rsrc_t rs_xh = make_rsrc(p.xh, bytesA), rs_xl = make_rsrc(p.xl, bytesA);
+  constexpr int XE = GN ? 4 : 2;             // bytes per activation element in global memory
+  const unsigned bytesA = (unsigned)((long)p.M * Cin * XE);
+  const rsrc_t rs_xh = make_rsrc(GN ? (const void*)p.xf : (const void*)p.xh, bytesA), rs_xl = make_rsrc(GN ? (const void*)p.xf : (const void*)p.xl, bytesA);
   const unsigned oobA = (bytesA + 15u) & ~15u;
   unsigned slab_off[3];
   int slab_piece[3];
+  const int srcchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
   {
-    const int srcchunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       int piece = wave + 8 * k;
@@ -355,9 +366,52 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
       const int r = piece * 16 + (lane >> 2), sy = r / 18, sx = r - sy * 18;
       const int y = y0 - 1 + sy, x = x0 - 1 + sx;
       const bool ok = r < 324 && y >= 0 && y < H && x >= 0 && x < W;
-      slab_off[k] = ok ? (unsigned)((((long)img * H + y) * W + x) * Cin * 2 + srcchunk * 16) : oobA;
+      slab_off[k] = ok ? (unsigned)(((((long)img * H + y) * W + x) * Cin + srcchunk * 8) * XE) : oobA;
     }
   }
+  // GN: the image's scale / shift behind the tile's LDS map, [2][Cin] f32
+  float* const gss = (float*)(smem + LDS_BYTES);
+  if constexpr (GN) {
+    for (int c = threadIdx.x; c < Cin; c += NT) { gss[c] = p.gsc[(long)img * Cin + c]; gss[Cin + c] = p.gsh[(long)img * Cin + c]; }
+    __syncthreads();
+  }
+  u32x4 xr[2];                  // GN: the slab third in flight / being transformed (one at a time inside the K loop)
+  float scv[4], shv[4];
+  // third `k` of the slab of channel chunk `chunk`, f32, into registers (zero outside the image / past the last chunk)
+  auto issue_slab_f = [&](u32x4 (&r)[2], int k, int chunk) {
+    const unsigned vo = chunk * 32 < Cin ? slab_off[k] : oobA;
+    r[0] = buf_load16(rs_xh, vo, (unsigned)(chunk * 128));
+    r[1] = buf_load16(rs_xh, vo + 16u, (unsigned)(chunk * 128));
+  };
+  // half `h` (four channels) of this lane's eight channels of chunk `chunk`
+  auto load_gss = [&](int chunk, int h) {
+    const float* q = gss + chunk * 32 + srcchunk * 8 + h * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { scv[j] = q[j]; shv[j] = q[Cin + j]; }
+  };
+  // element e (0..7) of a third: GroupNorm affine + SiLU, exactly gn_apply_split8_kernel's expression; in place
+  auto xform_elem = [&](u32x4 (&r)[2], int e) {
+    float t = fmaf(__uint_as_float(r[e >> 2][e & 3]), scv[e & 3], shv[e & 3]);
+    t = gn_silu(t);
+    asm volatile("" : "+v"(t));   // the ROUNDED product is what gets split: no contraction of (x * r) - hi into one fma
+    r[e >> 2][e & 3] = __float_as_uint(t);
+  };
+  // hi / lo split of third k and its two 16-byte LDS writes (where the plane DMA would have put them); zero padding stays zero
+  auto store_slab_f = [&](u32x4 (&r)[2], int buf, int k) {
+    u32x4 hi4, lo4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x2 hi, lo;
+      split4(r[h], hi, lo);
+      hi4[2 * h] = hi[0]; hi4[2 * h + 1] = hi[1];
+      lo4[2 * h] = lo[0]; lo4[2 * h + 1] = lo[1];
+    }
+    if (slab_off[k] == oobA) { hi4 = u32x4{0u, 0u, 0u, 0u}; lo4 = hi4; }
+    unsigned char* dst = smem + buf * SLAB + slab_piece[k] * 1024 + lane * 16;
+    *(u32x4*)dst = hi4;
+    *(u32x4*)(dst + PLANE) = lo4;
+  };
+
   // third `k` of the slab of channel chunk `chunk` into buffer `buf`
   auto issue_slab = [&](int buf, int k, int chunk) {
     const unsigned vo = chunk * 32 < Cin ? slab_off[k] : oobA;
@@ -452,22 +506,42 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
   // the weights of tap T+3.
 #ifndef CDMA_ABLATE_NO_DMA
 #define SLAB_ISSUE(T, Q)                                                                          \
-  if constexpr ((Q) == 0 && ((T) % 9) < 3) issue_slab(1 - (T) / 9, (T) % 9, chunk0 + (T) / 9 + 1);  \
+  if constexpr (!GN && (Q) == 0 && ((T) % 9) < 3) issue_slab(1 - (T) / 9, (T) % 9, chunk0 + (T) / 9 + 1);  \
+  if constexpr (GN && (Q) == 0 && ((T) % 9) == 0) issue_slab_f(xr, 0, chunk0 + (T) / 9 + 1);           \
+  if constexpr (GN && (Q) == 12 && (((T) % 9) == 2 || ((T) % 9) == 4)) issue_slab_f(xr, ((T) % 9) / 2, chunk0 + (T) / 9 + 1);  \
   if constexpr ((Q) == 2) issue_b(((T) + 3) % 3, chunk0 + ((T) + 3) / 9, ((T) + 3) % 9);
+// GN: one register set: third 0 is issued at the top of tap 0, thirds 1 / 2 at slot 12 of taps 2 / 4 (once the previous third has
+// left the registers); third k is transformed in tap 2k + 2: scale / shift halves at slots 1 / 6, one element per slot 2..5 and
+// 7..10, split + LDS write at slot 11 - all of it done before tap 8 reads the next chunk's first fragments
+#define SLAB_XF(T, Q)                                                                             \
+  if constexpr (GN && ((T) % 9) >= 2 && ((T) % 9) <= 6 && ((T) % 9) % 2 == 0) {                    \
+    constexpr int k_ = ((T) % 9) / 2 - 1;                                                         \
+    if constexpr ((Q) == 1) load_gss(chunk0 + (T) / 9 + 1, 0);                                    \
+    if constexpr ((Q) >= 2 && (Q) < 6) xform_elem(xr, (Q) - 2);                                   \
+    if constexpr ((Q) == 6) load_gss(chunk0 + (T) / 9 + 1, 1);                                    \
+    if constexpr ((Q) >= 7 && (Q) < 11) xform_elem(xr, (Q) - 3);                                  \
+    if constexpr ((Q) == 11) store_slab_f(xr, 1 - (T) / 9, k_);                                   \
+  }
 #else
 #define SLAB_ISSUE(T, Q)
+#define SLAB_XF(T, Q)
 #endif
 #define SLAB_SLOT(CUR, NXT, T, Q)                                                   \
   SLAB_PAIR(CUR, Q)                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                \
   SLAB_ISSUE(T, Q)                                                                  \
   SLAB_READ(NXT, (((T) + 1) % 3), (((T) + 1) % 9), Q)                               \
+  SLAB_XF(T, Q)                                                                     \
   __builtin_amdgcn_sched_barrier(0);
   // top-of-tap wait: the weights of tap T+1 (issued in tap T-1... see header) have landed once at most the DMAs issued after
-  // them are outstanding: 2 (weights of T+2) + 2 more when tap T-1 also issued a slab third (T-1 in 0..2 of its chunk)
+  // them are outstanding: 2 (weights of T+2) + 2 more when tap T-1 also issued a slab third (T-1 in 0..2 of its chunk).
+  // GN: thirds are issued at (tap 0, slot 0) and (taps 2 / 4, slot 12), i.e. after the weights of tap T+1 when T-1 is 0, 2 or 4 or
+  // T-2 is 2 or 4: two more at the top of taps 1, 3, 4, 5 and 6; the third itself is waited for by the compiler where the
+  // transform first reads it (a tap and a half after its issue)
 #ifndef CDMA_ABLATE_NO_DMA
 #define SLAB_WAIT(T)                                                                     \
-  if constexpr (((T) % 9) >= 1 && ((T) % 9) <= 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); \
+  if constexpr (GN ? (((T) % 9) == 1 || (((T) % 9) >= 3 && ((T) % 9) <= 6)) : (((T) % 9) >= 1 && ((T) % 9) <= 3))  \
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                          \
   else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
 #else
 #define SLAB_WAIT(T) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -487,10 +561,24 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
 
   // prologue: slab of chunk 0 and the weights of taps 0, 1, 2 in flight; tap 0's fragments into f0
   int chunk0 = 0;
-  issue_slab(0, 0, 0); issue_slab(0, 1, 0); issue_slab(0, 2, 0);
+  u32x4 pr[GN ? 3 : 1][2];      // (prologue only: the fragment registers are still free)
+  if constexpr (GN) { issue_slab_f(pr[0], 0, 0); issue_slab_f(pr[GN ? 1 : 0], 1, 0); issue_slab_f(pr[GN ? 2 : 0], 2, 0); }
+  else { issue_slab(0, 0, 0); issue_slab(0, 1, 0); issue_slab(0, 2, 0); }
   issue_b(0, 0, 0); issue_b(1, 0, 1); issue_b(2, 0, 2);
   CDMA_TS(1)
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (GN) {   // chunk 0's slab through the register path before the loop (the compiler waits for its six loads)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      load_gss(0, h);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xform_elem(pr[GN ? k : 0], h * 4 + e);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) store_slab_f(pr[GN ? k : 0], 0, k);
+  }
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   CDMA_TS(2)
@@ -510,6 +598,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
 #undef SLAB_TAP
 #undef SLAB_WAIT
 #undef SLAB_SLOT
+#undef SLAB_XF
 #undef SLAB_ISSUE
 #undef SLAB_PAIR
 #undef SLAB_READ
@@ -951,7 +1040,7 @@ extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, con
   if (use_slab && (H % 16) == 0 && (W % 16) == 0 && (Cin % 64) == 0) {   // patch-slab kernel (K order: chunk, tap, channel)
     static bool slab_attr = false;
     if (!slab_attr) {
-      (void)hipFuncSetAttribute((const void*)cslab::conv_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cslab::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)cslab::conv_slab_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cslab::LDS_BYTES);
       slab_attr = true;
     }
     const int nslab = (p.M >> 8) * ntn;
@@ -966,9 +1055,46 @@ extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, con
       hipLaunchKernelGGL(cslab::conv_slab_persist_kernel, dim3(nslab < ncu ? nslab : ncu), dim3(512), cslab::P_LDS_BYTES, (hipStream_t)stream, p);
       return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(cslab::conv_slab_kernel, dim3(nslab), dim3(512), cslab::LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(cslab::conv_slab_kernel<false>, dim3(nslab), dim3(512), cslab::LDS_BYTES, (hipStream_t)stream, p);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(cdma::conv_dma_kernel, dim3(ntm * ntn), dim3(512), cdma::LDS_BYTES, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
+// GroupNorm(32) + SiLU of the input fused into the patch-slab convolution (conv_slab_kernel<true>): `x` is the f32 NHWC activation,
+// gn_scale / gn_shift [batch][Cin] the per-image affine form of the normalisation (muse_groupnorm_scale_shift).  Same result, bit
+// for bit, as muse_groupnorm_silu_nhwc_split followed by muse_conv2d_nhwc_split2.  Patch-slab shapes only (H, W multiples of 16,
+// Cin a multiple of 64, Cin <= 2048); anything else returns MUSE_ERR_UNSUPPORTED and the caller keeps the two-kernel route.
+extern "C" int muse_conv2d_nhwc_gn_split2_ok(int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS) {
+  const long M = (long)batch * H * W;
+  return KS == 3 && (H % 16) == 0 && (W % 16) == 0 && (Cin % 64) == 0 && Cin <= 2048 && (Cout % 4) == 0 && M > 0 &&
+         M * Cin * 4 < (1L << 32) - 64 && (long)Cout * 9 * Cin * 2 < (1L << 32) - 64 && M < (1L << 31) - 256;
+}
+extern "C" int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale, const float* gn_shift, const void* w_hi, const void* w_lo,
+                                          const float* bias, const float* residual, float* out, double* gn_partial, int32_t gn_groups,
+                                          int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, void* stream) {
+  const long M = (long)batch * H * W;
+  if (M <= 0 || Cout <= 0) return 0;
+  if (!muse_conv2d_nhwc_gn_split2_ok(batch, H, W, Cin, Cout, KS)) return MUSE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)out) | ((uintptr_t)residual)) & 15) return MUSE_ERR_ALIGN;
+  cdma::Params p;
+  p.xh = p.xl = nullptr; p.xf = x; p.gsc = gn_scale; p.gsh = gn_shift;
+  p.wh = (const bf16_t*)w_hi; p.wl = (const bf16_t*)w_lo;
+  p.bias = bias; p.residual = residual; p.out = out;
+  p.gn_partial = gn_partial; p.gn_groups = gn_groups; p.gn_cpg = gn_groups > 0 ? Cout / gn_groups : 0;
+  if (gn_partial) {
+    const int cpg = p.gn_cpg;
+    if (gn_groups <= 0 || (Cout % gn_groups) || cpg < 4 || cpg > 128 || (cpg & (cpg - 1))) return MUSE_ERR_UNSUPPORTED;
+  }
+  p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.H = H; p.W = W; p.Cin = Cin;
+  const int ntn = (p.N + cslab::BN - 1) / cslab::BN;
+  constexpr int lds = cslab::LDS_BYTES + 2 * 2048 * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)cslab::conv_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(cslab::conv_slab_kernel<true>, dim3((p.M >> 8) * ntn), dim3(512), cslab::LDS_BYTES + 2 * Cin * 4, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           float t = fmaf(v[u][j], scv[j], shv[j]);
-          if (silu) t = t * __frcp_rn(1.0f + __expf(-t));
+          if (silu) t = gn_silu(t);
           v[u][j] = t;
         }
         if constexpr (VEC == 4) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         float t = v[j] * sc[vc * VEC + j] + sh[vc * VEC + j];
-        if (silu) t = t * __frcp_rn(1.0f + __expf(-t));
+        if (silu) t = gn_silu(t);
         v[j] = t;
       }
       storev<T, VEC>(y + off, v);
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void gn_apply_split8_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float t = fmaf(v[u][h][j], scv[h * 4 + j], shv[h * 4 + j]);
-          if (silu) t = t * __frcp_rn(1.0f + __expf(-t));
+          if (silu) t = gn_silu(t);
           raw[j] = __float_as_uint(t);
         }
         u32x2 hi, lo;
@@ -312,6 +312,52 @@ __global__ __launch_bounds__(256) void gn_apply_split8_kernel(const float* __res
       *(u32x4*)(y_lo + off) = lo4;
     }
   }
+}
+
+// The affine form of GroupNorm for a consumer that applies it itself (muse_conv2d_nhwc_gn_split2): scale[b][c] = rstd * gamma[c],
+// shift[b][c] = beta[c] - scale * mean from the [B, nchunk, G, 2] partial sums; one block per image, the arithmetic of the apply
+// kernels' preamble (double sums, float mean / rstd) -> the same floats.
+__global__ __launch_bounds__(256) void gn_scale_shift_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ scale,
+                                                             float* __restrict__ shift, int HW, int C, int G, int nchunk, float eps) {
+  __shared__ float gmean[64], grstd[64];
+  __shared__ double gs_[64], gq_[64];
+  const int b = blockIdx.x, cpg = C / G;
+  {
+    const int tpg = 256 / G, g = threadIdx.x / tpg, sub = threadIdx.x % tpg;
+    double s = 0.0, q = 0.0;
+    for (int c = sub; c < nchunk; c += tpg) {
+      const double* o = partial + (((long)b * nchunk + c) * G + g) * 2;
+      s += o[0]; q += o[1];
+    }
+    for (int o = 1; o < tpg; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (sub == 0) { gs_[g] = s; gq_[g] = q; }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const double s = gs_[threadIdx.x], q = gq_[threadIdx.x];
+    const double n = (double)HW * (double)cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gmean[threadIdx.x] = (float)mean;
+    grstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = grstd[g] * gamma[c];
+    scale[(long)b * C + c] = sc;
+    shift[(long)b * C + c] = beta[c] - sc * gmean[g];
+  }
+}
+extern "C" int muse_groupnorm_scale_shift(const double* partial, int32_t nchunk, const float* gamma, const float* beta, float* scale,
+                                          float* shift, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps, void* stream) {
+  if ((groups != 32 && groups != 64) || (C % groups) || nchunk <= 0) return MUSE_ERR_UNSUPPORTED;
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(gn_scale_shift_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, scale, shift, HW, C,
+                     groups, nchunk, eps);
+  return (int)hipGetLastError();
 }
 
 // f32 input, output as the two bf16 planes y_hi = bf16(y), y_lo = bf16(y - y_hi) the bf16x3 LDS-DMA convolution reads.

@@ -14,6 +14,7 @@ backward through it, and no CPU path.
 from __future__ import annotations
 
 import math
+import os
 from typing import Tuple
 
 import torch
@@ -34,6 +35,15 @@ class _Conv(nn.Module):
         if bias:
             bound = 1.0 / math.sqrt(cin * k * k)
             nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _GNInput:
+    """an f32 NHWC activation with the affine form of its GroupNorm, for the convolution that applies norm + SiLU itself
+    (ops.conv2d_nhwc_gn_split2)"""
+    __slots__ = ("x", "scale", "shift")
+
+    def __init__(self, x, scale, shift):
+        self.x, self.scale, self.shift = x, scale, shift
 
 
 class _Norm(nn.Module):
@@ -113,6 +123,7 @@ class _ConvEngine:
     def _init_engine(self):
         self.compute_dtype = torch.float32
         self.fuse_gn_stats = True   # convolution / pooling epilogues produce the next GroupNorm's statistics
+        self.fuse_gn_apply = os.environ.get("MUSE_GN_FUSE", "1") != "0"   # GroupNorm + SiLU applied inside the consuming patch-slab convolution
         self.dma_conv = True        # "bf16x3" mode: 3x3 convs after GroupNorm run as the LDS-DMA kernel on pre-split planes
         self._packed = {}
 
@@ -165,6 +176,9 @@ class _ConvEngine:
 
     def _conv(self, x, conv, B, H, W, cd, residual=None, upsample=False, gn_next=False):
         wp, cp, cout, k, bias = self._w(conv, cd)
+        if isinstance(x, _GNInput):   # GroupNorm + SiLU + split inside the convolution (_gn_for)
+            return ops.conv2d_nhwc_gn_split2(x.x, x.scale, x.shift, wp[0], wp[1], B, H, W, cp, cout, bias=bias, residual=residual,
+                                             gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
         if isinstance(x, tuple):   # (hi, lo) planes from _gn_for: the LDS-DMA bf16x3 convolution
             return ops.conv2d_nhwc_split2(x[0], x[1], wp[0], wp[1], B, H, W, cp, cout, bias=bias, residual=residual,
                                           gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
@@ -180,6 +194,12 @@ class _ConvEngine:
         """GroupNorm+SiLU feeding `conv`: in "bf16x3" mode the result is written directly as the (hi, lo) bf16 operand
         planes of the LDS-DMA convolution when the layer qualifies (3x3, Cin % 32 == 0)"""
         cout, cin, k, _ = conv.weight.shape
+        stats = getattr(x, "_gn_stats", None)
+        if (cd == "bf16x3" and self.dma_conv and self.fuse_gn_apply and stats is not None and ops.conv_slab_ok(H, W, cin)
+                and ops.conv_gn_split2_ok(B, H, W, cin, cout, k)):
+            # the convolution normalises, activates and splits its own input while staging it: no apply pass, no operand planes
+            sc, sh = ops.groupnorm_scale_shift(stats, norm.weight.data, norm.bias.data, B, H * W, cin, groups=32, eps=1e-6)
+            return _GNInput(x, sc, sh)
         if cd == "bf16x3" and self.dma_conv and ops.conv_split2_ok(B, H, W, cin, cout, k) and (256 % (cin // 4)) == 0:
             return ops.groupnorm_silu_nhwc_split(x, norm.weight.data, norm.bias.data, B, H * W, cin, groups=32, eps=1e-6, silu=True,
                                                  stats=getattr(x, "_gn_stats", None))

@@ -733,6 +733,44 @@ def conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=None, re
     return out
 
 
+def conv_gn_split2_ok(B, H, W, Cin, Cout, KS):
+    """shapes muse_conv2d_nhwc_gn_split2 takes (GroupNorm + SiLU + split fused into the patch-slab convolution)"""
+    return bool(lib().muse_conv2d_nhwc_gn_split2_ok(B, H, W, Cin, Cout, KS))
+
+
+def groupnorm_scale_shift(stats, gamma, beta, B, HW, C, groups=32, eps=1e-6):
+    """(scale, shift) [B, C] f32 with GroupNorm(x)[b, :, c] = x * scale[b, c] + shift[b, c], from a producer's partial sums
+    `stats` = (partial, nchunk)"""
+    part, nchunk = stats
+    require_gpu(part, gamma, beta)
+    sc = torch.empty((B, C), dtype=torch.float32, device=part.device)
+    sh = torch.empty((B, C), dtype=torch.float32, device=part.device)
+    check(lib().muse_groupnorm_scale_shift(part.data_ptr(), nchunk, gamma.data_ptr(), beta.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                           B, HW, C, groups, eps, stream()), "muse_groupnorm_scale_shift")
+    return sc, sh
+
+
+def conv2d_nhwc_gn_split2(x, scale, shift, w_hi, w_lo, B, H, W, Cin, Cout, bias=None, residual=None, gn_groups=0):
+    """conv3x3(silu(GroupNorm(x))) in one kernel: x f32 NHWC, scale / shift from groupnorm_scale_shift (see
+    muse_conv2d_nhwc_gn_split2); otherwise as conv2d_nhwc_split2"""
+    require_gpu(x, scale, shift, w_hi, w_lo)
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    part, nchunk = None, 0
+    if gn_groups and conv_gn_stats_ok(H, W, Cout, gn_groups):
+        nchunk = (H * W) // 256
+        part = torch.empty(B * nchunk * gn_groups * 2, dtype=torch.float64, device=out.device)
+    e0 = _prof_begin()
+    check(lib().muse_conv2d_nhwc_gn_split2(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(), ptr(bias),
+                                           ptr(residual), out.data_ptr(), ptr(part), gn_groups if part is not None else 0,
+                                           B, H, W, Cin, Cout, 3, stream()), "muse_conv2d_nhwc_gn_split2")
+    _prof_end(e0, "conv_bf16x3_dma", 2.0 * B * H * W * Cout * 9 * Cin)
+    if e0 is not None:
+        PROF_BYTES["conv_bf16x3_dma"] = PROF_BYTES.get("conv_bf16x3_dma", 0.0) + _nbytes(x, w_hi, w_lo, residual, out)
+    if part is not None:
+        out._gn_stats = (part, nchunk)
+    return out
+
+
 def conv_split2_ok(B, H, W, Cin, Cout, KS):
     """shapes muse_conv2d_nhwc_split2 takes (the rest stay on muse_conv2d_nhwc_split)"""
     M = B * H * W

@@ -857,3 +857,46 @@ def test_bias_grad_and_add_rowvec(rows, cols, ld, dtype):
         x = dy.clone().to(DEV)
         ops.add_rowvec_(x, b.to(DEV))
         assert torch.equal(x.cpu(), dy + b)                                  # one f32 add per element: exact
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res,gn", [(2, 32, 32, 128, 128, True, True), (1, 16, 16, 512, 512, False, True),
+                                                   (3, 16, 48, 64, 132, True, False), (1, 64, 32, 256, 128, False, True),
+                                                   (2, 16, 16, 128, 256, False, False)])
+def test_conv_with_fused_groupnorm_input_is_bit_identical(B, H, W, Cin, Cout, res, gn):
+    """muse_conv2d_nhwc_gn_split2 (GroupNorm + SiLU + hi/lo split applied while the patch-slab convolution stages its input)
+    against the two-kernel route it replaces (muse_groupnorm_silu_nhwc_split -> muse_conv2d_nhwc_split2): same bits in the output
+    and in the GroupNorm partial sums of the output, with image-border patches (zero padding AFTER the activation), several
+    channel chunks, a ragged Cout tile, residual and bias"""
+    ops = _ops()
+    x = rnd((B, H, W, Cin), 1, 1.5).to(DEV)
+    gamma, beta = (1.0 + 0.2 * rnd((Cin,), 2)).to(DEV), (0.3 * rnd((Cin,), 3)).to(DEV)
+    w = rnd((Cout, 3, 3, Cin), 4, 1.0 / math.sqrt(9 * Cin)).to(DEV)
+    w_hi, w_lo = ops.split_bf16(w.contiguous())
+    bias = rnd((Cout,), 5, 0.1).to(DEV)
+    resid = rnd((B, H, W, Cout), 6).to(DEV) if res else None
+    assert ops.conv_gn_split2_ok(B, H, W, Cin, Cout, 3)
+    # statistics of x the way a producer leaves them: run the apply pass once without stats and keep its partial sums
+    nchunk = _hip_lib().muse_groupnorm_nchunk(H * W)
+    part = torch.empty(B * nchunk * 32 * 2, dtype=torch.float64, device=DEV)
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=DEV)
+    lo = torch.empty_like(hi)
+    from muse.ops import check, stream
+    check(_hip_lib().muse_groupnorm_silu_nhwc_split(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                    part.data_ptr(), 0, B, H * W, Cin, 32, 1e-6, 1, stream()), "gn split")
+    ref = ops.conv2d_nhwc_split2(hi, lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=bias, residual=resid, gn_groups=32 if gn else 0)
+    sc, sh = ops.groupnorm_scale_shift((part, nchunk), gamma, beta, B, H * W, Cin)
+    got = ops.conv2d_nhwc_gn_split2(x, sc, sh, w_hi, w_lo, B, H, W, Cin, Cout, bias=bias, residual=resid, gn_groups=32 if gn else 0)
+    assert torch.equal(got, ref)
+    if gn and hasattr(ref, "_gn_stats"):
+        assert torch.equal(got._gn_stats[0], ref._gn_stats[0]) and got._gn_stats[1] == ref._gn_stats[1]
+    # and against the plain definition (f32 GroupNorm + SiLU + conv on the CPU; bf16x3 products: 2e-5 of the output scale)
+    xn = F.silu(F.group_norm(x.cpu().permute(0, 3, 1, 2), 32, gamma.cpu(), beta.cpu(), 1e-6))
+    y = F.conv2d(xn, w.cpu().permute(0, 3, 1, 2), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    if res:
+        y = y + resid.cpu()
+    assert rel_err(got, y) < 5e-5
+
+
+def _hip_lib():
+    from muse import _hip
+    return _hip.lib()
