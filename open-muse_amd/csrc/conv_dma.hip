@@ -387,12 +387,19 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
   auto load_gss = [&](int chunk, int h) {
     const float* q = gss + chunk * 32 + srcchunk * 8 + h * 4;
 #pragma unroll
+#ifndef GNX_CONST_SS      // (timing experiments, scripts/exp/conv_gn_variants.sh: what the scale / shift reads and the SiLU cost)
     for (int j = 0; j < 4; ++j) { scv[j] = q[j]; shv[j] = q[Cin + j]; }
+#else
+    for (int j = 0; j < 4; ++j) { scv[j] = 1.25f; shv[j] = 0.125f; }
+    (void)q;
+#endif
   };
   // element e (0..7) of a third: GroupNorm affine + SiLU, exactly gn_apply_split8_kernel's expression; in place
   auto xform_elem = [&](u32x4 (&r)[2], int e) {
     float t = fmaf(__uint_as_float(r[e >> 2][e & 3]), scv[e & 3], shv[e & 3]);
+#ifndef GNX_NO_SILU
     t = gn_silu(t);
+#endif
     asm volatile("" : "+v"(t));   // the ROUNDED product is what gets split: no contraction of (x * r) - hi into one fma
     r[e >> 2][e & 3] = __float_as_uint(t);
   };

@@ -7,7 +7,7 @@ from muse import ops
 
 dev = "cuda"
 for (B, H, W, Cin, Cout) in [(64, 256, 256, 128, 128), (64, 128, 128, 128, 128), (64, 64, 64, 256, 256), (64, 32, 32, 256, 256),
-                             (64, 16, 16, 512, 512), (64, 64, 64, 128, 256)]:
+                             (64, 16, 16, 512, 512), (64, 64, 64, 128, 256)][:int(sys.argv[1]) if len(sys.argv) > 1 else None]:
     x = torch.randn((B, H, W, Cin), device=dev)
     gamma, beta = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.1
     w = torch.randn((Cout, 3, 3, Cin), device=dev) / (9 * Cin) ** 0.5
