@@ -521,6 +521,10 @@ def main():
                                "per f32 product; `achieved` counts ALGORITHMIC flops (2*B*H*W*Cout*9*Cin), executed_mfma_tflops the issued "
                                "ones; against the plain 2500 peak frac would be frac/3") if x3 else "dense MFMA peak of the operand dtype",
                 "executed_mfma_tflops": round(ach * (3 if x3 else 1), 1),
+                "note": ("since round 3 this kernel also normalises its input (GroupNorm + SiLU + bf16x3 split inside the convolution, "
+                         "muse_conv2d_nhwc_gn_split2): `achieved` still counts the convolution's flops only, over a launch that now contains "
+                         "the former 5.3 ms / step GroupNorm apply pass - the fraction fell 0.56 -> ~0.50 while the step got 2.6 ms shorter "
+                         "(DESIGN.md section 5)") if dname == "conv_bf16x3_dma" else None,
                 "algorithmic_bytes_per_launch": round(prof_bytes[dname] / dn) if dname in prof_bytes else None,
                 "traffic_source": tnote,
                 "per_kernel": kinds, "hbm_bound_kernels": hbm_kinds}
