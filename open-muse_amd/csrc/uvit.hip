@@ -133,10 +133,56 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
     y[i] = acc;
   }
 }
+// C % 4 == 0: four channels per thread (16-byte accesses), one image row per block row, 32-bit index arithmetic (the scalar kernel
+// above spends most of its time in 64-bit div / mod: 0.94 TB/s on the 16 x 16 x 1024 stage of the U-ViT).  FLIP = the backward's
+// dx (correlation with the flipped taps).  Same tap order and fma chain per element as the scalar kernels -> the same bits.
+template <bool FLIP>
+__global__ __launch_bounds__(256) void dwconv3x3_v4_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                           int H, int W, int C) {
+  const int vpp = C >> 2;
+  const int vc = blockIdx.x * 256 + threadIdx.x;            // channel vector (vpp >= 256) ...
+  int cv, x0, xs;
+  if (vpp >= 256) { cv = vc; x0 = 0; xs = 1; }
+  else { cv = threadIdx.x % vpp; x0 = threadIdx.x / vpp; xs = 256 / vpp; }   // ... or several pixels of the row per pass
+  if (cv >= vpp) return;
+  const int row = blockIdx.y, yy = row % H;                 // row = b * H + y
+  f32x4 wk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ts = FLIP ? 8 - t : t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wk[t][j] = w[(cv * 4 + j) * 9 + ts];
+  }
+  for (int xx = x0; xx < W; xx += xs) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = yy + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = xx + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const f32x4 v = *(const f32x4*)(x + ((long)(row + ky - 1) * W + ix) * C + cv * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], wk[ky * 3 + kx][j], acc[j]);
+      }
+    }
+    *(f32x4*)(y + ((long)row * W + xx) * C + cv * 4) = acc;
+  }
+}
+template <bool FLIP>
+static int launch_dwconv_v4(const float* x, const float* w, float* y, int batch, int H, int W, int C, hipStream_t s) {
+  const int vpp = C >> 2;
+  if ((C & 3) || (vpp < 256 && (256 % vpp)) || ((((uintptr_t)x) | ((uintptr_t)y)) & 15) || (long)batch * H > 65535) return 0;
+  hipLaunchKernelGGL(dwconv3x3_v4_kernel<FLIP>, dim3(vpp >= 256 ? (vpp + 255) / 256 : 1, batch * H), dim3(256), 0, s, x, w, y, H, W, C);
+  return 1;
+}
 extern "C" int muse_dwconv3x3_nhwc(const float* x, const float* w, float* y, int32_t batch, int32_t H, int32_t W, int32_t C,
                                    void* stream) {
   const long n = (long)batch * H * W * C;
   if (n <= 0) return 0;
+  if (launch_dwconv_v4<false>(x, w, y, batch, H, W, C, (hipStream_t)stream)) return (int)hipGetLastError();
   long g = (n + 255) / 256; if (g > 65535) g = 65535;
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, w, y, H, W, C, n);
   return (int)hipGetLastError();
@@ -439,6 +485,52 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_dx_kernel(const float* __re
     dx[i] = acc;
   }
 }
+// four channels per lane (C % 4 == 0), 32-bit pixel arithmetic; same pixel order per wave and the same final (0+1)+(2+3) fold as
+// the scalar kernel below -> the same partial sums
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_dw_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  float* __restrict__ dwp, int H, int W, int C, int pixels) {
+  __shared__ float red[3][64 * 36];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cv = blockIdx.x * 64 + lane, vpp = C >> 2;
+  const int p0 = blockIdx.y * DW_PIX, p1 = min(pixels, p0 + DW_PIX);
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (cv < vpp) {
+    for (int p = p0 + wv; p < p1; p += 4) {
+      const int xx = p % W, row = p / W, yy = row % H;
+      const f32x4 g = *(const f32x4*)(dy + (long)p * C + cv * 4);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = xx + kx - 1;
+          if (ix < 0 || ix >= W) continue;
+          const f32x4 v = *(const f32x4*)(x + ((long)(row + ky - 1) * W + ix) * C + cv * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ky * 3 + kx][j] = fmaf(g[j], v[j], acc[ky * 3 + kx][j]);
+        }
+      }
+    }
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wv - 1][lane * 36 + j * 9 + t] = acc[t][j];
+  }
+  __syncthreads();
+  if (wv == 0 && cv < vpp) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        dwp[(long)blockIdx.y * C * 9 + (long)(cv * 4 + j) * 9 + t] =
+            (acc[t][j] + red[0][lane * 36 + j * 9 + t]) + (red[1][lane * 36 + j * 9 + t] + red[2][lane * 36 + j * 9 + t]);
+  }
+}
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ dwp, int H, int W, int C, long pixels) {
   __shared__ float red[4][64 * 9];
@@ -480,10 +572,16 @@ extern "C" int muse_dwconv3x3_bwd(const float* dy, const float* x, const float* 
   const long pixels = (long)batch * H * W, n = pixels * C;
   if (n <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  long g = (n + 255) / 256; if (g > 65535) g = 65535;
-  hipLaunchKernelGGL(dwconv3x3_bwd_dx_kernel, dim3((unsigned)g), dim3(256), 0, s, dy, w, dx, H, W, C, n);
-  hipLaunchKernelGGL(dwconv3x3_bwd_dw_kernel, dim3((C + 63) / 64, muse_dwconv3x3_bwd_nchunk(pixels)), dim3(256), 0, s, dy, x,
-                     dw_partial, H, W, C, pixels);
+  if (!launch_dwconv_v4<true>(dy, w, dx, batch, H, W, C, s)) {
+    long g = (n + 255) / 256; if (g > 65535) g = 65535;
+    hipLaunchKernelGGL(dwconv3x3_bwd_dx_kernel, dim3((unsigned)g), dim3(256), 0, s, dy, w, dx, H, W, C, n);
+  }
+  if ((C & 3) == 0 && pixels < (1L << 31) - DW_PIX && !((((uintptr_t)dy) | ((uintptr_t)x)) & 15))
+    hipLaunchKernelGGL(dwconv3x3_bwd_dw_v4_kernel, dim3((C / 4 + 63) / 64, muse_dwconv3x3_bwd_nchunk(pixels)), dim3(256), 0, s, dy, x,
+                       dw_partial, H, W, C, (int)pixels);
+  else
+    hipLaunchKernelGGL(dwconv3x3_bwd_dw_kernel, dim3((C + 63) / 64, muse_dwconv3x3_bwd_nchunk(pixels)), dim3(256), 0, s, dy, x,
+                       dw_partial, H, W, C, pixels);
   return (int)hipGetLastError();
 }
 

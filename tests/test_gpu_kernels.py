@@ -900,3 +900,20 @@ def test_conv_with_fused_groupnorm_input_is_bit_identical(B, H, W, Cin, Cout, re
 def _hip_lib():
     from muse import _hip
     return _hip.lib()
+
+
+@pytest.mark.parametrize("rows,inter", [(7, 8), (33, 1000), (300, 4096), (1030, 3072)])
+def test_glu_bf16_wide_kernels_match_the_f32_kernels_rounded(rows, inter):
+    """the 16-byte-per-thread bf16 GLU kernels (inter % 8 == 0) against the generic f32 kernels on the same bf16-valued inputs,
+    rounded to bf16: the same f32 expressions, so the outputs agree except where a last-bit difference of the f32 result (fma
+    contraction is the compiler's choice per kernel) straddles a bf16 rounding boundary - at most one bf16 ulp, a few elements in a
+    million"""
+    ops = _ops()
+    ab = rnd((rows, 2 * inter), 31, 1.5).to(torch.bfloat16).to(DEV)
+    dh = rnd((rows, inter), 32).to(torch.bfloat16).to(DEV)
+    for got, ref in ((ops.glu_fwd(ab), ops.glu_fwd(ab.float())), (ops.glu_bwd(ab, dh), ops.glu_bwd(ab.float(), dh.float()))):
+        assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+        refb = ref.to(torch.bfloat16)
+        ne = got != refb
+        assert float(ne.float().mean()) <= 1e-4
+        assert bool(((got.float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-30).all())      # never more than one bf16 ulp

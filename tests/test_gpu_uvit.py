@@ -69,7 +69,8 @@ def test_adaln_silu_sinusoid_weighted_mean():
     assert abs(float(ops.weighted_mean(v.to(DEV), w.to(DEV))[0]) - float((v * w).sum() / w.sum())) < 1e-6
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 24), (1, 16, 16, 96), (3, 5, 7, 8)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 24), (1, 16, 16, 96), (3, 5, 7, 8),
+                                     (2, 16, 16, 1024), (1, 8, 8, 2048), (2, 6, 5, 128), (1, 4, 4, 10)])   # (the 4-channel-per-thread kernels and their fallbacks)
 def test_depthwise_conv_and_grn(B, H, W, C):
     ops = _ops()
     x = rnd((B, H, W, C), 20)
@@ -182,7 +183,8 @@ def test_adaln_silu_scale_backward():
     assert rel_err(ops.scale_rows_(m, w, num, den, 32), exp) < 1e-6
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 24), (1, 16, 16, 96), (3, 5, 7, 8)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 24), (1, 16, 16, 96), (3, 5, 7, 8),
+                                     (2, 16, 16, 1024), (1, 8, 8, 2048), (2, 6, 5, 128), (1, 4, 4, 10)])   # (the 4-channel-per-thread kernels and their fallbacks)
 def test_depthwise_conv_and_grn_backward(B, H, W, C):
     ops = _ops()
     x = rnd((B, H, W, C), 50).double().requires_grad_(True)
