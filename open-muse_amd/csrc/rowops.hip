@@ -106,6 +106,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
     for (int j = 0; j < 4; ++j) dwacc[it][j] = 0.f;
   const int rbeg = blockIdx.x * LN_BWD_ROWS + wave * (LN_BWD_ROWS / 4);
+  // (fetching dy and x of the NEXT row while this one is reduced - what pays in ffn_mid_bwd and norm_res_bwd - was measured here
+  //  with -DLN_BWD_PREFETCH: 78 -> 118 VGPRs, 6 -> 4 waves per SIMD, 2.98 -> 3.60 ms per step: this kernel lives on occupancy)
+#ifdef LN_BWD_PREFETCH
+  constexpr bool PF = NIT <= 4;
+#else
+  constexpr bool PF = false;
+#endif
+  typename V4<TDY>::raw dn[PF ? NIT : 1];
+  typename V4<TX>::raw xn[PF ? NIT : 1];
+  auto fetch = [&](int row) {
+#pragma unroll
+    for (int it = 0; it < (PF ? NIT : 0); ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < cols) { dn[it] = V4<TDY>::load_raw(dy + (long)row * cols + c); xn[it] = V4<TX>::load_raw(x + (long)row * cols + c); }
+    }
+  };
+  if (PF && rbeg < rows) fetch(rbeg);
   for (int rr = 0; rr < LN_BWD_ROWS / 4; ++rr) {
     const int row = rbeg + rr;
     if (row >= rows) break;
@@ -114,12 +131,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     const TX* xr = x + (long)row * cols;
     float s1 = 0.f, s2 = 0.f;
     float gk[NIT][4], xh[NIT][4];
+    typename V4<TDY>::raw dc[PF ? NIT : 1];
+    typename V4<TX>::raw xc[PF ? NIT : 1];
+    if constexpr (PF) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { dc[it] = dn[it]; xc[it] = xn[it]; }
+      if (rr + 1 < LN_BWD_ROWS / 4 && row + 1 < rows) fetch(row + 1);
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = it * 256 + lane * 4;
       if (c < cols) {
         float d[4], v[4], g[4];
-        V4<TDY>::load(dyr + c, d); V4<TX>::load(xr + c, v); V4<float>::load(w + c, g);
+        if constexpr (PF) { V4<TDY>::unpack(dc[it], d); V4<TX>::unpack(xc[it], v); }
+        else { V4<TDY>::load(dyr + c, d); V4<TX>::load(xr + c, v); }
+        V4<float>::load(w + c, g);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           xh[it][j] = (v[j] - mu) * rs;
@@ -500,27 +526,37 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
     if (c < inter) V4<float>::load(w + c, wv[k]);
   }
   const int r0 = blockIdx.x * FFN_ROWS;
+  // every operand of a row is fetched while the PREVIOUS row is being reduced (the block's three barriers per row otherwise expose a
+  // full memory round trip per row)
+  typename V4<T>::raw ra_n[NV], rb_n[NV], rd_n[NV];
+  auto fetch = [&](int row) {
+    const T* abr = ab + (long)row * 2 * inter;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 256 + threadIdx.x) * 4;
+      if (c < inter) {
+        ra_n[k] = V4<T>::load_raw(abr + c); rb_n[k] = V4<T>::load_raw(abr + inter + c);
+        rd_n[k] = V4<T>::load_raw(dhm + (long)row * inter + c);
+      }
+    }
+  };
+  if (r0 < rows) fetch(r0);
   for (int rr = 0; rr < FFN_ROWS; ++rr) {
     const int row = r0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
     float gk[NV][4], xh[RECOMP ? 1 : NV][4], ev[RECOMP ? NV : 1][4];
     float s1 = 0.f, s2 = 0.f;
-    const T* abr = ab + (long)row * 2 * inter;
-    // the GLU operands of the second phase do not depend on the row reductions: their loads go out with the first phase's
-    // (twice the bytes in flight per block; behind the reductions the kernel ran at 3.2 TB/s)
-    typename V4<T>::raw ra[NV], rb[NV];
+    typename V4<T>::raw ra[NV], rb[NV], rd[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int c = (k * 256 + threadIdx.x) * 4;
-      if (c < inter) { ra[k] = V4<T>::load_raw(abr + c); rb[k] = V4<T>::load_raw(abr + inter + c); }
-    }
+    for (int k = 0; k < NV; ++k) { ra[k] = ra_n[k]; rb[k] = rb_n[k]; rd[k] = rd_n[k]; }
+    if (rr + 1 < FFN_ROWS && row + 1 < rows) fetch(row + 1);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 256 + threadIdx.x) * 4;
       if (c < inter) {
         float d[4], x[4];
-        V4<T>::load(dhm + (long)row * inter + c, d);
+        V4<T>::unpack(rd[k], d);
         if constexpr (RECOMP) {
           float a[4], b[4];
           V4<T>::unpack(ra[k], a); V4<T>::unpack(rb[k], b);

@@ -310,6 +310,90 @@ __global__ __launch_bounds__(256) void norm_res_bwd_kernel(const float* __restri
   for (int it = 0; it < NIT; ++it)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dwacc[it][j] = 0.f;
+  if constexpr (NIT <= 4) {
+    // the row (v, dy, dpre) lives in registers: ONE round trip to memory per row instead of five dependent ones (the kernel is
+    // latency-bound: every block of the grid is resident at once and each wave walks its four rows serially); the next row's
+    // loads are issued before this row's reductions.  Same expressions and summation orders as the general path below.
+    f32x4 wv4[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = lane * 4 + 256 * it;
+      wv4[it] = (w && c < cols) ? *(const f32x4*)(w + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    const long row0 = (long)blockIdx.x * NRB_ROWS + wave * (NRB_ROWS / 4);
+    f32x4 tn[NIT], dn[NIT], pn[NIT];
+    auto fetch = [&](long row) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = lane * 4 + 256 * it;
+        if (row < rows && c < cols) {
+          tn[it] = *(const f32x4*)(v + row * cols + c);
+          dn[it] = *(const f32x4*)(dy + row * cols + c);
+          if (dpre) pn[it] = *(const f32x4*)(dpre + row * cols + c);
+        }
+      }
+    };
+    fetch(row0);
+    for (int rr = 0; rr < NRB_ROWS / 4; ++rr) {
+      const long row = row0 + rr;
+      if (row >= rows) break;
+      f32x4 t[NIT], d[NIT], pr[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { t[it] = tn[it]; d[it] = dn[it]; pr[it] = pn[it]; }
+      if (rr + 1 < NRB_ROWS / 4) fetch(row + 1);
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (lane * 4 + 256 * it < cols) {
+          s += (t[it][0] + t[it][1]) + (t[it][2] + t[it][3]);
+          q += (t[it][0] * t[it][0] + t[it][1] * t[it][1]) + (t[it][2] * t[it][2] + t[it][3] * t[it][3]);
+        }
+      float mean = 0.f, rstd;
+      if (mode == 0) {
+        rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+      } else {
+        mean = wave_sum(s) / (float)cols;
+        float d2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (lane * 4 + 256 * it < cols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dd = t[it][j] - mean; d2 = fmaf(dd, dd, d2); }
+          }
+        rstd = 1.0f / sqrtf(wave_sum(d2) / (float)cols + eps);
+      }
+      float sg = 0.f, sgx = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (lane * 4 + 256 * it < cols) {
+          f32x4 g = d[it];
+          if (w) g *= wv4[it];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xh = (t[it][j] - mean) * rstd;
+            sg += g[j];
+            sgx = fmaf(g[j], xh, sgx);
+            dwacc[it][j] = fmaf(d[it][j], xh, dwacc[it][j]);
+          }
+        }
+      const float mg = mode == 0 ? 0.f : wave_sum(sg) / (float)cols;
+      const float mgx = wave_sum(sgx) / (float)cols;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = lane * 4 + 256 * it;
+        if (c < cols) {
+          f32x4 g = d[it];
+          if (w) g *= wv4[it];
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = rstd * (g[j] - mg - (t[it][j] - mean) * rstd * mgx);
+          if (dpre) o += pr[it];
+          *(f32x4*)(dv + row * cols + c) = o;
+          if (dvb) *(u32x2*)(dvb + row * cols + c) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+        }
+      }
+    }
+  } else
   for (int rr = 0; rr < NRB_ROWS / 4; ++rr) {
     const long row = (long)blockIdx.x * NRB_ROWS + wave * (NRB_ROWS / 4) + rr;
     if (row >= rows) break;
