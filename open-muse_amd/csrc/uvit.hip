@@ -52,10 +52,72 @@ __global__ __launch_bounds__(256) void norm_res_fwd_kernel(const float* __restri
     *(f32x4*)(y + row * cols + c) = o;
   }
 }
+// cols <= 1024: the row stays in registers between the statistics and the output pass (one read of x / res instead of two or
+// three; the general kernel above leans on the caches for the re-reads).  Same expressions and summation order -> the same bits.
+template <int NIT>
+__global__ __launch_bounds__(256) void norm_res_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                               const float* __restrict__ w, float* __restrict__ y,
+                                                               float* __restrict__ pre, long rows, int cols, float eps, int mode) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v[NIT];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = lane * 4 + 256 * it;
+    if (c < cols) {
+      v[it] = *(const f32x4*)(x + row * cols + c);
+      if (res) v[it] += *(const f32x4*)(res + row * cols + c);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = lane * 4 + 256 * it;
+    if (c < cols) {
+      if (pre) *(f32x4*)(pre + row * cols + c) = v[it];
+      s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+      q += (v[it][0] * v[it][0] + v[it][1] * v[it][1]) + (v[it][2] * v[it][2] + v[it][3] * v[it][3]);
+    }
+  }
+  float mean = 0.f, rstd;
+  if (mode == 0) {
+    rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+  } else {
+    mean = wave_sum(s) / (float)cols;
+    float d2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (lane * 4 + 256 * it < cols) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[it][j] - mean; d2 = fmaf(d, d, d2); }
+      }
+    rstd = 1.0f / sqrtf(wave_sum(d2) / (float)cols + eps);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = lane * 4 + 256 * it;
+    if (c < cols) {
+      f32x4 g = {1.f, 1.f, 1.f, 1.f};
+      if (w) g = *(const f32x4*)(w + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[it][j] - mean) * rstd * g[j];
+      *(f32x4*)(y + row * cols + c) = o;
+    }
+  }
+}
 extern "C" int muse_norm_res_fwd(const float* x, const float* res, const float* w, float* y, float* pre, int64_t rows,
                                  int32_t cols, float eps, int32_t mode, void* stream) {
   if (cols % 4 || (mode != 0 && mode != 1)) return MUSE_ERR_UNSUPPORTED;
   if (rows <= 0) return 0;
+  if (cols <= 1024) {
+    const dim3 grid((unsigned)((rows + 3) / 4));
+#define NRF(N) hipLaunchKernelGGL(norm_res_fwd_reg_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, res, w, y, pre, (long)rows, cols, eps, mode)
+    if (cols <= 256) NRF(1); else if (cols <= 512) NRF(2); else if (cols <= 768) NRF(3); else NRF(4);
+#undef NRF
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(norm_res_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, res, w, y, pre,
                      (long)rows, cols, eps, mode);
   return (int)hipGetLastError();
