@@ -303,6 +303,13 @@ int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale, const floa
                                int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, void* stream);
 int muse_groupnorm_scale_shift(const double* partial, int32_t nchunk, const float* gamma, const float* beta, float* scale,
                                float* shift, int32_t batch, int32_t HW, int32_t C, int32_t groups, float eps, void* stream);
+/* Encoder.conv_in (muse/modeling_maskgit_vqgan.py:175; taming :380): 3x3, padding 1, Cin <= 4 image channels -> Cout, as a direct
+ * exact-f32 convolution (K = 9 * Cin is no matrix-core problem; the output write is what costs).  x [B, H, W, Cpad] f32 NHWC (Cpad a
+ * multiple of 4, channels >= 4 ignored), w4 [Cout][9][4] f32 (tap-major, input channels zero-padded to 4), bias f32 [Cout] or NULL.
+ * gn_partial (optional, needs gn_groups * 4 == Cout): [B, H, gn_groups, 2] f64 sum / sum of squares of the output per image row -
+ * the `partial` / nchunk = H a following GroupNorm consumes.  Cout % 4 == 0, Cout / 4 divides 256. */
+int muse_conv_in_direct(const float* x, const float* w4, const float* bias, float* out, double* gn_partial, int32_t gn_groups,
+                        int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cpad, int32_t Cout, void* stream);
 /* f32 in; output as y_hi = bf16(y), y_lo = bf16(y - y_hi) (two [B, HW, C] bf16 planes) for muse_conv2d_nhwc_split2.
  * stats_nchunk == 0: statistics computed here into `partial`; > 0: `partial` = [B, stats_nchunk, G, 2] already filled. */
 int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta,

@@ -385,6 +385,91 @@ extern "C" int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* 
 }
 
 // =================================================================================================================
+// The first convolution of an encoder (conv_in, muse/modeling_maskgit_vqgan.py:175: 3 image channels -> hidden_channels, 3x3,
+// padding 1) as a direct f32 convolution on the vector ALUs: K = 27 is no matrix-core problem - the implicit-GEMM kernels spend the
+// launch on their 128 x 128 epilogue and write the 2.1 GB output of a 64 x 256 x 256 batch in partial lines (1.2 TB/s).  Here a thread
+// keeps the 27 x 4 weights of its four output channels in registers and walks the pixels of one image row; the 32 lanes of a pixel
+// read the same nine input vectors and store 512 contiguous bytes.  Exact f32 products; 1.35 ms on that batch (vector-ALU issue
+// bound: ~250 instructions per pixel and thread around the 108 fmas; a plain 2.1 GB fill takes 0.31 ms).
+// x: [B, H, W, Cpad] f32 (channels >= Cin are ignored), w4: [Cout][9][4] f32 (channel 3 zero when Cin == 3), out [B, H, W, Cout].
+// gn_partial (optional): [B, H, groups, 2] f64 sums of the output, one chunk per image row (groups of exactly four channels).
+// =================================================================================================================
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_in_direct_kernel(const float* __restrict__ x, const float* __restrict__ w4,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             double* __restrict__ gn_partial, int H, int W, int Cpad, int Cout) {
+  __shared__ double red[2][256];
+  const int qpp = Cout >> 2;                                   // channel quads (= threads) per pixel: divides 256
+  const int cq = threadIdx.x % qpp, px0 = threadIdx.x / qpp, pstep = 256 / qpp;
+  const int row = blockIdx.x, yy = row % H;                    // row = b * H + y
+  f32x4 wk[9][4];                                              // [tap][out channel j] = weights of the (<= 4) input channels
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wk[t][j] = *(const f32x4*)(w4 + ((long)(cq * 4 + j) * 9 + t) * 4);
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *(const f32x4*)(bias + cq * 4);
+  double gs = 0.0, gq = 0.0;
+  // the nine input vectors of a pixel (zeros outside the image) - fetched one pixel ahead of the 27 x 4 fma chain that uses them.
+  // (A sliding 3 x 3 window over consecutive pixels - three loads per pixel instead of nine - was measured: 256 VGPRs, 1.30 -> 1.84 ms
+  //  on the 64 x 256 x 256 batch; the nine loads of a pixel hit the same two addresses per wave and cost little.)
+  f32x4 vn[9];
+  auto fetch = [&](int xx) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = yy + ky - 1, ix = xx + kx - 1;
+        vn[ky * 3 + kx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? *(const f32x4*)(x + ((long)(row + ky - 1) * W + ix) * Cpad)
+                                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+  if (px0 < W) fetch(px0);
+  for (int xx = px0; xx < W; xx += pstep) {
+    f32x4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = vn[t];
+    if (xx + pstep < W) fetch(xx + pstep);
+    f32x4 acc = bv;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc[j] = fmaf(v[t][c], wk[t][j][c], acc[j]);
+    *(f32x4*)(out + ((long)row * W + xx) * Cout + cq * 4) = acc;
+    if (gn_partial) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { gs += (double)acc[j]; gq += (double)acc[j] * (double)acc[j]; }
+    }
+  }
+  if (gn_partial) {      // one group = one channel quad: fold the pstep pixel lanes of each quad in a fixed order
+    red[0][threadIdx.x] = gs; red[1][threadIdx.x] = gq;
+    __syncthreads();
+    if (threadIdx.x < qpp) {
+      double s = 0.0, q = 0.0;
+      for (int k = 0; k < pstep; ++k) { s += red[0][k * qpp + threadIdx.x]; q += red[1][k * qpp + threadIdx.x]; }
+      double* o = gn_partial + ((long)row * qpp + threadIdx.x) * 2;
+      o[0] = s; o[1] = q;
+    }
+  }
+}
+extern "C" int muse_conv_in_direct(const float* x, const float* w4, const float* bias, float* out, double* gn_partial, int32_t gn_groups,
+                                   int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cpad, int32_t Cout, void* stream) {
+  const int qpp = Cout >> 2;
+  if ((Cout & 3) || qpp > 256 || (256 % qpp) || Cpad < 4 || (Cpad & 3) || Cin < 1 || Cin > 4) return MUSE_ERR_UNSUPPORTED;
+  if (gn_partial && gn_groups * 4 != Cout) return MUSE_ERR_UNSUPPORTED;      // groups of exactly four channels
+  if ((((uintptr_t)x) | ((uintptr_t)w4) | ((uintptr_t)bias) | ((uintptr_t)out)) & 15) return MUSE_ERR_ALIGN;
+  if ((long)batch * H <= 0) return 0;
+  if ((long)batch * H >= (1L << 31)) return MUSE_ERR_UNSUPPORTED;
+#define CID(N) hipLaunchKernelGGL(conv_in_direct_kernel<N>, dim3((unsigned)(batch * H)), dim3(256), 0, (hipStream_t)stream, x, w4, bias, out, \
+                                  gn_partial, H, W, Cpad, Cout)
+  if (Cin == 3) CID(3); else if (Cin == 4) CID(4); else if (Cin == 1) CID(1); else CID(2);
+#undef CID
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
 // avg_pool2d(2,2) NHWC
 // =================================================================================================================
 template <typename T, int VEC>

@@ -124,6 +124,7 @@ class _ConvEngine:
         self.compute_dtype = torch.float32
         self.fuse_gn_stats = True   # convolution / pooling epilogues produce the next GroupNorm's statistics
         self.fuse_gn_apply = os.environ.get("MUSE_GN_FUSE", "1") != "0"   # GroupNorm + SiLU applied inside the consuming patch-slab convolution
+        self.direct_conv_in = os.environ.get("MUSE_CONV_IN_DIRECT", "1") != "0"   # bf16x3 mode: conv_in as a direct exact-f32 kernel
         self.dma_conv = True        # "bf16x3" mode: 3x3 convs after GroupNorm run as the LDS-DMA kernel on pre-split planes
         self._packed = {}
 
@@ -173,6 +174,21 @@ class _ConvEngine:
             hit = (wp, cp, cout, k, None if conv.bias is None else conv.bias.data.float().contiguous())
             self._packed[key] = hit
         return hit
+
+    def _conv_in(self, x, conv, B, H, W, cd, cpad):
+        """the image-to-features convolution: in the bf16x3 mode a direct exact-f32 kernel (3 input channels are no matrix-core
+        problem; ops.conv_in_direct), otherwise the mode's implicit GEMM"""
+        cout, cin, k, _ = conv.weight.shape
+        if cd == "bf16x3" and self.direct_conv_in and ops.conv_in_direct_ok(cin, cout, k, cpad):
+            key = (id(conv), "direct")
+            hit = self._packed.get(key)
+            if hit is None:
+                w4 = torch.zeros((cout, 9, 4), dtype=torch.float32, device=conv.weight.device)
+                w4[:, :, :cin] = conv.weight.data.float().permute(0, 2, 3, 1).reshape(cout, 9, cin)
+                hit = (w4.contiguous(), None if conv.bias is None else conv.bias.data.float().contiguous())
+                self._packed[key] = hit
+            return ops.conv_in_direct(x, hit[0], B, H, W, cin, cpad, cout, bias=hit[1], gn_groups=32 if self.fuse_gn_stats else 0)
+        return self._conv(x, conv, B, H, W, cd, gn_next=True)
 
     def _conv(self, x, conv, B, H, W, cd, residual=None, upsample=False, gn_next=False):
         wp, cp, cout, k, bias = self._w(conv, cd)
@@ -256,7 +272,7 @@ class MaskGitVQGAN(_ConvEngine, ModelMixin, ConfigMixin):
         enc = self.encoder
         B, C, H, W = pixel_values.shape
         x = ops.nchw_to_nhwc(pixel_values.float(), self._act_dtype(), self._cpad(C, cd))
-        h = self._conv(x, enc.conv_in, B, H, W, cd, gn_next=True)
+        h = self._conv_in(x, enc.conv_in, B, H, W, cd, self._cpad(C, cd))
         nres = self.config.num_resolutions
         for lvl, down in enumerate(enc.down):
             for blk in down.block:

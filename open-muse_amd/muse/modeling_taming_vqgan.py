@@ -208,7 +208,7 @@ class VQGANModel(_ConvEngine, ModelMixin, ConfigMixin):
         if (H | W) % (1 << (self.config.num_resolutions - 1)):
             raise ValueError("image height / width must be multiples of the reduction factor")
         x = ops.nchw_to_nhwc(pixel_values.float(), self._act_dtype(), self._cpad(C, cd))
-        h = self._conv(x, enc.conv_in, B, H, W, cd, gn_next=True)
+        h = self._conv_in(x, enc.conv_in, B, H, W, cd, self._cpad(C, cd))
         for lvl in enc.down:
             h = self._level(h, lvl, B, H, W, cd)
             if hasattr(lvl, "downsample"):

@@ -733,6 +733,28 @@ def conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=None, re
     return out
 
 
+def conv_in_direct_ok(Cin, Cout, KS, Cpad):
+    """shapes muse_conv_in_direct takes: the image-to-features 3x3 convolution of an encoder"""
+    return KS == 3 and Cin <= 4 and Cpad % 4 == 0 and Cpad >= 4 and Cout % 4 == 0 and Cout // 4 <= 256 and 256 % (Cout // 4) == 0
+
+
+def conv_in_direct(x, w4, B, H, W, Cin, Cpad, Cout, bias=None, gn_groups=0):
+    """conv_in as a direct exact-f32 convolution (muse_conv_in_direct): x [B, H, W, Cpad] f32, w4 [Cout, 9, 4] f32.
+    gn_groups * 4 == Cout: the GroupNorm statistics of the output ride on it (`out._gn_stats = (partial, H)`)."""
+    require_gpu(x, w4)
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    part = None
+    if gn_groups and gn_groups * 4 == Cout:
+        part = torch.empty(B * H * gn_groups * 2, dtype=torch.float64, device=x.device)
+    e0 = _prof_begin()
+    check(lib().muse_conv_in_direct(x.data_ptr(), w4.data_ptr(), ptr(bias), out.data_ptr(), ptr(part), gn_groups if part is not None else 0,
+                                    B, H, W, Cin, Cpad, Cout, stream()), "muse_conv_in_direct")
+    _prof_end(e0, "conv_in_direct", _nbytes(x, out), "byte")
+    if part is not None:
+        out._gn_stats = (part, H)
+    return out
+
+
 def conv_gn_split2_ok(B, H, W, Cin, Cout, KS):
     """shapes muse_conv2d_nhwc_gn_split2 takes (GroupNorm + SiLU + split fused into the patch-slab convolution)"""
     return bool(lib().muse_conv2d_nhwc_gn_split2_ok(B, H, W, Cin, Cout, KS))

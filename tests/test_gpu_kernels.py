@@ -917,3 +917,31 @@ def test_glu_bf16_wide_kernels_match_the_f32_kernels_rounded(rows, inter):
         ne = got != refb
         assert float(ne.float().mean()) <= 1e-4
         assert bool(((got.float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-30).all())      # never more than one bf16 ulp
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cpad,Cout", [(2, 16, 16, 3, 8, 128), (1, 5, 7, 3, 4, 32), (3, 8, 4, 1, 8, 64), (1, 32, 32, 4, 4, 256),
+                                                 (1, 6, 300, 2, 4, 128)])
+def test_conv_in_direct(B, H, W, Cin, Cpad, Cout):
+    """the direct exact-f32 image-to-features convolution (muse_conv_in_direct) against F.conv2d in float64 (f32 fma chains of <= 36
+    terms: 2e-6), with the GroupNorm partial sums of its output (one chunk per image row; f64 sums of the f32 outputs) when the
+    groups are four channels wide"""
+    ops = _ops()
+    x = torch.full((B, H, W, Cpad), 7.0)                      # (channels past Cin are never used)
+    x[..., :Cin] = rnd((B, H, W, Cin), 41)
+    w = rnd((Cout, Cin, 3, 3), 42, 0.3)
+    bias = rnd((Cout,), 43, 0.1)
+    w4 = torch.zeros(Cout, 9, 4)
+    w4[:, :, :Cin] = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    assert ops.conv_in_direct_ok(Cin, Cout, 3, Cpad)
+    groups = Cout // 4 if Cout // 4 in (32, 64) else 0
+    got = ops.conv_in_direct(x.to(DEV), w4.to(DEV), B, H, W, Cin, Cpad, Cout, bias=bias.to(DEV), gn_groups=groups)
+    ref = F.conv2d(x[..., :Cin].permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(got, ref) < 2e-6
+    if groups:
+        part, nchunk = got._gn_stats
+        assert nchunk == H
+        p = part.view(B, H, groups, 2).cpu()
+        g = got.cpu().double().view(B, H, W, groups, 4)
+        assert float((p[..., 0] - g.sum((2, 4))).abs().max()) < 1e-9 and float((p[..., 1] - (g * g).sum((2, 4))).abs().max()) < 1e-9
+    else:
+        assert not hasattr(got, "_gn_stats")
