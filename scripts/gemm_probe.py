@@ -46,6 +46,11 @@ if "conv" in which:
     timeit("conv bf16x3 64x128x128x128 3x3", lambda: ops.conv2d_nhwc_split(xi, wh, wl, B, Hh, Ww, C, C, 3), fl)
     xh, xl = ops.split_bf16(xi)
     timeit("conv bf16x3 DMA 64x128x128x128 3x3", lambda: ops.conv2d_nhwc_split2(xh, xl, wh, wl, B, Hh, Ww, C, C), fl)
+    # the fused form (GroupNorm + SiLU + split of the input inside the convolution): statistics as a producer leaves them
+    y0 = ops.conv2d_nhwc_split2(xh, xl, wh, wl, B, Hh, Ww, C, C, gn_groups=32)
+    gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+    sc, sh = ops.groupnorm_scale_shift(y0._gn_stats, gam, bet, B, Hh * Ww, C)
+    timeit("conv bf16x3 GN-fused 64x128x128x128 3x3", lambda: ops.conv2d_nhwc_gn_split2(y0, sc, sh, wh, wl, B, Hh, Ww, C, C), fl)
     for (b2, h2, c2) in ((16, 256, 128), (64, 64, 256), (64, 16, 512)):
         x2 = torch.randn(b2, h2, h2, c2, device=dev)
         w2 = torch.randn(c2, 3, 3, c2, device=dev) * 0.03
