@@ -71,4 +71,30 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// erf(x / sqrt(2)) for the kernels whose STORAGE type is bf16 (FAST = true): Abramowitz & Stegun 7.1.26 - branch-free, one reciprocal,
+// one exponential (exp(-x^2 / 2), the very factor the GELU derivative's density needs), five fmas; |error| <= 1.5e-7 (+ ~2 ulp of f32
+// evaluation), four orders below the bf16 rounding of the values these kernels store.  The bf16 GLU / ffn_mid kernels are vector-ALU
+// bound (~80 instructions per element with the library erff, whose two branches both execute in a divergent wave: ffn_mid_bwd 103 us
+// of VALU issue for 92 us of memory time); f32 storage keeps the library erff.  Forward and backward of a pair use the same
+// function, so the backward's recomputed gelu(a) * b is still the forward's tensor bit for bit.
+template <bool FAST> __device__ __forceinline__ float erf_rsqrt2(float x) {
+  if constexpr (!FAST) {
+    return erff(x * 0.70710678118654752440f);
+  } else {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));       // 1 / (1 + p |x| / sqrt(2)), p = 0.3275911
+    const float e = __expf(-0.5f * x * x);
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    return copysignf(1.0f - q * t * e, x);
+  }
+}
+template <bool FAST> __device__ __forceinline__ float gelu_erf_t(float x) { return 0.5f * x * (1.0f + erf_rsqrt2<FAST>(x)); }
+template <bool FAST> __device__ __forceinline__ float gelu_erf_grad_t(float x) {
+  const float cdf = 0.5f * (1.0f + erf_rsqrt2<FAST>(x));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
 #define MUSE_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

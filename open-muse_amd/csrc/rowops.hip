@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd_kernel(const T* __restrict__ 
         float a[4], b[4], o[4];
         V4<T>::load(abr + c, a); V4<T>::load(abr + inter + c, b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]) * b[j];
+        for (int j = 0; j < 4; ++j) o[j] = gelu_erf_t<sizeof(T) == 2>(a[j]) * b[j];
         if (h) V4<T>::store(h + (long)row * inter + c, o);
         if (sizeof(T) == 2) {  // LayerNorm sees the stored (bf16-rounded) h, exactly like the unfused path
 #pragma unroll
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
           V4<T>::unpack(ra[k], a); V4<T>::unpack(rb[k], b);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            ev[k][j] = erff(a[j] * 0.70710678118654752440f);
+            ev[k][j] = erf_rsqrt2<sizeof(T) == 2>(a[j]);
             x[j] = 0.5f * a[j] * (1.0f + ev[k][j]) * b[j];           // == gelu_erf(a) * b, bit for bit
             if (sizeof(T) == 2) x[j] = bf16_to_f32(f32_to_bf16(x[j]));
           }
@@ -601,8 +601,8 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd_kernel(const T* __restrict__ 
             db[j] = dh * g;
           } else {
             const float dh = rs * (gk[k][j] - c1 - xh[k][j] * c2);
-            da[j] = dh * b[j] * gelu_erf_grad(a[j]);
-            db[j] = dh * gelu_erf(a[j]);
+            da[j] = dh * b[j] * gelu_erf_grad_t<sizeof(T) == 2>(a[j]);
+            db[j] = dh * gelu_erf_t<sizeof(T) == 2>(a[j]);
           }
         }
         V4<T>::store(dr + c, da); V4<T>::store(dr + inter + c, db);
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void ffn_mid_fwd2_kernel(const bf16_t* __restr
       float a[8], b[8];
       unpack8(ra[k], a); unpack8(rb[k], b);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) hv[k][j] = gelu_erf(a[j]) * b[j];
+      for (int j = 0; j < 8; ++j) hv[k][j] = gelu_erf_t<true>(a[j]) * b[j];
       const u32x4 o = pack8(hv[k]);
       if (live && h) *(u32x4*)(h + (long)row * inter + k * 1024 + t * 8) = o;   // (h == nullptr: the backward recomputes it)
       unpack8(o, hv[k]);   // LayerNorm sees the stored (bf16-rounded) h, exactly like the unfused path
@@ -753,8 +753,8 @@ __global__ __launch_bounds__(256) void ffn_mid_bwd2_kernel(const bf16_t* __restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float dh = rs * (gk[k][j] - c1 - xh[k][j] * c2);
-          da[j] = dh * b[j] * gelu_erf_grad(a[j]);
-          db[j] = dh * gelu_erf(a[j]);
+          da[j] = dh * b[j] * gelu_erf_grad_t<true>(a[j]);
+          db[j] = dh * gelu_erf_t<true>(a[j]);
         }
         *(u32x4*)(dr + k * 1024 + t * 8) = pack8(da);
         *(u32x4*)(dr + inter + k * 1024 + t * 8) = pack8(db);
@@ -955,7 +955,7 @@ __global__ void glu_fwd_kernel(const T* __restrict__ ab, T* __restrict__ h, long
     V4<T>::load(ab + r * 2 * inter + c, a);
     V4<T>::load(ab + r * 2 * inter + inter + c, b);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]) * b[j];
+    for (int j = 0; j < 4; ++j) o[j] = gelu_erf_t<sizeof(T) == 2>(a[j]) * b[j];
     V4<T>::store(h + r * inter + c, o);
   }
 }
@@ -970,7 +970,7 @@ __global__ void glu_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ d
     V4<T>::load(ab + r * 2 * inter + inter + c, b);
     V4<T>::load(dh + r * inter + c, d);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { da[j] = d[j] * b[j] * gelu_erf_grad(a[j]); db[j] = d[j] * gelu_erf(a[j]); }
+    for (int j = 0; j < 4; ++j) { da[j] = d[j] * b[j] * gelu_erf_grad_t<sizeof(T) == 2>(a[j]); db[j] = d[j] * gelu_erf_t<sizeof(T) == 2>(a[j]); }
     V4<T>::store(dab + r * 2 * inter + c, da);
     V4<T>::store(dab + r * 2 * inter + inter + c, db);
   }
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256) void glu_fwd8_kernel(const bf16_t* __restrict_
     float a[8], b[8], o[8];
     unpack8_bf16(ra, a); unpack8_bf16(rb, b);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = gelu_erf(a[j]) * b[j];
+    for (int j = 0; j < 8; ++j) o[j] = gelu_erf_t<true>(a[j]) * b[j];
     *(u32x4*)(h + r * inter + c) = pack8_bf16(o);
   }
 }
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void glu_bwd8_kernel(const bf16_t* __restrict_
     unpack8_bf16(ra, a); unpack8_bf16(rb, b); unpack8_bf16(rd, d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float e = erff(a[j] * 0.70710678118654752440f);
+      const float e = erf_rsqrt2<true>(a[j]);
       const float cdf = 0.5f * (1.0f + e), pdf = 0.39894228040143267794f * __expf(-0.5f * a[j] * a[j]);
       da[j] = d[j] * b[j] * (cdf + a[j] * pdf);               // == d * b * gelu_erf_grad(a)
       db[j] = d[j] * (0.5f * a[j] * (1.0f + e));              // == d * gelu_erf(a)
@@ -1059,11 +1059,11 @@ __global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T
     V4<T>::load(x + i * 4, a);
     if (MODE == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]);
+      for (int j = 0; j < 4; ++j) o[j] = gelu_erf_t<sizeof(T) == 2>(a[j]);
     } else {
       float d[4]; V4<T>::load(dy + i * 4, d);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = d[j] * gelu_erf_grad(a[j]);
+      for (int j = 0; j < 4; ++j) o[j] = d[j] * gelu_erf_grad_t<sizeof(T) == 2>(a[j]);
     }
     V4<T>::store(out + i * 4, o);
   }

@@ -905,9 +905,9 @@ def _hip_lib():
 @pytest.mark.parametrize("rows,inter", [(7, 8), (33, 1000), (300, 4096), (1030, 3072)])
 def test_glu_bf16_wide_kernels_match_the_f32_kernels_rounded(rows, inter):
     """the 16-byte-per-thread bf16 GLU kernels (inter % 8 == 0) against the generic f32 kernels on the same bf16-valued inputs,
-    rounded to bf16: the same f32 expressions, so the outputs agree except where a last-bit difference of the f32 result (fma
-    contraction is the compiler's choice per kernel) straddles a bf16 rounding boundary - at most one bf16 ulp, a few elements in a
-    million"""
+    rounded to bf16.  The bf16 kernels evaluate erf with the branch-free form of common.h (|error| <= 5e-7 in f32, four orders
+    below a bf16 ulp), the f32 kernels with the library erff: the outputs agree except where that difference straddles a bf16
+    rounding boundary - never more than one bf16 ulp, well under one element in a thousand"""
     ops = _ops()
     ab = rnd((rows, 2 * inter), 31, 1.5).to(torch.bfloat16).to(DEV)
     dh = rnd((rows, inter), 32).to(torch.bfloat16).to(DEV)
@@ -915,8 +915,9 @@ def test_glu_bf16_wide_kernels_match_the_f32_kernels_rounded(rows, inter):
         assert got.dtype == torch.bfloat16 and got.shape == ref.shape
         refb = ref.to(torch.bfloat16)
         ne = got != refb
-        assert float(ne.float().mean()) <= 1e-4
-        assert bool(((got.float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-30).all())      # never more than one bf16 ulp
+        assert float(ne.float().mean()) <= 2e-3
+        # never more than one bf16 ulp, plus the approximation's absolute error (5e-7 |a|, visible only where gelu(a) itself is ~0)
+        assert bool(((got.float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 4e-6 * float(ref.abs().max())).all())
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cpad,Cout", [(2, 16, 16, 3, 8, 128), (1, 5, 7, 3, 4, 32), (3, 8, 4, 1, 8, 64), (1, 32, 32, 4, 4, 256),
