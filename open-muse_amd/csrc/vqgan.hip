@@ -387,13 +387,16 @@ extern "C" int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* 
 // =================================================================================================================
 // The first convolution of an encoder (conv_in, muse/modeling_maskgit_vqgan.py:175: 3 image channels -> hidden_channels, 3x3,
 // padding 1) as a direct f32 convolution on the vector ALUs: K = 27 is no matrix-core problem - the implicit-GEMM kernels spend the
-// launch on their 128 x 128 epilogue and write the 2.1 GB output of a 64 x 256 x 256 batch in partial lines (1.2 TB/s).  Here a thread
-// keeps the 27 x 4 weights of its four output channels in registers and walks the pixels of one image row; the 32 lanes of a pixel
-// read the same nine input vectors and store 512 contiguous bytes.  Exact f32 products; 1.35 ms on that batch (vector-ALU issue
-// bound: ~250 instructions per pixel and thread around the 108 fmas; a plain 2.1 GB fill takes 0.31 ms).
+// launch on their 128 x 128 epilogue and write the 2.1 GB output of a 64 x 256 x 256 batch in partial lines (1.51 ms).  Here a block
+// owns one image row: its three input rows go to LDS once, a thread keeps the 27 x 4 weights of its four output channels in registers
+// (as pairs: one v_pk_fma_f32 feeds two accumulators) and walks the row's pixels; the 32 lanes of a pixel read the same nine LDS
+// vectors and store 512 contiguous bytes.  Exact f32 products.  0.76 ms on that batch with the f64 GroupNorm sums (0.63 without; a
+// plain 2.1 GB fill takes 0.31 ms).  The first version read its inputs from global memory a pixel ahead and was bound by their
+// latency at two waves per SIMD (1.3 ms whatever the ALU count).
 // x: [B, H, W, Cpad] f32 (channels >= Cin are ignored), w4: [Cout][9][4] f32 (channel 3 zero when Cin == 3), out [B, H, W, Cout].
 // gn_partial (optional): [B, H, groups, 2] f64 sums of the output, one chunk per image row (groups of exactly four channels).
 // =================================================================================================================
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_direct_kernel(const float* __restrict__ x, const float* __restrict__ w4,
                                                              const float* __restrict__ bias, float* __restrict__ out,
@@ -402,47 +405,51 @@ __global__ __launch_bounds__(256) void conv_in_direct_kernel(const float* __rest
   const int qpp = Cout >> 2;                                   // channel quads (= threads) per pixel: divides 256
   const int cq = threadIdx.x % qpp, px0 = threadIdx.x / qpp, pstep = 256 / qpp;
   const int row = blockIdx.x, yy = row % H;                    // row = b * H + y
-  f32x4 wk[9][4];                                              // [tap][out channel j] = weights of the (<= 4) input channels
+  // weights of this thread's four output channels as PAIRS (j, j+1): one v_pk_fma_f32 feeds two accumulators from one input value
+  f32x2_t wk[9][CIN][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wk[t][j] = *(const f32x4*)(w4 + ((long)(cq * 4 + j) * 9 + t) * 4);
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+        wk[t][c][jp] = f32x2_t{w4[((long)(cq * 4 + 2 * jp) * 9 + t) * 4 + c], w4[((long)(cq * 4 + 2 * jp + 1) * 9 + t) * 4 + c]};
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias) bv = *(const f32x4*)(bias + cq * 4);
+  // the three input rows of this image row (first four channels of every pixel, one zero pixel either side, zero rows outside the
+  // image) are staged in LDS ONCE: the per-pixel loop then has no global load in it - with one pixel of look-ahead and two waves per
+  // SIMD it was bound by the memory latency of its nine loads per pixel (1.3 ms on the 64 x 256 x 256 batch, whatever the ALU count)
+  extern __shared__ __attribute__((aligned(16))) unsigned char cin_smem[];
+  f32x4* xs = (f32x4*)cin_smem;                               // [3][W + 2]
+  for (int i = threadIdx.x; i < 3 * (W + 2); i += 256) {
+    const int ky = i / (W + 2), ix = i - ky * (W + 2) - 1;
+    const bool ok = (ky == 1 || (ky == 0 ? yy > 0 : yy + 1 < H)) && ix >= 0 && ix < W;
+    xs[i] = ok ? *(const f32x4*)(x + ((long)(row + ky - 1) * W + ix) * Cpad) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
   double gs = 0.0, gq = 0.0;
-  // the nine input vectors of a pixel (zeros outside the image) - fetched one pixel ahead of the 27 x 4 fma chain that uses them.
-  // (A sliding 3 x 3 window over consecutive pixels - three loads per pixel instead of nine - was measured: 256 VGPRs, 1.30 -> 1.84 ms
-  //  on the 64 x 256 x 256 batch; the nine loads of a pixel hit the same two addresses per wave and cost little.)
-  f32x4 vn[9];
-  auto fetch = [&](int xx) {
+  auto pixel = [&](int xx) {
+    f32x2_t a01 = {bv[0], bv[1]}, a23 = {bv[2], bv[3]};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int iy = yy + ky - 1, ix = xx + kx - 1;
-        vn[ky * 3 + kx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? *(const f32x4*)(x + ((long)(row + ky - 1) * W + ix) * Cpad)
-                                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = xs[ky * (W + 2) + xx + kx];           // pixel xx + kx - 1 of input row ky (all lanes of a pixel: one address)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const f32x2_t in2 = {v[c], v[c]};
+          a01 = __builtin_elementwise_fma(in2, wk[ky * 3 + kx][c][0], a01);
+          a23 = __builtin_elementwise_fma(in2, wk[ky * 3 + kx][c][1], a23);
+        }
       }
-  };
-  if (px0 < W) fetch(px0);
-  for (int xx = px0; xx < W; xx += pstep) {
-    f32x4 v[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = vn[t];
-    if (xx + pstep < W) fetch(xx + pstep);
-    f32x4 acc = bv;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) acc[j] = fmaf(v[t][c], wk[t][j][c], acc[j]);
+    const f32x4 acc = {a01[0], a01[1], a23[0], a23[1]};
     *(f32x4*)(out + ((long)row * W + xx) * Cout + cq * 4) = acc;
     if (gn_partial) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { gs += (double)acc[j]; gq += (double)acc[j] * (double)acc[j]; }
     }
-  }
+  };
+  for (int xx = px0; xx < W; xx += pstep) pixel(xx);
   if (gn_partial) {      // one group = one channel quad: fold the pstep pixel lanes of each quad in a fixed order
     red[0][threadIdx.x] = gs; red[1][threadIdx.x] = gq;
     __syncthreads();
@@ -462,7 +469,9 @@ extern "C" int muse_conv_in_direct(const float* x, const float* w4, const float*
   if ((((uintptr_t)x) | ((uintptr_t)w4) | ((uintptr_t)bias) | ((uintptr_t)out)) & 15) return MUSE_ERR_ALIGN;
   if ((long)batch * H <= 0) return 0;
   if ((long)batch * H >= (1L << 31)) return MUSE_ERR_UNSUPPORTED;
-#define CID(N) hipLaunchKernelGGL(conv_in_direct_kernel<N>, dim3((unsigned)(batch * H)), dim3(256), 0, (hipStream_t)stream, x, w4, bias, out, \
+  const size_t lds = (size_t)3 * (W + 2) * 16;
+  if (lds > 48 * 1024) return MUSE_ERR_UNSUPPORTED;              // (W <= 1022)
+#define CID(N) hipLaunchKernelGGL(conv_in_direct_kernel<N>, dim3((unsigned)(batch * H)), dim3(256), lds, (hipStream_t)stream, x, w4, bias, out, \
                                   gn_partial, H, W, Cpad, Cout)
   if (Cin == 3) CID(3); else if (Cin == 4) CID(4); else if (Cin == 1) CID(1); else CID(2);
 #undef CID

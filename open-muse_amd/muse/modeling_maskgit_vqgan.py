@@ -179,7 +179,7 @@ class _ConvEngine:
         """the image-to-features convolution: in the bf16x3 mode a direct exact-f32 kernel (3 input channels are no matrix-core
         problem; ops.conv_in_direct), otherwise the mode's implicit GEMM"""
         cout, cin, k, _ = conv.weight.shape
-        if cd == "bf16x3" and self.direct_conv_in and ops.conv_in_direct_ok(cin, cout, k, cpad):
+        if cd == "bf16x3" and self.direct_conv_in and ops.conv_in_direct_ok(cin, cout, k, cpad, W):
             key = (id(conv), "direct")
             hit = self._packed.get(key)
             if hit is None:

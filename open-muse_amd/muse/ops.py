@@ -733,9 +733,11 @@ def conv2d_nhwc_split2(x_hi, x_lo, w_hi, w_lo, B, H, W, Cin, Cout, bias=None, re
     return out
 
 
-def conv_in_direct_ok(Cin, Cout, KS, Cpad):
-    """shapes muse_conv_in_direct takes: the image-to-features 3x3 convolution of an encoder"""
-    return KS == 3 and Cin <= 4 and Cpad % 4 == 0 and Cpad >= 4 and Cout % 4 == 0 and Cout // 4 <= 256 and 256 % (Cout // 4) == 0
+def conv_in_direct_ok(Cin, Cout, KS, Cpad, W=256):
+    """shapes muse_conv_in_direct takes: the image-to-features 3x3 convolution of an encoder (image rows of up to 1022 pixels: three
+    of them are staged in LDS)"""
+    return (KS == 3 and Cin <= 4 and Cpad % 4 == 0 and Cpad >= 4 and Cout % 4 == 0 and Cout // 4 <= 256 and 256 % (Cout // 4) == 0
+            and W <= 1022)
 
 
 def conv_in_direct(x, w4, B, H, W, Cin, Cpad, Cout, bias=None, gn_groups=0):
