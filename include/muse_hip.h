@@ -162,6 +162,8 @@ int muse_ffn_mid_bwd(const void* dhm, const void* h, const void* ab, const float
 /* y = gelu_erf(x); dx = dy * gelu'(x).  muse/modeling_transformer.py:981. */
 int muse_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream);
 int muse_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, void* stream);
+/* ... from f32 x / dy with the result written as bf16 (the dY operand of the next weight GEMMs in the bf16 compute mode) */
+int muse_gelu_bwd_f32_bf16(const float* x, const float* dy, void* dx_bf16, int64_t n, void* stream);
 
 /* Embed.forward (muse/modeling_transformer.py:942-957): out[b,s,:] = word[ids[b,s],:] + pos[s,:], f32 out.
  * bwd: deterministic (sorted by id on device, no float atomics): dword[v,:] (+)= sum over positions with id v,
@@ -358,6 +360,9 @@ int muse_silu_fwd(const float* x, float* y, int64_t n, void* stream);
 int muse_dwconv3x3_nhwc(const float* x, const float* w, float* y, int32_t batch, int32_t H, int32_t W, int32_t C, void* stream);
 int muse_grn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* scratch, int32_t batch, int64_t S,
                  int32_t C, void* stream);
+/* ... with the f32 result and / or its bf16 copy (the next GEMM's operand in the bf16 compute mode); either pointer may be null */
+int muse_grn_fwd_ex(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* scratch, int32_t batch,
+                    int64_t S, int32_t C, void* stream);
 int muse_sinusoidal_encode(const float* f, float* out, int64_t n, int32_t dim, float max_positions, void* stream);
 int muse_weighted_mean(const float* v, const float* w, float* out, int64_t n, void* stream);
 /* backward of the above (f32).  v = the forward's pre-norm sum x (+ res); dv = dx = dres; dw_partial [nblk, cols] is folded

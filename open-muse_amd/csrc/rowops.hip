@@ -1075,6 +1075,23 @@ extern "C" int muse_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, v
   else hipLaunchKernelGGL((gelu_kernel<bf16_t, 0>), dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, (long)n);
   return (int)hipGetLastError();
 }
+// dx = dy * gelu'(x) from f32 x / dy, written as bf16: the dY operand of the next weight GEMMs in the bf16 compute mode (what a cast
+// pass over the f32 result would produce, bit for bit)
+__global__ void gelu_bwd_f32_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dy, bf16_t* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 a = *(const f32x4*)(x + i * 4), d = *(const f32x4*)(dy + i * 4);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = d[j] * gelu_erf_grad(a[j]);
+    *(u32x2*)(out + i * 4) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+  }
+}
+extern "C" int muse_gelu_bwd_f32_bf16(const float* x, const float* dy, void* dx_bf16, int64_t n, void* stream) {
+  if (n % 4) return MUSE_ERR_BAD_ARG;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gelu_bwd_f32_bf16_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, (bf16_t*)dx_bf16, (long)(n / 4));
+  return (int)hipGetLastError();
+}
 extern "C" int muse_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, void* stream) {
   if (n % 4) return MUSE_ERR_BAD_ARG;
   if (n <= 0) return 0;

@@ -287,17 +287,48 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict_
     y[i] = gamma[c] * (v * nx[b * C + c]) + beta[c] + v;
   }
 }
-extern "C" int muse_grn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* scratch, int32_t batch,
-                            int64_t S, int32_t C, void* stream) {
+// C % 4 == 0: four channels per thread, the image in blockIdx.y (no 64-bit index division per element), f32 and / or bf16 output -
+// the bf16 copy is the next GEMM's operand in the bf16 compute mode, written here instead of by a cast pass over the f32 result
+__global__ __launch_bounds__(256) void grn_apply4_kernel(const float* __restrict__ x, const float* __restrict__ nx,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ y, bf16_t* __restrict__ yb, int S, int C) {
+  const int vpp = C >> 2, b = blockIdx.y;
+  const long base = (long)b * S * C;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < S * vpp; i += gridDim.x * 256) {
+    const int c = (i % vpp) * 4;
+    const long e = base + (long)(i / vpp) * C + c;
+    const f32x4 v = *(const f32x4*)(x + e), nn = *(const f32x4*)(nx + (long)b * C + c);
+    const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = ga[j] * (v[j] * nn[j]) + be[j] + v[j];
+    if (y) *(f32x4*)(y + e) = o;
+    if (yb) *(u32x2*)(yb + e) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+  }
+}
+extern "C" int muse_grn_fwd_ex(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* scratch,
+                               int32_t batch, int64_t S, int32_t C, void* stream) {
   const long n = (long)batch * S * C;
   if (n <= 0) return 0;
+  if (!y && !y_bf16) return MUSE_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* nx = scratch + (long)batch * C;   // scratch = [G | N], both kept for the backward
   hipLaunchKernelGGL(grn_colnorm_kernel, dim3((C + 63) / 64, batch), dim3(256), 0, s, x, scratch, (long)S, C);
   hipLaunchKernelGGL(grn_scale_kernel, dim3(batch), dim3(256), 0, s, (const float*)scratch, nx, C);
+  if ((C & 3) == 0 && S * (long)(C >> 2) < (1L << 31) && batch <= 65535 && !((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)y_bf16)) & 15)) {
+    long gx = (S * (long)(C >> 2) + 255) / 256; if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(grn_apply4_kernel, dim3((unsigned)gx, batch), dim3(256), 0, s, x, (const float*)nx, gamma, beta, y, (bf16_t*)y_bf16,
+                       (int)S, C);
+    return (int)hipGetLastError();
+  }
+  if (y_bf16) return MUSE_ERR_UNSUPPORTED;
   long g = (n + 255) / 256; if (g > 65535) g = 65535;
   hipLaunchKernelGGL(grn_apply_kernel, dim3((unsigned)g), dim3(256), 0, s, x, (const float*)nx, gamma, beta, y, (long)S, C, n);
   return (int)hipGetLastError();
+}
+extern "C" int muse_grn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* scratch, int32_t batch,
+                            int64_t S, int32_t C, void* stream) {
+  return muse_grn_fwd_ex(x, gamma, beta, y, nullptr, scratch, batch, S, C, stream);
 }
 
 // =================================================================================================================

@@ -76,6 +76,7 @@ SIGNATURES = {
                          c_void_p],
     "muse_gelu_fwd": [c_void_p, c_void_p, c_int, c_i64, c_void_p],
     "muse_gelu_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p],
+    "muse_gelu_bwd_f32_bf16": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "muse_embed_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "muse_embed_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "muse_embed_bwd_scratch_floats": [c_int, c_int],
@@ -127,6 +128,7 @@ SIGNATURES = {
     "muse_silu_fwd": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_dwconv3x3_nhwc": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "muse_grn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
+    "muse_grn_fwd_ex": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_sinusoidal_encode": [c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p],
     "muse_weighted_mean": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "muse_norm_res_bwd_nblk": [c_i64],

@@ -260,7 +260,9 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         ga = ops.gelu_fwd(a)
         grn = blk.channelwise["2"]
         gamma = self._f(grn.gamma).reshape(-1).contiguous()
-        g, stats = ops.grn_fwd(ga, gamma, self._f(grn.beta).reshape(-1).contiguous(), B, side * side, want_stats=True)
+        # (g is only ever a GEMM operand - forward product and the dW product of the backward: bf16 mode gets it as bf16 from the kernel)
+        g, stats = ops.grn_fwd(ga, gamma, self._f(grn.beta).reshape(-1).contiguous(), B, side * side, want_stats=True,
+                               out_dtype=self.compute_dtype)
         x = self._lin(g, blk.channelwise["4"], residual=h)                          # + x_res (:616)
         y, sva = self._adaln(x, blk.adaLN_modulation, scond, B)
         return y, dict(h=h, d=d, n=n, a=a, ga=ga, g=g, stats=stats, gamma=gamma, wdw=wdw, ada=sva, side=side)
@@ -274,7 +276,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         grn = blk.channelwise["2"]
         G[name + ".channelwise.2.gamma"] = dgam.view(grn.gamma.shape)
         G[name + ".channelwise.2.beta"] = dbet.view(grn.beta.shape)
-        da = ops.gelu_bwd(sv["a"], dga)
+        da = ops.gelu_bwd(sv["a"], dga, out_dtype=self.compute_dtype)               # (only the dY of channelwise.0's dW / dX products)
         dn = self._lin_bwd(da, sv["n"], blk.channelwise["0"], name + ".channelwise.0", G)
         dd = self._norm_bwd(dn, sv["d"], blk.norm.norm, name + ".norm.norm", G)
         dh, dwdw = ops.dwconv3x3_bwd(dd, sv["h"], sv["wdw"], B, side, side, C)

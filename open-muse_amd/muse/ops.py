@@ -485,8 +485,13 @@ def gelu_fwd(x):
     return y
 
 
-def gelu_bwd(x, dy):
+def gelu_bwd(x, dy, out_dtype=None):
+    """out_dtype=torch.bfloat16 with f32 x / dy: the result written directly as the bf16 operand of the next weight GEMMs"""
     require_gpu(x, dy)
+    if out_dtype == torch.bfloat16 and x.dtype == torch.float32 and dy.dtype == torch.float32:
+        dx = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        check(lib().muse_gelu_bwd_f32_bf16(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), stream()), "muse_gelu_bwd_f32_bf16")
+        return dx
     dx = torch.empty_like(x)
     check(lib().muse_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), dt(x), x.numel(), stream()), "muse_gelu_bwd")
     return dx
@@ -963,14 +968,16 @@ def dwconv3x3_nhwc(x, w, B, H, W, C_):
     return y
 
 
-def grn_fwd(x, gamma, beta, B, S, want_stats=False):
-    """GlobalResponseNorm over the S pixels of each image; x [B*S, C]"""
+def grn_fwd(x, gamma, beta, B, S, want_stats=False, out_dtype=torch.float32):
+    """GlobalResponseNorm over the S pixels of each image; x [B*S, C] f32.  out_dtype=torch.bfloat16: the result is written
+    only as the bf16 GEMM operand of the bf16 compute mode (no f32 copy, no cast pass)"""
     require_gpu(x, gamma, beta)
     C_ = x.shape[1]
-    y = torch.empty_like(x)
+    bf = out_dtype == torch.bfloat16 and C_ % 4 == 0
+    y = torch.empty(x.shape, dtype=torch.bfloat16 if bf else torch.float32, device=x.device)
     stats = torch.empty(2 * B * C_, dtype=torch.float32, device=x.device)   # [G | N], kept for grn_bwd
-    check(lib().muse_grn_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, S, C_, stream()),
-          "muse_grn_fwd")
+    check(lib().muse_grn_fwd_ex(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None if bf else y.data_ptr(), y.data_ptr() if bf else None,
+                                stats.data_ptr(), B, S, C_, stream()), "muse_grn_fwd_ex")
     return (y, stats) if want_stats else y
 
 

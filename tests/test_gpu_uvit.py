@@ -387,3 +387,19 @@ def test_cached_bf16_weights_never_go_stale_across_stackings(golden_dir):
     for mods in ((att.query,), (att.query, att.key, att.value), (att.key, att.value)):
         want = ops.cast_to_bf16(torch.cat([x.weight.data.reshape(x.weight.shape[0], -1) for x in mods]).contiguous())
         assert torch.equal(m._wb(*mods).view(torch.int16), want.view(torch.int16)), len(mods)
+
+
+def test_bf16_operand_outputs_of_grn_and_gelu_backward_equal_a_cast_of_the_f32_results():
+    """bf16 compute mode: GlobalResponseNorm and the GELU backward of a ResBlock write their result directly as the bf16 operand
+    of the next weight GEMMs (muse_grn_fwd_ex, muse_gelu_bwd_f32_bf16) - the same bits a cast pass over the f32 result gives"""
+    ops = _ops()
+    B, S, C = 3, 64, 256
+    x = rnd((B * S, C), 91).to(DEV)
+    gamma, beta = rnd((C,), 92).to(DEV), rnd((C,), 93).to(DEV)
+    y32, st32 = ops.grn_fwd(x, gamma, beta, B, S, want_stats=True)
+    y16, st16 = ops.grn_fwd(x, gamma, beta, B, S, want_stats=True, out_dtype=torch.bfloat16)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.to(torch.bfloat16)) and torch.equal(st16, st32)
+    dy = rnd((B * S, C), 94).to(DEV)
+    d32 = ops.gelu_bwd(x, dy)
+    d16 = ops.gelu_bwd(x, dy, out_dtype=torch.bfloat16)
+    assert d16.dtype == torch.bfloat16 and torch.equal(d16, d32.to(torch.bfloat16))
