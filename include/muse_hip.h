@@ -376,6 +376,20 @@ int muse_norm_res_bwd(const float* dy, const float* dpre, const float* v, const 
 /* ... also writing a bf16 copy of dv (may be null) */
 int muse_norm_res_bwd_ex(const float* dy, const float* dpre, const float* v, const float* w, float* dv, void* dv_bf16,
                          float* dw_partial, int64_t rows, int32_t cols, float eps, int32_t mode, void* stream);
+/* Norm + AdaLN as one op (every norm of a MaskGiTUViT_v2 TransformerLayer feeds an AdaLNModulation, :757-792):
+ *   fwd: v = x (+ res); pre = v (optional); n = Norm(v) * w (mode 0 RMSNorm / 1 LayerNorm); m[b,r,:] = n * (1 + ss[b,:C]) + ss[b,C:],
+ *        written as f32 (m) and / or bf16 (m_bf16); n itself is not written.  cols % 4 == 0, cols <= 1024.
+ *   bwd: dm = d(m), dpre = the gradient that reached `pre` directly (optional), v = pre.  dv = d(x) = d(res) (+ bf16 copy, optional);
+ *        dw_partial [nblk, cols] (muse_colsum -> d(w)); dss_partial [nblk, 2 cols] = (sum dm n | sum dm) over each block's 16 rows,
+ *        nblk = muse_norm_res_bwd_nblk(rows); rows_per_batch % 16 == 0, so image b owns rows_per_batch / 16 consecutive blocks:
+ *        muse_colsum_segments(dss_partial, dss, batch, rows_per_batch / 16, 2 cols) gives d(ss) [batch, 2 cols].
+ * muse_colsum_segments: out[s, c] = sum_{k < seg_rows} part[s * seg_rows + k, c], fixed order. */
+int muse_norm_adaln_fwd(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* m_bf16,
+                        int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream);
+int muse_norm_adaln_bwd(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv, void* dv_bf16,
+                        float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch, int32_t cols, float eps,
+                        int32_t mode, void* stream);
+int muse_colsum_segments(const float* part, float* out, int32_t nseg, int32_t seg_rows, int32_t cols, void* stream);
 int muse_adaln_bwd(const float* dy, const float* x, const float* ss, float* dx, float* dss, int32_t batch,
                    int64_t rows_per_batch, int32_t C, void* stream);
 int muse_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);

@@ -579,6 +579,235 @@ extern "C" int muse_norm_res_bwd(const float* dy, const float* dpre, const float
   return muse_norm_res_bwd_ex(dy, dpre, v, w, dv, nullptr, dw_partial, rows, cols, eps, mode, stream);
 }
 
+// =================================================================================================================
+// Norm + AdaLN fused (TransformerLayer :757-792: every norm of a layer is followed by an AdaLNModulation of its output).
+//   fwd: v = x (+ res); pre = v; n = Norm(v) * w; m[b, r, :] = n * (1 + ss[b, :C]) + ss[b, C:]  - n is never written
+//        (22 -> 14 bytes per element against muse_norm_res_fwd + muse_adaln_fwd_ex).
+//   bwd: n is recomputed from v; dn = dm (1 + scale); per-block column sums of dm * n and dm (-> d(scale | shift) of the block's
+//        image), then the norm backward of muse_norm_res_bwd on dn - one pass instead of adaln_bwd_dx + adaln_bwd_ss + norm_res_bwd
+//        (~34 -> 18 bytes per element).  16 rows per block, all of one image (rows_per_batch % 16 == 0); cols <= 1024.
+// =================================================================================================================
+template <int NIT>
+__global__ __launch_bounds__(256) void norm_adaln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ w, const float* __restrict__ ss,
+                                                             float* __restrict__ pre, float* __restrict__ m, bf16_t* __restrict__ mb,
+                                                             long rows, long rpb, int cols, float eps, int mode) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sb = ss + (row / rpb) * 2 * cols;
+  f32x4 v[NIT];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = lane * 4 + 256 * it;
+    if (c < cols) {
+      v[it] = *(const f32x4*)(x + row * cols + c);
+      if (res) v[it] += *(const f32x4*)(res + row * cols + c);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = lane * 4 + 256 * it;
+    if (c < cols) {
+      if (pre) *(f32x4*)(pre + row * cols + c) = v[it];
+      s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+      q += (v[it][0] * v[it][0] + v[it][1] * v[it][1]) + (v[it][2] * v[it][2] + v[it][3] * v[it][3]);
+    }
+  }
+  float mean = 0.f, rstd;
+  if (mode == 0) {
+    rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+  } else {
+    mean = wave_sum(s) / (float)cols;
+    float d2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (lane * 4 + 256 * it < cols) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[it][j] - mean; d2 = fmaf(d, d, d2); }
+      }
+    rstd = 1.0f / sqrtf(wave_sum(d2) / (float)cols + eps);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = lane * 4 + 256 * it;
+    if (c < cols) {
+      f32x4 g = {1.f, 1.f, 1.f, 1.f};
+      if (w) g = *(const f32x4*)(w + c);
+      const f32x4 sc = *(const f32x4*)(sb + c), sh = *(const f32x4*)(sb + cols + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float n = (v[it][j] - mean) * rstd * g[j];
+        o[j] = n * (1.0f + sc[j]) + sh[j];
+      }
+      if (m) *(f32x4*)(m + row * cols + c) = o;
+      if (mb) *(u32x2*)(mb + row * cols + c) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+    }
+  }
+}
+extern "C" int muse_norm_adaln_fwd(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* m_bf16,
+                                   int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
+  if (cols % 4 || cols > 1024 || (mode != 0 && mode != 1) || (!m && !m_bf16)) return MUSE_ERR_UNSUPPORTED;
+  const long rows = (long)batch * rows_per_batch;
+  if (rows <= 0) return 0;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define NAF(N) hipLaunchKernelGGL(norm_adaln_fwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, res, w, ss, pre, m, (bf16_t*)m_bf16, rows, \
+                                  (long)rows_per_batch, cols, eps, mode)
+  if (cols <= 256) NAF(1); else if (cols <= 512) NAF(2); else if (cols <= 768) NAF(3); else NAF(4);
+#undef NAF
+  return (int)hipGetLastError();
+}
+
+template <int NIT>
+__global__ __launch_bounds__(256) void norm_adaln_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ dpre,
+                                                             const float* __restrict__ v, const float* __restrict__ w,
+                                                             const float* __restrict__ ss, float* __restrict__ dv, bf16_t* __restrict__ dvb,
+                                                             float* __restrict__ dwp, float* __restrict__ dssp, long rows, long rpb,
+                                                             int cols, float eps, int mode) {
+  __shared__ float red[1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* sb = ss + (((long)blockIdx.x * NRB_ROWS) / rpb) * 2 * cols;       // the block's image
+  f32x4 wv4[NIT], sc1[NIT];
+  float dwacc[NIT][4], dsc[NIT][4], dsh[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = lane * 4 + 256 * it;
+    wv4[it] = (w && c < cols) ? *(const f32x4*)(w + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+    sc1[it] = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (c < cols) sc1[it] += *(const f32x4*)(sb + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dwacc[it][j] = 0.f; dsc[it][j] = 0.f; dsh[it][j] = 0.f; }
+  }
+  const long row0 = (long)blockIdx.x * NRB_ROWS + wave * (NRB_ROWS / 4);
+  f32x4 tn[NIT], dn_[NIT], pn[NIT];
+  auto fetch = [&](long row) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = lane * 4 + 256 * it;
+      if (row < rows && c < cols) {
+        tn[it] = *(const f32x4*)(v + row * cols + c);
+        dn_[it] = *(const f32x4*)(dm + row * cols + c);
+        if (dpre) pn[it] = *(const f32x4*)(dpre + row * cols + c);
+      }
+    }
+  };
+  fetch(row0);
+  for (int rr = 0; rr < NRB_ROWS / 4; ++rr) {
+    const long row = row0 + rr;
+    if (row >= rows) break;
+    f32x4 t[NIT], d[NIT], pr[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { t[it] = tn[it]; d[it] = dn_[it]; pr[it] = pn[it]; }
+    if (rr + 1 < NRB_ROWS / 4) fetch(row + 1);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (lane * 4 + 256 * it < cols) {
+        s += (t[it][0] + t[it][1]) + (t[it][2] + t[it][3]);
+        q += (t[it][0] * t[it][0] + t[it][1] * t[it][1]) + (t[it][2] * t[it][2] + t[it][3] * t[it][3]);
+      }
+    float mean = 0.f, rstd;
+    if (mode == 0) {
+      rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    } else {
+      mean = wave_sum(s) / (float)cols;
+      float d2 = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (lane * 4 + 256 * it < cols) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float dd = t[it][j] - mean; d2 = fmaf(dd, dd, d2); }
+        }
+      rstd = 1.0f / sqrtf(wave_sum(d2) / (float)cols + eps);
+    }
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (lane * 4 + 256 * it < cols) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (t[it][j] - mean) * rstd;
+          const float n = xh * wv4[it][j];                       // == the forward's (v - mean) * rstd * w
+          dsc[it][j] = fmaf(d[it][j], n, dsc[it][j]);
+          dsh[it][j] += d[it][j];
+          const float dn = d[it][j] * sc1[it][j];                // d(norm output)
+          d[it][j] = dn;
+          const float g = dn * wv4[it][j];
+          sg += g;
+          sgx = fmaf(g, xh, sgx);
+          dwacc[it][j] = fmaf(dn, xh, dwacc[it][j]);
+        }
+      }
+    const float mg = mode == 0 ? 0.f : wave_sum(sg) / (float)cols;
+    const float mgx = wave_sum(sgx) / (float)cols;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = lane * 4 + 256 * it;
+      if (c < cols) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (d[it][j] * wv4[it][j] - mg - (t[it][j] - mean) * rstd * mgx);
+        if (dpre) o += pr[it];
+        *(f32x4*)(dv + row * cols + c) = o;
+        if (dvb) *(u32x2*)(dvb + row * cols + c) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+      }
+    }
+  }
+  // fold the four waves' column partials in wave order: dw, then d(scale), then d(shift)
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    for (int wv = 0; wv < 4; ++wv) {
+      if (wave == wv) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int c = lane * 4 + 256 * it;
+          if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float a = which == 0 ? dwacc[it][j] : (which == 1 ? dsc[it][j] : dsh[it][j]);
+              red[c + j] = wv == 0 ? a : red[c + j] + a;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float* dst = which == 0 ? dwp + (long)blockIdx.x * cols : dssp + (long)blockIdx.x * 2 * cols + (which == 2 ? cols : 0);
+    for (int c = threadIdx.x; c < cols; c += 256) dst[c] = red[c];
+    __syncthreads();
+  }
+}
+extern "C" int muse_norm_adaln_bwd(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
+                                   void* dv_bf16, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
+                                   int32_t cols, float eps, int32_t mode, void* stream) {
+  if (cols % 4 || cols > 1024 || (mode != 0 && mode != 1) || (rows_per_batch % NRB_ROWS)) return MUSE_ERR_UNSUPPORTED;
+  const long rows = (long)batch * rows_per_batch;
+  if (rows <= 0) return 0;
+  const int nblk = muse_norm_res_bwd_nblk(rows);
+#define NAB(N) hipLaunchKernelGGL(norm_adaln_bwd_kernel<N>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dm, dpre, v, w, ss, dv, (bf16_t*)dv_bf16, \
+                                  dw_partial, dss_partial, rows, (long)rows_per_batch, cols, eps, mode)
+  if (cols <= 256) NAB(1); else if (cols <= 512) NAB(2); else if (cols <= 768) NAB(3); else NAB(4);
+#undef NAB
+  return (int)hipGetLastError();
+}
+// out[s, c] = sum_{k < seg_rows} part[s * seg_rows + k, c]   (fixed order): the per-image fold of norm_adaln_bwd's d(scale | shift) partials
+__global__ __launch_bounds__(256) void colsum_segments_kernel(const float* __restrict__ part, float* __restrict__ out, int seg_rows, int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const float* p = part + (long)blockIdx.y * seg_rows * cols + c;
+  float s = 0.f;
+  for (int k = 0; k < seg_rows; ++k) s += p[(long)k * cols];
+  out[(long)blockIdx.y * cols + c] = s;
+}
+extern "C" int muse_colsum_segments(const float* part, float* out, int32_t nseg, int32_t seg_rows, int32_t cols, void* stream) {
+  if (nseg <= 0 || cols <= 0) return 0;
+  if (nseg > 65535) return MUSE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(colsum_segments_kernel, dim3((cols + 255) / 256, nseg), dim3(256), 0, (hipStream_t)stream, part, out, seg_rows, cols);
+  return (int)hipGetLastError();
+}
+
 // AdaLN backward: dx = dy (1 + scale[b]);  dss[b, c] = sum_r dy x,  dss[b, C + c] = sum_r dy   (r over the rows of image b)
 __global__ __launch_bounds__(256) void adaln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ ss,
                                                            float* __restrict__ dx, long rows_per_batch, int C, long n4) {

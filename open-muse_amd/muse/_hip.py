@@ -135,6 +135,9 @@ SIGNATURES = {
     "muse_norm_res_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p],
     "muse_norm_res_bwd_ex": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_int, c_void_p],
     "muse_adaln_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
+    "muse_norm_adaln_fwd": [c_void_p] * 7 + [c_int, c_i64, c_int, c_float, c_int, c_void_p],
+    "muse_norm_adaln_bwd": [c_void_p] * 9 + [c_int, c_i64, c_int, c_float, c_int, c_void_p],
+    "muse_colsum_segments": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "muse_silu_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "muse_dwconv3x3_bwd_nchunk": [c_i64],
     "muse_dwconv3x3_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

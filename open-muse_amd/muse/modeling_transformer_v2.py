@@ -218,6 +218,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         self.mlm_layer = _Mlm(C, cin, c.codebook_size)
         self.compute_dtype = torch.float32
         self.wgrad_stream = os.environ.get("MUSE_WGRAD_STREAM", "1") != "0"   # bf16 mode: weight-gradient GEMMs on a second HIP stream
+        self.fuse_norm_adaln = os.environ.get("MUSE_NORM_ADALN", "1") != "0"  # norm + AdaLN of a transformer layer as one kernel (fwd and bwd)
         self._side_stream = None
         self._init_weights()
 
@@ -250,6 +251,35 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         d = self._lin_bwd(dss, scond, mod.mapper, name + ".mapper", G)
         dscond.add_(d)            # every AdaLN reads the same silu(cond): sum of a [B, H] tensor (plumbing)
         return dx
+
+    def _norm_adaln(self, x, norm_mod, ada: _AdaLN, scond, B, mode=0, residual=None):
+        """norm(x + residual) followed by its AdaLN modulation (TransformerLayer :757-792) as ONE kernel where the shape allows: the
+        norm output itself is never written.  -> (m = GEMM operand of the next block, v = x + residual, tape entry)"""
+        ss = self._lin(scond, ada.mapper)
+        if self.fuse_norm_adaln and ops.norm_adaln_ok(x.shape[0], x.shape[1], B):
+            od = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
+            m, v = ops.norm_adaln_fwd(x, self._f(norm_mod.weight), ss, B, float(self.config.layer_norm_eps), mode, residual=residual,
+                                      out_dtype=od)
+            return m, v, dict(ss=ss, fused=True)
+        n, v = self._norm(x, norm_mod, mode=mode, residual=residual, want_pre=True)
+        od = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
+        return ops.adaln_fwd(n, ss, B, out_dtype=od), v, dict(x=n, ss=ss)
+
+    def _norm_adaln_bwd(self, dm, sv, v, norm_mod, norm_name, ada: _AdaLN, ada_name, G, scond, dscond, B, mode=0, dpre=None):
+        """-> d(x) = d(residual) of _norm_adaln; the bf16 copy of it (dY of the next weight GEMMs) rides in the activation cache"""
+        if not sv.get("fused"):
+            dn = self._adaln_bwd(dm, sv, ada, ada_name, G, scond, dscond, B)
+            return self._norm_bwd(dn, v, norm_mod, norm_name, G, mode=mode, dpre=dpre, gemm_operand=True)
+        eps = float(self.config.layer_norm_eps)
+        if self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 2:
+            dv, dw, dss, dvb = ops.norm_adaln_bwd(dm, v, self._f(norm_mod.weight), sv["ss"], B, eps, mode, dpre=dpre, also_bf16=True)
+            self.__dict__.setdefault("_act_cache", {})[id(dv)] = (dv, dvb)
+        else:
+            dv, dw, dss = ops.norm_adaln_bwd(dm, v, self._f(norm_mod.weight), sv["ss"], B, eps, mode, dpre=dpre)
+        G[norm_name + ".weight"] = dw
+        d = self._lin_bwd(dss, scond, ada.mapper, ada_name + ".mapper", G)
+        dscond.add_(d)
+        return dv
 
     def _res_block(self, h, blk: _ResBlock, scond, B, side):
         C = h.shape[1]
@@ -348,14 +378,12 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         nh = c.num_attention_heads
         T["layers"] = []
         for lyr in self.transformer_layers:                                           # TransformerLayer :757-792
-            n1, res1 = self._norm(t, lyr.attn_layer_norm, residual=res, want_pre=True)
-            m1, a1s = self._adaln(n1, lyr.self_attn_adaLN_modulation, scond, B, gemm_operand=True)
+            m1, res1, a1s = self._norm_adaln(t, lyr.attn_layer_norm, lyr.self_attn_adaLN_modulation, scond, B, residual=res)
             a, s1 = self._attention(m1, m1, lyr.attention, B, S, S, nh)
-            n2, res2 = self._norm(a, lyr.crossattn_layer_norm, residual=res1, want_pre=True)
-            m2, a2s = self._adaln(n2, lyr.cross_attn_adaLN_modulation, scond, B, gemm_operand=True)
+            m2, res2, a2s = self._norm_adaln(a, lyr.crossattn_layer_norm, lyr.cross_attn_adaLN_modulation, scond, B, residual=res1)
             a2, s2 = self._attention(m2, enc, lyr.crossattention, B, S, L, nh)
-            n3, res3 = self._norm(a2, lyr.ffn.pre_mlp_layer_norm, mode=1, residual=res2, want_pre=True)   # LayerNorm (:928)
-            m3, a3s = self._adaln(n3, lyr.ffn.adaLN_modulation, scond, B, gemm_operand=True)
+            m3, res3, a3s = self._norm_adaln(a2, lyr.ffn.pre_mlp_layer_norm, lyr.ffn.adaLN_modulation, scond, B, mode=1,
+                                             residual=res2)                                                # LayerNorm (:928)
             w01 = self._w2(lyr.ffn.wi_0, lyr.ffn.wi_1)
             if self.compute_dtype == torch.bfloat16:
                 # the reference's autocast regime: the GLU input and output live in bf16 between the two GEMMs (no f32 round trip,
@@ -451,20 +479,17 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             I = gw01.shape[0] // 2
             G[nm + ".ffn.wi_0.weight"], G[nm + ".ffn.wi_1.weight"] = gw01[:I], gw01[I:]
             dm3 = self._mm_dx(dab, sv["w01"])
-            dn3 = self._adaln_bwd(dm3, sv["a3s"], lyr.ffn.adaLN_modulation, nm + ".ffn.adaLN_modulation", G, scond, dscond, B)
-            dv3 = self._norm_bwd(dn3, sv["res3"], lyr.ffn.pre_mlp_layer_norm, nm + ".ffn.pre_mlp_layer_norm", G, mode=1, dpre=dres,
-                                  gemm_operand=True)
+            dv3 = self._norm_adaln_bwd(dm3, sv["a3s"], sv["res3"], lyr.ffn.pre_mlp_layer_norm, nm + ".ffn.pre_mlp_layer_norm",
+                                       lyr.ffn.adaLN_modulation, nm + ".ffn.adaLN_modulation", G, scond, dscond, B, mode=1, dpre=dres)
             # cross attention (dv3 = d(a2) = d(res2))
             dm2, dctx = self._attention_bwd(dv3, sv["s2"], lyr.crossattention, nm + ".crossattention", G)
             denc.add_(dctx)
-            dn2 = self._adaln_bwd(dm2, sv["a2s"], lyr.cross_attn_adaLN_modulation, nm + ".cross_attn_adaLN_modulation", G, scond,
-                                  dscond, B)
-            dv2 = self._norm_bwd(dn2, sv["res2"], lyr.crossattn_layer_norm, nm + ".crossattn_layer_norm", G, dpre=dv3, gemm_operand=True)
+            dv2 = self._norm_adaln_bwd(dm2, sv["a2s"], sv["res2"], lyr.crossattn_layer_norm, nm + ".crossattn_layer_norm",
+                                       lyr.cross_attn_adaLN_modulation, nm + ".cross_attn_adaLN_modulation", G, scond, dscond, B, dpre=dv3)
             # self attention (dv2 = d(a) = d(res1))
             dm1, _ = self._attention_bwd(dv2, sv["s1"], lyr.attention, nm + ".attention", G, self_attn=True)
-            dn1 = self._adaln_bwd(dm1, sv["a1s"], lyr.self_attn_adaLN_modulation, nm + ".self_attn_adaLN_modulation", G, scond,
-                                  dscond, B)
-            dv1 = self._norm_bwd(dn1, sv["res1"], lyr.attn_layer_norm, nm + ".attn_layer_norm", G, dpre=dv2, gemm_operand=True)
+            dv1 = self._norm_adaln_bwd(dm1, sv["a1s"], sv["res1"], lyr.attn_layer_norm, nm + ".attn_layer_norm",
+                                       lyr.self_attn_adaLN_modulation, nm + ".self_attn_adaLN_modulation", G, scond, dscond, B, dpre=dv2)
             dt = dres = dv1                                                           # d(t_prev) = d(res_prev)
         pi = T["proj_in"]
         dn = self._lin_bwd(dt, pi["n"], self.project_to_hidden, "project_to_hidden", G)

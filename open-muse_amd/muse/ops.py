@@ -1041,6 +1041,40 @@ def norm_res_bwd(dy, v, w, eps, mode, dpre=None, want_dw=True, also_bf16=False):
     return (dv, dw, dvb) if also_bf16 else (dv, dw)
 
 
+def norm_adaln_ok(rows, cols, batch):
+    """shapes the fused norm + AdaLN kernels take (muse_norm_adaln_fwd / _bwd)"""
+    return cols % 4 == 0 and cols <= 1024 and rows % batch == 0 and (rows // batch) % 16 == 0
+
+
+def norm_adaln_fwd(x, w, ss, batch, eps, mode, residual=None, out_dtype=torch.float32):
+    """v = x (+ residual); m = Norm(v) * w * (1 + scale) + shift with (scale | shift) = ss [batch, 2C]  ->  (m in out_dtype, v)"""
+    require_gpu(x, ss)
+    rows, cols = x.shape
+    pre = torch.empty_like(x)
+    m = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
+    f32 = out_dtype == torch.float32
+    check(lib().muse_norm_adaln_fwd(x.data_ptr(), ptr(residual), ptr(w), ss.data_ptr(), pre.data_ptr(), m.data_ptr() if f32 else None,
+                                    None if f32 else m.data_ptr(), batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_fwd")
+    return m, pre
+
+
+def norm_adaln_bwd(dm, v, w, ss, batch, eps, mode, dpre=None, also_bf16=False):
+    """backward of norm_adaln_fwd -> (dv = dx = dres, dw, dss [batch, 2C][, bf16 copy of dv])"""
+    require_gpu(dm, v, ss)
+    rows, cols = v.shape
+    dv = torch.empty_like(v)
+    dvb = torch.empty(v.shape, dtype=torch.bfloat16, device=v.device) if also_bf16 else None
+    nblk = lib().muse_norm_res_bwd_nblk(rows)
+    part = torch.empty((nblk, cols), dtype=torch.float32, device=v.device)
+    spart = torch.empty((nblk, 2 * cols), dtype=torch.float32, device=v.device)
+    check(lib().muse_norm_adaln_bwd(dm.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), ss.data_ptr(), dv.data_ptr(), ptr(dvb), part.data_ptr(),
+                                    spart.data_ptr(), batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_bwd")
+    dw = colsum(part, torch.empty(cols, dtype=torch.float32, device=v.device))
+    dss = torch.empty((batch, 2 * cols), dtype=torch.float32, device=v.device)
+    check(lib().muse_colsum_segments(spart.data_ptr(), dss.data_ptr(), batch, nblk // batch, 2 * cols, stream()), "muse_colsum_segments")
+    return (dv, dw, dss, dvb) if also_bf16 else (dv, dw, dss)
+
+
 def adaln_bwd(dy, x, ss, batch):
     """-> (dx, dss [batch, 2C])"""
     require_gpu(dy, x, ss)

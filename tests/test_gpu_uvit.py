@@ -403,3 +403,32 @@ def test_bf16_operand_outputs_of_grn_and_gelu_backward_equal_a_cast_of_the_f32_r
     d32 = ops.gelu_bwd(x, dy)
     d16 = ops.gelu_bwd(x, dy, out_dtype=torch.bfloat16)
     assert d16.dtype == torch.bfloat16 and torch.equal(d16, d32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,S,C,mode,res", [(3, 16, 64, 0, True), (2, 32, 1024, 1, True), (4, 16, 768, 0, False), (2, 48, 256, 1, False)])
+def test_fused_norm_adaln_matches_the_two_kernel_route(B, S, C, mode, res):
+    """muse_norm_adaln_fwd / _bwd (norm + AdaLN of a MaskGiTUViT_v2 transformer layer in one pass; the norm output is never written,
+    the backward recomputes it) against norm_res_fwd -> adaln_fwd and adaln_bwd -> norm_res_bwd: forward bit-identical (f32 and the
+    bf16 operand copy), backward within f32 summation-order differences (the column sums of d(scale | shift) are folded per 16-row
+    block, then per image)"""
+    ops = _ops()
+    rows = B * S
+    x, r = rnd((rows, C), 61).to(DEV), (rnd((rows, C), 62).to(DEV) if res else None)
+    w = (1.0 + 0.2 * rnd((C,), 63)).to(DEV)
+    ss = (0.3 * rnd((B, 2 * C), 64)).to(DEV)
+    assert ops.norm_adaln_ok(rows, C, B)
+    n, pre = ops.norm_res_fwd(x, w, 1e-6, mode, residual=r, want_pre=True)
+    m_ref = ops.adaln_fwd(n, ss, B)
+    m, v = ops.norm_adaln_fwd(x, w, ss, B, 1e-6, mode, residual=r)
+    assert torch.equal(v, pre) and torch.equal(m, m_ref)
+    mb, _ = ops.norm_adaln_fwd(x, w, ss, B, 1e-6, mode, residual=r, out_dtype=torch.bfloat16)
+    assert torch.equal(mb, ops.adaln_fwd(n, ss, B, out_dtype=torch.bfloat16))
+    dm, dpre = rnd((rows, C), 65).to(DEV), rnd((rows, C), 66).to(DEV)
+    dn_ref, dss_ref = ops.adaln_bwd(dm, n, ss, B)
+    dv_ref, dw_ref = ops.norm_res_bwd(dn_ref, pre, w, 1e-6, mode, dpre=dpre)
+    dv, dw, dss, dvb = ops.norm_adaln_bwd(dm, v, w, ss, B, 1e-6, mode, dpre=dpre, also_bf16=True)
+    assert rel_err(dv, dv_ref) < 2e-6 and rel_err(dw, dw_ref) < 5e-6 and rel_err(dss, dss_ref) < 5e-6
+    assert torch.equal(dvb, dv.to(torch.bfloat16))
+    dv2, dw2, dss2 = ops.norm_adaln_bwd(dm, v, w, ss, B, 1e-6, mode)          # no residual-stream gradient, no bf16 copy
+    dv2_ref, _ = ops.norm_res_bwd(dn_ref, pre, w, 1e-6, mode)
+    assert rel_err(dv2, dv2_ref) < 2e-6 and torch.equal(dw2, dw) and torch.equal(dss2, dss)
