@@ -457,6 +457,21 @@ def main():
             prof = ops.profile_stop(with_kind=True)
             model.wgrad_stream = ws
             prof_bytes.update(ops.PROF_BYTES)
+            # the tokenizer once more with the GroupNorm applied by its own kernel (the two-kernel route the fused convolution replaced):
+            # the bare convolution's rate next to the fused kernel's, from the same process
+            if getattr(vq, "fuse_gn_apply", False):
+                vq.fuse_gn_apply = False
+                vq.get_code(px)
+                torch.cuda.synchronize()
+                ops.profile_start()
+                vq.get_code(px)
+                unf = ops.profile_stop(with_kind=True)
+                vq.fuse_gn_apply = True
+                cv = [(w, t) for n_, w, t, k in unf if n_ == "conv_bf16x3_dma"]
+                gn = [t for n_, w, t, k in unf if n_ == "groupnorm_silu"]
+                if cv:
+                    prof_bytes["__unfused__"] = {"conv_tflops": sum(w for w, _ in cv) / (sum(t for _, t in cv) * 1e-3) / 1e12,
+                                                 "conv_ms": sum(t for _, t in cv), "groupnorm_ms": sum(gn), "launches": len(cv)}
             # transformer forward + backward alone (tokens given, no optimizer): the north_star's "MaskGitTransformer step"
             ids, labels, _, _ = muse.prepare_inputs_and_labels(vq, None, cls, model.config.mask_token_id, image_tokens=vq.get_code(px))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -521,6 +536,12 @@ def main():
                                "per f32 product; `achieved` counts ALGORITHMIC flops (2*B*H*W*Cout*9*Cin), executed_mfma_tflops the issued "
                                "ones; against the plain 2500 peak frac would be frac/3") if x3 else "dense MFMA peak of the operand dtype",
                 "executed_mfma_tflops": round(ach * (3 if x3 else 1), 1),
+                "two_kernel_route": ({"conv_achieved": round(prof_bytes["__unfused__"]["conv_tflops"], 1),
+                                      "conv_frac": round(prof_bytes["__unfused__"]["conv_tflops"] / peak, 4),
+                                      "conv_ms_per_step": round(prof_bytes["__unfused__"]["conv_ms"], 3),
+                                      "groupnorm_apply_ms_per_step": round(prof_bytes["__unfused__"]["groupnorm_ms"], 3),
+                                      "what": "the same tokenizer pass with MUSE_GN_FUSE=0: bare patch-slab convolution + separate GroupNorm apply"}
+                                     if (dname == "conv_bf16x3_dma" and "__unfused__" in prof_bytes) else None),
                 "note": ("since round 3 this kernel also normalises its input (GroupNorm + SiLU + bf16x3 split inside the convolution, "
                          "muse_conv2d_nhwc_gn_split2): `achieved` still counts the convolution's flops only, over a launch that now contains "
                          "the former 5.3 ms / step GroupNorm apply pass - the fraction fell 0.56 -> ~0.50 while the step got 2.6 ms shorter "
