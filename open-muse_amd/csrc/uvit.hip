@@ -207,7 +207,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_v4_kernel(const float* __restri
   if (vpp >= 256) { cv = vc; x0 = 0; xs = 1; }
   else { cv = threadIdx.x % vpp; x0 = threadIdx.x / vpp; xs = 256 / vpp; }   // ... or several pixels of the row per pass
   if (cv >= vpp) return;
-  const int row = blockIdx.y, yy = row % H;                 // row = b * H + y
+  // row = b * H + y.  Workgroups go to the 8 XCDs round-robin: consecutive image rows (which share two of their three input rows)
+  // are handed to ONE XCD, so the shared rows come out of its L2 instead of being fetched by three of them
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x, nrow = gridDim.y;
+  int row = blockIdx.y;
+  if (gridDim.x == 1) {
+    const int xcd = wg & 7, q = nrow >> 3, r = nrow & 7;
+    row = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int yy = row % H;
   f32x4 wk[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_v4_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) wk[t][j] = w[(cv * 4 + j) * 9 + ts];
   }
+#pragma unroll 4      // (four pixels' loads in flight: the loop is otherwise one memory round trip per pixel)
   for (int xx = x0; xx < W; xx += xs) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -866,7 +875,7 @@ extern "C" int muse_silu_bwd(const float* x, const float* dy, float* dx, int64_t
 
 // depthwise 3x3 backward: dx = correlation of dy with the flipped taps;  dw[c][t] = sum_pixels dy[p] x[p + tap t]
 // dw partials: one block per 256 pixels -> dwp[chunk][c * 9 + t], folded by muse_colsum
-#define DW_PIX 256
+#define DW_PIX 64
 extern "C" int muse_dwconv3x3_bwd_nchunk(int64_t pixels) { return (int)((pixels + DW_PIX - 1) / DW_PIX); }
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                float* __restrict__ dx, int H, int W, int C, long n) {
@@ -903,6 +912,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_dw_v4_kernel(const float* _
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (cv < vpp) {
+#pragma unroll 2
     for (int p = p0 + wv; p < p1; p += 4) {
       const int xx = p % W, row = p / W, yy = row % H;
       const f32x4 g = *(const f32x4*)(dy + (long)p * C + cv * 4);
