@@ -219,6 +219,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         self.compute_dtype = torch.float32
         self.wgrad_stream = os.environ.get("MUSE_WGRAD_STREAM", "1") != "0"   # bf16 mode: weight-gradient GEMMs on a second HIP stream
         self.fuse_norm_adaln = os.environ.get("MUSE_NORM_ADALN", "1") != "0"  # norm + AdaLN of a transformer layer as one kernel (fwd and bwd)
+        self.batch_adaln_mappers = os.environ.get("MUSE_ADALN_BATCH", "1") != "0"   # every AdaLN mapper in a few batched products
         self._side_stream = None
         self._init_weights()
 
@@ -240,30 +241,104 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
     # ---- forward / backward ---------------------------------------------------------------------------------------------
     # Activations are channels-last rows [B * S, C].  Every helper returns (output, saved); the *_bwd twin consumes `saved`,
     # stores parameter gradients in `G` (name -> tensor) and returns the input gradients.  f32 throughout.
+    # ---- every AdaLN mapper of the network in a few batched products -------------------------------------------------------
+    # All AdaLNModulation layers read the SAME input, silu(cond) [B, cond_embed_dim] (:1032): 72 Linear layers of the config-4 model,
+    # i.e. 72 forward, 72 dX and 72 dW products with M = batch rows - 16-workgroup launches of 30-50 us each (8.6 ms of a 162 ms step).
+    # They are independent of everything else, so they run as one batched GEMM per weight shape: forward before the first block,
+    # d(weight) and d(silu(cond)) after the last backward block has delivered its d(scale | shift).
+    def _ada_sites(self):
+        """[(state-dict prefix, _AdaLN module)] of every site, cached"""
+        sites = self.__dict__.get("_ada_site_list")
+        if sites is None:
+            sites = []
+            for bname, blocks in (("down_blocks.0", self.down_blocks[0]), ("up_blocks.0", self.up_blocks[0])):
+                for i, rb in enumerate(blocks.res_blocks):
+                    sites.append((f"{bname}.res_blocks.{i}.adaLN_modulation", rb.adaLN_modulation))
+            for li, lyr in enumerate(self.transformer_layers):
+                nm = f"transformer_layers.{li}"
+                sites += [(nm + ".self_attn_adaLN_modulation", lyr.self_attn_adaLN_modulation),
+                          (nm + ".cross_attn_adaLN_modulation", lyr.cross_attn_adaLN_modulation),
+                          (nm + ".ffn.adaLN_modulation", lyr.ffn.adaLN_modulation)]
+            self.__dict__["_ada_site_list"] = sites
+        return sites
+
+    def _ada_forward_all(self, scond, B, need_grad):
+        """(scale | shift) of every AdaLN site: one batched product per mapper shape -> {id(module): ss [B, 2C]} (+ the groups for the
+        backward)"""
+        groups = {}
+        for name, mod in self._ada_sites():
+            groups.setdefault(tuple(mod.mapper.weight.shape), []).append((name, mod))
+        ss_of, tape = {}, []
+        xc_cache = {}
+        for (N, K), members in groups.items():
+            Z = len(members)
+            w2 = self._w2(*[m.mapper for _, m in members])                    # [Z * N, K], the compute dtype (cached stacking)
+            xc = xc_cache.get(w2.dtype)
+            if xc is None:
+                xc = xc_cache[w2.dtype] = self._pair(scond, w2)[0]
+            ss = torch.empty((Z, B, N), dtype=torch.float32, device=scond.device)
+            ops.gemm(xc, w2, ss, B, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N, batch=Z, sA=(0, 0), sB=(N * K, 0), sC=(B * N, 0))
+            dss = torch.empty((Z, B, N), dtype=torch.float32, device=scond.device) if need_grad else None
+            for z, (name, mod) in enumerate(members):
+                ss_of[id(mod)] = (ss[z], dss[z] if need_grad else None)
+            tape.append((members, w2, dss, N, K))
+        self.__dict__["_ada_ss"] = ss_of
+        return tape
+
+    def _ada_backward_all(self, tape, scond, dscond, B, G):
+        """d(mapper weights) and d(silu(cond)) of every AdaLN site from the d(scale | shift) the blocks left in the group buffers"""
+        for members, w2, dss, N, K in tape:
+            Z = len(members)
+            dsc, xc = self._pair(dss.view(Z * B, N), w2)[0].view(Z, B, N), self._pair(scond, w2)[0]
+            gw = torch.empty((Z * N, K), dtype=torch.float32, device=scond.device)
+            # dW_z = dss_z^T scond   (both operands k-major, k = batch rows)
+            ops.gemm(dsc, xc, gw, N, K, B, la=1, lb=1, lda=N, ldb=K, ldc=K, batch=Z, sA=(B * N, 0), sB=(0, 0), sC=(N * K, 0))
+            for z, (name, mod) in enumerate(members):
+                G[name + ".mapper.weight"] = gw[z * N:(z + 1) * N].view(mod.mapper.weight.shape)
+            # d(scond) += sum_z dss_z W_z
+            part = torch.empty((Z, B * K), dtype=torch.float32, device=scond.device)
+            ops.gemm(dsc, w2, part, B, K, N, la=0, lb=1, lda=N, ldb=K, ldc=K, batch=Z, sA=(B * N, 0), sB=(N * K, 0), sC=(B * K, 0))
+            ops.colsum(part, dscond.view(-1), accumulate=True)
+
+    def _ada_ss_of(self, mod, scond):
+        """(ss, dss slot or None) of a site: from the batched products when they ran, else the site's own Linear"""
+        hit = self.__dict__.get("_ada_ss", {}).get(id(mod))
+        if hit is not None:
+            return hit
+        return self._lin(scond, mod.mapper), None
+
     def _adaln(self, x, mod: _AdaLN, scond, B, gemm_operand=False):
         """gemm_operand (bf16 mode): the modulated tensor is consumed only as a GEMM operand -> written as bf16 directly"""
-        ss = self._lin(scond, mod.mapper)
+        ss, slot = self._ada_ss_of(mod, scond)
         od = torch.bfloat16 if (gemm_operand and self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
-        return ops.adaln_fwd(x, ss, B, out_dtype=od), dict(x=x, ss=ss)
+        return ops.adaln_fwd(x, ss, B, out_dtype=od), dict(x=x, ss=ss, slot=slot)
 
-    def _adaln_bwd(self, dy, sv, mod: _AdaLN, name, G, scond, dscond, B):
-        dx, dss = ops.adaln_bwd(dy, sv["x"], sv["ss"], B)
+    def _ada_dss(self, dss, sv, mod, name, G, scond, dscond):
+        """hand a site's d(scale | shift) on: into its slot of the batched backward, or through the site's own Linear backward"""
+        if sv.get("slot") is not None:
+            if dss.data_ptr() != sv["slot"].data_ptr():
+                sv["slot"].copy_(dss)
+            return
         d = self._lin_bwd(dss, scond, mod.mapper, name + ".mapper", G)
         dscond.add_(d)            # every AdaLN reads the same silu(cond): sum of a [B, H] tensor (plumbing)
+
+    def _adaln_bwd(self, dy, sv, mod: _AdaLN, name, G, scond, dscond, B):
+        dx, dss = ops.adaln_bwd(dy, sv["x"], sv["ss"], B, dss_out=sv.get("slot"))
+        self._ada_dss(dss, sv, mod, name, G, scond, dscond)
         return dx
 
     def _norm_adaln(self, x, norm_mod, ada: _AdaLN, scond, B, mode=0, residual=None):
         """norm(x + residual) followed by its AdaLN modulation (TransformerLayer :757-792) as ONE kernel where the shape allows: the
         norm output itself is never written.  -> (m = GEMM operand of the next block, v = x + residual, tape entry)"""
-        ss = self._lin(scond, ada.mapper)
+        ss, slot = self._ada_ss_of(ada, scond)
         if self.fuse_norm_adaln and ops.norm_adaln_ok(x.shape[0], x.shape[1], B):
             od = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
             m, v = ops.norm_adaln_fwd(x, self._f(norm_mod.weight), ss, B, float(self.config.layer_norm_eps), mode, residual=residual,
                                       out_dtype=od)
-            return m, v, dict(ss=ss, fused=True)
+            return m, v, dict(ss=ss, slot=slot, fused=True)
         n, v = self._norm(x, norm_mod, mode=mode, residual=residual, want_pre=True)
         od = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
-        return ops.adaln_fwd(n, ss, B, out_dtype=od), v, dict(x=n, ss=ss)
+        return ops.adaln_fwd(n, ss, B, out_dtype=od), v, dict(x=n, ss=ss, slot=slot)
 
     def _norm_adaln_bwd(self, dm, sv, v, norm_mod, norm_name, ada: _AdaLN, ada_name, G, scond, dscond, B, mode=0, dpre=None):
         """-> d(x) = d(residual) of _norm_adaln; the bf16 copy of it (dY of the next weight GEMMs) rides in the activation cache"""
@@ -272,13 +347,13 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             return self._norm_bwd(dn, v, norm_mod, norm_name, G, mode=mode, dpre=dpre, gemm_operand=True)
         eps = float(self.config.layer_norm_eps)
         if self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 2:
-            dv, dw, dss, dvb = ops.norm_adaln_bwd(dm, v, self._f(norm_mod.weight), sv["ss"], B, eps, mode, dpre=dpre, also_bf16=True)
+            dv, dw, dss, dvb = ops.norm_adaln_bwd(dm, v, self._f(norm_mod.weight), sv["ss"], B, eps, mode, dpre=dpre, also_bf16=True,
+                                                  dss_out=sv.get("slot"))
             self.__dict__.setdefault("_act_cache", {})[id(dv)] = (dv, dvb)
         else:
-            dv, dw, dss = ops.norm_adaln_bwd(dm, v, self._f(norm_mod.weight), sv["ss"], B, eps, mode, dpre=dpre)
+            dv, dw, dss = ops.norm_adaln_bwd(dm, v, self._f(norm_mod.weight), sv["ss"], B, eps, mode, dpre=dpre, dss_out=sv.get("slot"))
         G[norm_name + ".weight"] = dw
-        d = self._lin_bwd(dss, scond, ada.mapper, ada_name + ".mapper", G)
-        dscond.add_(d)
+        self._ada_dss(dss, sv, ada, ada_name, G, scond, dscond)
         return dv
 
     def _res_block(self, h, blk: _ResBlock, scond, B, side):
@@ -359,6 +434,8 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         sc1 = ops.silu_fwd(c1)
         cond = self._lin(sc1, self.cond_embed["2"])
         scond = ops.silu_fwd(cond)                                                    # every AdaLN sees silu(cond) (:1032)
+        self.__dict__["_ada_ss"] = {}
+        ada_tape = self._ada_forward_all(scond, B, need_grad) if self.batch_adaln_mappers else None
         # ConvEmbed :485-500
         ids = input_ids.reshape(-1).contiguous()
         emb0 = ops.gather_rows(f(self.embed.embeddings.weight), ids, torch.float32)
@@ -429,7 +506,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         if not need_grad:
             return logits, loss, None
         T.update(B=B, S=S, L=L, side=side, enc_in=enc_in, enc0=enc0, enc=enc, senc=senc, cond_in=cond_in, c1=c1, sc1=sc1, cond=cond,
-                 scond=scond, ids=ids, emb0=emb0, emb=emb, h_mlm=h, y1=y1, y2=y2, logits_p=logits_p, V=V, Vp=Vp)
+                 scond=scond, ids=ids, emb0=emb0, emb=emb, h_mlm=h, y1=y1, y2=y2, logits_p=logits_p, V=V, Vp=Vp, ada_tape=ada_tape)
         return logits, loss, T
 
     def _run_backward(self, T, g_loss):
@@ -507,6 +584,8 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         ops.embed_bwd(T["ids"].view(B, S), demb0, gemb, dpos, False)
         G["embed.embeddings.weight"] = gemb
         # conditioning: scond = silu(cond), cond = W2 silu(W0 cond_in)
+        if T.get("ada_tape") is not None:
+            self._ada_backward_all(T["ada_tape"], scond, dscond, B, G)
         dcond = ops.silu_bwd(T["cond"], dscond)
         dsc1 = self._lin_bwd(dcond, T["sc1"], self.cond_embed["2"], "cond_embed.2", G)
         dc1 = ops.silu_bwd(T["c1"], dsc1)

@@ -1058,7 +1058,7 @@ def norm_adaln_fwd(x, w, ss, batch, eps, mode, residual=None, out_dtype=torch.fl
     return m, pre
 
 
-def norm_adaln_bwd(dm, v, w, ss, batch, eps, mode, dpre=None, also_bf16=False):
+def norm_adaln_bwd(dm, v, w, ss, batch, eps, mode, dpre=None, also_bf16=False, dss_out=None):
     """backward of norm_adaln_fwd -> (dv = dx = dres, dw, dss [batch, 2C][, bf16 copy of dv])"""
     require_gpu(dm, v, ss)
     rows, cols = v.shape
@@ -1070,17 +1070,17 @@ def norm_adaln_bwd(dm, v, w, ss, batch, eps, mode, dpre=None, also_bf16=False):
     check(lib().muse_norm_adaln_bwd(dm.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), ss.data_ptr(), dv.data_ptr(), ptr(dvb), part.data_ptr(),
                                     spart.data_ptr(), batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_bwd")
     dw = colsum(part, torch.empty(cols, dtype=torch.float32, device=v.device))
-    dss = torch.empty((batch, 2 * cols), dtype=torch.float32, device=v.device)
+    dss = dss_out if dss_out is not None else torch.empty((batch, 2 * cols), dtype=torch.float32, device=v.device)
     check(lib().muse_colsum_segments(spart.data_ptr(), dss.data_ptr(), batch, nblk // batch, 2 * cols, stream()), "muse_colsum_segments")
     return (dv, dw, dss, dvb) if also_bf16 else (dv, dw, dss)
 
 
-def adaln_bwd(dy, x, ss, batch):
-    """-> (dx, dss [batch, 2C])"""
+def adaln_bwd(dy, x, ss, batch, dss_out=None):
+    """-> (dx, dss [batch, 2C]); dss_out: a contiguous [batch, 2C] f32 buffer to write dss into"""
     require_gpu(dy, x, ss)
     rows, C_ = x.shape
     dx = torch.empty_like(x)
-    dss = torch.empty_like(ss)
+    dss = dss_out if dss_out is not None else torch.empty(ss.shape, dtype=torch.float32, device=ss.device)
     check(lib().muse_adaln_bwd(dy.data_ptr(), x.data_ptr(), ss.data_ptr(), dx.data_ptr(), dss.data_ptr(), batch, rows // batch, C_,
                                stream()), "muse_adaln_bwd")
     return dx, dss
