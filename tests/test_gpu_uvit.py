@@ -432,3 +432,20 @@ def test_fused_norm_adaln_matches_the_two_kernel_route(B, S, C, mode, res):
     dv2, dw2, dss2 = ops.norm_adaln_bwd(dm, v, w, ss, B, 1e-6, mode)          # no residual-stream gradient, no bf16 copy
     dv2_ref, _ = ops.norm_res_bwd(dn_ref, pre, w, 1e-6, mode)
     assert rel_err(dv2, dv2_ref) < 2e-6 and torch.equal(dw2, dw) and torch.equal(dss2, dss)
+
+
+@pytest.mark.parametrize("batch_mappers,fuse_norm", [(False, False), (False, True), (True, False)])
+def test_uvit_unfused_routes_still_match_the_reference(golden_dir, batch_mappers, fuse_norm):
+    """the per-site AdaLN mapper products (MUSE_ADALN_BATCH=0) and the two-kernel norm -> AdaLN route (MUSE_NORM_ADALN=0) stay
+    reachable and correct: same golden check as the default (batched, fused) path"""
+    import muse
+    g, cfg, sd = _load_golden(golden_dir)
+    model = muse.MaskGiTUViT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train()
+    model.batch_adaln_mappers, model.fuse_norm_adaln = batch_mappers, fuse_norm
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    logits, loss = model(*args, labels=torch.from_numpy(g["labels"]).to(DEV))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    _grad_check(model, {k[len("grad."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad.")}, 5e-4)
