@@ -310,7 +310,7 @@ def uvit_leg(device, batch, seq, steps=3, f32=False):
     return out
 
 
-def cpu_baseline(cfg_name, device, bs=4, reps=3):
+def cpu_baseline(cfg_name, device, bs=4, reps=3, bench_batch=64):
     """the CPU oracle (port of the reference path: BASELINE.json configs[0], bs = 4) on this node's host cores: one warm-up step,
     then `reps` timed steps with per-phase times; median reported.  Each repetition tokenizes different images; the oracle's token
     indices are compared with the HIP tokenizer's (the bench's bf16x3 mode) on the same images: vq_index_mismatches."""
@@ -356,11 +356,74 @@ def cpu_baseline(cfg_name, device, bs=4, reps=3):
         ntok += tokens.numel()
     med = [statistics.median(p[i] for p in phases) for i in range(4)]
     total = statistics.median(sum(p) for p in phases)
+    # north_star "bit-exact VQ token indices", stated as measured on THE BENCHED BATCH (the 64 images rank 0 trains on): the oracle's
+    # tokenizer on them (8 at a time, untimed) against the HIP tokenizer in the benched mode; every disagreeing token with the oracle's
+    # own f32 top-2 margin and the gap between the two candidates, in f32 ulps of the distance (oracle/vq_parity.py; the full
+    # float64 accounting of each disagreement is tests/test_gpu_models.py::test_vq_indices_over_bench_batch_vs_oracle)
+    bench_vq = None
+    try:
+        from oracle import vq_parity as VP
+        pxb, _ = synthetic_batch(bench_batch, torch.device("cpu"), seed=1000)         # rank 0's images of the timed run ...
+        vsd = W.fill_state_dict(W.vqgan_shapes(W.VQGAN_F16), 1234, "vqgan")            # ... and its tokenizer weights (build_models)
+        vq.load_state_dict(vsd)
+        cb = vsd["quantize.embedding.weight"]
+        io, do = [], []
+        with torch.no_grad():
+            for i in range(0, bench_batch, 8):
+                z = O.vqgan_encoder(vsd, W.VQGAN_F16, pxb[i:i + 8])
+                d = O.vq_distances(z.permute(0, 2, 3, 1).reshape(-1, cb.shape[1]).contiguous(), cb)
+                do.append(d); io.append(torch.argmin(d, dim=1))
+        io, do = torch.cat(io), torch.cat(do)
+        ih = vq.get_code(pxb.to(device)).cpu().reshape(-1)
+        mm = VP.oracle_margins(do, io, ih)
+        bench_vq = {"tokens": int(io.numel()), "images": bench_batch, "disagreements": len(mm),
+                    "each": [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in m.items()} for m in mm[:16]],
+                    "unit": "f32 ulps of the distance (an ulp at d ~ 30 is 1.9e-6)"}
+    except Exception as e:   # noqa: BLE001
+        bench_vq = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
     return {"value": round(bs / total, 4), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
             "sample": f"config {cfg_name} train step at bs={bs} (BASELINE.json configs[0]), f32, oracle/maskgit_oracle.py on {cores} of "
                       f"{os.cpu_count()} host threads: 1 warm-up + median of {reps} steps ({total:.1f} s per step)",
             "phase_s": {"vq_encode+mask": round(med[0], 2), "forward": round(med[1], 2), "backward": round(med[2], 2), "adamw": round(med[3], 2)},
-            "vq_index_mismatches": f"{mism} of {ntok} tokens (HIP bf16x3 tokenizer vs the f32 oracle, {reps + 1} x {bs} images)"}
+            "vq_index_mismatches": f"{mism} of {ntok} tokens (HIP bf16x3 tokenizer vs the f32 oracle, {reps + 1} x {bs} images)",
+            "vq_index_mismatches_bench_batch": bench_vq}
+
+
+def comm_block(info, world, dp_ms, plain_ms, grad_dtype, rccl_log):
+    """What the data-parallel line did on the wire, so that a multi-GPU run explains itself (DESIGN.md section 6 predicts 7.6-7.8x at
+    N = 8 when RCCL spreads the buckets over all seven xGMI links, ~6.4x on a single f32 ring): ranks RCCL saw, gradient bytes and
+    buckets per step, the all-reduce alone (algorithm / bus bandwidth: busbw = algbw x 2 (N - 1) / N, the per-link figure to hold
+    against ~77 GB/s per direction of one xGMI link), the communication the step could not hide (data-parallel step minus the same
+    step without the reducer on the same GPUs), and RCCL's own description of the communicator (NCCL_DEBUG=INFO INIT / GRAPH lines:
+    channels, rings / trees, transports)."""
+    import glob
+    import re
+    out = {"backend": "nccl (RCCL)", "ranks": dist.get_world_size() if dist.is_initialized() else world, "grad_allreduce_dtype": grad_dtype,
+           "bytes_per_step": int(info.get("bytes_per_step", 0)), "buckets_per_step": info.get("buckets_per_step"),
+           "dp_step_ms": round(dp_ms, 3), "same_gpus_step_without_reducer_ms": None if plain_ms is None else round(plain_ms, 3),
+           "exposed_comm_ms": None if plain_ms is None else round(dp_ms - plain_ms, 3)}
+    for k in ("allreduce_alone_ms", "allreduce_alone_algbw_GBps", "allreduce_alone_busbw_GBps", "allreduce_alone_error"):
+        if k in info:
+            out[k] = info[k]
+    if world > 1 and "allreduce_alone_ms" in info and plain_ms is not None:
+        out["hidden_fraction_of_allreduce"] = round(max(0.0, 1.0 - max(0.0, dp_ms - plain_ms) / max(info["allreduce_alone_ms"], 1e-9)), 3)
+    lines = []
+    if rccl_log:
+        try:
+            pat = re.compile(r"(nranks|Channel|channel|Ring|Tree|ring|tree|Connected|Using network|NET/|P2P|xGMI|XGMI|algorithm|protocol|comm 0x)")
+            seen = set()
+            for f in sorted(glob.glob(rccl_log.replace("%h", "*").replace("%p", "*"))):
+                for l in open(f, errors="replace"):
+                    l = l.strip()
+                    key = re.sub(r"0x[0-9a-f]+|\[\d+\]|\d+:\d+", "", l)
+                    if pat.search(l) and key not in seen and len(lines) < 24:
+                        seen.add(key)
+                        lines.append(l[-200:])
+                break      # rank 0's file (sorted first) says what every rank built
+        except Exception as e:   # noqa: BLE001
+            lines.append(f"(RCCL log not read: {type(e).__name__})")
+    out["rccl_info"] = lines
+    return out
 
 
 def traffic_of(kernel_family):
@@ -405,18 +468,24 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torch.distributed.run (also with one rank)
+    rccl_log = None
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "NCCL_DEBUG" not in os.environ:     # RCCL's own account of what it built (rings / trees, channels, transports) for the `comm` block
+            rccl_log = f"/tmp/muse_rccl_{os.getpid()}.%h.%p.log"
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=rccl_log)
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     import muse
     from muse import ops
 
     prof_bytes = {}
+    comm_info, parity = {}, {}
 
-    def run(cfg_name, vq_dtype, steps, warmup, profile=False, tokens_given=False, inline_tokenizer=False):
+    def run(cfg_name, vq_dtype, steps, warmup, profile=False, tokens_given=False, inline_tokenizer=False, use_reducer=True):
         vq, model, opt, tcfg = build_models(cfg_name, vq_dtype, device, seed=1234)
-        reducer = muse.GradReducer(model, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32) if distributed else None
+        reducer = (muse.GradReducer(model, grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32)
+                   if distributed and use_reducer else None)
         step = muse.TrainStep(vq, model, opt, reducer)
         px, cls = synthetic_batch(args.batch, device, seed=1000 + rank)  # different data per rank (weak scaling)
         toks = vq.get_code(px) if tokens_given else None
@@ -433,6 +502,8 @@ def main():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
+        if reducer is not None:
+            reducer.stats = {"buckets": 0, "bytes": 0}
         t0 = time.perf_counter()
         for _ in range(steps):
             loss, mask_prob = one()
@@ -444,7 +515,31 @@ def main():
             t = torch.tensor([el], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t)
-            loss, _ = reducer.reduce_metrics(loss, mask_prob)     # the two logged scalars of the loop as one 2-float all-reduce
+            if reducer is not None:
+                loss, _ = reducer.reduce_metrics(loss, mask_prob)     # the two logged scalars of the loop as one 2-float all-reduce
+                comm_info.update(buckets_per_step=reducer.stats["buckets"] / steps, bytes_per_step=reducer.stats["bytes"] / steps)
+                try:    # the gradient all-reduce ALONE (no compute beside it), in the reducer's own buckets: what the links deliver
+                    g = model.flat_grads()
+                    be = reducer.bucket_elems
+                    cuts = list(range(g.numel(), 0, -be))
+                    def allreduce_all():
+                        for hi in cuts:
+                            reducer._reduce(g[max(0, hi - be):hi], True)
+                    allreduce_all()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    ta = time.perf_counter()
+                    for _ in range(3):
+                        allreduce_all()
+                    torch.cuda.synchronize()
+                    tb = torch.tensor([(time.perf_counter() - ta) / 3], device=device, dtype=torch.float64)
+                    dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                    nbytes = g.numel() * (2 if args.grad_dtype == "bf16" else 4)
+                    comm_info.update(allreduce_alone_ms=round(float(tb) * 1e3, 3),
+                                     allreduce_alone_algbw_GBps=round(nbytes / float(tb) / 1e9, 1),
+                                     allreduce_alone_busbw_GBps=round(nbytes / float(tb) / 1e9 * 2 * (world - 1) / max(world, 1), 1))
+                except Exception as e:   # noqa: BLE001   (diagnostics must never take the bench line down)
+                    comm_info["allreduce_alone_error"] = f"{type(e).__name__}: {str(e)[:160]}"
         prof = tr_ms = None
         if profile:
             # per-kernel timing needs the kernels one at a time: no token prefetch, weight gradients on the main stream
@@ -487,6 +582,22 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             tr_ms = e0.elapsed_time(e1) / n
+            # MEASURED parity of the benched mode on the benched batch (the line's `dtype` quotes these, not constants): the same
+            # weights and inputs through the bf16 mode and through the exact-f32 parity mode (which meets north_star's 1e-3 against
+            # the reference: tests/test_gpu_models.py::test_transformer_config_b_benched_batch_vs_reference_golden)
+            try:
+                with torch.no_grad():
+                    lg_b, ls_b = model(input_ids=ids, labels=labels)
+                    lg_b, ls_b = lg_b.float().clone(), float(ls_b)
+                    model.set_compute_dtype(torch.float32)
+                    lg_f, ls_f = model(input_ids=ids, labels=labels)
+                    model.set_compute_dtype(torch.bfloat16)
+                    parity.update(logits_max_abs_diff_over_max_logit=float((lg_b - lg_f).abs().max() / lg_f.abs().max()),
+                                  loss_rel_diff=abs(ls_b - float(ls_f)) / abs(float(ls_f)), loss_bf16=ls_b, loss_f32=float(ls_f),
+                                  rows=int(ids.numel()))
+                    del lg_b, lg_f
+            except Exception as e:   # noqa: BLE001
+                parity["error"] = f"{type(e).__name__}: {str(e)[:160]}"
         lossv = float(loss)
         del step, vq, model, opt, reducer
         gc.collect()               # (tapes and parameter views of the finished leg: later legs must not pay for a growing Python heap)
@@ -510,6 +621,13 @@ def main():
             print(json.dumps(latency_leg(device)))
         return
 
+    plain_ms = None
+    if distributed:
+        # the same step WITHOUT the reducer on the same GPUs first (every rank its own replica, max over ranks): the data-parallel
+        # step minus this is the communication the step could not hide
+        n_plain = max(3, args.steps // 2)
+        el_p, _, _, _ = run(args.config, args.vq_dtype, n_plain, min(args.warmup, 2), use_reducer=False)
+        plain_ms = el_p / n_plain * 1e3
     el, lossv, prof, tr_ms = run(args.config, args.vq_dtype, args.steps, args.warmup, profile=True)
     ms = el / args.steps * 1e3
     value = args.batch * world * args.steps / el
@@ -561,7 +679,8 @@ def main():
              "vqgan_hbm_frac": round(vq_bytes / (vq_ms * 1e-3) / 1e9 / HBM_PEAK, 4) if vq_ms else None,
              "vqgan_hbm_note": "GroupNorm+SiLU and 2x2 pooling kernels of the encoder: algorithmic bytes (each operand once) / their time / 8 TB/s",
              "mfma_ms_in_instrumented_step": round(sum(v[1] for v in mfma.values()), 2),
-             "hbm_kernel_ms_in_instrumented_step": round(sum(v[1] for v in hbm.values()), 2)}
+             "hbm_kernel_ms_in_instrumented_step": round(sum(v[1] for v in hbm.values()), 2),
+             "measured_parity_bf16_vs_f32_mode": {k: (round(v, 8) if isinstance(v, float) else v) for k, v in parity.items()}}
     if world == 1 and not args.no_extra:
         n2 = max(3, args.steps // 2)
 
@@ -590,8 +709,11 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "dtype": f"bf16 (transformer GEMM/attention operands; f32 accumulate, residual, norms, loss) + {args.vq_dtype} tokenizer"
                  + (" (f32 activations, f32-class products as 3 bf16 MFMAs)" if args.vq_dtype == "bf16x3" else "")
-                 + "; parity of this mode vs the f32 reference at the benched batch: loss 4e-5 rel, logits 1.0e-2 of max|logit| = the "
-                   "reference's own autocast-bf16 gap (1.2e-2); the f32 mode meets north_star's 1e-3 (logits 2e-6)",
+                 + ((f"; MEASURED in this run on the benched batch ({parity['rows']} rows), this mode vs the exact-f32 parity mode of the same "
+                     f"weights: loss {parity['loss_rel_diff']:.1e} rel, logits {parity['logits_max_abs_diff_over_max_logit']:.1e} of max|logit| "
+                     "(the reference's own autocast-bf16 gap at this geometry is 1.2e-2, tests/golden/transformer_b_full_bf16.npz; the f32 "
+                     "mode meets north_star's 1e-3 against the reference: logits 2e-6)") if "loss_rel_diff" in parity else
+                    "; parity of this mode was not measured in this run (" + parity.get("error", "profile leg skipped") + ")"),
         "data": "synthetic",
         "config": {"workload": f"MaskGit train step: MaskGitVQGAN f16-256 encode ({args.vq_dtype}) + cosine mask + "
                                f"MaskGitTransformer config {args.config} "
@@ -604,8 +726,10 @@ def main():
         "roofline": roofline,
         "extra": extra,
     }
+    if distributed:
+        out["comm"] = comm_block(comm_info, world, ms, plain_ms, args.grad_dtype, rccl_log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.config, device)
+        out["cpu_baseline"] = cpu_baseline(args.config, device, bench_batch=args.batch)
     if rank == 0:
         print(json.dumps(out))
     if distributed:

@@ -199,6 +199,19 @@ int muse_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, 
  * ceil(n / 4096); num_chunks = chunk_first[num_tensors]. */
 int muse_adamw_multi(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+/* AdamW with PARAMETER GROUPS (training/train_muse.py:425-445 builds two: weight decay on the matrices, none on bias / LayerNorm /
+ * embedding weights; torch.optim semantics - each group its own lr / betas / eps / weight_decay).  `group_hyper` (HOST memory, read
+ * during the call): ngroups <= 8 rows of {lr, beta1, beta2, eps, weight_decay}.
+ * _flat_groups: the flat buffer is cut into segments, seg_end[s] (device int64, ascending ABSOLUTE element offsets of the flat
+ * buffer) closes segment s and seg_group[s] (device int32) names its group; the call updates elements [base, base + n) - p, g, m, v,
+ * p_bf16 point at element `base` - so range-wise updates (inside backward, behind an all-reduce bucket) share one table.
+ * _multi_groups: muse_adamw_multi's table with a seventh column, the tensor's group.
+ * A one-group call is bit-identical to muse_adamw_flat / muse_adamw_multi. */
+int muse_adamw_flat_groups(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, int64_t base,
+                           const int64_t* seg_end, const int32_t* seg_group, int32_t nseg, const float* group_hyper,
+                           int32_t ngroups, int32_t step, float grad_scale, void* stream);
+int muse_adamw_multi_groups(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks,
+                            const float* group_hyper, int32_t ngroups, int32_t step, float grad_scale, void* stream);
 /* out[i] (+)= sum over s < nslices of ws[s*stride + i]: reduction of split-K partial results (n, stride % 4 == 0) */
 int muse_sum_slices(const float* ws, float* out, int32_t nslices, int64_t n, int64_t stride, int32_t accumulate, void* stream);
 int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);

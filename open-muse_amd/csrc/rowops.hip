@@ -1432,6 +1432,136 @@ extern "C" int muse_adamw_multi(const int64_t* table, const int32_t* chunk_first
   return (int)hipGetLastError();
 }
 
+// ---- parameter groups (training/train_muse.py:425-445: no weight decay on bias / LayerNorm / embedding weights) ---------------------
+// torch.optim semantics: every group carries its own lr / betas / eps / weight_decay.  The per-group constants are computed on the
+// host exactly like muse_adamw_flat computes its single set and travel BY VALUE in the kernel arguments (they change every step with
+// the lr schedule: no host -> device copy).  Same arithmetic, same order as adamw_kernel: a one-group call is bit-identical to it.
+#define MUSE_ADAMW_MAX_GROUPS 8
+struct AdamHyper { float b2, eps, decay, omb1, omb2, step_size, bc2_sqrt, pad; };
+struct AdamGroups { AdamHyper h[MUSE_ADAMW_MAX_GROUPS]; };
+static inline int adam_fill_groups(AdamGroups& G, const float* hyper, int ngroups, int step) {
+  if (ngroups < 1 || ngroups > MUSE_ADAMW_MAX_GROUPS || !hyper) return MUSE_ERR_BAD_ARG;
+  for (int k = 0; k < ngroups; ++k) {
+    const float lr = hyper[k * 5 + 0], beta1 = hyper[k * 5 + 1], beta2 = hyper[k * 5 + 2], eps = hyper[k * 5 + 3], wd = hyper[k * 5 + 4];
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamHyper& h = G.h[k];
+    h.step_size = (float)((double)lr / bc1);
+    h.bc2_sqrt = (float)sqrt(bc2);
+    h.decay = (float)(1.0 - (double)lr * (double)wd);
+    h.omb1 = (float)(1.0 - (double)beta1); h.omb2 = (float)(1.0 - (double)beta2);
+    h.b2 = beta2; h.eps = eps; h.pad = 0.f;
+  }
+  for (int k = ngroups; k < MUSE_ADAMW_MAX_GROUPS; ++k) G.h[k] = G.h[0];
+  return 0;
+}
+__device__ __forceinline__ void adam_update1(float& pp, float gr, float& mm, float& vv, const AdamHyper& h) {
+  pp = pp * h.decay;
+  mm = fmaf(h.omb1, gr - mm, mm);
+  vv = fmaf(h.omb2, gr * gr, vv * h.b2);
+  const float denom = sqrtf(vv) / h.bc2_sqrt + h.eps;
+  pp = pp - h.step_size * (mm / denom);
+}
+// Flat buffer cut into segments: seg_end[s] (ascending, ABSOLUTE element offsets in the flat buffer) closes segment s, seg_group[s]
+// names its parameter group.  The call covers elements [base, base + n) of the flat buffer (p, g, m, v, pb point at element `base`):
+// any slice, so the in-backward / behind-the-all-reduce range updates share the table.  Block b owns elements [4096 b, 4096 b + 4096)
+// of the slice; its first / last segment are found once per block (uniform binary searches), a lane then only steps inside that range.
+__global__ __launch_bounds__(256) void adamw_groups_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, bf16_t* __restrict__ pb, long n, long base,
+                                                           const long* __restrict__ seg_end, const int* __restrict__ seg_group, int nseg,
+                                                           AdamGroups G, float gscale) {
+  const long c0 = (long)blockIdx.x * 4096, c1 = c0 + 4096 < n ? c0 + 4096 : n;
+  auto seg_of = [&](long pos) {   // smallest s with seg_end[s] > pos (positions beyond the last end: the last segment)
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (seg_end[mid] > pos) hi = mid; else lo = mid + 1; }
+    return lo;
+  };
+  const int s0 = seg_of(base + c0), s1 = seg_of(base + c1 - 1);
+  if (s0 == s1) {                 // the common case: one group for the whole chunk
+    const AdamHyper h = G.h[seg_group[s0] & (MUSE_ADAMW_MAX_GROUPS - 1)];
+    long i = c0 + threadIdx.x * 4;
+    for (; i + 3 < c1; i += 1024) {
+      float pp[4], gg[4], mm[4], vv[4];
+      V4<float>::load(p + i, pp); V4<float>::load(g + i, gg); V4<float>::load(m + i, mm); V4<float>::load(v + i, vv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adam_update1(pp[j], gg[j] * gscale, mm[j], vv[j], h);
+      V4<float>::store(p + i, pp); V4<float>::store(m + i, mm); V4<float>::store(v + i, vv);
+      if (pb) V4<bf16_t>::store(pb + i, pp);
+    }
+    const long t0 = c0 + ((c1 - c0) & ~3L);
+    for (long k = t0 + threadIdx.x; k < c1; k += 256) {
+      float pp = p[k], mm = m[k], vv = v[k];
+      adam_update1(pp, g[k] * gscale, mm, vv, h);
+      p[k] = pp; m[k] = mm; v[k] = vv;
+      if (pb) pb[k] = f32_to_bf16(pp);
+    }
+    return;
+  }
+  for (long k = c0 + threadIdx.x; k < c1; k += 256) {   // a chunk with a segment boundary inside: element-wise, group per element
+    int s = s0;
+    while (s < s1 && seg_end[s] <= base + k) ++s;
+    const AdamHyper h = G.h[seg_group[s] & (MUSE_ADAMW_MAX_GROUPS - 1)];
+    float pp = p[k], mm = m[k], vv = v[k];
+    adam_update1(pp, g[k] * gscale, mm, vv, h);
+    p[k] = pp; m[k] = mm; v[k] = vv;
+    if (pb) pb[k] = f32_to_bf16(pp);
+  }
+}
+extern "C" int muse_adamw_flat_groups(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, int64_t base,
+                                      const int64_t* seg_end, const int32_t* seg_group, int32_t nseg, const float* group_hyper,
+                                      int32_t ngroups, int32_t step, float grad_scale, void* stream) {
+  if (n <= 0) return 0;
+  if (nseg < 1 || !seg_end || !seg_group) return MUSE_ERR_BAD_ARG;
+  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return MUSE_ERR_ALIGN;
+  if (p_bf16 && (((uintptr_t)p_bf16) & 7)) return MUSE_ERR_ALIGN;
+  AdamGroups G;
+  const int rc = adam_fill_groups(G, group_hyper, ngroups, step);
+  if (rc) return rc;
+  hipLaunchKernelGGL(adamw_groups_kernel, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (bf16_t*)p_bf16, (long)n, (long)base, (const long*)seg_end, seg_group, nseg, G, grad_scale);
+  return (int)hipGetLastError();
+}
+// Multi-tensor form with groups: `table` is 7 x int64 per tensor {p, g, m, v, p_bf16 or 0, n, group}.
+__global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __restrict__ table, const int* __restrict__ chunk_first, int nt,
+                                                                 AdamGroups G, float gscale) {
+  int lo = 0, hi = nt;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const long* e = table + (long)lo * 7;
+  float* p = (float*)e[0]; const float* g = (const float*)e[1]; float* m = (float*)e[2]; float* v = (float*)e[3];
+  bf16_t* pb = (bf16_t*)e[4];
+  const AdamHyper h = G.h[(int)e[6] & (MUSE_ADAMW_MAX_GROUPS - 1)];
+  const long n = e[5], base = (long)((int)blockIdx.x - chunk_first[lo]) * 4096;
+  const long end = base + 4096 < n ? base + 4096 : n;
+  const bool vec = !((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) && !(((uintptr_t)pb) & 7);
+  if (vec) {
+    for (long i = base + threadIdx.x * 4; i + 3 < end; i += 1024) {
+      float pp[4], gg[4], mm[4], vv[4];
+      V4<float>::load(p + i, pp); V4<float>::load(g + i, gg); V4<float>::load(m + i, mm); V4<float>::load(v + i, vv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adam_update1(pp[j], gg[j] * gscale, mm[j], vv[j], h);
+      V4<float>::store(p + i, pp); V4<float>::store(m + i, mm); V4<float>::store(v + i, vv);
+      if (pb) V4<bf16_t>::store(pb + i, pp);
+    }
+  }
+  const long s0 = vec ? base + ((end - base) & ~3L) : base;
+  for (long i = s0 + threadIdx.x; i < end; i += 256) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update1(pp, g[i] * gscale, mm, vv, h);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (pb) pb[i] = f32_to_bf16(pp);
+  }
+}
+extern "C" int muse_adamw_multi_groups(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks,
+                                       const float* group_hyper, int32_t ngroups, int32_t step, float grad_scale, void* stream) {
+  if (num_tensors <= 0 || num_chunks <= 0) return 0;
+  AdamGroups G;
+  const int rc = adam_fill_groups(G, group_hyper, ngroups, step);
+  if (rc) return rc;
+  hipLaunchKernelGGL(adamw_multi_groups_kernel, dim3(num_chunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, chunk_first,
+                     num_tensors, G, grad_scale);
+  return (int)hipGetLastError();
+}
+
 __global__ void cast_f2b_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

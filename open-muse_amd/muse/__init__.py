@@ -14,8 +14,8 @@ from .modeling_transformer_v2 import MaskGiTUViT, MaskGiTUViT_v2
 from . import pre_encode
 from .pipeline_muse import PipelineMuse
 from .sampling import get_mask_chedule
-from .training import (FusedAdamW, GradReducer, TrainStep, cond_dropout, mask_or_random_replace_tokens,
+from .training import (FusedAdamW, GradReducer, TrainStep, cond_dropout, grouped_parameters, mask_or_random_replace_tokens,
                        prepare_inputs_and_labels)
 
 __all__ = ["MaskGitVQGAN", "VQGANModel", "MaskGitTransformer", "MaskGiTUViT", "MaskGiTUViT_v2", "PipelineMuse", "get_mask_chedule", "FusedAdamW", "GradReducer",
-           "TrainStep", "prepare_inputs_and_labels", "mask_or_random_replace_tokens", "cond_dropout"]
+           "TrainStep", "prepare_inputs_and_labels", "mask_or_random_replace_tokens", "cond_dropout", "grouped_parameters"]

@@ -98,6 +98,7 @@ class _GeneralFn(torch.autograd.Function):
         ctx.enc_grad = bool(need_grad and enc is not None and enc.requires_grad)
         ctx.set_materialize_grads(False)
         if loss is None:
+            ctx.mark_non_differentiable(logits)       # (eval-mode forward under grad: plain, non-differentiable logits)
             return logits
         ctx.mark_non_differentiable(logits)
         return logits, loss
@@ -367,5 +368,10 @@ class GeneralMaskGitEngine(TapeOps):
             raise MuseHipError("MaskGitTransformer (MI355X build) has no CPU path: move the model and inputs to the GPU")
         params = [p for _, p in self.named_parameters()]
         need_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in params)
+        if labels is None and torch.is_grad_enabled() and self.training and any(p.requires_grad for p in params):
+            # this engine differentiates its internal loss only (the hand-written backward starts at the cross entropy); a
+            # logits-only forward in training mode under grad would hand back logits whose backward cannot run - say so here
+            raise MuseHipError("MaskGitTransformer (text-conditioned / general form): only the internal loss is differentiable - pass "
+                               "`labels` (and `label_smoothing`), or run the logits-only forward under torch.no_grad() / model.eval()")
         return _GeneralFn.apply(self, input_ids, encoder_hidden_states, labels, float(label_smoothing), float(cond_dropout_prob),
                                 cond_dropout_uniforms, need_grad, *params)

@@ -393,7 +393,8 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
                 self.compute_dtype = cd
                 self._wcache, self._wcache_owner = {}, {}
             if encoder_hidden_states is not None and not self.config.add_cross_attention:
-                encoder_hidden_states = None      # (layers without a cross-attention block: the reference would fail on a missing module)
+                # (layers without a cross-attention block: the reference fails on the missing module, :886-889; same error as the flat engine)
+                raise ValueError("this model was built without cross attention (add_cross_attention=False)")
             return self._gen_call(input_ids, encoder_hidden_states, labels, label_smoothing, cond_dropout_prob,
                                   kwargs.get("cond_dropout_uniforms"))
         if encoder_hidden_states is not None:

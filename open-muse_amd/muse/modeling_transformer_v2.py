@@ -289,6 +289,8 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         """d(mapper weights) and d(silu(cond)) of every AdaLN site from the d(scale | shift) the blocks left in the group buffers"""
         for members, w2, dss, N, K in tape:
             Z = len(members)
+            if N % 8 or K % 8:      # rows of the k-major bf16 operands would not be 16-byte chunks (_mm_dw's guard): f32 operands
+                w2 = w2 if w2.dtype == torch.float32 else ops.cast_to_f32(w2.contiguous())
             dsc, xc = self._pair(dss.view(Z * B, N), w2)[0].view(Z, B, N), self._pair(scond, w2)[0]
             gw = torch.empty((Z * N, K), dtype=torch.float32, device=scond.device)
             # dW_z = dss_z^T scond   (both operands k-major, k = batch rows)
@@ -483,6 +485,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             h, sr = self._res_block(h, blk.res_blocks[i], scond, B, side)
             h, sa = self._attn_block(h, blk.attention_blocks[i], enc, senc, B, S, L)
             T["up"].append((sr, sa))
+        self.__dict__["_ada_ss"] = {}     # every site has run: the tape holds what backward needs, nothing pins the [Z, B, N] buffers
         # ConvMlmLayer :1002-1022
         y1 = self._lin(h, self.mlm_layer.conv1)
         y2, _ = self._norm(y1, self.mlm_layer.layer_norm.norm)

@@ -571,6 +571,41 @@ def adamw_multi(table, chunk_first, num_tensors, num_chunks, lr, beta1, beta2, e
                                  weight_decay, step, grad_scale, stream()), "muse_adamw_multi")
 
 
+def _group_hyper(groups):
+    """host array of {lr, beta1, beta2, eps, weight_decay} rows for muse_adamw_*_groups (kept alive by the caller for the call)"""
+    import ctypes
+    if not 1 <= len(groups) <= 8:
+        raise _hip.MuseHipError(f"FusedAdamW: 1..8 parameter groups are supported, got {len(groups)}")
+    flat = []
+    for g in groups:
+        flat += [float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"])]
+    return (ctypes.c_float * len(flat))(*flat)
+
+
+def adamw_flat_groups(p, g, m, v, p_bf16, base, seg_end, seg_group, groups, step, grad_scale=1.0):
+    """AdamW on elements [base, base + p.numel()) of a flat buffer whose segments belong to different parameter groups
+    (muse_adamw_flat_groups); p, g, m, v, p_bf16 are the slices starting at `base`; `groups`: torch param_groups-like dicts"""
+    require_gpu(p, g, m, v, seg_end, seg_group)
+    import ctypes
+    hy = _group_hyper(groups)
+    e0 = _prof_begin()
+    check(lib().muse_adamw_flat_groups(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(p_bf16), p.numel(), int(base),
+                                       seg_end.data_ptr(), seg_group.data_ptr(), int(seg_end.numel()),
+                                       ctypes.cast(hy, ctypes.c_void_p), len(groups), int(step), float(grad_scale), stream()),
+          "muse_adamw_flat_groups")
+    _prof_end(e0, "adamw", 28.0 * p.numel() + (2.0 * p.numel() if p_bf16 is not None else 0.0), "byte")
+
+
+def adamw_multi_groups(table, chunk_first, num_tensors, num_chunks, groups, step, grad_scale=1.0):
+    """muse_adamw_multi with a group column in the table (7 x int64 per tensor)"""
+    require_gpu(table, chunk_first)
+    import ctypes
+    hy = _group_hyper(groups)
+    check(lib().muse_adamw_multi_groups(table.data_ptr(), chunk_first.data_ptr(), int(num_tensors), int(num_chunks),
+                                        ctypes.cast(hy, ctypes.c_void_p), len(groups), int(step), float(grad_scale), stream()),
+          "muse_adamw_multi_groups")
+
+
 def cast_to_bf16(src, dst=None):
     require_gpu(src)
     if dst is None:
@@ -885,10 +920,11 @@ def nhwc_to_nchw(x, C_):
     return out
 
 
-def vq_nearest(z_flat, codebook, en=None):
+def vq_nearest(z_flat, codebook, en=None, return_dist=False):
     """argmin_j |z - e_j|^2 computed as the reference does: addmm(|z|^2 + |e|^2, z, e^T, alpha=-2) then argmin.
 
-    z_flat [N, D] f32, codebook [Kc, D] f32 -> int64 [N]."""
+    z_flat [N, D] f32, codebook [Kc, D] f32 -> int64 [N] (with return_dist also the f32 distance rows [N, Kc] the argmin ran over:
+    the parity tests' near-tie accounting reads them)."""
     require_gpu(z_flat, codebook)
     N, D = z_flat.shape
     Kc = codebook.shape[0]
@@ -902,7 +938,7 @@ def vq_nearest(z_flat, codebook, en=None):
          bias=en, rowvec=zn)
     idx = torch.empty(N, dtype=torch.int64, device=z_flat.device)
     check(lib().muse_argmin_rows(dist.data_ptr(), idx.data_ptr(), N, Kc, Kc, stream()), "muse_argmin_rows")
-    return idx
+    return (idx, dist) if return_dist else idx
 
 
 def vq_neg_distances_scaled(z_flat, codebook, inv_temp):

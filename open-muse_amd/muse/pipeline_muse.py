@@ -82,8 +82,10 @@ class PipelineMuse:
             n = num_images_per_prompt
             rep = lambda t: None if t is None else t.to(self.device).repeat_interleave(n, dim=0)   # noqa: E731
             t0 = float(temperature[0]) if isinstance(temperature, (tuple, list)) else float(temperature)
-            neg = negative_prompt_embeds if negative_prompt_embeds is not None else empty_embeds
-            ids = self.transformer.generate2(encoder_hidden_states=rep(prompt_embeds), negative_embeds=rep(neg), timesteps=timesteps,
+            # `empty_embeds` is NOT the negative prompt here: the reference's MaskGitTransformer.generate2 swallows it in **kwargs
+            # (muse/modeling_transformer.py:1363-1378) and fills the unconditional half with zeros_like(encoder_hidden_states) when no
+            # negative_embeds are given (:1398-1402) - so does ours
+            ids = self.transformer.generate2(encoder_hidden_states=rep(prompt_embeds), negative_embeds=rep(negative_prompt_embeds), timesteps=timesteps,
                                              temperature=t0, guidance_scale=guidance_scale, noise_schedule=schedule,
                                              generator=generator)
             intermediate = None

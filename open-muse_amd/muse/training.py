@@ -141,21 +141,50 @@ class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        if len(self.param_groups) != 1:
-            raise MuseHipError("FusedAdamW supports a single parameter group (the reference uses one: :257-263)")
-        owner = _owner_of(self.param_groups[0]["params"])
+        # Parameter groups: `params` may be the list of dicts training/train_muse.py:425-445 builds (weight decay on the matrices,
+        # none on bias / LayerNorm / embedding weights) - torch.optim semantics, every group its own lr / betas / eps / weight_decay.
+        # One group runs the single-set kernels (muse_adamw_flat / _multi); several run the *_groups kernels, still ONE launch.
+        if len(self.param_groups) > 8:
+            raise MuseHipError(f"FusedAdamW: at most 8 parameter groups (got {len(self.param_groups)})")
+        every = self._all_params()
+        owner = _owner_of(every)
         self._model = weakref.ref(owner) if owner is not None else None
+        self._flat_gid = self._seg_dev = None
         if owner is not None:
-            mine, theirs = self.param_groups[0]["params"], owner._param_order()
-            if len(mine) != len(theirs) or any(a is not b for a, b in zip(mine, theirs)):
+            theirs = owner._param_order()
+            if len(every) != len(theirs) or {id(q) for q in every} != {id(q) for q in theirs}:
                 raise MuseHipError("FusedAdamW steps the model's whole flat parameter buffer: pass model.parameters() "
-                                   "(all of them, in order); for a subset use torch.optim.AdamW")
+                                   "(all of them, as one list or split into groups); for a subset use torch.optim.AdamW")
+            gid = {id(q): k for k, grp in enumerate(self.param_groups) for q in grp["params"]}
+            self._flat_gid = [gid[id(q)] for q in theirs]           # group of each parameter, in the flat buffer's order
         self._m = self._v = None
         self._step = 0
         self._table = self._chunk_first = self._table_key = self._stage = None   # per-tensor mode: device table of muse_adamw_multi
         self._ranges_done = self._ranges_done_live = None                        # (step, [(begin, end), ...]) applied inside backward
         self._upd_stream, self._upd_used = None, False                           # stream of the per-bucket update (begin_step_in_reducer)
         self.grad_scale = 1.0   # multiplied into the gradient inside the kernel (GradReducer sets 1/world for SUM reductions)
+
+    def _all_params(self):
+        """every parameter, in torch.optim's state-dict order (group by group)"""
+        return [q for grp in self.param_groups for q in grp["params"]]
+
+    def _segments(self, model):
+        """device tables of the flat buffer's parameter-group segments: (seg_end int64 - absolute element offsets -, seg_group int32).
+        Neighbouring parameters of one group form one segment; a parameter's alignment padding stays with it."""
+        flat = model.flat_params()
+        if self._seg_dev is not None and self._seg_dev[0].device == flat.device and self._seg_dev[2] == tuple(model._offsets):
+            return self._seg_dev[0], self._seg_dev[1]
+        ends, gids = [], []
+        offs = list(model._offsets) + [flat.numel()]
+        for i, k in enumerate(self._flat_gid):
+            if gids and gids[-1] == k:
+                ends[-1] = offs[i + 1]
+            else:
+                ends.append(offs[i + 1])
+                gids.append(k)
+        self._seg_dev = (torch.tensor(ends, dtype=torch.int64, device=flat.device),
+                         torch.tensor(gids, dtype=torch.int32, device=flat.device), tuple(model._offsets))
+        return self._seg_dev[0], self._seg_dev[1]
 
     def _flat_grad_checked(self, model, params):
         """the flat gradient buffer, after making sure it really holds this step's gradients: every p.grad must be the
@@ -176,9 +205,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         self._check_not_partial()
         loss = closure() if closure is not None else None
-        grp = self.param_groups[0]
         if self._model is None:
-            return self._step_per_tensor(grp, loss)
+            return self._step_per_tensor(loss)
         model = self._model()
         if model is None:
             raise MuseHipError("FusedAdamW: the model that owned these parameters is gone")
@@ -186,11 +214,12 @@ class FusedAdamW(torch.optim.Optimizer):
             raise MuseHipError("FusedAdamW: the model's flat parameter buffer was rebuilt (model.to(...) / load after the "
                                "optimizer was created is fine, replacing p.data is not)")
         flat = model.flat_params()
-        if any(p.grad is None for p in grp["params"]):
-            if all(p.grad is None for p in grp["params"]):
+        order = model._param_order()
+        if any(p.grad is None for p in order):
+            if all(p.grad is None for p in order):
                 return loss  # nothing to do before the first backward (torch skips None grads)
             raise MuseHipError("FusedAdamW: some parameters have no gradient; the flat step needs all of them")
-        g = self._flat_grad_checked(model, grp["params"])
+        g = self._flat_grad_checked(model, order)
         self._ensure_flat_state(flat)
         self._step += 1
         shadow = model._flat_c if model._flat_c is not None and model._flat_c.device == flat.device else None
@@ -212,8 +241,13 @@ class FusedAdamW(torch.optim.Optimizer):
         return loss
 
     def _apply(self, model, b, e, shadow):
-        grp = self.param_groups[0]
         flat, g = model.flat_params(), model.flat_grads()
+        if len(self.param_groups) > 1:
+            seg_end, seg_group = self._segments(model)
+            ops.adamw_flat_groups(flat[b:e], g[b:e], self._m[b:e], self._v[b:e], None if shadow is None else shadow[b:e], b,
+                                  seg_end, seg_group, self.param_groups, self._step_for_apply, grad_scale=float(self.grad_scale))
+            return
+        grp = self.param_groups[0]
         ops.adamw_flat(flat[b:e], g[b:e], self._m[b:e], self._v[b:e], None if shadow is None else shadow[b:e], float(grp["lr"]),
                        grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], self._step_for_apply,
                        grad_scale=float(self.grad_scale))
@@ -328,18 +362,20 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._m.shape != flat.shape:
             raise MuseHipError("FusedAdamW: optimizer state does not match the model's flat parameter buffer")
 
-    def _step_per_tensor(self, grp, loss):
+    def _step_per_tensor(self, loss):
         """parameters that are ordinary (contiguous f32) tensors: one muse_adamw_multi launch over all of them.  torch.optim.AdamW
         semantics: a parameter without a gradient is skipped and keeps its own state; the step count is shared (all
-        parameters of these models receive a gradient every step)."""
-        params = [p for p in grp["params"] if p.grad is not None]
+        parameters of these models receive a gradient every step).  With several parameter groups the table carries each
+        tensor's group and the launch is muse_adamw_multi_groups."""
+        multi = len(self.param_groups) > 1
+        params = [(p, k) for k, grp in enumerate(self.param_groups) for p in grp["params"] if p.grad is not None]
         if not params:
             return loss
         if self._m is None:
             self._m, self._v = {}, {}
         self._step += 1
         rows = []
-        for p in params:
+        for p, gk in params:
             if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                 raise MuseHipError("FusedAdamW: parameters and gradients must be contiguous float32 tensors")
             k = id(p)
@@ -351,19 +387,21 @@ class FusedAdamW(torch.optim.Optimizer):
             shadow = getattr(p, "_muse_shadow", None)   # the model's cached bf16 compute copy of this weight (MaskGiTUViT bf16 mode)
             if shadow is not None and (shadow.numel() != p.numel() or shadow.device != p.device or not shadow.is_contiguous()):
                 shadow = None
-            rows.append((p.data.data_ptr(), p.grad.data_ptr(), self._m[k].data_ptr(), self._v[k].data_ptr(),
-                         shadow.data_ptr() if shadow is not None else 0, p.numel()))
+            row = (p.data.data_ptr(), p.grad.data_ptr(), self._m[k].data_ptr(), self._v[k].data_ptr(),
+                   shadow.data_ptr() if shadow is not None else 0, p.numel())
+            rows.append(row + (gk,) if multi else row)
         # one launch for all tensors.  Gradients are fresh allocations every step, so the pointer table is rebuilt every step: ~500
         # rows staged through two alternating PINNED host buffers and copied asynchronously (a pageable copy would make the host
         # wait for the stream and lose its run-ahead into the next step)
-        dev = params[0].device
+        dev = params[0][0].device
+        ncol = 7 if multi else 6
         key = tuple(rows)
         if self._table_key != key:
             nt = len(rows)
-            if self._table is None or self._table.shape[0] < nt or self._table.device != dev:
-                self._table = torch.empty((nt, 6), dtype=torch.int64, device=dev)
+            if self._table is None or self._table.shape[0] < nt or self._table.shape[1] != ncol or self._table.device != dev:
+                self._table = torch.empty((nt, ncol), dtype=torch.int64, device=dev)
                 self._chunk_first = torch.empty(nt + 1, dtype=torch.int32, device=dev)
-                self._stage = [(torch.empty((nt, 6), dtype=torch.int64).pin_memory(), torch.empty(nt + 1, dtype=torch.int32).pin_memory(),
+                self._stage = [(torch.empty((nt, ncol), dtype=torch.int64).pin_memory(), torch.empty(nt + 1, dtype=torch.int32).pin_memory(),
                                 torch.cuda.Event()) for _ in range(2)]
                 self._stage_i = 0
             ht, hf, ev = self._stage[self._stage_i]
@@ -381,15 +419,27 @@ class FusedAdamW(torch.optim.Optimizer):
             self._chunk_first[:nt + 1].copy_(hf[:nt + 1], non_blocking=True)
             ev.record(torch.cuda.current_stream(dev))
             self._table_key, self._nchunks = key, nchunks
+        if multi:
+            ops.adamw_multi_groups(self._table, self._chunk_first, len(rows), self._nchunks, self.param_groups, self._step,
+                                   grad_scale=float(self.grad_scale))
+            return loss
+        grp = self.param_groups[0]
         ops.adamw_multi(self._table, self._chunk_first, len(rows), self._nchunks, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
                         grp["eps"], grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
         return loss
 
     # ---- checkpointing in torch.optim.AdamW's layout ----------------------------------------------------------------
+    def _flat_offsets(self, model):
+        return {id(q): o for q, o in zip(model._param_order(), model._offsets)}
+
     def state_dict(self):
-        ps = self.param_groups[0]["params"]
-        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
-        group["params"] = list(range(len(ps)))
+        ps = self._all_params()
+        groups, n0 = [], 0
+        for grp in self.param_groups:                      # torch.optim's packing: parameters numbered group by group
+            g = {k: v for k, v in grp.items() if k != "params"}
+            g["params"] = list(range(n0, n0 + len(grp["params"])))
+            n0 += len(grp["params"])
+            groups.append(g)
         state = {}
         if self._step > 0 and self._m is not None:
             stepv = torch.tensor(float(self._step))
@@ -398,22 +448,26 @@ class FusedAdamW(torch.optim.Optimizer):
                     if id(p) in self._m:
                         state[i] = {"step": stepv.clone(), "exp_avg": self._m[id(p)], "exp_avg_sq": self._v[id(p)]}
             else:
-                model = self._model()
-                for i, (p, o) in enumerate(zip(ps, model._offsets)):
-                    n = p.numel()
+                offs = self._flat_offsets(self._model())
+                for i, p in enumerate(ps):
+                    o, n = offs[id(p)], p.numel()
                     state[i] = {"step": stepv.clone(), "exp_avg": self._m[o:o + n].view(p.shape),
                                 "exp_avg_sq": self._v[o:o + n].view(p.shape)}
-        return {"state": state, "param_groups": [group]}
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
         if "state" not in sd or "param_groups" not in sd:
             raise MuseHipError("FusedAdamW.load_state_dict expects torch.optim's layout {'state', 'param_groups'}")
-        ps = self.param_groups[0]["params"]
-        grp = sd["param_groups"][0]
-        ids = list(grp.get("params", range(len(ps))))
-        if len(ids) != len(ps):
-            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
-        self.param_groups[0].update({k: v for k, v in grp.items() if k != "params"})
+        ps = self._all_params()
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        ids = []
+        for mine, grp in zip(self.param_groups, sd["param_groups"]):
+            gi = list(grp.get("params", range(len(ids), len(ids) + len(mine["params"]))))
+            if len(gi) != len(mine["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            ids += gi
+            mine.update({k: v for k, v in grp.items() if k != "params"})
         state = {ids.index(k) if k in ids else k: v for k, v in sd["state"].items()}
         steps = {int(float(v["step"])) for v in state.values()}
         if len(steps) > 1:
@@ -437,15 +491,26 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(state) != len(ps):
             raise MuseHipError("FusedAdamW (flat): the checkpoint must carry state for every parameter")
         flat = model.flat_params()
+        offs = self._flat_offsets(model)
         self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
-        for i, (p, o) in enumerate(zip(ps, model._offsets)):
-            n = p.numel()
+        for i, p in enumerate(ps):
+            o, n = offs[id(p)], p.numel()
             for name, buf in (("exp_avg", self._m), ("exp_avg_sq", self._v)):
                 t = state[i][name]
                 if tuple(t.shape) != tuple(p.shape):
                     raise ValueError(f"FusedAdamW.load_state_dict: {name} of parameter {i} has shape {tuple(t.shape)}, "
                                      f"expected {tuple(p.shape)}")
                 buf[o:o + n].view(p.shape).copy_(t.detach().to(device=flat.device, dtype=torch.float32))
+
+
+def grouped_parameters(model, weight_decay, no_decay=("bias", "layer_norm.weight", "mlm_ln.weight", "embeddings.weight")):
+    """The two parameter groups of training/train_muse.py:425-437 - weight decay on everything whose name carries none of the
+    `no_decay` fragments, 0.0 on the rest - ready for `muse.FusedAdamW(grouped_parameters(model, wd), lr=..., weight_decay=wd)`."""
+    named = list(model.named_parameters())
+    return [
+        {"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": weight_decay},
+        {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
+    ]
 
 
 class GradReducer:
@@ -475,6 +540,7 @@ class GradReducer:
         self._handles = []
         self._stream = None
         self.post_reduce = None   # callable(lo, hi): runs on the reduction stream right after bucket [lo, hi) has been averaged
+        self.stats = {"buckets": 0, "bytes": 0}
         # Models with a flat gradient buffer (MaskGitTransformer) report finished ranges during backward.  Models whose
         # parameters are ordinary tensors (MaskGiTUViT: one autograd node hands every gradient back at once) are reduced in
         # finish(): gradients packed, in reverse parameter order, into the same large buckets.
@@ -522,6 +588,8 @@ class GradReducer:
         packed = []
         for bucket in self._buckets(grads):
             flat = torch.cat([g.reshape(-1) for g in bucket])        # pack (one pass); the collective then moves one large message
+            self.stats["buckets"] += 1
+            self.stats["bytes"] += flat.numel() * (2 if self.grad_dtype == torch.bfloat16 else 4)
             if on_gpu:
                 self._stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._stream):
@@ -563,6 +631,8 @@ class GradReducer:
 
     def _launch(self, lo, hi):
         g = self.model.flat_grads()[lo:hi]
+        self.stats["buckets"] += 1                     # (bench.py's `comm` block: buckets and payload bytes per step)
+        self.stats["bytes"] += (hi - lo) * (2 if self.grad_dtype == torch.bfloat16 else 4)
         if g.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(priority=-1)

@@ -273,6 +273,109 @@ def test_adamw_multi_matches_flat():
                 assert torch.equal(x.view(torch.int16), y.view(torch.int16))
 
 
+def test_adamw_flat_groups_matches_torch_and_flat():
+    """muse_adamw_flat_groups: a flat buffer whose segments belong to different parameter groups (training/train_muse.py:425-445:
+    weight decay on the matrices, none on bias / LayerNorm / embedding weights; here also a third group with its own lr / betas / eps).
+    (1) one group: bit-identical to muse_adamw_flat; (2) segment boundaries that are not multiples of 4 or of the 4096-element chunk,
+    range-wise calls (base > 0) == one call over the whole buffer, bit for bit; (3) == torch.optim.AdamW with the same groups."""
+    ops = _ops()
+    sizes = [5000, 768, 4096, 3, 10001, 8, 4100, 12288]            # parameters, back to back (offsets not aligned to anything)
+    gid = [0, 1, 0, 2, 0, 1, 1, 0]
+    groups = [dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05), dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0),
+              dict(lr=3e-4, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.1)]
+    n = sum(sizes)
+    npad = (n + 3) // 4 * 4
+    p0, g0 = rnd((npad,), 90), rnd((npad,), 91, 0.1)
+    def fresh():
+        return (p0.to(DEV).clone(), g0.to(DEV).clone(), torch.zeros(npad, device=DEV), torch.zeros(npad, device=DEV),
+                torch.zeros(npad, dtype=torch.bfloat16, device=DEV))
+    ends, gids, o = [], [], 0
+    for sz, k in zip(sizes, gid):
+        o += sz
+        if gids and gids[-1] == k:
+            ends[-1] = o
+        else:
+            ends.append(o); gids.append(k)
+    ends[-1] = npad
+    seg_end = torch.tensor(ends, dtype=torch.int64, device=DEV)
+    seg_group = torch.tensor(gids, dtype=torch.int32, device=DEV)
+    # (1) one group == muse_adamw_flat
+    a, b = fresh(), fresh()
+    one_end = torch.tensor([npad], dtype=torch.int64, device=DEV)
+    one_grp = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for step in (1, 2):
+        ops.adamw_flat(a[0], a[1], a[2], a[3], a[4], 1e-3, 0.9, 0.999, 1e-8, 0.05, step, grad_scale=0.5)
+        ops.adamw_flat_groups(b[0], b[1], b[2], b[3], b[4], 0, one_end, one_grp, groups[:1], step, grad_scale=0.5)
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)
+    # (2) whole buffer == three ranges
+    a, b = fresh(), fresh()
+    cuts = [0, 5768, 5768 + 4096 + 4, npad]      # 16-byte aligned range starts, inside and between segments
+    for step in (1, 2, 3):
+        ops.adamw_flat_groups(a[0], a[1], a[2], a[3], a[4], 0, seg_end, seg_group, groups, step)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            ops.adamw_flat_groups(b[0][lo:hi], b[1][lo:hi], b[2][lo:hi], b[3][lo:hi], b[4][lo:hi], lo, seg_end, seg_group, groups, step)
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)
+    assert torch.equal(a[4][:n].cpu(), a[0][:n].cpu().to(torch.bfloat16))
+    # (3) torch.optim.AdamW with the same groups
+    twins, o = [], 0
+    for sz in sizes:
+        twins.append(torch.nn.Parameter(p0[o:o + sz].clone())); o += sz
+    ref = torch.optim.AdamW([dict(params=[t for t, k in zip(twins, gid) if k == j], **groups[j]) for j in range(3)])
+    for step in (1, 2, 3):
+        o = 0
+        for t, sz in zip(twins, sizes):
+            t.grad = g0[o:o + sz].clone(); o += sz
+        ref.step()
+    o = 0
+    for t, sz, k in zip(twins, sizes, gid):
+        assert float((a[0][o:o + sz].cpu() - t.data).abs().max()) < 2e-6, (o, k)
+        o += sz
+
+
+def test_adamw_multi_groups_matches_multi_and_torch():
+    """muse_adamw_multi_groups (table with a group column): one group == muse_adamw_multi bit for bit; two groups == torch.optim.AdamW"""
+    ops = _ops()
+    sizes = [1, 3, 4096, 4097, 10007, 5]
+    gid = [0, 1, 0, 0, 1, 1]
+    groups = [dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05), dict(lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0)]
+    def build():
+        ts = []
+        for i, sz in enumerate(sizes):
+            ts.append((rnd((sz,), 120 + 2 * i).to(DEV), rnd((sz,), 121 + 2 * i, 0.1).to(DEV), torch.zeros(sz, device=DEV),
+                       torch.zeros(sz, device=DEV)))
+        return ts
+    def table(ts, with_group, gids):
+        rows, first, nch = [], [], 0
+        for (p, g, m, v), k in zip(ts, gids):
+            r = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 0, p.numel())
+            rows.append(r + (k,) if with_group else r)
+            first.append(nch); nch += (p.numel() + 4095) // 4096
+        first.append(nch)
+        return torch.tensor(rows, dtype=torch.int64).to(DEV), torch.tensor(first, dtype=torch.int32).to(DEV), nch
+    a, b = build(), build()
+    ta, fa, nch = table(a, False, gid)
+    tb, fb, _ = table(b, True, [0] * len(sizes))
+    for step in (1, 2):
+        ops.adamw_multi(ta, fa, len(sizes), nch, 1e-3, 0.9, 0.99, 1e-8, 0.05, step)
+        ops.adamw_multi_groups(tb, fb, len(sizes), nch, groups[:1], step)
+    for x, y in zip(a, b):
+        for u, w in zip(x, y):
+            assert torch.equal(u, w)
+    c = build()
+    tc, fc, _ = table(c, True, gid)
+    twins = [torch.nn.Parameter(t[0].cpu().clone()) for t in c]
+    ref = torch.optim.AdamW([dict(params=[t for t, k in zip(twins, gid) if k == j], **groups[j]) for j in range(2)])
+    for step in (1, 2, 3):
+        for t, x in zip(twins, c):
+            t.grad = x[1].cpu().clone()
+        ref.step()
+        ops.adamw_multi_groups(tc, fc, len(sizes), nch, groups, step)
+    for t, x in zip(twins, c):
+        assert float((x[0].cpu() - t.data).abs().max()) < 2e-6
+
+
 def test_adamw_matches_torch():
     ops = _ops()
     n = 4099

@@ -110,6 +110,49 @@ def test_generate2_text_guided_vs_reference_golden(golden_dir):
     assert torch.equal(outs[0], outs[1]) and int(outs[0].max()) < cfg["codebook_size"]
 
 
+def test_pipeline_text_conditioned_two_prompts_guided(golden_dir):
+    """muse.PipelineMuse on a text-conditioned MaskGitTransformer with TWO prompts, two images per prompt and guidance > 0: the
+    unconditional half is zeros unless `negative_prompt_embeds` is given - `empty_embeds` (a [1, L, D] tensor the reference's
+    MaskGitTransformer.generate2 swallows in **kwargs, muse/modeling_transformer.py:1363-1402) must not become the negative prompt
+    (it would neither match the reference nor the doubled batch's row count).  The pipeline's token ids == generate2 called the
+    way the reference's pipeline calls it, with the same generator."""
+    import muse
+    g = np.load(os.path.join(golden_dir, "generate2_text_tiny.npz"))
+    cfg = W.TRANSFORMER_TEXT_TINY
+    m = muse.MaskGitTransformer(**cfg)
+    m.load_state_dict(W.fill_state_dict(W.transformer_shapes(cfg), int(g["seed"]), "transformer"))
+    v = muse.MaskGitVQGAN(**W.VQGAN_TINY)
+    pipe = muse.PipelineMuse(vae=v, transformer=m).to(DEV)
+    m.eval().set_compute_dtype(torch.float32)
+    L = int(g["text_len"])
+    _, _, enc = W.transformer_text_inputs(cfg, 2, L, int(g["seed"]) + 1)
+    empty = torch.full((1, L, enc.shape[-1]), 0.37)
+    neg = torch.from_numpy(g["negative_embeds"])[:2]
+    seen = {}
+    orig = m.generate2
+    def spy(*a, **k):
+        seen["neg"] = k.get("negative_embeds")
+        seen["ids"] = orig(*a, **k)
+        return seen["ids"]
+    m.generate2 = spy
+    try:
+        gen = lambda: torch.Generator(device=DEV).manual_seed(11)   # noqa: E731
+        imgs = pipe(prompt_embeds=enc, empty_embeds=empty, timesteps=3, guidance_scale=2.5, num_images_per_prompt=2, output_type="np",
+                    generator=gen())
+        assert imgs.shape[0] == 4 and np.isfinite(imgs).all() and seen["neg"] is None
+        want = orig(encoder_hidden_states=enc.to(DEV).repeat_interleave(2, dim=0), negative_embeds=None, timesteps=3, temperature=2.0,
+                    guidance_scale=2.5, generator=gen())
+        assert torch.equal(seen["ids"], want)
+        pipe(prompt_embeds=enc, negative_prompt_embeds=neg, empty_embeds=empty, timesteps=3, guidance_scale=2.5, num_images_per_prompt=2,
+             output_type="np", generator=gen())
+        assert seen["neg"].shape[0] == 4
+        want = orig(encoder_hidden_states=enc.to(DEV).repeat_interleave(2, dim=0), negative_embeds=neg.to(DEV).repeat_interleave(2, dim=0),
+                    timesteps=3, temperature=2.0, guidance_scale=2.5, generator=gen())
+        assert torch.equal(seen["ids"], want)
+    finally:
+        m.generate2 = orig
+
+
 def test_uvit_generate2_vs_reference_golden(golden_dir):
     """MaskGiTUViT_v2.generate2 of the reference with classifier-free guidance 3.0, temperature (2, 0), 5 steps: final ids and the
     per-step raw samples (`intermediate`)"""

@@ -298,6 +298,38 @@ def test_uvit_train_step_with_fused_adamw(golden_dir):
         assert rel_err(p, q) < 1e-5, name
 
 
+def test_uvit_fused_adamw_parameter_groups(golden_dir):
+    """training/train_muse.py:425-445 on the U-ViT: two groups (no weight decay on bias / layer_norm.weight / mlm_ln.weight /
+    embeddings.weight) through ONE muse_adamw_multi_groups launch == torch.optim.AdamW with the same groups"""
+    import muse
+    g, cfg, sd = _load_golden(golden_dir)
+    model = muse.MaskGiTUViT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train()
+    wd = 0.3
+    groups = muse.training.grouped_parameters(model, wd)
+    assert groups[0]["params"] and groups[1]["params"]
+    opt = muse.FusedAdamW(groups, lr=1e-3, betas=(0.9, 0.99), weight_decay=wd, eps=1e-8)
+    twins = {n: torch.nn.Parameter(p.detach().clone()) for n, p in model.named_parameters()}
+    nd = ("bias", "layer_norm.weight", "mlm_ln.weight", "embeddings.weight")            # the literal of train_muse.py:426-436
+    ref = torch.optim.AdamW([{"params": [p for n, p in twins.items() if not any(x in n for x in nd)], "weight_decay": wd},
+                             {"params": [p for n, p in twins.items() if any(x in n for x in nd)], "weight_decay": 0.0}],
+                            lr=1e-3, betas=(0.9, 0.99), weight_decay=wd, eps=1e-8)
+    assert [len(x["params"]) for x in ref.param_groups] == [len(x["params"]) for x in groups]
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        _, loss = model(*args, labels=labels)
+        loss.backward()
+        for n, p in model.named_parameters():
+            twins[n].grad = p.grad.detach().clone()
+        opt.step()
+        ref.step()
+    for n, p in model.named_parameters():
+        assert rel_err(p, twins[n]) < 1e-5, n
+
+
 def test_uvit_bf16_mode_vs_reference_golden(golden_dir):
     """set_compute_dtype(torch.bfloat16): weight-GEMM operands rounded to bf16 (f32 accumulate / outputs), everything else f32.
     Expected from a CPU emulation of the same rounding: logits 8e-3, loss 1.3e-4, gradients <= 2.5e-2 (relative to max)."""

@@ -56,6 +56,80 @@ def test_flat_parameter_storage():
     assert g.numel() == m.flat_params().numel()
 
 
+def test_fused_adamw_parameter_groups_host_logic(monkeypatch):
+    """training/train_muse.py:425-445 hands the optimizer TWO parameter groups (no weight decay on bias / LayerNorm / embedding
+    weights).  Host side of muse.FusedAdamW for them, without a GPU: the segment table of the flat buffer (neighbouring parameters of a
+    group merged, padding kept with its parameter), range-wise application against the shared table, torch.optim.AdamW's state-dict
+    numbering.  The HIP kernel is replaced by its CPU restatement (oracle.adamw_step per segment) - the kernel itself is tested on the
+    GPU (test_adamw_flat_groups_matches_torch_and_flat)."""
+    import muse
+    from muse import ops
+    from oracle import maskgit_oracle as O
+    calls = []
+
+    def groups_cpu(p, g, m, v, p_bf16, base, seg_end, seg_group, groups, step, grad_scale=1.0):
+        assert p_bf16 is None and grad_scale == 1.0
+        calls.append((base, base + p.numel()))
+        lo = 0
+        for e, k in zip(seg_end.tolist(), seg_group.tolist()):
+            a, b = max(lo, base), min(e, base + p.numel())
+            if a < b:
+                h = groups[k]
+                sl = slice(a - base, b - base)
+                O.adamw_step(p[sl], g[sl], m[sl], v[sl], int(step), h["lr"], h["betas"][0], h["betas"][1], h["eps"], h["weight_decay"])
+            lo = e
+    monkeypatch.setattr(ops, "adamw_flat_groups", groups_cpu)
+    monkeypatch.setattr(ops, "adamw_flat", lambda *a, **k: (_ for _ in ()).throw(AssertionError("single-group kernel on a grouped optimizer")))
+    torch.manual_seed(5)
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TINY)
+    m.set_compute_dtype(torch.float32)
+    wd = 0.3
+    groups = muse.grouped_parameters(m, wd)
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert sorted(names[id(p)] for p in groups[1]["params"] if "layers" not in names[id(p)]) == [
+        "embed.position_embeddings.weight", "embed.word_embeddings.weight", "encoder_layer_norm.weight", "mlm_layer.mlm_ln.weight"]
+    opt = muse.FusedAdamW(groups, lr=1e-2, betas=(0.9, 0.99), weight_decay=wd, eps=1e-8)
+    seg_end, seg_group = opt._segments(m)
+    assert int(seg_end[-1]) == m.flat_params().numel() and bool((seg_end[1:] > seg_end[:-1]).all())
+    assert bool((seg_group[1:] != seg_group[:-1]).all())                  # neighbouring segments of one group are merged
+    gid_of = {id(p): k for k, g in enumerate(groups) for p in g["params"]}
+    for p, o in zip(m._param_order(), m._offsets):                        # every parameter lies inside a segment of its own group
+        s = int((seg_end > o).nonzero()[0])
+        assert int(seg_group[s]) == gid_of[id(p)] and o + p.numel() <= int(seg_end[s])
+    twins = {n: torch.nn.Parameter(p.detach().clone()) for n, p in m.named_parameters()}
+    nd = ("bias", "layer_norm.weight", "mlm_ln.weight", "embeddings.weight")
+    ref = torch.optim.AdamW([{"params": [p for n, p in twins.items() if not any(x in n for x in nd)], "weight_decay": wd},
+                             {"params": [p for n, p in twins.items() if any(x in n for x in nd)], "weight_decay": 0.0}],
+                            lr=1e-2, betas=(0.9, 0.99), weight_decay=wd, eps=1e-8)
+    n = m.flat_params().numel()
+    for step in range(3):
+        g = m.flat_grads()
+        g.copy_(torch.sin(torch.arange(n, dtype=torch.float32) * 0.01 * (step + 1)))
+        for p, gv in zip(m._param_order(), m._grad_views):
+            p.grad = gv
+            twins[names[id(p)]].grad = gv.detach().clone()
+        if step == 1:     # range-wise, as backward reports: the tail first, then the rest (what begin_step_in_backward's hook does)
+            opt._ensure_flat_state(m.flat_params())
+            opt._ranges_done_live = (opt._step + 1, [])
+            cut = m._offsets[len(m._offsets) // 2] + 8
+            opt._apply(m, cut, n, None); opt._ranges_done_live[1].append((cut, n))
+            opt._ranges_done, opt._ranges_done_live = opt._ranges_done_live, None
+        opt.step()
+        ref.step()
+    assert (0, n) in calls and any(b > 0 for b, _ in calls)
+    for k, p in m.named_parameters():
+        assert float((p.detach() - twins[k].detach()).abs().max()) < 1e-6, k
+    sd, rsd = opt.state_dict(), ref.state_dict()
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in rsd["param_groups"]]
+    for i, st in rsd["state"].items():
+        assert torch.allclose(sd["state"][i]["exp_avg_sq"], st["exp_avg_sq"], rtol=1e-5, atol=1e-10), i
+    opt2 = muse.FusedAdamW(muse.grouped_parameters(m, wd), lr=1e-2, betas=(0.9, 0.99), weight_decay=wd, eps=1e-8)
+    opt2.load_state_dict(rsd)
+    assert opt2._step == 3 and [g["weight_decay"] for g in opt2.param_groups] == [wd, 0.0]
+    with pytest.raises(muse._hip.MuseHipError):
+        muse.FusedAdamW([{"params": [p]} for p in list(m.parameters())[:9]], lr=1e-3)     # nine groups / a subset of the buffer
+
+
 def test_vqgan_surface(golden_dir):
     import muse
     v = muse.MaskGitVQGAN(**W.VQGAN_TINY)
