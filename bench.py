@@ -276,7 +276,9 @@ def uvit_leg(device, batch, seq, steps=3, f32=False):
     with torch.no_grad():
         for n, p in model.named_parameters():
             p.fill_(1.0) if n.endswith("norm.weight") else p.normal_(0.0, 0.02, generator=g)
-    opt = muse.FusedAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
+    # the optimizer as training/train_muse.py:425-445 builds it: two parameter groups, no weight decay on bias / layer_norm.weight /
+    # mlm_ln.weight / embeddings.weight (one muse_adamw_multi_groups launch)
+    opt = muse.FusedAdamW(muse.grouped_parameters(model, 0.01), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
     ids = torch.randint(0, 8256, (batch, seq), device=device, generator=g)
     labels = torch.where(torch.rand(batch, seq, device=device, generator=g) < 0.5,
                          torch.randint(0, 8192, (batch, seq), device=device, generator=g), torch.full((batch, seq), -100, device=device))

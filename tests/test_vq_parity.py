@@ -34,20 +34,20 @@ def _case(nudge_ulps, push):
     de = cb[j] - cb[i]
     gap = float(dist_o[b, t, j] - dist_o[b, t, i])
     z_h = zf.clone()
-    z_h[b, t] += de * (push * max(gap, VP.ulp32(d)) / (2.0 * float(de.pow(2).sum())))
+    z_h[b, t] += de * ((push * max(gap, 0.0) + 40.0 * VP.ulp32(d)) / (2.0 * float(de.pow(2).sum())))   # 40 ulp: clear of either side's rounding
     dist_h = O.vq_distances(z_h.reshape(B * T, C), cb).view(B, T, -1)
     idx_h = dist_h.argmin(-1)
     return sd, cfg, px, idx_o, dist_o, zf, idx_h, dist_h, z_h, (b, t, i, j)
 
 
 def test_near_tie_is_accepted_and_measured():
-    sd, cfg, px, idx_o, dist_o, z_o, idx_h, dist_h, z_h, (b, t, i, j) = _case(nudge_ulps=6.0, push=3.0)
+    sd, cfg, px, idx_o, dist_o, z_o, idx_h, dist_h, z_h, (b, t, i, j) = _case(nudge_ulps=6.0, push=1.0)
     assert int(idx_o[b, t]) == i and int(idx_h[b, t]) == j, "the constructed near-tie did not flip"
     recs, ok = VP.explain(sd, cfg, px, idx_o, dist_o, z_o, idx_h, dist_h, z_h)
     print(VP.format_records(recs))
     assert ok and len(recs) == int((idx_o != idx_h).sum())
     r = next(x for x in recs if (x["image"], x["token"]) == (b, t))
-    assert r["accepted"] and abs(r["exact_margin_ulp"]) < 40 and r["oracle_top2_margin_ulp"] < 40
+    assert r["accepted"] and abs(r["exact_margin_ulp"]) < 80 and r["oracle_top2_margin_ulp"] < 80
     assert r["hip"]["shift_ulp"] < 0 and abs(r["hip"]["rounding_ulp"]) <= r["hip"]["rounding_bound_ulp"]
     m = VP.oracle_margins(dist_o.view(-1, dist_o.shape[-1]), idx_o, idx_h)
     assert len(m) == len(recs) and abs(m[0]["candidate_gap_ulp"] - r["oracle"]["g_ulp"]) < 1e-6
