@@ -68,6 +68,15 @@ int muse_gemm_tile(const muse_gemm_desc* d);
  * logic (tests assert that the train step's products take the persistent form; MUSE_G256P=0 turns it off). */
 int muse_gemm_path(const muse_gemm_desc* d);
 
+/* GROUPED weight gradients: n <= 6 products C_i[M_i, N_i] = A_i^T B_i (layout_a = layout_b = 1: k-major bf16 operands, k = the token
+ * dimension; f32 output; the four dW = dY^T X of a transformer layer, muse/modeling_transformer.py:770-778,973-977 under autograd)
+ * in ONE launch of the 256^2 LDS-DMA kernel over the concatenated tile lists.  `split_k` (the same for every product) cuts K into
+ * slices written to C_i + s * split_stride_i (reduce with muse_sum_multi: deterministic); split_k = 1 writes (or, accumulate = 1,
+ * adds to) C_i directly.  muse_gemm_group_ok: 0 if muse_gemm_group would take the list, else the error it would return (products
+ * the 256^2 kernel does not take: MUSE_ERR_UNSUPPORTED - the caller then uses muse_gemm per product). */
+int muse_gemm_group_ok(const muse_gemm_desc* d, int32_t n, int32_t split_k);
+int muse_gemm_group(const muse_gemm_desc* d, int32_t n, int32_t split_k, void* stream);
+
 /* 2-D transpose out[c, r] = in[r, c] (strided-batched); used only by the fallback that feeds k-major operands to
  * the k-contiguous GEMM path (MUSE_GEMM_TR=0). */
 int muse_transpose(const void* in, void* out, int32_t dtype, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out,
@@ -214,6 +223,11 @@ int muse_adamw_multi_groups(const int64_t* table, const int32_t* chunk_first, in
                             const float* group_hyper, int32_t ngroups, int32_t step, float grad_scale, void* stream);
 /* out[i] (+)= sum over s < nslices of ws[s*stride + i]: reduction of split-K partial results (n, stride % 4 == 0) */
 int muse_sum_slices(const float* ws, float* out, int32_t nslices, int64_t n, int64_t stride, int32_t accumulate, void* stream);
+/* njobs <= 16 reductions in ONE launch, each bit-identical to the single-job kernel it stands for: kind 0 = muse_sum_slices
+ * (ws[i] -> out[i], nslices[i] slices of n[i] elements stride[i] apart), kind 1 = muse_colsum (out[i][c] (+)= sum over the
+ * nslices[i] rows of the [nslices[i], n[i]] f32 matrix ws[i]).  All arrays are HOST arrays read during the call. */
+int muse_sum_multi(const void* const* ws, void* const* out, const int32_t* nslices, const int64_t* n, const int64_t* stride,
+                   const int32_t* accumulate, const int32_t* kind, int32_t njobs, void* stream);
 int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 

@@ -96,6 +96,49 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   return MUSE_ERR_BAD_ARG;
 }
 
+// ---- grouped weight gradients (gemm256.h: kernel_group) ---------------------------------------------------------------------------
+// n <= 6 products C_i[M_i, N_i] = A_i^T B_i with both operands k-major bf16 (dW = dY^T X: k = the token dimension), f32 outputs, in
+// ONE launch; split_k slices (the same count for every product) go to C_i + s * split_stride_i and are folded by
+// muse_sum_slices_multi.  Every product must be one the 256^2 LDS-DMA kernel takes (muse_gemm_group_ok).
+static int group_fill(const muse_gemm_desc* d, int n, int split_k, g256::GroupParams& gp) {
+  if (!d || n < 1 || n > g256::MAXG || split_k < 1) return MUSE_ERR_BAD_ARG;
+  int start = 0;
+  for (int i = 0; i < n; ++i) {
+    if (d[i].dtype != MUSE_BF16 || d[i].out_dtype != MUSE_F32 || d[i].layout_a != 1 || d[i].layout_b != 1) return MUSE_ERR_UNSUPPORTED;
+    if ((d[i].batch > 1) || d[i].bias || d[i].rowvec || d[i].residual || d[i].act) return MUSE_ERR_UNSUPPORTED;
+    muse_gemm_desc di = d[i];
+    di.split_k = split_k;
+    if (split_k > 1 && di.split_stride == 0) return MUSE_ERR_BAD_ARG;
+    const int rc = fill_params(&di, gp.p[i]);
+    if (rc) return rc;
+    if (di.M < 256 || di.N < 256 || di.K < 128 || !gemm256_ok<float>(gp.p[i], 1, 1)) return MUSE_ERR_UNSUPPORTED;
+    if (split_k > 1 && d[i].accumulate) return MUSE_ERR_BAD_ARG;     // (accumulation happens in muse_sum_slices_multi)
+    gp.tile_start[i] = start;
+    start += ((di.M + 255) / 256) * ((di.N + 255) / 256);
+  }
+  for (int i = n; i <= g256::MAXG; ++i) gp.tile_start[i] = start;
+  for (int i = n; i < g256::MAXG; ++i) gp.p[i] = gp.p[0];
+  gp.n = n;
+  return 0;
+}
+extern "C" int muse_gemm_group_ok(const muse_gemm_desc* d, int32_t n, int32_t split_k) {
+  g256::GroupParams gp;
+  return group_fill(d, n, split_k, gp);
+}
+extern "C" int muse_gemm_group(const muse_gemm_desc* d, int32_t n, int32_t split_k, void* stream) {
+  g256::GroupParams gp;
+  const int rc = group_fill(d, n, split_k, gp);
+  if (rc) return rc;
+  auto kern = g256::kernel_group<float, 1, 1, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gp.tile_start[n], split_k, 1), dim3(512), g256::LDS_BYTES, (hipStream_t)stream, gp);
+  return (int)hipGetLastError();
+}
+
 #ifdef G256_TIMESTAMPS
 extern "C" int muse_debug_gemm_ts(long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g256::g_gemm_ts), &buf, sizeof(buf)); }
 #endif

@@ -420,14 +420,10 @@ __device__ long* g_gemm_ts = nullptr;
 #else
 #define G256_TS(IDX)
 #endif
-template <typename TC, int AL, int BL, int BKV, bool SPREAD = false>
-__global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  G256_TS(0)
-
-  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
-  const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const int tid_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+// one 256 x 256 output tile (or one K slice of it): `tid_` = the tile's index in the problem's grouped raster
+template <typename TC, int AL, int BL, int BKV, bool SPREAD>
+__device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, unsigned char* smem) {
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   constexpr int GM = 4;
   const int grp = tid_ / (GM * ntn), first_m = grp * GM;
   const int gm = min(ntm - first_m, GM), in_grp = tid_ - grp * (GM * ntn);
@@ -607,6 +603,41 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
     }
   }
   G256_TS(3)
+}
+
+template <typename TC, int AL, int BL, int BKV, bool SPREAD = false>
+__global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  G256_TS(0)
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+  const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int tid_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+  tile_body<TC, AL, BL, BKV, SPREAD>(p, tid_, smem);
+}
+
+// ---- grouped launch: the tiles of up to MAXG independent products in ONE grid (the four weight gradients of a transformer layer:
+// 72 + 36 + 27 + 9 tiles at config B).  Each product alone needs a deep K split to fill 256 CUs (out-proj: 9 tiles x 28 slices of 9
+// K-tiles each, a third of such a block is prologue + f32 epilogue) and ends in its own ragged round; together they fill the chip with
+// one or two slices of >= 128 K-tiles per tile.  blockIdx.x walks the concatenated tile lists (XCD-swizzled as a whole: neighbouring
+// tiles of a product still share their operand panels in one XCD's L2), blockIdx.y is the K slice, the same for every product.
+constexpr int MAXG = 6;
+struct GroupParams {
+  GemmParams p[MAXG];
+  int tile_start[MAXG + 1];   // first global tile index of each product (tile_start[n] = total)
+  int n;
+};
+template <typename TC, int AL, int BL, bool SPREAD>
+__global__ __launch_bounds__(512, 2) void kernel_group(const GroupParams gp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ntiles = gp.tile_start[gp.n];
+  const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int gt = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < MAXG; ++k) pi += (k < gp.n && gt >= gp.tile_start[k]) ? 1 : 0;
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  const GemmParams p = gp.p[pi];
+  tile_body<TC, AL, BL, 64, SPREAD>(p, gt - gp.tile_start[pi], smem);
 }
 
 }  // namespace g256

@@ -1661,4 +1661,72 @@ extern "C" int muse_sum_slices(const float* ws, float* out, int32_t nslices, int
   return (int)hipGetLastError();
 }
 
+// ---- several reductions in ONE launch (the weight-gradient stream's tail work of a transformer layer: the split-K slice sums of its
+// grouped dW launch and the column sums of its LayerNorm / GLU weight gradients).  Two job kinds, each the literal arithmetic of the
+// single-job kernel it replaces (bit-identical results: sum_slices_kernel / colsum_kernel):
+//   kind 0  out[i] (+)= sum_{s < ns} ws[s * stride + i], i < n        items of 4096 outputs (1024 threads x 4)
+//   kind 1  out[c] (+)= sum_{r < ns} ws[r * n + c], c < n             items of 16 columns, 64 row groups (colsum_kernel's order)
+#define MUSE_SUM_MAX_JOBS 16
+struct SumJob { const float* ws; float* out; long n, stride; int ns, acc, first_item, kind; };
+struct SumJobs { SumJob j[MUSE_SUM_MAX_JOBS]; int n; };
+__global__ __launch_bounds__(1024) void sum_multi_kernel(const SumJobs J) {
+  __shared__ float red[64][17];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < MUSE_SUM_MAX_JOBS; ++i) k += (i < J.n && (int)blockIdx.x >= J.j[i].first_item) ? 1 : 0;
+  const SumJob jb = J.j[k];
+  const int item = (int)blockIdx.x - jb.first_item;
+  if (jb.kind == 0) {
+    const long i = (long)item * 4096 + threadIdx.x * 4;
+    if (i < jb.n) {             // (n % 4 == 0)
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      if (jb.acc) V4<float>::load(jb.out + i, a);
+      for (int s = 0; s < jb.ns; ++s) {
+        float t[4]; V4<float>::load(jb.ws + s * jb.stride + i, t);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += t[q];
+      }
+      V4<float>::store(jb.out + i, a);
+    }
+    return;
+  }
+  const int c16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int cols = (int)jb.n, rows = jb.ns;
+  const int c = item * 16 + c16;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int r = rg;
+    for (; r + 64 < rows; r += 128) { s0 += jb.ws[(long)r * cols + c]; s1 += jb.ws[(long)(r + 64) * cols + c]; }
+    if (r < rows) s0 += jb.ws[(long)r * cols + c];
+  }
+  red[rg][c16] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) sum += red[q][c16];
+    jb.out[c] = jb.acc ? jb.out[c] + sum : sum;
+  }
+}
+// kind[i] = 0: slice sum (n[i], stride[i] multiples of 4, 16-byte aligned pointers); 1: column sum of a [nslices[i], n[i]] f32 matrix
+extern "C" int muse_sum_multi(const void* const* ws, void* const* out, const int32_t* nslices, const int64_t* n, const int64_t* stride,
+                              const int32_t* accumulate, const int32_t* kind, int32_t njobs, void* stream) {
+  if (njobs <= 0) return 0;
+  if (njobs > MUSE_SUM_MAX_JOBS) return MUSE_ERR_BAD_ARG;
+  SumJobs J;
+  int items = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (n[i] <= 0 || nslices[i] < 1 || (kind[i] != 0 && kind[i] != 1)) return MUSE_ERR_BAD_ARG;
+    if (kind[i] == 0 && ((n[i] & 3) || (stride[i] & 3) || (((uintptr_t)ws[i]) & 15) || (((uintptr_t)out[i]) & 15))) return MUSE_ERR_ALIGN;
+    SumJob& j = J.j[i];
+    j.ws = (const float*)ws[i]; j.out = (float*)out[i]; j.n = n[i]; j.stride = stride[i]; j.ns = nslices[i]; j.acc = accumulate[i];
+    j.first_item = items; j.kind = kind[i];
+    items += kind[i] == 0 ? (int)((n[i] / 4 + 1023) / 1024) : (int)((n[i] + 15) / 16);
+  }
+  for (int i = njobs; i < MUSE_SUM_MAX_JOBS; ++i) J.j[i] = J.j[0];
+  J.n = njobs;
+  hipLaunchKernelGGL(sum_multi_kernel, dim3(items), dim3(1024), 0, (hipStream_t)stream, J);
+  return (int)hipGetLastError();
+}
+
 extern "C" int muse_version(void) { return 1; }

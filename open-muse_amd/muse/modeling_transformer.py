@@ -568,7 +568,30 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
         side = self._wgrad_side_stream(dev) if (self.wgrad_stream and cd == torch.bfloat16) else None
         csq = [] if side is not None else None     # column sums of the LayerNorm / GLU weight gradients, launched on the side stream
 
+        # Grouped form (ops.WGRAD_GROUP >= 1, bf16 mode): the weight gradients of a layer are collected and issued as ONE launch of
+        # the 256^2 kernel over all their tiles + ONE reduction launch (slice sums and the layer's column sums) when the layer is
+        # done (`ready`): 144 tiles x 2 slices of 128 K-tiles each at config B instead of 4 launches of 243-288 blocks with 9-64
+        # K-tiles each (a third of a short block is prologue + f32 epilogue) and 8 small reduction launches.
+        group = [] if (cd == torch.bfloat16 and ops.WGRAD_GROUP >= 1) else None
+
+        def flush_group():
+            if not group:
+                return
+            if side is None:
+                ops.linear_wgrad_group(group, csq)
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.linear_wgrad_group(group, csq)
+                for dy, x, *_ in group:
+                    dy.record_stream(side)   # the caching allocator must not hand these blocks out while the side stream reads them
+                    x.record_stream(side)
+            group.clear()
+
         def wgrad(dy, x, dw, accumulate, **kw):
+            if group is not None:
+                group.append((dy, x, dw, accumulate, kw.get("M"), kw.get("lda")))
+                return
             if side is None:
                 return ops.linear_wgrad(dy, x, dw, accumulate, **kw)
             side.wait_stream(main)           # dy (and on the first use x) were produced on the main stream
@@ -579,6 +602,7 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
             x.record_stream(side)
 
         def ready(i0, i1):
+            flush_group()
             if self.grad_ready_hook is not None and self.direct_grad:
                 end = off[i1] if i1 < len(off) else self._flat_n
                 if side is None:

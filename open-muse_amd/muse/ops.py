@@ -232,6 +232,81 @@ def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     return dw
 
 
+# ---- grouped weight gradients -------------------------------------------------------------------------------------------------------
+# MUSE_WGRAD_GROUP = K slices per product of a grouped dW launch (0: off - one split-K launch + slice sum per weight, the round-3 path).
+WGRAD_GROUP = int(os.environ.get("MUSE_WGRAD_GROUP", "2"))
+
+
+def sum_multi(jobs):
+    """jobs: list of (kind, ws, out, nslices, n, stride, accumulate) with kind 0 = slice sum (muse_sum_slices), 1 = column sum
+    (muse_colsum) - ONE launch, each job bit-identical to its single-job kernel"""
+    for i in range(0, len(jobs), 16):
+        part = jobs[i:i + 16]
+        n = len(part)
+        vp, i32, i64 = C.c_void_p * n, C.c_int32 * n, C.c_int64 * n
+        check(lib().muse_sum_multi(vp(*[j[1].data_ptr() for j in part]), vp(*[j[2].data_ptr() for j in part]),
+                                   i32(*[int(j[3]) for j in part]), i64(*[int(j[4]) for j in part]), i64(*[int(j[5]) for j in part]),
+                                   i32(*[1 if j[6] else 0 for j in part]), i32(*[int(j[0]) for j in part]), n, stream()), "muse_sum_multi")
+
+
+def linear_wgrad_group(items, colsums=None, split=None):
+    """The weight gradients of one transformer layer in ONE launch + one reduction launch.
+    items: list of (dy, x, dw, accumulate, M, lda) as linear_wgrad takes them (M / lda may be None); colsums: a queue of pending
+    column sums (see _colsum_or_defer) folded into the same reduction launch.  Falls back to linear_wgrad per item whenever the
+    256^2 kernel does not take every product (f32 mode, tiny shapes)."""
+    split = WGRAD_GROUP if split is None else split
+    descs, meta = [], []
+    ok = split >= 1 and 1 <= len(items) <= 6 and all(it[0].dtype == torch.bfloat16 and it[1].dtype == torch.bfloat16 for it in items)
+    if ok:
+        arr = (GemmDesc * len(items))()
+        for d, (dy, x, dw, accumulate, M, lda) in zip(arr, items):
+            T_, N = dy.shape
+            N = M if M is not None else N
+            K = x.shape[1]
+            ok = ok and dw.dtype == torch.float32 and dw.is_contiguous() and (N * K) % 4 == 0
+            d.A, d.B = dy.data_ptr(), x.data_ptr()
+            d.dtype, d.out_dtype, d.layout_a, d.layout_b = BF16, F32, 1, 1
+            d.M, d.N, d.K, d.batch, d.zdiv = N, K, T_, 1, 1
+            d.lda, d.ldb, d.ldc = (lda or dy.stride(0)), x.stride(0), K
+            d.alpha = 1.0
+            meta.append((N, K, T_))
+        if ok:
+            ws = []
+            for d, (dy, x, dw, accumulate, M, lda), (N, K, T_) in zip(arr, items, meta):
+                if split > 1:
+                    w = torch.empty((split, N, K), dtype=torch.float32, device=dw.device)
+                    ws.append(w)
+                    d.C, d.split_k, d.split_stride, d.accumulate = w.data_ptr(), split, N * K, 0
+                else:
+                    d.C, d.split_k, d.split_stride, d.accumulate = dw.data_ptr(), 1, 0, (1 if accumulate else 0)
+            ok = lib().muse_gemm_group_ok(arr, len(items), split) == 0
+    if not ok:
+        for dy, x, dw, accumulate, M, lda in items:
+            linear_wgrad(dy, x, dw, accumulate, M=M, lda=lda)
+        if colsums:
+            flush_colsums(colsums)
+        return
+    e0 = _prof_begin()
+    check(lib().muse_gemm_group(arr, len(items), split, stream()), "muse_gemm_group")
+    _prof_end(e0, "gemm_bf16_TT", sum(2.0 * N * K * T_ for N, K, T_ in meta))
+    jobs = []
+    if split > 1:
+        # (the slice count the kernel really cuts: ceil(nk / ceil(nk / split)) slices are non-empty; the others leave their workspace
+        #  slice untouched, so only the written ones are summed)
+        for w, (dy, x, dw, accumulate, M, lda), (N, K, T_) in zip(ws, items, meta):
+            nk = (T_ + 63) // 64
+            per = (nk + split - 1) // split
+            jobs.append((0, w, dw, (nk + per - 1) // per, N * K, N * K, accumulate))
+    if colsums:
+        cur = torch.cuda.current_stream(colsums[0][0].device)
+        for part, dw, nblk, cols, accumulate in colsums:
+            jobs.append((1, part, dw, nblk, cols, cols, accumulate))
+            part.record_stream(cur)
+        colsums.clear()
+    if jobs:
+        sum_multi(jobs)
+
+
 def transpose(src, dst):
     """dst[c, r] = src[r, c] for contiguous 2-D tensors of the same dtype"""
     require_gpu(src, dst)

@@ -273,6 +273,69 @@ def test_adamw_multi_matches_flat():
                 assert torch.equal(x.view(torch.int16), y.view(torch.int16))
 
 
+@pytest.mark.parametrize("split", [1, 2, 3])
+def test_grouped_weight_gradients_match_per_product_launches(split, monkeypatch):
+    """muse_gemm_group (the four dW = dY^T X of a transformer layer as ONE launch over the concatenated tile lists, gemm256.h:
+    kernel_group) + muse_sum_multi: every product bit-identical to its own muse_gemm launch with the same K split + muse_sum_slices
+    (same kernel body, same slices, same summation order), and right against float64; ragged token counts, a product whose dY rows
+    are wider than its valid columns (logits head: M = V, lda = Vp), accumulate into an existing gradient."""
+    ops = _ops()
+    monkeypatch.setenv("MUSE_GEMM256", "1")                 # the per-product reference launches take the 256^2 kernel too (cost model off)
+    T = 64 * 5 + 40                                         # K = tokens: not a multiple of the 64-wide K-tile
+    shapes = [(512, 256), (256, 768), (768, 256), (256, 256)]   # (N_out, K_in): 2 + 3 + 3 + 1 tiles
+    items, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        ld = N + 8 if i == 3 else N
+        dy = rnd((T, ld), 300 + i, 0.5).to(DEV).to(torch.bfloat16)
+        x = rnd((T, K), 310 + i, 0.5).to(DEV).to(torch.bfloat16)
+        acc = i == 1
+        dw0 = rnd((N, K), 320 + i).to(DEV) if acc else torch.full((N, K), float("nan"), device=DEV)
+        items.append((dy, x, dw0.clone(), acc, N if i == 3 else None, ld if i == 3 else None))
+        want = dw0.clone()
+        if split > 1:
+            ws = torch.empty((split, N, K), dtype=torch.float32, device=DEV)
+            ops.gemm(dy, x, ws, N, K, T, la=1, lb=1, lda=ld, ldb=K, ldc=K, split_k=split, split_stride=N * K)
+            nk = (T + 63) // 64
+            per = (nk + split - 1) // split
+            from muse._hip import check, lib, stream
+            check(lib().muse_sum_slices(ws.data_ptr(), want.data_ptr(), (nk + per - 1) // per, N * K, N * K, 1 if acc else 0, stream()), "sum")
+        else:
+            ops.gemm(dy, x, want, N, K, T, la=1, lb=1, lda=ld, ldb=K, ldc=K, accumulate=acc)
+        refs.append((want, (dw0.double() if acc else 0) + dy[:, :N].double().t() @ x.double()))
+    ops.linear_wgrad_group(items, None, split=split)
+    for (dy, x, dw, acc, M, lda), (want, f64) in zip(items, refs):
+        assert torch.equal(dw, want), float((dw - want).abs().max())
+        assert rel_err(dw, f64) < 5e-6
+    from muse._hip import GemmDesc, lib
+    assert lib().muse_gemm_group_ok((GemmDesc * 1)(), 1, 1) != 0          # an empty descriptor is refused, not launched
+
+
+def test_sum_multi_is_bit_identical_to_the_single_job_kernels():
+    """muse_sum_multi: several slice sums (muse_sum_slices) and column sums (muse_colsum) in one launch, each bit-identical to its
+    single-job kernel; with and without accumulation, sizes that do not fill the last work item"""
+    ops = _ops()
+    from muse._hip import check, lib, stream
+    jobs, want = [], []
+    for i, (ns, n) in enumerate([(2, 4096 * 3 + 8), (7, 1000), (3, 4096)]):
+        ws = rnd((ns, n), 400 + i).to(DEV)
+        acc = i == 1
+        out = rnd((n,), 410 + i).to(DEV) if acc else torch.full((n,), float("nan"), device=DEV)
+        ref = out.clone()
+        check(lib().muse_sum_slices(ws.data_ptr(), ref.data_ptr(), ns, n, n, 1 if acc else 0, stream()), "sum")
+        jobs.append((0, ws, out, ns, n, n, acc)); want.append(ref)
+    for i, (rows, cols) in enumerate([(514, 768), (129, 3072), (5, 20)]):
+        part = rnd((rows, cols), 420 + i).to(DEV)
+        acc = i == 2
+        out = rnd((cols,), 430 + i).to(DEV) if acc else torch.full((cols,), float("nan"), device=DEV)
+        ref = out.clone()
+        check(lib().muse_colsum(part.data_ptr(), ref.data_ptr(), rows, cols, 1 if acc else 0, stream()), "colsum")
+        jobs.append((1, part, out, rows, cols, cols, acc)); want.append(ref)
+    ops.sum_multi(jobs)
+    for j, w in zip(jobs, want):
+        assert torch.equal(j[2], w), (j[0], j[3], j[4])
+    assert rel_err(jobs[3][2], jobs[3][1].double().sum(0)) < 1e-6
+
+
 def test_adamw_flat_groups_matches_torch_and_flat():
     """muse_adamw_flat_groups: a flat buffer whose segments belong to different parameter groups (training/train_muse.py:425-445:
     weight decay on the matrices, none on bias / LayerNorm / embedding weights; here also a third group with its own lr / betas / eps).
