@@ -342,6 +342,7 @@ class GeneralMaskGitEngine(TapeOps):
             dx, _ = self._attn_block_g_bwd(dx1, sv["s1"], lyr.attn_layer_norm, lyr.attention, lyr.post_attn_layer_norm if nf else None,
                                            nm + ".attn_layer_norm", nm + ".attention", nm + ".post_attn_layer_norm", G, mode, True)
             T["layers"][li] = None
+            self._report_grads(G)        # (data-parallel: this layer's gradients go to the reducer's buckets while backward continues)
         if pd_h > 0.0:
             ops.dropout(dx, pd_h, seed, 0, out=dx)
         gw = torch.zeros_like(self._f(self.embed.word_embeddings.weight))
@@ -359,6 +360,7 @@ class GeneralMaskGitEngine(TapeOps):
                 de_in = denc
             if want_enc_grad:
                 G["__encoder_hidden_states__"] = de_in.view(B, L, -1)
+        self._report_grads(G, final=True)
         if self.__dict__.pop("_side_busy", False):
             torch.cuda.current_stream(dev).wait_stream(self._side_stream)   # every weight gradient is complete before autograd sees it
         return G

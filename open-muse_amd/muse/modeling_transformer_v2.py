@@ -540,6 +540,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             sr, sa = T["up"][i]
             dh = self._attn_block_bwd(dh, sa, blk.attention_blocks[i], f"up_blocks.0.attention_blocks.{i}", G, senc, denc, dsenc)
             dh = self._res_block_bwd(dh, sr, blk.res_blocks[i], f"up_blocks.0.res_blocks.{i}", G, scond, dscond, B)
+            self._report_grads(G)        # (data-parallel: finished gradients go to the reducer's buckets while backward continues)
         po = T["proj_out"]
         dn = self._lin_bwd(dh, po["n"], self.project_from_hidden, "project_from_hidden", G)
         dres = self._norm_bwd(dn, po["v"], self.project_from_hidden_norm, "project_from_hidden_norm", G, gemm_operand=True)   # = dt = d(residual)
@@ -571,6 +572,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             dv1 = self._norm_adaln_bwd(dm1, sv["a1s"], sv["res1"], lyr.attn_layer_norm, nm + ".attn_layer_norm",
                                        lyr.self_attn_adaLN_modulation, nm + ".self_attn_adaLN_modulation", G, scond, dscond, B, dpre=dv2)
             dt = dres = dv1                                                           # d(t_prev) = d(res_prev)
+            self._report_grads(G)
         pi = T["proj_in"]
         dn = self._lin_bwd(dt, pi["n"], self.project_to_hidden, "project_to_hidden", G)
         dh = self._norm_bwd(dn, pi["h"], self.project_to_hidden_norm, "project_to_hidden_norm", G)
@@ -579,6 +581,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             sr, sa = T["down"][i]
             dh = self._attn_block_bwd(dh, sa, blk.attention_blocks[i], f"down_blocks.0.attention_blocks.{i}", G, senc, denc, dsenc)
             dh = self._res_block_bwd(dh, sr, blk.res_blocks[i], f"down_blocks.0.res_blocks.{i}", G, scond, dscond, B)
+            self._report_grads(G)
         # ConvEmbed
         demb = self._lin_bwd(dh, T["emb"], self.embed.conv, "embed.conv", G)
         demb0 = self._norm_bwd(demb, T["emb0"], self.embed.layer_norm, "embed.layer_norm", G)
@@ -598,6 +601,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             denc.add_(ops.silu_bwd(T["enc"], dsenc))
         denc0 = self._norm_bwd(denc, T["enc0"], self.encoder_proj_layer_norm, "encoder_proj_layer_norm", G)
         self._lin_bwd(denc0, T["enc_in"], self.encoder_proj, "encoder_proj", G, need_dx=False)
+        self._report_grads(G, final=True)
         if self.__dict__.pop("_side_busy", False):
             torch.cuda.current_stream(dev).wait_stream(self._side_stream)   # every weight gradient is complete before autograd sees it
         return G

@@ -20,6 +20,23 @@ _BF16_OPERANDS = int(os.environ.get("MUSE_UVIT_BF16_OPERANDS", "3"))
 
 
 class TapeOps:
+    # Data-parallel training: `grad_tensors_hook(tensors, final, side_stream)` is called from inside the hand-written backward every
+    # time a block's parameter gradients are COMPLETE (muse.GradReducer hangs itself here) - the all-reduce of a bucket then runs on
+    # the communication stream while backward computes the earlier blocks, like DDP's bucketed overlap which the reference gets from
+    # accelerate (training/train_muse.py:753-759).  `final=True` comes with the last gradients, before autograd sees any of them.
+    grad_tensors_hook = None
+
+    def _report_grads(self, G, final=False):
+        hook = self.grad_tensors_hook
+        if hook is None:
+            return
+        seen = self.__dict__.setdefault("_grads_reported", set())
+        new = [v for k, v in G.items() if k not in seen and not k.startswith("__") and v is not None]
+        seen.update(G.keys())
+        hook(new, final, self._side_stream if self.__dict__.get("_side_busy", False) else None)
+        if final:
+            self.__dict__["_grads_reported"] = set()
+
     @staticmethod
     def _f(p):
         return p.data if p.dtype == torch.float32 else p.data.float()

@@ -553,6 +553,13 @@ class GradReducer:
                 model.mark_weights_changed()
         else:
             self._params = [p for p in model.parameters() if p.requires_grad]
+            # the tape engines (MaskGiTUViT, text-conditioned MaskGitTransformer) report finished gradients from inside their
+            # hand-written backward: buckets are packed and all-reduced on the communication stream while backward computes the
+            # earlier blocks (DDP's overlap, training/train_muse.py:753-759); finish() then has nothing left to do.  Models without
+            # the hook are reduced after backward.
+            self._pending, self._pending_n, self._in_backward_done = [], 0, False
+            if hasattr(model, "grad_tensors_hook"):
+                model.grad_tensors_hook = self._on_tensors
             if broadcast_params:
                 with torch.no_grad():
                     for bucket in self._buckets([p.data for p in self._params]):
@@ -578,7 +585,63 @@ class GradReducer:
             out.append(cur)
         return out
 
+    def _on_tensors(self, tensors, final, side_stream=None):
+        """called from inside backward (TapeOps._report_grads) with gradient tensors that are complete on the model's compute stream
+        (and its weight-gradient stream `side_stream`).  They are collected into buckets of >= bucket_elems elements; a full bucket is
+        packed, all-reduced and unpacked IN PLACE on the communication stream, behind both compute streams.  `final`: flush the
+        rest and make the compute stream wait for every bucket - autograd receives averaged gradients."""
+        for t in tensors:
+            self._pending.append(t)
+            self._pending_n += t.numel()
+        if self._pending and (self._pending_n >= self.bucket_elems or final):
+            self._reduce_list(self._pending, side_stream)
+            self._pending, self._pending_n = [], 0
+        if final:
+            for h in self._handles:
+                h.wait()
+            self._handles = []
+            if self._stream is not None and self._live:
+                torch.cuda.current_stream().wait_stream(self._stream)
+                self._live = False
+            self._in_backward_done = True
+
+    _live = False
+
+    def _reduce_list(self, bucket, side_stream=None):
+        on_gpu = bucket[0].is_cuda
+        self.stats["buckets"] += 1
+        self.stats["bytes"] += sum(t.numel() for t in bucket) * (2 if self.grad_dtype == torch.bfloat16 else 4)
+        if not on_gpu:
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            self._reduce(flat, False)
+            o = 0
+            for g in bucket:
+                g.copy_(flat[o:o + g.numel()].view_as(g))
+                o += g.numel()
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(priority=-1)
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        if side_stream is not None:
+            self._stream.wait_stream(side_stream)
+        with torch.cuda.stream(self._stream):
+            flat = torch.cat([g.reshape(-1) for g in bucket])        # pack on the communication stream: no work on the compute streams
+            h = self._reduce(flat, True)
+            if h is not None:
+                h.wait()                                             # stream-side: the unpack below follows the collective
+            o = 0
+            for g in bucket:
+                g.copy_(flat[o:o + g.numel()].view_as(g))
+                o += g.numel()
+        for g in bucket:
+            g.record_stream(self._stream)
+        self._live = True
+
     def _finish_tensor_list(self):
+        if self._in_backward_done:           # every gradient was reduced from inside backward (_on_tensors)
+            self._in_backward_done = False
+            return
         grads = [p.grad for p in reversed(self._params) if p.grad is not None]
         if not grads:
             return

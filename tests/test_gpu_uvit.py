@@ -330,6 +330,53 @@ def test_uvit_fused_adamw_parameter_groups(golden_dir):
         assert rel_err(p, twins[n]) < 1e-5, n
 
 
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_uvit_gradient_buckets_reduced_inside_backward_on_rccl(golden_dir, cd):
+    """data-parallel U-ViT on the real backend (RCCL group of one rank): muse.GradReducer hangs itself on the model's
+    `grad_tensors_hook`; the hand-written backward reports finished gradients block by block, buckets are packed / all-reduced /
+    unpacked on the communication stream behind the compute and weight-gradient streams while backward continues
+    (training/train_muse.py:753-759 gets this from DDP), finish() has nothing left.  With one rank the average is the local gradient:
+    every parameter gradient must equal the run without a reducer bit for bit, f32 and bf16 compute (weight gradients on the side
+    stream), several buckets per backward."""
+    import torch.distributed as dist
+    import muse
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29650 + os.getpid() % 150)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    g, cfg, sd = _load_golden(golden_dir)
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+
+    def run(with_reducer):
+        model = muse.MaskGiTUViT(**cfg)
+        model.load_state_dict(sd, strict=True)
+        model.to(DEV).train().set_compute_dtype(cd)
+        red = muse.GradReducer(model, bucket_bytes=16 * 1024) if with_reducer else None
+        seen = []
+        if red is not None:
+            inner = red._reduce_list
+            red._reduce_list = lambda bucket, side=None: (seen.append(len(bucket)), inner(bucket, side))
+        _, loss = model(*args, labels=labels)
+        loss.backward()
+        n_inside = len(seen)
+        if red is not None:
+            red.finish()
+            assert len(seen) == n_inside and n_inside >= 3 and red.stats["buckets"] == n_inside
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}, float(loss)
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        g0, l0 = run(False)
+        g1, l1 = run(True)
+        assert l0 == l1
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+    finally:
+        dist.destroy_process_group()
+
+
 def test_uvit_bf16_mode_vs_reference_golden(golden_dir):
     """set_compute_dtype(torch.bfloat16): weight-GEMM operands rounded to bf16 (f32 accumulate / outputs), everything else f32.
     Expected from a CPU emulation of the same rounding: logits 8e-3, loss 1.3e-4, gradients <= 2.5e-2 (relative to max)."""

@@ -201,3 +201,98 @@ def test_optimizer_in_reducer_world4(tmp_path):
         assert all(a[1] <= b[0] for a, b in zip(seen, seen[1:]))    # ... that never overlap
         covered = sum(hi - lo for lo, hi in seen)
         assert covered == n if step != 1 else covered < n
+
+
+class _TapeLike(torch.nn.Module):
+    """a model with the tape engines' reporting protocol (muse/tape_ops.py: grad_tensors_hook) and a backward that, like theirs, is ONE
+    autograd node handing every parameter gradient back at once - but reports finished gradients block by block while it runs"""
+    grad_tensors_hook = None
+
+    def __init__(self):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList([torch.nn.Linear(6, 6, bias=True) for _ in range(5)])
+        self.calls = []
+
+    def forward(self, x):
+        model = self
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, *params):
+                ctx.save_for_backward(x)
+                return (x.sum() * sum(p.sum() for p in params)).reshape(())
+
+            @staticmethod
+            def backward(ctx, g):
+                (x,) = ctx.saved_tensors
+                grads = []
+                params = [p for _, p in model.named_parameters()]
+                # last block first, two tensors (weight, bias) per report
+                out = [None] * len(params)
+                order = list(reversed(range(0, len(params), 2)))
+                for n, i in enumerate(order):
+                    new = []
+                    for j in (i, i + 1):
+                        out[j] = torch.full_like(params[j], float(x.sum()) * float(g)) + torch.arange(params[j].numel(), dtype=torch.float32).view_as(params[j]) * (j + 1)
+                        new.append(out[j])
+                    if model.grad_tensors_hook is not None:
+                        model.calls.append(len(new))
+                        model.grad_tensors_hook(new, n == len(order) - 1, None)
+                return (None,) + tuple(out)
+        return Fn.apply(x, *[p for _, p in self.named_parameters()])
+
+
+def _worker_in_backward(rank, world, port, out):
+    """GradReducer on a tape-engine-like model: buckets are filled from inside backward (grad_tensors_hook), reduced in place, finish()
+    has nothing left to do; == the post-backward tensor-list reduction == the mean over ranks"""
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    import muse
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(400 + rank)
+    m = _TapeLike()
+    red = muse.GradReducer(m, bucket_bytes=4 * 60)        # 60 elements: a bucket = (weight 36 + bias 6) of one block + the next weight
+    assert m.grad_tensors_hook is not None
+    launched = []
+    inner = red._reduce_list
+    red._reduce_list = lambda bucket, side=None: (launched.append(sum(t.numel() for t in bucket)), inner(bucket, side))
+    x = torch.full((3, 6), float(rank + 1))
+    res = {}
+    for step in range(2):
+        m.zero_grad(set_to_none=True)
+        launched.clear()
+        m(x).backward()
+        n_in_backward = len(launched)
+        red.finish()                                       # nothing left: every gradient was reduced inside backward
+        assert len(launched) == n_in_backward
+        res[step] = ([p.grad.clone() for p in m.parameters()], list(launched))
+    # the same model without the hook: the post-backward path must give the same averages
+    m.grad_tensors_hook = None
+    m.zero_grad(set_to_none=True)
+    m(x).backward()
+    red.finish()
+    res["post"] = [p.grad.clone() for p in m.parameters()]
+    torch.save({"res": res, "p": [p.detach().clone() for p in m.parameters()]}, os.path.join(out, f"b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_buckets_from_inside_backward_world2(tmp_path):
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_in_backward, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "b0.pt")
+    r1 = torch.load(tmp_path / "b1.pt")
+    for a, b in zip(r0["p"], r1["p"]):
+        assert torch.equal(a, b)                                          # rank 0's parameters everywhere
+    for step in (0, 1):
+        g0, launched0 = r0["res"][step]
+        g1, launched1 = r1["res"][step]
+        assert launched0 == launched1 and len(launched0) >= 3 and sum(launched0) == sum(p.numel() for p in r0["p"])
+        assert all(n >= 60 for n in launched0[:-1])                       # full buckets, a ragged last one
+        for j, (a, b, p) in enumerate(zip(g0, g1, r0["p"])):
+            # rank r's gradient: 18 (r + 1) + arange * (j + 1); the mean over the two ranks: 27 + arange * (j + 1)
+            expect = torch.full_like(p, 27.0) + torch.arange(p.numel(), dtype=torch.float32).view_as(p) * (j + 1)
+            assert torch.equal(a, b) and torch.allclose(a, expect), (step, j)
+    for a, b in zip(r0["res"][0][0], r0["res"]["post"]):
+        assert torch.allclose(a, b)
