@@ -339,6 +339,15 @@ int muse_groupnorm_scale_shift(const double* partial, int32_t nchunk, const floa
  * the `partial` / nchunk = H a following GroupNorm consumes.  Cout % 4 == 0, Cout / 4 divides 256. */
 int muse_conv_in_direct(const float* x, const float* w4, const float* bias, float* out, double* gn_partial, int32_t gn_groups,
                         int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cpad, int32_t Cout, void* stream);
+/* Decoder.conv_out behind norm_out + swish (muse/modeling_maskgit_vqgan.py:236-240; hidden_channels -> 3 image channels) as ONE
+ * direct exact-f32 convolution: x [B, H, W, C] f32 is normalised with the per-image affine form of the GroupNorm (scale / shift
+ * [B, C] f32 from muse_groupnorm_scale_shift), activated (SiLU) and convolved 3x3 / padding 1 (zero padding after the activation)
+ * with w [Cout][9][C] f32 (+ bias [Cout]) -> out [B, H, W, Cout] f32.  H, W % 16 == 0, C % 32 == 0, Cout <= 4. */
+int muse_conv_out_direct(const float* x, const float* scale, const float* shift, const float* w, const float* bias, float* out,
+                         int32_t batch, int32_t H, int32_t W, int32_t C, int32_t Cout, void* stream);
+/* F.interpolate(scale_factor=2, "nearest") of x [B, H, W, C] f32 written as the (hi, lo) bf16 operand planes [B, 2H, 2W, C] of
+ * muse_conv2d_nhwc_split2 (UpsamplingBlock, :141-149): hi = bf16(x), lo = bf16(x - hi).  C % 8 == 0. */
+int muse_upsample2x_split_nhwc(const float* x, void* y_hi, void* y_lo, int32_t batch, int32_t H, int32_t W, int32_t C, void* stream);
 /* f32 in; output as y_hi = bf16(y), y_lo = bf16(y - y_hi) (two [B, HW, C] bf16 planes) for muse_conv2d_nhwc_split2.
  * stats_nchunk == 0: statistics computed here into `partial`; > 0: `partial` = [B, stats_nchunk, G, 2] already filled. */
 int muse_groupnorm_silu_nhwc_split(const float* x, void* y_hi, void* y_lo, const float* gamma, const float* beta,

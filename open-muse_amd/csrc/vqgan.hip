@@ -479,6 +479,136 @@ extern "C" int muse_conv_in_direct(const float* x, const float* w4, const float*
 }
 
 // =================================================================================================================
+// The LAST convolution of a decoder (conv_out, muse/modeling_maskgit_vqgan.py:236-240: norm_out -> swish -> 3x3, hidden_channels -> 3
+// image channels) as a direct exact-f32 convolution that normalises and activates its own input.  Three output channels are no
+// matrix-core problem: the implicit-GEMM kernels compute 128-wide channel tiles for 3 live columns (4.8 ms on a 64 x 256 x 256 batch,
+// behind a 1.2 ms GroupNorm statistics + apply pass of the 2.1 GB input).  Here a block owns a 16 x 16 pixel patch; per 32-channel
+// chunk the 18 x 18 halo'd patch is staged in LDS ONCE as silu(x * scale[b, c] + shift[b, c]) (the GroupNorm in its per-image affine
+// form, muse_groupnorm_scale_shift from the producer's partial sums; zero padding AFTER the activation, like the reference pads the
+// activated tensor) with a 36-float pixel stride (conflict-free 16-byte reads across the 16 pixels of a row), the weights of the
+// chunk next to it (every lane reads the same address: broadcast), and each thread accumulates its pixel's COUT outputs over the
+// nine taps x 32 channels with plain f32 fmas.  Input read once (+ 27 % halo), output written once.
+// x [B, H, W, C] f32, scale / shift [B, C] f32, w [COUT][9][C] f32, out [B, H, W, COUT] f32.  H, W % 16 == 0, C % 32 == 0.
+// =================================================================================================================
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_out_direct_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int H, int W, int C) {
+  constexpr int PS = 36;                                   // floats per staged pixel (32 channels + 4 pad)
+  __shared__ __attribute__((aligned(16))) float xs[18 * 18 * PS];
+  __shared__ __attribute__((aligned(16))) float ws[COUT * 9 * 32];
+  const int tiles_x = W >> 4, tiles_y = H >> 4;
+  const int t = blockIdx.x, b = t / (tiles_x * tiles_y), ti = t - b * (tiles_x * tiles_y);
+  const int y0 = (ti / tiles_x) << 4, x0 = (ti % tiles_x) << 4;
+  const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    __syncthreads();                                       // the previous chunk's reads are done
+    // stage the 18 x 18 x 32 patch: 324 pixels x 8 float4 = 2592 vectors over 256 threads
+    for (int i = threadIdx.x; i < 18 * 18 * 8; i += 256) {
+      const int pix = i >> 3, q = i & 7;
+      const int yy = y0 + pix / 18 - 1, xx = x0 + pix % 18 - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const f32x4 r = *(const f32x4*)(x + (((long)b * H + yy) * W + xx) * C + c0 + q * 4);
+        const f32x4 sc = *(const f32x4*)(scale + (long)b * C + c0 + q * 4);
+        const f32x4 sh = *(const f32x4*)(shift + (long)b * C + c0 + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gn_silu(fmaf(r[j], sc[j], sh[j]));
+      }
+      *(f32x4*)(xs + pix * PS + q * 4) = v;
+    }
+    for (int i = threadIdx.x; i < COUT * 9 * 8; i += 256) {
+      const int ot = i >> 3, q = i & 7;                    // ot = o * 9 + tap
+      *(f32x4*)(ws + ot * 32 + q * 4) = *(const f32x4*)(w + (long)ot * C + c0 + q * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float* xp = xs + ((py + ky) * 18 + px + kx) * PS;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 v = *(const f32x4*)(xp + q * 4);
+#pragma unroll
+          for (int o = 0; o < COUT; ++o) {
+            const f32x4 wv = *(const f32x4*)(ws + (o * 9 + ky * 3 + kx) * 32 + q * 4);
+            acc[o] = fmaf(v[0], wv[0], acc[o]);
+            acc[o] = fmaf(v[1], wv[1], acc[o]);
+            acc[o] = fmaf(v[2], wv[2], acc[o]);
+            acc[o] = fmaf(v[3], wv[3], acc[o]);
+          }
+        }
+      }
+  }
+  float* op = out + (((long)b * H + y0 + py) * W + x0 + px) * COUT;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) op[o] = acc[o];
+}
+extern "C" int muse_conv_out_direct(const float* x, const float* scale, const float* shift, const float* w, const float* bias, float* out,
+                                    int32_t batch, int32_t H, int32_t W, int32_t C, int32_t Cout, void* stream) {
+  if ((H & 15) || (W & 15) || (C & 31) || C < 32 || Cout < 1 || Cout > 4) return MUSE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)scale) | ((uintptr_t)shift) | ((uintptr_t)w)) & 15) return MUSE_ERR_ALIGN;
+  const long tiles = (long)batch * (H >> 4) * (W >> 4);
+  if (tiles <= 0) return 0;
+  if (tiles >= (1L << 31)) return MUSE_ERR_UNSUPPORTED;
+#define COD(N) hipLaunchKernelGGL(conv_out_direct_kernel<N>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, scale, shift, w, bias, out, H, W, C)
+  if (Cout == 3) COD(3); else if (Cout == 4) COD(4); else if (Cout == 1) COD(1); else COD(2);
+#undef COD
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
+// F.interpolate(scale_factor=2, mode="nearest") of an f32 NHWC tensor written directly as the (hi, lo) bf16 operand planes of the
+// bf16x3 patch-slab convolution that follows it (UpsamplingBlock, muse/modeling_maskgit_vqgan.py:141-149): the up-sampling
+// convolutions of the decoder then run on the LDS-DMA kernel like every other 3 x 3 layer instead of the register-staged
+// muse_conv2d_nhwc_split (5.1 / 4.6 ms against ~3.1 ms for the same flops on the 64 x 256 x 256 / 128 x 128 layers).
+// x [B, H, W, C] f32 -> y_hi, y_lo [B, 2H, 2W, C] bf16.  Eight channels per thread: two 16-byte loads, four 16-byte stores per plane.
+// =================================================================================================================
+__global__ __launch_bounds__(256) void upsample2x_split_kernel(const float* __restrict__ x, bf16_t* __restrict__ y_hi,
+                                                               bf16_t* __restrict__ y_lo, long npix, int H, int W, int C) {
+  const int vpp = C >> 3;
+  const long n = npix * vpp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int vc = (int)(i % vpp);
+    long p = i / vpp;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const long b = p / H;
+    const float* src = x + (((b * H + yy) * W + xx) * (long)C) + vc * 8;
+    const u32x4 v0 = *(const u32x4*)src, v1 = *(const u32x4*)(src + 4);
+    u32x2 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    const u32x4 hv = {h0[0], h0[1], h1[0], h1[1]}, lv = {l0[0], l0[1], l1[0], l1[1]};
+    const long W2 = 2L * W;
+    const long o00 = (((b * 2 * H + 2 * yy) * W2 + 2 * xx) * (long)C) + vc * 8;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const long o = o00 + ((long)dy * W2 + dx) * C;
+        *(u32x4*)(y_hi + o) = hv;
+        *(u32x4*)(y_lo + o) = lv;
+      }
+  }
+}
+extern "C" int muse_upsample2x_split_nhwc(const float* x, void* y_hi, void* y_lo, int32_t batch, int32_t H, int32_t W, int32_t C,
+                                          void* stream) {
+  if (C & 7) return MUSE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 15) return MUSE_ERR_ALIGN;
+  const long npix = (long)batch * H * W;
+  if (npix <= 0) return 0;
+  long g = (npix * (C >> 3) + 255) / 256; if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(upsample2x_split_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y_hi, (bf16_t*)y_lo, npix, H, W, C);
+  return (int)hipGetLastError();
+}
+
+// =================================================================================================================
 // avg_pool2d(2,2) NHWC
 // =================================================================================================================
 template <typename T, int VEC>

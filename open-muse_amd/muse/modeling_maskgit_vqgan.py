@@ -126,6 +126,10 @@ class _ConvEngine:
         self.fuse_gn_apply = os.environ.get("MUSE_GN_FUSE", "1") != "0"   # GroupNorm + SiLU applied inside the consuming patch-slab convolution
         self.direct_conv_in = os.environ.get("MUSE_CONV_IN_DIRECT", "1") != "0"   # bf16x3 mode: conv_in as a direct exact-f32 kernel
         self.dma_conv = True        # "bf16x3" mode: 3x3 convs after GroupNorm run as the LDS-DMA kernel on pre-split planes
+        # bf16x3 mode, decoder: norm_out -> swish -> conv_out (-> 3 image channels) as one direct exact-f32 kernel; the up-sampling
+        # convolutions on the LDS-DMA kernel (nearest x2 written as the convolution's operand planes)
+        self.direct_conv_out = os.environ.get("MUSE_CONV_OUT_DIRECT", "1") != "0"
+        self.upsample_split = os.environ.get("MUSE_UPSAMPLE_SPLIT", "1") != "0"
         self._packed = {}
 
     def _check(self, t):
@@ -202,6 +206,34 @@ class _ConvEngine:
             return ops.conv2d_nhwc_split(x, wp[0], wp[1], B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample,
                                          gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
         return ops.conv2d_nhwc(x, wp, B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)
+
+    def _upsample_conv(self, h, conv: _Conv, B, H, W, cd):
+        """UpsamplingBlock (:141-149): nearest x2 then 3x3 convolution; H, W = the OUTPUT size.  bf16x3 mode: the up-sampled tensor is
+        written once as the (hi, lo) operand planes and the convolution runs on the LDS-DMA kernel; other modes / shapes gather the
+        nearest neighbour inside the convolution."""
+        cout, cin, k, _ = conv.weight.shape
+        if (cd == "bf16x3" and self.dma_conv and self.upsample_split and cin % 8 == 0 and h.dtype == torch.float32
+                and ops.conv_split2_ok(B, H, W, cin, cout, k)):
+            planes = ops.upsample2x_split(h, B, H // 2, W // 2, cin)
+            return self._conv(planes, conv, B, H, W, cd, gn_next=True)
+        return self._conv(h, conv, B, H, W, cd, upsample=True, gn_next=True)
+
+    def _conv_out(self, h, norm: _Norm, conv: _Conv, B, H, W, cd):
+        """norm_out -> swish -> conv_out of a decoder (:236-240).  bf16x3 mode with few output channels (the image): one direct
+        exact-f32 kernel that normalises / activates its own input from the producer's GroupNorm sums."""
+        cout, cin, k, _ = conv.weight.shape
+        stats = getattr(h, "_gn_stats", None)
+        if (cd == "bf16x3" and self.direct_conv_out and stats is not None and h.dtype == torch.float32
+                and ops.conv_out_direct_ok(H, W, cin, cout, k)):
+            key = (id(conv), "direct_out")
+            hit = self._packed.get(key)
+            if hit is None:
+                hit = (conv.weight.data.float().permute(0, 2, 3, 1).reshape(cout, 9, cin).contiguous(),
+                       None if conv.bias is None else conv.bias.data.float().contiguous())
+                self._packed[key] = hit
+            sc, sh = ops.groupnorm_scale_shift(stats, norm.weight.data, norm.bias.data, B, H * W, cin, groups=32, eps=1e-6)
+            return ops.conv_out_direct(h, sc, sh, hit[0], hit[1], B, H, W, cin, cout)
+        return self._conv(self._gn_for(h, norm, conv, B, H, W, cd), conv, B, H, W, cd)
 
     def _gn(self, x, norm: _Norm, B, HW, C, silu=True):
         return ops.groupnorm_silu_nhwc(x, norm.weight.data, norm.bias.data, B, HW, C, groups=32, eps=1e-6, silu=silu)
@@ -304,9 +336,8 @@ class MaskGitVQGAN(_ConvEngine, ModelMixin, ConfigMixin):
                 h = self._res(h, blk, B, H, W, cd)
             if lvl != 0:
                 H, W = H * 2, W * 2
-                h = self._conv(h, up.upsample_conv, B, H, W, cd, upsample=True, gn_next=True)
-        h = self._gn_for(h, dec.norm_out, dec.conv_out, B, H, W, cd)
-        out = self._conv(h, dec.conv_out, B, H, W, cd)
+                h = self._upsample_conv(h, up.upsample_conv, B, H, W, cd)
+        out = self._conv_out(h, dec.norm_out, dec.conv_out, B, H, W, cd)
         return ops.nhwc_to_nchw(out, self.config.num_channels)
 
     def _codebook(self):

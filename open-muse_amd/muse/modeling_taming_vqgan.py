@@ -236,10 +236,10 @@ class VQGANModel(_ConvEngine, ModelMixin, ConfigMixin):
             if hasattr(lvl, "upsample"):
                 H, W = H * 2, W * 2
                 if hasattr(lvl.upsample, "conv"):
-                    h = self._conv(h, lvl.upsample.conv, B, H, W, cd, upsample=1, gn_next=True)
+                    h = self._upsample_conv(h, lvl.upsample.conv, B, H, W, cd)
                 else:   # plain nearest x2 (resample_with_conv = False): a rare configuration, torch's interpolate on the GPU
                     h = F.interpolate(h.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1).contiguous()
-        h = self._conv(self._gn_for(h, dec.norm_out, dec.conv_out, B, H, W, cd), dec.conv_out, B, H, W, cd)
+        h = self._conv_out(h, dec.norm_out, dec.conv_out, B, H, W, cd)
         return ops.nhwc_to_nchw(h, self.config.num_channels)
 
     def _codebook(self):

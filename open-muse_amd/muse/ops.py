@@ -872,6 +872,34 @@ def conv_in_direct(x, w4, B, H, W, Cin, Cpad, Cout, bias=None, gn_groups=0):
     return out
 
 
+def conv_out_direct_ok(H, W, Cin, Cout, KS):
+    """shapes muse_conv_out_direct takes: the features-to-image 3x3 convolution of a decoder"""
+    return KS == 3 and Cout <= 4 and Cin % 32 == 0 and Cin >= 32 and H % 16 == 0 and W % 16 == 0
+
+
+def conv_out_direct(x, scale, shift, w, bias, B, H, W, Cin, Cout):
+    """norm_out -> swish -> conv_out as one direct exact-f32 convolution (muse_conv_out_direct): x [B, H, W, Cin] f32, scale / shift
+    [B, Cin] (groupnorm_scale_shift), w [Cout, 9, Cin] f32 -> [B, H, W, Cout] f32"""
+    require_gpu(x, scale, shift, w)
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
+    check(lib().muse_conv_out_direct(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), w.data_ptr(), ptr(bias), out.data_ptr(),
+                                     B, H, W, Cin, Cout, stream()), "muse_conv_out_direct")
+    _prof_end(e0, "conv_out_direct", _nbytes(x, out), "byte")
+    return out
+
+
+def upsample2x_split(x, B, H, W, C):
+    """nearest x2 of x [B, H, W, C] f32 as the (hi, lo) bf16 operand planes [B, 2H, 2W, C] of conv2d_nhwc_split2"""
+    require_gpu(x)
+    hi = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty_like(hi)
+    e0 = _prof_begin()
+    check(lib().muse_upsample2x_split_nhwc(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), B, H, W, C, stream()), "muse_upsample2x_split_nhwc")
+    _prof_end(e0, "upsample2x_split", _nbytes(x, hi, lo), "byte")
+    return hi, lo
+
+
 def conv_gn_split2_ok(B, H, W, Cin, Cout, KS):
     """shapes muse_conv2d_nhwc_gn_split2 takes (GroupNorm + SiLU + split fused into the patch-slab convolution)"""
     return bool(lib().muse_conv2d_nhwc_gn_split2_ok(B, H, W, Cin, Cout, KS))

@@ -1112,3 +1112,48 @@ def test_conv_in_direct(B, H, W, Cin, Cpad, Cout):
         assert float((p[..., 0] - g.sum((2, 4))).abs().max()) < 1e-9 and float((p[..., 1] - (g * g).sum((2, 4))).abs().max()) < 1e-9
     else:
         assert not hasattr(got, "_gn_stats")
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout", [(2, 32, 48, 64, 3), (1, 16, 16, 128, 3), (3, 16, 32, 32, 4), (1, 48, 16, 96, 1)])
+def test_conv_out_direct(B, H, W, C, Cout):
+    """the direct exact-f32 features-to-image convolution with its GroupNorm + SiLU applied on the way in (muse_conv_out_direct:
+    Decoder.norm_out -> swish -> conv_out, muse/modeling_maskgit_vqgan.py:236-240) against silu(x * scale + shift) -> F.conv2d in
+    float64: f32 fma chains of 9 * C terms; zero padding AFTER the activation (a border pixel must not see silu(shift))"""
+    ops = _ops()
+    x = rnd((B, H, W, C), 500)
+    sc, sh = rnd((B, C), 501, 0.5) + 1.0, rnd((B, C), 502, 0.5)
+    w = rnd((Cout, 3, 3, C), 503, 0.1)
+    bias = rnd((Cout,), 504)
+    assert ops.conv_out_direct_ok(H, W, C, Cout, 3)
+    got = ops.conv_out_direct(x.to(DEV), sc.to(DEV), sh.to(DEV), w.reshape(Cout, 9, C).contiguous().to(DEV), bias.to(DEV), B, H, W, C, Cout)
+    t = x.double() * sc.double()[:, None, None, :] + sh.double()[:, None, None, :]
+    act = t * torch.sigmoid(t)
+    ref = torch.nn.functional.conv2d(act.permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double(), padding=1).permute(0, 2, 3, 1)
+    assert got.shape == (B, H, W, Cout)
+    assert rel_err(got, ref) < 3e-6
+    nb = ops.conv_out_direct(x.to(DEV), sc.to(DEV), sh.to(DEV), w.reshape(Cout, 9, C).contiguous().to(DEV), None, B, H, W, C, Cout)
+    assert rel_err(nb, ref - bias.double()) < 3e-6
+    assert not ops.conv_out_direct_ok(H + 1, W, C, Cout, 3) and not ops.conv_out_direct_ok(H, W, C, 8, 3)
+
+
+def test_upsample2x_split_is_the_split_of_the_interpolated_tensor():
+    """muse_upsample2x_split_nhwc: nearest x2 written as the bf16x3 operand planes == hi = bf16(x), lo = bf16(x - hi) of
+    F.interpolate(x, scale_factor=2, mode="nearest"), bit for bit; and the patch-slab convolution on those planes == the
+    register-staged convolution that gathers the nearest neighbour itself, to f32 round-off"""
+    ops = _ops()
+    B, H, W, C = 2, 16, 24, 64
+    x = rnd((B, H, W, C), 510)
+    hi, lo = ops.upsample2x_split(x.to(DEV), B, H, W, C)
+    up = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1).contiguous()
+    h = up.to(torch.bfloat16)
+    l = (up - h.float()).to(torch.bfloat16)
+    assert hi.shape == (B, 2 * H, 2 * W, C)
+    assert torch.equal(hi.cpu().view(torch.int16), h.view(torch.int16)) and torch.equal(lo.cpu().view(torch.int16), l.view(torch.int16))
+    Cout = 64
+    w = rnd((Cout, 3, 3, C), 511, 0.05)
+    wh, wl = ops.split_bf16(w.to(DEV))
+    bias = rnd((Cout,), 512).to(DEV)
+    a = ops.conv2d_nhwc_split2(hi, lo, wh, wl, B, 2 * H, 2 * W, C, Cout, bias=bias)
+    b = ops.conv2d_nhwc_split(x.to(DEV), wh, wl, B, 2 * H, 2 * W, C, Cout, 3, bias=bias, upsample=True)
+    ref = torch.nn.functional.conv2d(up.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(a, ref) < 3e-5 and rel_err(b, ref) < 3e-5 and rel_err(a, b) < 5e-6

@@ -392,6 +392,27 @@ def test_vqgan_f16_256_vs_reference_golden(golden_dir):
         assert float(np.abs(W.subsample(rec, 16384).cpu().numpy() - g["rec"]).max()) < 2e-4 * float(g["rec_absmax"]), mode
 
 
+def test_vqgan_decoder_special_kernels_match_the_generic_route():
+    """bf16x3 decoder: conv_out as the direct exact-f32 kernel with its GroupNorm applied on the way in (muse_conv_out_direct) and the
+    up-sampling convolutions on the LDS-DMA kernel over pre-split up-sampled planes (muse_upsample2x_split_nhwc) against the generic
+    route (GroupNorm apply pass + implicit-GEMM convolution, nearest neighbour gathered inside the register-staged convolution):
+    same image to f32-class round-off, MaskGitVQGAN f16-256 and the taming VQGANModel"""
+    import muse
+    for klass, cfg, shapes in ((muse.MaskGitVQGAN, W.VQGAN_F16, W.vqgan_shapes),):
+        v = klass(**cfg)
+        v.load_state_dict(W.fill_state_dict(shapes(cfg), 600, "vqgan"))
+        v.to(DEV).eval().set_compute_dtype("bf16x3")
+        idx = torch.from_numpy(np.random.default_rng(5).integers(0, cfg["num_embeddings"], size=(2, 256))).to(DEV)
+        assert v.direct_conv_out and v.upsample_split
+        rec1 = v.decode_code(idx)
+        v.direct_conv_out = v.upsample_split = False
+        rec0 = v.decode_code(idx)
+        assert rec1.shape == (2, 3, 256, 256)
+        e = maxrel(rec1, rec0)
+        print(f"{klass.__name__}: decoder special kernels vs generic route {e:.2e}")
+        assert e < 3e-5
+
+
 def test_vq_indices_over_bench_batch_vs_oracle():
     """north_star: VQ token indices bit-exact.  The f16-256 tokenizer on the 64-image bench batch in the exact-f32 and the bf16x3 (bench
     default) mode against oracle.vqgan_encode.  Stated as MEASURED: the number of disagreeing tokens, and for each of them the full
