@@ -131,7 +131,7 @@ def leg_isolated(spec, fallback):
         return fallback()
 
 
-def uvit_leg_isolated(device, batch, seq, steps, f32=False):
+def uvit_leg_isolated(device, batch, seq, steps, f32=False, x3=False):
     """uvit_leg in a fresh process.  The U-ViT step is ~4500 small launches; at the end of this long-lived process (allocator state,
     Python heap of all the earlier legs) the same leg measured 205 ms per step against 163 ms in a process of its own, which is what a
     training job is - so it gets one (GPU memory of this process has been released by then)."""
@@ -139,14 +139,14 @@ def uvit_leg_isolated(device, batch, seq, steps, f32=False):
     try:
         torch.cuda.empty_cache()
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--uvit-leg", f"{batch},{seq},{steps}" + (",f32" if f32 else "")], capture_output=True, text=True,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--uvit-leg", f"{batch},{seq},{steps}" + (",f32" if f32 else "") + (",x3" if x3 else "")], capture_output=True, text=True,
                            timeout=600, env=env)
         line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
         print(f"bench: config-4 leg {batch},{seq} did not run in a subprocess ({type(e).__name__}); running it in-process", file=sys.stderr)
         try:
-            out = uvit_leg(device, batch, seq, steps, f32)
+            out = uvit_leg(device, batch, seq, steps, f32, x3)
             out["note"] = f"in-process (subprocess failed: {type(e).__name__})"
         except Exception as e2:   # noqa: BLE001
             torch.cuda.empty_cache()
@@ -257,7 +257,7 @@ def latency_leg(device, timesteps=12):
     return out
 
 
-def uvit_leg(device, batch, seq, steps=3, f32=False):
+def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False):
     """BASELINE.json config 4: configs/cc12m_uvit_clip.yaml MaskGiTUViT (UVIT_CC12M: 728.7 M parameters, 22 layers, hidden 1024, GLU 4096,
     1024-channel ResBlock / attention stages; block_num_heads 16 per SURVEY.md D3), synthetic CLIP states (77 x 768), tokens given,
     bf16 compute (fused self / cross attention, bf16 weight copies refreshed inside the AdamW kernel): forward + backward + FusedAdamW"""
@@ -271,7 +271,7 @@ def uvit_leg(device, batch, seq, steps=3, f32=False):
         M.MaskGiTUViT_v2._init_weights = init
     n_params = sum(p.numel() for p in model.parameters())
     assert n_params == 728725504, n_params          # the geometry GF_UVIT_FWD was counted on
-    model.to(device).train().set_compute_dtype(torch.float32 if f32 else torch.bfloat16)
+    model.to(device).train().set_compute_dtype("bf16x3" if x3 else (torch.float32 if f32 else torch.bfloat16))
     g = torch.Generator(device=device).manual_seed(0)
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -302,8 +302,10 @@ def uvit_leg(device, batch, seq, steps=3, f32=False):
     dt = (time.perf_counter() - t0) / steps
     tf = 3 * GF_UVIT_FWD[seq] * batch / dt / 1e3
     out = {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 1), "batch": batch, "seq_len": seq,
-           "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK["f32" if f32 else "bf16"], 4), "loss": round(float(loss), 4), "parameters": n_params,
-           "dtype": ("exact f32 everywhere (f32-input MFMA, 157 TFLOP/s peak): at or above the precision of the yaml's mixed_precision: no + "
+           "tflops": round(tf, 1), "mfma_frac": round(tf / (PEAK["bf16"] / 3 if x3 else PEAK["f32" if f32 else "bf16"]), 4), "loss": round(float(loss), 4), "parameters": n_params,
+           "dtype": ("bf16x3: f32 tensors, every GEMM (linears, dX, dW, attention products) as three bf16 MFMA products of hi / lo operand planes with f32 "
+                     "accumulation (<= 2^-16 relative per product: at or above the yaml's mixed_precision: no + enable_tf32, 10-bit mantissa products); "
+                     "mfma_frac against the 833 TFLOP/s roof of that scheme (2500 / 3)") if x3 else ("exact f32 everywhere (f32-input MFMA, 157 TFLOP/s peak): at or above the precision of the yaml's mixed_precision: no + "
                      "enable_tf32 (10-bit mantissa products); gfx950 has no xf32 MFMA") if f32 else
                     "bf16 weight-GEMM / attention operands, f32 accumulate, residual stream, norms, loss (the yaml itself sets mixed_precision: no)",
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
@@ -414,7 +416,9 @@ def comm_block(info, world, dp_ms, plain_ms, grad_dtype, rccl_log):
         try:
             pat = re.compile(r"(nranks|Channel|channel|Ring|Tree|ring|tree|Connected|Using network|NET/|P2P|xGMI|XGMI|algorithm|protocol|comm 0x)")
             seen = set()
-            for f in sorted(glob.glob(rccl_log.replace("%h", "*").replace("%p", "*"))):
+            files = sorted(glob.glob(rccl_log + "*"))
+            out["rccl_log_files"] = len(files)
+            for f in files:
                 for l in open(f, errors="replace"):
                     l = l.strip()
                     key = re.sub(r"0x[0-9a-f]+|\[\d+\]|\d+:\d+", "", l)
@@ -452,6 +456,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (config A / 4 / 5, tokenizer variants)")
     ap.add_argument("--uvit-leg", default=None, help="internal: run one config-4 leg 'batch,seq,steps' and print its JSON")
+    ap.add_argument("--device", type=int, default=None, help="internal: GPU index of a secondary leg (default: LOCAL_RANK or 0)")
     ap.add_argument("--leg", default=None, help="internal: run one secondary leg ('run,<cfg>,<vq>,<mode>,<steps>,<batch>' | 'vqgan,<batch>' | "
                                                 "'taming,<batch>') and print its JSON")
     args = ap.parse_args()
@@ -459,12 +464,12 @@ def main():
         parts = args.uvit_leg.split(",")
         b, sq, st = (int(x) for x in parts[:3])
         torch.cuda.set_device(0)
-        print(json.dumps(uvit_leg(torch.device("cuda", 0), b, sq, st, f32=len(parts) > 3 and parts[3] == "f32")))
+        print(json.dumps(uvit_leg(torch.device("cuda", 0), b, sq, st, f32=len(parts) > 3 and parts[3] == "f32", x3=len(parts) > 3 and parts[3] == "x3")))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) if args.device is None else args.device
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
@@ -474,7 +479,7 @@ def main():
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "NCCL_DEBUG" not in os.environ:     # RCCL's own account of what it built (rings / trees, channels, transports) for the `comm` block
-            rccl_log = f"/tmp/muse_rccl_{os.getpid()}.%h.%p.log"
+            rccl_log = f"/tmp/muse_rccl_{os.getpid()}_r{rank}.log"
             os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=rccl_log)
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
@@ -624,12 +629,29 @@ def main():
         return
 
     plain_ms = None
-    if distributed:
+    if distributed and os.environ.get("MUSE_BENCH_COMM_PLAIN", "1") != "0":
         # the same step WITHOUT the reducer on the same GPUs first (every rank its own replica, max over ranks): the data-parallel
-        # step minus this is the communication the step could not hide
-        n_plain = max(3, args.steps // 2)
-        el_p, _, _, _ = run(args.config, args.vq_dtype, n_plain, min(args.warmup, 2), use_reducer=False)
-        plain_ms = el_p / n_plain * 1e3
+        # step minus this is the communication the step could not hide.  In a process of its own per rank: a second leg inside this
+        # process measures 10-15 % slower than a fresh one (same effect as leg_isolated's note), and the timed run must be the fresh one.
+        try:
+            import subprocess
+            n_plain = max(4, args.steps // 2)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_DEBUG",
+                                                                    "NCCL_DEBUG_FILE", "NCCL_DEBUG_SUBSYS", "TORCHELASTIC_RUN_ID")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--leg", f"run,{args.config},{args.vq_dtype},plain,{n_plain},{args.batch}",
+                   "--device", str(local)] + (["--no-prefetch"] if args.no_prefetch else [])
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            ips = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])["images_per_s"]
+            t = torch.tensor([args.batch / ips * 1e3], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            plain_ms = float(t)
+        except Exception as e:   # noqa: BLE001   (diagnostics must never take the bench line down)
+            print(f"bench: the no-reducer comparison leg did not run ({type(e).__name__}: {e})", file=sys.stderr)
+            try:
+                t = torch.tensor([0.0], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)      # keep the ranks' collectives paired
+            except Exception:   # noqa: BLE001
+                pass
     el, lossv, prof, tr_ms = run(args.config, args.vq_dtype, args.steps, args.warmup, profile=True)
     ms = el / args.steps * 1e3
     value = args.batch * world * args.steps / el
@@ -702,6 +724,8 @@ def main():
         extra["config4_uvit_seq1024"] = uvit_leg_isolated(device, 48, 1024, 2)
         # ... and at the YAML's own precision class (cc12m_uvit_clip.yaml:102-103 mixed_precision "no" + TF32): exact f32 here
         extra["config4_uvit_seq256_f32"] = uvit_leg_isolated(device, 32, 256, 2, f32=True)
+        # ... and the same precision class on the bf16 matrix pipes: f32 tensors, three bf16 MFMA products per GEMM
+        extra["config4_uvit_seq256_bf16x3"] = uvit_leg_isolated(device, 64, 256, 2, x3=True)
         # the reference's PUBLISHED metric (its only published numbers): text-to-image pipeline latency, 12 steps, 256 x 256
         extra["inference_latency"] = leg_isolated("latency", lambda: latency_leg(device))
 

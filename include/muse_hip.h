@@ -228,6 +228,8 @@ int muse_sum_slices(const float* ws, float* out, int32_t nslices, int64_t n, int
  * nslices[i] rows of the [nslices[i], n[i]] f32 matrix ws[i]).  All arrays are HOST arrays read during the call. */
 int muse_sum_multi(const void* const* ws, void* const* out, const int32_t* nslices, const int64_t* n, const int64_t* stride,
                    const int32_t* accumulate, const int32_t* kind, int32_t njobs, void* stream);
+/* hi = bf16(in), lo = bf16(in - hi): the operand planes of a bf16x3 product (in ~= hi + lo to 2^-16 relative) */
+int muse_split_f32_to_bf16x2(const float* in, void* hi, void* lo, int64_t n, void* stream);
 int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 

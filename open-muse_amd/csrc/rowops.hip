@@ -1562,6 +1562,33 @@ extern "C" int muse_adamw_multi_groups(const int64_t* table, const int32_t* chun
   return (int)hipGetLastError();
 }
 
+// f32 -> the two bf16 planes of the bf16x3 product scheme: hi = bf16(x), lo = bf16(x - hi) (x ~= hi + lo to 2^-16 relative); the
+// operand form of every f32 GEMM of the "bf16x3" compute mode of the tape engines (three bf16 MFMA products hi*hi + hi*lo + lo*hi with
+// f32 accumulation: TF32-class-or-tighter arithmetic at 1/3 of the bf16 matrix rate - gfx950 has no xf32 MFMA and its exact-f32
+// MFMA peaks at 157 TFLOP/s)
+__global__ void split_f2bb_kernel(const float* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 v = *(const u32x4*)(in + i * 4);
+    u32x2 h, l;
+    split4(v, h, l);
+    *(u32x2*)(hi + i * 4) = h;
+    *(u32x2*)(lo + i * 4) = l;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const bf16_t h = f32_to_bf16(in[i]);
+    hi[i] = h;
+    lo[i] = f32_to_bf16(in[i] - bf16_to_f32(h));
+  }
+}
+extern "C" int muse_split_f32_to_bf16x2(const float* in, void* hi, void* lo, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  if ((((uintptr_t)in) & 15) || ((((uintptr_t)hi) | ((uintptr_t)lo)) & 7)) return MUSE_ERR_ALIGN;
+  hipLaunchKernelGGL(split_f2bb_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)hi, (bf16_t*)lo, (long)n);
+  return (int)hipGetLastError();
+}
+
 __global__ void cast_f2b_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

@@ -92,7 +92,8 @@ class _GeneralFn(torch.autograd.Function):
     def forward(ctx, model, input_ids, enc, labels, label_smoothing, cond_dropout_prob, cond_uniforms, need_grad, *params):
         model.__dict__["_act_cache"] = {}
         model.__dict__["_act_cache_on"] = bool(need_grad)
-        logits, loss, tape = model._gen_forward(input_ids, enc, labels, label_smoothing, cond_dropout_prob, cond_uniforms, need_grad)
+        with model._gemm_mode():
+            logits, loss, tape = model._gen_forward(input_ids, enc, labels, label_smoothing, cond_dropout_prob, cond_uniforms, need_grad)
         model.__dict__["_act_cache_on"] = False
         ctx.model, ctx.tape = model, tape
         ctx.enc_grad = bool(need_grad and enc is not None and enc.requires_grad)
@@ -110,7 +111,8 @@ class _GeneralFn(torch.autograd.Function):
         if g_loss is None:
             raise MuseHipError("MaskGitTransformer (text-conditioned / general form): only the loss is differentiable (pass labels)")
         model = ctx.model
-        G = model._gen_backward(ctx.tape, g_loss, ctx.enc_grad)
+        with model._gemm_mode():
+            G = model._gen_backward(ctx.tape, g_loss, ctx.enc_grad)
         ctx.tape = None
         model.__dict__["_act_cache"] = {}
         grads = tuple(G.get(name) for name, _ in model.named_parameters())

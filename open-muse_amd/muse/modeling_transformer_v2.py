@@ -156,7 +156,8 @@ class _UViTFn(torch.autograd.Function):
     def forward(ctx, model, input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad, *params):
         model.__dict__["_act_cache"] = {}
         model.__dict__["_act_cache_on"] = bool(need_grad)
-        logits, loss, tape = model._run_forward(input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad)
+        with model._gemm_mode():
+            logits, loss, tape = model._run_forward(input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad)
         model.__dict__["_act_cache_on"] = False
         ctx.model, ctx.tape = model, tape
         ctx.set_materialize_grads(False)
@@ -172,7 +173,8 @@ class _UViTFn(torch.autograd.Function):
         if g_loss is None:
             raise MuseHipError("MaskGiTUViT_v2: only the loss is differentiable (pass labels)")
         model = ctx.model
-        G = model._run_backward(ctx.tape, g_loss)
+        with model._gemm_mode():
+            G = model._run_backward(ctx.tape, g_loss)
         ctx.tape = None
         model.__dict__["_act_cache"] = {}
         grads = tuple(G.get(name) for name, _ in model.named_parameters())

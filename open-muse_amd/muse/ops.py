@@ -87,6 +87,11 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     require_gpu(A, B, C_)
     if A.dtype != B.dtype:
         raise _hip.MuseHipError("gemm operands must share a dtype")
+    if _F32_AS_BF16X3[0] and A.dtype == torch.float32 and C_.dtype == torch.float32 and act == 0 and split_k == 1:
+        done = _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec, residual, ldr, batch,
+                            zdiv, sA, sB, sC, accumulate)
+        if done:
+            return C_
     if not USE_TR and A.dtype == torch.bfloat16 and (la == 1 or lb == 1):
         return _gemm_via_transpose(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec,
                                    residual, ldr, batch, zdiv, sA, sB, sC, accumulate, act)
@@ -115,6 +120,71 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     check(lib().muse_gemm(C.byref(d), stream()), "muse_gemm")
     _prof_end(e0, f"gemm_{'bf16' if d.dtype == BF16 else 'f32'}_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
     return C_
+
+
+# ---- "bf16x3": every f32 GEMM as three bf16 MFMA products ---------------------------------------------------------------------------
+# The exact-f32 parity mode of the tape engines (MaskGiTUViT, text-conditioned MaskGitTransformer) runs its GEMMs on the f32-input MFMA
+# (157 TFLOP/s peak).  configs/cc12m_uvit_clip.yaml:102-103 trains in f32 tensors with TF32 products (10-bit mantissa); gfx950 has no
+# xf32 MFMA, the CDNA4 counterpart at or above that precision is the three-product scheme the tokenizer already uses: operands split
+# into hi = bf16(x), lo = bf16(x - hi), C = hi*hi + hi*lo + lo*hi with f32 accumulation (the dropped lo*lo term is 2^-16 relative) on
+# the bf16 kernels at 1/3 of their rate.  Scoped by a context manager the models enter for "bf16x3" compute; a product the bf16 kernels
+# cannot take (operand rows that are not whole 16-byte chunks in bf16) silently stays on the exact-f32 kernel.
+_F32_AS_BF16X3 = [False]
+
+
+class f32_gemms_as_bf16x3:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _F32_AS_BF16X3[0]
+        _F32_AS_BF16X3[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _F32_AS_BF16X3[0] = self.prev
+        return False
+
+
+def split_f32(t):
+    """f32 tensor -> (hi, lo) bf16 tensors of the same shape AND strides (a GEMM's offsets / leading dimensions / batch strides
+    stay valid); contiguous storage goes through muse_split_f32_to_bf16x2"""
+    require_gpu(t)
+    if t.is_contiguous():
+        hi = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        lo = torch.empty_like(hi)
+        check(lib().muse_split_f32_to_bf16x2(t.data_ptr(), hi.data_ptr(), lo.data_ptr(), t.numel(), stream()), "muse_split_f32_to_bf16x2")
+        return hi, lo
+    hi = torch.empty_strided(t.shape, t.stride(), dtype=torch.bfloat16, device=t.device)
+    lo = torch.empty_strided(t.shape, t.stride(), dtype=torch.bfloat16, device=t.device)
+    hi.copy_(t)
+    lo.copy_(t - hi.float())
+    return hi, lo
+
+
+def _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec, residual, ldr, batch, zdiv,
+                 sA, sB, sC, accumulate):
+    """-> True when the product ran as three bf16 GEMMs accumulating into the f32 output, False when the bf16 kernels cannot take it"""
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr() + a_off * 2, B.data_ptr() + b_off * 2, C_.data_ptr() + c_off * 4     # (alignment probe: bf16 offsets)
+    d.dtype, d.out_dtype, d.layout_a, d.layout_b = BF16, F32, la, lb
+    d.M, d.N, d.K, d.batch, d.zdiv = M, N, K, batch, zdiv
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.sA0, d.sA1 = sA
+    d.sB0, d.sB1 = sB
+    d.sC0, d.sC1 = sC
+    d.alpha = alpha
+    if (a_off % 8) or (b_off % 8) or lib().muse_gemm_tile(C.byref(d)) < 0:
+        return False
+    with f32_gemms_as_bf16x3(False):
+        ah, al = split_f32(A)
+        bh, bl = split_f32(B)
+        kw = dict(la=la, lb=lb, lda=lda, ldb=ldb, ldc=ldc, a_off=a_off, b_off=b_off, c_off=c_off, alpha=alpha, batch=batch, zdiv=zdiv,
+                  sA=sA, sB=sB, sC=sC)
+        gemm(ah, bh, C_, M, N, K, bias=bias, rowvec=rowvec, residual=residual, ldr=ldr, accumulate=accumulate, **kw)
+        gemm(ah, bl, C_, M, N, K, accumulate=True, **kw)
+        gemm(al, bh, C_, M, N, K, accumulate=True, **kw)
+    return True
 
 
 def _gemm_via_transpose(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec, residual,
@@ -216,6 +286,15 @@ def _wgrad_plan(dy, x, N, K, T_, lda, ldb):
 def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     """dw[N,K] (+)= dy[T,N]^T @ x[T,K]   (both operands k-major, f32 output into the flat grad buffer).
     Split-K slices write partial tiles to a workspace that muse_sum_slices folds into dw in a fixed order."""
+    if _F32_AS_BF16X3[0] and dy.dtype == torch.float32 and x.dtype == torch.float32 and dw.dtype == torch.float32 \
+            and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[1] % 8 == 0 and (M if M is not None else dy.shape[1]) % 8 == 0:
+        with f32_gemms_as_bf16x3(False):      # three bf16 products through the bf16 split-K machinery, accumulated in a fixed order
+            dyh, dyl = split_f32(dy)
+            xh, xl = split_f32(x)
+            linear_wgrad(dyh, xh, dw, accumulate, M=M, lda=lda)
+            linear_wgrad(dyh, xl, dw, True, M=M, lda=lda)
+            linear_wgrad(dyl, xh, dw, True, M=M, lda=lda)
+        return dw
     T_, N = dy.shape
     if M is not None:
         N = M

@@ -46,11 +46,19 @@ class TapeOps:
         (linears, 1x1 convs, their dX / dW) are rounded to bf16 and run on the bf16 MFMA kernels with f32 accumulation and f32
         outputs - the reference's autocast regime; the residual stream, norms, AdaLN, GRN, depthwise conv, softmax / attention
         core and the loss stay f32."""
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
-        self.compute_dtype = dtype
+        if dtype not in (torch.float32, torch.bfloat16, "bf16x3"):
+            raise ValueError('compute dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
+        # "bf16x3": the f32 mode's tensors and kernels, with every f32 GEMM computed as three bf16 MFMA products of hi / lo operand
+        # planes (ops.f32_gemms_as_bf16x3): TF32-class-or-tighter products (2^-16 relative) at 1/3 of the bf16 matrix rate instead of
+        # the 157 TFLOP/s exact-f32 MFMA - the CDNA4 counterpart of the `enable_tf32` regime of configs/cc12m_uvit_clip.yaml:102-103
+        self.__dict__["_f32_split3"] = dtype == "bf16x3"
+        self.compute_dtype = torch.float32 if dtype == "bf16x3" else dtype
         self._wcache, self._wcache_owner = {}, {}
         return self
+
+    def _gemm_mode(self):
+        """context manager for one forward / backward pass: f32 GEMMs as three bf16 products in "bf16x3" mode"""
+        return ops.f32_gemms_as_bf16x3(self.__dict__.get("_f32_split3", False))
 
     def mark_weights_changed(self):
         """call after writing parameters behind autograd's back (`p.data.copy_`, EMA swap): drops the cached bf16 weights"""

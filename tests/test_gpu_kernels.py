@@ -1157,3 +1157,46 @@ def test_upsample2x_split_is_the_split_of_the_interpolated_tensor():
     b = ops.conv2d_nhwc_split(x.to(DEV), wh, wl, B, 2 * H, 2 * W, C, Cout, 3, bias=bias, upsample=True)
     ref = torch.nn.functional.conv2d(up.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
     assert rel_err(a, ref) < 3e-5 and rel_err(b, ref) < 3e-5 and rel_err(a, b) < 5e-6
+
+
+def test_f32_gemm_as_three_bf16_products():
+    """ops.f32_gemms_as_bf16x3: an f32 GEMM as hi*hi + hi*lo + lo*hi of bf16 operand planes with f32 accumulation (the "bf16x3"
+    compute mode of the tape engines).  Error against float64: <= 2^-16 relative per product - between plain bf16 operands (2^-9) and
+    the exact-f32 MFMA; every layout, a batched strided product with offsets, epilogue extras on the first launch only, the
+    weight-gradient path with its K split; a product with rows that are not 16-byte chunks in bf16 stays on the exact kernel."""
+    ops = _ops()
+    T, K, N = 300, 256, 384
+    x, w = rnd((T, K), 600).to(DEV), rnd((N, K), 601).to(DEV)
+    res, bias = rnd((T, N), 602).to(DEV), rnd((N,), 603).to(DEV)
+    ref = x.double() @ w.double().t() + bias.double() + res.double()
+    exact = ops.linear(x, w, residual=res, bias=bias)
+    with ops.f32_gemms_as_bf16x3():
+        y3 = ops.linear(x, w, residual=res, bias=bias)
+        dx3 = ops.linear_dgrad(res, w)                                          # [T, N] @ [N, K]: k-major B
+        dw3 = torch.empty((N, K), device=DEV)
+        ops.linear_wgrad(res, x, dw3, False)
+        dw3b = dw3.clone()
+        ops.linear_wgrad(res, x, dw3b, True)
+    yb = ops.linear(x.to(torch.bfloat16), w.to(torch.bfloat16), out_dtype=torch.float32)
+    scale = float((x.double().abs() @ w.double().abs().t()).max())
+    e3 = float((y3.double() - ref).abs().max()) / scale
+    eb = float((yb.double() - (x.double() @ w.double().t())).abs().max()) / scale
+    ee = float((exact.double() - ref).abs().max()) / scale
+    print(f"bf16x3 GEMM error / sum|a||b|: {e3:.2e} (plain bf16 operands {eb:.2e}, exact-f32 MFMA {ee:.2e}; 2^-16 = 1.5e-5)")
+    assert e3 < 2.0 ** -16 and e3 < eb / 30
+    assert rel_err(dx3, res.double() @ w.double()) < 2e-5
+    assert rel_err(dw3, res.double().t() @ x.double()) < 2e-5 and rel_err(dw3b, 2 * (res.double().t() @ x.double())) < 2e-5
+    # batched, strided, with an operand offset (attention's P V shape)
+    Bn, S, hd = 6, 64, 32
+    P, V = rnd((Bn, S, S), 604).to(DEV), rnd((Bn * S, hd * 2), 605).to(DEV)
+    o = torch.empty((Bn, S, hd), device=DEV)
+    with ops.f32_gemms_as_bf16x3():
+        ops.gemm(P, V, o, S, hd, S, la=0, lb=1, lda=S, ldb=2 * hd, ldc=hd, b_off=hd, batch=Bn, zdiv=1, sA=(S * S, 0), sB=(S * 2 * hd, 0),
+                 sC=(S * hd, 0))
+    refo = torch.bmm(P.double(), V.view(Bn, S, 2 * hd)[:, :, hd:].double())
+    assert rel_err(o, refo) < 2e-5
+    # rows of 12 floats: no 16-byte chunks in bf16 -> the exact kernel answers, bit for bit
+    a, b = rnd((40, 12), 606).to(DEV), rnd((24, 12), 607).to(DEV)
+    with ops.f32_gemms_as_bf16x3():
+        c1 = ops.linear(a, b)
+    assert torch.equal(c1, ops.linear(a, b))

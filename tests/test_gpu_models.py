@@ -302,6 +302,34 @@ def test_transformer_general_vs_reference_golden(golden_dir, name, cfg, cd):
 
 
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_general_transformer_bf16x3_mode_vs_reference_golden(golden_dir):
+    """set_compute_dtype("bf16x3") on the text-conditioned MaskGitTransformer at the width of configs/cc12m.yaml (two layers, hidden 1024,
+    77 text states): f32 tensors, every f32 GEMM (linears, their dX / dW, the materialised attention products) as three bf16 MFMA
+    products - against the REAL reference's f32 outputs at north_star's 1e-3, like the exact-f32 mode"""
+    g = np.load(os.path.join(golden_dir, "transformer_cc12m_2l.npz"))
+    cfg = W.TRANSFORMER_CC12M_2L
+    m = _build_general(cfg, int(g["seed"]), "bf16x3")
+    ids, labels, enc = W.transformer_text_inputs(cfg, int(g["batch"]), int(g["text_len"]), int(g["seed"]) + 1)
+    from muse import ops
+    calls = []
+    inner = ops._gemm_bf16x3
+    ops._gemm_bf16x3 = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    try:
+        logits, loss = m(input_ids=ids.to(DEV), encoder_hidden_states=enc.to(DEV), labels=labels.to(DEV))
+        loss.backward()
+    finally:
+        ops._gemm_bf16x3 = inner
+    assert len(calls) > 20                                         # the mode really routed the GEMMs
+    el = float(np.abs(W.subsample(logits.detach(), 16384).cpu().numpy() - g["logits"]).max()) / float(g["logits_absmax"])
+    lrel = abs(float(loss) - float(g["loss"])) / float(g["loss"])
+    params = dict(m.named_parameters())
+    keys = [f[5:] for f in g.files if f.startswith("grad.")]
+    worst = max(float(np.abs(W.subsample(params[k].grad.detach()).cpu().numpy() - g["grad." + k]).max()) / float(g["absmax." + k]) for k in keys)
+    print(f"bf16x3 mode at the cc12m width vs the reference (f32): logits {el:.2e}, loss {lrel:.1e}, worst gradient {worst:.2e}")
+    assert el < 1e-3 and lrel < 1e-4 and worst < 2e-3
+
+
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
 def test_biased_transformer_trains(cd):
     """a `use_bias=True` model under muse.FusedAdamW: every bias (zero-initialised, like the reference's, :1203-1219) receives a
     gradient, moves, and the loss on a repeated batch falls"""

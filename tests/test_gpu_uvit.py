@@ -415,12 +415,14 @@ def test_uvit_config4_vs_reference_golden(golden_dir):
     ids, enc, cond, micro, labels = (t.to(DEV) for t in W.uvit_inputs(int(g["batch"]), int(g["seq"]), int(g["text_len"]), int(g["seed"]) + 1))
     keys = W.UVIT_FULL_GRAD_KEYS
     ref_gap = max(float(np.abs(g["grad." + k] - gb["grad." + k]).max()) / float(g["absmax." + k]) for k in keys)
-    for cd in (torch.float32, torch.bfloat16):
+    # "bf16x3": f32 tensors, every GEMM as three bf16 MFMA products (TF32-class-or-tighter: the yaml's enable_tf32 regime on CDNA4) -
+    # held to the f32 mode's bounds (north_star's 1e-3)
+    for cd in (torch.float32, "bf16x3", torch.bfloat16):
         model.set_compute_dtype(cd)
         model.zero_grad(set_to_none=True)
         logits, loss = model(ids, enc, cond, micro, labels=labels)
         loss.backward()
-        f32 = cd == torch.float32
+        f32 = cd != torch.bfloat16
         assert tuple(logits.shape) == tuple(g["logits_shape"])
         el = float(np.abs(W.subsample(logits.detach().float(), 16384).cpu().numpy() - g["logits"]).max()) / float(g["logits_absmax"])
         lrel = abs(float(loss) - float(g["loss"])) / float(g["loss"])
