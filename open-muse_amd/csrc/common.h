@@ -24,7 +24,8 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 
 // SiLU behind a GroupNorm: the ONE expression the GroupNorm kernels (vqgan.hip) and the convolution that applies the norm itself
 // (conv_dma.hip) share, so both routes produce the same bits.  Hardware reciprocal (v_rcp_f32, 1 ulp): the correctly rounded division
-// is eleven VALU instructions per element, which the fused convolution could not hide under its MFMAs.
+// is eleven VALU instructions per element, which the fused convolution could not hide under its MFMAs.  Only the bf16x3 operand
+// routes use it; GroupNorm kernels that write an f32 / bf16 tensor (the exact-f32 parity mode) divide with correct rounding.
 __device__ __forceinline__ float gn_silu(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
 
 // bf16x3 operand split of 4 floats: hi = bf16(x), lo = bf16(x - hi)  (conv_split.hip / conv_dma.hip / GroupNorm split output)

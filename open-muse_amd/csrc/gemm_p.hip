@@ -6,38 +6,56 @@
 
 namespace {
 
-// One queue-counter slot (64 bytes) per stream: launches on one stream are ordered, and every launch leaves its slot zeroed.
+// One queue-counter slot (64 bytes) per (device, stream): launches on one stream are ordered, and every launch leaves its slot
+// zeroed.  The table is PER DEVICE (a counter block lives in the memory of the device whose kernels draw tickets from it; a process
+// that drives several GPUs gets one block each).  A stream that is being captured into a HIP graph gets no slot: a replayed graph
+// and an eager launch on a pooled stream that happens to reuse the handle would share one counter - the caller falls back to the
+// launch-per-tile kernel while capturing.
+constexpr int kMaxDev = 16;
 struct Slots {
-  std::mutex mu;
   unsigned* base = nullptr;
   hipStream_t streams[64];
   int n = 0;
   int cus = 0;
   bool failed = false;
+  bool attr_set[4] = {false, false, false, false};
 };
-Slots g_slots;
+std::mutex g_mu;
+Slots g_slots[kMaxDev];
 
-unsigned* counters_for(hipStream_t s, int* cus) {
-  std::lock_guard<std::mutex> lk(g_slots.mu);
-  if (g_slots.failed) return nullptr;
-  if (!g_slots.base) {
+Slots* slots_of_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return nullptr; }
+  Slots& S = g_slots[dev];
+  if (S.failed) return nullptr;
+  if (!S.base) {
     hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipMalloc((void**)&g_slots.base, 64 * 64) != hipSuccess || hipMemset(g_slots.base, 0, 64 * 64) != hipSuccess) {
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || hipMalloc((void**)&S.base, 64 * 64) != hipSuccess ||
+        hipMemset(S.base, 0, 64 * 64) != hipSuccess) {
       (void)hipGetLastError();
-      g_slots.failed = true;
-      g_slots.base = nullptr;
+      S.failed = true;
+      S.base = nullptr;
       return nullptr;
     }
-    g_slots.cus = prop.multiProcessorCount;
+    S.cus = prop.multiProcessorCount;
   }
-  *cus = g_slots.cus;
-  for (int i = 0; i < g_slots.n; ++i)
-    if (g_slots.streams[i] == s) return g_slots.base + i * 16;
-  if (g_slots.n == 64) return nullptr;
-  g_slots.streams[g_slots.n] = s;
-  return g_slots.base + (g_slots.n++) * 16;
+  return &S;
+}
+
+unsigned* counters_for(hipStream_t s, int* cus, Slots** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+  if (cap != hipStreamCaptureStatusNone) return nullptr;
+  Slots* S = slots_of_current_device();
+  if (!S) return nullptr;
+  *cus = S->cus;
+  *out = S;
+  for (int i = 0; i < S->n; ++i)
+    if (S->streams[i] == s) return S->base + i * 16;
+  if (S->n == 64) return nullptr;
+  S->streams[S->n] = s;
+  return S->base + (S->n++) * 16;
 }
 
 // MUSE_G256P_DEBUG=1: say on stderr why a product does not take the persistent kernel
@@ -66,7 +84,8 @@ bool eligible(const GemmParams& p, int la, int lb, int batch) {
 template <typename TC, int AL, int BL>
 int launch(const GemmParams& p, hipStream_t stream) {
   int cus = 0;
-  unsigned* counters = counters_for(stream, &cus);
+  Slots* S = nullptr;
+  unsigned* counters = counters_for(stream, &cus, &S);
   if (!counters || cus < 8) {
     if (getenv("MUSE_G256P_DEBUG")) fprintf(stderr, "[g256p] no queue slot (counters %p, %d CUs)\n", (void*)counters, cus);
     return -1;
@@ -93,10 +112,10 @@ int launch(const GemmParams& p, hipStream_t stream) {
   a.staux = staux;
   a.stagger = stagger;
   auto kern = g256p::kernel<TC, AL, BL>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  constexpr int form = (sizeof(TC) == 4 ? 2 : 0) + BL;      // the dynamic-LDS attribute is per function AND per device
+  if (!S->attr_set[form]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g256p::LDS_BYTES_P);
-    attr_set = true;
+    S->attr_set[form] = true;
   }
   hipLaunchKernelGGL(kern, dim3(8 * nbx), dim3(512), g256p::LDS_BYTES_P, stream, a);
   return (int)hipGetLastError();

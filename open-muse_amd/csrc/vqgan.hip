@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           float t = fmaf(v[u][j], scv[j], shv[j]);
-          if (silu) t = gn_silu(t);
+          // operand planes of the bf16x3 convolution: the hardware-reciprocal SiLU the fused convolution uses (same bits on both routes);
+          // an f32 / bf16 OUTPUT tensor (the exact-f32 parity mode of the tokenizer among them) keeps the correctly rounded division
+          if (silu) t = y_hi ? gn_silu(t) : t / (1.0f + __expf(-t));
           v[u][j] = t;
         }
         if constexpr (VEC == 4) {
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         float t = v[j] * sc[vc * VEC + j] + sh[vc * VEC + j];
-        if (silu) t = gn_silu(t);
+        if (silu) t = t / (1.0f + __expf(-t));
         v[j] = t;
       }
       storev<T, VEC>(y + off, v);
