@@ -478,9 +478,23 @@ def main():
     rccl_log = None
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if "NCCL_DEBUG" not in os.environ:     # RCCL's own account of what it built (rings / trees, channels, transports) for the `comm` block
+        want_log = (world > 1 or os.environ.get("MUSE_BENCH_RCCL_DEBUG") == "1") and "NCCL_DEBUG" not in os.environ
+        if want_log:
+            # RCCL's own account of what it built (rings / trees, channels, transports) for the `comm` block.  NCCL_DEBUG=INFO writes to
+            # the C-level stdout unless NCCL_DEBUG_FILE is honoured; so that no such line can ever land next to the ONE JSON line this
+            # script owes its caller, file descriptor 1 is pointed at the log file for the rest of the process and Python's sys.stdout
+            # is re-opened on the real stdout.
             rccl_log = f"/tmp/muse_rccl_{os.getpid()}_r{rank}.log"
-            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=rccl_log)
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=rccl_log + ".file")
+            try:
+                sys.stdout.flush()
+                real = os.dup(1)
+                sink = os.open(rccl_log, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                os.dup2(sink, 1)
+                os.close(sink)
+                sys.stdout = os.fdopen(real, "w", buffering=1)
+            except OSError:
+                pass
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     import muse

@@ -575,15 +575,16 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
 
         # Grouped form (ops.WGRAD_GROUP >= 1, bf16 mode): the weight gradients of a layer are collected and issued as ONE launch of
         # the 256^2 kernel over all their tiles + ONE reduction launch (slice sums and the layer's column sums) when the layer is
-        # done (`ready`): 144 tiles x 2 slices of 128 K-tiles each at config B instead of 4 launches of 243-288 blocks with 9-64
-        # K-tiles each (a third of a short block is prologue + f32 epilogue) and 8 small reduction launches.
+        # done (`ready`): 144 tiles of 257 K-tiles each at config B (one slice beside the backward chain, five when it runs alone:
+        # ops.WGRAD_GROUP / WGRAD_GROUP_SERIAL) instead of 4 launches of 243-288 blocks with 9-64 K-tiles each (a third of a short
+        # block is prologue + f32 epilogue) and 8 small reduction launches.
         group = [] if (cd == torch.bfloat16 and ops.WGRAD_GROUP >= 1) else None
 
         def flush_group():
             if not group:
                 return
             if side is None:
-                ops.linear_wgrad_group(group, csq)
+                ops.linear_wgrad_group(group, csq, split=ops.WGRAD_GROUP_SERIAL)     # nothing runs beside it: slices that fill the chip
             else:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):

@@ -312,8 +312,14 @@ def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
 
 
 # ---- grouped weight gradients -------------------------------------------------------------------------------------------------------
-# MUSE_WGRAD_GROUP = K slices per product of a grouped dW launch (0: off - one split-K launch + slice sum per weight, the round-3 path).
-WGRAD_GROUP = int(os.environ.get("MUSE_WGRAD_GROUP", "2"))
+# MUSE_WGRAD_GROUP = K slices per product of a grouped dW launch when it runs BESIDE the backward chain on the weight-gradient stream
+# (0: off - one split-K launch + slice sum per weight, the round-3 path).  Default 1: 144 blocks of 257 K-tiles at config B - no
+# workspace, no slice sum, one f32 epilogue per tile; the launch fills 144 of 256 CUs and the concurrent dX / row kernels take the
+# rest.  Same box, default bench loop (profiles/r04_wgrad_group_ab.txt): off 1155 images/s, 1 slice 1190, 2: 1185, 3: 1182, 5: 1172, 7: 1163.
+# MUSE_WGRAD_GROUP_SERIAL = the slice count when nothing runs beside it (weight gradients on the main stream: wgrad_stream off, the
+# instrumented serial step of bench.py): 5 slices = 720 blocks = 2.8 rounds of the chip (1114 TFLOP/s alone; 1 slice: 798).
+WGRAD_GROUP = int(os.environ.get("MUSE_WGRAD_GROUP", "1"))
+WGRAD_GROUP_SERIAL = int(os.environ.get("MUSE_WGRAD_GROUP_SERIAL", "5"))
 
 
 def sum_multi(jobs):
