@@ -68,7 +68,7 @@ int muse_gemm_tile(const muse_gemm_desc* d);
  * logic (tests assert that the train step's products take the persistent form; MUSE_G256P=0 turns it off). */
 int muse_gemm_path(const muse_gemm_desc* d);
 
-/* GROUPED weight gradients: n <= 6 products C_i[M_i, N_i] = A_i^T B_i (layout_a = layout_b = 1: k-major bf16 operands, k = the token
+/* GROUPED weight gradients: n <= 8 products C_i[M_i, N_i] = A_i^T B_i (layout_a = layout_b = 1: k-major bf16 operands, k = the token
  * dimension; f32 output; the four dW = dY^T X of a transformer layer, muse/modeling_transformer.py:770-778,973-977 under autograd)
  * in ONE launch of the 256^2 LDS-DMA kernel over the concatenated tile lists.  `split_k` (the same for every product) cuts K into
  * slices written to C_i + s * split_stride_i (reduce with muse_sum_multi: deterministic); split_k = 1 writes (or, accumulate = 1,

@@ -97,7 +97,7 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
 }
 
 // ---- grouped weight gradients (gemm256.h: kernel_group) ---------------------------------------------------------------------------
-// n <= 6 products C_i[M_i, N_i] = A_i^T B_i with both operands k-major bf16 (dW = dY^T X: k = the token dimension), f32 outputs, in
+// n <= 8 products C_i[M_i, N_i] = A_i^T B_i with both operands k-major bf16 (dW = dY^T X: k = the token dimension), f32 outputs, in
 // ONE launch; split_k slices (the same count for every product) go to C_i + s * split_stride_i and are folded by
 // muse_sum_slices_multi.  Every product must be one the 256^2 LDS-DMA kernel takes (muse_gemm_group_ok).
 static int group_fill(const muse_gemm_desc* d, int n, int split_k, g256::GroupParams& gp) {

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
 // K-tiles each, a third of such a block is prologue + f32 epilogue) and ends in its own ragged round; together they fill the chip with
 // one or two slices of >= 128 K-tiles per tile.  blockIdx.x walks the concatenated tile lists (XCD-swizzled as a whole: neighbouring
 // tiles of a product still share their operand panels in one XCD's L2), blockIdx.y is the K slice, the same for every product.
-constexpr int MAXG = 6;
+constexpr int MAXG = 8;
 struct GroupParams {
   GemmParams p[MAXG];
   int tile_start[MAXG + 1];   // first global tile index of each product (tile_start[n] = total)

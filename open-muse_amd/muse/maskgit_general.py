@@ -111,6 +111,8 @@ class _GeneralFn(torch.autograd.Function):
         if g_loss is None:
             raise MuseHipError("MaskGitTransformer (text-conditioned / general form): only the loss is differentiable (pass labels)")
         model = ctx.model
+        model.__dict__["_dw_pending"] = []          # (a backward that raised may have left collected products behind)
+        model.__dict__["_grads_reported"] = set()
         with model._gemm_mode():
             G = model._gen_backward(ctx.tape, g_loss, ctx.enc_grad)
         ctx.tape = None

@@ -203,6 +203,14 @@ class _ConvEngine:
             return ops.conv2d_nhwc_split2(x[0], x[1], wp[0], wp[1], B, H, W, cp, cout, bias=bias, residual=residual,
                                           gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
         if cd == "bf16x3":
+            if (self.dma_conv and self.upsample_split and not upsample and k == 3 and x.dtype == torch.float32 and x.is_contiguous()
+                    and cp == x.shape[-1] and ops.conv_split2_ok(B, H, W, cp, cout, k) and ops.conv_slab_ok(H, W, cp)):
+                # a 3x3 layer whose input is a plain f32 tensor (Decoder.conv_in on the gathered codebook rows): split once into the
+                # operand planes and run on the LDS-DMA kernel (the register-staged kernel took 1.1 ms for this 39 GFLOP layer at
+                # 64 x 16 x 16: too few workgroups for its tiling)
+                hi, lo = ops.split_f32(x)
+                return ops.conv2d_nhwc_split2(hi, lo, wp[0], wp[1], B, H, W, cp, cout, bias=bias, residual=residual,
+                                              gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
             return ops.conv2d_nhwc_split(x, wp[0], wp[1], B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample,
                                          gn_groups=32 if (gn_next and self.fuse_gn_stats) else 0)
         return ops.conv2d_nhwc(x, wp, B, H, W, cp, cout, k, bias=bias, residual=residual, upsample=upsample)

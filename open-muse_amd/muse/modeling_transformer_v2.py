@@ -173,6 +173,8 @@ class _UViTFn(torch.autograd.Function):
         if g_loss is None:
             raise MuseHipError("MaskGiTUViT_v2: only the loss is differentiable (pass labels)")
         model = ctx.model
+        model.__dict__["_dw_pending"] = []          # (a backward that raised may have left collected products behind)
+        model.__dict__["_grads_reported"] = set()
         with model._gemm_mode():
             G = model._run_backward(ctx.tape, g_loss)
         ctx.tape = None

@@ -341,7 +341,7 @@ def linear_wgrad_group(items, colsums=None, split=None):
     256^2 kernel does not take every product (f32 mode, tiny shapes)."""
     split = WGRAD_GROUP if split is None else split
     descs, meta = [], []
-    ok = split >= 1 and 1 <= len(items) <= 6 and all(it[0].dtype == torch.bfloat16 and it[1].dtype == torch.bfloat16 for it in items)
+    ok = split >= 1 and 1 <= len(items) <= 8 and all(it[0].dtype == torch.bfloat16 and it[1].dtype == torch.bfloat16 for it in items)
     if ok:
         arr = (GemmDesc * len(items))()
         for d, (dy, x, dw, accumulate, M, lda) in zip(arr, items):

@@ -26,7 +26,26 @@ class TapeOps:
     # accelerate (training/train_muse.py:753-759).  `final=True` comes with the last gradients, before autograd sees any of them.
     grad_tensors_hook = None
 
+    def _flush_dw(self):
+        """issue the collected weight-gradient products of the finished block(s): one grouped launch per <= 8 products on the
+        weight-gradient stream, behind everything the main stream has enqueued so far"""
+        pend = self.__dict__.get("_dw_pending")
+        if not pend:
+            return
+        side = self._side_stream
+        main = torch.cuda.current_stream(pend[0][2].device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for i in range(0, len(pend), 8):
+                ops.linear_wgrad_group(pend[i:i + 8], None)
+        for dyc, xc, *_ in pend:
+            dyc.record_stream(side)
+            xc.record_stream(side)
+        self.__dict__["_dw_pending"] = []
+        self.__dict__["_side_busy"] = True
+
     def _report_grads(self, G, final=False):
+        self._flush_dw()
         hook = self.grad_tensors_hook
         if hook is None:
             return
@@ -173,6 +192,14 @@ class TapeOps:
         if self._side_stream is None or self._side_stream.device != x.device:
             self._side_stream = torch.cuda.Stream(device=x.device)
         side = self._side_stream
+        if ops.WGRAD_GROUP >= 1 and dyc.dtype == torch.bfloat16 and xc.dtype == torch.bfloat16:
+            # grouped form: the block's weight gradients are collected and issued as ONE launch over all their tiles when the block is
+            # done (_flush_dw, called from _report_grads) - the returned tensor is filled then; nothing reads a weight gradient earlier
+            with torch.cuda.stream(side):
+                dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
+            dw.record_stream(main)
+            self.__dict__.setdefault("_dw_pending", []).append((dyc, xc, dw, False, M, lda))
+            return dw
         side.wait_stream(main)
         with torch.cuda.stream(side):
             dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
