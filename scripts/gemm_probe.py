@@ -37,6 +37,16 @@ if "nt" in which:
     timeit("linear dgrad [16448x6144]x[6144x768]", lambda: ops.linear_dgrad(dab, w01, out=dx), 2.0 * T * H * 2 * I)
 if "tt" in which:
     timeit("linear wgrad [6144x16448]x[16448x768]", lambda: ops.linear_wgrad(dab, x, dw, True), 2.0 * T * H * 2 * I)
+if "grp" in which:
+    # the four weight gradients of a config-B layer as ONE grouped launch (muse_gemm_group), alone on the chip: 1 and 5 K slices
+    shapes = [(2 * I, H), (H, I), (3 * H, H), (H, H)]
+    items = []
+    for n_out, k_in in shapes:
+        items.append((torch.randn(T, n_out, device=dev).to(torch.bfloat16), torch.randn(T, k_in, device=dev).to(torch.bfloat16),
+                      torch.zeros(n_out, k_in, device=dev), False, None, None))
+    fl = sum(2.0 * T * a * b for a, b in shapes)
+    for sk in (1, 5):
+        timeit(f"grouped layer dW, {sk} slice(s) [144 tiles x 257 K-tiles]", lambda: ops.linear_wgrad_group(items, None, split=sk), fl)
 if "conv" in which:
     B, Hh, Ww, C = 64, 128, 128, 128
     xi = torch.randn(B, Hh, Ww, C, device=dev)

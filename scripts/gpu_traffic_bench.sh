@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic (PMC) of every kernel of the train step: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one pass),
-# kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -> gpurun_out/r03_traffic.json (copy to profiles/)
+# kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -> gpurun_out/r04_traffic.json (copy to profiles/)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; O=gpurun_out; mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c
@@ -8,5 +8,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "$c exit $?"
 done
 f=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-[ -n "$f" ] && [ -n "$w" ] && python scripts/traffic_summary.py "$f" "$w" $O/r03_traffic.json || { tail -5 $O/pmc_FETCH_SIZE.log; tail -5 $O/pmc_WRITE_SIZE.log; }
+[ -n "$f" ] && [ -n "$w" ] && python scripts/traffic_summary.py "$f" "$w" $O/r04_traffic.json || { tail -5 $O/pmc_FETCH_SIZE.log; tail -5 $O/pmc_WRITE_SIZE.log; }
 find $O -name "*.csv" -size +4M -delete
