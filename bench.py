@@ -478,23 +478,24 @@ def main():
     rccl_log = None
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        want_log = (world > 1 or os.environ.get("MUSE_BENCH_RCCL_DEBUG") == "1") and "NCCL_DEBUG" not in os.environ
-        if want_log:
-            # RCCL's own account of what it built (rings / trees, channels, transports) for the `comm` block.  NCCL_DEBUG=INFO writes to
-            # the C-level stdout unless NCCL_DEBUG_FILE is honoured; so that no such line can ever land next to the ONE JSON line this
-            # script owes its caller, file descriptor 1 is pointed at the log file for the rest of the process and Python's sys.stdout
-            # is re-opened on the real stdout.
-            rccl_log = f"/tmp/muse_rccl_{os.getpid()}_r{rank}.log"
-            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=rccl_log + ".file")
-            try:
-                sys.stdout.flush()
-                real = os.dup(1)
-                sink = os.open(rccl_log, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-                os.dup2(sink, 1)
-                os.close(sink)
-                sys.stdout = os.fdopen(real, "w", buffering=1)
-            except OSError:
-                pass
+        # RCCL prints to the C-level stdout (its version banner whenever NCCL_DEBUG is set - the GPU boxes export NCCL_DEBUG=VERSION -, its
+        # INFO lines unless NCCL_DEBUG_FILE is honoured).  So that no such line can ever land next to the ONE JSON line this script owes
+        # its caller, file descriptor 1 is pointed at a log file for the rest of the process and Python's sys.stdout is re-opened on
+        # the real stdout.  With more than one rank (or MUSE_BENCH_RCCL_DEBUG=1) RCCL is also asked for its INIT / GRAPH lines: its own
+        # account of what it built (rings / trees, channels, transports) goes into the `comm` block.
+        rccl_log = f"/tmp/muse_rccl_{os.getpid()}_r{rank}.log"
+        if (world > 1 or os.environ.get("MUSE_BENCH_RCCL_DEBUG") == "1") and os.environ.get("MUSE_BENCH_RCCL_DEBUG") != "0" \
+                and os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN"):
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV")
+        try:
+            sys.stdout.flush()
+            real = os.dup(1)
+            sink = os.open(rccl_log, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            os.dup2(sink, 1)
+            os.close(sink)
+            sys.stdout = os.fdopen(real, "w", buffering=1)
+        except OSError:
+            rccl_log = None
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     import muse

@@ -703,7 +703,7 @@ def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
     """the LDS-DMA bf16x3 convolution on pre-split planes computes the same products as the register-staged bf16x3 kernel on
     the f32 tensor the planes came from: BIT-identical where the K order is the same (tap-major kernel), within f32
     summation-order noise for the patch-slab kernel (K order chunk, tap, channel; ops.conv_slab_ok); and the planes GroupNorm
-    writes are the split of the tensor GroupNorm writes"""
+    writes are the split of the tensor GroupNorm writes up to the SiLU reciprocal's last bit"""
     ops = _ops()
     x = rnd((B, H, W, Cin), 180).to(DEV)
     w = (rnd((Cout, 3, 3, Cin), 181) / math.sqrt(9 * Cin)).to(DEV)
@@ -744,8 +744,16 @@ def test_conv2d_split2_dma_matches_split(B, H, W, Cin, Cout, bias, res):
     gam, bet = (1 + 0.1 * rnd((Cin,), 184)).to(DEV), (0.1 * rnd((Cin,), 185)).to(DEV)
     y = ops.groupnorm_silu_nhwc(x, gam, bet, B, H * W, Cin)
     y_hi, y_lo = ops.groupnorm_silu_nhwc_split(x, gam, bet, B, H * W, Cin)
+    # (the planes carry the hardware-reciprocal SiLU of the fused convolution - bit-identical to that route, see
+    #  test_conv_with_fused_groupnorm_input_is_bit_identical - while a tensor OUTPUT keeps the correctly rounded division of the
+    #  exact-f32 parity mode: the two agree to an f32 ulp before the split, so hi is the same bf16 except at a rounding boundary and
+    #  hi + lo reproduces the tensor to the split's 2^-16)
     e_hi, e_lo = ops.split_bf16(y)
-    assert torch.equal(y_hi.view(torch.int16), e_hi.view(torch.int16)) and torch.equal(y_lo.view(torch.int16), e_lo.view(torch.int16))
+    hi_diff = float((y_hi.view(torch.int16) != e_hi.view(torch.int16)).float().mean())
+    assert hi_diff < 5e-3, hi_diff
+    assert float(((y_hi.float() + y_lo.float()) - y).abs().max()) <= 2.0 ** -15 * float(y.abs().max())
+    ulps = ((y_hi.float() + y_lo.float()) - (e_hi.float() + e_lo.float())).abs() / (y.abs() * 2.0 ** -16 + 1e-30)
+    assert float(ulps.max()) <= 2.0, float(ulps.max())      # the two reconstructions: within two units of the planes' last place
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
