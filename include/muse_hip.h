@@ -347,6 +347,9 @@ int muse_conv_in_direct(const float* x, const float* w4, const float* bias, floa
  * with w [Cout][9][C] f32 (+ bias [Cout]) -> out [B, H, W, Cout] f32.  H, W % 16 == 0, C % 32 == 0, Cout <= 4. */
 int muse_conv_out_direct(const float* x, const float* scale, const float* shift, const float* w, const float* bias, float* out,
                          int32_t batch, int32_t H, int32_t W, int32_t C, int32_t Cout, void* stream);
+/* F.interpolate(scale_factor=2, mode="nearest") of an NHWC tensor (f32, C % 4 == 0; bf16, C % 8 == 0): the taming Upsample without
+ * its convolution (muse/modeling_taming_vqgan.py:36-47, resample_with_conv = False) -> y [B, 2H, 2W, C] */
+int muse_upsample2x_nhwc(const void* x, void* y, int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t C, void* stream);
 /* F.interpolate(scale_factor=2, "nearest") of x [B, H, W, C] f32 written as the (hi, lo) bf16 operand planes [B, 2H, 2W, C] of
  * muse_conv2d_nhwc_split2 (UpsamplingBlock, :141-149): hi = bf16(x), lo = bf16(x - hi).  C % 8 == 0. */
 int muse_upsample2x_split_nhwc(const float* x, void* y_hi, void* y_lo, int32_t batch, int32_t H, int32_t W, int32_t C, void* stream);

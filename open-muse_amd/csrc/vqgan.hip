@@ -599,6 +599,37 @@ __global__ __launch_bounds__(256) void upsample2x_split_kernel(const float* __re
       }
   }
 }
+// plain nearest x2 of an NHWC tensor (taming Upsample with resample_with_conv = False, muse/modeling_taming_vqgan.py:36-47)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, long npix, int H, int W, int C) {
+  const int vpp = C / VEC;
+  const long n = npix * vpp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int vc = (int)(i % vpp);
+    long p = i / vpp;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const long b = p / H;
+    const u32x4 v = *(const u32x4*)(x + (((b * H + yy) * W + xx) * (long)C) + vc * VEC);
+    const long W2 = 2L * W;
+    const long o00 = (((b * 2 * H + 2 * yy) * W2 + 2 * xx) * (long)C) + vc * VEC;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) *(u32x4*)(y + o00 + ((long)dy * W2 + dx) * C) = v;
+  }
+}
+extern "C" int muse_upsample2x_nhwc(const void* x, void* y, int32_t dtype, int32_t batch, int32_t H, int32_t W, int32_t C, void* stream) {
+  const int vec = dtype == MUSE_BF16 ? 8 : 4;
+  if (C % vec) return MUSE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return MUSE_ERR_ALIGN;
+  const long npix = (long)batch * H * W;
+  if (npix <= 0) return 0;
+  long g = (npix * (C / vec) + 255) / 256; if (g > 65536) g = 65536;
+  if (dtype == MUSE_F32) hipLaunchKernelGGL((upsample2x_kernel<float, 4>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, npix, H, W, C);
+  else hipLaunchKernelGGL((upsample2x_kernel<bf16_t, 8>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, npix, H, W, C);
+  return (int)hipGetLastError();
+}
 extern "C" int muse_upsample2x_split_nhwc(const float* x, void* y_hi, void* y_lo, int32_t batch, int32_t H, int32_t W, int32_t C,
                                           void* stream) {
   if (C & 7) return MUSE_ERR_UNSUPPORTED;

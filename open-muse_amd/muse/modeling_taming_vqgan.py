@@ -237,8 +237,11 @@ class VQGANModel(_ConvEngine, ModelMixin, ConfigMixin):
                 H, W = H * 2, W * 2
                 if hasattr(lvl.upsample, "conv"):
                     h = self._upsample_conv(h, lvl.upsample.conv, B, H, W, cd)
-                else:   # plain nearest x2 (resample_with_conv = False): a rare configuration, torch's interpolate on the GPU
-                    h = F.interpolate(h.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1).contiguous()
+                else:   # plain nearest x2 (resample_with_conv = False)
+                    if h.shape[-1] % (8 if h.dtype == torch.bfloat16 else 4) == 0:
+                        h = ops.upsample2x(h.contiguous(), B, H // 2, W // 2, h.shape[-1])
+                    else:   # (channel counts that are not whole 16-byte vectors: no shipped configuration)
+                        h = F.interpolate(h.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1).contiguous()
         h = self._conv_out(h, dec.norm_out, dec.conv_out, B, H, W, cd)
         return ops.nhwc_to_nchw(h, self.config.num_channels)
 

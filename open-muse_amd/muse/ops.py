@@ -974,6 +974,14 @@ def conv_out_direct(x, scale, shift, w, bias, B, H, W, Cin, Cout):
     return out
 
 
+def upsample2x(x, B, H, W, C):
+    """nearest x2 of an NHWC tensor [B, H, W, C] (f32 / bf16) -> [B, 2H, 2W, C] (muse_upsample2x_nhwc)"""
+    require_gpu(x)
+    y = torch.empty((B, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
+    check(lib().muse_upsample2x_nhwc(x.data_ptr(), y.data_ptr(), dt(x), B, H, W, C, stream()), "muse_upsample2x_nhwc")
+    return y
+
+
 def upsample2x_split(x, B, H, W, C):
     """nearest x2 of x [B, H, W, C] f32 as the (hi, lo) bf16 operand planes [B, 2H, 2W, C] of conv2d_nhwc_split2"""
     require_gpu(x)

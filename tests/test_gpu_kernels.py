@@ -1208,3 +1208,14 @@ def test_f32_gemm_as_three_bf16_products():
     with ops.f32_gemms_as_bf16x3():
         c1 = ops.linear(a, b)
     assert torch.equal(c1, ops.linear(a, b))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample2x_matches_interpolate(dtype):
+    """muse_upsample2x_nhwc == F.interpolate(scale_factor=2, mode="nearest") (taming Upsample without its convolution), bit for bit"""
+    ops = _ops()
+    B, H, W, C = 2, 5, 7, 24
+    x = rnd((B, H, W, C), 520).to(dtype)
+    y = ops.upsample2x(x.to(DEV), B, H, W, C)
+    ref = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1).to(dtype)
+    assert y.shape == (B, 2 * H, 2 * W, C) and torch.equal(y.cpu(), ref)
