@@ -414,14 +414,14 @@ def comm_block(info, world, dp_ms, plain_ms, grad_dtype, rccl_log):
     lines = []
     if rccl_log:
         try:
-            pat = re.compile(r"(nranks|Channel|channel|Ring|Tree|ring|tree|Connected|Using network|NET/|P2P|xGMI|XGMI|algorithm|protocol|comm 0x)")
+            pat = re.compile(r"(nranks|nRanks|Channel|channel|Ring|Tree|ring|tree|Connected|Using network|NET/|P2P|xGMI|XGMI|algorithm|protocol|Pattern|comm 0x)")
             seen = set()
             files = sorted(glob.glob(rccl_log + "*"))
             out["rccl_log_files"] = len(files)
             for f in files:
                 for l in open(f, errors="replace"):
                     l = l.strip()
-                    key = re.sub(r"0x[0-9a-f]+|\[\d+\]|\d+:\d+", "", l)
+                    key = re.sub(r"0x[0-9a-f]+|\d+", "#", l)          # one line per KIND of message (Tree 0 .. Tree 63 -> one)
                     if pat.search(l) and key not in seen and len(lines) < 24:
                         seen.add(key)
                         lines.append(l[-200:])

@@ -174,6 +174,12 @@ def _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, 
     d.sB0, d.sB1 = sB
     d.sC0, d.sC1 = sC
     d.alpha = alpha
+    if batch > 1:
+        # the batched products of the materialised attention core (per-head Q K^T, P V and their gradients: K = head_dim or the
+        # sequence length, a few hundred at most) stay on the exact-f32 MFMA: they are ~4 % of a layer's flops, and three launches of
+        # the 128^2 bf16 kernel plus the operand splits cost MORE than one exact product at these sizes (rocprof of the config-4
+        # bf16x3 leg, profiles/r04_config4_bf16x3_kernel_stats_before.csv: 4452 + 4464 launches of ~45 us)
+        return False
     if (a_off % 8) or (b_off % 8) or lib().muse_gemm_tile(C.byref(d)) < 0:
         return False
     with f32_gemms_as_bf16x3(False):
