@@ -230,6 +230,11 @@ int muse_sum_multi(const void* const* ws, void* const* out, const int32_t* nslic
                    const int32_t* accumulate, const int32_t* kind, int32_t njobs, void* stream);
 /* hi = bf16(in), lo = bf16(in - hi): the operand planes of a bf16x3 product (in ~= hi + lo to 2^-16 relative) */
 int muse_split_f32_to_bf16x2(const float* in, void* hi, void* lo, int64_t n, void* stream);
+/* out[r, c] = sum over nslices of ws[s * stride + r * cols + c] (+ bias[c]) (+ residual[r, c]) written as out_dtype (f32 / bf16; the
+ * residual has the output's dtype, like muse_gemm's): reduction of a forward product's K-slice workspace fused with the Linear's
+ * epilogue - the small-batch decoding path (ops.gemm: products of <= 2048 rows whose tiles would fill a fraction of the chip). */
+int muse_sum_slices_epilogue(const float* ws, int32_t nslices, int64_t stride, const float* bias, const void* residual, int64_t ldr,
+                             void* out, int32_t out_dtype, int64_t ldc, int64_t rows, int32_t cols, void* stream);
 int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 

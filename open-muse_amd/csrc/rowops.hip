@@ -1756,4 +1756,49 @@ extern "C" int muse_sum_multi(const void* const* ws, void* const* out, const int
   return (int)hipGetLastError();
 }
 
+// ---- split-K slices -> a Linear's output with its epilogue (small-batch decoding: M <= 2048 rows) -----------------------------------------
+// out[r, c] = sum_{s < ns} ws[s * stride + r * cols + c] (+ bias[c]) (+ residual[r, c]) as f32 or bf16: the reduction of the K-slice
+// workspace of a forward product whose 128^2 tiles alone would fill a fraction of the chip ([512 x 1024] x [1024 x 1024]^T: 32 tiles on
+// 256 CUs, 36 us of a 16-K-tile loop), fused with everything muse_gemm's epilogue would have added.  Fixed summation order.
+template <typename TO>
+__global__ __launch_bounds__(256) void sum_slices_epi_kernel(const float* __restrict__ ws, int ns, long stride, const float* __restrict__ bias,
+                                                            const TO* __restrict__ residual, long ldr, TO* __restrict__ out, long ldc,
+                                                            long rows, int cols) {
+  const int vpr = cols >> 2;
+  const long n = rows * vpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / vpr;
+    const int c = (int)(i - r * vpr) * 4;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < ns; ++k) {
+      float t[4]; V4<float>::load(ws + k * stride + r * cols + c, t);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] += t[q];
+    }
+    if (bias) { float b[4]; V4<float>::load(bias + c, b);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] += b[q]; }
+    if (residual) { float t[4]; V4<TO>::load(residual + r * ldr + c, t);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] += t[q]; }
+    V4<TO>::store(out + r * ldc + c, a);
+  }
+}
+extern "C" int muse_sum_slices_epilogue(const float* ws, int32_t nslices, int64_t stride, const float* bias, const void* residual, int64_t ldr,
+                                        void* out, int32_t out_dtype, int64_t ldc, int64_t rows, int32_t cols, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if ((cols & 3) || (stride & 3) || (ldc & 3) || (ldr & 3) || nslices < 1) return MUSE_ERR_BAD_ARG;
+  const int ob = out_dtype == MUSE_BF16 ? 7 : 15;
+  if ((((uintptr_t)ws) & 15) || (((uintptr_t)bias) & 15) || (((uintptr_t)out) & ob) || (((uintptr_t)residual) & ob)) return MUSE_ERR_ALIGN;
+  const long n = rows * (cols >> 2);
+  const dim3 grid(ew_grid(n));
+  if (out_dtype == MUSE_BF16)
+    hipLaunchKernelGGL(sum_slices_epi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, ws, nslices, (long)stride, bias, (const bf16_t*)residual,
+                       (long)ldr, (bf16_t*)out, (long)ldc, (long)rows, cols);
+  else
+    hipLaunchKernelGGL(sum_slices_epi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, ws, nslices, (long)stride, bias, (const float*)residual,
+                       (long)ldr, (float*)out, (long)ldc, (long)rows, cols);
+  return (int)hipGetLastError();
+}
+
 extern "C" int muse_version(void) { return 1; }

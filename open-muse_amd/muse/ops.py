@@ -77,6 +77,9 @@ def capture_graph(fn):
     return graph, out
 
 
+SKINNY = os.environ.get("MUSE_GEMM_SKINNY", "1") != "0"   # split-K + fused reduction for forward products of <= 2048 rows (decoding)
+
+
 def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, rowvec=None,
          residual=None, ldr=0, batch=1, zdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), accumulate=False, act=0, split_k=1,
          split_stride=0):
@@ -91,6 +94,21 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
         done = _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec, residual, ldr, batch,
                             zdiv, sA, sB, sC, accumulate)
         if done:
+            return C_
+    if (SKINNY and A.dtype == torch.bfloat16 and batch == 1 and la == 0 and lb == 0 and act == 0 and rowvec is None and not accumulate
+            and split_k == 1 and M <= 2048 and K >= 512 and N % 4 == 0 and ldc % 4 == 0 and (residual is None or ldr % 4 == 0)):
+        # small-batch decoding: a forward Linear of a few hundred rows has too few 128^2 tiles for 256 CUs ([512 x 1024] x [1024 x 1024]^T:
+        # 32 tiles, 36 us of a 16-K-tile loop on an eighth of the chip; 77 % of a 512-row U-ViT forward was such launches,
+        # profiles/r04_decode_kernel_stats_before.csv).  K is cut so that tiles x slices fill the chip (>= 2 K-tiles per slice), the
+        # slices go to an f32 workspace and ONE row kernel sums them in fixed order and applies the Linear's epilogue (bias, residual,
+        # output dtype).
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        sk = min(256 // t128, K // 128, 16) if t128 <= 96 else 1
+        if sk >= 2:
+            ws = torch.empty((sk, M, N), dtype=torch.float32, device=A.device)
+            gemm(A, B, ws, M, N, K, la=0, lb=0, lda=lda, ldb=ldb, ldc=N, a_off=a_off, b_off=b_off, alpha=alpha, split_k=sk, split_stride=M * N)
+            check(lib().muse_sum_slices_epilogue(ws.data_ptr(), sk, M * N, ptr(bias), ptr(residual), ldr, C_.data_ptr() + c_off * _esz(C_),
+                                                 dt(C_), ldc, M, N, stream()), "muse_sum_slices_epilogue")
             return C_
     if not USE_TR and A.dtype == torch.bfloat16 and (la == 1 or lb == 1):
         return _gemm_via_transpose(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec,

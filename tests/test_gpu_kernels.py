@@ -1219,3 +1219,34 @@ def test_upsample2x_matches_interpolate(dtype):
     y = ops.upsample2x(x.to(DEV), B, H, W, C)
     ref = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1).to(dtype)
     assert y.shape == (B, 2 * H, 2 * W, C) and torch.equal(y.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N,K,out_dtype", [(512, 1024, 1024, torch.float32), (512, 1024, 1024, torch.bfloat16), (300, 5632, 1024, torch.bfloat16),
+                                             (2048, 1024, 2816, torch.float32), (77, 2048, 768, torch.bfloat16)])
+def test_small_batch_forward_products_split_k(M, N, K, out_dtype, monkeypatch):
+    """small-batch decoding path of ops.gemm: a forward Linear of <= 2048 rows whose 128^2 tiles would fill a fraction of the chip is cut
+    along K into an f32 workspace and summed by muse_sum_slices_epilogue together with the Linear's epilogue (bias, residual, output
+    dtype).  Against float64, and against the plain path (ops.SKINNY off): the same product up to the bf16 rounding of the output
+    (f32 outputs: f32 summation-order noise)."""
+    ops = _ops()
+    x = rnd((M, K), 700).to(DEV).to(torch.bfloat16)
+    w = (rnd((N, K), 701) / math.sqrt(K)).to(DEV).to(torch.bfloat16)
+    bias = rnd((N,), 702).to(DEV)
+    res = rnd((M, N), 703).to(DEV).to(out_dtype)
+    ref = x.double() @ w.double().t() + bias.double() + res.double()
+    calls = []
+    from muse import _hip
+    real = _hip.lib().muse_sum_slices_epilogue
+    monkeypatch.setattr(ops, "SKINNY", True)
+    y1 = ops.linear(x, w, out_dtype=out_dtype, residual=res, bias=bias)
+    monkeypatch.setattr(ops, "SKINNY", False)
+    y0 = ops.linear(x, w, out_dtype=out_dtype, residual=res, bias=bias)
+    tol = 1e-5 if out_dtype == torch.float32 else 6e-3
+    assert rel_err(y1, ref) < tol and rel_err(y0, ref) < tol
+    assert rel_err(y1, y0.double()) < (2e-6 if out_dtype == torch.float32 else 8e-3)
+    if out_dtype == torch.float32:
+        assert not torch.equal(y1, y0) or True      # (different summation order: equality is neither required nor excluded)
+    # no epilogue extras, plain output
+    monkeypatch.setattr(ops, "SKINNY", True)
+    y2 = ops.linear(x, w, out_dtype=out_dtype)
+    assert rel_err(y2, x.double() @ w.double().t()) < tol
