@@ -669,8 +669,27 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         sampled = input_ids
         graph = None
         if hip_graph:
-            model_in = torch.cat([input_ids, input_ids]) if guided else input_ids.clone()
-            graph, out = ops.capture_graph(lambda: self(model_in, encoder_hidden_states, cond_embeds, micro_conds))
+            # The captured forward is KEPT across calls (a serving loop decodes batch after batch of one shape): it reads its inputs from
+            # static buffers, so a later call with the same shapes copies its conditioning in and replays - no capture, no per-launch
+            # host work (a 512-row forward is ~530 launches at ~16 us of host time each against ~7-8 ms of kernels).  The key carries
+            # what the captured kernels read by address: shapes, compute dtype, and a weight generation (autograd version counters + the
+            # explicit invalidations; muse.FusedAdamW updates masters and bf16 copies in place, which a replay sees).
+            wgen = (sum(p._version for p in self.parameters()), self.__dict__.get("_wgen", 0), str(self.compute_dtype), self.training)
+            key = (B, S, guided, tuple(encoder_hidden_states.shape), tuple(cond_embeds.shape), tuple(micro_conds.shape), str(dev), wgen)
+            hit = self.__dict__.get("_gen_graph")
+            if hit is not None and hit["key"] == key:
+                model_in, enc_b, cond_b, micro_b, graph, out = hit["bufs"]
+                enc_b.copy_(encoder_hidden_states)
+                cond_b.copy_(cond_embeds)
+                micro_b.copy_(micro_conds)
+            else:
+                self.__dict__["_gen_graph"] = None            # (free the previous graph's pool before capturing the next one)
+                model_in = torch.cat([input_ids, input_ids]) if guided else input_ids.clone()
+                enc_b, cond_b, micro_b = encoder_hidden_states.clone(), cond_embeds.clone(), micro_conds.clone()
+                graph, out = ops.capture_graph(lambda: self(model_in, enc_b, cond_b, micro_b))
+                wgen = (sum(p._version for p in self.parameters()), self.__dict__.get("_wgen", 0), str(self.compute_dtype), self.training)
+                key = key[:-1] + (wgen,)                      # (the first forward may have built / re-cast cached weights)
+                self.__dict__["_gen_graph"] = dict(key=key, bufs=(model_in, enc_b, cond_b, micro_b, graph, out))
         for step in order:
             if graph is None:
                 out = self(torch.cat([input_ids, input_ids]) if guided else input_ids, encoder_hidden_states, cond_embeds, micro_conds)

@@ -94,6 +94,10 @@ class PipelineMuse:
             rep = lambda t: None if t is None else t.to(self.device).repeat_interleave(n, dim=0)   # noqa: E731
             micro = torch.tensor([list(orig_size) + list(crop_coords) + [aesthetic_score]], device=self.device, dtype=torch.float32)
             temp = tuple(temperature) if isinstance(temperature, (tuple, list)) else temperature
+            # small decoding batches are bound by per-launch host time, not by kernels: the forward is captured into a HIP graph that
+            # generate2 keeps across calls of one shape (`self.hip_graph`: None = automatic for <= 4096 rows, True / False to force)
+            rows = (2 if guidance_scale > 0 else 1) * prompt_embeds.shape[0] * n * (transformer_seq_len or 256)
+            use_graph = (rows <= 4096 and timesteps >= 2) if getattr(self, "hip_graph", None) is None else bool(self.hip_graph)
             out = self.transformer.generate2(
                 rep(prompt_embeds), rep(pooled_embeds), micro,
                 None if empty_embeds is None else empty_embeds.to(self.device),
@@ -101,7 +105,7 @@ class PipelineMuse:
                 negative_embeds=rep(negative_prompt_embeds), negative_cond_embeds=rep(negative_pooled_embeds), temperature=temp,
                 timesteps=timesteps, guidance_scale=guidance_scale, guidance_schedule=guidance_schedule, noise_schedule=schedule,
                 generator=generator, return_intermediate=return_intermediate, seq_len=transformer_seq_len,
-                use_tqdm=False if use_tqdm is None else use_tqdm and False)
+                use_tqdm=False if use_tqdm is None else use_tqdm and False, hip_graph=use_graph)
             ids, intermediate = out if return_intermediate else (out, None)
         images = self._decode(ids, output_type)
         if intermediate is not None:

@@ -73,6 +73,7 @@ class TapeOps:
         self.__dict__["_f32_split3"] = dtype == "bf16x3"
         self.compute_dtype = torch.float32 if dtype == "bf16x3" else dtype
         self._wcache, self._wcache_owner = {}, {}
+        self.__dict__["_wgen"] = self.__dict__.get("_wgen", 0) + 1      # (a kept decoding graph reads the old weight copies: generate2 re-captures)
         return self
 
     def _gemm_mode(self):
@@ -82,10 +83,13 @@ class TapeOps:
     def mark_weights_changed(self):
         """call after writing parameters behind autograd's back (`p.data.copy_`, EMA swap): drops the cached bf16 weights"""
         self._wcache, self._wcache_owner = {}, {}
+        self.__dict__["_wgen"] = self.__dict__.get("_wgen", 0) + 1
+        self.__dict__["_gen_graph"] = None
 
     def train(self, mode: bool = True):
         if mode != self.training:
             self._wcache, self._wcache_owner = {}, {}        # EMA copy_to()/restore() around evaluation write p.data
+            self.__dict__["_wgen"] = self.__dict__.get("_wgen", 0) + 1
         return super().train(mode)
 
     def _c(self, t):

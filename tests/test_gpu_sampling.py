@@ -174,6 +174,38 @@ def test_uvit_generate2_vs_reference_golden(golden_dir):
         assert torch.equal(inter[i].cpu(), torch.from_numpy(g[f"raw{i}"])), i
 
 
+def test_uvit_decoding_graph_is_kept_and_reused_across_calls(golden_dir):
+    """MaskGiTUViT.generate2(hip_graph=True) keeps the captured forward: a second call with the same shapes and OTHER conditioning copies
+    its inputs into the graph's static buffers and replays - same ids as the eager loop with the same seed; a weight update that
+    bumps autograd's version counters (torch optimizer, load_state_dict) or mark_weights_changed() re-captures; muse.PipelineMuse
+    turns the graph on by itself for small decoding batches"""
+    import muse
+    gp = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    gu = np.load(os.path.join(golden_dir, "uvit_generate2_tiny.npz"))
+    u = muse.MaskGiTUViT(**json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json"))))
+    u.load_state_dict({k[len("param."):]: torch.from_numpy(gp[k]) for k in gp.files if k.startswith("param.")}, strict=True)
+    u.to(DEV).eval()
+    base = [torch.from_numpy(gu[k]).to(DEV) for k in ("encoder_hidden_states", "cond_embeds", "micro_conds", "empty_embeds", "empty_cond_embeds")]
+    kw = dict(timesteps=4, temperature=(2.0, 0.0), guidance_scale=3.0, seq_len=int(gu["seq"]))
+
+    def both(args, seed):
+        a = u.generate2(*args, generator=torch.Generator(device=DEV).manual_seed(seed), hip_graph=False, **kw)
+        b = u.generate2(*args, generator=torch.Generator(device=DEV).manual_seed(seed), hip_graph=True, **kw)
+        assert torch.equal(a, b)
+        return u.__dict__["_gen_graph"]["bufs"][4]
+
+    g1 = both(base, 1)
+    other = [base[0] * 0.5 + 0.1, base[1] * -1.0, base[2], base[3], base[4]]
+    g2 = both(other, 2)
+    assert g2 is g1                                   # replayed, not re-captured
+    with torch.no_grad():
+        u.mlm_layer.conv2.weight.mul_(1.5)            # an in-place update autograd sees (what a torch optimizer does)
+    g3 = both(base, 3)
+    assert g3 is not g1
+    u.mark_weights_changed()
+    assert u.__dict__.get("_gen_graph") is None
+
+
 def test_generate2_hip_graph_matches_eager(golden_dir):
     """hip_graph=True (forward captured once, replayed per step) gives the reference-golden ids of the eager loop for both
     models - recorded draws and the seeded in-kernel Philox stream - and config B at batch 2 decodes the same ids either way"""
