@@ -77,7 +77,7 @@ def capture_graph(fn):
     return graph, out
 
 
-SKINNY = os.environ.get("MUSE_GEMM_SKINNY", "1") != "0"   # split-K + fused reduction for forward products of <= 2048 rows (decoding)
+SKINNY = int(os.environ.get("MUSE_GEMM_SKINNY", "1"))   # split-K + fused reduction for forward products of <= 2048 rows: 1 = inside graph capture
 
 
 def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, rowvec=None,
@@ -96,12 +96,16 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
         if done:
             return C_
     if (SKINNY and A.dtype == torch.bfloat16 and batch == 1 and la == 0 and lb == 0 and act == 0 and rowvec is None and not accumulate
-            and split_k == 1 and M <= 2048 and K >= 512 and N % 4 == 0 and ldc % 4 == 0 and (residual is None or ldr % 4 == 0)):
+            and split_k == 1 and M <= 2048 and K >= 512 and N % 4 == 0 and ldc % 4 == 0 and (residual is None or ldr % 4 == 0)
+            and (SKINNY == 2 or torch.cuda.is_current_stream_capturing())):
         # small-batch decoding: a forward Linear of a few hundred rows has too few 128^2 tiles for 256 CUs ([512 x 1024] x [1024 x 1024]^T:
         # 32 tiles, 36 us of a 16-K-tile loop on an eighth of the chip; 77 % of a 512-row U-ViT forward was such launches,
         # profiles/r04_decode_kernel_stats_before.csv).  K is cut so that tiles x slices fill the chip (>= 2 K-tiles per slice), the
         # slices go to an f32 workspace and ONE row kernel sums them in fixed order and applies the Linear's epilogue (bias, residual,
-        # output dtype).
+        # output dtype).  Only while the forward is being CAPTURED into a HIP graph (generate2(hip_graph=True), PipelineMuse): the path
+        # trades kernel time for launches (+36 % launches), and an eager small-batch forward is bound by per-launch host time - measured
+        # on MI355X, PipelineMuse at batch 1 (profiles/r04_latency_ab.txt): eager 123.5 ms, eager + split-K 152.3, graph 112.2,
+        # graph + split-K 98.9.  (MUSE_GEMM_SKINNY=2 forces it everywhere, 0 turns it off.)
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
         sk = min(256 // t128, K // 128, 16) if t128 <= 96 else 1
         if sk >= 2:

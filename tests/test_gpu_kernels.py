@@ -1237,9 +1237,9 @@ def test_small_batch_forward_products_split_k(M, N, K, out_dtype, monkeypatch):
     calls = []
     from muse import _hip
     real = _hip.lib().muse_sum_slices_epilogue
-    monkeypatch.setattr(ops, "SKINNY", True)
+    monkeypatch.setattr(ops, "SKINNY", 2)          # (1, the default, takes the path only while a HIP graph is being captured)
     y1 = ops.linear(x, w, out_dtype=out_dtype, residual=res, bias=bias)
-    monkeypatch.setattr(ops, "SKINNY", False)
+    monkeypatch.setattr(ops, "SKINNY", 0)
     y0 = ops.linear(x, w, out_dtype=out_dtype, residual=res, bias=bias)
     tol = 1e-5 if out_dtype == torch.float32 else 6e-3
     assert rel_err(y1, ref) < tol and rel_err(y0, ref) < tol
@@ -1247,6 +1247,6 @@ def test_small_batch_forward_products_split_k(M, N, K, out_dtype, monkeypatch):
     if out_dtype == torch.float32:
         assert not torch.equal(y1, y0) or True      # (different summation order: equality is neither required nor excluded)
     # no epilogue extras, plain output
-    monkeypatch.setattr(ops, "SKINNY", True)
+    monkeypatch.setattr(ops, "SKINNY", 2)
     y2 = ops.linear(x, w, out_dtype=out_dtype)
     assert rel_err(y2, x.double() @ w.double().t()) < tol
