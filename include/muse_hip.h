@@ -235,6 +235,12 @@ int muse_split_f32_to_bf16x2(const float* in, void* hi, void* lo, int64_t n, voi
  * epilogue - the small-batch decoding path (ops.gemm: products of <= 2048 rows whose tiles would fill a fraction of the chip). */
 int muse_sum_slices_epilogue(const float* ws, int32_t nslices, int64_t stride, const float* bias, const void* residual, int64_t ldr,
                              void* out, int32_t out_dtype, int64_t ldc, int64_t rows, int32_t cols, void* stream);
+/* The same split written as ONE GEMM operand of three times the K length: the bf16x3 product hi*hi + hi*lo + lo*hi is a single product
+ * of A' = (hi | hi | lo) and B' = (hi | lo | hi) along K.  in [rows, cols] f32 (row stride ld_in); mode 0: planes concatenated along the
+ * columns, out [rows, 3 cols] (k-contiguous operand), mode 1: stacked along the rows, out [3 rows, cols] (k-major operand), both with row
+ * stride ld_out; lo_pos = 1 | 2: the third that carries the lo plane.  cols % 4 == 0. */
+int muse_split_f32_to_bf16_cat3(const float* in, void* out, int64_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t mode,
+                                int32_t lo_pos, void* stream);
 int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 

@@ -1589,6 +1589,38 @@ extern "C" int muse_split_f32_to_bf16x2(const float* in, void* hi, void* lo, int
   return (int)hipGetLastError();
 }
 
+// The bf16x3 product as ONE GEMM: C = A_hi B_hi + A_hi B_lo + A_lo B_hi is a single product over a three times longer K with the
+// operands laid out as A' = (hi | hi | lo), B' = (hi | lo | hi) along K - one launch, one epilogue, no read-modify-write of C between
+// the three terms.  This kernel writes such an operand from the f32 tensor [rows, cols] (row stride ld_in): mode 0 concatenates the
+// three planes along the columns (k-contiguous operand: out [rows, 3 cols]), mode 1 stacks them along the rows (k-major operand:
+// out [3 rows, cols], row stride ld_out); lo_pos (1 or 2) says which third carries the lo plane.
+__global__ void split_cat3_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long rows, int cols, long ld_in, long ld_out,
+                                  int mode, int lo_pos) {
+  const int vpr = cols >> 2;
+  const long n = rows * vpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / vpr;
+    const int c = (int)(i - r * vpr) * 4;
+    const u32x4 v = *(const u32x4*)(in + r * ld_in + c);
+    u32x2 h, l;
+    split4(v, h, l);
+#pragma unroll
+    for (int sgm = 0; sgm < 3; ++sgm) {
+      bf16_t* o = mode == 0 ? out + r * ld_out + (long)sgm * cols + c : out + ((long)sgm * rows + r) * ld_out + c;
+      *(u32x2*)o = (sgm == lo_pos) ? l : h;
+    }
+  }
+}
+extern "C" int muse_split_f32_to_bf16_cat3(const float* in, void* out, int64_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t mode,
+                                           int32_t lo_pos, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if ((cols & 3) || (ld_in & 3) || (ld_out & 3) || (mode != 0 && mode != 1) || (lo_pos != 1 && lo_pos != 2)) return MUSE_ERR_BAD_ARG;
+  if ((((uintptr_t)in) & 15) || (((uintptr_t)out) & 7)) return MUSE_ERR_ALIGN;
+  hipLaunchKernelGGL(split_cat3_kernel, dim3(ew_grid(rows * (cols >> 2))), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)rows, cols,
+                     (long)ld_in, (long)ld_out, mode, lo_pos);
+  return (int)hipGetLastError();
+}
+
 __global__ void cast_f2b_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {

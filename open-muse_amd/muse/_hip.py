@@ -100,6 +100,7 @@ SIGNATURES = {
     "muse_split_f32_to_bf16x2": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "muse_upsample2x_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "muse_sum_slices_epilogue": [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_i64, c_i64, c_int, c_void_p],
+    "muse_split_f32_to_bf16_cat3": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, c_int, c_void_p],
     "muse_sum_slices": [c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_void_p],
     "muse_cast_f32_to_bf16": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_cast_bf16_to_f32": [c_void_p, c_void_p, c_i64, c_void_p],

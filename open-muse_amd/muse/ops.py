@@ -184,6 +184,25 @@ def split_f32(t):
     return hi, lo
 
 
+X3_CAT = os.environ.get("MUSE_X3_CAT", "1") != "0"    # bf16x3 GEMM mode: one launch over a 3K-long concatenated operand pair (0: three launches)
+
+
+def split_cat3(t, layout, K, lo_pos):
+    """the bf16x3 operand of a 2-D contiguous f32 tensor for a product over its K dimension: layout 0 (k-contiguous [R, K]) ->
+    ([R, 3K], ld 3K), layout 1 (k-major [K, R]) -> ([3K, R], ld R); thirds (hi | hi | lo) for lo_pos 2, (hi | lo | hi) for lo_pos 1"""
+    require_gpu(t)
+    rows, cols = t.shape
+    if layout == 0:
+        out = torch.empty((rows, 3 * cols), dtype=torch.bfloat16, device=t.device)
+        ld_out = 3 * cols
+    else:
+        out = torch.empty((3 * rows, cols), dtype=torch.bfloat16, device=t.device)
+        ld_out = cols
+    check(lib().muse_split_f32_to_bf16_cat3(t.data_ptr(), out.data_ptr(), rows, cols, t.stride(0), ld_out, layout, lo_pos, stream()),
+          "muse_split_f32_to_bf16_cat3")
+    return out, ld_out
+
+
 def _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec, residual, ldr, batch, zdiv,
                  sA, sB, sC, accumulate):
     """-> True when the product ran as three bf16 GEMMs accumulating into the f32 output, False when the bf16 kernels cannot take it"""
@@ -204,6 +223,18 @@ def _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, 
         return False
     if (a_off % 8) or (b_off % 8) or lib().muse_gemm_tile(C.byref(d)) < 0:
         return False
+    if (X3_CAT and a_off == 0 and b_off == 0 and A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous() and K % 8 == 0
+            and A.stride(0) == lda and B.stride(0) == ldb and A.shape[1 if la == 0 else 0] == K and B.shape[1 if lb == 0 else 0] == K
+            and A.shape[0 if la == 0 else 1] >= M and B.shape[0 if lb == 0 else 1] >= N and 3 * A.numel() * 2 < (1 << 31)
+            and 3 * B.numel() * 2 < (1 << 31)):
+        # ONE launch: A' = (hi | hi | lo), B' = (hi | lo | hi) along a three times longer K (muse_split_f32_to_bf16_cat3) - one epilogue,
+        # no read-modify-write of C between the terms, the persistent kernel where the plain product would take it
+        with f32_gemms_as_bf16x3(False):
+            a3, lda3 = split_cat3(A, la, K, 2)
+            b3, ldb3 = split_cat3(B, lb, K, 1)
+            gemm(a3, b3, C_, M, N, 3 * K, la=la, lb=lb, lda=lda3, ldb=ldb3, ldc=ldc, c_off=c_off, alpha=alpha, bias=bias, rowvec=rowvec,
+                 residual=residual, ldr=ldr, accumulate=accumulate)
+        return True
     with f32_gemms_as_bf16x3(False):
         ah, al = split_f32(A)
         bh, bl = split_f32(B)
@@ -316,12 +347,19 @@ def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     Split-K slices write partial tiles to a workspace that muse_sum_slices folds into dw in a fixed order."""
     if _F32_AS_BF16X3[0] and dy.dtype == torch.float32 and x.dtype == torch.float32 and dw.dtype == torch.float32 \
             and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[1] % 8 == 0 and (M if M is not None else dy.shape[1]) % 8 == 0:
-        with f32_gemms_as_bf16x3(False):      # three bf16 products through the bf16 split-K machinery, accumulated in a fixed order
-            dyh, dyl = split_f32(dy)
-            xh, xl = split_f32(x)
-            linear_wgrad(dyh, xh, dw, accumulate, M=M, lda=lda)
-            linear_wgrad(dyh, xl, dw, True, M=M, lda=lda)
-            linear_wgrad(dyl, xh, dw, True, M=M, lda=lda)
+        with f32_gemms_as_bf16x3(False):
+            if (X3_CAT and dy.dim() == 2 and x.dim() == 2 and dy.is_contiguous() and x.is_contiguous() and (lda is None or lda == dy.stride(0))
+                    and dy.shape[0] == x.shape[0] and 3 * dy.numel() * 2 < (1 << 32) - 64 and 3 * x.numel() * 2 < (1 << 32) - 64):
+                # one product over 3 T tokens: dY' = (hi ; hi ; lo), X' = (hi ; lo ; hi) stacked along the token dimension
+                dy3, _ = split_cat3(dy, 1, dy.shape[0], 2)
+                x3, _ = split_cat3(x, 1, x.shape[0], 1)
+                linear_wgrad(dy3, x3, dw, accumulate, M=M, lda=lda)
+            else:                             # three bf16 products through the bf16 split-K machinery, accumulated in a fixed order
+                dyh, dyl = split_f32(dy)
+                xh, xl = split_f32(x)
+                linear_wgrad(dyh, xh, dw, accumulate, M=M, lda=lda)
+                linear_wgrad(dyh, xl, dw, True, M=M, lda=lda)
+                linear_wgrad(dyl, xh, dw, True, M=M, lda=lda)
         return dw
     T_, N = dy.shape
     if M is not None:

@@ -1185,6 +1185,14 @@ def test_f32_gemm_as_three_bf16_products():
         ops.linear_wgrad(res, x, dw3, False)
         dw3b = dw3.clone()
         ops.linear_wgrad(res, x, dw3b, True)
+    # the same products as three launches (MUSE_X3_CAT=0) instead of one over the concatenated 3K-long operands: same terms, another order
+    import unittest.mock as um
+    with um.patch.object(ops, "X3_CAT", False), ops.f32_gemms_as_bf16x3():
+        y3b = ops.linear(x, w, residual=res, bias=bias)
+        dx3b = ops.linear_dgrad(res, w)
+        dw3c = torch.empty((N, K), device=DEV)
+        ops.linear_wgrad(res, x, dw3c, False)
+    assert rel_err(y3, y3b.double()) < 2e-6 and rel_err(dx3, dx3b.double()) < 2e-6 and rel_err(dw3, dw3c.double()) < 2e-6
     yb = ops.linear(x.to(torch.bfloat16), w.to(torch.bfloat16), out_dtype=torch.float32)
     scale = float((x.double().abs() @ w.double().abs().t()).max())
     e3 = float((y3.double() - ref).abs().max()) / scale
