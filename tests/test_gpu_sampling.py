@@ -208,7 +208,7 @@ def test_uvit_decoding_graph_is_kept_and_reused_across_calls(golden_dir):
 
 def test_generate2_hip_graph_matches_eager(golden_dir):
     """hip_graph=True (forward captured once, replayed per step) gives the reference-golden ids of the eager loop for both
-    models - recorded draws and the seeded in-kernel Philox stream - and config B at batch 2 decodes the same ids either way"""
+    models (f32 compute: recorded draws); config B at batch 2 in bf16: both loops reproducible from a seed"""
     import time
     import muse
     g = np.load(os.path.join(golden_dir, "generate2_tiny.npz"))
@@ -231,21 +231,26 @@ def test_generate2_hip_graph_matches_eager(golden_dir):
     ids_u = u.generate2(*args, timesteps=Tu, temperature=tuple(float(x) for x in gu["temperature"]),
                         guidance_scale=float(gu["guidance_scale"]), seq_len=int(gu["seq"]), noise=_noise(gu, Tu), hip_graph=True)
     assert torch.equal(ids_u.cpu(), torch.from_numpy(gu["ids"]))
-    # the benched transformer (config B), bf16, batch 2, 18 steps: same ids from the same seed, wall time of both loops
+    # the benched transformer (config B), bf16, batch 2, 18 steps: each loop reproduces its own ids from the same seed; wall time of both.
+    # (Since round 4 the CAPTURED forward cuts its small-batch Linears along K - ops.gemm's decoding path, taken only inside graph capture
+    #  because it trades kernel time for launches - so in bf16 the graph loop and the eager loop sum those products in different (fixed)
+    #  orders and their samples are two valid draws, not the same one; in f32 compute the two loops stay bit-identical: the goldens above.)
     big = muse.MaskGitTransformer(**W.TRANSFORMER_B)
     big.to(DEV).eval().set_compute_dtype(torch.bfloat16)
     res = {}
     for mode in (False, True):
-        for rep in range(2):   # second repetition timed (the first pays one-time packing and builds the graph, kept by the model)
+        outs = []
+        for rep in range(3):   # last repetition timed (the first pays one-time packing and builds the graph, kept by the model)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = big.generate2(class_ids=torch.tensor([3, 700], device=DEV), timesteps=18, temperature=2.0,
                                 generator=torch.Generator(device=DEV).manual_seed(11), hip_graph=mode)
             torch.cuda.synchronize()
+            outs.append(out)
             res[mode] = (out, time.perf_counter() - t0)
-    assert torch.equal(res[False][0], res[True][0])
+        assert torch.equal(outs[1], outs[2]) and torch.equal(outs[0], outs[1])
+        assert int(out.min()) >= 0 and int(out.max()) < W.TRANSFORMER_B["codebook_size"]
     print(f"generate2 config B bs 2, 18 steps: eager {res[False][1] * 1e3:.1f} ms, hip_graph {res[True][1] * 1e3:.1f} ms")
-    # (measured equal, 78.6 vs 78.3 ms: at this size the step is bound by the ~300 short kernels' own latency, not by launching them)
 
 
 class _Cfg(dict):
