@@ -45,10 +45,19 @@ class _Lin(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin))
 
 
+_NORM_AFFINE = [True]     # set by MaskGiTUViT_v2.__init__ while it builds its submodules (config.ln_elementwise_affine)
+
+
 class _NormW(nn.Module):
+    """Norm (reference :632-726).  ln_elementwise_affine=False: no learnable gain (`self.weight = None` in the reference, :656-660) - here a
+    non-persistent buffer of ones, so that the state dict and named_parameters() match the reference's while the kernels keep one form"""
+
     def __init__(self, c):
         super().__init__()
-        self.weight = nn.Parameter(torch.ones(c))
+        if _NORM_AFFINE[0]:
+            self.weight = nn.Parameter(torch.ones(c))
+        else:
+            self.register_buffer("weight", torch.ones(c), persistent=False)
 
 
 class _Norm2D(nn.Module):
@@ -201,9 +210,10 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         c = self.config
         if len(c.block_out_channels) != 1:
             raise ValueError("block_out_channels must have exactly one entry (reference :166)")
-        if c.use_bias or c.force_down_up_sample or c.use_fused_mlp or not c.ln_elementwise_affine or c.norm_type != "rmsnorm":
+        if c.use_bias or c.force_down_up_sample or c.use_fused_mlp or c.norm_type != "rmsnorm":
             raise NotImplementedError("MI355X build of MaskGiTUViT_v2: only the shipped configuration family is built "
-                                      "(rmsnorm, bias-free, GLU feed-forward, no forced down/up-sampling)")
+                                      "(rmsnorm with or without learnable gains, bias-free, GLU feed-forward, no forced down/up-sampling)")
+        _NORM_AFFINE[0] = bool(c.ln_elementwise_affine)
         if c.hidden_dropout != 0.0 or c.attention_dropout != 0.0:
             raise NotImplementedError("dropout > 0 is outside the MI355X hot-path build")
         H, C, cin = c.hidden_size, c.block_out_channels[0], c.in_channels
@@ -225,6 +235,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         self.fuse_norm_adaln = os.environ.get("MUSE_NORM_ADALN", "1") != "0"  # norm + AdaLN of a transformer layer as one kernel (fwd and bwd)
         self.batch_adaln_mappers = os.environ.get("MUSE_ADALN_BATCH", "1") != "0"   # every AdaLN mapper in a few batched products
         self._side_stream = None
+        _NORM_AFFINE[0] = True
         self._init_weights()
 
     def _init_weights(self):
@@ -358,7 +369,8 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             self.__dict__.setdefault("_act_cache", {})[id(dv)] = (dv, dvb)
         else:
             dv, dw, dss = ops.norm_adaln_bwd(dm, v, self._f(norm_mod.weight), sv["ss"], B, eps, mode, dpre=dpre, dss_out=sv.get("slot"))
-        G[norm_name + ".weight"] = dw
+        if isinstance(norm_mod.weight, nn.Parameter):        # (ln_elementwise_affine=False: the gain is a constant, not a parameter)
+            G[norm_name + ".weight"] = dw
         self._ada_dss(dss, sv, ada, ada_name, G, scond, dscond)
         return dv
 

@@ -243,7 +243,8 @@ class TapeOps:
             self.__dict__.setdefault("_act_cache", {})[id(dv)] = (dv, dvb)
         else:
             dv, dw = ops.norm_res_bwd(dy, v, self._f(mod.weight), float(self.config.layer_norm_eps), mode, dpre=dpre)
-        G[name + ".weight"] = dw
+        if isinstance(mod.weight, torch.nn.Parameter):       # (a norm without a learnable gain keeps a constant buffer of ones)
+            G[name + ".weight"] = dw
         return dv
 
     def _attention(self, x, ctx, att, B, Sq, Skv, nh, residual=None, drop=None):

@@ -377,6 +377,31 @@ def test_uvit_gradient_buckets_reduced_inside_backward_on_rccl(golden_dir, cd):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_uvit_without_norm_gains_vs_reference_golden(golden_dir, cd):
+    """ln_elementwise_affine=False (reference :656-660, :705-711: norms without learnable gains): same state-dict keys and parameter
+    list as the real reference (no norm weights), logits / loss / every gradient against its outputs (tests/golden/uvit_tiny_noaffine.npz)"""
+    import muse
+    g = np.load(os.path.join(golden_dir, "uvit_tiny_noaffine.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny_noaffine.json")))
+    sd = {k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}
+    model = muse.MaskGiTUViT(**cfg)
+    assert set(model.state_dict().keys()) == set(sd.keys()) and not any(k.endswith("norm.weight") for k in sd)
+    assert [n for n, _ in model.named_parameters()] == [k for k in sd if k in dict(model.named_parameters())]
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train().set_compute_dtype(cd)
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    logits, loss = model(*args, labels=labels)
+    loss.backward()
+    f32 = cd == torch.float32
+    assert rel_err(logits, torch.from_numpy(g["logits"])) < (1e-3 if f32 else 3e-2)
+    assert abs(float(loss) - float(g["loss"])) < (1e-4 if f32 else 2e-3) * abs(float(g["loss"]))
+    _grad_check(model, {k[len("grad."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad.")}, 1e-3 if f32 else 8e-2)
+    opt = muse.FusedAdamW(muse.grouped_parameters(model, 0.01), lr=1e-3)
+    opt.step()                                                  # (the optimizer sees exactly the reference's parameter list)
+
+
 def test_uvit_bf16_mode_vs_reference_golden(golden_dir):
     """set_compute_dtype(torch.bfloat16): weight-GEMM operands rounded to bf16 (f32 accumulate / outputs), everything else f32.
     Expected from a CPU emulation of the same rounding: logits 8e-3, loss 1.3e-4, gradients <= 2.5e-2 (relative to max)."""

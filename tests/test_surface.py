@@ -4,6 +4,8 @@ import os
 import re
 import tempfile
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -375,3 +377,19 @@ def test_bench_config4_is_the_baseline_geometry():
     finally:
         M.MaskGiTUViT_v2._init_weights = init
     assert sum(p.numel() for p in model.parameters()) == 728725504
+
+
+def test_uvit_without_norm_gains_surface(golden_dir):
+    """ln_elementwise_affine=False: the state dict and the parameter list of muse.MaskGiTUViT equal the real reference's (no norm
+    weights; the gains are non-persistent constant buffers here), save / load round-trips"""
+    import json
+    import muse
+    g = np.load(os.path.join(golden_dir, "uvit_tiny_noaffine.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny_noaffine.json")))
+    ref_keys = [k[len("param."):] for k in g.files if k.startswith("param.")]
+    m = muse.MaskGiTUViT(**cfg)
+    assert list(m.state_dict().keys()) == ref_keys and not any(k.endswith("norm.weight") for k in ref_keys)
+    assert [n for n, _ in m.named_parameters()] == [k for k in ref_keys if "grad." + k in g.files]
+    m.load_state_dict({k: torch.from_numpy(g["param." + k]) for k in ref_keys}, strict=True)
+    m2 = muse.MaskGiTUViT(**dict(cfg, ln_elementwise_affine=True))           # the flag does not leak into the next model built
+    assert any(k.endswith("norm.weight") for k in m2.state_dict())
