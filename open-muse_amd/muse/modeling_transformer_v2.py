@@ -210,9 +210,10 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         c = self.config
         if len(c.block_out_channels) != 1:
             raise ValueError("block_out_channels must have exactly one entry (reference :166)")
-        if c.use_bias or c.force_down_up_sample or c.use_fused_mlp or c.norm_type != "rmsnorm":
-            raise NotImplementedError("MI355X build of MaskGiTUViT_v2: only the shipped configuration family is built "
-                                      "(rmsnorm with or without learnable gains, bias-free, GLU feed-forward, no forced down/up-sampling)")
+        if c.use_bias or c.force_down_up_sample or c.use_fused_mlp or c.norm_type not in ("rmsnorm", "layernorm"):
+            raise NotImplementedError("MI355X build of MaskGiTUViT_v2: only the bias-free GLU family without forced down/up-sampling is "
+                                      "built (norm_type rmsnorm or layernorm, with or without learnable gains)")
+        self.__dict__["_default_norm_mode"] = 1 if c.norm_type == "layernorm" else 0     # (Norm, reference :632-641)
         _NORM_AFFINE[0] = bool(c.ln_elementwise_affine)
         if c.hidden_dropout != 0.0 or c.attention_dropout != 0.0:
             raise NotImplementedError("dropout > 0 is outside the MI355X hot-path build")
@@ -344,9 +345,10 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         self._ada_dss(dss, sv, mod, name, G, scond, dscond)
         return dx
 
-    def _norm_adaln(self, x, norm_mod, ada: _AdaLN, scond, B, mode=0, residual=None):
+    def _norm_adaln(self, x, norm_mod, ada: _AdaLN, scond, B, mode=None, residual=None):
         """norm(x + residual) followed by its AdaLN modulation (TransformerLayer :757-792) as ONE kernel where the shape allows: the
         norm output itself is never written.  -> (m = GEMM operand of the next block, v = x + residual, tape entry)"""
+        mode = self._nm(mode)
         ss, slot = self._ada_ss_of(ada, scond)
         if self.fuse_norm_adaln and ops.norm_adaln_ok(x.shape[0], x.shape[1], B):
             od = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
@@ -357,8 +359,9 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         od = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
         return ops.adaln_fwd(n, ss, B, out_dtype=od), v, dict(x=n, ss=ss, slot=slot)
 
-    def _norm_adaln_bwd(self, dm, sv, v, norm_mod, norm_name, ada: _AdaLN, ada_name, G, scond, dscond, B, mode=0, dpre=None):
+    def _norm_adaln_bwd(self, dm, sv, v, norm_mod, norm_name, ada: _AdaLN, ada_name, G, scond, dscond, B, mode=None, dpre=None):
         """-> d(x) = d(residual) of _norm_adaln; the bf16 copy of it (dY of the next weight GEMMs) rides in the activation cache"""
+        mode = self._nm(mode)
         if not sv.get("fused"):
             dn = self._adaln_bwd(dm, sv, ada, ada_name, G, scond, dscond, B)
             return self._norm_bwd(dn, v, norm_mod, norm_name, G, mode=mode, dpre=dpre, gemm_operand=True)

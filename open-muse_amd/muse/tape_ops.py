@@ -225,17 +225,23 @@ class TapeOps:
         G[name + ".weight"] = self._mm_dw(dyc, x, w2.shape).view(mod.weight.shape)
         return self._mm_dx(dyc, w2) if need_dx else None
 
-    def _norm(self, x, mod, mode=0, residual=None, want_pre=False):
+    def _nm(self, mode):
+        """norm kind of a call that does not name one: the model's `norm_type` (0 RMSNorm, 1 LayerNorm; MaskGiTUViT sets `_default_norm_mode`)"""
+        return self.__dict__.get("_default_norm_mode", 0) if mode is None else mode
+
+    def _norm(self, x, mod, mode=None, residual=None, want_pre=False):
+        mode = self._nm(mode)
         y, pre = ops.norm_res_fwd(x, self._f(mod.weight), float(self.config.layer_norm_eps), mode, residual=residual,
                                   want_pre=want_pre)
         if getattr(mod, "bias", None) is not None and self.__dict__.get("_use_bias", False):
             ops.add_rowvec_(y, self._f(mod.bias))           # LayerNorm bias (reference :130-137; RMSNorm never has one)
         return y, pre
 
-    def _norm_bwd(self, dy, v, mod, name, G, mode=0, dpre=None, gemm_operand=False):
+    def _norm_bwd(self, dy, v, mod, name, G, mode=None, dpre=None, gemm_operand=False):
         """v = the tensor that was normalised (x + residual); returns d(x) = d(residual).
         gemm_operand (bf16 mode): dv is also the dY of the next weight GEMMs - the kernel writes its bf16 copy in the same pass
         and _c(dv) finds it instead of launching a cast."""
+        mode = self._nm(mode)
         if getattr(mod, "bias", None) is not None and self.__dict__.get("_use_bias", False):
             G[name + ".bias"] = ops.bias_grad(dy)
         if gemm_operand and self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 2:

@@ -377,16 +377,18 @@ def test_uvit_gradient_buckets_reduced_inside_backward_on_rccl(golden_dir, cd):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("name", ["uvit_tiny_noaffine", "uvit_tiny_layernorm"])
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
-def test_uvit_without_norm_gains_vs_reference_golden(golden_dir, cd):
-    """ln_elementwise_affine=False (reference :656-660, :705-711: norms without learnable gains): same state-dict keys and parameter
-    list as the real reference (no norm weights), logits / loss / every gradient against its outputs (tests/golden/uvit_tiny_noaffine.npz)"""
+def test_uvit_norm_variants_vs_reference_golden(golden_dir, cd, name):
+    """ln_elementwise_affine=False (reference :656-660, :705-711: norms without learnable gains) and norm_type="layernorm" (:637-638):
+    same state-dict keys and parameter list as the real reference, logits / loss / every gradient against its outputs
+    (tests/golden/uvit_tiny_noaffine.npz, uvit_tiny_layernorm.npz)"""
     import muse
-    g = np.load(os.path.join(golden_dir, "uvit_tiny_noaffine.npz"))
-    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny_noaffine.json")))
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_" + name + ".json")))
     sd = {k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}
     model = muse.MaskGiTUViT(**cfg)
-    assert set(model.state_dict().keys()) == set(sd.keys()) and not any(k.endswith("norm.weight") for k in sd)
+    assert set(model.state_dict().keys()) == set(sd.keys()) and any(k.endswith("norm.weight") for k in sd) == (name != "uvit_tiny_noaffine")
     assert [n for n, _ in model.named_parameters()] == [k for k in sd if k in dict(model.named_parameters())]
     model.load_state_dict(sd, strict=True)
     model.to(DEV).train().set_compute_dtype(cd)

@@ -158,7 +158,7 @@ def test_mask_sampling(golden_dir, name):
     np.testing.assert_array_equal(prob.numpy(), g["mask_prob"])
 
 
-@pytest.mark.parametrize("name", ["uvit_tiny", "uvit_tiny_noaffine"])
+@pytest.mark.parametrize("name", ["uvit_tiny", "uvit_tiny_noaffine", "uvit_tiny_layernorm"])
 def test_uvit_oracle_vs_reference_golden(golden_dir, name):
     """SURVEY.md section 8 row a12 (MaskGiTUViT_v2, config 4): logits, plain / smoothed+weighted loss and EVERY parameter
     gradient of the CPU restatement against the real reference (tests/golden/make_golden.py::golden_uvit); `uvit_tiny_noaffine`:

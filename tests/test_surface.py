@@ -312,8 +312,9 @@ def test_uvit_surface_and_roundtrip(golden_dir):
             assert torch.equal(a, b)
     with pytest.raises(MuseHipError):                                                # no CPU path
         m(torch.zeros(1, 16, dtype=torch.long), torch.zeros(1, 7, 24), torch.zeros(1, 16), torch.zeros(1, 5))
-    with pytest.raises(NotImplementedError):
-        muse.MaskGiTUViT(**{**cfg, "norm_type": "layernorm"})
+    with pytest.raises(NotImplementedError):                                         # outside the built family: refused loudly
+        muse.MaskGiTUViT(**{**cfg, "force_down_up_sample": True})
+    assert muse.MaskGiTUViT(**{**cfg, "norm_type": "layernorm"})._default_norm_mode == 1   # (built since round 4: tests/golden/uvit_tiny_layernorm.npz)
     with pytest.raises(AssertionError):
         m.generate()
 
