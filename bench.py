@@ -471,6 +471,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) if args.device is None else args.device
+    if os.environ.get("MUSE_BENCH_DEVICE") is not None:      # (protocol tests of the N > 1 path on a box with fewer GPUs than ranks)
+        local = int(os.environ["MUSE_BENCH_DEVICE"])
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
