@@ -403,7 +403,7 @@ def comm_block(info, world, dp_ms, plain_ms, grad_dtype, rccl_log):
     channels, rings / trees, transports)."""
     import glob
     import re
-    out = {"backend": "nccl (RCCL)", "ranks": dist.get_world_size() if dist.is_initialized() else world, "grad_allreduce_dtype": grad_dtype,
+    out = {"backend": "nccl (RCCL)" if dist.get_backend() != "gloo" else "gloo (protocol test)", "ranks": dist.get_world_size() if dist.is_initialized() else world, "grad_allreduce_dtype": grad_dtype,
            "bytes_per_step": int(info.get("bytes_per_step", 0)), "buckets_per_step": info.get("buckets_per_step"),
            "dp_step_ms": round(dp_ms, 3), "same_gpus_step_without_reducer_ms": None if plain_ms is None else round(plain_ms, 3),
            "exposed_comm_ms": None if plain_ms is None else round(dp_ms - plain_ms, 3)}
@@ -499,7 +499,10 @@ def main():
             sys.stdout = os.fdopen(real, "w", buffering=1)
         except OSError:
             rccl_log = None
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if os.environ.get("MUSE_BENCH_BACKEND", "nccl") == "gloo":   # protocol test of the N > 1 path on a box with fewer GPUs than ranks
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     import muse
     from muse import ops

@@ -534,6 +534,8 @@ class GradReducer:
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
+        # gloo has no ReduceOp.AVG: pre-scale and SUM (also for GPU tensors: protocol tests of the N > 1 path run two gloo ranks on one GPU)
+        self._has_avg = dist.get_backend(process_group) != "gloo"
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.grad_dtype = grad_dtype
         self._hi = self._lo = None
@@ -678,7 +680,7 @@ class GradReducer:
         """mean over ranks of one bucket (in place)"""
         if self.grad_dtype == torch.bfloat16:
             c = ops.cast_to_bf16(g) if on_gpu else g.to(torch.bfloat16)
-            if on_gpu:
+            if on_gpu and self._has_avg:
                 dist.all_reduce(c, op=dist.ReduceOp.AVG, group=self.pg)
                 ops.cast_to_f32(c, g)
             else:   # gloo: no AVG and no bf16 arithmetic guarantee: reduce the bf16-rounded values in f32
@@ -686,7 +688,7 @@ class GradReducer:
                 dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.pg)
                 g.copy_(c)
             return None
-        if on_gpu:
+        if on_gpu and self._has_avg:
             return dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
         g.mul_(1.0 / self.world)
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
@@ -744,7 +746,7 @@ class GradReducer:
         `accelerator.gather(mask_prob.repeat(bs)).mean()`, train_maskgit_imagenet.py:430-431) as ONE 2-float all-reduce
         instead of two all-gathers of bs and bs^2 floats.  -> (mean loss, mean mask rate) over all ranks."""
         v = torch.stack([loss.detach().float().reshape(()), mask_prob.detach().float().mean()])
-        if v.is_cuda:
+        if v.is_cuda and self._has_avg:
             dist.all_reduce(v, op=dist.ReduceOp.AVG, group=self.pg)
         else:
             v.mul_(1.0 / self.world)
