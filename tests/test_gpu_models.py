@@ -985,6 +985,33 @@ def test_bench_under_torchrun_single_rank():
     assert line["n_gpus"] == 1 and line["value"] > 100 and line["config"]["parallelism"] == "dp1" and line["roofline"]["frac"] > 0
 
 
+def test_bench_two_rank_protocol_on_one_gpu():
+    """bench.py with TWO ranks: everything the driver's N > 1 launch line does except RCCL itself (which refuses two ranks on one GPU:
+    "Duplicate GPU detected") - both ranks on GPU 0 over gloo (MUSE_BENCH_BACKEND / MUSE_BENCH_DEVICE): rank-0 weight broadcast, buckets
+    all-reduced from inside backward with AdamW behind each, the no-reducer comparison leg in a process of its own per rank and its
+    paired all-reduce, barrier-bracketed timing with the max over ranks, the metric all-reduce, the `comm` block, ONE JSON line on
+    rank 0's stdout and nothing else.  (Throughput over gloo means nothing; the assertions are about the protocol.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MUSE_BENCH_BACKEND="gloo", MUSE_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 16 and line["value"] > 0
+    comm = line["comm"]
+    assert comm["ranks"] == 2 and comm["buckets_per_step"] >= 1 and comm["bytes_per_step"] == 922245120
+    assert comm["same_gpus_step_without_reducer_ms"] > 0 and comm["allreduce_alone_ms"] > 0 and "hidden_fraction_of_allreduce" in comm
+    assert 1.0 < line["extra"]["loss"] < 10.0
+
+
 def test_get_soft_code_matches_oracle():
     """VectorQuantizer.get_soft_code (muse/modeling_maskgit_vqgan.py:327-340): softmax(-distances / temp) over the codebook from the
     HIP GEMM + softmax kernels against the oracle's distances; the hard code is the exact argmin; the stochastic draw is a valid id"""
