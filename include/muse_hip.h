@@ -410,6 +410,11 @@ int muse_adaln_fwd_ex(const float* x, const float* ss, float* y, void* y_bf16, i
                       void* stream);
 int muse_silu_fwd(const float* x, float* y, int64_t n, void* stream);
 int muse_dwconv3x3_nhwc(const float* x, const float* w, float* y, int32_t batch, int32_t H, int32_t W, int32_t C, void* stream);
+/* 2x2 space-to-depth (inverse = 0: x full [B, H, W, C] -> y packed [B, H/2, W/2, 4C], channel order (di, dj, c)) and its inverse
+ * (inverse = 1: x packed -> y full); H, W are the FULL-resolution sides in both directions (even), C % 4 == 0.  With it the stride-2
+ * 2x2 convolution of DownsampleBlock (reference muse/modeling_transformer_v2.py:510-514) and the stride-2 2x2 transposed convolution
+ * of UpsampleBlock (:558-562) are single products on muse_gemm; each direction is the other's backward. */
+int muse_space_to_depth2_nhwc(const float* x, float* y, int32_t batch, int32_t H, int32_t W, int32_t C, int32_t inverse, void* stream);
 int muse_grn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* scratch, int32_t batch, int64_t S,
                  int32_t C, void* stream);
 /* ... with the f32 result and / or its bf16 copy (the next GEMM's operand in the bf16 compute mode); either pointer may be null */

@@ -249,6 +249,37 @@ static int launch_dwconv_v4(const float* x, const float* w, float* y, int batch,
   hipLaunchKernelGGL(dwconv3x3_v4_kernel<FLIP>, dim3(vpp >= 256 ? (vpp + 255) / 256 : 1, batch * H), dim3(256), 0, s, x, w, y, H, W, C);
   return 1;
 }
+// =================================================================================================================
+// 2x2 space-to-depth / depth-to-space on channels-last rows: the data movement that turns the stride-2 2x2 convolution of
+// DownsampleBlock (reference muse/modeling_transformer_v2.py:510-514) and the stride-2 2x2 transposed convolution of UpsampleBlock
+// (:558-562) into plain products on the GEMM kernels.  full [B, H, W, C] <-> packed [B, H/2, W/2, (di, dj, c)], 16 bytes per thread.
+// =================================================================================================================
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void space_depth2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C4,
+                                                           long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    long r = i / C4;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const long b = r / H;
+    const long packed = (((b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * C4 + c;
+    if (INVERSE) ((f32x4*)y)[i] = ((const f32x4*)x)[packed];
+    else ((f32x4*)y)[packed] = ((const f32x4*)x)[i];
+  }
+}
+extern "C" int muse_space_to_depth2_nhwc(const float* x, float* y, int32_t batch, int32_t H, int32_t W, int32_t C, int32_t inverse,
+                                         void* stream) {
+  if (batch < 0 || H <= 0 || W <= 0 || C <= 0) return MUSE_ERR_BAD_ARG;
+  if ((H | W) & 1 || (C & 3) || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return MUSE_ERR_UNSUPPORTED;
+  const long n4 = (long)batch * H * W * (C >> 2);
+  if (n4 == 0) return 0;
+  long g = (n4 + 255) / 256; if (g > 16384) g = 16384;
+  if (inverse) hipLaunchKernelGGL(space_depth2_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C >> 2, n4);
+  else hipLaunchKernelGGL(space_depth2_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C >> 2, n4);
+  return (int)hipGetLastError();
+}
+
 extern "C" int muse_dwconv3x3_nhwc(const float* x, const float* w, float* y, int32_t batch, int32_t H, int32_t W, int32_t C,
                                    void* stream) {
   const long n = (long)batch * H * W * C;

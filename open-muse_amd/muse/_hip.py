@@ -139,6 +139,7 @@ SIGNATURES = {
     "muse_adaln_fwd_ex": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_silu_fwd": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_dwconv3x3_nhwc": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "muse_space_to_depth2_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "muse_grn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_grn_fwd_ex": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_sinusoidal_encode": [c_void_p, c_void_p, c_i64, c_int, c_float, c_void_p],

@@ -112,11 +112,27 @@ class _AttnBlock2D(nn.Module):
         self.crossattention = _Attn(c, c)
 
 
-class _Block(nn.Module):
-    def __init__(self, c, hidden, n):
+class _ConvT(nn.Module):
+    """nn.ConvTranspose2d(cin, cout, k, stride=k) of the reference: weight [cin, cout, k, k]"""
+
+    def __init__(self, cin, cout, k):
         super().__init__()
+        self.weight = nn.Parameter(torch.empty(cin, cout, k, k))
+
+
+class _Block(nn.Module):
+    """DownsampleBlock (reference :506-541) / UpsampleBlock (:544-583).  resample ("down" / "up" / None, config.force_down_up_sample):
+    Sequential(Norm2D, Conv2d(c, c, 2, stride 2)) registered BEFORE the blocks, or Sequential(Norm2D, ConvTranspose2d(c, c, 2, stride 2))
+    registered AFTER them - the reference's module order, so that state dicts and parameter lists line up"""
+
+    def __init__(self, c, hidden, n, resample=None):
+        super().__init__()
+        if resample == "down":
+            self.downsample = nn.ModuleDict({"0": _Norm2D(c), "1": _Conv(c, c, 2)})
         self.res_blocks = nn.ModuleList([_ResBlock(c, hidden) for _ in range(n)])
         self.attention_blocks = nn.ModuleList([_AttnBlock2D(c, hidden) for _ in range(n)])
+        if resample == "up":
+            self.upsample = nn.ModuleDict({"0": _Norm2D(c), "1": _ConvT(c, c, 2)})
 
 
 class _FFN(nn.Module):
@@ -210,9 +226,9 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         c = self.config
         if len(c.block_out_channels) != 1:
             raise ValueError("block_out_channels must have exactly one entry (reference :166)")
-        if c.use_bias or c.force_down_up_sample or c.use_fused_mlp or c.norm_type not in ("rmsnorm", "layernorm"):
-            raise NotImplementedError("MI355X build of MaskGiTUViT_v2: only the bias-free GLU family without forced down/up-sampling is "
-                                      "built (norm_type rmsnorm or layernorm, with or without learnable gains)")
+        if c.use_bias or c.use_fused_mlp or c.norm_type not in ("rmsnorm", "layernorm"):
+            raise NotImplementedError("MI355X build of MaskGiTUViT_v2: only the bias-free GLU family is built (norm_type rmsnorm or "
+                                      "layernorm, with or without learnable gains, with or without the forced down/up-sampling)")
         self.__dict__["_default_norm_mode"] = 1 if c.norm_type == "layernorm" else 0     # (Norm, reference :632-641)
         _NORM_AFFINE[0] = bool(c.ln_elementwise_affine)
         if c.hidden_dropout != 0.0 or c.attention_dropout != 0.0:
@@ -223,13 +239,13 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         self.encoder_proj_layer_norm = _NormW(H)
         self.embed = _Embed(c.vocab_size, cin, C)
         self.cond_embed = nn.ModuleDict({"0": _Lin(c.micro_cond_embed_dim + c.cond_embed_dim, H), "2": _Lin(H, H)})
-        self.down_blocks = nn.ModuleList([_Block(C, H, c.num_res_blocks)])
+        self.down_blocks = nn.ModuleList([_Block(C, H, c.num_res_blocks, "down" if c.force_down_up_sample else None)])
         self.project_to_hidden_norm = _NormW(C)
         self.project_to_hidden = _Lin(C, H)
         self.transformer_layers = nn.ModuleList([_Layer(H, c.intermediate_size) for _ in range(c.num_hidden_layers)])
         self.project_from_hidden_norm = _NormW(H)
         self.project_from_hidden = _Lin(H, C)
-        self.up_blocks = nn.ModuleList([_Block(C, H, c.num_res_blocks)])
+        self.up_blocks = nn.ModuleList([_Block(C, H, c.num_res_blocks, "up" if c.force_down_up_sample else None)])
         self.mlm_layer = _Mlm(C, cin, c.codebook_size)
         self.compute_dtype = torch.float32
         self.wgrad_stream = os.environ.get("MUSE_WGRAD_STREAM", "1") != "0"   # bf16 mode: weight-gradient GEMMs on a second HIP stream
@@ -246,6 +262,8 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
                 nn.init.trunc_normal_(m.weight, std=0.02)
             elif isinstance(m, nn.Embedding):
                 nn.init.trunc_normal_(m.weight, std=0.02)
+            elif isinstance(m, _ConvT):       # not an nn.Conv2d: the reference's _init_weights (:225-231) leaves torch's default init
+                nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
         nn.init.xavier_uniform_(self.embed.conv.weight, 0.02)
         nn.init.normal_(self.embed.embeddings.weight, std=float(np.sqrt(1 / self.config.vocab_size)))
         nn.init.constant_(self.mlm_layer.conv1.weight, 0)
@@ -432,13 +450,43 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             denc.add_(dctx)
         return dh
 
+    # ---- force_down_up_sample (configs/research_run_512_with_downsample*.yaml): 2x2 stride-2 conv before the down block, 2x2 stride-2
+    # transposed conv after the up block (reference :510-514, :558-562).  Both are ONE product on the GEMM kernels around a
+    # space-to-depth move (ops.space_to_depth2 / depth_to_space2): conv  y[p, co] = sum_(di,dj,ci) x2[p, (di,dj,ci)] W[co, ci, di, dj],
+    # transposed conv  y2[p, (di,dj,co)] = sum_ci x[p, ci] W[ci, co, di, dj] followed by the depth-to-space placement.
+    def _w_resample(self, mod, transposed):
+        """the 2x2 kernel as the [N_out, K_in] operand of the product: [C, (di,dj,ci)] / [(di,dj,co), C]; compute dtype (the
+        re-layout of a C x C x 2 x 2 tensor is a device copy: plumbing)"""
+        w = self._f(mod.weight)
+        w2 = (w.permute(2, 3, 1, 0) if transposed else w.permute(0, 2, 3, 1)).reshape((-1, w.shape[0]) if transposed else (w.shape[0], -1))
+        w2 = w2.contiguous()
+        if self.compute_dtype == torch.bfloat16 and w2.shape[1] % 8 == 0 and w2.shape[0] % 8 == 0:
+            w2 = ops.cast_to_bf16(w2)
+        return w2
+
+    def _mm_dw_now(self, dy, x, shape2):
+        """dy^T x -> f32 [N, K] on the current stream (the two resampling kernels need their gradient re-laid out right away, so they
+        stay out of the grouped side-stream launch)"""
+        if shape2[-1] % 8 or shape2[0] % 8 or self.compute_dtype != torch.bfloat16:
+            dyc = dy if dy.dtype == torch.float32 else ops.cast_to_f32(dy.contiguous())
+            xc = x if x.dtype == torch.float32 else ops.cast_to_f32(x.contiguous())
+        else:
+            dyc, xc = self._c(dy), self._c(x)
+        dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
+        ops.linear_wgrad(dyc, xc, dw, False)
+        return dw
+
     def _run_forward(self, input_ids, encoder_hidden_states, cond_embeds, micro_conds, labels, label_smoothing, loss_weight,
                      need_grad):
         c = self.config
-        B, S = input_ids.shape
-        side = int(S ** 0.5)
-        if side * side != S:
+        B, St = input_ids.shape                                                       # St tokens on a side_t x side_t grid
+        side_t = int(St ** 0.5)
+        if side_t * side_t != St:
             raise ValueError("the token sequence must be a square grid")
+        down_up = bool(c.force_down_up_sample)
+        if down_up and side_t % 2:
+            raise ValueError("force_down_up_sample needs an even token grid")
+        S, side = (St // 4, side_t // 2) if down_up else (St, side_t)                 # what the blocks and the transformer layers see
         L = encoder_hidden_states.shape[1]
         H, C = c.hidden_size, c.block_out_channels[0]
         f = self._f
@@ -464,6 +512,12 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         h = self._lin(emb, self.embed.conv)
         T["down"] = []
         blk = self.down_blocks[0]
+        if down_up:                                                                   # Norm2D -> Conv2d(C, C, 2, stride 2)  (:510-514)
+            n0, _ = self._norm(h, blk.downsample["0"].norm)
+            x2 = ops.space_to_depth2(n0, B, side_t, side_t, C)
+            wd = self._w_resample(blk.downsample["1"], False)
+            T["downsample"] = dict(h=h, x2=x2, wd=wd)
+            h = self._mm(x2, wd)
         for i in range(c.num_res_blocks):
             h, sr = self._res_block(h, blk.res_blocks[i], scond, B, side)
             h, sa = self._attn_block(h, blk.attention_blocks[i], enc, senc, B, S, L)
@@ -505,15 +559,20 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             h, sa = self._attn_block(h, blk.attention_blocks[i], enc, senc, B, S, L)
             T["up"].append((sr, sa))
         self.__dict__["_ada_ss"] = {}     # every site has run: the tape holds what backward needs, nothing pins the [Z, B, N] buffers
+        if down_up:                                                                   # Norm2D -> ConvTranspose2d(C, C, 2, stride 2)  (:558-562)
+            n1, _ = self._norm(h, blk.upsample["0"].norm)
+            wu = self._w_resample(blk.upsample["1"], True)
+            T["upsample"] = dict(h=h, n=n1, wu=wu)
+            h = ops.depth_to_space2(self._mm(n1, wu), B, side_t, side_t, C)
         # ConvMlmLayer :1002-1022
         y1 = self._lin(h, self.mlm_layer.conv1)
         y2, _ = self._norm(y1, self.mlm_layer.layer_norm.norm)
         V = c.codebook_size
         Vp = (V + 7) // 8 * 8
         w2 = self._w2(self.mlm_layer.conv2)
-        logits_p = torch.empty((B * S, Vp), dtype=torch.float32, device=y2.device)
-        ops.gemm(self._c(y2), w2, logits_p, B * S, V, c.in_channels, lda=c.in_channels, ldb=c.in_channels, ldc=Vp)
-        logits = logits_p.view(B, S, Vp) if Vp == V else logits_p[:, :V].contiguous().view(B, S, V)
+        logits_p = torch.empty((B * St, Vp), dtype=torch.float32, device=y2.device)
+        ops.gemm(self._c(y2), w2, logits_p, B * St, V, c.in_channels, lda=c.in_channels, ldb=c.in_channels, ldc=Vp)
+        logits = logits_p.view(B, St, Vp) if Vp == V else logits_p[:, :V].contiguous().view(B, St, V)
         loss = None
         if labels is not None:
             lab = labels.reshape(-1).contiguous()
@@ -527,7 +586,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             T["ce"] = dict(lab=lab, lse=lse, loss_out=loss_out, lw=lw, ls=float(label_smoothing))
         if not need_grad:
             return logits, loss, None
-        T.update(B=B, S=S, L=L, side=side, enc_in=enc_in, enc0=enc0, enc=enc, senc=senc, cond_in=cond_in, c1=c1, sc1=sc1, cond=cond,
+        T.update(B=B, S=S, St=St, side_t=side_t, L=L, side=side, enc_in=enc_in, enc0=enc0, enc=enc, senc=senc, cond_in=cond_in, c1=c1, sc1=sc1, cond=cond,
                  scond=scond, ids=ids, emb0=emb0, emb=emb, h_mlm=h, y1=y1, y2=y2, logits_p=logits_p, V=V, Vp=Vp, ada_tape=ada_tape)
         return logits, loss, T
 
@@ -535,6 +594,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         """gradients of every parameter for d(loss) = g_loss: {state-dict name: tensor}"""
         c = self.config
         B, S, L, V, Vp = T["B"], T["S"], T["L"], T["V"], T["Vp"]
+        St, side_t = T["St"], T["side_t"]
         H, C = c.hidden_size, c.block_out_channels[0]
         G = {}
         ce = T["ce"]
@@ -555,6 +615,13 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         denc = torch.zeros_like(T["enc"])
         dsenc = torch.zeros_like(senc) if senc is not None else None
         blk = self.up_blocks[0]
+        if "upsample" in T:     # y = depth_to_space(n1 Wu^T): d(n1 Wu^T) = space_to_depth(dy)
+            u = T["upsample"]
+            dy2 = ops.space_to_depth2(dh, B, side_t, side_t, C)
+            dyc = dy2 if u["wu"].dtype == torch.float32 else self._c(dy2)
+            gw = self._mm_dw_now(dyc, u["n"], (4 * C, C))                              # [(di, dj, co), ci] -> [ci, co, di, dj]
+            G["up_blocks.0.upsample.1.weight"] = gw.view(2, 2, C, C).permute(3, 2, 0, 1).contiguous()
+            dh = self._norm_bwd(self._mm_dx(dyc, u["wu"]), u["h"], blk.upsample["0"].norm, "up_blocks.0.upsample.0.norm", G)
         for i in reversed(range(c.num_res_blocks)):
             sr, sa = T["up"][i]
             dh = self._attn_block_bwd(dh, sa, blk.attention_blocks[i], f"up_blocks.0.attention_blocks.{i}", G, senc, denc, dsenc)
@@ -601,12 +668,19 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             dh = self._attn_block_bwd(dh, sa, blk.attention_blocks[i], f"down_blocks.0.attention_blocks.{i}", G, senc, denc, dsenc)
             dh = self._res_block_bwd(dh, sr, blk.res_blocks[i], f"down_blocks.0.res_blocks.{i}", G, scond, dscond, B)
             self._report_grads(G)
+        if "downsample" in T:   # y = x2 Wd^T, x2 = space_to_depth(norm(h))
+            d = T["downsample"]
+            dyc = dh if d["wd"].dtype == torch.float32 else self._c(dh)
+            gw = self._mm_dw_now(dyc, d["x2"], (C, 4 * C))                             # [co, (di, dj, ci)] -> [co, ci, di, dj]
+            G["down_blocks.0.downsample.1.weight"] = gw.view(C, 2, 2, C).permute(0, 3, 1, 2).contiguous()
+            dn0 = ops.depth_to_space2(self._mm_dx(dyc, d["wd"]), B, side_t, side_t, C)
+            dh = self._norm_bwd(dn0, d["h"], blk.downsample["0"].norm, "down_blocks.0.downsample.0.norm", G)
         # ConvEmbed
         demb = self._lin_bwd(dh, T["emb"], self.embed.conv, "embed.conv", G)
         demb0 = self._norm_bwd(demb, T["emb0"], self.embed.layer_norm, "embed.layer_norm", G)
         gemb = torch.zeros_like(self._f(self.embed.embeddings.weight))
-        dpos = torch.empty((S, gemb.shape[1]), dtype=torch.float32, device=dev)      # (position table of the shared kernel: unused here)
-        ops.embed_bwd(T["ids"].view(B, S), demb0, gemb, dpos, False)
+        dpos = torch.empty((St, gemb.shape[1]), dtype=torch.float32, device=dev)     # (position table of the shared kernel: unused here)
+        ops.embed_bwd(T["ids"].view(B, St), demb0, gemb, dpos, False)
         G["embed.embeddings.weight"] = gemb
         # conditioning: scond = silu(cond), cond = W2 silu(W0 cond_in)
         if T.get("ada_tape") is not None:

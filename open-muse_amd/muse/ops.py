@@ -1266,6 +1266,24 @@ def dwconv3x3_nhwc(x, w, B, H, W, C_):
     return y
 
 
+def space_to_depth2(x, B, H, W, C_):
+    """x [B*H*W, C] f32 (NHWC rows) -> [B*(H/2)*(W/2), 4C], channel order (di, dj, c): the operand of the stride-2 2x2 convolution as
+    a product (DownsampleBlock, reference modeling_transformer_v2.py:510-514); also the backward of depth_to_space2"""
+    require_gpu(x)
+    y = torch.empty((B * (H // 2) * (W // 2), 4 * C_), dtype=torch.float32, device=x.device)
+    check(lib().muse_space_to_depth2_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, C_, 0, stream()), "muse_space_to_depth2_nhwc")
+    return y
+
+
+def depth_to_space2(x, B, H, W, C_):
+    """x [B*(H/2)*(W/2), 4C] f32, channel order (di, dj, c) -> [B*H*W, C]: the stride-2 2x2 transposed convolution's output placement
+    (UpsampleBlock, reference :558-562); H, W are the full-resolution sides"""
+    require_gpu(x)
+    y = torch.empty((B * H * W, C_), dtype=torch.float32, device=x.device)
+    check(lib().muse_space_to_depth2_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, C_, 1, stream()), "muse_space_to_depth2_nhwc")
+    return y
+
+
 def grn_fwd(x, gamma, beta, B, S, want_stats=False, out_dtype=torch.float32):
     """GlobalResponseNorm over the S pixels of each image; x [B*S, C] f32.  out_dtype=torch.bfloat16: the result is written
     only as the bf16 GEMM operand of the bf16 compute mode (no f32 copy, no cast pass)"""

@@ -154,9 +154,11 @@ def uvit_forward(sd: SD, cfg: dict, input_ids: Tensor, encoder_hidden_states: Te
     emb = F.embedding(input_ids.view(B, side, side), sd["embed.embeddings.weight"])
     emb, _ = norm(emb, sd, "embed.layer_norm.", cfg)
     h = F.conv2d(emb.permute(0, 3, 1, 2), sd["embed.conv.weight"], sd.get("embed.conv.bias"))
-    # DownsampleBlock :506-541 (force_down_up_sample=False in every shipped config: no stride-2 conv)
-    if cfg.get("force_down_up_sample", False):
-        raise NotImplementedError("force_down_up_sample is not used by the target configs")
+    # DownsampleBlock :506-541; force_down_up_sample (configs/research_run_512_with_downsample*.yaml): Norm2D -> 2x2 stride-2 conv (:510-514)
+    down_up = bool(cfg.get("force_down_up_sample", False))
+    if down_up:
+        h = F.conv2d(norm2d(h, sd, "down_blocks.0.downsample.0.", cfg), sd["down_blocks.0.downsample.1.weight"],
+                     sd.get("down_blocks.0.downsample.1.bias"), stride=2)
     for i in range(cfg["num_res_blocks"]):
         h = res_block(h, cond, sd, f"down_blocks.0.res_blocks.{i}.", cfg)
         h = attention_block_2d(h, enc, sd, f"down_blocks.0.attention_blocks.{i}.", cfg)
@@ -174,6 +176,9 @@ def uvit_forward(sd: SD, cfg: dict, input_ids: Tensor, encoder_hidden_states: Te
     for i in range(cfg["num_res_blocks"]):                                                    # UpsampleBlock :544-583
         h = res_block(h, cond, sd, f"up_blocks.0.res_blocks.{i}.", cfg)
         h = attention_block_2d(h, enc, sd, f"up_blocks.0.attention_blocks.{i}.", cfg)
+    if down_up:                                                                               # Norm2D -> 2x2 stride-2 transposed conv (:558-562)
+        h = F.conv_transpose2d(norm2d(h, sd, "up_blocks.0.upsample.0.", cfg), sd["up_blocks.0.upsample.1.weight"],
+                               sd.get("up_blocks.0.upsample.1.bias"), stride=2)
     # ConvMlmLayer :1002-1022 (1x1 convs = per-pixel linears)
     h = F.conv2d(h, sd["mlm_layer.conv1.weight"], sd.get("mlm_layer.conv1.bias"))
     h = norm2d(h, sd, "mlm_layer.layer_norm.", cfg)

@@ -612,6 +612,7 @@ if __name__ == "__main__":
     golden_uvit("uvit_tiny", UVIT_TINY, batch=2, seq=16, text_len=7, seed=400)
     golden_uvit("uvit_tiny_noaffine", dict(UVIT_TINY, ln_elementwise_affine=False), batch=2, seq=16, text_len=7, seed=410)   # norms without gains (:656-660)
     golden_uvit("uvit_tiny_layernorm", dict(UVIT_TINY, norm_type="layernorm"), batch=2, seq=16, text_len=7, seed=420)        # Norm = LayerNorm (:637-638)
+    golden_uvit("uvit_tiny_downup", dict(UVIT_TINY, force_down_up_sample=True), batch=2, seq=64, text_len=7, seed=430)       # stride-2 conv / transposed conv around the blocks (:510-514, :558-562)
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))   # the repo root, for `oracle`
     golden_generate2("generate2_tiny", W.TRANSFORMER_TINY, batch=3, seed=500, timesteps=6, temperature=4.5)
     golden_uvit_generate2("uvit_generate2_tiny", UVIT_TINY, batch=2, seq=16, text_len=7, seed=520, timesteps=5, temperature=(2, 0),

@@ -377,12 +377,13 @@ def test_uvit_gradient_buckets_reduced_inside_backward_on_rccl(golden_dir, cd):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["uvit_tiny_noaffine", "uvit_tiny_layernorm"])
+@pytest.mark.parametrize("name", ["uvit_tiny_noaffine", "uvit_tiny_layernorm", "uvit_tiny_downup"])
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
 def test_uvit_norm_variants_vs_reference_golden(golden_dir, cd, name):
-    """ln_elementwise_affine=False (reference :656-660, :705-711: norms without learnable gains) and norm_type="layernorm" (:637-638):
+    """ln_elementwise_affine=False (reference :656-660, :705-711: norms without learnable gains), norm_type="layernorm" (:637-638) and
+    force_down_up_sample=True (:510-514, :558-562: stride-2 2x2 conv / transposed conv around the blocks, 8 x 8 tokens -> 4 x 4 inside):
     same state-dict keys and parameter list as the real reference, logits / loss / every gradient against its outputs
-    (tests/golden/uvit_tiny_noaffine.npz, uvit_tiny_layernorm.npz)"""
+    (tests/golden/uvit_tiny_noaffine.npz, uvit_tiny_layernorm.npz, uvit_tiny_downup.npz)"""
     import muse
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = json.load(open(os.path.join(golden_dir, "config_" + name + ".json")))
@@ -466,6 +467,70 @@ def test_uvit_config4_vs_reference_golden(golden_dir):
         for k in keys:
             assert errs[k] < (2e-3 if f32 else 1.5e-1), (cd, k, errs[k])
             assert nerrs[k] < (1e-3 if f32 else 3e-2), (cd, k, nerrs[k])
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 24), (3, 6, 10, 768), (1, 32, 32, 768)])
+def test_space_to_depth2_and_its_inverse(B, H, W, C):
+    """muse_space_to_depth2_nhwc: full [B, H, W, C] <-> packed [B, H/2, W/2, (di, dj, c)], exact data movement in both directions;
+    through it the stride-2 2x2 conv and transposed conv of force_down_up_sample equal torch's on the same operands (f32 products)"""
+    from muse import ops
+    torch.manual_seed(H * W + C)
+    x = torch.randn(B * H * W, C, device=DEV)
+    want = x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B * (H // 2) * (W // 2), 4 * C)
+    x2 = ops.space_to_depth2(x, B, H, W, C)
+    assert torch.equal(x2, want)
+    assert torch.equal(ops.depth_to_space2(x2, B, H, W, C), x)
+    if C <= 64:
+        wd = torch.randn(C, C, 2, 2, device=DEV) * 0.1
+        ref = F.conv2d(x.view(B, H, W, C).permute(0, 3, 1, 2), wd, stride=2).permute(0, 2, 3, 1).reshape(-1, C)
+        got = ops.linear(x2, wd.permute(0, 2, 3, 1).reshape(C, -1).contiguous(), out_dtype=torch.float32)
+        assert rel_err(got, ref) < 1e-5
+        xs = torch.randn(B * (H // 2) * (W // 2), C, device=DEV)
+        wu = torch.randn(C, C, 2, 2, device=DEV) * 0.1
+        ref = F.conv_transpose2d(xs.view(B, H // 2, W // 2, C).permute(0, 3, 1, 2), wu, stride=2).permute(0, 2, 3, 1).reshape(-1, C)
+        got = ops.depth_to_space2(ops.linear(xs, wu.permute(2, 3, 1, 0).reshape(-1, C).contiguous(), out_dtype=torch.float32), B, H, W, C)
+        assert rel_err(got, ref) < 1e-5
+    with pytest.raises(Exception):
+        ops.space_to_depth2(torch.randn(3 * 3 * 8, 8, device=DEV), 1, 3, 3, 8)      # odd sides are refused, not mis-indexed
+
+
+def test_uvit_forced_down_up_sample_modes_and_decoding(golden_dir):
+    """force_down_up_sample=True beyond the golden comparison (test_uvit_norm_variants_vs_reference_golden): the bf16x3 mode against the
+    reference's f32 outputs, the CPU oracle's logits on a second batch, and generate2 (eager == kept HIP graph, ids in range)"""
+    import muse
+    from oracle import uvit_oracle as U
+    g = np.load(os.path.join(golden_dir, "uvit_tiny_downup.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny_downup.json")))
+    sd = {k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}
+    model = muse.MaskGiTUViT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train().set_compute_dtype("bf16x3")
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    logits, loss = model(*args, labels=torch.from_numpy(g["labels"]).to(DEV))
+    loss.backward()
+    assert rel_err(logits, torch.from_numpy(g["logits"])) < 1e-3 and abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    _grad_check(model, {k[len("grad."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad.")}, 1e-3)
+    # a 4 x 4 grid (2 x 2 inside the blocks), inference signature, against the oracle
+    model.eval().set_compute_dtype(torch.float32)
+    gen = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, cfg["vocab_size"], (3, 16), generator=gen)
+    enc, cond = torch.randn(3, 5, cfg["encoder_hidden_size"], generator=gen), torch.randn(3, cfg["cond_embed_dim"], generator=gen)
+    micro = torch.tensor([[256.0, 256.0, 0.0, 0.0, 6.0]]).repeat(3, 1)
+    with torch.no_grad():
+        want = U.uvit_forward(sd, cfg, ids, enc, cond, micro)
+        got = model(ids.to(DEV), enc.to(DEV), cond.to(DEV), micro.to(DEV))
+    assert got.shape == want.shape and rel_err(got, want) < 1e-4
+    with pytest.raises(ValueError):
+        model(ids[:, :9].to(DEV), enc.to(DEV), cond.to(DEV), micro.to(DEV))          # 3 x 3 tokens: no 2 x 2 blocks
+    # decoding: 64 tokens, classifier-free guidance, eager and the kept graph sample the same ids from the same seed
+    kw = dict(encoder_hidden_states=enc.to(DEV), cond_embeds=cond.to(DEV), micro_conds=micro.to(DEV),
+              empty_embeds=torch.zeros(1, 5, cfg["encoder_hidden_size"], device=DEV), empty_cond_embeds=torch.zeros(1, cfg["cond_embed_dim"], device=DEV),
+              timesteps=4, guidance_scale=2.0, seq_len=64)
+    a = model.generate2(generator=torch.Generator().manual_seed(3), **kw)
+    b = model.generate2(generator=torch.Generator().manual_seed(3), hip_graph=True, **kw)
+    c = model.generate2(generator=torch.Generator().manual_seed(3), hip_graph=True, **kw)
+    assert a.shape == (3, 64) and int(a.min()) >= 0 and int(a.max()) < cfg["codebook_size"]
+    assert torch.equal(a, b) and torch.equal(b, c)
 
 
 def test_cached_bf16_weights_never_go_stale_across_stackings(golden_dir):

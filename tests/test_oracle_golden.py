@@ -158,11 +158,12 @@ def test_mask_sampling(golden_dir, name):
     np.testing.assert_array_equal(prob.numpy(), g["mask_prob"])
 
 
-@pytest.mark.parametrize("name", ["uvit_tiny", "uvit_tiny_noaffine", "uvit_tiny_layernorm"])
+@pytest.mark.parametrize("name", ["uvit_tiny", "uvit_tiny_noaffine", "uvit_tiny_layernorm", "uvit_tiny_downup"])
 def test_uvit_oracle_vs_reference_golden(golden_dir, name):
     """SURVEY.md section 8 row a12 (MaskGiTUViT_v2, config 4): logits, plain / smoothed+weighted loss and EVERY parameter
     gradient of the CPU restatement against the real reference (tests/golden/make_golden.py::golden_uvit); `uvit_tiny_noaffine`:
-    ln_elementwise_affine=False, norms without learnable gains (:656-660: their weights are absent from the state dict)"""
+    ln_elementwise_affine=False, norms without learnable gains (:656-660: their weights are absent from the state dict); `uvit_tiny_downup`:
+    force_down_up_sample=True on an 8 x 8 token grid (stride-2 conv / transposed conv around the blocks, :510-514 / :558-562)"""
     import json
     from oracle import uvit_oracle as U
     g = np.load(os.path.join(golden_dir, name + ".npz"))

@@ -313,7 +313,7 @@ def test_uvit_surface_and_roundtrip(golden_dir):
     with pytest.raises(MuseHipError):                                                # no CPU path
         m(torch.zeros(1, 16, dtype=torch.long), torch.zeros(1, 7, 24), torch.zeros(1, 16), torch.zeros(1, 5))
     with pytest.raises(NotImplementedError):                                         # outside the built family: refused loudly
-        muse.MaskGiTUViT(**{**cfg, "force_down_up_sample": True})
+        muse.MaskGiTUViT(**{**cfg, "use_fused_mlp": True})
     assert muse.MaskGiTUViT(**{**cfg, "norm_type": "layernorm"})._default_norm_mode == 1   # (built since round 4: tests/golden/uvit_tiny_layernorm.npz)
     with pytest.raises(AssertionError):
         m.generate()
@@ -378,6 +378,33 @@ def test_bench_config4_is_the_baseline_geometry():
     finally:
         M.MaskGiTUViT_v2._init_weights = init
     assert sum(p.numel() for p in model.parameters()) == 728725504
+
+
+def test_uvit_forced_down_up_sample_surface(golden_dir):
+    """force_down_up_sample=True (configs/research_run_512_with_downsample*.yaml): state-dict keys IN ORDER, shapes and the parameter
+    list equal the real reference's (downsample registered before the blocks, upsample after them; the transposed conv keeps torch's
+    default init because the reference's _init_weights only matches nn.Conv2d / nn.Linear, :225-231)"""
+    import json
+    import muse
+    g = np.load(os.path.join(golden_dir, "uvit_tiny_downup.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny_downup.json")))
+    ref = {k[len("param."):]: tuple(g[k].shape) for k in g.files if k.startswith("param.")}
+    torch.manual_seed(0)
+    m = muse.MaskGiTUViT(**cfg)
+    assert list(m.state_dict().keys()) == list(ref.keys()) and {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref
+    assert [n for n, _ in m.named_parameters()] == list(ref.keys())
+    for k in ("down_blocks.0.downsample.0.norm.weight", "down_blocks.0.downsample.1.weight", "up_blocks.0.upsample.0.norm.weight",
+              "up_blocks.0.upsample.1.weight"):
+        assert k in ref
+    C = cfg["block_out_channels"][0]
+    wu = m.up_blocks[0].upsample["1"].weight.detach()
+    assert float(wu.abs().max()) <= 1.0 / (4 * C) ** 0.5 and float(wu.abs().max()) > 0.05      # kaiming_uniform(a = sqrt 5): +-1/sqrt(fan_in)
+    assert abs(float(m.down_blocks[0].downsample["1"].weight.detach().std()) - 0.02) < 0.002        # trunc_normal(std 0.02) like every conv
+    m.load_state_dict({k: torch.from_numpy(g["param." + k]) for k in ref}, strict=True)
+    with tempfile.TemporaryDirectory() as d:
+        m.save_pretrained(d)
+        m2 = muse.MaskGiTUViT.from_pretrained(d)
+        assert m2.config.force_down_up_sample and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
 
 
 def test_uvit_without_norm_gains_surface(golden_dir):
