@@ -140,8 +140,11 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
     ):
         super().__init__()
         if use_conv_in_out:
-            raise NotImplementedError("MaskGitTransformer (MI355X build): use_conv_in_out is not built (no configuration of the "
-                                      "reference sets it; ConvEmbed / ConvMlmLayer are only reachable through it)")
+            # (configs/cc12m_movq.yaml and imagenet_text2image_movq_conv.yaml set it without `embedding_size`, which the reference's own
+            #  constructor cannot build: nn.Embedding(vocab_size, None) raises, modeling_transformer.py:1132-1141, :1007)
+            raise NotImplementedError("MaskGitTransformer (MI355X build): use_conv_in_out is not built (the two reference configurations "
+                                      "that set it do not construct in the reference either; ConvEmbed / ConvMlmLayer of this class are "
+                                      "only reachable through it)")
         if norm_type not in ("layernorm", "rmsnorm"):
             raise ValueError(f"norm_type must be 'layernorm' or 'rmsnorm', got {norm_type}")
         # (`embedding_size` is accepted and, as in the reference, unused: the constructor hands `hidden_size` to Embed for both widths,
