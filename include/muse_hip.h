@@ -202,6 +202,12 @@ int muse_cross_entropy_bwd(const void* logits, int32_t dtype, const int64_t* lab
  * training/train_maskgit_imagenet.py:242-261,438); optionally refreshes the bf16 compute copy of the weights. */
 int muse_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+/* Exponential moving average of the weights, every tracked tensor in ONE launch (EMAModel.step, reference muse/modeling_ema.py:118-137,
+ * called behind the optimizer step at training/train_muse.py:779-780): shadow = shadow - one_minus_decay * (shadow - param), the three
+ * f32 roundings of the reference's tensor expression kept.  `table` (device): 4 x int64 per tensor {shadow, param, n, mode}, mode 0 =
+ * update, 1 = copy (requires_grad == False, :134-135); `chunk_first` as for muse_adamw_multi. */
+int muse_ema_multi(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks, float one_minus_decay,
+                   void* stream);
 /* The same update for many separate f32 tensors in ONE launch (models whose parameters are ordinary tensors: MaskGiTUViT_v2,
  * muse/modeling_transformer_v2.py; the reference reaches this through apex FusedAdam's multi_tensor_apply).  `table` (device):
  * 6 x int64 per tensor {p, g, m, v, p_bf16 or 0, n}; `chunk_first` (device, num_tensors + 1 x int32): exclusive prefix sum of

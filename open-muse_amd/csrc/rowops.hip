@@ -1418,6 +1418,47 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const long* __restrict
     if (pb) pb[i] = f32_to_bf16(pp);
   }
 }
+// Exponential moving average of the weights (reference muse/modeling_ema.py:118-137, called right behind the optimizer step,
+// training/train_muse.py:779-780): shadow -= (1 - decay) * (shadow - param) over EVERY tracked tensor in one launch - the reference
+// issues three elementwise kernels per tensor.  Table: 4 x int64 per tensor {shadow, param, n, mode}; mode 0 = the update, mode 1 =
+// plain copy (a parameter with requires_grad == False, :134-135).  chunk_first as in adamw_multi_kernel.  The three roundings of the
+// reference's expression (subtract, multiply, subtract - each an f32 tensor op there) are kept: no contraction into an fma.
+__device__ __forceinline__ float ema_update1(float s, float p, float omd) {
+#pragma clang fp contract(off)
+  const float t = s - p;
+  const float u = omd * t;
+  return s - u;
+}
+__global__ __launch_bounds__(256) void ema_multi_kernel(const long* __restrict__ table, const int* __restrict__ chunk_first, int nt, float omd) {
+  int lo = 0, hi = nt;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const long* e = table + (long)lo * 4;
+  float* s = (float*)e[0]; const float* p = (const float*)e[1];
+  const long n = e[2], base = (long)((int)blockIdx.x - chunk_first[lo]) * 4096;
+  const bool copy = e[3] != 0;
+  const long end = base + 4096 < n ? base + 4096 : n;
+  const bool vec = !((((uintptr_t)s) | ((uintptr_t)p)) & 15);
+  if (vec) {
+    for (long i = base + threadIdx.x * 4; i + 3 < end; i += 1024) {
+      float ss[4], pp[4];
+      V4<float>::load(s + i, ss); V4<float>::load(p + i, pp);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ss[j] = copy ? pp[j] : ema_update1(ss[j], pp[j], omd);
+      V4<float>::store(s + i, ss);
+    }
+  }
+  const long s0 = vec ? base + ((end - base) & ~3L) : base;
+  for (long i = s0 + threadIdx.x; i < end; i += 256) s[i] = copy ? p[i] : ema_update1(s[i], p[i], omd);
+}
+extern "C" int muse_ema_multi(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks,
+                              float one_minus_decay, void* stream) {
+  if (num_tensors <= 0 || num_chunks <= 0) return 0;
+  if (!table || !chunk_first) return MUSE_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ema_multi_kernel, dim3(num_chunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, chunk_first, num_tensors,
+                     one_minus_decay);
+  return (int)hipGetLastError();
+}
+
 extern "C" int muse_adamw_multi(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
   if (num_tensors <= 0 || num_chunks <= 0) return 0;

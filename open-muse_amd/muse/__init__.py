@@ -2,11 +2,13 @@
 
 Same import surface as the reference package for the classes on the path (reference muse/__init__.py:18-25):
 MaskGitTransformer, MaskGiTUViT, MaskGitVQGAN, VQGANModel (the taming tokenizer of the text-to-image configs),
-PipelineMuse, get_mask_chedule; everything computes through libmuse_hip.so (hand-written HIP kernels for gfx950).
-Components the hot path does not touch (MoVQ / Paella VQ models, EMA, the inpainting pipeline) are not part of this build.
+PipelineMuse, EMAModel (the weight average train_muse.py advances behind every optimizer step), get_mask_chedule; everything computes
+through libmuse_hip.so (hand-written HIP kernels for gfx950).
+Components the hot path does not touch (MoVQ / Paella VQ models, the inpainting pipeline) are not part of this build.
 """
 __version__ = "0.0.1"
 
+from .ema import EMAModel
 from .modeling_maskgit_vqgan import MaskGitVQGAN
 from .modeling_taming_vqgan import VQGANModel
 from .modeling_transformer import MaskGitTransformer
@@ -17,5 +19,5 @@ from .sampling import get_mask_chedule
 from .training import (FusedAdamW, GradReducer, TrainStep, cond_dropout, grouped_parameters, mask_or_random_replace_tokens,
                        prepare_inputs_and_labels)
 
-__all__ = ["MaskGitVQGAN", "VQGANModel", "MaskGitTransformer", "MaskGiTUViT", "MaskGiTUViT_v2", "PipelineMuse", "get_mask_chedule", "FusedAdamW", "GradReducer",
+__all__ = ["EMAModel", "MaskGitVQGAN", "VQGANModel", "MaskGitTransformer", "MaskGiTUViT", "MaskGiTUViT_v2", "PipelineMuse", "get_mask_chedule", "FusedAdamW", "GradReducer",
            "TrainStep", "prepare_inputs_and_labels", "mask_or_random_replace_tokens", "cond_dropout", "grouped_parameters"]

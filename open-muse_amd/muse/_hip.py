@@ -89,6 +89,7 @@ SIGNATURES = {
     "muse_adamw_flat": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float,
                         c_float, c_int, c_float, c_void_p],
     "muse_adamw_multi": [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p],
+    "muse_ema_multi": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "muse_adamw_flat_groups": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_float, c_void_p],
     "muse_adamw_multi_groups": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p],

@@ -797,6 +797,14 @@ def adamw_multi(table, chunk_first, num_tensors, num_chunks, lr, beta1, beta2, e
                                  weight_decay, step, grad_scale, stream()), "muse_adamw_multi")
 
 
+def ema_multi(table, chunk_first, num_tensors, num_chunks, one_minus_decay):
+    """shadow -= (1 - decay) * (shadow - param) over a device-side table of tensors in one launch (muse_ema_multi; muse.EMAModel builds
+    the table)"""
+    require_gpu(table, chunk_first)
+    check(lib().muse_ema_multi(table.data_ptr(), chunk_first.data_ptr(), int(num_tensors), int(num_chunks), float(one_minus_decay), stream()),
+          "muse_ema_multi")
+
+
 def _group_hyper(groups):
     """host array of {lr, beta1, beta2, eps, weight_decay} rows for muse_adamw_*_groups (kept alive by the caller for the call)"""
     import ctypes

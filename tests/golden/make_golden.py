@@ -419,6 +419,28 @@ def golden_uvit(name, cfg, batch, seq, text_len, seed):
     print(name, "loss", float(loss), "weighted", float(loss_w), "logits", tuple(logits.shape), "max|logit|", float(logits.abs().max()))
 
 
+def golden_ema(name, seed, steps=14):
+    """muse/modeling_ema.py:EMAModel (the real class) over `steps` calls of step() on changing parameters, two schedules: the decay each
+    call used and every shadow tensor after every call"""
+    from muse.modeling_ema import EMAModel
+    out = dict(seed=np.int64(seed), steps=np.int64(steps))
+    for si, kw in enumerate(W.EMA_SCHEDULES):
+        params = [torch.nn.Parameter(t) for t in W.ema_params(seed, 0)]
+        params[4].requires_grad_(False)
+        ema = EMAModel(params, **kw)
+        for step in range(1, steps + 1):
+            with torch.no_grad():
+                for p_, t in zip(params, W.ema_params(seed, step)):
+                    p_.copy_(t)
+            ema.step(params)
+            out[f"s{si}.decay{step}"] = np.float64(-1.0 if (step - 1) % kw["update_every"] else ema.cur_decay_value)
+            for i, sh in enumerate(ema.shadow_params):
+                out[f"s{si}.shadow{step}.{i}"] = np_(sh).copy()        # (sub_ updates the shadow in place: a view would alias every later step)
+        assert ema.optimization_step == steps
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "decays", [round(float(out[f"s0.decay{t}"]), 4) for t in range(1, steps + 1)])
+
+
 def replay_decode_noise(seed, steps, rows, seq, vocab):
     """the draws a reference generate2 call makes from torch.Generator().manual_seed(seed), per step: torch.multinomial(probs
     [rows*seq, vocab], 1) fills an Exp(1) tensor of the probabilities' shape (ATen multinomial_out, one-sample fast path), then
@@ -618,6 +640,7 @@ if __name__ == "__main__":
     golden_uvit_generate2("uvit_generate2_tiny", UVIT_TINY, batch=2, seq=16, text_len=7, seed=520, timesteps=5, temperature=(2, 0),
                           guidance_scale=3.0)
     golden_mask_muse("mask_muse", seed=540)
+    golden_ema("ema_tiny", seed=560)
     golden_transformer_autocast("transformer_tiny_bf16", W.TRANSFORMER_TINY, batch=3, seed=100)
     golden_transformer_autocast("transformer_hd48_bf16", W.TRANSFORMER_HD48, batch=2, seed=120)
     golden_transformer_text("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY, batch=3, text_len=7, seed=800)

@@ -413,3 +413,15 @@ def uvit_inputs(batch: int, seq: int, text_len: int, seed: int, vocab_size: int 
     micro = np.tile(np.array([[256.0, 256.0, 0.0, 0.0, 6.0]], dtype=np.float32), (batch, 1))
     micro[1:, 2] = 16.0
     return tuple(torch.from_numpy(a) for a in (input_ids, enc, cond, micro, labels))
+
+
+# ---- the weight average (muse/modeling_ema.py): tracked tensors and schedules of tests/golden/ema_tiny.npz ------------------------------
+EMA_SHAPES = [(7,), (33, 5), (1030,), (515,), (3, 1, 2, 2), ()]      # (index 4 is frozen: requires_grad False -> copied, :134-135)
+EMA_SCHEDULES = [dict(decay=0.9999, update_after_step=2, update_every=1),
+                 dict(decay=0.999, min_decay=0.3, update_every=2, use_ema_warmup=True, inv_gamma=1.0, power=2 / 3)]
+
+
+def ema_params(seed, step):
+    """the tracked tensors at a training step: seeded, so the tests regenerate them instead of storing them"""
+    g = torch.Generator().manual_seed(seed * 1000 + step)
+    return [torch.randn(sh, generator=g) * (1.0 + 0.1 * i) for i, sh in enumerate(EMA_SHAPES)]

@@ -324,3 +324,31 @@ def test_uvit_oracle_at_config4_vs_reference(golden_dir):
             assert float(np.abs(W.subsample(grads[k]).numpy() - g["grad." + k]).max()) <= 2e-5 * float(g["absmax." + k]), k
     finally:
         torch.set_num_threads(1)
+
+
+# ---- the weight average behind the optimizer step (muse/modeling_ema.py; training/train_muse.py:779-780) -----------------------------------
+def test_ema_oracle_vs_reference_golden(golden_dir):
+    """the numpy restatement of EMAModel.get_decay / step against what the REAL reference class produced (tests/golden/ema_tiny.npz,
+    make_golden.py::golden_ema): two schedules (update_after_step; warmup + min_decay + update_every 2), 14 calls on changing
+    parameters, a frozen tensor among them - decays equal, every shadow tensor BIT-identical after every call"""
+    from oracle import ema_oracle as E
+    g = np.load(os.path.join(golden_dir, "ema_tiny.npz"))
+    seed, steps = int(g["seed"]), int(g["steps"])
+    rg = [i != 4 for i in range(len(W.EMA_SHAPES))]
+    for si, kw in enumerate(W.EMA_SCHEDULES):
+        sched = E.Schedule(**kw)
+        shadow = [t.numpy().copy() for t in W.ema_params(seed, 0)]
+        used = 0
+        for step in range(1, steps + 1):
+            params = [t.numpy() for t in W.ema_params(seed, step)]
+            decay = sched.next()
+            if decay is None:
+                assert float(g[f"s{si}.decay{step}"]) == -1.0
+            else:
+                assert decay == float(g[f"s{si}.decay{step}"])
+                shadow = E.ema_update(shadow, params, rg, decay)
+                used += 1
+            for i, sh in enumerate(shadow):
+                assert np.array_equal(sh, g[f"s{si}.shadow{step}.{i}"]), (si, step, i)
+        assert used == (steps if kw.get("update_every", 1) == 1 else steps // 2)
+

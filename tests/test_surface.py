@@ -421,3 +421,82 @@ def test_uvit_without_norm_gains_surface(golden_dir):
     m.load_state_dict({k: torch.from_numpy(g["param." + k]) for k in ref_keys}, strict=True)
     m2 = muse.MaskGiTUViT(**dict(cfg, ln_elementwise_affine=True))           # the flag does not leak into the next model built
     assert any(k.endswith("norm.weight") for k in m2.state_dict())
+
+
+def test_ema_model_host_logic(golden_dir):
+    """muse.EMAModel (CPU side): the reference's decay schedule (against the decays the real class used, tests/golden/ema_tiny.npz),
+    state-dict keys and validation errors, store / copy_to / restore (parameter version counters move: the models' cached bf16 weights
+    are keyed on them), the call counters of skipped steps, and a loud refusal to update on the CPU"""
+    import muse
+    import weights as W
+    from muse._hip import MuseHipError
+    from muse.modeling_ema import EMAModel as SameClass
+    assert SameClass is muse.EMAModel
+    g = np.load(os.path.join(golden_dir, "ema_tiny.npz"))
+    seed, steps = int(g["seed"]), int(g["steps"])
+    for si, kw in enumerate(W.EMA_SCHEDULES):
+        ema = muse.EMAModel([torch.nn.Parameter(t) for t in W.ema_params(seed, 0)], **kw)
+        for step in range(1, steps + 1):
+            want = float(g[f"s{si}.decay{step}"])
+            if want >= 0:
+                assert ema.get_decay(step) == want
+    params = [torch.nn.Parameter(t) for t in W.ema_params(seed, 0)]
+    ema = muse.EMAModel(params, decay=0.99, update_every=3)
+    assert list(ema.state_dict().keys()) == ["decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma",
+                                             "power", "shadow_params"]                       # reference :163-177
+    assert all(torch.equal(s, p) and s.data_ptr() != p.data_ptr() for s, p in zip(ema.shadow_params, params))
+    with pytest.raises(MuseHipError):
+        ema.step(params)                                                                     # call 1 updates: no CPU path
+    assert ema.optimization_step == 1
+    ema.step(params)                                                                         # calls 2, 3 are skipped (update_every 3): counters only
+    ema.step(params)
+    assert ema.optimization_step == 3 and ema.cur_decay_value == 0.0
+    # swap in / out
+    v0 = [p._version for p in params]
+    ema.shadow_params = [s + 1 for s in ema.shadow_params]
+    with pytest.raises(RuntimeError):
+        ema.restore(params)
+    ema.store(params)
+    ema.copy_to(params)
+    assert all(torch.equal(p, s) for p, s in zip(params, ema.shadow_params)) and all(p._version > v for p, v in zip(params, v0))
+    ema.restore(params)
+    assert all(torch.equal(p.detach(), t) for p, t in zip(params, W.ema_params(seed, 0))) and ema.temp_stored_params is None
+    # state dict round trip + the reference's validation
+    sd = ema.state_dict()
+    other = muse.EMAModel(params)
+    other.load_state_dict(sd)
+    assert other.decay == 0.99 and other.optimization_step == 3 and all(torch.equal(a, b) for a, b in zip(other.shadow_params, ema.shadow_params))
+    assert other.shadow_params[0].data_ptr() != ema.shadow_params[0].data_ptr()            # deep copy, like the reference
+    for bad, msg in ((dict(decay=1.5), "Decay must be between 0 and 1"), (dict(min_decay=1), "Invalid min_decay"),
+                     (dict(optimization_step=1.0), "Invalid optimization_step"), (dict(use_ema_warmup=1), "Invalid use_ema_warmup"),
+                     (dict(power="x"), "Invalid power"), (dict(shadow_params=(1,)), "shadow_params must be a list"),
+                     (dict(shadow_params=[1]), "shadow_params must all be Tensors")):
+        with pytest.raises(ValueError, match=msg):
+            muse.EMAModel(params).load_state_dict(bad)
+    with pytest.raises(ValueError, match="model_cls"):
+        ema.save_pretrained("/nonexistent")
+
+
+def test_ema_model_save_and_from_pretrained(golden_dir):
+    """EMAModel.save_pretrained / from_pretrained (reference :64-88): the average is written as the model's weights and the EMA scalars
+    into its config.json.  Like the reference (observed on the real class: decay 0.97 / step 42 saved, 0.9999 / 0 after from_pretrained),
+    from_pretrained restores the AVERAGE but not the scalars: `load_config(return_unused_kwargs=True)` hands back the unused *call*
+    kwargs, which are empty - kept as is, a drop-in does not change what a resumed run does"""
+    import json
+    import muse
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    torch.manual_seed(1)
+    m = muse.MaskGiTUViT(**cfg)
+    ema = muse.EMAModel(m.parameters(), decay=0.97, update_after_step=5, model_cls=muse.MaskGiTUViT, model_config=m.config)
+    ema.shadow_params = [s * 0.5 for s in ema.shadow_params]
+    ema.optimization_step = 42
+    with tempfile.TemporaryDirectory() as d:
+        ema.save_pretrained(d)
+        saved = json.load(open(os.path.join(d, "config.json")))
+        assert saved["decay"] == 0.97 and saved["update_after_step"] == 5 and saved["optimization_step"] == 42 and "shadow_params" not in saved
+        back = muse.EMAModel.from_pretrained(d, muse.MaskGiTUViT)
+        assert back.decay == 0.9999 and back.update_after_step == 0 and back.optimization_step == 0      # (the reference's behaviour)
+        assert back.model_cls is muse.MaskGiTUViT and back.model_config is not None
+        assert all(torch.equal(a, b) for a, b in zip(back.shadow_params, ema.shadow_params))
+        assert all(torch.equal(p.detach() * 0.5, s) for p, s in zip(m.parameters(), back.shadow_params))
+
