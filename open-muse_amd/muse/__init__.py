@@ -2,9 +2,9 @@
 
 Same import surface as the reference package for the classes on the path (reference muse/__init__.py:18-25):
 MaskGitTransformer, MaskGiTUViT, MaskGitVQGAN, VQGANModel (the taming tokenizer of the text-to-image configs),
-PipelineMuse, EMAModel (the weight average train_muse.py advances behind every optimizer step), get_mask_chedule; everything computes
+PipelineMuse, PipelineMuseInpainting, EMAModel (the weight average train_muse.py advances behind every optimizer step), get_mask_chedule; everything computes
 through libmuse_hip.so (hand-written HIP kernels for gfx950).
-Components the hot path does not touch (MoVQ / Paella VQ models, the inpainting pipeline) are not part of this build.
+Components the hot path does not touch (MoVQ / Paella VQ models) are not part of this build.
 """
 __version__ = "0.0.1"
 
@@ -14,10 +14,10 @@ from .modeling_taming_vqgan import VQGANModel
 from .modeling_transformer import MaskGitTransformer
 from .modeling_transformer_v2 import MaskGiTUViT, MaskGiTUViT_v2
 from . import pre_encode
-from .pipeline_muse import PipelineMuse
+from .pipeline_muse import PipelineMuse, PipelineMuseInpainting
 from .sampling import get_mask_chedule
 from .training import (FusedAdamW, GradReducer, TrainStep, cond_dropout, grouped_parameters, mask_or_random_replace_tokens,
                        prepare_inputs_and_labels)
 
-__all__ = ["EMAModel", "MaskGitVQGAN", "VQGANModel", "MaskGitTransformer", "MaskGiTUViT", "MaskGiTUViT_v2", "PipelineMuse", "get_mask_chedule", "FusedAdamW", "GradReducer",
+__all__ = ["EMAModel", "MaskGitVQGAN", "VQGANModel", "MaskGitTransformer", "MaskGiTUViT", "MaskGiTUViT_v2", "PipelineMuse", "PipelineMuseInpainting", "get_mask_chedule", "FusedAdamW", "GradReducer",
            "TrainStep", "prepare_inputs_and_labels", "mask_or_random_replace_tokens", "cond_dropout", "grouped_parameters"]

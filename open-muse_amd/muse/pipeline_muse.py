@@ -1,8 +1,9 @@
-"""muse.PipelineMuse — class-conditional generation wrapper (reference: muse/pipeline_muse.py:38-369).
+"""muse.PipelineMuse / muse.PipelineMuseInpainting - generation wrappers (reference: muse/pipeline_muse.py:38-369, :372-510).
 
-Thin: `generate2` on the transformer then `vae.decode_code`; both run on the HIP kernels.  Text conditioning needs
-a CLIP/T5 encoder, which is outside the hot-path build, so only `is_class_conditioned=True` is executable here; the
-constructor / `to` / `from_pretrained` / `save_pretrained` signatures are kept.
+Thin: `generate2` on the transformer, then `vae.decode_code`; both run on the HIP kernels (the inpainting pipeline first tokenises the
+picture with `vae.encode`).  The text encoder is the reference's own third-party dependency (a `transformers` CLIP / T5 model and its
+tokenizer, handed to the constructor): when one is given, `text=` is encoded by calling it exactly as the reference does; without one the
+pipelines take PRE-COMPUTED text states (`prompt_embeds`, ...).  Constructor / `to` / `from_pretrained` / `save_pretrained` signatures kept.
 """
 from __future__ import annotations
 
@@ -56,25 +57,80 @@ class PipelineMuse:
         """reference :66-243, same argument names and defaults.  Three executable paths: class-conditional MaskGitTransformer
         (`class_ids`), text-conditioned MaskGitTransformer on PRE-COMPUTED text states (`prompt_embeds`, `negative_prompt_embeds`),
         and MaskGiTUViT conditioned on PRE-COMPUTED text states (`prompt_embeds` [B, 77, D] + `pooled_embeds`
-        [B, D], with `empty_embeds` / `empty_pooled_embeds` or the negative_* pair for classifier-free guidance); running a text
-        encoder on `text` needs CLIP, which is outside the hot-path build.  `temperature` may be the reference's (start, end)
-        tuple: MaskGitTransformer.generate2 takes a float, so the tuple's first entry is used there."""
-        from .sampling import get_mask_chedule
+        [B, D], with `empty_embeds` / `empty_pooled_embeds` or the negative_* pair for classifier-free guidance).  `text=` is encoded
+        by the pipeline's own `text_encoder` / `tokenizer` when the constructor was given them (`_encode_text`: the reference's calls).
+        `temperature` may be the reference's (start, end) tuple: MaskGitTransformer.generate2 takes a float, so the tuple's first
+        entry is used there."""
         if text is None and class_ids is None and prompt_embeds is None:
             raise ValueError("Either text or class_ids must be provided.")
         if text is not None and class_ids is not None:
             raise ValueError("Only one of text or class_ids may be provided.")
-        if text is not None:
-            raise NotImplementedError("text-conditioned generation from raw text needs a text encoder (outside the MI355X hot-path "
-                                      "build): pass prompt_embeds / pooled_embeds instead")
-        schedule = get_mask_chedule(noise_schedule)
+        if text is not None and prompt_embeds is None:
+            e = self._encode_text(text, negative_text if negative_prompt_embeds is None else None, clip_skip)
+            prompt_embeds, pooled_embeds = e["prompt_embeds"], e["pooled_embeds"]
+            if e["negative_prompt_embeds"] is not None:
+                negative_prompt_embeds, negative_pooled_embeds = e["negative_prompt_embeds"], e["negative_pooled_embeds"]
+            if e["empty_embeds"] is not None:
+                empty_embeds, empty_pooled_embeds = e["empty_embeds"], e["empty_pooled_embeds"]
+        ids, intermediate = self._generate(None, class_ids, prompt_embeds, pooled_embeds, negative_prompt_embeds, negative_pooled_embeds,
+                                           empty_embeds, empty_pooled_embeds, timesteps, noise_schedule, guidance_scale, guidance_schedule,
+                                           temperature, num_images_per_prompt, generator, orig_size, crop_coords, aesthetic_score,
+                                           return_intermediate, transformer_seq_len)
+        images = self._decode(ids, output_type)
+        if intermediate is not None:
+            return images, [self._decode(t, output_type) for t in intermediate]
+        return images
+
+    # ---- text states from the pipeline's own encoder (reference :107-190) -------------------------------------------------------------------
+    def _encode_text(self, text, negative_text, clip_skip=None):
+        """tokenizer + text encoder called as the reference calls them: penultimate (or `clip_skip`) hidden state + `text_embeds` for a
+        transformer with `add_cond_embeds` (CLIPTextModelWithProjection), `last_hidden_state` otherwise (T5 / plain CLIP); the negative
+        prompt likewise (always the penultimate layer, :149-152); without a negative prompt the empty prompt's states for
+        classifier-free guidance (:178-186).  -> dict of f32 tensors on the pipeline's device (None where the reference has None)"""
+        if self.text_encoder is None or self.tokenizer is None:
+            raise NotImplementedError("PipelineMuse(text=...) needs the pipeline's `text_encoder` and `tokenizer` (a transformers CLIP / T5 "
+                                      "model, as in the reference); without them pass prompt_embeds / pooled_embeds")
+        tok, enc = self.tokenizer, self.text_encoder
+        pooled_wanted = bool(getattr(self.transformer.config, "add_cond_embeds", False))
+
+        def ids_of(t):
+            return tok(t, return_tensors="pt", padding="max_length", truncation=True, max_length=tok.model_max_length).input_ids.to(self.device)
+
+        def states(t, layer):
+            if pooled_wanted:
+                out = enc(ids_of(t), return_dict=True, output_hidden_states=True)
+                return out.hidden_states[layer], out.text_embeds
+            return enc(ids_of(t)).last_hidden_state, None
+
+        text = [text] if isinstance(text, str) else list(text)
+        f32 = lambda t: None if t is None else t.float()   # noqa: E731
+        hidden, pooled = states(text, -(clip_skip + 1) if clip_skip is not None else -2)
+        out = dict(prompt_embeds=f32(hidden), pooled_embeds=f32(pooled), negative_prompt_embeds=None, negative_pooled_embeds=None,
+                   empty_embeds=None, empty_pooled_embeds=None)
+        if negative_text is not None:
+            negative_text = [negative_text] * len(text) if isinstance(negative_text, str) else list(negative_text)
+            nh, npool = states(negative_text, -2)
+            out.update(negative_prompt_embeds=f32(nh), negative_pooled_embeds=f32(npool))
+        else:
+            empty = tok("", padding="max_length", return_tensors="pt").input_ids.to(self.device)
+            o = enc(empty, output_hidden_states=True)
+            out.update(empty_embeds=f32(o.hidden_states[-2]), empty_pooled_embeds=f32(o[0]))
+        return out
+
+    # ---- tokens from conditioning (shared by the inpainting pipeline, which starts from a partly masked token grid) --------------------------
+    def _generate(self, input_ids, class_ids, prompt_embeds, pooled_embeds, negative_prompt_embeds, negative_pooled_embeds, empty_embeds,
+                  empty_pooled_embeds, timesteps, noise_schedule, guidance_scale, guidance_schedule, temperature, num_images_per_prompt,
+                  generator, orig_size, crop_coords, aesthetic_score, return_intermediate=False, transformer_seq_len=None):
+        from .sampling import get_mask_chedule
+        schedule = get_mask_chedule(noise_schedule) if isinstance(noise_schedule, str) else noise_schedule
+        start = {} if input_ids is None else {"input_ids": input_ids}
         if class_ids is not None:
             if isinstance(class_ids, int):
                 class_ids = [class_ids]
-            class_ids = torch.tensor(class_ids, device=self.device, dtype=torch.long).repeat_interleave(num_images_per_prompt, dim=0)
+            class_ids = torch.as_tensor(class_ids, device=self.device, dtype=torch.long).repeat_interleave(num_images_per_prompt, dim=0)
             t0 = float(temperature[0]) if isinstance(temperature, (tuple, list)) else float(temperature)
             ids = self.transformer.generate2(class_ids=class_ids, timesteps=timesteps, temperature=t0, guidance_scale=guidance_scale,
-                                             noise_schedule=schedule, generator=generator)
+                                             noise_schedule=schedule, generator=generator, **start)
             intermediate = None
         elif isinstance(self.transformer, MaskGitTransformer):
             # text-conditioned MaskGitTransformer on pre-computed text states (reference :207-243 hands the same keyword set to
@@ -87,7 +143,7 @@ class PipelineMuse:
             # negative_embeds are given (:1398-1402) - so does ours
             ids = self.transformer.generate2(encoder_hidden_states=rep(prompt_embeds), negative_embeds=rep(negative_prompt_embeds), timesteps=timesteps,
                                              temperature=t0, guidance_scale=guidance_scale, noise_schedule=schedule,
-                                             generator=generator)
+                                             generator=generator, **start)
             intermediate = None
         else:
             n = num_images_per_prompt
@@ -96,7 +152,8 @@ class PipelineMuse:
             temp = tuple(temperature) if isinstance(temperature, (tuple, list)) else temperature
             # small decoding batches are bound by per-launch host time, not by kernels: the forward is captured into a HIP graph that
             # generate2 keeps across calls of one shape (`self.hip_graph`: None = automatic for <= 4096 rows, True / False to force)
-            rows = (2 if guidance_scale > 0 else 1) * prompt_embeds.shape[0] * n * (transformer_seq_len or 256)
+            seq = input_ids.shape[1] if input_ids is not None else (transformer_seq_len or 256)
+            rows = (2 if guidance_scale > 0 else 1) * prompt_embeds.shape[0] * n * seq
             use_graph = (rows <= 4096 and timesteps >= 2) if getattr(self, "hip_graph", None) is None else bool(self.hip_graph)
             out = self.transformer.generate2(
                 rep(prompt_embeds), rep(pooled_embeds), micro,
@@ -104,13 +161,10 @@ class PipelineMuse:
                 None if empty_pooled_embeds is None else empty_pooled_embeds.to(self.device),
                 negative_embeds=rep(negative_prompt_embeds), negative_cond_embeds=rep(negative_pooled_embeds), temperature=temp,
                 timesteps=timesteps, guidance_scale=guidance_scale, guidance_schedule=guidance_schedule, noise_schedule=schedule,
-                generator=generator, return_intermediate=return_intermediate, seq_len=transformer_seq_len,
-                use_tqdm=False if use_tqdm is None else use_tqdm and False, hip_graph=use_graph)
+                generator=generator, return_intermediate=return_intermediate, seq_len=seq,
+                use_tqdm=False, hip_graph=use_graph, **start)
             ids, intermediate = out if return_intermediate else (out, None)
-        images = self._decode(ids, output_type)
-        if intermediate is not None:
-            return images, [self._decode(t, output_type) for t in intermediate]
-        return images
+        return ids, intermediate
 
     def _decode(self, ids, output_type):
         images = torch.clamp(self.vae.decode_code(ids), 0.0, 1.0).permute(0, 2, 3, 1).float().cpu().numpy()
@@ -145,3 +199,56 @@ class PipelineMuse:
             vae = load_vae(vae_path)
             transformer = load_transformer(transformer_path)
         return cls(vae=vae, transformer=transformer, is_class_conditioned=is_class_conditioned)
+
+
+def _center_square(image, size):
+    """torchvision's Resize(size, BILINEAR) -> CenterCrop(size) -> ToTensor() of the reference (:399-405) on a PIL image, without
+    torchvision: the shorter side to `size` (PIL bilinear), the centred size x size window, uint8 / 255 as [3, size, size] f32"""
+    from PIL import Image
+    w, h = image.size
+    nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+    image = image.convert("RGB").resize((nw, nh), Image.BILINEAR)
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+    arr = np.asarray(image.crop((left, top, left + size, top + size)), dtype=np.uint8)
+    return torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div(255.0)
+
+
+class PipelineMuseInpainting(PipelineMuse):
+    """reference :372-510: tokenise the picture (`vae.encode`), put the mask token where `mask` is set, let `generate2` fill those
+    positions (it keeps every token that is not the mask token), decode."""
+
+    @torch.no_grad()
+    def __call__(self, image, mask: torch.Tensor, text: Optional[Union[str, List[str]]] = None,
+                 negative_text: Optional[Union[str, List[str]]] = None, class_ids=None, timesteps: int = 8, guidance_scale: float = 8.0,
+                 guidance_schedule=None, temperature=1.0, topk_filter_thres: float = 0.9, num_images_per_prompt: int = 1,
+                 use_maskgit_generate: bool = True, generator: Optional[torch.Generator] = None, use_fp16: bool = False,
+                 image_size: int = 256, orig_size=(256, 256), crop_coords=(0, 0), aesthetic_score=6.0,
+                 prompt_embeds: Optional[torch.Tensor] = None, pooled_embeds: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds: Optional[torch.Tensor] = None, negative_pooled_embeds: Optional[torch.Tensor] = None,
+                 empty_embeds: Optional[torch.Tensor] = None, empty_pooled_embeds: Optional[torch.Tensor] = None, output_type: str = "pil"):
+        """same arguments as the reference; in addition the pre-computed text states PipelineMuse takes, and `image` may already be a
+        [3, H, W] tensor in [0, 1].  `mask`: bool [tokens] (or [h, w]) over the token grid, True = repaint"""
+        assert use_maskgit_generate
+        if text is None and class_ids is None and prompt_embeds is None:
+            raise ValueError("Either text or class_ids must be provided.")
+        if text is not None and class_ids is not None:
+            raise ValueError("Only one of text or class_ids may be provided.")
+        pixels = image if isinstance(image, torch.Tensor) else _center_square(image, image_size)
+        _, tokens = self.vae.encode(pixels.unsqueeze(0).to(self.device).float())
+        tokens = tokens.reshape(1, -1).clone()
+        mask = torch.as_tensor(mask, dtype=torch.bool, device=tokens.device).reshape(-1)
+        if mask.numel() != tokens.shape[1]:
+            raise ValueError(f"mask has {mask.numel()} entries for {tokens.shape[1]} image tokens")
+        tokens[mask[None]] = self.transformer.config.mask_token_id
+        if text is not None and prompt_embeds is None:
+            e = self._encode_text(text, negative_text, None)
+            prompt_embeds, pooled_embeds = e["prompt_embeds"], e["pooled_embeds"]
+            negative_prompt_embeds, negative_pooled_embeds = e["negative_prompt_embeds"], e["negative_pooled_embeds"]
+            empty_embeds, empty_pooled_embeds = e["empty_embeds"], e["empty_pooled_embeds"]
+        batch = (len(class_ids) if isinstance(class_ids, (list, tuple)) else 1) if class_ids is not None else prompt_embeds.shape[0]
+        tokens = tokens.repeat(batch * num_images_per_prompt, 1)
+        ids, _ = self._generate(tokens, class_ids, prompt_embeds, pooled_embeds, negative_prompt_embeds, negative_pooled_embeds,
+                                empty_embeds, empty_pooled_embeds, timesteps, "cosine", guidance_scale, guidance_schedule, temperature,
+                                num_images_per_prompt, generator, orig_size, crop_coords, aesthetic_score)
+        return self._decode(ids, output_type)
+

@@ -153,6 +153,134 @@ def test_pipeline_text_conditioned_two_prompts_guided(golden_dir):
         m.generate2 = orig
 
 
+class _StubTokenizer:
+    """stands in for a transformers tokenizer: fixed-length ids from the characters of the prompt"""
+    model_max_length = 7
+
+    def __call__(self, text, return_tensors="pt", padding=None, truncation=None, max_length=None):
+        text = [text] if isinstance(text, str) else list(text)
+        ids = torch.tensor([[(sum(map(ord, t)) + 7 * i * (len(t) + 1)) % 50 for i in range(self.model_max_length)] for t in text])
+        return type("Enc", (), {"input_ids": ids})()
+
+
+class _StubTextOut:
+    def __init__(self, hidden_states, text_embeds):
+        self.hidden_states, self.text_embeds, self.last_hidden_state = hidden_states, text_embeds, hidden_states[-1]
+
+    def __getitem__(self, i):            # CLIPTextModelWithProjection output: [0] = text_embeds (reference :184-186 reads outputs[0])
+        return (self.text_embeds, self.last_hidden_state)[i]
+
+
+class _StubTextEncoder(torch.nn.Module):
+    """stands in for CLIPTextModelWithProjection: three "layers" of hidden states and a pooled projection"""
+
+    def __init__(self, width, pooled):
+        super().__init__()
+        torch.manual_seed(5)
+        self.emb, self.proj = torch.nn.Embedding(50, width), torch.nn.Linear(width, pooled)
+
+    def forward(self, input_ids, return_dict=None, output_hidden_states=None):
+        h0 = self.emb(input_ids)
+        h1 = torch.tanh(h0 * 2 + 0.5)
+        h2 = h1 * h1 - 0.25
+        return _StubTextOut((h0, h1, h2), self.proj(h2.mean(dim=1)))
+
+
+def test_pipeline_encodes_text_with_its_own_encoder(golden_dir):
+    """PipelineMuse(text=...) with a text encoder and tokenizer handed to the constructor (the reference's own third-party dependency:
+    here two stubs with the transformers call signatures): the pipeline calls them as the reference does (:107-190) - penultimate hidden
+    state (or `clip_skip`) + `text_embeds`, the negative prompt on the penultimate layer, the empty prompt's states when there is no
+    negative prompt - and produces the images the pre-computed-states entry produces from the same tensors; without an encoder the
+    refusal is loud"""
+    import muse
+    gp = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    u = muse.MaskGiTUViT(**cfg)
+    u.load_state_dict({k[len("param."):]: torch.from_numpy(gp[k]) for k in gp.files if k.startswith("param.")}, strict=True)
+    v = muse.MaskGitVQGAN(**W.VQGAN_TINY)
+    tok, enc = _StubTokenizer(), _StubTextEncoder(cfg["encoder_hidden_size"], cfg["cond_embed_dim"])
+    pipe = muse.PipelineMuse(vae=v, transformer=u, text_encoder=enc, tokenizer=tok).to(DEV)
+    u.eval()
+    prompts = ["a red fox", "two cats"]
+    gen = lambda: torch.Generator(device=DEV).manual_seed(21)   # noqa: E731
+    kw = dict(timesteps=3, guidance_scale=2.0, num_images_per_prompt=2, output_type="np", transformer_seq_len=16)
+    with torch.no_grad():
+        o = enc(tok(prompts).input_ids.to(DEV))
+        on = enc(tok([""] * 2).input_ids.to(DEV))
+        oe = enc(tok("").input_ids.to(DEV))
+    # (1) default negative_text "" -> the negative prompt's penultimate states and pooled embedding
+    a = pipe(text=prompts, generator=gen(), **kw)
+    b = pipe(prompt_embeds=o.hidden_states[-2], pooled_embeds=o.text_embeds, negative_prompt_embeds=on.hidden_states[-2],
+             negative_pooled_embeds=on.text_embeds, generator=gen(), **kw)
+    assert a.shape == (4, 16, 16, 3) and np.array_equal(a, b)
+    # (2) no negative prompt -> the empty prompt's states; clip_skip picks the layer
+    a = pipe(text=prompts, negative_text=None, clip_skip=2, generator=gen(), **kw)
+    b = pipe(prompt_embeds=o.hidden_states[-3], pooled_embeds=o.text_embeds, empty_embeds=oe.hidden_states[-2], empty_pooled_embeds=oe.text_embeds,
+             generator=gen(), **kw)
+    c = pipe(prompt_embeds=o.hidden_states[-2], pooled_embeds=o.text_embeds, empty_embeds=oe.hidden_states[-2], empty_pooled_embeds=oe.text_embeds,
+             generator=gen(), **kw)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    with pytest.raises(NotImplementedError):
+        muse.PipelineMuse(vae=v, transformer=u).to(DEV)(text="a red fox")
+
+
+def test_inpainting_pipeline_repaints_only_the_masked_tokens(golden_dir):
+    """muse.PipelineMuseInpainting (reference :372-510): the picture is tokenised by vae.encode, the masked positions get the mask token,
+    generate2 fills them - every other token of every returned sample is the picture's own; class-conditional MaskGitTransformer (PIL
+    input through the resize / centre-crop of the reference) and MaskGiTUViT on pre-computed text states (tensor input)"""
+    import muse
+    from PIL import Image
+    from muse.pipeline_muse import _center_square
+    v = muse.MaskGitVQGAN(**W.VQGAN_TINY)
+    torch.manual_seed(2)
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TINY)
+    pipe = muse.PipelineMuseInpainting(vae=v, transformer=m, is_class_conditioned=True).to(DEV)
+    m.eval()
+    rng = np.random.default_rng(0)
+    img = Image.fromarray((rng.random((24, 40, 3)) * 255).astype(np.uint8))
+    px = _center_square(img, 16)
+    assert px.shape == (3, 16, 16) and 0.0 <= float(px.min()) and float(px.max()) <= 1.0
+    mask = torch.zeros(16, dtype=torch.bool)
+    mask[[1, 5, 6, 11]] = True
+    own = v.encode(px[None].to(DEV))[1].reshape(-1)
+    seen = {}
+
+    def spy_on(model):
+        orig = model.generate2
+        def spy(*a, **k):
+            seen["in"] = k["input_ids"].clone()
+            seen["out"] = orig(*a, **k)
+            return seen["out"]
+        model.generate2 = spy
+    spy_on(m)
+    out = pipe(img, mask, class_ids=3, timesteps=4, num_images_per_prompt=3, image_size=16, output_type="np",
+               generator=torch.Generator(device=DEV).manual_seed(4))
+    mask_id = m.config.mask_token_id
+    assert out.shape == (3, 16, 16, 3) and seen["in"].shape == (3, 16)
+    assert bool((seen["in"][:, mask] == mask_id).all()) and bool((seen["in"][:, ~mask] == own[~mask]).all())
+    ids = seen["out"]
+    assert bool((ids[:, ~mask.to(DEV)] == own[~mask.to(DEV)]).all()) and int(ids.min()) >= 0 and int(ids.max()) < W.VQGAN_TINY["num_embeddings"]
+    assert np.array_equal(out, torch.clamp(v.decode_code(ids), 0, 1).permute(0, 2, 3, 1).cpu().numpy())
+    with pytest.raises(ValueError):
+        pipe(img, mask[:9], class_ids=3, image_size=16)
+    # MaskGiTUViT, text states given, [h, w] mask, tensor image
+    gp = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    u = muse.MaskGiTUViT(**cfg)
+    u.load_state_dict({k[len("param."):]: torch.from_numpy(gp[k]) for k in gp.files if k.startswith("param.")}, strict=True)
+    pipe_u = muse.PipelineMuseInpainting(vae=v, transformer=u).to(DEV)
+    u.eval()
+    spy_on(u)
+    g = torch.Generator().manual_seed(9)
+    enc, pooled = torch.randn(2, 7, cfg["encoder_hidden_size"], generator=g), torch.randn(2, cfg["cond_embed_dim"], generator=g)
+    out = pipe_u(px, mask.view(4, 4), prompt_embeds=enc, pooled_embeds=pooled, empty_embeds=torch.zeros(1, 7, cfg["encoder_hidden_size"]),
+                 empty_pooled_embeds=torch.zeros(1, cfg["cond_embed_dim"]), timesteps=3, guidance_scale=1.5, output_type="np",
+                 generator=torch.Generator(device=DEV).manual_seed(4))
+    ids = seen["out"]
+    assert out.shape == (2, 16, 16, 3) and ids.shape == (2, 16) and bool((ids[:, ~mask.to(DEV)] == own[~mask.to(DEV)]).all())
+    assert int(ids.max()) < cfg["codebook_size"]
+
+
 def test_uvit_generate2_vs_reference_golden(golden_dir):
     """MaskGiTUViT_v2.generate2 of the reference with classifier-free guidance 3.0, temperature (2, 0), 5 steps: final ids and the
     per-step raw samples (`intermediate`)"""

@@ -500,3 +500,35 @@ def test_ema_model_save_and_from_pretrained(golden_dir):
         assert all(torch.equal(a, b) for a, b in zip(back.shadow_params, ema.shadow_params))
         assert all(torch.equal(p.detach() * 0.5, s) for p, s in zip(m.parameters(), back.shadow_params))
 
+
+def test_inpainting_pipeline_surface_and_image_preparation():
+    """muse.PipelineMuseInpainting exists with the reference's call signature (:374-395); its image preparation = Resize(shorter side,
+    bilinear) -> CenterCrop -> ToTensor of the reference (:399-405) restated on PIL alone (no torchvision in this image)"""
+    import inspect
+    import muse
+    from PIL import Image
+    from muse.pipeline_muse import _center_square
+    assert issubclass(muse.PipelineMuseInpainting, muse.PipelineMuse)
+    names = list(inspect.signature(muse.PipelineMuseInpainting.__call__).parameters)
+    assert names[:21] == ["self", "image", "mask", "text", "negative_text", "class_ids", "timesteps", "guidance_scale", "guidance_schedule",
+                          "temperature", "topk_filter_thres", "num_images_per_prompt", "use_maskgit_generate", "generator", "use_fp16",
+                          "image_size", "orig_size", "crop_coords", "aesthetic_score", "prompt_embeds", "pooled_embeds"]
+    d = inspect.signature(muse.PipelineMuseInpainting.__call__).parameters
+    assert d["timesteps"].default == 8 and d["guidance_scale"].default == 8.0 and d["image_size"].default == 256 and d["temperature"].default == 1.0
+    # a 64 x 32 picture whose left half is black and right half white, to 16 x 16: shorter side 32 -> 16 (so 32 x 16), centre 16 columns
+    arr = np.zeros((32, 64, 3), np.uint8)
+    arr[:, 32:] = 255
+    t = _center_square(Image.fromarray(arr), 16)
+    assert t.shape == (3, 16, 16) and t.dtype == torch.float32
+    assert float(t[:, :, :7].max()) == 0.0 and float(t[:, :, 9:].min()) == 1.0              # the edge sits in the middle of the crop
+    # already square at the target size: untouched, exactly uint8 / 255
+    rng = np.random.default_rng(1)
+    a = (rng.random((16, 16, 3)) * 255).astype(np.uint8)
+    assert torch.equal(_center_square(Image.fromarray(a), 16), torch.from_numpy(a).permute(2, 0, 1).float() / 255.0)
+    # tall picture: the crop is vertical
+    tall = np.zeros((48, 16, 3), np.uint8)
+    tall[16:32] = 200
+    assert float(_center_square(Image.fromarray(tall), 16).min()) == float(torch.tensor(200.0) / 255.0)
+    with pytest.raises(NotImplementedError):
+        muse.PipelineMuse(vae=None, transformer=None)._encode_text("a", None)                  # no text encoder: loud
+
