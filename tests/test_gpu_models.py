@@ -652,6 +652,41 @@ def test_taming_vqgan_f16_8192_vs_oracle():
         assert ez < ztol and er < rtol and len(mism) <= 2, (mode, ez, er, len(mism))
 
 
+def test_taming_vqgan_f16_8192_at_512_pixels_vs_oracle():
+    """the same tokenizer on a 512 x 512 picture (configs/research_run_512*.yaml: 32 x 32 = 1024 tokens, pixel attention over 1024
+    positions of 512 channels in the mid blocks and the last level) against oracle/taming_oracle.py: latents, token indices (any
+    mismatch must be an f32 near-tie of the oracle's own distances), reconstruction; bf16x3, the mode pre-encoding runs in"""
+    import muse
+    from oracle import taming_oracle as T
+    # (the checkpoint's own config: resolution 256, attention where the CONFIGURED resolution reaches 16 - the last level - whatever
+    #  the picture's size, muse/modeling_taming_vqgan.py:232-241; the 512-pixel runs feed it 512 x 512 pictures)
+    cfg = dict(resolution=256, num_channels=3, hidden_channels=128, channel_mult=(1, 1, 2, 2, 4), num_res_blocks=2,
+               attn_resolutions=(16,), no_attn_mid_block=False, z_channels=256, num_embeddings=8192, quantized_embed_dim=256,
+               resample_with_conv=True)
+    sd = W.fill_state_dict(W.taming_shapes(cfg), 640, "vqgan")
+    px = W.images(1, 512, 641)
+    torch.set_num_threads(min(32, os.cpu_count()))
+    with torch.no_grad():
+        z, zq, idx = T.encode(sd, cfg, px)
+        rec = T.decode_code(sd, cfg, idx)
+        dist = T.vq_distances(z.permute(0, 2, 3, 1).reshape(-1, 256), sd["quantize.embedding.weight"]).view(1, 1024, -1)
+    assert tuple(idx.shape) == (1, 1024)
+    v = muse.VQGANModel(**cfg)
+    v.load_state_dict(sd)
+    v.to(DEV).eval().set_compute_dtype("bf16x3")
+    z_hip, _ = v._encode_nhwc(px.to(DEV))
+    ez = maxrel(z_hip.view(1, 32, 32, 256).permute(0, 3, 1, 2), z)
+    idx_hip = v.get_code(px.to(DEV)).cpu()
+    mism = (idx_hip != idx).nonzero().tolist()
+    for b, t in mism:
+        d = dist[b, t]
+        assert abs(float(d[idx_hip[b, t]]) - float(d[idx[b, t]])) < 1e-4 * abs(float(d[idx[b, t]])), (b, t)
+    out = v.decode_code(idx.to(DEV))
+    er = maxrel(out, rec)
+    print(f"taming f16-8192 at 512 x 512, bf16x3: z {ez:.1e}, index mismatches {len(mism)} / 1024, rec {er:.1e}")
+    assert tuple(out.shape) == (1, 3, 512, 512) and ez < 2e-4 and er < 3e-4 and len(mism) <= 2, (ez, er, len(mism))
+
+
 def test_train_step_end_to_end_vs_oracle():
     """encode -> mask -> fwd/bwd -> AdamW with the tiny configs vs oracle.train_step + oracle.adamw_step (f32)."""
     import muse
