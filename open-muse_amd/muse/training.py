@@ -543,6 +543,8 @@ class GradReducer:
         self._stream = None
         self.post_reduce = None   # callable(lo, hi): runs on the reduction stream right after bucket [lo, hi) has been averaged
         self.stats = {"buckets": 0, "bytes": 0}
+        self._sync = True         # False inside no_sync(): gradient accumulation, no collective
+        self._deferred = False    # tape engines: this backward adds to existing gradients -> the SUM is reduced in finish()
         # Models with a flat gradient buffer (MaskGitTransformer) report finished ranges during backward.  Models whose
         # parameters are ordinary tensors (MaskGiTUViT: one autograd node hands every gradient back at once) are reduced in
         # finish(): gradients packed, in reverse parameter order, into the same large buckets.
@@ -574,6 +576,29 @@ class GradReducer:
                 if hasattr(model, "mark_weights_changed"):
                     model.mark_weights_changed()
 
+    def no_sync(self):
+        """Gradient accumulation: backward inside this context keeps the gradients local (no collective, no per-bucket callback), like
+        `DistributedDataParallel.no_sync()` - what `accelerator.accumulate(model)` enters on all but the last micro-batch of
+        `gradient_accumulation_steps` (training/train_muse.py:734; 2 in ten of the reference's configurations, cc12m_uvit_clip.yaml among
+        them).  The first synchronising backward after it averages the ACCUMULATED gradients: the flat buffer already holds the sum when
+        its ranges are reported; the tape engines hand over only that micro-batch's gradients, so their in-backward buckets are skipped
+        for this step and finish() reduces the `.grad` tensors autograd has summed into.
+
+            for i, batch in enumerate(micro_batches):
+                with (reducer.no_sync() if i + 1 < len(micro_batches) else contextlib.nullcontext()):
+                    loss(batch).backward()
+            reducer.finish(); optimizer.step(); optimizer.zero_grad(set_to_none=True)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._sync = self._sync, False
+            try:
+                yield self
+            finally:
+                self._sync = prev
+        return ctx()
+
     def _buckets(self, tensors):
         """consecutive tensors grouped into buckets of >= bucket_elems elements (the last one may be smaller)"""
         out, cur, n = [], [], 0
@@ -592,6 +617,12 @@ class GradReducer:
         (and its weight-gradient stream `side_stream`).  They are collected into buckets of >= bucket_elems elements; a full bucket is
         packed, all-reduced and unpacked IN PLACE on the communication stream, behind both compute streams.  `final`: flush the
         rest and make the compute stream wait for every bucket - autograd receives averaged gradients."""
+        if not self._sync:
+            return                                   # no_sync(): this micro-batch's gradients stay local (autograd accumulates them)
+        if not self._pending and not self._deferred and any(p.grad is not None for p in self._params):
+            self._deferred = True                    # gradients of earlier micro-batches exist: reduce the sums after backward (finish)
+        if self._deferred:
+            return
         for t in tensors:
             self._pending.append(t)
             self._pending_n += t.numel()
@@ -641,6 +672,9 @@ class GradReducer:
         self._live = True
 
     def _finish_tensor_list(self):
+        self._deferred = False
+        if not self._sync:
+            return
         if self._in_backward_done:           # every gradient was reduced from inside backward (_on_tensors)
             self._in_backward_done = False
             return
@@ -717,6 +751,8 @@ class GradReducer:
 
     def _on_ready(self, begin: int, end: int):
         """backward reports finished [begin, end) ranges of the flat grad buffer, from the end of the buffer downward"""
+        if not self._sync:
+            return                                   # no_sync(): the buffer keeps accumulating, nothing is sent
         if self._hi is None:
             self._hi, self._lo = end, begin
         elif end == self._lo:
@@ -732,6 +768,8 @@ class GradReducer:
         """flush the last bucket and make the compute stream wait for every outstanding all-reduce"""
         if not self._flat_mode:
             return self._finish_tensor_list()
+        if not self._sync:
+            return
         if self._hi is not None:
             self._launch(self._lo, self._hi)
             self._hi = self._lo = None

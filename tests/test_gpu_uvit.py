@@ -377,6 +377,78 @@ def test_uvit_gradient_buckets_reduced_inside_backward_on_rccl(golden_dir, cd):
         dist.destroy_process_group()
 
 
+def test_gradient_accumulation_under_the_reducer_on_rccl(golden_dir):
+    """gradient_accumulation_steps = 2 (cc12m_uvit_clip.yaml and nine more configurations; accelerate's accumulate() = DDP.no_sync on the
+    first micro-batch) on an RCCL group of one rank: muse.GradReducer.no_sync() keeps the first micro-batch local, the second backward's
+    gradients are summed into .grad by autograd and finish() averages the SUM.  U-ViT (tape engine) and the class-conditional
+    MaskGitTransformer (flat buffer, ranges reduced from inside the second backward): gradients and the AdamW-updated parameters equal
+    the run without a reducer, bit for bit"""
+    import contextlib
+    import torch.distributed as dist
+    import weights as W
+    import muse
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29810 + os.getpid() % 150)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    g, cfg, sd = _load_golden(golden_dir)
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    labels2 = torch.where(labels >= 0, (labels + 3) % cfg["codebook_size"], labels)
+
+    def run_uvit(with_reducer):
+        model = muse.MaskGiTUViT(**cfg)
+        model.load_state_dict(sd, strict=True)
+        model.to(DEV).train().set_compute_dtype(torch.bfloat16)
+        opt = muse.FusedAdamW(muse.grouped_parameters(model, 0.01), lr=1e-3)
+        red = muse.GradReducer(model, bucket_bytes=16 * 1024) if with_reducer else None
+        for i, lab in enumerate((labels, labels2)):
+            with (red.no_sync() if red is not None and i == 0 else contextlib.nullcontext()):
+                _, loss = model(*args, labels=lab)
+                (loss / 2).backward()
+            if red is not None and i == 0:
+                assert red.stats["buckets"] == 0
+        if red is not None:
+            red.finish()
+            assert red.stats["buckets"] >= 3 and red.stats["bytes"] == 4 * sum(p.numel() for p in model.parameters())
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        opt.step()
+        torch.cuda.synchronize()
+        return grads, {k: p.detach().clone() for k, p in model.named_parameters()}
+
+    def run_flat(with_reducer):
+        tcfg = dict(W.TRANSFORMER_TINY)
+        m = muse.MaskGitTransformer(**tcfg)
+        m.load_state_dict(W.fill_state_dict(W.transformer_shapes(tcfg), 701, "transformer"))
+        m.to(DEV).train().set_compute_dtype(torch.bfloat16)
+        opt = muse.FusedAdamW(m.parameters(), lr=1e-3)
+        red = muse.GradReducer(m, bucket_bytes=16 * 1024) if with_reducer else None
+        batches = [W.transformer_inputs(tcfg, 3, 41), W.transformer_inputs(tcfg, 3, 42)]
+        for i, (ids, lab) in enumerate(batches):
+            with (red.no_sync() if red is not None and i == 0 else contextlib.nullcontext()):
+                _, loss = m(input_ids=ids.to(DEV), labels=lab.to(DEV))
+                (loss / 2).backward()
+            if red is not None and i == 0:
+                assert red.stats["buckets"] == 0
+        if red is not None:
+            red.finish()
+            assert red.stats["buckets"] >= 2 and red.stats["bytes"] == 4 * m.flat_grads().numel()
+        grads = m.flat_grads().clone()
+        opt.step()
+        torch.cuda.synchronize()
+        return grads, m.flat_params().clone()
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        (g0, p0), (g1, p1) = run_uvit(False), run_uvit(True)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]) and torch.equal(p0[k], p1[k]), k
+        (f0, q0), (f1, q1) = run_flat(False), run_flat(True)
+        assert torch.equal(f0, f1) and torch.equal(q0, q1)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("name", ["uvit_tiny_noaffine", "uvit_tiny_layernorm", "uvit_tiny_downup"])
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
 def test_uvit_norm_variants_vs_reference_golden(golden_dir, cd, name):

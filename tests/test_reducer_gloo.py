@@ -296,3 +296,95 @@ def test_grad_reducer_buckets_from_inside_backward_world2(tmp_path):
             assert torch.equal(a, b) and torch.allclose(a, expect), (step, j)
     for a, b in zip(r0["res"][0][0], r0["res"]["post"]):
         assert torch.allclose(a, b)
+
+
+def _worker_accumulate(rank, world, port, out):
+    """gradient accumulation (GradReducer.no_sync, accelerate's accumulate() / DDP.no_sync): the micro-batches inside the context send
+    nothing; the synchronising backward averages the ACCUMULATED gradients - flat-buffer model and tape-engine-like model"""
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import muse
+    import weights as W
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)
+    res = {}
+    # ---- flat buffer: replay backward's range reports around two micro-batches
+    m = muse.MaskGitTransformer(**W.TRANSFORMER_TINY)
+    red = muse.GradReducer(m, bucket_bytes=16 * 1024)
+    g = m.flat_grads()
+    n = g.numel()
+    off, L = m._offsets, m.num_hidden_layers
+    t0 = 2 + L * 11
+
+    def report():
+        m.grad_ready_hook(off[t0], n)
+        for li in reversed(range(L)):
+            m.grad_ready_hook(off[2 + li * 11], off[2 + li * 11 + 11])
+        m.grad_ready_hook(off[0], off[2])
+    seen = []
+    red.post_reduce = lambda lo, hi: seen.append((lo, hi))
+    a = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    b = torch.cos(torch.arange(n, dtype=torch.float32)) * (3 - rank)
+    g.copy_(a)
+    with red.no_sync():
+        report()
+        red.finish()
+    res["flat_local_after_no_sync"] = bool(torch.equal(g, a)) and not seen and red.stats["buckets"] == 0
+    g.add_(b)                                              # the second micro-batch accumulates into the buffer
+    report()
+    red.finish()
+    res["flat"] = g.clone()
+    res["flat_covered"] = sum(hi - lo for lo, hi in seen) == n
+    # ---- tape engine: only the micro-batch's own gradients are reported, autograd sums them into .grad
+    mt = _TapeLike()
+    redt = muse.GradReducer(mt, bucket_bytes=4 * 60)
+    launched = []
+    inner = redt._reduce_list
+    redt._reduce_list = lambda bucket, side=None: (launched.append(sum(t.numel() for t in bucket)), inner(bucket, side))
+    x1, x2 = torch.full((3, 6), float(rank + 1)), torch.full((3, 6), 0.5 * (rank + 2))
+    mt.zero_grad(set_to_none=True)
+    with redt.no_sync():
+        mt(x1).backward()
+        redt.finish()
+    local = [p.grad.clone() for p in mt.parameters()]
+    mt(x2).backward()
+    in_backward = len(launched)
+    redt.finish()
+    res["tape"] = [p.grad.clone() for p in mt.parameters()]
+    res["tape_local"] = local
+    res["tape_in_backward_buckets"] = in_backward
+    res["tape_bytes"] = redt.stats["bytes"]
+    # the next ordinary step goes back to buckets from inside backward
+    mt.zero_grad(set_to_none=True)
+    launched.clear()
+    mt(x1).backward()
+    res["tape_next_in_backward"] = len(launched)
+    redt.finish()
+    res["tape_next"] = [p.grad.clone() for p in mt.parameters()]
+    torch.save(res, os.path.join(out, f"acc{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_no_sync_accumulation_world2(tmp_path):
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_worker_accumulate, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"acc{k}.pt") for k in range(world)]
+    n = r[0]["flat"].numel()
+    ar = torch.arange(n, dtype=torch.float32)
+    want = (ar * 1 + torch.cos(ar) * 3 + ar * 2 + torch.cos(ar) * 2) / 2          # mean over the ranks of (a_r + b_r)
+    for k in range(world):
+        assert r[k]["flat_local_after_no_sync"] and r[k]["flat_covered"]
+        assert torch.allclose(r[k]["flat"], want, rtol=1e-6, atol=1e-6)
+        assert r[k]["tape_in_backward_buckets"] == 0 and r[k]["tape_next_in_backward"] >= 3      # deferred once, then buckets again
+        assert r[k]["tape_bytes"] == 4 * sum(t.numel() for t in r[k]["tape"])                  # every element sent exactly once
+    # _TapeLike's gradient for input x on parameter j: x.sum() + arange * (j + 1); x1 = rank + 1, x2 = (rank + 2) / 2, 18 elements each
+    for j, (g0, g1) in enumerate(zip(r[0]["tape"], r[1]["tape"])):
+        ramp = torch.arange(g0.numel(), dtype=torch.float32).view_as(g0) * (j + 1)
+        per_rank = [18.0 * (k + 1) + 9.0 * (k + 2) for k in range(world)]
+        assert torch.equal(g0, g1) and torch.allclose(g0, torch.full_like(g0, sum(per_rank) / world) + 2 * ramp)
+        assert torch.allclose(r[0]["tape_local"][j], torch.full_like(g0, 18.0) + ramp)           # rank 0 after the no_sync micro-batch: its own
+        assert torch.allclose(r[0]["tape_next"][j], torch.full_like(g0, 27.0) + ramp)
+
