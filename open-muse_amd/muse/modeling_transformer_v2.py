@@ -234,6 +234,9 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         if c.hidden_dropout != 0.0 or c.attention_dropout != 0.0:
             raise NotImplementedError("dropout > 0 is outside the MI355X hot-path build")
         H, C, cin = c.hidden_size, c.block_out_channels[0], c.in_channels
+        for width, heads in ((C, c.block_num_heads), (H, c.num_attention_heads)):     # Attention.__init__ of the reference (:842-847), same text:
+            if width % heads != 0:                                                     # configs/cc12m_uvit_clip.yaml as shipped (1024 channels, 12 heads)
+                raise ValueError(f"self.hidden_size: {width} must be divisible by self.num_heads: {heads}")     # trips it
         self.output_size = c.codebook_size
         self.encoder_proj = _Lin(c.encoder_hidden_size, H)
         self.encoder_proj_layer_norm = _NormW(H)

@@ -441,6 +441,47 @@ def golden_ema(name, seed, steps=14):
     print(name, "decays", [round(float(out[f"s0.decay{t}"]), 4) for t in range(1, steps + 1)])
 
 
+def reference_configs(path="/root/reference/configs"):
+    """the `model.transformer` section (+ the few dataset / training keys the loop reads) of every configs/*.yaml whose section the
+    reference's own classes can construct - 16 of 25: a multi-entry block_out_channels trips MaskGiTUViT_v2's assert (:166), and
+    use_conv_in_out without embedding_size trips nn.Embedding(vocab, None) - written to tests/golden/reference_configs.json for
+    tests/test_gpu_reference_configs.py (the yaml files do not travel to the GPU box)"""
+    import glob
+    import json
+    import yaml
+    out = {}
+    for f in sorted(glob.glob(os.path.join(path, "*.yaml"))):
+        try:
+            c = yaml.safe_load(open(f))
+            m = c.get("model", {})
+        except Exception:      # noqa: BLE001  (three files are data-shard lists, not OmegaConf trees)
+            continue
+        t = m.get("transformer")
+        if t is None:
+            continue
+        bo = t.get("block_out_channels")
+        if (isinstance(bo, (list, tuple)) and len(bo) != 1) or t.get("use_conv_in_out"):
+            continue
+        cls = ref_muse.MaskGiTUViT if m.get("architecture", "transformer") == "uvit" else ref_muse.MaskGitTransformer
+        try:
+            with torch.device("meta"):
+                cls(**t)                                   # the reference really constructs it ...
+            err = None
+        except Exception as e:                             # noqa: BLE001  ... or says why not (block_num_heads 12 on 1024 channels: SURVEY.md D3)
+            err = f"{type(e).__name__}: {e}"
+        pre = c.get("dataset", {}).get("preprocessing", {})
+        out[os.path.basename(f)] = dict(
+            reference_error=err,
+            architecture=m.get("architecture", "transformer"), transformer=t, resolution=pre.get("resolution"),
+            max_seq_length=pre.get("max_seq_length"), text_encoder=m.get("text_encoder", {}).get("type"), vq=m.get("vq_model", {}).get("type"),
+            training={k: c.get("training", {}).get(k) for k in ("gradient_accumulation_steps", "batch_size", "mixed_precision", "use_ema",
+                                                                "min_masking_rate", "label_smoothing", "cond_dropout_prob",
+                                                                "predict_all_tokens", "noise_type")})
+    with open(os.path.join(HERE, "reference_configs.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("reference_configs", len(out), "configurations")
+
+
 def replay_decode_noise(seed, steps, rows, seq, vocab):
     """the draws a reference generate2 call makes from torch.Generator().manual_seed(seed), per step: torch.multinomial(probs
     [rows*seq, vocab], 1) fills an Exp(1) tensor of the probabilities' shape (ATen multinomial_out, one-sample fast path), then
@@ -641,6 +682,7 @@ if __name__ == "__main__":
                           guidance_scale=3.0)
     golden_mask_muse("mask_muse", seed=540)
     golden_ema("ema_tiny", seed=560)
+    reference_configs()
     golden_transformer_autocast("transformer_tiny_bf16", W.TRANSFORMER_TINY, batch=3, seed=100)
     golden_transformer_autocast("transformer_hd48_bf16", W.TRANSFORMER_HD48, batch=2, seed=120)
     golden_transformer_text("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY, batch=3, text_len=7, seed=800)

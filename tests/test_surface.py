@@ -532,3 +532,27 @@ def test_inpainting_pipeline_surface_and_image_preparation():
     with pytest.raises(NotImplementedError):
         muse.PipelineMuse(vae=None, transformer=None)._encode_text("a", None)                  # no text encoder: loud
 
+
+def test_every_reference_configuration_constructs_or_fails_like_the_reference(golden_dir):
+    """tests/golden/reference_configs.json: the `model.transformer` section of every configs/*.yaml the reference's classes can be asked
+    to build, with what the REAL class answered (make_golden.py::reference_configs).  Ours answers the same: builds where it builds
+    (same parameter count as the state-dict template implies), raises the same ValueError text where it does not (1024 channels on 12
+    block heads) and builds with the D3 override BASELINE.json's config 4 uses"""
+    import json
+    import muse
+    cfgs = json.load(open(os.path.join(golden_dir, "reference_configs.json")))
+    assert len(cfgs) == 16 and sum(v["reference_error"] is None for v in cfgs.values()) == 8
+    for name, entry in cfgs.items():
+        cls = muse.MaskGiTUViT if entry["architecture"] == "uvit" else muse.MaskGitTransformer
+        t = dict(entry["transformer"])
+        with torch.device("meta"):
+            if entry["reference_error"] is None:
+                m = cls(**t)
+            else:
+                with pytest.raises(ValueError) as e:
+                    cls(**t)
+                assert entry["reference_error"] == f"ValueError: {e.value}", name
+                m = cls(**dict(t, block_num_heads=16))
+        assert sum(p.numel() for p in m.parameters()) > 1e8, name
+        assert m.config.mask_token_id == t["vocab_size"] - 1
+
