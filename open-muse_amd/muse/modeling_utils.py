@@ -57,8 +57,15 @@ class ConfigMixin:
                 setattr(self, k, v)  # reference :834-839 — config keys are also attributes of the module
             except AttributeError:
                 pass
-        merged = {**dict(getattr(self, "_internal_dict", {})), **kwargs}
+        old = getattr(self, "_internal_dict", None)
+        merged = {**dict(old or {}), **kwargs}
         self._internal_dict = FrozenDict(merged)
+        # derived values a constructor hung on the config as plain attributes (the VQGANs' num_resolutions / latent_size, reference
+        # modeling_maskgit_vqgan.py:370-372) survive a later registration (from_pretrained adds `_name_or_path`): the reference's
+        # submodules keep reading them from the old object, ours read the model's current one
+        for k, v in (vars(old).items() if old is not None else ()):
+            if k not in merged and not k.startswith("_"):
+                object.__setattr__(self._internal_dict, k, v)
 
     @property
     def config(self) -> FrozenDict:

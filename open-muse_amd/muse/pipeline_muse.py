@@ -174,31 +174,56 @@ class PipelineMuse:
         return [Image.fromarray((255 * im).astype(np.uint8)).convert("RGB") for im in images]   # reference to_pil_image :245-252
 
     def save_pretrained(self, save_directory: Union[str, os.PathLike], push_to_hub: bool = False):
+        """reference :357-369: text encoder + tokenizer under `text_encoder/` (when the pipeline has them), `vae/`, `transformer/`"""
+        if not self.is_class_conditioned and self.text_encoder is not None and self.tokenizer is not None:
+            self.text_encoder.save_pretrained(os.path.join(save_directory, "text_encoder"))
+            self.tokenizer.save_pretrained(os.path.join(save_directory, "text_encoder"))
         self.vae.save_pretrained(os.path.join(save_directory, "vae"))
         self.transformer.save_pretrained(os.path.join(save_directory, "transformer"))
 
     @classmethod
     def from_pretrained(cls, model_name_or_path: str = None, text_encoder_path: Optional[str] = None,
-                        vae_path: Optional[str] = None, transformer_path: Optional[str] = None,
-                        is_class_conditioned: bool = False, **kwargs):
+                        vae_path: Optional[str] = None, transformer_path: Optional[str] = None, vae=None, text_encoder=None,
+                        transformer=None, is_class_conditioned: bool = False, **kwargs):
+        """reference :254-355, same arguments.  The text encoder and tokenizer of a text-conditioned pipeline are the reference's own
+        `transformers` classes, loaded the way the reference loads them (`CLIPTextModelWithProjection`, `AutoTokenizer`) - from
+        `<model>/text_encoder` or `text_encoder_path`; a LOCAL checkpoint directory without a `text_encoder/` folder gives a pipeline
+        that takes pre-computed text states instead (this build's addition)."""
         def load_transformer(path, **kw):   # the class named in the checkpoint's config.json (reference :300-318)
             from .modeling_transformer_v2 import MaskGiTUViT_v2
             cfg = MaskGitTransformer.load_config(path, **kw)
             klass = MaskGiTUViT_v2 if str(cfg.get("_class_name", "")).startswith("MaskGiTUViT") else MaskGitTransformer
             return klass.from_pretrained(path, **kw)
+
         def load_vae(path, **kw):           # likewise for the tokenizer (reference :320-329; MoVQ / Paella are not part of this build)
             from .modeling_taming_vqgan import VQGANModel
             name = str(MaskGitVQGAN.load_config(path, **kw).get("_class_name", "MaskGitVQGAN"))
             if name not in ("MaskGitVQGAN", "VQGANModel"):
                 raise ValueError(f"Unknown VAE class: {name}")
             return (VQGANModel if name == "VQGANModel" else MaskGitVQGAN).from_pretrained(path, **kw)
+
+        if model_name_or_path is None and (vae_path is None or transformer_path is None or
+                                           (text_encoder_path is None and not is_class_conditioned and text_encoder is None)):
+            raise ValueError("If model_name_or_path is None, then text_encoder_path, vae_path, and transformer_path must be provided.")
+        sub = {} if model_name_or_path is None else {"subfolder": "text_encoder"}
+        te_path = text_encoder_path if model_name_or_path is None else model_name_or_path
+        tokenizer = None
+        if not is_class_conditioned and te_path is not None:
+            local_without = os.path.isdir(str(te_path)) and not os.path.isdir(os.path.join(str(te_path), sub.get("subfolder", "")))
+            if not local_without:
+                from transformers import AutoTokenizer, CLIPTextModelWithProjection
+                if text_encoder is None:
+                    text_encoder = CLIPTextModelWithProjection.from_pretrained(te_path, **sub)
+                tokenizer = AutoTokenizer.from_pretrained(te_path, **sub)
         if model_name_or_path is not None:
-            vae = load_vae(model_name_or_path, subfolder="vae")
-            transformer = load_transformer(model_name_or_path, subfolder="transformer")
+            vae = vae if vae is not None else load_vae(model_name_or_path, subfolder="vae")
+            transformer = transformer if transformer is not None else load_transformer(model_name_or_path, subfolder="transformer")
         else:
-            vae = load_vae(vae_path)
-            transformer = load_transformer(transformer_path)
-        return cls(vae=vae, transformer=transformer, is_class_conditioned=is_class_conditioned)
+            vae = vae if vae is not None else load_vae(vae_path)
+            transformer = transformer if transformer is not None else load_transformer(transformer_path)
+        if is_class_conditioned:
+            return cls(vae=vae, transformer=transformer, is_class_conditioned=True)
+        return cls(vae=vae, transformer=transformer, text_encoder=text_encoder, tokenizer=tokenizer, is_class_conditioned=False)
 
 
 def _center_square(image, size):

@@ -425,3 +425,39 @@ def ema_params(seed, step):
     """the tracked tensors at a training step: seeded, so the tests regenerate them instead of storing them"""
     g = torch.Generator().manual_seed(seed * 1000 + step)
     return [torch.randn(sh, generator=g) * (1.0 + 0.1 * i) for i, sh in enumerate(EMA_SHAPES)]
+
+
+# ---- a real (tiny) CLIP text tower and tokenizer, built offline: what PipelineMuse loads as `text_encoder` / `tokenizer` -----------------
+def tiny_clip(workdir, hidden=24, pooled=16, max_len=7, seed=5):
+    """(transformers.CLIPTextModelWithProjection, transformers.CLIPTokenizer): character-level byte-BPE vocabulary without merges
+    (514 entries), 3 layers; `hidden` = the U-ViT's encoder_hidden_size, `pooled` = its cond_embed_dim"""
+    import json
+    import os
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection, CLIPTokenizer
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    chars = [chr(c) for c in cs]
+    vocab = {}
+    for c in chars:
+        vocab[c] = len(vocab)
+    for c in chars:
+        vocab[c + "</w>"] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    os.makedirs(workdir, exist_ok=True)
+    with open(os.path.join(workdir, "vocab.json"), "w") as f:
+        json.dump(vocab, f)
+    with open(os.path.join(workdir, "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n")
+    tok = CLIPTokenizer(os.path.join(workdir, "vocab.json"), os.path.join(workdir, "merges.txt"), model_max_length=max_len)
+    torch.manual_seed(seed)
+    cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=3, num_attention_heads=2,
+                         max_position_embeddings=max_len, projection_dim=pooled, bos_token_id=len(vocab) - 2, eos_token_id=len(vocab) - 1,
+                         pad_token_id=len(vocab) - 1)
+    return CLIPTextModelWithProjection(cfg).eval(), tok
+

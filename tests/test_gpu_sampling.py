@@ -224,6 +224,37 @@ def test_pipeline_encodes_text_with_its_own_encoder(golden_dir):
         muse.PipelineMuse(vae=v, transformer=u).to(DEV)(text="a red fox")
 
 
+def test_pipeline_from_pretrained_text_to_image_with_a_real_clip_tower(golden_dir, tmp_path):
+    """the text-to-image entry of the reference end to end: a checkpoint directory laid out as PipelineMuse.save_pretrained writes it
+    (text_encoder/ = a real transformers CLIPTextModelWithProjection + CLIPTokenizer, tiny and built offline; vae/; transformer/),
+    PipelineMuse.from_pretrained(dir).to("cuda"), pipe("a red fox").  The images equal what the pre-computed-states entry gives for
+    the states computed here from the same tower (penultimate layer + text_embeds, negative prompt "", :107-190); bf16 transformer"""
+    import muse
+    gp = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    u = muse.MaskGiTUViT(**cfg)
+    u.load_state_dict({k[len("param."):]: torch.from_numpy(gp[k]) for k in gp.files if k.startswith("param.")}, strict=True)
+    enc, tok = W.tiny_clip(str(tmp_path / "clip_src"), hidden=cfg["encoder_hidden_size"], pooled=cfg["cond_embed_dim"])
+    muse.PipelineMuse(vae=muse.MaskGitVQGAN(**W.VQGAN_TINY), transformer=u, text_encoder=enc, tokenizer=tok).save_pretrained(str(tmp_path / "ckpt"))
+    pipe = muse.PipelineMuse.from_pretrained(str(tmp_path / "ckpt")).to(DEV, dtype=torch.float32)
+    assert type(pipe.text_encoder).__name__ == "CLIPTextModelWithProjection" and next(pipe.text_encoder.parameters()).is_cuda
+    prompts = ["a red fox", "two cats on a sofa"]
+    gen = lambda: torch.Generator(device=DEV).manual_seed(5)   # noqa: E731
+    kw = dict(timesteps=3, guidance_scale=1.5, output_type="np", transformer_seq_len=16)
+    imgs = pipe(prompts, generator=gen(), **kw)
+    assert imgs.shape == (2, 16, 16, 3) and np.isfinite(imgs).all()
+
+    def states(texts):
+        ids = pipe.tokenizer(texts, return_tensors="pt", padding="max_length", truncation=True, max_length=pipe.tokenizer.model_max_length).input_ids
+        with torch.no_grad():
+            o = pipe.text_encoder(ids.to(DEV), return_dict=True, output_hidden_states=True)
+        return o.hidden_states[-2].float(), o.text_embeds.float()
+    (h, pooled), (nh, npooled) = states(prompts), states(["", ""])
+    want = pipe(prompt_embeds=h, pooled_embeds=pooled, negative_prompt_embeds=nh, negative_pooled_embeds=npooled, generator=gen(), **kw)
+    assert np.array_equal(imgs, want)
+    assert not np.array_equal(imgs, pipe(["a blue whale", "two cats on a sofa"], generator=gen(), **kw))       # the prompt matters
+
+
 def test_inpainting_pipeline_repaints_only_the_masked_tokens(golden_dir):
     """muse.PipelineMuseInpainting (reference :372-510): the picture is tokenised by vae.encode, the masked positions get the mask token,
     generate2 fills them - every other token of every returned sample is the picture's own; class-conditional MaskGitTransformer (PIL

@@ -556,3 +556,61 @@ def test_every_reference_configuration_constructs_or_fails_like_the_reference(go
         assert sum(p.numel() for p in m.parameters()) > 1e8, name
         assert m.config.mask_token_id == t["vocab_size"] - 1
 
+
+def test_pipeline_save_and_from_pretrained_with_a_text_encoder(golden_dir, tmp_path):
+    """PipelineMuse.save_pretrained / from_pretrained as the reference lays a text-to-image pipeline out (:254-369): `text_encoder/`
+    (a real, tiny transformers CLIPTextModelWithProjection + CLIPTokenizer built offline), `vae/`, `transformer/`; the classes are
+    picked from the checkpoints' config.json; a local checkpoint without `text_encoder/` loads as a pipeline for pre-computed text
+    states; the separate-paths form needs all three paths"""
+    import json
+    import muse
+    import weights as W
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    enc, tok = W.tiny_clip(str(tmp_path / "clip_src"), hidden=cfg["encoder_hidden_size"], pooled=cfg["cond_embed_dim"])
+    torch.manual_seed(3)
+    pipe = muse.PipelineMuse(vae=muse.VQGANModel(**W.TAMING_TINY), transformer=muse.MaskGiTUViT(**cfg), text_encoder=enc, tokenizer=tok)
+    d = str(tmp_path / "pipe")
+    pipe.save_pretrained(d)
+    assert sorted(os.listdir(d)) == ["text_encoder", "transformer", "vae"]
+    back = muse.PipelineMuse.from_pretrained(d)
+    assert type(back.vae).__name__ == "VQGANModel" and type(back.transformer).__name__ == "MaskGiTUViT_v2" and not back.is_class_conditioned
+    assert type(back.text_encoder).__name__ == "CLIPTextModelWithProjection" and back.tokenizer.model_max_length == 7
+    for a, b in zip(enc.state_dict().values(), back.text_encoder.state_dict().values()):
+        assert torch.equal(a, b)
+    for a, b in zip(pipe.transformer.state_dict().values(), back.transformer.state_dict().values()):
+        assert torch.equal(a, b)
+    ids = lambda t: t(["a red fox"], return_tensors="pt", padding="max_length", truncation=True, max_length=t.model_max_length).input_ids   # noqa: E731
+    assert torch.equal(ids(tok), ids(back.tokenizer))
+    # the same checkpoint as a class-conditional pipeline: no text encoder is touched
+    assert muse.PipelineMuse.from_pretrained(d, is_class_conditioned=True).text_encoder is None
+    # separate paths (:270-286), and the reference's complaint when one is missing
+    sep = muse.PipelineMuse.from_pretrained(text_encoder_path=os.path.join(d, "text_encoder"), vae_path=os.path.join(d, "vae"),
+                                            transformer_path=os.path.join(d, "transformer"))
+    assert type(sep.text_encoder).__name__ == "CLIPTextModelWithProjection" and sep.tokenizer is not None
+    with pytest.raises(ValueError, match="text_encoder_path, vae_path, and transformer_path must be"):
+        muse.PipelineMuse.from_pretrained(vae_path=os.path.join(d, "vae"), transformer_path=os.path.join(d, "transformer"))
+    # a local checkpoint without text_encoder/: a pipeline for pre-computed text states
+    import shutil
+    shutil.rmtree(os.path.join(d, "text_encoder"))
+    bare = muse.PipelineMuse.from_pretrained(d)
+    assert bare.text_encoder is None and bare.tokenizer is None
+
+
+def test_tokenizers_keep_their_derived_config_values_through_from_pretrained():
+    """the VQGANs hang derived values on their config as plain attributes (num_resolutions, reduction_factor, latent_size - reference
+    modeling_maskgit_vqgan.py:370-372, not part of config.json); from_pretrained registers `_name_or_path` afterwards, which rebuilds
+    the config object: the derived values must still be there (the encode / decode engines read them), and still not be saved"""
+    import json
+    import muse
+    import weights as W
+    for cls, cfg in ((muse.MaskGitVQGAN, W.VQGAN_TINY), (muse.VQGANModel, W.TAMING_TINY)):
+        v = cls(**cfg)
+        with tempfile.TemporaryDirectory() as d:
+            v.save_pretrained(d)
+            saved = json.load(open(os.path.join(d, "config.json")))
+            assert "num_resolutions" not in saved and "latent_size" not in saved
+            b = cls.from_pretrained(d)
+        assert b.config.num_resolutions == len(cfg["channel_mult"]) and b.config.reduction_factor == 2 ** (len(cfg["channel_mult"]) - 1)
+        assert b.config.latent_size == cfg["resolution"] // b.config.reduction_factor and "_name_or_path" in b.config
+        assert "num_resolutions" not in dict(b.config)
+
