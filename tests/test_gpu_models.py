@@ -926,6 +926,49 @@ def test_pipeline_class_conditional():
     assert imgs.shape == (3, 32, 32, 3) and np.isfinite(imgs).all()
 
 
+def test_every_model_class_computes_the_same_after_save_and_from_pretrained(golden_dir, tmp_path):
+    """save_pretrained -> from_pretrained -> compute, for every class of the surface: the reloaded model (returned in eval mode with
+    `_name_or_path` registered, reference modeling_utils.py:228-552) produces bit-identical results to the one that was saved - both
+    tokenizers (encode + decode; their engines read derived config values that a re-registration of the config once dropped), the
+    flat-buffer MaskGitTransformer, the text-conditioned general form and the U-ViT"""
+    import json
+    import muse
+    px16, px32 = W.images(2, 16, 31).to(DEV), W.images(2, 32, 32).to(DEV)
+    for cls, cfg, px in ((muse.MaskGitVQGAN, W.VQGAN_TINY, px16), (muse.VQGANModel, W.TAMING_TINY, px32)):
+        v = cls(**cfg).to(DEV).eval()
+        d = str(tmp_path / cls.__name__)
+        v.save_pretrained(d)
+        b = cls.from_pretrained(d).to(DEV)
+        assert not b.training and b.config._name_or_path == d
+        ids = v.get_code(px)
+        assert torch.equal(b.get_code(px), ids) and torch.equal(b.decode_code(ids), v.decode_code(ids))
+        assert torch.equal(b.encode(px)[0], v.encode(px)[0])
+    tcfg = dict(W.TRANSFORMER_TINY)
+    ids, labels = (t.to(DEV) for t in W.transformer_inputs(tcfg, 3, 51))
+    m = muse.MaskGitTransformer(**tcfg).to(DEV).eval()
+    m.save_pretrained(str(tmp_path / "flat"))
+    b = muse.MaskGitTransformer.from_pretrained(str(tmp_path / "flat")).to(DEV)
+    with torch.no_grad():
+        assert torch.equal(b(input_ids=ids), m(input_ids=ids)) and torch.equal(b(input_ids=ids, labels=labels)[1], m(input_ids=ids, labels=labels)[1])
+    xcfg = dict(W.TRANSFORMER_TEXT_TINY)
+    xi, xl, enc = (t.to(DEV) for t in W.transformer_text_inputs(xcfg, 2, 5, 52))
+    m = muse.MaskGitTransformer(**xcfg).to(DEV).eval()
+    m.save_pretrained(str(tmp_path / "text"))
+    b = muse.MaskGitTransformer.from_pretrained(str(tmp_path / "text")).to(DEV)
+    with torch.no_grad():
+        assert torch.equal(b(input_ids=xi, encoder_hidden_states=enc), m(input_ids=xi, encoder_hidden_states=enc))
+    g = np.load(os.path.join(golden_dir, "uvit_tiny_downup.npz"))
+    ucfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny_downup.json")))
+    u = muse.MaskGiTUViT(**ucfg)
+    u.load_state_dict({k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}, strict=True)
+    u.to(DEV).eval()
+    u.save_pretrained(str(tmp_path / "uvit"))
+    b = muse.MaskGiTUViT.from_pretrained(str(tmp_path / "uvit")).to(DEV)
+    args = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    with torch.no_grad():
+        assert b.config.force_down_up_sample and torch.equal(b(*args), u(*args))
+
+
 def test_grad_reducer_on_rccl_single_rank(golden_dir):
     """the N>1 path of bench.py on the real backend: RCCL ("nccl") process group of size 1, bucketed all-reduce of the flat
     gradient buffer on the side stream fired from backward; gradients must equal the un-reduced reference golden"""
