@@ -377,6 +377,46 @@ def test_uvit_gradient_buckets_reduced_inside_backward_on_rccl(golden_dir, cd):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("half", [torch.float16, torch.bfloat16])
+def test_half_precision_conditioning_inside_autocast_as_the_training_script_hands_it(golden_dir, half):
+    """training/train_muse.py keeps the text encoder in the mixed-precision dtype: `encoder_hidden_states` / `cond_embeds` (and the
+    `micro_conds` built from their dtype, :660-663) reach the model as fp16 / bf16 tensors, and validation calls it inside
+    torch.autocast (:1068).  The hand-written path ignores autocast and upcasts its inputs: same logits / loss / gradients as the
+    call with those values already in f32; U-ViT and the text-conditioned MaskGitTransformer; cond_dropout keeps the dtype"""
+    import muse
+    import weights as W
+    g, cfg, sd = _load_golden(golden_dir)
+    model = muse.MaskGiTUViT(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train().set_compute_dtype(torch.bfloat16)
+    ids, enc, cond, micro = [torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "encoder_hidden_states", "cond_embeds", "micro_conds")]
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    eh, ch, mh = enc.to(half), cond.to(half), micro.to(half)
+
+    def run(*a, ctx):
+        model.zero_grad(set_to_none=True)
+        with ctx:
+            logits, loss = model(ids, *a, labels=labels)
+        loss.backward()
+        return logits.detach(), loss.detach(), [p.grad.clone() for p in model.parameters()]
+    import contextlib
+    l0, s0, g0 = run(eh.float(), ch.float(), mh.float(), ctx=contextlib.nullcontext())
+    l1, s1, g1 = run(eh, ch, mh, ctx=torch.autocast("cuda", dtype=half))
+    assert l1.dtype == torch.float32 and torch.equal(l0, l1) and torch.equal(s0, s1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    xcfg = dict(W.TRANSFORMER_TEXT_TINY)
+    m = muse.MaskGitTransformer(**xcfg)
+    m.load_state_dict(W.fill_state_dict(W.transformer_shapes(xcfg), 800, "transformer"))
+    m.to(DEV).train().set_compute_dtype(torch.bfloat16)
+    xi, xl, xe = (t.to(DEV) for t in W.transformer_text_inputs(xcfg, 2, 5, 52))
+    with torch.autocast("cuda", dtype=half):
+        a = m(input_ids=xi, encoder_hidden_states=xe.to(half), labels=xl)
+    b = m(input_ids=xi, encoder_hidden_states=xe.to(half).float(), labels=xl)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    e2, c2 = muse.cond_dropout(eh, ch, torch.zeros(1, enc.shape[1], enc.shape[2], device=DEV, dtype=half), torch.zeros(1, cond.shape[1], device=DEV, dtype=half),
+                               0.5, uniforms=torch.tensor([0.1, 0.9], device=DEV))
+    assert e2.dtype == half and c2.dtype == half and torch.equal(e2[0], eh[0]) and float(e2[1].abs().max()) == 0.0 and float(c2[1].abs().max()) == 0.0
+
+
 def test_gradient_accumulation_under_the_reducer_on_rccl(golden_dir):
     """gradient_accumulation_steps = 2 (cc12m_uvit_clip.yaml and nine more configurations; accelerate's accumulate() = DDP.no_sync on the
     first micro-batch) on an RCCL group of one rank: muse.GradReducer.no_sync() keeps the first micro-batch local, the second backward's
