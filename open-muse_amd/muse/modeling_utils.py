@@ -45,6 +45,16 @@ class FrozenDict(OrderedDict):
             self._blocked()
         super().__setitem__(k, v)
 
+    # copy.deepcopy(model) (the reference's training_utils.EMA keeps a deep copy of the model, :61-80) and pickling go through
+    # __reduce_ex__: rebuild from the items, then restore the attributes that are not items (the constructors' derived values)
+    def __reduce__(self):
+        extra = {k: v for k, v in vars(self).items() if k not in self and k != "_sealed"}
+        return (self.__class__, (dict(self),), extra)
+
+    def __setstate__(self, state):
+        for k, v in (state or {}).items():
+            object.__setattr__(self, k, v)
+
 
 class ConfigMixin:
     config_name = CONFIG_NAME

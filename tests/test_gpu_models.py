@@ -950,6 +950,16 @@ def test_every_model_class_computes_the_same_after_save_and_from_pretrained(gold
     b = muse.MaskGitTransformer.from_pretrained(str(tmp_path / "flat")).to(DEV)
     with torch.no_grad():
         assert torch.equal(b(input_ids=ids), m(input_ids=ids)) and torch.equal(b(input_ids=ids, labels=labels)[1], m(input_ids=ids, labels=labels)[1])
+    # copy.deepcopy of a model on the GPU (training_utils.EMA of the reference tracks one): the parameters of the copy are no longer
+    # views of ITS flat buffer until the first forward rebuilds it - same results, then independent weights
+    import copy
+    c = copy.deepcopy(m)
+    with torch.no_grad():
+        assert torch.equal(c(input_ids=ids), m(input_ids=ids)) and c._flat_ok() and c._flat.data_ptr() != m._flat.data_ptr()
+        want = m(input_ids=ids).clone()
+        next(c.parameters()).mul_(1.5)
+        c.mark_weights_changed()
+        assert torch.equal(m(input_ids=ids), want) and not torch.equal(c(input_ids=ids), want)
     xcfg = dict(W.TRANSFORMER_TEXT_TINY)
     xi, xl, enc = (t.to(DEV) for t in W.transformer_text_inputs(xcfg, 2, 5, 52))
     m = muse.MaskGitTransformer(**xcfg).to(DEV).eval()

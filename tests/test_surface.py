@@ -614,3 +614,29 @@ def test_tokenizers_keep_their_derived_config_values_through_from_pretrained():
         assert b.config.latent_size == cfg["resolution"] // b.config.reduction_factor and "_name_or_path" in b.config
         assert "num_resolutions" not in dict(b.config)
 
+
+def test_models_and_configs_survive_deepcopy_and_pickle(golden_dir):
+    """copy.deepcopy(model) - what the reference's training_utils.EMA does with the model it tracks (:61-80) - and pickling of the
+    config: the frozen config rebuilds from its items and keeps its derived attributes, stays frozen; the copy owns its own storage"""
+    import copy
+    import json
+    import pickle
+    import muse
+    import weights as W
+    ucfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    for m in (muse.MaskGitTransformer(**W.TRANSFORMER_TINY), muse.MaskGitTransformer(**W.TRANSFORMER_TEXT_TINY), muse.MaskGiTUViT(**ucfg),
+              muse.MaskGitVQGAN(**W.VQGAN_TINY), muse.VQGANModel(**W.TAMING_TINY)):
+        c = copy.deepcopy(m)
+        assert dict(c.config) == dict(m.config) and c.config is not m.config
+        assert all(torch.equal(a, b) and a.data_ptr() != b.data_ptr() for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+        with torch.no_grad():
+            next(c.parameters()).add_(1.0)
+        assert not torch.equal(next(c.parameters()), next(m.parameters()))
+        cfg2 = pickle.loads(pickle.dumps(m.config))
+        assert cfg2 == m.config and type(cfg2) is type(m.config)
+        for k in ("num_resolutions", "latent_size"):
+            if hasattr(m.config, k):
+                assert getattr(cfg2, k) == getattr(m.config, k) and getattr(c.config, k) == getattr(m.config, k) and k not in dict(cfg2)
+        with pytest.raises(Exception, match="cannot mutate"):
+            cfg2["x"] = 1
+
