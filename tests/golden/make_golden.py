@@ -482,6 +482,27 @@ def reference_configs(path="/root/reference/configs"):
     print("reference_configs", len(out), "configurations")
 
 
+def golden_checkpoints():
+    """checkpoint directories written by the REFERENCE's save_pretrained (config.json + pytorch_model.bin, modeling_utils.py:228-285) for
+    one tiny model of every class, with known parameters: tests/test_surface.py loads them with this package's from_pretrained (and, in the
+    build container, hands this package's checkpoints to the reference's from_pretrained)"""
+    out = os.path.join(HERE, "ckpt")
+    gp = np.load(os.path.join(HERE, "uvit_tiny.npz"))
+    import json
+    ucfg = json.load(open(os.path.join(HERE, "config_uvit_tiny.json")))
+    from muse.modeling_transformer_v2 import MaskGiTUViT_v2
+    jobs = [("transformer_tiny", ref_muse.MaskGitTransformer(**W.TRANSFORMER_TINY), W.fill_state_dict(W.transformer_shapes(W.TRANSFORMER_TINY), 100, "transformer")),
+            ("transformer_text_tiny", ref_muse.MaskGitTransformer(**W.TRANSFORMER_TEXT_TINY),
+             W.fill_state_dict(W.transformer_shapes(W.TRANSFORMER_TEXT_TINY), 800, "transformer")),
+            ("uvit_tiny", MaskGiTUViT_v2(**ucfg), {k[len("param."):]: torch.from_numpy(gp[k]) for k in gp.files if k.startswith("param.")}),
+            ("vqgan_tiny", ref_muse.MaskGitVQGAN(**W.VQGAN_CKPT), W.fill_state_dict(W.vqgan_shapes(W.VQGAN_CKPT), 300, "vqgan")),
+            ("taming_tiny", ref_muse.VQGANModel(**W.TAMING_CKPT), W.fill_state_dict(W.taming_shapes(W.TAMING_CKPT), 310, "vqgan"))]
+    for name, model, sd in jobs:
+        model.load_state_dict(sd, strict=True)
+        model.save_pretrained(os.path.join(out, name))
+        print("checkpoint", name, sorted(os.listdir(os.path.join(out, name))), sum(v.numel() for v in sd.values()), "parameters")
+
+
 def replay_decode_noise(seed, steps, rows, seq, vocab):
     """the draws a reference generate2 call makes from torch.Generator().manual_seed(seed), per step: torch.multinomial(probs
     [rows*seq, vocab], 1) fills an Exp(1) tensor of the probabilities' shape (ATen multinomial_out, one-sample fast path), then
@@ -683,6 +704,7 @@ if __name__ == "__main__":
     golden_mask_muse("mask_muse", seed=540)
     golden_ema("ema_tiny", seed=560)
     reference_configs()
+    golden_checkpoints()
     golden_transformer_autocast("transformer_tiny_bf16", W.TRANSFORMER_TINY, batch=3, seed=100)
     golden_transformer_autocast("transformer_hd48_bf16", W.TRANSFORMER_HD48, batch=2, seed=120)
     golden_transformer_text("transformer_text_tiny", W.TRANSFORMER_TEXT_TINY, batch=3, text_len=7, seed=800)

@@ -461,3 +461,8 @@ def tiny_clip(workdir, hidden=24, pooled=16, max_len=7, seed=5):
                          pad_token_id=len(vocab) - 1)
     return CLIPTextModelWithProjection(cfg).eval(), tok
 
+
+# the two tokenizers of tests/golden/ckpt/ (reference-written checkpoints): two levels, one block per level - small files
+VQGAN_CKPT = dict(VQGAN_TINY, channel_mult=(1, 1), num_res_blocks=1)
+TAMING_CKPT = dict(TAMING_TINY, channel_mult=(1, 1), num_res_blocks=1, attn_resolutions=(16,))
+

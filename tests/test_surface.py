@@ -640,3 +640,90 @@ def test_models_and_configs_survive_deepcopy_and_pickle(golden_dir):
         with pytest.raises(Exception, match="cannot mutate"):
             cfg2["x"] = 1
 
+
+_CKPT = [("transformer_tiny", "MaskGitTransformer"), ("transformer_text_tiny", "MaskGitTransformer"), ("uvit_tiny", "MaskGiTUViT"),
+         ("vqgan_tiny", "MaskGitVQGAN"), ("taming_tiny", "VQGANModel")]
+
+
+def _ckpt_expected(golden_dir, name):
+    import json
+    import weights as W
+    if name == "uvit_tiny":
+        g = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+        return {k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}
+    shapes, seed, kind = {"transformer_tiny": (W.transformer_shapes(W.TRANSFORMER_TINY), 100, "transformer"),
+                          "transformer_text_tiny": (W.transformer_shapes(W.TRANSFORMER_TEXT_TINY), 800, "transformer"),
+                          "vqgan_tiny": (W.vqgan_shapes(W.VQGAN_CKPT), 300, "vqgan"),
+                          "taming_tiny": (W.taming_shapes(W.TAMING_CKPT), 310, "vqgan")}[name]
+    return W.fill_state_dict(shapes, seed, kind)
+
+
+@pytest.mark.parametrize("name,cls_name", _CKPT)
+def test_checkpoints_written_by_the_reference_load_here(golden_dir, name, cls_name):
+    """tests/golden/ckpt/<name>: config.json + pytorch_model.bin written by the REAL reference's save_pretrained
+    (make_golden.py::golden_checkpoints).  This package's from_pretrained reads them: same parameters under the same names, eval mode,
+    `_name_or_path` registered, every config key of the file present with its value; and what it saves back is, file for file, what the
+    reference wrote (same config.json content, same tensors under the same keys in pytorch_model.bin)"""
+    import json
+    import muse
+    d = os.path.join(golden_dir, "ckpt", name)
+    cls = getattr(muse, cls_name)
+    m, info = cls.from_pretrained(d, output_loading_info=True)
+    assert info["missing_keys"] == [] and info["unexpected_keys"] == [] and info["mismatched_keys"] == []
+    want = _ckpt_expected(golden_dir, name)
+    sd = m.state_dict()
+    written = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    assert list(sd.keys()) == list(written.keys()) and set(sd.keys()) == set(want.keys())       # the reference's names, in its order
+    assert all(torch.equal(sd[k], want[k]) for k in want) and not m.training and m.config._name_or_path == d
+    ref_cfg = json.load(open(os.path.join(d, "config.json")))
+    for k, v in ref_cfg.items():
+        if not k.startswith("_"):
+            got = m.config[k]
+            assert (list(got) if isinstance(got, (tuple, list)) else got) == v, k
+    with tempfile.TemporaryDirectory() as out:
+        m.save_pretrained(out)
+        assert sorted(os.listdir(out)) == ["config.json", "pytorch_model.bin"]
+        mine = json.load(open(os.path.join(out, "config.json")))
+        skip = ("_name_or_path",)
+        assert {k: v for k, v in mine.items() if k not in skip} == {k: v for k, v in ref_cfg.items() if k not in skip}
+        a = torch.load(os.path.join(out, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        b = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        assert list(a.keys()) == list(b.keys()) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/muse"), reason="needs the reference tree (build container only)")
+@pytest.mark.parametrize("name,cls_name", _CKPT)
+def test_checkpoints_written_here_load_in_the_reference(golden_dir, name, cls_name, tmp_path):
+    """the other direction, where the reference is importable: a checkpoint written by THIS package's save_pretrained is loaded by the
+    real reference's from_pretrained in a separate process (both packages are called `muse`), strictly, and its parameters come back
+    bit-identical under the same names; for the transformers the reference then also computes logits on the CPU from it"""
+    import subprocess
+    import sys
+    import muse
+    cls = getattr(muse, cls_name)
+    m = cls.from_pretrained(os.path.join(golden_dir, "ckpt", name))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.25)                                   # not the bytes the reference wrote
+    if hasattr(m, "mark_weights_changed"):
+        m.mark_weights_changed()
+    d = str(tmp_path / "mine")
+    m.save_pretrained(d)
+    torch.save({k: v.clone() for k, v in m.state_dict().items()}, str(tmp_path / "want.pt"))
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, '/root/reference')\n"
+        "import muse\n"
+        "from muse.modeling_transformer_v2 import MaskGiTUViT_v2\n"
+        f"cls = MaskGiTUViT_v2 if {cls_name!r} == 'MaskGiTUViT' else getattr(muse, {cls_name!r})\n"
+        f"m, info = cls.from_pretrained({d!r}, output_loading_info=True, low_cpu_mem_usage=False)\n"
+        "assert not info['missing_keys'] and not info['unexpected_keys'] and not info['mismatched_keys'], info\n"
+        f"want = torch.load({str(tmp_path / 'want.pt')!r})\n"
+        "sd = m.state_dict()\n"
+        "assert list(sd.keys()) == list(want.keys()), (list(sd.keys())[:3], list(want.keys())[:3])\n"
+        "assert all(torch.equal(sd[k], want[k]) for k in want)\n"
+        "print('REFERENCE_LOADED', type(m).__name__, len(sd))\n")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert r.returncode == 0 and "REFERENCE_LOADED" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
