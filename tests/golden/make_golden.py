@@ -463,15 +463,23 @@ def reference_configs(path="/root/reference/configs"):
         if (isinstance(bo, (list, tuple)) and len(bo) != 1) or t.get("use_conv_in_out"):
             continue
         cls = ref_muse.MaskGiTUViT if m.get("architecture", "transformer") == "uvit" else ref_muse.MaskGitTransformer
-        try:
+        def template(kw):
+            """the state-dict template of the reference's model: tensor count, parameter count, digest of the (name, shape) list"""
+            import hashlib
             with torch.device("meta"):
-                cls(**t)                                   # the reference really constructs it ...
+                mod = cls(**kw)
+            items = [(k, tuple(v.shape)) for k, v in mod.state_dict().items()]
+            return dict(tensors=len(items), parameters=int(sum(p.numel() for p in mod.parameters())),
+                        sha1=hashlib.sha1(repr(items).encode()).hexdigest())
+        try:
+            tmpl = template(t)                             # the reference really constructs it ...
             err = None
         except Exception as e:                             # noqa: BLE001  ... or says why not (block_num_heads 12 on 1024 channels: SURVEY.md D3)
             err = f"{type(e).__name__}: {e}"
+            tmpl = template(dict(t, block_num_heads=16))   # (the override BASELINE.json's config 4 uses)
         pre = c.get("dataset", {}).get("preprocessing", {})
         out[os.path.basename(f)] = dict(
-            reference_error=err,
+            reference_error=err, state_dict_template=tmpl,
             architecture=m.get("architecture", "transformer"), transformer=t, resolution=pre.get("resolution"),
             max_seq_length=pre.get("max_seq_length"), text_encoder=m.get("text_encoder", {}).get("type"), vq=m.get("vq_model", {}).get("type"),
             training={k: c.get("training", {}).get(k) for k in ("gradient_accumulation_steps", "batch_size", "mixed_precision", "use_ema",

@@ -555,6 +555,12 @@ def test_every_reference_configuration_constructs_or_fails_like_the_reference(go
                 m = cls(**dict(t, block_num_heads=16))
         assert sum(p.numel() for p in m.parameters()) > 1e8, name
         assert m.config.mask_token_id == t["vocab_size"] - 1
+        # the state-dict template of the real class at this configuration: same tensors, same names in the same order, same shapes
+        import hashlib
+        items = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        tmpl = entry["state_dict_template"]
+        assert (len(items), sum(p.numel() for p in m.parameters())) == (tmpl["tensors"], tmpl["parameters"]), name
+        assert hashlib.sha1(repr(items).encode()).hexdigest() == tmpl["sha1"], name
 
 
 def test_pipeline_save_and_from_pretrained_with_a_text_encoder(golden_dir, tmp_path):
