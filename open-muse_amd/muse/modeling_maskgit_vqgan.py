@@ -263,6 +263,14 @@ class _ConvEngine:
 
 
 class MaskGitVQGAN(_ConvEngine, ModelMixin, ConfigMixin):
+    _cast_selects_compute_mode = True
+
+    def _compute_mode_for(self, dtype):
+        """`.half()` / `.to(dtype=...)` / `from_pretrained(torch_dtype=...)` leave the tokenizer as it is: the reference keeps the VAE in
+        fp32 whatever the pipeline's dtype (pipeline_muse.py:62), the parameters here stay f32 and the arithmetic is chosen with
+        set_compute_dtype (exact f32, "bf16x3", bf16)"""
+        return dtype is not None and dtype.is_floating_point
+
     @register_to_config
     def __init__(
         self,

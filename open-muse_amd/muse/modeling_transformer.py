@@ -105,6 +105,7 @@ class _MaskGitFn(torch.autograd.Function):
 
 
 class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
+    _cast_selects_compute_mode = True     # model.half() / .to(dtype) / from_pretrained(torch_dtype=) pick the compute mode; masters stay f32 (ModelMixin)
     _supports_gradient_checkpointing = True
 
     @register_to_config

@@ -209,6 +209,7 @@ class _UViTFn(torch.autograd.Function):
 
 
 class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
+    _cast_selects_compute_mode = True     # model.half() / .to(dtype) / from_pretrained(torch_dtype=) pick the compute mode; masters stay f32 (ModelMixin)
     def __init__(self, **kwargs):
         super().__init__()
         cfg = dict(_DEFAULTS)

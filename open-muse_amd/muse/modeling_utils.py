@@ -277,6 +277,39 @@ class ModelMixin(torch.nn.Module):
             return model, dict(missing_keys=missing, unexpected_keys=unexpected, mismatched_keys=mismatched, error_msgs=[])
         return model
 
+    # ---- precision casts -----------------------------------------------------------------------------------------------------------
+    # The reference's scripts cast whole models (`model.half()`, scripts/benchmark_models.py:33-34; `.to(device, dtype=dtype)`,
+    # pipeline_muse.py:55-64; `from_pretrained(torch_dtype=...)`).  Here the master parameters stay float32 (what FusedAdamW steps, what
+    # save_pretrained writes) and a floating-point cast selects the transformers' COMPUTE mode instead: half / bfloat16 -> the bf16 MFMA
+    # path (the kernels have no f16 variant; bf16 has the wider exponent and the same MFMA rate), float32 / float64 -> exact f32.
+    # The tokenizers ("keep vae in fp32", pipeline_muse.py:62) keep their own mode.
+    _cast_selects_compute_mode = False          # the transformer classes set this
+
+    def _compute_mode_for(self, dtype):
+        if dtype is not None and dtype.is_floating_point and self._cast_selects_compute_mode:
+            self.set_compute_dtype(torch.bfloat16 if dtype in (torch.float16, torch.bfloat16) else torch.float32)
+            return True
+        return False
+
+    def half(self):
+        return self if self._compute_mode_for(torch.float16) else super().half()
+
+    def bfloat16(self):
+        return self if self._compute_mode_for(torch.bfloat16) else super().bfloat16()
+
+    def float(self):
+        return self if self._compute_mode_for(torch.float32) else super().float()
+
+    def double(self):
+        return self if self._compute_mode_for(torch.float64) else super().double()
+
+    def to(self, *args, **kwargs):
+        if not self._cast_selects_compute_mode:
+            return super().to(*args, **kwargs)
+        device, dtype, non_blocking, _ = torch._C._nn._parse_to(*args, **kwargs)
+        self._compute_mode_for(dtype)
+        return super().to(device=device, non_blocking=non_blocking) if device is not None else self
+
     # ---- introspection -----------------------------------------------------------------------------------------
     @property
     def device(self) -> torch.device:

@@ -960,6 +960,16 @@ def test_every_model_class_computes_the_same_after_save_and_from_pretrained(gold
         next(c.parameters()).mul_(1.5)
         c.mark_weights_changed()
         assert torch.equal(m(input_ids=ids), want) and not torch.equal(c(input_ids=ids), want)
+    # the reference's precision casts pick the compute mode here (masters stay f32): .half() / .to(device, dtype=) / torch_dtype=
+    with torch.no_grad():
+        want16 = m.set_compute_dtype(torch.bfloat16)(input_ids=ids).clone()
+        m.set_compute_dtype(torch.float32)
+        assert not torch.equal(want16, m(input_ids=ids))
+        assert torch.equal(m.half()(input_ids=ids), want16) and next(m.parameters()).dtype == torch.float32
+        b16 = muse.MaskGitTransformer.from_pretrained(str(tmp_path / "flat"), torch_dtype=torch.float16).to(DEV)
+        assert torch.equal(b16(input_ids=ids), want16)
+        assert torch.equal(muse.MaskGitTransformer.from_pretrained(str(tmp_path / "flat")).to(DEV, dtype=torch.bfloat16)(input_ids=ids), want16)
+        m.float()
     xcfg = dict(W.TRANSFORMER_TEXT_TINY)
     xi, xl, enc = (t.to(DEV) for t in W.transformer_text_inputs(xcfg, 2, 5, 52))
     m = muse.MaskGitTransformer(**xcfg).to(DEV).eval()

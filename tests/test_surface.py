@@ -733,3 +733,31 @@ def test_checkpoints_written_here_load_in_the_reference(golden_dir, name, cls_na
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
     assert r.returncode == 0 and "REFERENCE_LOADED" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
+
+def test_precision_casts_select_the_compute_mode_and_keep_f32_masters(golden_dir):
+    """`model.half()` (scripts/benchmark_models.py:33-34), `.to(device, dtype=...)` (pipeline_muse.py:55-64) and
+    `from_pretrained(torch_dtype=...)` of the reference cast the parameters; here the masters stay float32 and the cast picks the
+    transformers' compute mode (fp16 / bf16 -> bf16 MFMA path, fp32 -> exact f32); the tokenizers ignore it ("keep vae in fp32")"""
+    import json
+    import muse
+    import weights as W
+    ucfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    flat, text, uvit = muse.MaskGitTransformer(**W.TRANSFORMER_TINY), muse.MaskGitTransformer(**W.TRANSFORMER_TEXT_TINY), muse.MaskGiTUViT(**ucfg)
+    mode = lambda m: m._resolve_cd() if hasattr(m, "_resolve_cd") else m.compute_dtype      # noqa: E731  ("auto" resolves to f32 outside autocast)
+    for m in (flat, text, uvit):
+        assert m.half() is m and mode(m) == torch.bfloat16 and all(p.dtype == torch.float32 for p in m.parameters())
+        assert m.float() is m and mode(m) == torch.float32
+        assert m.bfloat16() is m and mode(m) == torch.bfloat16
+        assert m.to(torch.float32) is m and mode(m) == torch.float32
+        assert m.to("cpu", dtype=torch.float16) is m and mode(m) == torch.bfloat16
+        assert m.to("cpu") is m and mode(m) == torch.bfloat16 and m.dtype == torch.float32        # a pure device move changes nothing
+        with tempfile.TemporaryDirectory() as d:
+            m.save_pretrained(d)
+            assert all(v.dtype == torch.float32 for v in torch.load(os.path.join(d, "pytorch_model.bin"), weights_only=True).values())
+            b = type(m).from_pretrained(d, torch_dtype=torch.float16)
+            assert mode(b) == torch.bfloat16 and all(p.dtype == torch.float32 for p in b.parameters())
+            assert mode(type(m).from_pretrained(d)) == torch.float32
+    for v in (muse.MaskGitVQGAN(**W.VQGAN_TINY), muse.VQGANModel(**W.TAMING_TINY)):
+        before = v.compute_dtype
+        assert v.half() is v and v.to(dtype=torch.bfloat16) is v and all(p.dtype == torch.float32 for p in v.parameters()) and v.compute_dtype == before
+
