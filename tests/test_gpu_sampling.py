@@ -255,6 +255,28 @@ def test_pipeline_from_pretrained_text_to_image_with_a_real_clip_tower(golden_di
     assert not np.array_equal(imgs, pipe(["a blue whale", "two cats on a sofa"], generator=gen(), **kw))       # the prompt matters
 
 
+def test_the_reference_benchmark_script_flow_runs_unchanged(golden_dir):
+    """scripts/benchmark_models.py of the reference, statement for statement, on a reference-written config: load_config(path) ->
+    from_config(config).to(device) -> eval() -> generate2(encoder_hidden_states=fp32 states) -> half() on the states and the model ->
+    generate2 again -> enable_xformers_memory_efficient_attention() -> generate2; torch.utils.benchmark around one of them"""
+    import torch.utils.benchmark as benchmark
+    from muse import MaskGitTransformer
+    config = MaskGitTransformer.load_config(os.path.join(golden_dir, "ckpt", "transformer_text_tiny"))
+    model = MaskGitTransformer.from_config(config).to(DEV)
+    model.eval()
+    encoder_hidden_states = torch.randn(3, 9, model.config.encoder_hidden_size, device=DEV, dtype=torch.float32)
+    ids = model.generate2(encoder_hidden_states=encoder_hidden_states, timesteps=4)
+    assert ids.shape == (3, model.config.num_vq_tokens) and int(ids.min()) >= 0 and int(ids.max()) < model.config.codebook_size
+    encoder_hidden_states = encoder_hidden_states.half()
+    model = model.half()
+    f = lambda: model.generate2(encoder_hidden_states=encoder_hidden_states, timesteps=4)      # noqa: E731
+    ids16 = f()
+    assert ids16.shape == ids.shape and int(ids16.max()) < model.config.codebook_size
+    model.enable_xformers_memory_efficient_attention()
+    t = benchmark.Timer(stmt="f()", globals={"f": f}).timeit(2)
+    assert t.mean > 0 and f().shape == ids.shape
+
+
 def test_inpainting_pipeline_repaints_only_the_masked_tokens(golden_dir):
     """muse.PipelineMuseInpainting (reference :372-510): the picture is tokenised by vae.encode, the masked positions get the mask token,
     generate2 fills them - every other token of every returned sample is the picture's own; class-conditional MaskGitTransformer (PIL
