@@ -121,10 +121,14 @@ class VQGANModel(_ConvEngine, ModelMixin, ConfigMixin):
     _cast_selects_compute_mode = True
 
     def _compute_mode_for(self, dtype):
-        """`.half()` / `.to(dtype=...)` / `from_pretrained(torch_dtype=...)` leave the tokenizer as it is: the reference keeps the VAE in
-        fp32 whatever the pipeline's dtype (pipeline_muse.py:62), the parameters here stay f32 and the arithmetic is chosen with
-        set_compute_dtype (exact f32, "bf16x3", bf16)"""
-        return dtype is not None and dtype.is_floating_point
+        """`.half()` / `.to(dtype=fp16 | bf16)` / `from_pretrained(torch_dtype=...)` (benchmark/muse_perf.py:251-252 casts the VAE to
+        fp16): the parameters stay f32 and the tokenizer takes its fast f32-CLASS mode "bf16x3" (three bf16 MFMA products per f32
+        product: token indices and images stay at the parity bar, which a plain half-precision tokenizer would not); a cast to f32 / f64
+        selects exact f32.  (The reference's pipeline keeps the VAE in fp32, pipeline_muse.py:62: PipelineMuse.to does not cast it.)"""
+        if dtype is None or not dtype.is_floating_point:
+            return False
+        self.set_compute_dtype("bf16x3" if dtype in (torch.float16, torch.bfloat16) else torch.float32)
+        return True
 
     @register_to_config
     def __init__(

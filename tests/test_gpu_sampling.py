@@ -255,6 +255,46 @@ def test_pipeline_from_pretrained_text_to_image_with_a_real_clip_tower(golden_di
     assert not np.array_equal(imgs, pipe(["a blue whale", "two cats on a sofa"], generator=gen(), **kw))       # the prompt matters
 
 
+@pytest.mark.parametrize("resolution", [256, 512])
+def test_the_reference_latency_benchmark_flow_runs_unchanged(golden_dir, tmp_path, resolution):
+    """benchmark/muse_perf.py::muse_benchmark (the source of the reference's published latency table), statement for statement with tiny
+    stand-ins for the hub checkpoint: AutoTokenizer / CLIPTextModelWithProjection from `<model>/text_encoder` cast to fp16,
+    VQGANModel.from_pretrained(model, subfolder="vae").to(device, dtype=fp16), MaskGiTUViT(use_fused_mlp=False,
+    use_fused_residual_norm=..., force_down_up_sample=resolution == 512).to(device, dtype=fp16).eval(), the xformers switch,
+    PipelineMuse(tokenizer=, text_encoder=, vae=, transformer=) with `.device` / `.dtype` set by hand, pipe(prompt,
+    num_images_per_prompt=, timesteps=, transformer_seq_len=) inside a torch.utils.benchmark Timer"""
+    from torch.utils.benchmark import Timer
+    from transformers import AutoTokenizer, CLIPTextModelWithProjection
+    from muse import MaskGiTUViT, PipelineMuse, VQGANModel
+    ucfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    enc, tok = W.tiny_clip(str(tmp_path / "clip_src"), hidden=ucfg["encoder_hidden_size"], pooled=ucfg["cond_embed_dim"])
+    model = str(tmp_path / "hub_model")
+    enc.save_pretrained(os.path.join(model, "text_encoder"))
+    tok.save_pretrained(os.path.join(model, "text_encoder"))
+    VQGANModel(**dict(W.TAMING_TINY, num_embeddings=ucfg["codebook_size"])).save_pretrained(os.path.join(model, "vae"))
+    device, dtype = "cuda", torch.float16
+    tokenizer = AutoTokenizer.from_pretrained(model, subfolder="text_encoder")
+    text_encoder = CLIPTextModelWithProjection.from_pretrained(model, subfolder="text_encoder")
+    text_encoder.to(device=device, dtype=dtype)
+    vae = VQGANModel.from_pretrained(model, subfolder="vae")
+    vae.to(device=device, dtype=dtype)
+    tiny = {k: v for k, v in ucfg.items() if k not in ("force_down_up_sample", "use_fused_mlp", "use_fused_residual_norm")}
+    transformer = MaskGiTUViT(use_fused_mlp=False, use_fused_residual_norm=True, force_down_up_sample=resolution == 512, **tiny)
+    transformer = transformer.to(device=device, dtype=dtype)
+    transformer.eval()
+    transformer.enable_xformers_memory_efficient_attention()
+    pipe = PipelineMuse(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, transformer=transformer)
+    pipe.device = device
+    pipe.dtype = dtype
+    assert vae.compute_dtype == "bf16x3" and transformer.compute_dtype == torch.bfloat16 and next(transformer.parameters()).dtype == torch.float32
+    seq_len = (resolution // 32) ** 2          # (tiny stand-in: 8 x 8 / 16 x 16 tokens where the real run has 16 x 16 / 32 x 32)
+    prompt = "A high tech solarpunk utopia in the Amazon rainforest"
+    out = pipe(prompt, num_images_per_prompt=2, timesteps=2, transformer_seq_len=seq_len)
+    assert len(out) == 2 and out[0].size == (int(seq_len ** 0.5) * 4,) * 2          # PIL images, 4 pixels per token side for this tiny tokenizer
+    t = Timer(stmt="benchmark_fn()", globals={"benchmark_fn": lambda: pipe(prompt, num_images_per_prompt=2, timesteps=3, transformer_seq_len=seq_len)}).timeit(2)
+    assert t.mean > 0
+
+
 def test_the_reference_benchmark_script_flow_runs_unchanged(golden_dir):
     """scripts/benchmark_models.py of the reference, statement for statement, on a reference-written config: load_config(path) ->
     from_config(config).to(device) -> eval() -> generate2(encoder_hidden_states=fp32 states) -> half() on the states and the model ->

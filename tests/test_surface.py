@@ -757,7 +757,8 @@ def test_precision_casts_select_the_compute_mode_and_keep_f32_masters(golden_dir
             b = type(m).from_pretrained(d, torch_dtype=torch.float16)
             assert mode(b) == torch.bfloat16 and all(p.dtype == torch.float32 for p in b.parameters())
             assert mode(type(m).from_pretrained(d)) == torch.float32
-    for v in (muse.MaskGitVQGAN(**W.VQGAN_TINY), muse.VQGANModel(**W.TAMING_TINY)):
-        before = v.compute_dtype
-        assert v.half() is v and v.to(dtype=torch.bfloat16) is v and all(p.dtype == torch.float32 for p in v.parameters()) and v.compute_dtype == before
-
+    for v in (muse.MaskGitVQGAN(**W.VQGAN_TINY), muse.VQGANModel(**W.TAMING_TINY)):     # tokenizers: half -> the f32-class "bf16x3" mode
+        assert v.half() is v and v.compute_dtype == "bf16x3" and all(p.dtype == torch.float32 for p in v.parameters())
+        assert v.float() is v and v.compute_dtype == torch.float32
+        assert v.to(dtype=torch.bfloat16) is v and v.compute_dtype == "bf16x3" and all(p.dtype == torch.float32 for p in v.parameters())
+        assert v.to("cpu") is v and v.compute_dtype == "bf16x3"
