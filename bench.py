@@ -253,6 +253,46 @@ def latency_leg(device, timesteps=12):
                 vae.decode_code(toks)
             torch.cuda.synchronize()
         out[f"decode_ms_bs{bs}"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    # the 512 x 512 rows of the same table (benchmark/artifacts/all.csv:7,41: 572.2 / 1172.4 ms): muse_perf.py builds the transformer
+    # with force_down_up_sample=True for them (:257) - 1024 tokens, 256 inside the blocks and layers - and decodes a 32 x 32 token grid
+    del pipe, tr
+    torch.cuda.empty_cache()
+    try:
+        M.MaskGiTUViT_v2._init_weights = lambda self: None
+        try:
+            tr = muse.MaskGiTUViT(force_down_up_sample=True)
+        finally:
+            M.MaskGiTUViT_v2._init_weights = init
+        pipe = muse.PipelineMuse(vae=vae, transformer=tr)
+        pipe.to(device, dtype=torch.bfloat16)
+        tr.eval()
+        with torch.no_grad():
+            for n, p in tr.named_parameters():
+                p.fill_(1.0) if n.endswith("norm.weight") else p.normal_(0.0, 0.02, generator=g)
+        tr.mark_weights_changed()
+        out["reference_published_ms"].update({"bs1_512_a100_fp16": 572.2, "bs8_512_a100_fp16": 1172.4, "source_512": "benchmark/artifacts/all.csv:7,41"})
+        out["model_512"] = (f"MaskGiTUViT(force_down_up_sample=True), {sum(p.numel() for p in tr.parameters()) / 1e6:.1f} M parameters, 1024 tokens "
+                            f"(256 inside), 512 x 512 decode; otherwise as above")
+        for bs in (1, 8):
+            enc = torch.randn(1, 77, 768, device=device, generator=g)
+            pooled = torch.randn(1, 768, device=device, generator=g)
+            empty, empty_p = torch.randn(1, 77, 768, device=device, generator=g), torch.randn(1, 768, device=device, generator=g)
+
+            def call512(steps):
+                return pipe(prompt_embeds=enc, pooled_embeds=pooled, empty_embeds=empty, empty_pooled_embeds=empty_p, num_images_per_prompt=bs,
+                            timesteps=steps, transformer_seq_len=1024, orig_size=(512, 512), output_type="np", use_tqdm=False,
+                            generator=torch.Generator(device=device).manual_seed(1))
+            call512(2)
+            call512(timesteps)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                call512(timesteps)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            out[f"pipeline_ms_bs{bs}_512"] = round(statistics.median(ts), 1)
+    except Exception as e:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
+        out["error_512"] = f"{type(e).__name__}: {str(e)[:200]}"
     del pipe, tr, vae
     torch.cuda.empty_cache()
     return out

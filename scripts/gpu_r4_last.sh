@@ -11,6 +11,6 @@ d = json.loads([l for l in open("$O/r4_last_bench.json") if l.startswith("{")][-
 e = d["extra"]
 print("value", d["value"], "ms", d["ms_per_step"], "frac", d["roofline"]["frac"], "tr", e["transformer_mfma_frac"], e["transformer_fwd_bwd_ms"])
 print("c5", e.get("vqgan_encode_decode_images_per_s_bf16x3"), "c4", e["config4_uvit_seq256"]["images_per_s"], e["config4_uvit_seq1024"]["images_per_s"], "x3", e["config4_uvit_seq256_bf16x3"]["images_per_s"], "f32", e["config4_uvit_seq256_f32"]["images_per_s"])
-print("latency", {k: v for k, v in e["inference_latency"].items() if "ms" in k and "ref" not in k})
+print("latency", {k: v for k, v in e["inference_latency"].items() if ("ms" in k or "error" in k) and "ref" not in k})
 print(len(open("$O/r4_last_bench.json").read().strip().splitlines()), "stdout line(s)")
 PY
