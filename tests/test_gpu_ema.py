@@ -118,3 +118,51 @@ def test_ema_around_a_training_step_and_validation_swap(golden_dir, cd):
         ema.restore(model.parameters())
         assert all(torch.equal(a, b) for a, b in zip(live, model.parameters()))
         assert torch.equal(model(*args), logits_live)
+
+
+def test_offline_ema_script_flow(golden_dir, tmp_path):
+    """scripts/compute_offline_ema.py of the reference, statement for statement: the class from the checkpoint's config.json, the first
+    checkpoint loaded with from_pretrained(Path).to(device), EMAModel(parameters=, decay=, update_every=interval), ema.to(device), one
+    step() per training step with a NEW model object loaded at every checkpoint (other tensors behind the same EMA), copy_to,
+    save_pretrained - against the oracle on the same parameter sequence"""
+    from pathlib import Path
+    import muse
+    from muse import EMAModel, MaskGiTUViT, MaskGitTransformer
+    from oracle import ema_oracle as E
+    cfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    g = np.load(os.path.join(golden_dir, "uvit_tiny.npz"))
+    sd = {k[len("param."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param.")}
+    interval, end_step, decay = 3, 9, 0.95
+    root = Path(tmp_path)
+    states = {}
+    for step in (0, 3, 6, 9):                                    # checkpoint-<n>/unwrapped_model, as the training script writes them
+        m = MaskGiTUViT(**cfg)
+        m.load_state_dict({k: v * (1.0 + 0.01 * step) for k, v in sd.items()}, strict=True)
+        m.save_pretrained(root / f"checkpoint-{step}" / "unwrapped_model")
+        states[step] = [p.detach().numpy().copy() for p in m.parameters()]
+    dirs = sorted(root.glob("checkpoint-*"), key=lambda p: int(p.name.split("-")[-1]))
+    transformer_config = MaskGitTransformer.load_config(dirs[0] / "unwrapped_model")
+    model_cls = MaskGitTransformer if transformer_config["_class_name"] == "MaskGitTransformer" else MaskGiTUViT
+    assert transformer_config["_class_name"] in ("MaskGiTUViT", "MaskGiTUViT_v2") and model_cls is MaskGiTUViT
+    device = "cuda"
+    model = model_cls.from_pretrained(dirs[0] / "unwrapped_model").to(device)
+    ema_model = EMAModel(parameters=model.parameters(), decay=decay, update_every=interval)
+    ema_model.to(device)
+    shadow, sched, current = [a.copy() for a in states[0]], E.Schedule(decay=decay, update_every=interval), states[0]
+    for step in range(0, end_step):
+        if (step + 1) % interval == 0:
+            model = model_cls.from_pretrained(root / f"checkpoint-{step + 1}" / "unwrapped_model")
+            model.to(device)
+            current = states[step + 1]
+        ema_model.step(model.parameters())
+        d = sched.next()
+        if d is not None:
+            shadow = E.ema_update(shadow, current, [True] * len(shadow), d)
+    assert ema_model.optimization_step == end_step
+    for a, b in zip(ema_model.shadow_params, shadow):
+        assert np.array_equal(a.cpu().numpy(), b)
+    ema_model.copy_to(model.parameters())
+    model.save_pretrained(root / "ema")
+    back = model_cls.from_pretrained(root / "ema")
+    assert all(np.array_equal(p.detach().numpy(), b) for p, b in zip(back.parameters(), shadow))
+

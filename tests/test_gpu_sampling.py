@@ -295,6 +295,43 @@ def test_the_reference_latency_benchmark_flow_runs_unchanged(golden_dir, tmp_pat
     assert t.mean > 0
 
 
+def test_the_inpainting_log_script_flow(golden_dir, tmp_path):
+    """scripts/log_inpainting_images.py of the reference: PipelineMuseInpainting.from_pretrained(model_name_or_path=,
+    is_class_conditioned=).to(device=), the xformers switch on pipe.transformer, a numpy-built token mask moved to the device as bool, a
+    PIL image resized to image_size, pipe(image=, mask=, class_ids= | text=, timesteps=, guidance_scale=, temperature=,
+    use_maskgit_generate=, num_images_per_prompt=, image_size=) -> PIL images; class-conditional and text (real tiny CLIP tower)"""
+    from PIL import Image
+    import muse
+    from muse import PipelineMuseInpainting
+    rng = np.random.default_rng(3)
+    picture = Image.fromarray((rng.random((40, 56, 3)) * 255).astype(np.uint8))
+    # class-conditional checkpoint
+    d = str(tmp_path / "cls")
+    muse.PipelineMuse(vae=muse.MaskGitVQGAN(**W.VQGAN_TINY), transformer=muse.MaskGitTransformer(**W.TRANSFORMER_TINY),
+                      is_class_conditioned=True).save_pretrained(d)
+    pipe = PipelineMuseInpainting.from_pretrained(model_name_or_path=d, is_class_conditioned=True).to(device=DEV)
+    pipe.transformer.enable_xformers_memory_efficient_attention()
+    image_size, vae_scaling_factor = 16, 4
+    class_ids = torch.tensor([7]).to(device=DEV, dtype=torch.long)
+    mask = np.zeros((image_size // vae_scaling_factor, image_size // vae_scaling_factor))
+    mask[1:3, 0:2] = 1
+    mask = torch.tensor(mask.reshape(-1)).to(DEV, dtype=torch.bool)
+    image = picture.resize((image_size, image_size))
+    images = pipe(image=image, mask=mask, class_ids=class_ids, timesteps=3, guidance_scale=2.0, temperature=1.0, use_maskgit_generate=True,
+                  num_images_per_prompt=2, image_size=image_size)
+    assert len(images) == 2 and all(im.size == (16, 16) and im.mode == "RGB" for im in images)
+    # text-conditioned checkpoint with its text encoder
+    ucfg = json.load(open(os.path.join(golden_dir, "config_uvit_tiny.json")))
+    enc, tok = W.tiny_clip(str(tmp_path / "clip_src"), hidden=ucfg["encoder_hidden_size"], pooled=ucfg["cond_embed_dim"])
+    d = str(tmp_path / "txt")
+    muse.PipelineMuse(vae=muse.MaskGitVQGAN(**W.VQGAN_TINY), transformer=muse.MaskGiTUViT(**ucfg), text_encoder=enc, tokenizer=tok).save_pretrained(d)
+    pipe = PipelineMuseInpainting.from_pretrained(model_name_or_path=d, is_class_conditioned=False).to(device=DEV)
+    pipe.transformer.enable_xformers_memory_efficient_attention()
+    images = pipe(image=image, mask=mask, text="a small boat", timesteps=3, guidance_scale=2.0, temperature=1.0, use_maskgit_generate=True,
+                  num_images_per_prompt=2, image_size=image_size)
+    assert len(images) == 2 and all(im.size == (16, 16) for im in images)
+
+
 def test_the_reference_benchmark_script_flow_runs_unchanged(golden_dir):
     """scripts/benchmark_models.py of the reference, statement for statement, on a reference-written config: load_config(path) ->
     from_config(config).to(device) -> eval() -> generate2(encoder_hidden_states=fp32 states) -> half() on the states and the model ->
