@@ -511,6 +511,32 @@ def golden_checkpoints():
         print("checkpoint", name, sorted(os.listdir(os.path.join(out, name))), sum(v.numel() for v in sd.values()), "parameters")
 
 
+def golden_sampling_helpers(name, seed):
+    """muse/sampling.py of the reference on seeded inputs: every schedule get_mask_chedule knows, log, top_k, gumbel_sample and
+    mask_by_random_topk with seeded CPU generators"""
+    from muse import sampling as S
+    g = torch.Generator().manual_seed(seed)
+    t = torch.cat([torch.tensor([0.0, 1.0, 0.5]), torch.rand(13, generator=g)])
+    out = dict(t=np_(t), seed=np.int64(seed))
+    for method in ("cosine", "linear", "pow0.5", "pow2", "pow3.5", "sigmoid"):
+        out["schedule." + method] = np_(S.get_mask_chedule(method)(t))
+    out["schedule.sigmoid_kw"] = np_(S.get_mask_chedule("sigmoid", start=-2, end=4, tau=0.7)(t))
+    x = torch.rand(4, 9, generator=g) * torch.tensor([1.0, 1e-3, 1e-12, 1e-25]).view(4, 1)
+    out["log.in"], out["log.out"] = np_(x), np_(S.log(x))
+    logits = torch.randn(2, 5, 16, generator=g)
+    out["top_k.in"] = np_(logits)
+    for thres in (0.9, 0.5, 0.97):
+        out[f"top_k.{thres}"] = np_(S.top_k(logits, thres))
+    out["gumbel_sample.t1"] = np_(S.gumbel_sample(logits, temperature=1.0, generator=torch.Generator().manual_seed(seed + 1)))
+    out["gumbel_sample.t0"] = np_(S.gumbel_sample(logits, temperature=0.0, generator=torch.Generator().manual_seed(seed + 2)))
+    probs = torch.softmax(torch.randn(3, 16, generator=g), dim=-1)
+    mask_len = torch.tensor([[1], [7], [15]])
+    out["mask.probs"], out["mask.len"] = np_(probs), np_(mask_len)
+    out["mask.out"] = np_(S.mask_by_random_topk(mask_len, probs, temperature=2.0, generator=torch.Generator().manual_seed(seed + 3)))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "masked per row", out["mask.out"].sum(-1).tolist())
+
+
 def replay_decode_noise(seed, steps, rows, seq, vocab):
     """the draws a reference generate2 call makes from torch.Generator().manual_seed(seed), per step: torch.multinomial(probs
     [rows*seq, vocab], 1) fills an Exp(1) tensor of the probabilities' shape (ATen multinomial_out, one-sample fast path), then
@@ -711,6 +737,7 @@ if __name__ == "__main__":
                           guidance_scale=3.0)
     golden_mask_muse("mask_muse", seed=540)
     golden_ema("ema_tiny", seed=560)
+    golden_sampling_helpers("sampling_helpers", seed=570)
     reference_configs()
     golden_checkpoints()
     golden_transformer_autocast("transformer_tiny_bf16", W.TRANSFORMER_TINY, batch=3, seed=100)

@@ -762,3 +762,26 @@ def test_precision_casts_select_the_compute_mode_and_keep_f32_masters(golden_dir
         assert v.float() is v and v.compute_dtype == torch.float32
         assert v.to(dtype=torch.bfloat16) is v and v.compute_dtype == "bf16x3" and all(p.dtype == torch.float32 for p in v.parameters())
         assert v.to("cpu") is v and v.compute_dtype == "bf16x3"
+
+
+def test_sampling_helpers_vs_reference_golden(golden_dir):
+    """muse.sampling's import-surface helpers against the REAL reference module on seeded inputs (tests/golden/sampling_helpers.npz,
+    make_golden.py::golden_sampling_helpers): every schedule get_mask_chedule knows (and its keyword form), log with its clamp, top_k,
+    gumbel_sample and mask_by_random_topk under seeded CPU generators - exact"""
+    from muse import sampling as S
+    g = np.load(os.path.join(golden_dir, "sampling_helpers.npz"))
+    seed, t = int(g["seed"]), torch.from_numpy(g["t"])
+    for method in ("cosine", "linear", "pow0.5", "pow2", "pow3.5", "sigmoid"):
+        got, want = S.get_mask_chedule(method)(t), torch.from_numpy(g["schedule." + method])
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), method
+    assert torch.allclose(S.get_mask_chedule("sigmoid", start=-2, end=4, tau=0.7)(t), torch.from_numpy(g["schedule.sigmoid_kw"]), rtol=1e-6, atol=1e-7)
+    assert torch.equal(S.log(torch.from_numpy(g["log.in"])), torch.from_numpy(g["log.out"]))
+    logits = torch.from_numpy(g["top_k.in"])
+    for thres in (0.9, 0.5, 0.97):
+        assert torch.equal(S.top_k(logits, thres), torch.from_numpy(g[f"top_k.{thres}"]))
+    assert torch.equal(S.gumbel_sample(logits, temperature=1.0, generator=torch.Generator().manual_seed(seed + 1)), torch.from_numpy(g["gumbel_sample.t1"]))
+    assert torch.equal(S.gumbel_sample(logits, temperature=0.0, generator=torch.Generator().manual_seed(seed + 2)), torch.from_numpy(g["gumbel_sample.t0"]))
+    got = S.mask_by_random_topk(torch.from_numpy(g["mask.len"]), torch.from_numpy(g["mask.probs"]), temperature=2.0,
+                                generator=torch.Generator().manual_seed(seed + 3))
+    assert torch.equal(got, torch.from_numpy(g["mask.out"])) and got.sum(-1).tolist() == [1, 7, 15]
+
