@@ -537,6 +537,54 @@ def golden_sampling_helpers(name, seed):
     print(name, "masked per row", out["mask.out"].sum(-1).tolist())
 
 
+LR_CASES = [("constant", {}), ("constant_with_warmup", dict(num_warmup_steps=5)), ("linear", dict(num_warmup_steps=4, num_training_steps=30)),
+            ("cosine", dict(num_warmup_steps=6, num_training_steps=30)), ("cosine_with_restarts", dict(num_warmup_steps=3, num_training_steps=30, num_cycles=3)),
+            ("polynomial", dict(num_warmup_steps=5, num_training_steps=30, power=2.0)), ("polynomial", dict(num_warmup_steps=0, num_training_steps=20))]
+
+
+def golden_lr_schedules(name, steps=36):
+    """muse/lr_schedulers.py::get_scheduler of the reference for every schedule name: the learning rates of two parameter groups (base
+    1e-3 and 2.5e-4) over `steps` scheduler steps - past the end of training for the ones that have one"""
+    from muse.lr_schedulers import get_scheduler
+    out = dict(steps=np.int64(steps))
+    for ci, (kind, kw) in enumerate(LR_CASES):
+        w = [torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(3))]
+        opt = torch.optim.AdamW([{"params": [w[0]]}, {"params": [w[1]], "lr": 2.5e-4}], lr=1e-3)
+        sched = get_scheduler(kind, opt, **kw)
+        lrs = []
+        for _ in range(steps):
+            lrs.append([g["lr"] for g in opt.param_groups])
+            opt.step()
+            sched.step()
+        out[f"case{ci}"] = np.asarray(lrs, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {c[0]: float(out[f"case{i}"][-1, 0]) for i, c in enumerate(LR_CASES)})
+
+
+def golden_training_utils(name, seed):
+    """muse/training_utils.py's logging diagnostics (the reference module) on a seeded batch of 12 images x 20 tokens x 16 classes whose
+    masked shares cover all ten buckets but one"""
+    from muse import training_utils as TU
+    g = torch.Generator().manual_seed(seed)
+    B, S, V, mask_id = 12, 20, 16, 15
+    tokens = torch.randint(0, V - 1, (B, S), generator=g)
+    counts = [1, 2, 3, 5, 7, 9, 11, 13, 16, 18, 20, 4]            # 0.05 ... 1.0 of 20 tokens: buckets 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 1
+    input_ids = tokens.clone()
+    for b, n in enumerate(counts):
+        input_ids[b, torch.randperm(S, generator=g)[:n]] = mask_id
+    labels = torch.where(input_ids == mask_id, tokens, torch.full_like(tokens, -100))
+    logits = torch.randn(B, S, V, generator=g) * 2
+    out = dict(input_ids=np_(input_ids), labels=np_(labels), logits=np_(logits), mask_id=np.int64(mask_id))
+    out["buckets"] = np_(TU.input_ids_to_masked_buckets(input_ids, mask_id))
+    out["pixel_entropy"] = np_(TU.pixel_entropy_per_percent_masked_bucket(logits.clone(), input_ids, mask_id))
+    out["image_entropy"] = np_(TU.image_entropy_per_percent_masked_bucket(logits.clone(), input_ids, mask_id))
+    out["cross_entropy"] = np_(TU.cross_entropy_per_percent_masked_bucket(logits.clone(), labels, input_ids, mask_id, V, 0.1))
+    df = TU.token_probability_distributions_per_percent_masked_bucket(logits.clone(), input_ids, mask_id)
+    out["dist.bucket"], out["dist.prob"] = df["bucket"].to_numpy().astype(np.int64), df["masked_pixel_prob"].to_numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "buckets", out["buckets"].tolist(), "rows", len(df))
+
+
 def replay_decode_noise(seed, steps, rows, seq, vocab):
     """the draws a reference generate2 call makes from torch.Generator().manual_seed(seed), per step: torch.multinomial(probs
     [rows*seq, vocab], 1) fills an Exp(1) tensor of the probabilities' shape (ATen multinomial_out, one-sample fast path), then
@@ -738,6 +786,8 @@ if __name__ == "__main__":
     golden_mask_muse("mask_muse", seed=540)
     golden_ema("ema_tiny", seed=560)
     golden_sampling_helpers("sampling_helpers", seed=570)
+    golden_lr_schedules("lr_schedules")
+    golden_training_utils("training_utils", seed=580)
     reference_configs()
     golden_checkpoints()
     golden_transformer_autocast("transformer_tiny_bf16", W.TRANSFORMER_TINY, batch=3, seed=100)

@@ -466,3 +466,9 @@ def tiny_clip(workdir, hidden=24, pooled=16, max_len=7, seed=5):
 VQGAN_CKPT = dict(VQGAN_TINY, channel_mult=(1, 1), num_res_blocks=1)
 TAMING_CKPT = dict(TAMING_TINY, channel_mult=(1, 1), num_res_blocks=1, attn_resolutions=(16,))
 
+
+# the schedule cases of tests/golden/lr_schedules.npz (make_golden.py::golden_lr_schedules keeps the same list)
+LR_CASES = [("constant", {}), ("constant_with_warmup", dict(num_warmup_steps=5)), ("linear", dict(num_warmup_steps=4, num_training_steps=30)),
+            ("cosine", dict(num_warmup_steps=6, num_training_steps=30)), ("cosine_with_restarts", dict(num_warmup_steps=3, num_training_steps=30, num_cycles=3)),
+            ("polynomial", dict(num_warmup_steps=5, num_training_steps=30, power=2.0)), ("polynomial", dict(num_warmup_steps=0, num_training_steps=20))]
+

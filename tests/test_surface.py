@@ -785,3 +785,87 @@ def test_sampling_helpers_vs_reference_golden(golden_dir):
                                 generator=torch.Generator().manual_seed(seed + 3))
     assert torch.equal(got, torch.from_numpy(g["mask.out"])) and got.sum(-1).tolist() == [1, 7, 15]
 
+
+def test_lr_schedules_vs_reference_golden(golden_dir):
+    """`from muse.lr_schedulers import get_scheduler` (training/train_muse.py:61,512-517): every schedule name of the reference over a
+    whole run and past its end, two parameter groups, on muse.FusedAdamW's param_groups - the learning rates the REAL module produced
+    (tests/golden/lr_schedules.npz) to the last bit of float64 arithmetic that is order-independent (1e-15 relative); argument errors as
+    the reference raises them"""
+    import weights as W
+    import muse
+    from muse.lr_schedulers import SchedulerType, get_scheduler
+    g = np.load(os.path.join(golden_dir, "lr_schedules.npz"))
+    steps = int(g["steps"])
+    for ci, (kind, kw) in enumerate(W.LR_CASES):
+        w = [torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(3))]
+        opt = muse.FusedAdamW([{"params": [w[0]]}, {"params": [w[1]], "lr": 2.5e-4}], lr=1e-3)
+        sched = get_scheduler(kind, opt, **kw)
+        got = []
+        for _ in range(steps):
+            got.append([grp["lr"] for grp in opt.param_groups])
+            sched.step()                      # (the optimizer itself has no CPU path: only the schedule is under test here)
+        np.testing.assert_allclose(np.asarray(got), g[f"case{ci}"], rtol=1e-15, atol=0, err_msg=kind)
+    opt = muse.FusedAdamW([torch.nn.Parameter(torch.zeros(2))], lr=1e-3)
+    assert SchedulerType("cosine") is SchedulerType.COSINE
+    with pytest.raises(ValueError, match="requires `num_warmup_steps`"):
+        get_scheduler("linear", opt)
+    with pytest.raises(ValueError, match="requires `num_training_steps`"):
+        get_scheduler("cosine", opt, num_warmup_steps=3)
+    with pytest.raises(ValueError):
+        get_scheduler("not_a_schedule", opt)
+    with pytest.raises(ValueError, match="must be be smaller than initial lr"):
+        get_scheduler("polynomial", muse.FusedAdamW([torch.nn.Parameter(torch.zeros(2))], lr=1e-8), num_warmup_steps=1, num_training_steps=5)
+
+
+def test_training_utils_diagnostics_vs_reference_golden(golden_dir):
+    """`muse.training_utils` as training/train_muse.py uses it (:50, :1319-1375): the masked-share buckets and the four logging
+    diagnostics on the batch of tests/golden/training_utils.npz equal what the REAL reference module returned (bit for bit: the same
+    torch reductions on the CPU), including the data frame of token distributions; set_seed seeds `random`, numpy and torch"""
+    import random
+    from muse import training_utils as TU
+    import muse.training_utils                                  # noqa: F401  (the script's import form)
+    g = np.load(os.path.join(golden_dir, "training_utils.npz"))
+    ids, labels, logits = (torch.from_numpy(g[k]) for k in ("input_ids", "labels", "logits"))
+    mask_id = int(g["mask_id"])
+    buckets = TU.input_ids_to_masked_buckets(ids, mask_id)
+    assert buckets.dtype == torch.long and torch.equal(buckets, torch.from_numpy(g["buckets"])) and sorted(set(buckets.tolist())) == list(range(10))
+    assert torch.equal(TU.pixel_entropy_per_percent_masked_bucket(logits.clone(), ids, mask_id), torch.from_numpy(g["pixel_entropy"]))
+    assert torch.equal(TU.image_entropy_per_percent_masked_bucket(logits.clone(), ids, mask_id), torch.from_numpy(g["image_entropy"]))
+    assert torch.equal(TU.cross_entropy_per_percent_masked_bucket(logits.clone(), labels, ids, mask_id, logits.shape[-1], 0.1),
+                       torch.from_numpy(g["cross_entropy"]))
+    df = TU.token_probability_distributions_per_percent_masked_bucket(logits.clone(), ids, mask_id)
+    assert list(df.columns) == ["bucket", "masked_pixel_prob"]
+    assert np.array_equal(df["bucket"].to_numpy(), g["dist.bucket"]) and np.array_equal(df["masked_pixel_prob"].to_numpy().astype(np.float32), g["dist.prob"])
+    empty = TU.average_by_buckets(torch.tensor([2.0, 4.0]), torch.tensor([3, 3]), 10)
+    assert empty.tolist() == [0, 0, 0, 3.0, 0, 0, 0, 0, 0, 0]
+    TU.set_seed(5)
+    a = (random.random(), float(np.random.rand()), float(torch.rand(())))
+    TU.set_seed(5)
+    assert a == (random.random(), float(np.random.rand()), float(torch.rand(())))
+
+
+def test_the_training_scripts_import_block_resolves():
+    """the import statements of training/train_muse.py:49-61 and training/train_maskgit_imagenet.py:37-40, verbatim: every name exists;
+    the two tokenizers outside the build refuse to construct instead of being absent at import time"""
+    import muse
+    import muse.training_utils                                                        # noqa: F401
+    from muse import (                                                                # noqa: F401
+        MOVQ,
+        EMAModel,
+        MaskGitTransformer,
+        MaskGiTUViT,
+        MaskGitVQGAN,
+        PaellaVQModel,
+        VQGANModel,
+        get_mask_chedule,
+    )
+    from muse.lr_schedulers import get_scheduler                                      # noqa: F401
+    from muse.sampling import cosine_schedule                                         # noqa: F401
+    from muse import PipelineMuse, PipelineMuseInpainting                             # noqa: F401  (scripts/*.py)
+    for cls in (MOVQ, PaellaVQModel):
+        with pytest.raises(NotImplementedError, match="not part of the MI355X hot-path build"):
+            cls()
+        with pytest.raises(NotImplementedError):
+            cls.from_pretrained("anything")
+    assert muse.__version__ == "0.0.1"
+
