@@ -231,7 +231,6 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             raise NotImplementedError("MI355X build of MaskGiTUViT_v2: only the bias-free GLU family is built (norm_type rmsnorm or "
                                       "layernorm, with or without learnable gains, with or without the forced down/up-sampling)")
         self.__dict__["_default_norm_mode"] = 1 if c.norm_type == "layernorm" else 0     # (Norm, reference :632-641)
-        _NORM_AFFINE[0] = bool(c.ln_elementwise_affine)
         if c.hidden_dropout != 0.0 or c.attention_dropout != 0.0:
             raise NotImplementedError("dropout > 0 is outside the MI355X hot-path build")
         H, C, cin = c.hidden_size, c.block_out_channels[0], c.in_channels
@@ -239,6 +238,14 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             if width % heads != 0:                                                     # configs/cc12m_uvit_clip.yaml as shipped (1024 channels, 12 heads)
                 raise ValueError(f"self.hidden_size: {width} must be divisible by self.num_heads: {heads}")     # trips it
         self.output_size = c.codebook_size
+        try:   # the submodules read the gain mode while they are built; whatever happens in between, the module-level default comes back
+            _NORM_AFFINE[0] = bool(c.ln_elementwise_affine)
+            self._build_submodules(c, H, C, cin)
+        finally:
+            _NORM_AFFINE[0] = True
+        self._init_weights()
+
+    def _build_submodules(self, c, H, C, cin):
         self.encoder_proj = _Lin(c.encoder_hidden_size, H)
         self.encoder_proj_layer_norm = _NormW(H)
         self.embed = _Embed(c.vocab_size, cin, C)
@@ -256,8 +263,6 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         self.fuse_norm_adaln = os.environ.get("MUSE_NORM_ADALN", "1") != "0"  # norm + AdaLN of a transformer layer as one kernel (fwd and bwd)
         self.batch_adaln_mappers = os.environ.get("MUSE_ADALN_BATCH", "1") != "0"   # every AdaLN mapper in a few batched products
         self._side_stream = None
-        _NORM_AFFINE[0] = True
-        self._init_weights()
 
     def _init_weights(self):
         """reference :205-237: trunc_normal(0.02) for Linear / Conv / Embedding, ones for norm gains, then the special cases"""

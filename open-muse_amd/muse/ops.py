@@ -109,6 +109,12 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
         sk = min(256 // t128, K // 128, 16) if t128 <= 96 else 1
         if sk >= 2:
+            # the kernels cut K on 64-wide tile boundaries, ceil(nk / sk) tiles per slice: a slice that starts at or beyond nk returns
+            # without writing its part of the workspace, so only the slices that hold work may be summed (M=256, K=2816: 16 -> 15)
+            nk = (K + 63) // 64
+            per = (nk + sk - 1) // sk
+            sk = (nk + per - 1) // per
+        if sk >= 2:
             ws = torch.empty((sk, M, N), dtype=torch.float32, device=A.device)
             gemm(A, B, ws, M, N, K, la=0, lb=0, lda=lda, ldb=ldb, ldc=N, a_off=a_off, b_off=b_off, alpha=alpha, split_k=sk, split_stride=M * N)
             check(lib().muse_sum_slices_epilogue(ws.data_ptr(), sk, M * N, ptr(bias), ptr(residual), ldr, C_.data_ptr() + c_off * _esz(C_),
@@ -415,6 +421,7 @@ def linear_wgrad_group(items, colsums=None, split=None):
             N = M if M is not None else N
             K = x.shape[1]
             ok = ok and dw.dtype == torch.float32 and dw.is_contiguous() and (N * K) % 4 == 0
+            ok = ok and (split == 1 or dw.data_ptr() % 16 == 0)   # muse_sum_multi's slice sums store 16 bytes at a time
             d.A, d.B = dy.data_ptr(), x.data_ptr()
             d.dtype, d.out_dtype, d.layout_a, d.layout_b = BF16, F32, 1, 1
             d.M, d.N, d.K, d.batch, d.zdiv = N, K, T_, 1, 1

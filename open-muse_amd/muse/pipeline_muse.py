@@ -66,11 +66,13 @@ class PipelineMuse:
         if text is not None and class_ids is not None:
             raise ValueError("Only one of text or class_ids may be provided.")
         if text is not None and prompt_embeds is None:
-            e = self._encode_text(text, negative_text if negative_prompt_embeds is None else None, clip_skip)
+            e = self._encode_text(text, negative_text if negative_prompt_embeds is None else None, clip_skip,
+                                  want_empty=negative_prompt_embeds is None)
             prompt_embeds, pooled_embeds = e["prompt_embeds"], e["pooled_embeds"]
             if e["negative_prompt_embeds"] is not None:
                 negative_prompt_embeds, negative_pooled_embeds = e["negative_prompt_embeds"], e["negative_pooled_embeds"]
-            if e["empty_embeds"] is not None:
+            # (reference :178-186: the empty prompt's states only when there are no negative states, supplied or encoded)
+            if e["empty_embeds"] is not None and negative_prompt_embeds is None:
                 empty_embeds, empty_pooled_embeds = e["empty_embeds"], e["empty_pooled_embeds"]
         ids, intermediate = self._generate(None, class_ids, prompt_embeds, pooled_embeds, negative_prompt_embeds, negative_pooled_embeds,
                                            empty_embeds, empty_pooled_embeds, timesteps, noise_schedule, guidance_scale, guidance_schedule,
@@ -82,7 +84,7 @@ class PipelineMuse:
         return images
 
     # ---- text states from the pipeline's own encoder (reference :107-190) -------------------------------------------------------------------
-    def _encode_text(self, text, negative_text, clip_skip=None):
+    def _encode_text(self, text, negative_text, clip_skip=None, want_empty=True):
         """tokenizer + text encoder called as the reference calls them: penultimate (or `clip_skip`) hidden state + `text_embeds` for a
         transformer with `add_cond_embeds` (CLIPTextModelWithProjection), `last_hidden_state` otherwise (T5 / plain CLIP); the negative
         prompt likewise (always the penultimate layer, :149-152); without a negative prompt the empty prompt's states for
@@ -111,7 +113,7 @@ class PipelineMuse:
             negative_text = [negative_text] * len(text) if isinstance(negative_text, str) else list(negative_text)
             nh, npool = states(negative_text, -2)
             out.update(negative_prompt_embeds=f32(nh), negative_pooled_embeds=f32(npool))
-        else:
+        elif want_empty:   # (not when the caller brought pre-computed negative states: no extra encoder pass, no second conditioning source)
             empty = tok("", padding="max_length", return_tensors="pt").input_ids.to(self.device)
             o = enc(empty, output_hidden_states=True)
             out.update(empty_embeds=f32(o.hidden_states[-2]), empty_pooled_embeds=f32(o[0]))

@@ -621,6 +621,11 @@ class GradReducer:
             return                                   # no_sync(): this micro-batch's gradients stay local (autograd accumulates them)
         if not self._pending and not self._deferred and any(p.grad is not None for p in self._params):
             self._deferred = True                    # gradients of earlier micro-batches exist: reduce the sums after backward (finish)
+            # ... also when the earlier backward of this step was itself reduced in-backward (two synchronising backwards before one
+            # finish()): its averaged gradients are identical on every rank, so averaging the sums again yields avg(g1) + avg(g2),
+            # what DDP's per-backward all-reduce produces.  Without this, finish() took the "already reduced" early return and every
+            # rank kept avg(g1) + its LOCAL g2.
+            self._in_backward_done = False
         if self._deferred:
             return
         for t in tensors:

@@ -1230,7 +1230,10 @@ def test_upsample2x_matches_interpolate(dtype):
 
 
 @pytest.mark.parametrize("M,N,K,out_dtype", [(512, 1024, 1024, torch.float32), (512, 1024, 1024, torch.bfloat16), (300, 5632, 1024, torch.bfloat16),
-                                             (2048, 1024, 2816, torch.float32), (77, 2048, 768, torch.bfloat16)])
+                                             (2048, 1024, 2816, torch.float32), (77, 2048, 768, torch.bfloat16),
+                                             # slice counts that do not divide the K-tiles (16 asked / 15 hold work, 5 / 4): the empty
+                                             # trailing slice of the workspace is never written and must not be summed
+                                             (256, 1024, 2816, torch.float32), (768, 1024, 1024, torch.bfloat16)])
 def test_small_batch_forward_products_split_k(M, N, K, out_dtype, monkeypatch):
     """small-batch decoding path of ops.gemm: a forward Linear of <= 2048 rows whose 128^2 tiles would fill a fraction of the chip is cut
     along K into an f32 workspace and summed by muse_sum_slices_epilogue together with the Linear's epilogue (bias, residual, output

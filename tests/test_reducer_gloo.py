@@ -363,6 +363,13 @@ def _worker_accumulate(rank, world, port, out):
     res["tape_next_in_backward"] = len(launched)
     redt.finish()
     res["tape_next"] = [p.grad.clone() for p in mt.parameters()]
+    # two SYNCHRONISING backwards before one finish() (accumulation without no_sync): the first is reduced from inside backward, the
+    # second finds gradients and is deferred - finish() must still reduce the sums (DDP: avg(g1) + avg(g2) on every rank)
+    mt.zero_grad(set_to_none=True)
+    mt(x1).backward()
+    mt(x2).backward()
+    redt.finish()
+    res["tape_two_sync"] = [p.grad.clone() for p in mt.parameters()]
     torch.save(res, os.path.join(out, f"acc{rank}.pt"))
     dist.destroy_process_group()
 
@@ -387,4 +394,6 @@ def test_grad_reducer_no_sync_accumulation_world2(tmp_path):
         assert torch.equal(g0, g1) and torch.allclose(g0, torch.full_like(g0, sum(per_rank) / world) + 2 * ramp)
         assert torch.allclose(r[0]["tape_local"][j], torch.full_like(g0, 18.0) + ramp)           # rank 0 after the no_sync micro-batch: its own
         assert torch.allclose(r[0]["tape_next"][j], torch.full_like(g0, 27.0) + ramp)
+        t0, t1 = r[0]["tape_two_sync"][j], r[1]["tape_two_sync"][j]
+        assert torch.equal(t0, t1) and torch.allclose(t0, torch.full_like(g0, sum(per_rank) / world) + 2 * ramp)
 
