@@ -19,17 +19,12 @@
 // slot(g, j) <-> key 32s + 16*(j>>2) + 4g + (j&3), which the V^T operand reproduces through its tr-read row addresses.
 // head_dim 48 contracts as one K=32 MFMA plus one K=16 MFMA (v_mfma_f32_16x16x16_bf16) instead of two half-empty K=32 ones.
 #include "common.h"
+#include "attention_params.h"
 #include "../../include/muse_hip.h"
 #include <stdlib.h>
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-}
-#define ATT_OOB 0x7ffffff0u
 
 template <int HD> struct HeadCfg {
   static constexpr int N32 = HD / 32;               // K = 32 steps of the head-dim contraction
@@ -182,18 +177,6 @@ __device__ __forceinline__ float quad_g_max(float v) {
   return v;
 }
 
-struct AttnParams {
-  const bf16_t *q, *k, *v, *o, *d_o;       // o / d_o: forward output (read by backward), upstream gradient
-  bf16_t *out, *dq, *dk, *dv;              // out: forward ctx
-  float *lse, *dsum;                       // [batch*heads, sqp]
-  long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;   // elements between consecutive tokens
-  long bq, bk, bv, bo, bdo, bdq, bdk, bdv;           // elements between consecutive images
-  int nh, sq, skv, sqp;
-  int nchunk, chunk_rows;                  // stationary rows per workgroup (multiple of 16)
-  int tile_rows, ntile;                    // streamed rows per LDS tile (multiple of 32), number of tiles
-  int shared;                              // 1: the workgroup's last stationary tile is split over all waves (see below)
-  float alpha;
-};
 
 // blockIdx -> logical work item such that consecutive logical items (chunks of one head) run on one XCD (block b runs on XCD b % 8)
 __device__ __forceinline__ int xcd_remap() {
@@ -817,6 +800,10 @@ extern "C" int muse_attention_fwd_ex(const muse_attn_desc* d, float* lse, void* 
   AttnParams P = base_params(d);
   P.out = (bf16_t*)d->o; P.lse = lse;
   hipStream_t st = (hipStream_t)stream;
+  {   // one-tile self-attention at head_dim 48 (S = 257): the 32 x 32-block kernels of attention2.hip
+    const int r2 = attn2_fwd_try(P, d->head_dim, d->batch, st);
+    if (r2 != 0) return r2 > 0 ? 0 : -r2;
+  }
   switch (d->head_dim) {
     case 16: return attn_fwd_launch<16>(P, d->batch, st);
     case 32: return attn_fwd_launch<32>(P, d->batch, st);
@@ -842,6 +829,11 @@ extern "C" int muse_attention_bwd_ex(const muse_attn_desc* d, const void* d_o, i
   P.dk = (bf16_t*)dk; P.lddk = lddk; P.bdk = bsdk;
   P.dv = (bf16_t*)dv; P.lddv = lddv; P.bdv = bsdv;
   hipStream_t st = (hipStream_t)stream;
+  {   // (the fused backward wants 16-byte aligned gradient rows: its stores are 16 bytes wide)
+    const bool al16 = (((uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0;
+    const int r2 = al16 ? attn2_bwd_try(P, d->head_dim, d->batch, st) : 0;
+    if (r2 != 0) return r2 > 0 ? 0 : -r2;
+  }
   switch (d->head_dim) {
     case 16: return attn_bwd_launch<16>(P, d->batch, st);
     case 32: return attn_bwd_launch<32>(P, d->batch, st);

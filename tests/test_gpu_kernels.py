@@ -585,6 +585,48 @@ def test_fused_attention_fwd_bwd(B, S, nh, hd):
         assert e < 3e-2, (nm, e)
 
 
+@pytest.mark.parametrize("B,S,nh,wgs", [(5, 257, 4, 1), (3, 257, 16, 0), (3, 256, 4, 1), (2, 240, 3, 1), (3, 258, 4, 1), (2, 260, 3, 0), (2, 225, 2, 0)])
+def test_one_tile_attention_blocks32(B, S, nh, wgs, monkeypatch):
+    """attention2.hip (32 x 32 MFMA blocks, exact softmax, persistent workgroups with LDS-DMA prefetch, ONE fused backward kernel) on
+    the shapes it takes (self-attention, head_dim 48, 225 <= S <= 260): against float64 on the same bf16 inputs, and against the
+    general kernels of attention.hip (MUSE_ATTN2=0) - both round P to bf16 once, so they agree far inside the f64 tolerance.
+    `wgs` = 1: eight workgroups walk all heads (buffer swap, delayed stores, the next head's DMA under the current head's math)."""
+    ops = _ops()
+    hd = 48
+    H = nh * hd
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+    qkv = (rnd((B * S, 3 * H), 140, 1.0)).to(torch.bfloat16)
+    dctx = rnd((B * S, H), 141).to(torch.bfloat16)
+    x = qkv.double().view(B, S, 3, nh, hd).requires_grad_(True)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    sc = q @ k.transpose(-1, -2) * alpha
+    ref = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B * S, H)
+    ref.backward(dctx.double())
+    g = x.grad.reshape(B * S, 3 * H)
+    if wgs:
+        monkeypatch.setenv("MUSE_ATTN2_WGS_PER_XCD", str(wgs))
+    monkeypatch.setenv("MUSE_ATTN2", "1")
+    ctx, lse = ops.attention_fwd(qkv.to(DEV), B, S, nh, hd, alpha)
+    dqkv = ops.attention_bwd(qkv.to(DEV), ctx, dctx.to(DEV), lse, B, S, nh, hd, alpha)
+    monkeypatch.setenv("MUSE_ATTN2", "0")
+    ctx0, lse0 = ops.attention_fwd(qkv.to(DEV), B, S, nh, hd, alpha)
+    dqkv0 = ops.attention_bwd(qkv.to(DEV), ctx0, dctx.to(DEV), lse0, B, S, nh, hd, alpha)
+    assert torch.isfinite(ctx.float()).all() and torch.isfinite(dqkv.float()).all()
+    assert rel_err(ctx.float(), ref.detach()) < 1.5e-2
+    assert rel_err(lse[:, :S], torch.logsumexp(sc, dim=-1).reshape(B * nh, S).detach()) < 1e-3
+    for i, nm in enumerate("qkv"):
+        e = rel_err(dqkv[:, i * H:(i + 1) * H].float(), g[:, i * H:(i + 1) * H])
+        assert e < 3e-2, (nm, e)
+    # the two kernel families: same contract, different summation orders
+    assert rel_err(ctx.float(), ctx0.double()) < 8e-3 and rel_err(lse[:, :S], lse0[:, :S].double()) < 1e-4
+    assert rel_err(dqkv.float(), dqkv0.double()) < 1.5e-2
+    # every row of every head written (no stale rows from a skipped block): per-row agreement, not just a norm
+    rowdiff = (ctx.float() - ref.detach().float().to(DEV)).abs().amax(dim=1)
+    assert float(rowdiff.max()) < 0.1, float(rowdiff.max())
+    growdiff = (dqkv.float() - g.float().to(DEV)).abs().amax(dim=1) / g.abs().max().float()
+    assert float(growdiff.max()) < 0.1, float(growdiff.max())
+
+
 @pytest.mark.parametrize("B,Sq,Skv,nh,hd", [(2, 256, 77, 2, 64), (1, 1024, 77, 2, 64), (2, 40, 130, 2, 48), (1, 1024, 1024, 2, 64),
                                              (1, 600, 300, 1, 48), (2, 256, 256, 3, 32), (1, 1025, 1025, 1, 16), (2, 50, 7, 2, 64)])
 def test_fused_attention_general_lengths(B, Sq, Skv, nh, hd):
