@@ -99,8 +99,9 @@ __device__ __forceinline__ void lds_dma16(const i32x4& desc, unsigned lds_addr, 
                : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(desc) : "memory");
 }
 // one operand image [288 rows][STR] <- rows 0 .. rows_valid-1 of a head's [S][HD] slice (row r at r * ld_bytes); everything else zeros.
-// 32 (hd 48) wave-instructions, 4 per wave; the lane <-> slot map is linear (that is what the LDS side of the DMA does), the source
+// 32 (hd 48) wave-instructions, 8 per wave; the lane <-> slot map is linear (that is what the LDS side of the DMA does), the source
 // offset is per lane.
+constexpr int NW = 4;   // waves per workgroup
 template <int HD>
 __device__ __forceinline__ void dma_image(unsigned char* img, const void* base, unsigned bytes, unsigned ld_bytes, int rows_valid,
                                           const LaneGeom& g) {
@@ -108,7 +109,7 @@ __device__ __forceinline__ void dma_image(unsigned char* img, const void* base, 
   const i32x4 desc = dma_desc(base, bytes);
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(lds_u8*)img);
 #pragma unroll
-  for (int n0 = 0; n0 < C::NDMA; n0 += 8) {
+  for (int n0 = 0; n0 < C::NDMA; n0 += NW) {
     const int n = n0 + g.wave;
     if (n < C::NDMA) {
       const int s = n * 64 + g.lane;
@@ -216,227 +217,230 @@ __device__ __forceinline__ void store_rows(rsrc_t rs, unsigned ld_bytes, int blk
   for (int c = 0; c < Cfg<HD>::NST; ++c) __builtin_amdgcn_raw_buffer_store_b128(v[c], rs, (int)(ro + c * 32), 0, 0);
 }
 
-// this workgroup's heads: XCD x (= blockIdx & 7) owns a contiguous run of heads, its workgroups take them round robin
-struct HeadWalk {
-  int head, end, step;
-  __device__ __forceinline__ void init(int total) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int q = total >> 3, r = total & 7;
-    const int begin = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    end = begin + q + (xcd < r ? 1 : 0);
-    head = begin + slot;
-    step = gridDim.x >> 3;
-  }
-};
-
+// blockIdx -> head such that consecutive heads (the 16 heads of an image share the 128-byte lines of its packed qkv rows) run on one
+// XCD (block b runs on XCD b % 8)
+__device__ __forceinline__ int xcd_remap() {
+  const int nb = gridDim.x, id = blockIdx.x, xcd = id & 7, slot = id >> 3, q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+// my LDS-DMA pieces have landed, and so have everyone's (nothing else orders a ds_read behind a DMA)
 __device__ __forceinline__ void wait_all_and_barrier() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 }
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
 
-#ifdef ATT2_TS   // bring-up / timing experiments (scripts/exp/attn2_ts.py): s_memtime stamps per wave, 16 per head, first 4 heads of a workgroup
+// Two workgroups share a CU and every workgroup takes the same time: started together they stay in the same phase (both fetching,
+// then both computing) for the whole launch.  The workgroups of the SECOND dispatch round-robin (blockIdx ncu .. 2 ncu - 1: the
+// dispatcher fills one slot per CU before it starts on the second - observed, used for speed only) therefore wait `cycles` before
+// their first instruction; every later workgroup starts when a slot frees, i.e. already out of phase.
+__device__ __forceinline__ void stagger_start(int ncu, int cycles) {
+  if (cycles > 0 && (int)blockIdx.x >= ncu && (int)blockIdx.x < 2 * ncu) {
+    const long t0 = (long)__builtin_amdgcn_s_memtime();
+    while ((long)__builtin_amdgcn_s_memtime() - t0 < (long)cycles) __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+#ifdef ATT2_TS   // timing experiments (scripts/exp/attn2_ts.py): s_memtime stamps per wave
 __device__ long* g_ts = nullptr;
-#define ATT2_STAMP(K) do { __builtin_amdgcn_sched_barrier(0); if (g_ts && g.lane == 0 && ts_it < 4) g_ts[((long)(blockIdx.x * 8 + g.wave) * 4 + ts_it) * 16 + (K)] = (long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATT2_STAMP(K) do { __builtin_amdgcn_sched_barrier(0); if (g_ts && g.lane == 0) g_ts[((long)blockIdx.x * NW + g.wave) * 16 + (K)] = (long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define ATT2_STAMP(K)
 #endif
 
-// =================================================================================================================
-// forward
-// =================================================================================================================
+// Workgroup = ONE head, NW = 4 waves (one per SIMD), two workgroups per CU (64 KiB of images each, 256 VGPRs per wave): the two
+// co-resident workgroups are not synchronised with each other, so one's operand fetch, softmax VALU or store burst runs under the
+// other's MFMAs.  (First form of this file: one persistent 8-wave workgroup per CU with the next head's K / V prefetched by DMA -
+// every wave of the CU then sat in the same phase at the same time: a 6 k-cycle vector-memory issue burst, 3.6 k cycles of MFMA with
+// idle VALU, 3.6 k of VALU with idle MFMA, per head; 39 us against 42 for attention.hip, profiles/r05_attn2_v1_timeline.txt.)
 constexpr int MAXSH = 4;                      // real rows of the 9th block (S - 256)
 constexpr int FWD_PW = 52;                    // floats per (wave, query) of the shared block's partials: O[48] | m | l | pad
+constexpr int BWD_PW = 100;                   // phase 1 dQ[48]; phase 2 dK[48] | dV[48] (+ pad)
 
-template <int HD, bool TAIL>
-__global__ __launch_bounds__(512, 2) void fwd_kernel(const AttnParams P, int total_heads) {
-  using C = Cfg<HD>;
-  constexpr int NKB = TAIL ? 9 : 8;           // key blocks (block 8 holds S - 256 <= MAXSH keys)
-  constexpr int NFULL = 8;                    // blocks that are handled whole (query blocks owned by a wave)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* scratch = (float*)(smem + 4 * C::IMG);
-  const LaneGeom g = make_geom<HD>();
-  HeadWalk hw;
-  hw.init(total_heads);
-  if (hw.head >= hw.end) return;
-  const int S = P.sq;
-  const int nsh = S - 256;                                    // TAIL: real rows of block 8
-  const int last_valid = S - 32 * (NKB - 1);                  // real keys of the last key block
-  const unsigned ldq_b = (unsigned)P.ldq * 2, ldk_b = (unsigned)P.ldk * 2, ldv_b = (unsigned)P.ldv * 2, ldo_b = (unsigned)P.ldo * 2;
-  const float c = P.alpha * LOG2E;
-
-  auto rsrc_of = [&](const bf16_t* base, long bs, long ld, int head) {
-    const int b = head / P.nh, hh = head - b * P.nh;
-    return make_rsrc(base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2);
-  };
-  auto dma_of = [&](unsigned char* img, const bf16_t* base, long bs, long ld, int head) {
-    const int b = head / P.nh, hh = head - b * P.nh;
-    dma_image<HD>(img, base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2, (unsigned)ld * 2, S, g);
-  };
-  auto issue_head = [&](int head, int buf) {
-    unsigned char* Kimg = smem + buf * 2 * C::IMG;
-    dma_of(Kimg, P.k, P.bk, P.ldk, head);
-    dma_of(Kimg + C::IMG, P.v, P.bv, P.ldv, head);
-  };
-
-  issue_head(hw.head, 0);
-  FragB<HD> qn = load_fragb<HD>(rsrc_of(P.q, P.bq, P.ldq, hw.head), ldq_b, g.wave, g);
-  u32x4 pend[C::NST];
-  float pend_lse = 0.f;
-  int pend_head = -1, buf = 0;
-
-  int ts_it = 0;
-  (void)ts_it;
-  for (;;) {
-    const int head = hw.head;
-    ATT2_STAMP(0);
-    wait_all_and_barrier();                 // this head's images have landed (every wave waited for its own pieces); the other buffer is free
-    ATT2_STAMP(1);
-    const bool has_next = head + hw.step < hw.end;
-    const FragB<HD> qf = qn;
-    if (has_next) {
-      issue_head(head + hw.step, buf ^ 1);
-      qn = load_fragb<HD>(rsrc_of(P.q, P.bq, P.ldq, head + hw.step), ldq_b, g.wave, g);
-    }
-    if (pend_head >= 0) {                   // the previous head's rows go out a whole head before the next wait
-      store_rows<HD>(rsrc_of(P.out, P.bo, P.ldo, pend_head), ldo_b, g.wave, pend, g);
-      if (g.h == 0) P.lse[(long)pend_head * P.sqp + g.wave * 32 + g.n] = pend_lse;
-    }
-    FragB<HD> qs;
-    if (TAIL) qs = load_fragb<HD>(rsrc_of(P.q, P.bq, P.ldq, head), ldq_b, 8, g);   // the shared query block, used after the own block
-    ATT2_STAMP(2);
-    const unsigned char* Kimg = smem + buf * 2 * C::IMG;
-    const unsigned char* Vimg = Kimg + C::IMG;
-
-    // ---- own query block: scores against every key block, exact softmax, P V ----
-    {
-      f32x16 s[NFULL];
-      float st0 = NEG_BIG, st1 = NEG_BIG;   // TAIL: the two score registers of block 8 that can hold a real key (rows h and 2 + h)
+// B operand rows of a block whose only real rows are the first `nreal` (the 9th block): the other lanes load nothing
+template <int HD>
+__device__ __forceinline__ FragB<HD> load_fragb_few(rsrc_t rs, unsigned ld_bytes, int blk, int nreal, const LaneGeom& g) {
+  FragB<HD> r;
 #pragma unroll
-      for (int kb = 0; kb < NFULL; ++kb)
-        s[kb] = mma_rows<HD>(Kimg, g, kb, qf, (!TAIL && kb == NFULL - 1) ? mask16(last_valid, g.h) : zero16());
-      if (TAIL) {
-        const f32x16 t = mma_rows<HD>(Kimg, g, 8, qf, mask16(last_valid, g.h));
-        st0 = t[0]; st1 = t[4];
-      }
-      ATT2_STAMP(3);
-      float m = fmaxf(st0, st1);
+  for (int ks = 0; ks < Cfg<HD>::KS; ++ks) r.f[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+  if (g.n < nreal) r = load_fragb<HD>(rs, ld_bytes, blk, g);
+  return r;
+}
+template <int HD>
+__device__ __forceinline__ void write_partial(float* mine, const f32x16 (&acc)[Cfg<HD>::NDB], int h) {
 #pragma unroll
-      for (int kb = 0; kb < NFULL; ++kb)
+  for (int db = 0; db < Cfg<HD>::NDB; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kb][r]);
-      m = fmaxf(m, xhalf(m));
-      const float mc = m * c;
-      float l = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < NFULL; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc)); l += s[kb][r]; }
-      f32x16 pt = zero16();
-      if (TAIL) {
-        pt[0] = __builtin_amdgcn_exp2f(fmaf(st0, c, -mc));
-        pt[4] = __builtin_amdgcn_exp2f(fmaf(st1, c, -mc));
-        l += pt[0] + pt[4];
-      }
-      l += xhalf(l);
-      ATT2_STAMP(4);
-      f32x16 o[C::NDB];
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) o[db] = zero16();
-#pragma unroll
-      for (int kb = 0; kb < NFULL; ++kb) mma_seq<HD>(Vimg, g, kb, s[kb], 2, o);
-      if (TAIL) mma_seq<HD>(Vimg, g, 8, pt, 1, o);
-      ATT2_STAMP(5);
-      pack_rows<HD>(o, 1.0f / l, pend);
-      pend_lse = m * P.alpha + __logf(l);
-      pend_head = head;
-      ATT2_STAMP(6);
-    }
-
-    // ---- the 9th query block (S - 256 real rows): wave w takes key block w (wave 7 also block 8), partials meet in LDS ----
-    if (TAIL) {
-      const bool with_tail = g.wave == 7;
-      f32x16 sa = mma_rows<HD>(Kimg, g, g.wave, qs, zero16());
-      float st0 = NEG_BIG, st1 = NEG_BIG;
-      if (with_tail) {
-        const f32x16 t = mma_rows<HD>(Kimg, g, 8, qs, mask16(last_valid, g.h));
-        st0 = t[0]; st1 = t[4];
-      }
-      float m = fmaxf(st0, st1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r]);
-      m = fmaxf(m, xhalf(m));
-      const float mc = m * c;
-      float l = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sa[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c, -mc)); l += sa[r]; }
-      f32x16 pt = zero16();
-      if (with_tail) {
-        pt[0] = __builtin_amdgcn_exp2f(fmaf(st0, c, -mc));
-        pt[4] = __builtin_amdgcn_exp2f(fmaf(st1, c, -mc));
-        l += pt[0] + pt[4];
-      }
-      l += xhalf(l);
-      f32x16 o[C::NDB];
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) o[db] = zero16();
-      mma_seq<HD>(Vimg, g, g.wave, sa, 2, o);
-      if (with_tail) mma_seq<HD>(Vimg, g, 8, pt, 1, o);
-      if (g.n < nsh) {
-        float* mine = scratch + (g.wave * MAXSH + g.n) * FWD_PW;
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4)
-            if (32 * db + 8 * q4 < HD)
-              *(f32x4*)(mine + 32 * db + 8 * q4 + 4 * g.h) = f32x4{o[db][4 * q4], o[db][4 * q4 + 1], o[db][4 * q4 + 2], o[db][4 * q4 + 3]};
-        if (g.h == 0) { mine[HD] = m; mine[HD + 1] = l; }
-      }
-      ATT2_STAMP(7);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      ATT2_STAMP(8);
-      if (g.wave == 0) {
-        const int b = head / P.nh, hh = head - b * P.nh;
-        for (int idx = g.lane; idx < nsh * HD; idx += 64) {
-          const int q = idx / HD, d = idx - q * HD;
-          float mg = NEG_BIG;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) mg = fmaxf(mg, scratch[(w * MAXSH + q) * FWD_PW + HD]);
-          float lsum = 0.f, osum = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) {
-            const float* pw = scratch + (w * MAXSH + q) * FWD_PW;
-            const float f = __builtin_amdgcn_exp2f((pw[HD] - mg) * c);
-            lsum = fmaf(pw[HD + 1], f, lsum);
-            osum = fmaf(pw[d], f, osum);
-          }
-          P.out[b * P.bo + (long)(256 + q) * P.ldo + hh * HD + d] = f32_to_bf16(osum / lsum);
-          if (d == 0) P.lse[(long)head * P.sqp + 256 + q] = mg * P.alpha + __logf(lsum);
-        }
-      }
-    }
-    ATT2_STAMP(9);
-#ifdef ATT2_TS
-    ++ts_it;
-#endif
-    if (!has_next) break;
-    hw.head += hw.step;
-    buf ^= 1;
-  }
-  store_rows<HD>(rsrc_of(P.out, P.bo, P.ldo, pend_head), ldo_b, g.wave, pend, g);
-  if (g.h == 0) P.lse[(long)pend_head * P.sqp + g.wave * 32 + g.n] = pend_lse;
+    for (int q4 = 0; q4 < 4; ++q4)
+      if (32 * db + 8 * q4 < HD)
+        *(f32x4*)(mine + 32 * db + 8 * q4 + 4 * h) = f32x4{acc[db][4 * q4], acc[db][4 * q4 + 1], acc[db][4 * q4 + 2], acc[db][4 * q4 + 3]};
 }
 
 // =================================================================================================================
-// backward: one kernel, two phases per head
+// forward
 // =================================================================================================================
-// ATT2_BWD_UNROLL: unroll factor of the backward kernel's block loops (0 = fully unrolled).  Fully unrolled the compiler hoists the
-// operand reads of many blocks ahead and lands at 256 VGPRs with spills; a factor of 3 (9 = 3 x 3 blocks at S = 257) keeps a block's
-// softmax-backward VALU beside the next block's MFMAs without that.
+template <int HD, bool TAIL>
+__global__ __launch_bounds__(NW * 64, 2) void fwd_kernel(const AttnParams P, int ncu, int stagger) {
+  using C = Cfg<HD>;
+  constexpr int NKB = TAIL ? 9 : 8;           // key blocks (block 8 holds S - 256 <= MAXSH keys)
+  constexpr int NFULL = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + C::IMG;
+  float* scratch = (float*)(smem + 2 * C::IMG);
+  const LaneGeom g = make_geom<HD>();
+  stagger_start(ncu, stagger);
+  const int head = xcd_remap();
+  const int b = head / P.nh, hh = head - b * P.nh;
+  const int S = P.sq;
+  const int nsh = S - 256;                                    // TAIL: real rows of block 8
+  const int last_valid = S - 32 * (NKB - 1);                  // real keys of the last key block
+  const unsigned ldq_b = (unsigned)P.ldq * 2, ldo_b = (unsigned)P.ldo * 2;
+  const float c = P.alpha * LOG2E;
+  const rsrc_t rq = make_rsrc(P.q + b * P.bq + hh * HD, (unsigned)((S - 1) * P.ldq + HD) * 2);
+  const rsrc_t ro = make_rsrc(P.out + b * P.bo + hh * HD, (unsigned)((S - 1) * P.ldo + HD) * 2);
+
+  ATT2_STAMP(0);
+  dma_image<HD>(Kimg, P.k + b * P.bk + hh * HD, (unsigned)((S - 1) * P.ldk + HD) * 2, (unsigned)P.ldk * 2, S, g);
+  dma_image<HD>(Vimg, P.v + b * P.bv + hh * HD, (unsigned)((S - 1) * P.ldv + HD) * 2, (unsigned)P.ldv * 2, S, g);
+  FragB<HD> qf = load_fragb<HD>(rq, ldq_b, g.wave, g);
+  ATT2_STAMP(1);
+  // K has landed (mine: every operation but the 8 V pieces and the 3 Q loads issued behind it; then everyone's); V may still be in flight
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg<HD>::NDMA / NW + Cfg<HD>::KS) : "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  ATT2_STAMP(2);
+
+  // ---- own query blocks (wave, wave + 4): scores against every key block, exact softmax, P V ----
+#pragma unroll 1
+  for (int i = 0; i < 2; ++i) {
+    const int qb = g.wave + NW * i;
+    FragB<HD> qnext;
+    if (i == 0) qnext = load_fragb<HD>(rq, ldq_b, g.wave + NW, g);
+    else if (TAIL) qnext = load_fragb_few<HD>(rq, ldq_b, 8, nsh, g);     // the 9th block's rows, for the shared pass below
+    f32x16 s[NFULL];
+    float st0 = NEG_BIG, st1 = NEG_BIG;   // TAIL: the two score registers of block 8 that can hold a real key (rows h and 2 + h)
+#pragma unroll
+    for (int kb = 0; kb < NFULL; ++kb)
+      s[kb] = mma_rows<HD>(Kimg, g, kb, qf, (!TAIL && kb == NFULL - 1) ? mask16(last_valid, g.h) : zero16());
+    if (TAIL) {
+      const f32x16 t = mma_rows<HD>(Kimg, g, 8, qf, mask16(last_valid, g.h));
+      st0 = t[0]; st1 = t[4];
+    }
+    if (i == 0) ATT2_STAMP(5);
+    float m = fmaxf(st0, st1);
+#pragma unroll
+    for (int kb = 0; kb < NFULL; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kb][r]);
+    m = fmaxf(m, xhalf(m));
+    const float mc = m * c;
+    float l = 0.f;
+    if (i == 0) {   // V has landed (the first block's scores and row maxima ran under its flight)
+      wait_all_and_barrier();
+      ATT2_STAMP(6);
+    }
+    f32x16 o[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) o[db] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NFULL; ++kb) {      // (a block's exponentials sit next to the previous block's P V in program order)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc)); l += s[kb][r]; }
+      mma_seq<HD>(Vimg, g, kb, s[kb], 2, o);
+    }
+    if (TAIL) {
+      f32x16 pt = zero16();
+      pt[0] = __builtin_amdgcn_exp2f(fmaf(st0, c, -mc));
+      pt[4] = __builtin_amdgcn_exp2f(fmaf(st1, c, -mc));
+      l += pt[0] + pt[4];
+      mma_seq<HD>(Vimg, g, 8, pt, 1, o);
+    }
+    l += xhalf(l);
+    if (i == 0) ATT2_STAMP(7);
+    u32x4 rows[C::NST];
+    pack_rows<HD>(o, 1.0f / l, rows);
+    store_rows<HD>(ro, ldo_b, qb, rows, g);
+    if (i == 0) ATT2_STAMP(8);
+    if (g.h == 0 && qb * 32 + g.n < S) P.lse[(long)head * P.sqp + qb * 32 + g.n] = m * P.alpha + __logf(l);
+    qf = qnext;
+  }
+  ATT2_STAMP(3);
+
+  // ---- the 9th query block (S - 256 real rows): wave w takes key blocks 2 w, 2 w + 1 (wave 3 also block 8), partials meet in LDS ----
+  if (TAIL) {
+    const bool with_tail = g.wave == NW - 1;
+    f32x16 sa = mma_rows<HD>(Kimg, g, 2 * g.wave, qf, zero16());
+    f32x16 sb = mma_rows<HD>(Kimg, g, 2 * g.wave + 1, qf, zero16());
+    float st0 = NEG_BIG, st1 = NEG_BIG;
+    if (with_tail) {
+      const f32x16 t = mma_rows<HD>(Kimg, g, 8, qf, mask16(last_valid, g.h));
+      st0 = t[0]; st1 = t[4];
+    }
+    float m = fmaxf(st0, st1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(sa[r], sb[r]));
+    m = fmaxf(m, xhalf(m));
+    const float mc = m * c;
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sa[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c, -mc));
+      sb[r] = __builtin_amdgcn_exp2f(fmaf(sb[r], c, -mc));
+      l += sa[r] + sb[r];
+    }
+    f32x16 o[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) o[db] = zero16();
+    mma_seq<HD>(Vimg, g, 2 * g.wave, sa, 2, o);
+    mma_seq<HD>(Vimg, g, 2 * g.wave + 1, sb, 2, o);
+    if (with_tail) {
+      f32x16 pt = zero16();
+      pt[0] = __builtin_amdgcn_exp2f(fmaf(st0, c, -mc));
+      pt[4] = __builtin_amdgcn_exp2f(fmaf(st1, c, -mc));
+      l += pt[0] + pt[4];
+      mma_seq<HD>(Vimg, g, 8, pt, 1, o);
+    }
+    l += xhalf(l);
+    if (g.n < nsh) {
+      float* mine = scratch + (g.wave * MAXSH + g.n) * FWD_PW;
+      write_partial<HD>(mine, o, g.h);
+      if (g.h == 0) { mine[HD] = m; mine[HD + 1] = l; }
+    }
+    lds_barrier();
+    if (g.wave == 0) {
+      for (int idx = g.lane; idx < nsh * HD; idx += 64) {
+        const int q = idx / HD, d = idx - q * HD;
+        float mg = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mg = fmaxf(mg, scratch[(w * MAXSH + q) * FWD_PW + HD]);
+        float lsum = 0.f, osum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const float* pw = scratch + (w * MAXSH + q) * FWD_PW;
+          const float f = __builtin_amdgcn_exp2f((pw[HD] - mg) * c);
+          lsum = fmaf(pw[HD + 1], f, lsum);
+          osum = fmaf(pw[d], f, osum);
+        }
+        P.out[b * P.bo + (long)(256 + q) * P.ldo + hh * HD + d] = f32_to_bf16(osum / lsum);
+        if (d == 0) P.lse[(long)head * P.sqp + 256 + q] = mg * P.alpha + __logf(lsum);
+      }
+    }
+  }
+  ATT2_STAMP(4);
+}
+
+// =================================================================================================================
+// backward: one kernel, two phases per head over the same two LDS images
+// =================================================================================================================
+// ATT2_BWD_UNROLL: unroll factor of the backward kernel's block loops (0 = fully unrolled)
 #ifndef ATT2_BWD_UNROLL
-#define ATT2_BWD_UNROLL 3
+#define ATT2_BWD_UNROLL 0
 #endif
 #if ATT2_BWD_UNROLL == 0
 #define ATT2_BLOCK_LOOP _Pragma("unroll")
@@ -447,50 +451,48 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel(const AttnParams P, int tot
 #else
 #define ATT2_BLOCK_LOOP _Pragma("unroll 3")
 #endif
-constexpr int BWD_PW = 100;   // floats per (wave, row) of a shared block's partials: phase 1 dQ[48], phase 2 dK[48] | dV[48] (+ pad)
 
 // P = exp2(s c - lse2), dS = P (dp - dsum) for the 16 registers of a block; lse2 / dsum either per lane (phase 1: the lane's query)
 // or per register (phase 2: the register's query)
+// (dp arrives as dP - dsum: the dP product accumulates onto a C operand that holds -dsum)
 template <bool PER_REG>
-__device__ __forceinline__ void p_and_ds(f32x16& s, f32x16& dp, float c, const f32x16& l2, const f32x16& dsm) {
+__device__ __forceinline__ void p_and_ds(f32x16& s, f32x16& dp, float c, const f32x16& l2) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -(PER_REG ? l2[r] : l2[0])));
-    dp[r] = pv * (dp[r] - (PER_REG ? dsm[r] : dsm[0]));
+    dp[r] = pv * dp[r];
     s[r] = pv;
   }
 }
 
 template <int HD, bool TAIL>
-__global__ __launch_bounds__(512, 2) void bwd_kernel(const AttnParams P, int total_heads) {
+__global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int ncu, int stagger) {
   using C = Cfg<HD>;
   constexpr int NB = TAIL ? 9 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Qimg = smem;
-  unsigned char* Kimg = smem + C::IMG;
-  unsigned char* Vimg = smem + 2 * C::IMG;
-  unsigned char* Dimg = smem + 3 * C::IMG;              // dO
-  float* L2 = (float*)(smem + 4 * C::IMG);              // lse * log2(e) per query, in MFMA-row order: position 32 blk + i <-> query 32 blk + perm32(i)
-  float* DS = L2 + C::ROWS;                             // dsum, same order
+  unsigned char* imgA = smem;                           // phase 1: K, phase 2: Q
+  unsigned char* imgB = smem + C::IMG;                  // phase 1: V, phase 2: dO
+  float* L2 = (float*)(smem + 2 * C::IMG);              // lse * log2(e) per query, in MFMA-row order: position 32 blk + i <-> query 32 blk + perm32(i)
+  float* DS = L2 + C::ROWS;                             // -dsum, same order
   float* scratch = DS + C::ROWS;
   const LaneGeom g = make_geom<HD>();
-  HeadWalk hw;
-  hw.init(total_heads);
-  if (hw.head >= hw.end) return;
+  stagger_start(ncu, stagger);
+  const int head = xcd_remap();
+  const int b = head / P.nh, hh = head - b * P.nh;
   const int S = P.sq;
   const int nsh = S - 256;
   const int last_valid = S - 32 * (NB - 1);
+  const float c = P.alpha * LOG2E;
+  auto rsrc_of = [&](const bf16_t* base, long bs, long ld) { return make_rsrc(base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2); };
+  auto dma_of = [&](unsigned char* img, const bf16_t* base, long bs, long ld) {
+    dma_image<HD>(img, base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2, (unsigned)ld * 2, S, g);
+  };
+  const rsrc_t rq = rsrc_of(P.q, P.bq, P.ldq), rk = rsrc_of(P.k, P.bk, P.ldk), rv = rsrc_of(P.v, P.bv, P.ldv), ro = rsrc_of(P.o, P.bo, P.ldo),
+               rdo = rsrc_of(P.d_o, P.bdo, P.lddo);
   const unsigned ldq_b = (unsigned)P.ldq * 2, ldk_b = (unsigned)P.ldk * 2, ldv_b = (unsigned)P.ldv * 2, ldo_b = (unsigned)P.ldo * 2,
                  lddo_b = (unsigned)P.lddo * 2, lddq_b = (unsigned)P.lddq * 2, lddk_b = (unsigned)P.lddk * 2, lddv_b = (unsigned)P.lddv * 2;
-  const float c = P.alpha * LOG2E;
-
-  auto rsrc_of = [&](const bf16_t* base, long bs, long ld, int head) {
-    const int b = head / P.nh, hh = head - b * P.nh;
-    return make_rsrc(base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2);
-  };
   // lse2 / dsum of the queries blk * 32 + n (this lane's query), from global memory
-  auto query_consts = [&](int head, int blk, const FragB<HD>& dof, float& l2, float& dsm) {
-    const FragB<HD> of = load_fragb<HD>(rsrc_of(P.o, P.bo, P.ldo, head), ldo_b, blk, g);
+  auto query_consts = [&](int blk, const FragB<HD>& dof, const FragB<HD>& of, float& l2, float& dsm) {
     const int q = blk * 32 + g.n;
     const float lse = q < S ? P.lse[(long)head * P.sqp + q] : 0.f;
     float d = 0.f;
@@ -503,193 +505,164 @@ __global__ __launch_bounds__(512, 2) void bwd_kernel(const AttnParams P, int tot
     l2 = q < S ? lse * LOG2E : 1e30f;      // rows past the end: P = exp2(.. - 1e30) = 0
   };
 
-  auto dma_of = [&](unsigned char* img, const bf16_t* base, long bs, long ld, int head) {
-    const int b = head / P.nh, hh = head - b * P.nh;
-    dma_image<HD>(img, base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2, (unsigned)ld * 2, S, g);
+  // ================= phase 1: queries stationary -> dQ; K, V images =================
+  ATT2_STAMP(0);
+  dma_of(imgA, P.k, P.bk, P.ldk);
+  dma_of(imgB, P.v, P.bv, P.ldv);
+  ATT2_STAMP(1);
+  wait_all_and_barrier();
+  ATT2_STAMP(2);
+  // one query block against one key block: dq += (P (dP - dsum)) K
+  auto k_block = [&](int kb, bool last, const FragB<HD>& qf, const FragB<HD>& dof, const f32x16& l2v, const f32x16& dsv, f32x16 (&dq)[C::NDB]) {
+    f32x16 s = mma_rows<HD>(imgA, g, kb, qf, last ? mask16(last_valid, g.h) : zero16());
+    f32x16 dp = mma_rows<HD>(imgB, g, kb, dof, dsv);      // dsv = -dsum in every register
+    p_and_ds<false>(s, dp, c, l2v);
+    mma_seq<HD>(imgA, g, kb, dp, (last && TAIL) ? 1 : 2, dq);
   };
-  dma_of(Kimg, P.k, P.bk, P.ldk, hw.head);
-  dma_of(Vimg, P.v, P.bv, P.ldv, hw.head);
-  u32x4 pdk[C::NST], pdv[C::NST];
-  int pend_head = -1;
-
-  for (;;) {
-    const int head = hw.head;
-    const bool has_next = head + hw.step < hw.end;
-    // ================= phase 1: queries stationary -> dQ; K, V images =================
-    wait_all_and_barrier();                 // K, V of this head have landed; everybody has left phase 2 of the previous head
-    dma_of(Qimg, P.q, P.bq, P.ldq, head);
-    dma_of(Dimg, P.d_o, P.bdo, P.lddo, head);
-    if (pend_head >= 0) {
-      store_rows<HD>(rsrc_of(P.dk, P.bdk, P.lddk, pend_head), lddk_b, g.wave, pdk, g);
-      store_rows<HD>(rsrc_of(P.dv, P.bdv, P.lddv, pend_head), lddv_b, g.wave, pdv, g);
-    }
-    u32x4 pdq[C::NST];
+  // (Measured and dropped, profiles/r05_attn2_steps.txt: two key blocks per step with S / dP of both as four independent accumulator
+  //  chains and dQ split over two accumulator sets - 256 VGPRs with 10 spilled, 103 us against 91-96; the operand rows of both own
+  //  blocks fetched under the DMA's flight - 214 VGPRs, 93-99 us: no gain.)
+#pragma unroll 1
+  for (int i = 0; i < 2; ++i) {
+    const int qb = g.wave + NW * i;
+    const FragB<HD> qf = load_fragb<HD>(rq, ldq_b, qb, g);
+    const FragB<HD> dof = load_fragb<HD>(rdo, lddo_b, qb, g);
+    f32x16 l2v, dsv;
     {
-      const FragB<HD> qf = load_fragb<HD>(rsrc_of(P.q, P.bq, P.ldq, head), ldq_b, g.wave, g);
-      const FragB<HD> dof = load_fragb<HD>(rsrc_of(P.d_o, P.bdo, P.lddo, head), lddo_b, g.wave, g);
+      const FragB<HD> of = load_fragb<HD>(ro, ldo_b, qb, g);
       float l2, dsm;
-      query_consts(head, g.wave, dof, l2, dsm);
-      if (g.h == 0) { L2[g.wave * 32 + perm32_inv(g.n)] = l2; DS[g.wave * 32 + perm32_inv(g.n)] = dsm; }
-      f32x16 l2v, dsv;
-      l2v[0] = l2; dsv[0] = dsm;
-      f32x16 dq[C::NDB];
+      query_consts(qb, dof, of, l2, dsm);
+      if (g.h == 0) { L2[qb * 32 + perm32_inv(g.n)] = l2; DS[qb * 32 + perm32_inv(g.n)] = -dsm; }   // (DS holds -dsum)
+      l2v[0] = l2;
 #pragma unroll
-      for (int db = 0; db < C::NDB; ++db) dq[db] = zero16();
-      ATT2_BLOCK_LOOP
-      for (int kb = 0; kb < NB; ++kb) {
-        const bool last = kb == NB - 1;
-        f32x16 s = mma_rows<HD>(Kimg, g, kb, qf, last ? mask16(last_valid, g.h) : zero16());
-        f32x16 dp = mma_rows<HD>(Vimg, g, kb, dof, zero16());
-        p_and_ds<false>(s, dp, c, l2v, dsv);
-        mma_seq<HD>(Kimg, g, kb, dp, (last && TAIL) ? 1 : 2, dq);
-      }
-      pack_rows<HD>(dq, P.alpha, pdq);
+      for (int r = 0; r < 16; ++r) dsv[r] = -dsm;
     }
-    if (TAIL) {   // query block 8: wave w against key block w (wave 7 also block 8); partial dQ rows through LDS
-      const FragB<HD> qf = load_fragb<HD>(rsrc_of(P.q, P.bq, P.ldq, head), ldq_b, 8, g);
-      const FragB<HD> dof = load_fragb<HD>(rsrc_of(P.d_o, P.bdo, P.lddo, head), lddo_b, 8, g);
-      float l2, dsm;
-      query_consts(head, 8, dof, l2, dsm);
-      if (g.wave == 0 && g.h == 0) { L2[256 + perm32_inv(g.n)] = l2; DS[256 + perm32_inv(g.n)] = dsm; }
-      f32x16 l2v, dsv;
-      l2v[0] = l2; dsv[0] = dsm;
-      f32x16 dq[C::NDB];
+    f32x16 dq[C::NDB];
 #pragma unroll
-      for (int db = 0; db < C::NDB; ++db) dq[db] = zero16();
-      {
-        f32x16 s = mma_rows<HD>(Kimg, g, g.wave, qf, zero16());
-        f32x16 dp = mma_rows<HD>(Vimg, g, g.wave, dof, zero16());
-        p_and_ds<false>(s, dp, c, l2v, dsv);
-        mma_seq<HD>(Kimg, g, g.wave, dp, 2, dq);
-      }
-      if (g.wave == 7) {
-        f32x16 s = mma_rows<HD>(Kimg, g, 8, qf, mask16(last_valid, g.h));
-        f32x16 dp = mma_rows<HD>(Vimg, g, 8, dof, zero16());
-        p_and_ds<false>(s, dp, c, l2v, dsv);
-        mma_seq<HD>(Kimg, g, 8, dp, 1, dq);
-      }
-      if (g.n < nsh) {
-        float* mine = scratch + (g.wave * MAXSH + g.n) * BWD_PW;
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4)
-            if (32 * db + 8 * q4 < HD)
-              *(f32x4*)(mine + 32 * db + 8 * q4 + 4 * g.h) = f32x4{dq[db][4 * q4], dq[db][4 * q4 + 1], dq[db][4 * q4 + 2], dq[db][4 * q4 + 3]};
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (g.wave == 0) {
-        const int b = head / P.nh, hh = head - b * P.nh;
-        for (int idx = g.lane; idx < nsh * HD; idx += 64) {
-          const int q = idx / HD, d = idx - q * HD;
-          float a = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) a += scratch[(w * MAXSH + q) * BWD_PW + d];
-          P.dq[b * P.bdq + (long)(256 + q) * P.lddq + hh * HD + d] = f32_to_bf16(a * P.alpha);
-        }
-      }
-    }
-
-    // ================= phase 2: keys stationary -> dK, dV; Q, dO images =================
-    wait_all_and_barrier();                 // Q, dO have landed; L2 / DS are complete; everybody is done with the K, V images
-    if (has_next) {
-      dma_of(Kimg, P.k, P.bk, P.ldk, head + hw.step);
-      dma_of(Vimg, P.v, P.bv, P.ldv, head + hw.step);
-    }
-    store_rows<HD>(rsrc_of(P.dq, P.bdq, P.lddq, head), lddq_b, g.wave, pdq, g);
-    auto q_block = [&](int qb, const FragB<HD>& kf, const FragB<HD>& vf, int t2, f32x16 (&dk)[C::NDB], f32x16 (&dv)[C::NDB]) {
-      f32x16 s = mma_rows<HD>(Qimg, g, qb, kf, zero16());
-      f32x16 dp = mma_rows<HD>(Dimg, g, qb, vf, zero16());
-      f32x16 l2v, dsv;
-#pragma unroll
-      for (int T = 0; T < 4; ++T) {
-        const f32x4 a = *(const f32x4*)(L2 + qb * 32 + 8 * T + 4 * g.h);
-        const f32x4 d = *(const f32x4*)(DS + qb * 32 + 8 * T + 4 * g.h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { l2v[4 * T + j] = a[j]; dsv[4 * T + j] = d[j]; }
-      }
-      p_and_ds<true>(s, dp, c, l2v, dsv);
-      mma_seq<HD>(Dimg, g, qb, s, t2, dv);
-      mma_seq<HD>(Qimg, g, qb, dp, t2, dk);
-    };
-    {
-      const FragB<HD> kf = load_fragb<HD>(rsrc_of(P.k, P.bk, P.ldk, head), ldk_b, g.wave, g);
-      const FragB<HD> vf = load_fragb<HD>(rsrc_of(P.v, P.bv, P.ldv, head), ldv_b, g.wave, g);
-      f32x16 dk[C::NDB], dv[C::NDB];
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
-      ATT2_BLOCK_LOOP
-      for (int qb = 0; qb < NB; ++qb) q_block(qb, kf, vf, (TAIL && qb == NB - 1) ? 1 : 2, dk, dv);
-      pack_rows<HD>(dk, P.alpha, pdk);
-      pack_rows<HD>(dv, 1.0f, pdv);
-      pend_head = head;
-    }
-    if (TAIL) {   // key block 8: wave w against query block w (wave 7 also block 8); partial dK / dV rows through LDS
-      const FragB<HD> kf = load_fragb<HD>(rsrc_of(P.k, P.bk, P.ldk, head), ldk_b, 8, g);
-      const FragB<HD> vf = load_fragb<HD>(rsrc_of(P.v, P.bv, P.ldv, head), ldv_b, 8, g);
-      f32x16 dk[C::NDB], dv[C::NDB];
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
-      q_block(g.wave, kf, vf, 2, dk, dv);
-      if (g.wave == 7) q_block(8, kf, vf, 1, dk, dv);
-      if (g.n < nsh) {
-        float* mine = scratch + (g.wave * MAXSH + g.n) * BWD_PW;
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4)
-            if (32 * db + 8 * q4 < HD) {
-              *(f32x4*)(mine + 32 * db + 8 * q4 + 4 * g.h) = f32x4{dk[db][4 * q4], dk[db][4 * q4 + 1], dk[db][4 * q4 + 2], dk[db][4 * q4 + 3]};
-              *(f32x4*)(mine + HD + 32 * db + 8 * q4 + 4 * g.h) = f32x4{dv[db][4 * q4], dv[db][4 * q4 + 1], dv[db][4 * q4 + 2], dv[db][4 * q4 + 3]};
-            }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (g.wave == 0) {
-        const int b = head / P.nh, hh = head - b * P.nh;
-        for (int idx = g.lane; idx < nsh * HD; idx += 64) {
-          const int k = idx / HD, d = idx - k * HD;
-          float a = 0.f, e = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) { a += scratch[(w * MAXSH + k) * BWD_PW + d]; e += scratch[(w * MAXSH + k) * BWD_PW + HD + d]; }
-          P.dk[b * P.bdk + (long)(256 + k) * P.lddk + hh * HD + d] = f32_to_bf16(a * P.alpha);
-          P.dv[b * P.bdv + (long)(256 + k) * P.lddv + hh * HD + d] = f32_to_bf16(e);
-        }
-      }
-    }
-    if (!has_next) break;
-    hw.head += hw.step;
+    for (int db = 0; db < C::NDB; ++db) dq[db] = zero16();
+    ATT2_BLOCK_LOOP
+    for (int kb = 0; kb < NB; ++kb) k_block(kb, kb == NB - 1, qf, dof, l2v, dsv, dq);
+    u32x4 rows[C::NST];
+    pack_rows<HD>(dq, P.alpha, rows);
+    store_rows<HD>(rsrc_of(P.dq, P.bdq, P.lddq), lddq_b, qb, rows, g);
+    if (i == 0) ATT2_STAMP(3);
   }
-  store_rows<HD>(rsrc_of(P.dk, P.bdk, P.lddk, pend_head), lddk_b, g.wave, pdk, g);
-  store_rows<HD>(rsrc_of(P.dv, P.bdv, P.lddv, pend_head), lddv_b, g.wave, pdv, g);
+  ATT2_STAMP(4);
+  if (TAIL) {   // query block 8: wave w against key blocks 2 w, 2 w + 1 (wave 3 also block 8); partial dQ rows through LDS
+    const FragB<HD> qf = load_fragb_few<HD>(rq, ldq_b, 8, nsh, g);
+    const FragB<HD> dof = load_fragb_few<HD>(rdo, lddo_b, 8, nsh, g);
+    const FragB<HD> of = load_fragb_few<HD>(ro, ldo_b, 8, nsh, g);
+    float l2, dsm;
+    query_consts(8, dof, of, l2, dsm);
+    if (g.wave == 0 && g.h == 0) { L2[256 + perm32_inv(g.n)] = l2; DS[256 + perm32_inv(g.n)] = -dsm; }
+    f32x16 l2v, dsv;
+    l2v[0] = l2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dsv[r] = -dsm;
+    f32x16 dq[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) dq[db] = zero16();
+    k_block(2 * g.wave, false, qf, dof, l2v, dsv, dq);
+    k_block(2 * g.wave + 1, false, qf, dof, l2v, dsv, dq);
+    if (g.wave == NW - 1) k_block(8, true, qf, dof, l2v, dsv, dq);
+    if (g.n < nsh) write_partial<HD>(scratch + (g.wave * MAXSH + g.n) * BWD_PW, dq, g.h);
+  }
+  ATT2_STAMP(5);
+  lds_barrier();              // everybody is done with the K, V images; L2 / DS and the partials are written
+  ATT2_STAMP(6);
+  dma_of(imgA, P.q, P.bq, P.ldq);
+  dma_of(imgB, P.d_o, P.bdo, P.lddo);
+  ATT2_STAMP(7);
+  if (TAIL && g.wave == 0) {
+    for (int idx = g.lane; idx < nsh * HD; idx += 64) {
+      const int q = idx / HD, d = idx - q * HD;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += scratch[(w * MAXSH + q) * BWD_PW + d];
+      P.dq[b * P.bdq + (long)(256 + q) * P.lddq + hh * HD + d] = f32_to_bf16(a * P.alpha);
+    }
+  }
+  // ================= phase 2: keys stationary -> dK, dV; Q, dO images =================
+  wait_all_and_barrier();     // (also: wave 0 has read the phase-1 partials before anybody writes the phase-2 ones)
+  ATT2_STAMP(8);
+  auto q_block = [&](int qb, const FragB<HD>& kf, const FragB<HD>& vf, int t2, f32x16 (&dk)[C::NDB], f32x16 (&dv)[C::NDB]) {
+    f32x16 l2v, dsv;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      const f32x4 a = *(const f32x4*)(L2 + qb * 32 + 8 * T + 4 * g.h);
+      const f32x4 d = *(const f32x4*)(DS + qb * 32 + 8 * T + 4 * g.h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { l2v[4 * T + j] = a[j]; dsv[4 * T + j] = d[j]; }
+    }
+    f32x16 s = mma_rows<HD>(imgA, g, qb, kf, zero16());
+    f32x16 dp = mma_rows<HD>(imgB, g, qb, vf, dsv);       // -dsum of the registers' queries as the C operand
+    p_and_ds<true>(s, dp, c, l2v);
+    mma_seq<HD>(imgB, g, qb, s, t2, dv);
+    mma_seq<HD>(imgA, g, qb, dp, t2, dk);
+  };
+#pragma unroll 1
+  for (int i = 0; i < 2; ++i) {
+    const int kb = g.wave + NW * i;
+    const FragB<HD> kf = load_fragb<HD>(rk, ldk_b, kb, g);
+    const FragB<HD> vf = load_fragb<HD>(rv, ldv_b, kb, g);
+    f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+    ATT2_BLOCK_LOOP
+    for (int qb = 0; qb < NB; ++qb) q_block(qb, kf, vf, (TAIL && qb == NB - 1) ? 1 : 2, dk, dv);
+    u32x4 rows[C::NST];
+    pack_rows<HD>(dk, P.alpha, rows);
+    store_rows<HD>(rsrc_of(P.dk, P.bdk, P.lddk), lddk_b, kb, rows, g);
+    pack_rows<HD>(dv, 1.0f, rows);
+    store_rows<HD>(rsrc_of(P.dv, P.bdv, P.lddv), lddv_b, kb, rows, g);
+    if (i == 0) ATT2_STAMP(9);
+  }
+  ATT2_STAMP(10);
+  if (TAIL) {   // key block 8: wave w against query blocks 2 w, 2 w + 1 (wave 3 also block 8); partial dK / dV rows through LDS
+    const FragB<HD> kf = load_fragb_few<HD>(rk, ldk_b, 8, nsh, g);
+    const FragB<HD> vf = load_fragb_few<HD>(rv, ldv_b, 8, nsh, g);
+    f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+    q_block(2 * g.wave, kf, vf, 2, dk, dv);
+    q_block(2 * g.wave + 1, kf, vf, 2, dk, dv);
+    if (g.wave == NW - 1) q_block(8, kf, vf, 1, dk, dv);
+    if (g.n < nsh) {
+      float* mine = scratch + (g.wave * MAXSH + g.n) * BWD_PW;
+      write_partial<HD>(mine, dk, g.h);
+      write_partial<HD>(mine + HD, dv, g.h);
+    }
+    lds_barrier();
+    if (g.wave == 0) {
+      for (int idx = g.lane; idx < nsh * HD; idx += 64) {
+        const int k = idx / HD, d = idx - k * HD;
+        float a = 0.f, e = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { a += scratch[(w * MAXSH + k) * BWD_PW + d]; e += scratch[(w * MAXSH + k) * BWD_PW + HD + d]; }
+        P.dk[b * P.bdk + (long)(256 + k) * P.lddk + hh * HD + d] = f32_to_bf16(a * P.alpha);
+        P.dv[b * P.bdv + (long)(256 + k) * P.lddv + hh * HD + d] = f32_to_bf16(e);
+      }
+    }
+  }
+  ATT2_STAMP(11);
 }
 
-static int cus_per_xcd() {
-  static int v = []() {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 32; }
-    const int n = prop.multiProcessorCount / 8;
-    return n > 0 ? n : 1;
-  }();
-  return v;
-}
 static bool enabled() {
   const char* e = getenv("MUSE_ATTN2");      // read per call: tests compare both kernel families in one process
   return !(e && e[0] == '0');
 }
+static int num_cus() {
+  static int v = []() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return v;
+}
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static bool shape_ok(const AttnParams& P, int head_dim) {
   return enabled() && head_dim == 48 && P.sq == P.skv && P.sq >= 225 && P.sq <= 256 + MAXSH;
-}
-static int grid_for(int total_heads) {
-  int cap = cus_per_xcd();
-  const char* e = getenv("MUSE_ATTN2_WGS_PER_XCD");   // tests: a small grid makes every workgroup walk several heads
-  if (e && atoi(e) > 0 && atoi(e) < cap) cap = atoi(e);
-  const int per = (total_heads + 7) / 8;
-  return 8 * (per < cap ? per : cap);
 }
 
 }  // namespace attn2
@@ -701,20 +674,14 @@ extern "C" int muse_dbg_attn2_ts(void* p) { long* v = (long*)p; return (int)hipM
 int attn2_fwd_try(const AttnParams& P, int head_dim, int batch, hipStream_t st) {
   using namespace attn2;
   if (!shape_ok(P, head_dim)) return 0;
-  const int total = batch * P.nh;
   constexpr int HD = 48;
-  const size_t lds = 4 * (size_t)Cfg<HD>::IMG + 8 * MAXSH * FWD_PW * 4;
-  if (P.sq > 256) {
-    auto k = fwd_kernel<HD, true>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(k, dim3(grid_for(total)), dim3(512), lds, st, P, total);
-  } else {
-    auto k = fwd_kernel<HD, false>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(k, dim3(grid_for(total)), dim3(512), lds, st, P, total);
-  }
+  const size_t lds = 2 * (size_t)Cfg<HD>::IMG + NW * MAXSH * FWD_PW * 4;
+  auto launch = [&](auto k) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(batch * P.nh), dim3(NW * 64), lds, st, P, num_cus(), env_int("MUSE_ATTN2_STAGGER_FWD", 6000));
+  };
+  if (P.sq > 256) launch(fwd_kernel<HD, true>);
+  else launch(fwd_kernel<HD, false>);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 1 : -(int)e;
 }
@@ -722,20 +689,14 @@ int attn2_fwd_try(const AttnParams& P, int head_dim, int batch, hipStream_t st) 
 int attn2_bwd_try(const AttnParams& P, int head_dim, int batch, hipStream_t st) {
   using namespace attn2;
   if (!shape_ok(P, head_dim)) return 0;
-  const int total = batch * P.nh;
   constexpr int HD = 48;
-  const size_t lds = 4 * (size_t)Cfg<HD>::IMG + 2 * Cfg<HD>::ROWS * 4 + 8 * MAXSH * BWD_PW * 4;
-  if (P.sq > 256) {
-    auto k = bwd_kernel<HD, true>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(k, dim3(grid_for(total)), dim3(512), lds, st, P, total);
-  } else {
-    auto k = bwd_kernel<HD, false>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(k, dim3(grid_for(total)), dim3(512), lds, st, P, total);
-  }
+  const size_t lds = 2 * (size_t)Cfg<HD>::IMG + 2 * Cfg<HD>::ROWS * 4 + NW * MAXSH * BWD_PW * 4;
+  auto launch = [&](auto k) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(batch * P.nh), dim3(NW * 64), lds, st, P, num_cus(), env_int("MUSE_ATTN2_STAGGER_BWD", 0));
+  };
+  if (P.sq > 256) launch(bwd_kernel<HD, true>);
+  else launch(bwd_kernel<HD, false>);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 1 : -(int)e;
 }

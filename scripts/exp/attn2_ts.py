@@ -13,7 +13,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B * S, 3 * H, device=dev, generator=g).to(torch.bfloat16)
 alpha = hd ** -0.5
 lib = ctypes.CDLL(_hip.LIB_PATH)
-ts = torch.zeros(256 * 8 * 4 * 16, dtype=torch.int64, device=dev)
+nblk = B * nh
+ts = torch.zeros(nblk * 4 * 16, dtype=torch.int64, device=dev)
 for _ in range(3):
     ops.attention_fwd(qkv, B, S, nh, hd, alpha)
 torch.cuda.synchronize()
@@ -21,18 +22,33 @@ assert lib.muse_dbg_attn2_ts(ctypes.c_void_p(ts.data_ptr())) == 0
 ops.attention_fwd(qkv, B, S, nh, hd, alpha)
 torch.cuda.synchronize()
 lib.muse_dbg_attn2_ts(ctypes.c_void_p(0))
-t = ts.view(256, 8, 4, 16).cpu().double()
-names = ["top", "barrier passed", "dma+loads+stores issued", "QK done", "softmax done", "PV done", "packed", "shared computed", "merge barrier", "head end"]
-for it in range(4):
-    base = t[:, :, it, 0].min(dim=1, keepdim=True).values.unsqueeze(-1) if False else t[:, :, it, 0:1]
-    print(f"head {it}: mean cycles since this wave's top (min / mean / max over 2048 waves)")
-    for k in range(1, 10):
-        d = (t[:, :, it, k] - t[:, :, it, 0])
-        print(f"   {names[k]:26s} {d.min():9.0f} {d.mean():9.0f} {d.max():9.0f}")
-    if it < 3:
-        d = t[:, :, it + 1, 0] - t[:, :, it, 0]
-        print(f"   next top                   {d.min():9.0f} {d.mean():9.0f} {d.max():9.0f}")
-print("kernel span (cycles):", float(t[:, :, :, 9].max() - t[:, :, 0, 0].min()))
-w = t[0, :, 1, :10] - t[0, 0, 1, 0]
-print("block 0, head 1, per wave rows = waves, cols = stamps:")
-for r in w: print("   " + " ".join(f"{x:8.0f}" for x in r))
+t = ts.view(nblk, 4, 16).cpu().double()
+order = [(1, "dma + q loads issued"), (2, "images landed, barrier"), (5, "block 0: QK done"), (6, "block 0: max done"), (7, "block 0: exp + PV done"),
+         (8, "block 0: packed, stores issued"), (3, "both own blocks done"), (4, "shared block + merge done")]
+print("cycles since the wave's entry (min / mean / max over %d waves)" % (nblk * 4))
+for k, nm in order:
+    d = t[:, :, k] - t[:, :, 0]
+    print(f"   {nm:34s} {d.min():9.0f} {d.mean():9.0f} {d.max():9.0f}")
+t0 = t[:, :, 0].min()
+print("kernel span (cycles):", float(t[:, :, 4].max() - t0), " workgroup lifetime mean:", float((t[:, :, 4].max(dim=1).values - t[:, :, 0].min(dim=1).values).mean()))
+start = (t[:, 0, 0] - t0).sort().values
+print("workgroup start times (cycles) percentiles 0/25/50/75/100:", [float(start[int(q * (nblk - 1))]) for q in (0, .25, .5, .75, 1)])
+
+# ---- backward ----
+do = torch.randn(B * S, H, device=dev, generator=g).to(torch.bfloat16)
+ctx, lse = ops.attention_fwd(qkv, B, S, nh, hd, alpha)
+for _ in range(3):
+    ops.attention_bwd(qkv, ctx, do, lse, B, S, nh, hd, alpha)
+torch.cuda.synchronize()
+ts.zero_()
+assert lib.muse_dbg_attn2_ts(ctypes.c_void_p(ts.data_ptr())) == 0
+ops.attention_bwd(qkv, ctx, do, lse, B, S, nh, hd, alpha)
+torch.cuda.synchronize()
+lib.muse_dbg_attn2_ts(ctypes.c_void_p(0))
+t = ts.view(nblk, 4, 16).cpu().double()
+order = [(1, "K, V dma issued"), (2, "K, V landed, barrier"), (3, "phase 1: first query block stored"), (4, "phase 1: both query blocks"), (5, "phase 1: shared block computed"),
+         (6, "barrier (images free)"), (7, "Q, dO dma issued"), (8, "Q, dO landed, barrier"), (9, "phase 2: first key block stored"), (10, "phase 2: both key blocks"), (11, "end")]
+print("BACKWARD: cycles since the wave's entry (min / mean / max over %d waves)" % (nblk * 4))
+for k, nm in order:
+    d = t[:, :, k] - t[:, :, 0]
+    print(f"   {nm:36s} {d.min():9.0f} {d.mean():9.0f} {d.max():9.0f}")

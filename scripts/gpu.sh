@@ -17,6 +17,11 @@ attn)   # attention2.hip bring-up: parity tests, then old vs new (and build vari
   done
   timeout 300 python scripts/attn_bench.py 20 0 2>&1 | sed 's/^/new again| /' | tee -a $O/${tag}_attn_bench.txt
   ;;
+attn_stag)  # start stagger of the second workgroup per CU: sweep
+  for f in 0 6000 12000 18000 24000; do for b in 0 20000 40000; do
+    MUSE_ATTN2_STAGGER_FWD=$f MUSE_ATTN2_STAGGER_BWD=$b timeout 300 python scripts/attn_bench.py 20 0 2>&1 | grep config | sed "s/^/stagger fwd $f bwd $b | /" | tee -a $O/${tag}_attn_stagger.txt
+  done; done
+  ;;
 attn_ts)
   MUSE_HIP_LIB=$PWD/open-muse_amd/csrc/variants/libmuse_hip_ts.so timeout 300 python scripts/exp/attn2_ts.py 2>&1 | grep -v amdgpu.ids | tee $O/${tag}_attn_ts.txt
   ;;
