@@ -25,6 +25,40 @@ attn_stag)  # start stagger of the second workgroup per CU: sweep
 attn_ts)
   MUSE_HIP_LIB=$PWD/open-muse_amd/csrc/variants/libmuse_hip_ts.so timeout 300 python scripts/exp/attn2_ts.py 2>&1 | grep -v amdgpu.ids | tee $O/${tag}_attn_ts.txt
   ;;
+ab)     # same-box A/B of the headline step: scripts/gpu.sh ab <tag> "ENV=a ENV2=b" "ENV=c" ...   (one bench.py --no-extra run per quoted setting)
+  for setting in "${@:3}"; do
+    for rep in 1 2; do
+      env $setting timeout 900 python bench.py --no-extra --no-cpu-baseline --steps 20 --warmup 5 2> $O/${tag}_ab.err | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); e = d.get('extra', {})
+        print('%-40s rep $rep  %8.1f img/s  %7.2f ms  transformer fwd+bwd %s ms  frac %s' % ('$setting', d['value'], d['ms_per_step'], e.get('transformer_fwd_bwd_ms'), e.get('transformer_mfma_frac')))
+" | tee -a $O/${tag}_ab.txt
+    done
+  done
+  ;;
+trace)  # concurrency picture of the default multi-stream step: kernel trace of a short bench run -> scripts/overlap_report.py
+  rm -rf $O/${tag}_trace; cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/${tag}_trace -o t -- python $OLDPWD/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extra > $OLDPWD/$O/${tag}_trace_bench.txt 2>&1
+  cd $OLDPWD
+  f=$(find $O/${tag}_trace -name "t_kernel_trace.csv" | head -1)
+  python scripts/overlap_report.py $f --last-ms 250 > $O/${tag}_overlap.txt 2>&1; tail -60 $O/${tag}_overlap.txt
+  g=$(find $O/${tag}_trace -name "t_kernel_stats.csv" | head -1); cp $g $O/${tag}_kernel_stats.csv
+  find $O/${tag}_trace -name "*.csv" -size +3M -delete
+  ;;
+g256p)  # persistent-GEMM epilogue modes (MUSE_G256P_EPI: 2 product, 3 no stores, 4 role-split ablation, 5 role split): timing, then check
+  export MUSE_GEMM256=1
+  run() { env "$@" timeout 300 python scripts/exp/g256p_probe.py $MODE 2>&1 | grep -v amdgpu.ids | sed "s/^\[/[$* /"; }
+  MODE=time
+  { for m in ${@:3}; do run MUSE_G256P_EPI=$m; done; run MUSE_G256P_EPI=2; } > $O/${tag}_g256p_time.txt 2>&1
+  grep -E "total|FFN-in \[T,768\]|QKV    \[T" $O/${tag}_g256p_time.txt | cut -c1-160
+  ;;
+g256p_check)
+  export MUSE_GEMM256=1
+  MUSE_G256P_EPI=${3:-5} timeout 600 python scripts/exp/g256p_probe.py check 2>&1 | grep -v amdgpu.ids > $O/${tag}_g256p_check.txt
+  grep -c "rerun_identical True" $O/${tag}_g256p_check.txt; grep -E "False|e-0[01]|e\+0|Error|error" $O/${tag}_g256p_check.txt | cut -c1-200 | head -20
+  ;;
 tests)
   timeout 2400 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/${tag}_pytest.txt 2>&1; echo "pytest exit $?" >> $O/${tag}_pytest.txt
   grep -E "passed|failed|pytest exit|^FAILED|^ERROR" $O/${tag}_pytest.txt | tail -5
