@@ -120,6 +120,9 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
             check(lib().muse_sum_slices_epilogue(ws.data_ptr(), sk, M * N, ptr(bias), ptr(residual), ldr, C_.data_ptr() + c_off * _esz(C_),
                                                  dt(C_), ldc, M, N, stream()), "muse_sum_slices_epilogue")
             return C_
+    # (Measured and dropped, round 5: the ragged last row tile of M = 16448 as a launch of its own wherever it saves a round of the
+    #  256-CU chip - N = 6144 / 3072 / 2048: the step came out 0.45 ms SLOWER, 53.08 against 52.64 ms same box, transformer alone 33.34
+    #  against 32.85: the extra launches cost more than the rounds, and in the step other streams fill the tail anyway.)
     if not USE_TR and A.dtype == torch.bfloat16 and (la == 1 or lb == 1):
         return _gemm_via_transpose(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec,
                                    residual, ldr, batch, zdiv, sA, sB, sC, accumulate, act)
