@@ -575,7 +575,9 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
         # main chain leaves idle (dX GEMMs with 195 tiles on 256 CUs, kernel tails, the HBM-bound LayerNorm / GLU backward).
         main = torch.cuda.current_stream(dev)
         side = self._wgrad_side_stream(dev) if (self.wgrad_stream and cd == torch.bfloat16) else None
-        csq = [] if side is not None else None     # column sums of the LayerNorm / GLU weight gradients, launched on the side stream
+        # column sums of the LayerNorm / GLU weight gradients: queued, then launched on the side stream - or, without one, handed to
+        # the layer's grouped reduction launch (98 launches of 6 us per serial step otherwise)
+        csq = [] if (side is not None or (cd == torch.bfloat16 and ops.WGRAD_GROUP >= 1)) else None
 
         # Grouped form (ops.WGRAD_GROUP >= 1, bf16 mode): the weight gradients of a layer are collected and issued as ONE launch of
         # the 256^2 kernel over all their tiles + ONE reduction launch (slice sums and the layer's column sums) when the layer is
@@ -729,6 +731,8 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
             with torch.cuda.stream(side):
                 ops.flush_colsums(csq)
             main.wait_stream(side)   # the optimizer (and anything else on the main stream) sees every weight gradient
+        elif csq:
+            ops.flush_colsums(csq)
         if self.direct_grad:
             return [None] * len(params)
         return [view(GW, i, tuple(p.shape)) for i, p in enumerate(params)]

@@ -587,10 +587,11 @@ def test_fused_attention_fwd_bwd(B, S, nh, hd):
 
 @pytest.mark.parametrize("B,S,nh,wgs", [(5, 257, 4, 1), (3, 257, 16, 0), (3, 256, 4, 1), (2, 240, 3, 1), (3, 258, 4, 1), (2, 260, 3, 0), (2, 225, 2, 0)])
 def test_one_tile_attention_blocks32(B, S, nh, wgs, monkeypatch):
-    """attention2.hip (32 x 32 MFMA blocks, exact softmax, persistent workgroups with LDS-DMA prefetch, ONE fused backward kernel) on
+    """attention2.hip (32 x 32 MFMA blocks, exact softmax, operands by LDS-DMA, ONE fused two-phase backward kernel) on
     the shapes it takes (self-attention, head_dim 48, 225 <= S <= 260): against float64 on the same bf16 inputs, and against the
     general kernels of attention.hip (MUSE_ATTN2=0) - both round P to bf16 once, so they agree far inside the f64 tolerance.
-    `wgs` = 1: eight workgroups walk all heads (buffer swap, delayed stores, the next head's DMA under the current head's math)."""
+    One head per 4-wave workgroup; several heads per image and several images so that the XCD remap of the grid is exercised.
+    (`wgs` sets MUSE_ATTN2_WGS_PER_XCD, which only the first, persistent form of the kernels read; harmless now.)"""
     ops = _ops()
     hd = 48
     H = nh * hd
