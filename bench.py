@@ -447,7 +447,9 @@ def comm_block(info, world, dp_ms, plain_ms, grad_dtype, rccl_log):
            "bytes_per_step": int(info.get("bytes_per_step", 0)), "buckets_per_step": info.get("buckets_per_step"),
            "dp_step_ms": round(dp_ms, 3), "same_gpus_step_without_reducer_ms": None if plain_ms is None else round(plain_ms, 3),
            "exposed_comm_ms": None if plain_ms is None else round(dp_ms - plain_ms, 3)}
-    for k in ("allreduce_alone_ms", "allreduce_alone_algbw_GBps", "allreduce_alone_busbw_GBps", "allreduce_alone_error"):
+    out["bucket_bytes"] = info.get("bucket_bytes")
+    for k in ("allreduce_alone_ms", "allreduce_alone_algbw_GBps", "allreduce_alone_busbw_GBps", "allreduce_alone_error", "per_bucket",
+              "per_bucket_error"):
         if k in info:
             out[k] = info[k]
     if world > 1 and "allreduce_alone_ms" in info and plain_ms is not None:
@@ -585,7 +587,17 @@ def main():
             el = float(t)
             if reducer is not None:
                 loss, _ = reducer.reduce_metrics(loss, mask_prob)     # the two logged scalars of the loop as one 2-float all-reduce
-                comm_info.update(buckets_per_step=reducer.stats["buckets"] / steps, bytes_per_step=reducer.stats["bytes"] / steps)
+                comm_info.update(buckets_per_step=reducer.stats["buckets"] / steps, bytes_per_step=reducer.stats["bytes"] / steps,
+                                 bucket_bytes=int(reducer.bucket_elems * 4))
+                try:    # one more step with per-bucket events: which share of each bucket's all-reduce backward hid
+                    reducer.trace = []
+                    one()
+                    torch.cuda.synchronize()
+                    comm_info["per_bucket"] = reducer.bucket_overlap()
+                except Exception as e:   # noqa: BLE001
+                    comm_info["per_bucket_error"] = f"{type(e).__name__}: {str(e)[:160]}"
+                finally:
+                    reducer.trace = None
                 try:    # the gradient all-reduce ALONE (no compute beside it), in the reducer's own buckets: what the links deliver
                     g = model.flat_grads()
                     be = reducer.bucket_elems

@@ -543,6 +543,11 @@ class GradReducer:
         self._stream = None
         self.post_reduce = None   # callable(lo, hi): runs on the reduction stream right after bucket [lo, hi) has been averaged
         self.stats = {"buckets": 0, "bytes": 0}
+        # bench.py's `comm` block: a list here makes every flat-buffer bucket leave (start event, end event, payload bytes) on the
+        # communication stream and finish() an event at the point where backward's last kernel has been enqueued on the compute
+        # stream - per bucket, the share of its all-reduce that ran before that point is what backward hid (bucket_overlap())
+        self.trace = None
+        self._bwd_end = None
         self._sync = True         # False inside no_sync(): gradient accumulation, no collective
         self._deferred = False    # tape engines: this backward adds to existing gradients -> the SUM is reduced in finish()
         # Models with a flat gradient buffer (MaskGitTransformer) report finished ranges during backward.  Models whose
@@ -742,7 +747,17 @@ class GradReducer:
                 self._stream = torch.cuda.Stream(priority=-1)
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
+                ev = None
+                if self.trace is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 h = self._reduce(g, True)
+                if ev is not None:
+                    if h is not None:
+                        h.wait()
+                        h = None
+                    ev[1].record()
+                    self.trace.append((ev[0], ev[1], (hi - lo) * (2 if self.grad_dtype == torch.bfloat16 else 4)))
                 if self.post_reduce is not None:
                     if h is not None:
                         h.wait()          # (a stream-side wait: the reduction stream continues behind the collective; the host does not block)
@@ -775,6 +790,9 @@ class GradReducer:
             return self._finish_tensor_list()
         if not self._sync:
             return
+        if self.trace is not None and self.model.flat_grads().is_cuda:
+            self._bwd_end = torch.cuda.Event(enable_timing=True)
+            self._bwd_end.record()                   # backward's last kernel is on the compute stream; what follows is exposed
         if self._hi is not None:
             self._launch(self._lo, self._hi)
             self._hi = self._lo = None
@@ -783,6 +801,20 @@ class GradReducer:
         self._handles = []
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+
+    def bucket_overlap(self):
+        """after a traced step and a device synchronisation: per bucket {bytes, ms, hidden_fraction} - the share of the bucket's
+        all-reduce (as timed on the communication stream) that ran before backward's last kernel was enqueued.  A bucket launched
+        in finish() itself (the last, ragged one) is exposed by construction."""
+        out = []
+        if not self.trace or self._bwd_end is None:
+            return out
+        for e0, e1, nbytes in self.trace:
+            ms = e0.elapsed_time(e1)
+            before = e0.elapsed_time(self._bwd_end)          # > 0: the bucket started that long before the end of backward
+            hidden = 0.0 if ms <= 0 else max(0.0, min(1.0, before / ms))
+            out.append({"bytes": int(nbytes), "ms": round(ms, 3), "hidden_fraction": round(hidden, 3)})
+        return out
 
     def reduce_metrics(self, loss, mask_prob):
         """The two logged scalars of the reference's loop (`accelerator.gather(loss.repeat(bs)).mean()` and

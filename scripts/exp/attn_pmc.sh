@@ -10,8 +10,8 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in rows:
-    k = r.get("Kernel_Name", "")[:44]
-    if "attn_" not in k: continue
+    k = r.get("Kernel_Name", "")[:60]
+    if "attn" not in k: continue
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     cnt[(k, r["Counter_Name"])] += 1
 for k, d in agg.items():

@@ -59,6 +59,9 @@ g256p_check)
   MUSE_G256P_EPI=${3:-5} timeout 600 python scripts/exp/g256p_probe.py check 2>&1 | grep -v amdgpu.ids > $O/${tag}_g256p_check.txt
   grep -c "rerun_identical True" $O/${tag}_g256p_check.txt; grep -E "False|e-0[01]|e\+0|Error|error" $O/${tag}_g256p_check.txt | cut -c1-200 | head -20
   ;;
+attn_pmc)
+  bash scripts/exp/attn_pmc.sh; cp $O/attn_pmc_summary.txt $O/${tag}_attn_pmc.txt
+  ;;
 tests)
   timeout 2400 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/${tag}_pytest.txt 2>&1; echo "pytest exit $?" >> $O/${tag}_pytest.txt
   grep -E "passed|failed|pytest exit|^FAILED|^ERROR" $O/${tag}_pytest.txt | tail -5

@@ -1107,6 +1107,11 @@ def test_bench_two_rank_protocol_on_one_gpu():
     comm = line["comm"]
     assert comm["ranks"] == 2 and comm["buckets_per_step"] >= 1 and comm["bytes_per_step"] == 922245120
     assert comm["same_gpus_step_without_reducer_ms"] > 0 and comm["allreduce_alone_ms"] > 0 and "hidden_fraction_of_allreduce" in comm
+    # the fields that make a 6.4x-or-7.7x outcome attributable from one line: payload dtype, bucket size, per-bucket hidden share
+    assert comm["grad_allreduce_dtype"] == "f32" and comm["bucket_bytes"] == 64 << 20
+    pb = comm["per_bucket"]
+    assert len(pb) == round(comm["buckets_per_step"]) and sum(b["bytes"] for b in pb) == comm["bytes_per_step"]
+    assert all(0.0 <= b["hidden_fraction"] <= 1.0 and b["ms"] > 0 for b in pb)
     assert 1.0 < line["extra"]["loss"] < 10.0
 
 
