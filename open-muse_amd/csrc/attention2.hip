@@ -101,15 +101,19 @@ __device__ __forceinline__ void lds_dma16(const i32x4& desc, unsigned lds_addr, 
 // one operand image [288 rows][STR] <- rows 0 .. rows_valid-1 of a head's [S][HD] slice (row r at r * ld_bytes); everything else zeros.
 // 32 (hd 48) wave-instructions, 8 per wave; the lane <-> slot map is linear (that is what the LDS side of the DMA does), the source
 // offset is per lane.
-constexpr int NW = 4;   // waves per workgroup
-template <int HD>
+constexpr int NW = 4;   // waves per workgroup of the forward kernel
+#ifndef ATT2_BWD_NW
+#define ATT2_BWD_NW 4    // ... of the backward kernel.  (8 = one block per wave and phase, 4 waves per SIMD: does not fit 128 VGPRs - phase 2
+                         // holds dK, dV (64) + the K, V operand rows (24) + S, dP (32) before any temporary: 36-51 spilled dwords, not pursued)
+#endif
+template <int HD, int NWV = NW>
 __device__ __forceinline__ void dma_image(unsigned char* img, const void* base, unsigned bytes, unsigned ld_bytes, int rows_valid,
                                           const LaneGeom& g) {
   using C = Cfg<HD>;
   const i32x4 desc = dma_desc(base, bytes);
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(lds_u8*)img);
 #pragma unroll
-  for (int n0 = 0; n0 < C::NDMA; n0 += NW) {
+  for (int n0 = 0; n0 < C::NDMA; n0 += NWV) {
     const int n = n0 + g.wave;
     if (n < C::NDMA) {
       const int s = n * 64 + g.lane;
@@ -248,7 +252,7 @@ __device__ __forceinline__ void stagger_start(int ncu, int cycles) {
 
 #ifdef ATT2_TS   // timing experiments (scripts/exp/attn2_ts.py): s_memtime stamps per wave
 __device__ long* g_ts = nullptr;
-#define ATT2_STAMP(K) do { __builtin_amdgcn_sched_barrier(0); if (g_ts && g.lane == 0) g_ts[((long)blockIdx.x * NW + g.wave) * 16 + (K)] = (long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATT2_STAMP(K) do { __builtin_amdgcn_sched_barrier(0); if (g_ts && g.lane == 0) g_ts[((long)blockIdx.x * (blockDim.x >> 6) + g.wave) * 16 + (K)] = (long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define ATT2_STAMP(K)
 #endif
@@ -465,9 +469,10 @@ __device__ __forceinline__ void p_and_ds(f32x16& s, f32x16& dp, float c, const f
   }
 }
 
-template <int HD, bool TAIL>
-__global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int ncu, int stagger) {
+template <int HD, bool TAIL, int NWB>
+__global__ __launch_bounds__(NWB * 64, NWB == 8 ? 4 : 2) void bwd_kernel(const AttnParams P, int ncu, int stagger) {
   using C = Cfg<HD>;
+  constexpr int BPW = 8 / NWB;   // own blocks per wave and phase; key / query blocks of the shared (9th) block per wave
   constexpr int NB = TAIL ? 9 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* imgA = smem;                           // phase 1: K, phase 2: Q
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int
   const float c = P.alpha * LOG2E;
   auto rsrc_of = [&](const bf16_t* base, long bs, long ld) { return make_rsrc(base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2); };
   auto dma_of = [&](unsigned char* img, const bf16_t* base, long bs, long ld) {
-    dma_image<HD>(img, base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2, (unsigned)ld * 2, S, g);
+    dma_image<HD, NWB>(img, base + b * bs + hh * HD, (unsigned)((S - 1) * ld + HD) * 2, (unsigned)ld * 2, S, g);
   };
   const rsrc_t rq = rsrc_of(P.q, P.bq, P.ldq), rk = rsrc_of(P.k, P.bk, P.ldk), rv = rsrc_of(P.v, P.bv, P.ldv), ro = rsrc_of(P.o, P.bo, P.ldo),
                rdo = rsrc_of(P.d_o, P.bdo, P.lddo);
@@ -523,8 +528,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int
   //  chains and dQ split over two accumulator sets - 256 VGPRs with 10 spilled, 103 us against 91-96; the operand rows of both own
   //  blocks fetched under the DMA's flight - 214 VGPRs, 93-99 us: no gain.)
 #pragma unroll 1
-  for (int i = 0; i < 2; ++i) {
-    const int qb = g.wave + NW * i;
+  for (int i = 0; i < BPW; ++i) {
+    const int qb = g.wave + NWB * i;
     const FragB<HD> qf = load_fragb<HD>(rq, ldq_b, qb, g);
     const FragB<HD> dof = load_fragb<HD>(rdo, lddo_b, qb, g);
     f32x16 l2v, dsv;
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int
     if (i == 0) ATT2_STAMP(3);
   }
   ATT2_STAMP(4);
-  if (TAIL) {   // query block 8: wave w against key blocks 2 w, 2 w + 1 (wave 3 also block 8); partial dQ rows through LDS
+  if (TAIL) {   // query block 8: wave w against BPW key blocks (the last wave also block 8); partial dQ rows through LDS
     const FragB<HD> qf = load_fragb_few<HD>(rq, ldq_b, 8, nsh, g);
     const FragB<HD> dof = load_fragb_few<HD>(rdo, lddo_b, 8, nsh, g);
     const FragB<HD> of = load_fragb_few<HD>(ro, ldo_b, 8, nsh, g);
@@ -562,9 +567,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int
     f32x16 dq[C::NDB];
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) dq[db] = zero16();
-    k_block(2 * g.wave, false, qf, dof, l2v, dsv, dq);
-    k_block(2 * g.wave + 1, false, qf, dof, l2v, dsv, dq);
-    if (g.wave == NW - 1) k_block(8, true, qf, dof, l2v, dsv, dq);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) k_block(BPW * g.wave + j, false, qf, dof, l2v, dsv, dq);
+    if (g.wave == NWB - 1) k_block(8, true, qf, dof, l2v, dsv, dq);
     if (g.n < nsh) write_partial<HD>(scratch + (g.wave * MAXSH + g.n) * BWD_PW, dq, g.h);
   }
   ATT2_STAMP(5);
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int
       const int q = idx / HD, d = idx - q * HD;
       float a = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) a += scratch[(w * MAXSH + q) * BWD_PW + d];
+      for (int w = 0; w < NWB; ++w) a += scratch[(w * MAXSH + q) * BWD_PW + d];
       P.dq[b * P.bdq + (long)(256 + q) * P.lddq + hh * HD + d] = f32_to_bf16(a * P.alpha);
     }
   }
@@ -601,8 +606,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int
     mma_seq<HD>(imgA, g, qb, dp, t2, dk);
   };
 #pragma unroll 1
-  for (int i = 0; i < 2; ++i) {
-    const int kb = g.wave + NW * i;
+  for (int i = 0; i < BPW; ++i) {
+    const int kb = g.wave + NWB * i;
     const FragB<HD> kf = load_fragb<HD>(rk, ldk_b, kb, g);
     const FragB<HD> vf = load_fragb<HD>(rv, ldv_b, kb, g);
     f32x16 dk[C::NDB], dv[C::NDB];
@@ -618,15 +623,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int
     if (i == 0) ATT2_STAMP(9);
   }
   ATT2_STAMP(10);
-  if (TAIL) {   // key block 8: wave w against query blocks 2 w, 2 w + 1 (wave 3 also block 8); partial dK / dV rows through LDS
+  if (TAIL) {   // key block 8: wave w against BPW query blocks (the last wave also block 8); partial dK / dV rows through LDS
     const FragB<HD> kf = load_fragb_few<HD>(rk, ldk_b, 8, nsh, g);
     const FragB<HD> vf = load_fragb_few<HD>(rv, ldv_b, 8, nsh, g);
     f32x16 dk[C::NDB], dv[C::NDB];
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
-    q_block(2 * g.wave, kf, vf, 2, dk, dv);
-    q_block(2 * g.wave + 1, kf, vf, 2, dk, dv);
-    if (g.wave == NW - 1) q_block(8, kf, vf, 1, dk, dv);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) q_block(BPW * g.wave + j, kf, vf, 2, dk, dv);
+    if (g.wave == NWB - 1) q_block(8, kf, vf, 1, dk, dv);
     if (g.n < nsh) {
       float* mine = scratch + (g.wave * MAXSH + g.n) * BWD_PW;
       write_partial<HD>(mine, dk, g.h);
@@ -638,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_kernel(const AttnParams P, int
         const int k = idx / HD, d = idx - k * HD;
         float a = 0.f, e = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { a += scratch[(w * MAXSH + k) * BWD_PW + d]; e += scratch[(w * MAXSH + k) * BWD_PW + HD + d]; }
+        for (int w = 0; w < NWB; ++w) { a += scratch[(w * MAXSH + k) * BWD_PW + d]; e += scratch[(w * MAXSH + k) * BWD_PW + HD + d]; }
         P.dk[b * P.bdk + (long)(256 + k) * P.lddk + hh * HD + d] = f32_to_bf16(a * P.alpha);
         P.dv[b * P.bdv + (long)(256 + k) * P.lddv + hh * HD + d] = f32_to_bf16(e);
       }
@@ -690,13 +695,14 @@ int attn2_bwd_try(const AttnParams& P, int head_dim, int batch, hipStream_t st) 
   using namespace attn2;
   if (!shape_ok(P, head_dim)) return 0;
   constexpr int HD = 48;
-  const size_t lds = 2 * (size_t)Cfg<HD>::IMG + 2 * Cfg<HD>::ROWS * 4 + NW * MAXSH * BWD_PW * 4;
+  constexpr int NWB = ATT2_BWD_NW;
+  const size_t lds = 2 * (size_t)Cfg<HD>::IMG + 2 * Cfg<HD>::ROWS * 4 + NWB * MAXSH * BWD_PW * 4;
   auto launch = [&](auto k) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(batch * P.nh), dim3(NW * 64), lds, st, P, num_cus(), env_int("MUSE_ATTN2_STAGGER_BWD", 0));
+    hipLaunchKernelGGL(k, dim3(batch * P.nh), dim3(NWB * 64), lds, st, P, num_cus(), env_int("MUSE_ATTN2_STAGGER_BWD", 0));
   };
-  if (P.sq > 256) launch(bwd_kernel<HD, true>);
-  else launch(bwd_kernel<HD, false>);
+  if (P.sq > 256) launch(bwd_kernel<HD, true, NWB>);
+  else launch(bwd_kernel<HD, false, NWB>);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 1 : -(int)e;
 }
