@@ -62,6 +62,38 @@ g256p_check)
 attn_pmc)
   bash scripts/exp/attn_pmc.sh; cp $O/attn_pmc_summary.txt $O/${tag}_attn_pmc.txt
   ;;
+final)  # validation of the committed tree: device, full GPU suite (printed error figures), smoke, PMC traffic passes (FETCH_SIZE / WRITE_SIZE in
+        # separate runs), MFMA-busy / clock counters over the GEMM / convolution probes, the default bench line with every leg, rocprof
+        # of the serial bench, the driver's launch line at one rank.  scripts/gpu.sh final <tag>
+  T=$tag
+  rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > $O/${T}_device.txt
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -rP -p no:cacheprovider > $O/${T}_pytest_gpu.txt 2>&1; echo "pytest exit $?" >> $O/${T}_pytest_gpu.txt
+  grep -E "passed|failed|pytest exit|^FAILED|^ERROR" $O/${T}_pytest_gpu.txt | tail -8
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${T}_smoke.txt 2>&1; echo "smoke exit $?" >> $O/${T}_smoke.txt; tail -2 $O/${T}_smoke.txt
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $O/pmc_$c
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prefetch > $O/pmc_$c.log 2>&1
+    echo "$c exit $?"
+  done
+  f=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && [ -n "$w" ] && python scripts/traffic_summary.py "$f" "$w" $O/${T}_traffic.json && cp $O/${T}_traffic.json profiles/r05_traffic.json
+  find $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE -name "*.csv" -size +4M -delete
+  rm -rf $O/pmc_mfma
+  REPS=3 WHICH=nn,nt,grp,conv timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o p -- python scripts/gemm_probe.py > $O/pmc_mfma.log 2>&1
+  python scripts/pmc_fold.py $O/pmc_mfma | tee $O/${T}_pmc_mfma_clock.txt | tail -14
+  find $O/pmc_mfma -name "*.csv" -size +2M -delete
+  timeout 1800 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err; echo "bench exit $?"; tail -c 400 $O/${T}_bench.err
+  python scripts/bench_summary.py $O/${T}_bench.json
+  rm -rf $O/prof_serial
+  MUSE_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-prefetch > $O/${T}_prof.txt 2>&1
+  f=$(find $O/prof_serial -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${T}_kernel_stats.csv && head -14 "$f" | cut -c1-170
+  find $O/prof_serial -name "*kernel_trace*" -size +8M -delete
+  MUSE_BENCH_RCCL_DEBUG=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-extra --no-cpu-baseline 2>$O/${T}_dp1.err > $O/${T}_dp1.out
+  python -c "
+import json
+ls=[l for l in open('$O/${T}_dp1.out') if l.strip()]
+print('stdout lines', len(ls)); d=json.loads(ls[-1]); print('dp1', d['value'], d['ms_per_step']); open('$O/${T}_dp1_comm_block.json','w').write(json.dumps(d.get('comm'), indent=1)); print(json.dumps(d.get('comm'))[:1500])"
+  ;;
 tests)
   timeout 2400 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/${tag}_pytest.txt 2>&1; echo "pytest exit $?" >> $O/${tag}_pytest.txt
   grep -E "passed|failed|pytest exit|^FAILED|^ERROR" $O/${tag}_pytest.txt | tail -5

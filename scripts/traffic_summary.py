@@ -1,4 +1,4 @@
-"""Fold the two PMC passes of scripts/gpu_traffic_bench.sh (FETCH_SIZE, WRITE_SIZE counter_collection.csv) into
+"""Fold the two PMC passes of scripts/gpu.sh final (FETCH_SIZE, WRITE_SIZE counter_collection.csv) into
 profiles/r02_traffic.json: per kernel, per launch, HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the counters are in KiB; on
 gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read - /opt/skills/guides/MI355X_MICROARCH.md, section HBM).
     python scripts/traffic_summary.py fetch.csv write.csv out.json"""
@@ -23,7 +23,7 @@ for k in fetch:
                         "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
 top = dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:40])
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prefetch`; "
-                   "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, averaged over all launches of the kernel in the run (scripts/gpu_traffic_bench.sh)",
+                   "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, averaged over all launches of the kernel in the run (scripts/gpu.sh final)",
            "kernels": top}, open(sys.argv[3], "w"), indent=1)
 for k, v in list(top.items())[:12]:
     print(f"{v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch x{v['launches_sampled']:4d}  {k[:90]}")
