@@ -5,7 +5,9 @@ ds_read_b128 / ds_read_b64_tr_b16 operand addresses, the register <-> row map of
 v_permlane32_swap store packing, the L2 / DS array order) on top of the DOCUMENTED instruction semantics
 (/opt/skills/guides/cdna_hip_programming.md section 3, T10, T21) and checks the result against plain attention in float64.
 A formula that is wrong here is wrong on the GPU; one that is right here can still meet a hardware semantic the guide states
-differently - the GPU parity tests decide that.
+differently - the GPU parity tests decide that (they passed on the first run).  The work split emulated here is the first form's
+(eight waves, one query / key block each, the 9th block's streamed dimension cut in eight); the shipped kernels give each of four
+waves two blocks and two slices - the lane arithmetic, which is what this file checks, is the same.
 
     python scripts/exp/attn2_emulate.py [S]
 """
