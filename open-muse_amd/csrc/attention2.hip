@@ -10,20 +10,20 @@
 //   * v_mfma_f32_32x32x16_bf16 with the scores TRANSPOSED (S^T = K Q^T): a lane owns ONE query column and 16 keys of each
 //     32-key block, so row maxima / sums are plain register chains + one cross-half exchange, and head_dim 48 = 3 K-steps of 16
 //     exactly (no K = 32 + K = 16 pair with its wait states).  A 32-row block re-uses each LDS operand row twice as often.
-//   * exact (non-online) softmax: the 8-9 score blocks of a query block stay in registers (one workgroup of 8 waves per CU,
-//     256 VGPRs per wave), so there is no per-tile rescale of the output accumulator.
+//   * exact (non-online) softmax: the 8-9 score blocks of a query block stay in registers (two waves per SIMD, up to 256 VGPRs per
+//     wave), so there is no per-tile rescale of the output accumulator.
 //   * P goes from the score registers to the B operand of the second product WITHOUT lane exchanges: register r of a lane is
 //     key-slot pi(r) of the block, and the A operand (V^T, read with ds_read_b64_tr_b16) is addressed through the same
 //     permutation pi - a contraction does not care about the order of its slots.  pi is chosen so that BOTH read patterns of an
 //     image are bank-conflict free at a row stride of head_dim * 2 + 16 bytes (see perm32).
-//   * persistent workgroups: a workgroup walks its heads; the next head's K / V (backward: the next PHASE's operand pair) arrive by
-//     LDS-DMA (buffer_load ... lds) into the other half of LDS while the current one is being computed: HBM latency and the
-//     55-110 KB per head never sit in front of the math.  Heads are dealt per XCD in contiguous runs (the 16 heads of an image share
-//     their 128-byte lines of the packed qkv rows).
+//   * one head per 4-wave workgroup, two workgroups per CU, operand images by LDS-DMA (buffer_load ... lds, no register pass); the
+//     co-resident workgroups are not synchronised with each other, so one's fetch runs under the other's math (see the comment at
+//     `constexpr int MAXSH` for the persistent prefetching form this replaced).  Consecutive heads run on one XCD (the 16 heads of
+//     an image share the 128-byte lines of its packed qkv rows).
 //   * backward as ONE kernel, two phases per head over the same LDS images: (1) queries stationary -> dQ (K, V images; writes
 //     lse / dsum per query to LDS), (2) keys stationary -> dK, dV (Q, dO images).  Q, K, V, dO, O are read from HBM once.
-//   * the 257th token: query block 8 / key block 8 hold ONE real row.  Every wave takes one 32-wide slice of that block's
-//     streamed dimension and the eight partial results meet in LDS (a few hundred floats).
+//   * the 257th token: query block 8 / key block 8 hold ONE real row.  Every wave takes a slice of that block's streamed
+//     dimension and the partial results meet in LDS (a few hundred floats).
 #include "attention_params.h"
 #include <stdlib.h>
 
