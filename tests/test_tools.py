@@ -37,3 +37,18 @@ def test_overlap_report_interval_arithmetic(tmp_path):
     assert t.family("void ffn_mid_bwd_kernel<unsigned short, 3, true>") == "rows" and t.family("ncclDevKernel_AllReduce") == "collective"
     # --last-ms keeps only the tail of the trace
     assert len(t.load(str(p), last_ms=2.5)) == 1
+
+
+def test_attention2_lane_arithmetic_on_cpu():
+    """scripts/exp/attn2_emulate.py restates the address formulas of csrc/attention2.hip lane by lane (the row permutation pi, both LDS
+    read patterns, the C/D register <-> row map of the 32 x 32 x 16 MFMA, the v_permlane32_swap store packing, the lse / dsum hand-over
+    order) on the documented instruction semantics and checks forward and fused backward of one head against float64 attention - and
+    that both read patterns are bank-conflict free under the guide's LDS model.  S = 257 (one real row in the 9th block) and 240 (keys
+    masked inside the 8th block); the GPU tests (test_one_tile_attention_blocks32) are the parity tests proper."""
+    import subprocess
+    import sys
+    for S in ("257", "240"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "exp", "attn2_emulate.py"), S], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-1500:]
+        assert "OK" in out.stdout and "worst multiplicity of a 16-byte slot inside a service group = 1" in out.stdout
+        assert "worst multiplicity of a bank inside a 32-lane group = 1" in out.stdout
