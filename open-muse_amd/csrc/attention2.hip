@@ -314,6 +314,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_kernel(const AttnParams P, int
   dma_image<HD>(Vimg, P.v + b * P.bv + hh * HD, (unsigned)((S - 1) * P.ldv + HD) * 2, (unsigned)P.ldv * 2, S, g);
   FragB<HD> qf = load_fragb<HD>(rq, ldq_b, g.wave, g);
   ATT2_STAMP(1);
+  static_assert(Cfg<HD>::NDMA % NW == 0, "every wave issues the same number of DMA pieces per image: the counted wait below relies on it");
   // K has landed (mine: every operation but the 8 V pieces and the 3 Q loads issued behind it; then everyone's); V may still be in flight
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg<HD>::NDMA / NW + Cfg<HD>::KS) : "memory");
   __builtin_amdgcn_s_barrier();
