@@ -626,6 +626,28 @@ def test_one_tile_attention_blocks32(B, S, nh, monkeypatch):
     assert float(growdiff.max()) < 0.1, float(growdiff.max())
 
 
+def test_one_tile_attention_under_graph_capture():
+    """the 32 x 32-block attention kernels inside a captured HIP graph (the decoding loop of generate2 captures its forward; a
+    training step can be captured too): replay == eager, bit for bit, forward and backward"""
+    ops = _ops()
+    B, S, nh, hd = 2, 257, 4, 48
+    H = nh * hd
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+    qkv = rnd((B * S, 3 * H), 150, 1.0).to(torch.bfloat16).to(DEV)
+    dctx = rnd((B * S, H), 151).to(torch.bfloat16).to(DEV)
+    ctx0, lse0 = ops.attention_fwd(qkv, B, S, nh, hd, alpha)
+    dqkv0 = ops.attention_bwd(qkv, ctx0, dctx, lse0, B, S, nh, hd, alpha)
+
+    def run():
+        c, l = ops.attention_fwd(qkv, B, S, nh, hd, alpha)
+        return c, l, ops.attention_bwd(qkv, c, dctx, l, B, S, nh, hd, alpha)
+    graph, (c1, l1, d1) = ops.capture_graph(run)
+    c1.zero_(); d1.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(c1, ctx0) and torch.equal(l1[:, :S], lse0[:, :S]) and torch.equal(d1, dqkv0)
+
+
 @pytest.mark.parametrize("B,Sq,Skv,nh,hd", [(2, 256, 77, 2, 64), (1, 1024, 77, 2, 64), (2, 40, 130, 2, 48), (1, 1024, 1024, 2, 64),
                                              (1, 600, 300, 1, 48), (2, 256, 256, 3, 32), (1, 1025, 1025, 1, 16), (2, 50, 7, 2, 64)])
 def test_fused_attention_general_lengths(B, Sq, Skv, nh, hd):
