@@ -90,7 +90,7 @@ class _GeneralFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, input_ids, enc, labels, label_smoothing, cond_dropout_prob, cond_uniforms, need_grad, *params):
-        model.__dict__["_act_cache"] = {}
+        model._drop_step_caches()
         model.__dict__["_act_cache_on"] = bool(need_grad)
         with model._gemm_mode():
             logits, loss, tape = model._gen_forward(input_ids, enc, labels, label_smoothing, cond_dropout_prob, cond_uniforms, need_grad)
@@ -113,10 +113,10 @@ class _GeneralFn(torch.autograd.Function):
         model = ctx.model
         model.__dict__["_dw_pending"] = []          # (a backward that raised may have left collected products behind)
         model.__dict__["_grads_reported"] = set()
-        with model._gemm_mode():
+        with model._gemm_mode(backward=True):
             G = model._gen_backward(ctx.tape, g_loss, ctx.enc_grad)
         ctx.tape = None
-        model.__dict__["_act_cache"] = {}
+        model._drop_step_caches()
         grads = tuple(G.get(name) for name, _ in model.named_parameters())
         return (None, None, G.get("__encoder_hidden_states__"), None, None, None, None, None) + grads
 

@@ -179,7 +179,7 @@ class _UViTFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad, *params):
-        model.__dict__["_act_cache"] = {}
+        model._drop_step_caches()
         model.__dict__["_act_cache_on"] = bool(need_grad)
         with model._gemm_mode():
             logits, loss, tape = model._run_forward(input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad)
@@ -200,10 +200,10 @@ class _UViTFn(torch.autograd.Function):
         model = ctx.model
         model.__dict__["_dw_pending"] = []          # (a backward that raised may have left collected products behind)
         model.__dict__["_grads_reported"] = set()
-        with model._gemm_mode():
+        with model._gemm_mode(backward=True):
             G = model._run_backward(ctx.tape, g_loss)
         ctx.tape = None
-        model.__dict__["_act_cache"] = {}
+        model._drop_step_caches()
         grads = tuple(G.get(name) for name, _ in model.named_parameters())
         return (None,) * 9 + grads
 

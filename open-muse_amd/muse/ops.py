@@ -161,19 +161,72 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
 # the bf16 kernels at 1/3 of their rate.  Scoped by a context manager the models enter for "bf16x3" compute; a product the bf16 kernels
 # cannot take (operand rows that are not whole 16-byte chunks in bf16) silently stays on the exact-f32 kernel.
 _F32_AS_BF16X3 = [False]
+_X3_IMAGES = [None]      # the operand-image cache of the pass that is running (X3Images), or None
+
+
+class X3Images:
+    """The bf16x3 operand images of ONE training step, so that a tensor is split once per step instead of once per product.  An
+    activation x is the A operand of its Linear's forward product and the B operand of the weight-gradient product; a gradient dY is
+    the A operand of the dX product and the A operand of dW.  With the patterns chosen in `_gemm_bf16x3` / `linear_wgrad` ONE image
+    serves both uses: the row-concatenated image [T, 3K] of the forward / dX product, viewed as [3T, K], IS the token-stacked image of
+    the dW product (token t's three thirds are rows 3t .. 3t+2 - a contraction does not care about the order of its slots).
+    Keyed by (storage address, shape, strides, autograd version, layout, pattern); an entry keeps its source tensor alive, so an
+    address cannot come back with other contents while the entry exists.  HIP kernels of this package write through raw pointers
+    (no version bump): the owner clears the cache at the start of a forward and at the end of a backward - within those bounds a GEMM
+    operand is never rewritten between two uses (the tape needs the same bytes for dW).  Images made during the backward (dY) are
+    dead two products later: they live in a short LRU."""
+
+    def __init__(self, recent=12):
+        self.persist, self.lru, self.recent, self.backward = {}, {}, int(recent), False
+        self.hits = self.misses = 0
+
+    def clear(self):
+        self.persist.clear()
+        self.lru.clear()
+
+    @staticmethod
+    def _key(t, layout, lo_pos):
+        return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, layout, lo_pos)
+
+    def get(self, t, layout, K, lo_pos, last_use=False):
+        key = self._key(t, layout, lo_pos)
+        hit = self.persist.pop(key, None) if last_use else self.persist.get(key)
+        if hit is not None and last_use:      # (the weight-gradient product is an activation's last reader - bar siblings that share it, q / k / v)
+            self._recent(key, hit)
+        if hit is None:
+            hit = self.lru.get(key)
+        if hit is not None:
+            self.hits += 1
+            return hit[1], hit[2]
+        self.misses += 1
+        out, ld = _split_cat3_now(t, layout, K, lo_pos)
+        if self.backward or last_use:
+            self._recent(key, (t, out, ld))
+        else:
+            self.persist[key] = (t, out, ld)
+        return out, ld
+
+    def _recent(self, key, entry):
+        self.lru[key] = entry
+        while len(self.lru) > self.recent:
+            self.lru.pop(next(iter(self.lru)))
 
 
 class f32_gemms_as_bf16x3:
-    def __init__(self, on=True):
+    """`images`: an X3Images to share operand images between the products of a step (None: every product splits its operands)"""
+    def __init__(self, on=True, images=None):
         self.on = bool(on)
+        self.images = images
 
     def __enter__(self):
-        self.prev = _F32_AS_BF16X3[0]
+        self.prev = (_F32_AS_BF16X3[0], _X3_IMAGES[0])
         _F32_AS_BF16X3[0] = self.on
+        if self.on:
+            _X3_IMAGES[0] = self.images
         return self
 
     def __exit__(self, *exc):
-        _F32_AS_BF16X3[0] = self.prev
+        _F32_AS_BF16X3[0], _X3_IMAGES[0] = self.prev
         return False
 
 
@@ -196,7 +249,15 @@ def split_f32(t):
 X3_CAT = os.environ.get("MUSE_X3_CAT", "1") != "0"    # bf16x3 GEMM mode: one launch over a 3K-long concatenated operand pair (0: three launches)
 
 
-def split_cat3(t, layout, K, lo_pos):
+def split_cat3(t, layout, K, lo_pos, last_use=False):
+    """_split_cat3_now through the running step's image cache (X3Images), when there is one"""
+    im = _X3_IMAGES[0]
+    if im is None:
+        return _split_cat3_now(t, layout, K, lo_pos)
+    return im.get(t, layout, K, lo_pos, last_use)
+
+
+def _split_cat3_now(t, layout, K, lo_pos):
     """the bf16x3 operand of a 2-D contiguous f32 tensor for a product over its K dimension: layout 0 (k-contiguous [R, K]) ->
     ([R, 3K], ld 3K), layout 1 (k-major [K, R]) -> ([3K, R], ld R); thirds (hi | hi | lo) for lo_pos 2, (hi | lo | hi) for lo_pos 1"""
     require_gpu(t)
@@ -238,9 +299,12 @@ def _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, 
             and 3 * B.numel() * 2 < (1 << 31)):
         # ONE launch: A' = (hi | hi | lo), B' = (hi | lo | hi) along a three times longer K (muse_split_f32_to_bf16_cat3) - one epilogue,
         # no read-modify-write of C between the terms, the persistent kernel where the plain product would take it
+        # which operand carries (hi | hi | lo) and which (hi | lo | hi) is free as long as the two differ; chosen so that the images of
+        # a Linear's forward (x W^T: lb = 0) and dX (dY W: lb = 1) products are the ones its dW product wants (X3Images)
+        pa, pb = (2, 1) if lb == 0 else (1, 2)
         with f32_gemms_as_bf16x3(False):
-            a3, lda3 = split_cat3(A, la, K, 2)
-            b3, ldb3 = split_cat3(B, lb, K, 1)
+            a3, lda3 = split_cat3(A, la, K, pa)
+            b3, ldb3 = split_cat3(B, lb, K, pb)
             gemm(a3, b3, C_, M, N, 3 * K, la=la, lb=lb, lda=lda3, ldb=ldb3, ldc=ldc, c_off=c_off, alpha=alpha, bias=bias, rowvec=rowvec,
                  residual=residual, ldr=ldr, accumulate=accumulate)
         return True
@@ -359,10 +423,13 @@ def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
         with f32_gemms_as_bf16x3(False):
             if (X3_CAT and dy.dim() == 2 and x.dim() == 2 and dy.is_contiguous() and x.is_contiguous() and (lda is None or lda == dy.stride(0))
                     and dy.shape[0] == x.shape[0] and 3 * dy.numel() * 2 < (1 << 32) - 64 and 3 * x.numel() * 2 < (1 << 32) - 64):
-                # one product over 3 T tokens: dY' = (hi ; hi ; lo), X' = (hi ; lo ; hi) stacked along the token dimension
-                dy3, _ = split_cat3(dy, 1, dy.shape[0], 2)
-                x3, _ = split_cat3(x, 1, x.shape[0], 1)
-                linear_wgrad(dy3, x3, dw, accumulate, M=M, lda=lda)
+                # one product over 3 T slots: the ROW-concatenated images dY' [T, 3N] = (hi | lo | hi), X' [T, 3K] = (hi | hi | lo) - the ones
+                # the dX product of dY and the forward product of x made (X3Images) - read as [3T, N] / [3T, K]: slot 3t + s holds third s
+                # of token t in both, so the contraction over slots is sum_t hi hi + lo hi + hi lo
+                T_ = dy.shape[0]
+                dy3, _ = split_cat3(dy, 0, dy.shape[1], 1)
+                x3, _ = split_cat3(x, 0, x.shape[1], 2, last_use=True)
+                linear_wgrad(dy3.view(3 * T_, dy.shape[1]), x3.view(3 * T_, x.shape[1]), dw, accumulate, M=M, lda=lda)
             else:                             # three bf16 products through the bf16 split-K machinery, accumulated in a fixed order
                 dyh, dyl = split_f32(dy)
                 xh, xl = split_f32(x)

@@ -16,6 +16,7 @@ from . import ops
 from ._hip import MuseHipError
 
 # MUSE_UVIT_BF16_OPERANDS (experiments): bit 0 = AdaLN writes the bf16 GEMM operand, bit 1 = norm backward writes the bf16 copy of dv
+_X3_IMAGE_CACHE = os.environ.get("MUSE_X3_IMAGES", "1") != "0"   # bf16x3 mode: share operand images inside a step (0: split per product)
 _BF16_OPERANDS = int(os.environ.get("MUSE_UVIT_BF16_OPERANDS", "3"))
 
 
@@ -76,9 +77,25 @@ class TapeOps:
         self.__dict__["_wgen"] = self.__dict__.get("_wgen", 0) + 1      # (a kept decoding graph reads the old weight copies: generate2 re-captures)
         return self
 
-    def _gemm_mode(self):
-        """context manager for one forward / backward pass: f32 GEMMs as three bf16 products in "bf16x3" mode"""
-        return ops.f32_gemms_as_bf16x3(self.__dict__.get("_f32_split3", False))
+    def _gemm_mode(self, backward=False):
+        """context manager for one forward / backward pass: f32 GEMMs as three bf16 products in "bf16x3" mode.  A training step
+        (forward that records a tape, then its backward) shares the operand images of its products (ops.X3Images): an activation /
+        gradient is split once, not once per product that reads it."""
+        on = self.__dict__.get("_f32_split3", False)
+        images = None
+        if on and _X3_IMAGE_CACHE and (backward or self.__dict__.get("_act_cache_on", False)):
+            images = self.__dict__.get("_x3_images")
+            if images is None:
+                images = self.__dict__["_x3_images"] = ops.X3Images()
+            images.backward = bool(backward)
+        return ops.f32_gemms_as_bf16x3(on, images)
+
+    def _drop_step_caches(self):
+        """start of a forward / end of a backward: nothing of the previous pass (bf16 activation copies, bf16x3 operand images) survives"""
+        self.__dict__["_act_cache"] = {}
+        images = self.__dict__.get("_x3_images")
+        if images is not None:
+            images.clear()
 
     def mark_weights_changed(self):
         """call after writing parameters behind autograd's back (`p.data.copy_`, EMA swap): drops the cached bf16 weights"""

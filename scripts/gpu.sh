@@ -94,6 +94,15 @@ import json
 ls=[l for l in open('$O/${T}_dp1.out') if l.strip()]
 print('stdout lines', len(ls)); d=json.loads(ls[-1]); print('dp1', d['value'], d['ms_per_step']); open('$O/${T}_dp1_comm_block.json','w').write(json.dumps(d.get('comm'), indent=1)); print(json.dumps(d.get('comm'))[:1500])"
   ;;
+c4prof) # config 4 (U-ViT) kernel profile, serial: scripts/gpu.sh c4prof <tag> [leg, default 64,256,2,x3]
+  leg=${3:-64,256,2,x3}
+  rm -rf $O/${tag}_c4; cd /tmp
+  MUSE_WGRAD_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/${tag}_c4 -o c -- python $OLDPWD/bench.py --uvit-leg $leg > $OLDPWD/$O/${tag}_c4_leg.txt 2>&1
+  cd $OLDPWD; tail -1 $O/${tag}_c4_leg.txt | cut -c1-300
+  f=$(find $O/${tag}_c4 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${tag}_c4_kernel_stats.csv && head -40 "$f" | cut -c1-150
+  find $O/${tag}_c4 -name "*.csv" -size +3M -delete
+  timeout 600 python bench.py --uvit-leg $leg 2>/dev/null | tail -1 | cut -c1-200
+  ;;
 tests)
   timeout 2400 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/${tag}_pytest.txt 2>&1; echo "pytest exit $?" >> $O/${tag}_pytest.txt
   grep -E "passed|failed|pytest exit|^FAILED|^ERROR" $O/${tag}_pytest.txt | tail -5

@@ -326,6 +326,22 @@ def test_general_transformer_bf16x3_mode_vs_reference_golden(golden_dir):
     worst = max(float(np.abs(W.subsample(params[k].grad.detach()).cpu().numpy() - g["grad." + k]).max()) / float(g["absmax." + k]) for k in keys)
     print(f"bf16x3 mode at the cc12m width vs the reference (f32): logits {el:.2e}, loss {lrel:.1e}, worst gradient {worst:.2e}")
     assert el < 1e-3 and lrel < 1e-4 and worst < 2e-3
+    # the step shared its operand images (ops.X3Images: an activation / gradient split once, read by the forward or dX product AND the
+    # weight-gradient product); the same step with every product splitting its own operands gives the same bits, and nothing of a
+    # step's images survives it
+    im = m.__dict__["_x3_images"]
+    print(f"operand images: {im.hits} shared reads, {im.misses} splits")
+    assert im.hits >= 20 and not im.persist and not im.lru
+    first = {k: params[k].grad.clone() for k in keys}
+    from muse import tape_ops
+    import unittest.mock as um
+    m.zero_grad(set_to_none=True)
+    with um.patch.object(tape_ops, "_X3_IMAGE_CACHE", False):
+        logits2, loss2 = m(input_ids=ids.to(DEV), encoder_hidden_states=enc.to(DEV), labels=labels.to(DEV))
+        loss2.backward()
+    assert torch.equal(logits2, logits) and torch.equal(loss2, loss)
+    for k in keys:
+        assert torch.equal(params[k].grad, first[k]), k
 
 
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
