@@ -148,6 +148,16 @@ int muse_attention_fwd_ex(const muse_attn_desc* d, float* lse, void* stream);
 int muse_attention_bwd_ex(const muse_attn_desc* d, const void* d_o, int64_t lddo, int64_t bsdo, const float* lse, float* dsum,
                           void* dq, int64_t lddq, int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv,
                           int64_t bsdv, void* stream);
+/* The same seam for the "bf16x3" compute mode (f32 tensors, TF32-class products: configs/cc12m_uvit_clip.yaml:102-103 trains with
+ * mixed_precision "no" + enable_tf32): q / k / v / o / d_o / dq / dk / dv are FLOAT tensors (strides in elements, multiples of 4),
+ * every product of the forward and the backward is three bf16 MFMA products of (hi, lo) operand planes the kernel makes itself
+ * (<= 2^-16 relative per product), softmax and accumulation in f32.  head_dim 64, seq_q = 256, seq_kv in 225..256 or 65..96
+ * (self-attention of config 4's 16 x 16 grid; its 77 text states); anything else: MUSE_ERR_UNSUPPORTED (the caller keeps the
+ * materialised route: muse_gemm batched + muse_softmax_*).  lse is f32 [batch*heads, 256]. */
+int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* stream);
+int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, int64_t lddo, int64_t bsdo, const float* lse, void* dq,
+                          int64_t lddq, int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv, int64_t bsdv,
+                          void* stream);
 /* packed self-attention: qkv [B*S, 3*H] (q | k | v, H = heads*head_dim: the fused QKV projection), ctx [B*S, H], dqkv [B*S, 3*H] */
 int muse_attention_fwd(const void* qkv, void* ctx, float* lse, int32_t batch, int32_t seq, int32_t heads,
                        int32_t head_dim, float alpha, void* stream);

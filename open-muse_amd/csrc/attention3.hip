@@ -1,0 +1,370 @@
+// Fused attention of the "bf16x3" compute mode: f32 tensors in and out, every product (Q K^T, P V, and the five of the backward) as
+// three bf16 MFMA products of hi / lo operand planes with f32 accumulation (hi = bf16(x), lo = bf16(x - hi); hi*hi + hi*lo + lo*hi,
+// the dropped lo*lo term is 2^-16 relative) - the TF32-class regime configs/cc12m_uvit_clip.yaml:102-103 trains in (f32 tensors,
+// enable_tf32), on hardware without an xf32 MFMA.  Replaces, for that mode, the materialised route of the tape engines
+// (muse/modeling_transformer_v2.py:881-889 -> reference Attention.attention: baddbmm -> softmax -> matmul and their autograd
+// backward): six batched exact-f32 products + two softmax passes over a [B * heads, 256, S_kv] f32 score tensor, 24 % of a
+// config-4 step at the YAML's precision (profiles/r05_c4_kernel_stats_before.csv).
+//
+// Shapes: head_dim 64, 256 queries (the 16 x 16 latent grid of config 4), S_kv <= 256 keys in whole-kernel template steps
+// (8 key blocks: self-attention; 3: the 77 text states of the cross-attention).  Everything else: MUSE_ERR_UNSUPPORTED, the
+// caller keeps the materialised route.
+//
+// Built from attention2.hip's pieces (attention_blocks.h): 32 x 32 x 16 MFMA blocks with the scores TRANSPOSED, exact softmax
+// with a query block's score blocks in registers, P / dS from the score registers into the B operand of the next product without a
+// lane exchange (row permutation pi), operand images with a row stride of head_dim * 2 + 16 bytes that are bank-conflict free for
+// both read patterns.  What differs:
+//   * the operand images exist twice (hi plane, lo plane) and are WRITTEN BY THE KERNEL: the f32 rows are loaded to registers,
+//     split (common.h split4 - the same split muse_split_f32_to_bf16x2 and the GEMMs' operand images use) and stored; no pre-pass
+//     over q / k / v in HBM, no LDS-DMA;
+//   * a block product is three MFMAs per K step (lo*hi, hi*lo, hi*hi: small terms first); P and dS are split in registers;
+//   * four planes of 256 rows are 147 KB: ONE 8-wave workgroup per CU and head, each wave owns one 32-query block (forward,
+//     backward phase 1) / one 32-key block (backward phase 2).
+#include "attention_blocks.h"
+#include "../../include/muse_hip.h"
+
+namespace attn3 {
+
+using namespace attn2;
+
+constexpr int HD = 64;
+using C = Cfg<HD>;                       // KS = 4, NDB = 2, STR = 144 (9 slots of 16 bytes)
+constexpr int NW3 = 8;                   // waves per workgroup
+constexpr int NT = NW3 * 64;
+constexpr int SQ = 256;                  // queries
+constexpr int PLANE = SQ * C::STR;       // bytes of one 256-row plane
+
+struct Params {
+  const float *q, *k, *v, *o, *d_o;
+  float *out, *dq, *dk, *dv, *lse;
+  long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;     // elements between consecutive tokens
+  long bq, bk, bv, bo, bdo, bdq, bdk, bdv;             // elements between consecutive images
+  int nh, skv;
+  float alpha;
+};
+
+struct FragB3 { bf16x8 h[C::KS], l[C::KS]; };     // B operand of a head-dim contraction, both planes
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+  u32x2 h0, l0, h1, l1;
+  split4(__builtin_bit_cast(u32x4, a), h0, l0);
+  split4(__builtin_bit_cast(u32x4, b), h1, l1);
+  hi = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+  lo = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+}
+
+// the raw f32 values lane (n, h) supplies as B operand of row `row`: columns 16 ks + 8 h .. + 7
+struct Raw { f32x4 a[C::KS], b[C::KS]; };
+__device__ __forceinline__ Raw load_raw(const float* rowp, bool valid, int h) {
+  Raw r;
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    if (valid) {
+      r.a[ks] = *(const f32x4*)(rowp + 16 * ks + 8 * h);
+      r.b[ks] = *(const f32x4*)(rowp + 16 * ks + 8 * h + 4);
+    } else {
+      r.a[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+      r.b[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ FragB3 split_raw(const Raw& r) {
+  FragB3 f;
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) split8(r.a[ks], r.b[ks], f.h[ks], f.l[ks]);
+  return f;
+}
+
+// rows 0 .. nrows-1 of two [.][64] f32 slices -> their (hi, lo) image planes; rows at or past `valid` are zeros.  Every load of both
+// slices is in flight before the first conversion.  nrows * 8 sixteen-byte slots per plane, NT threads: slot s = row * 8 + chunk.
+template <int NROWS>
+__device__ __forceinline__ void fill_two(unsigned char* ah, unsigned char* al, const float* a, long lda, unsigned char* bh, unsigned char* bl,
+                                         const float* b, long ldb, int valid) {
+  constexpr int PER = (NROWS * 8 + NT - 1) / NT;
+  f32x4 va[PER][2], vb[PER][2];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int s = (int)threadIdx.x + i * NT, row = s >> 3, c = s & 7;
+    if (s < NROWS * 8 && row < valid) {
+      const float* pa = a + (long)row * lda + c * 8;
+      const float* pb = b + (long)row * ldb + c * 8;
+      va[i][0] = *(const f32x4*)pa; va[i][1] = *(const f32x4*)(pa + 4);
+      vb[i][0] = *(const f32x4*)pb; vb[i][1] = *(const f32x4*)(pb + 4);
+    } else {
+      va[i][0] = va[i][1] = vb[i][0] = vb[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int s = (int)threadIdx.x + i * NT, row = s >> 3, c = s & 7;
+    if (s < NROWS * 8) {
+      bf16x8 hi, lo;
+      split8(va[i][0], va[i][1], hi, lo);
+      *(bf16x8*)(ah + row * C::STR + c * 16) = hi;
+      *(bf16x8*)(al + row * C::STR + c * 16) = lo;
+      split8(vb[i][0], vb[i][1], hi, lo);
+      *(bf16x8*)(bh + row * C::STR + c * 16) = hi;
+      *(bf16x8*)(bl + row * C::STR + c * 16) = lo;
+    }
+  }
+}
+
+// acc += rows(blk) of the image x fragment, three products per K step
+__device__ __forceinline__ f32x16 mma_rows3(const unsigned char* ih, const unsigned char* il, const LaneGeom& g, int blk, const FragB3& b, f32x16 acc) {
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const bf16x8 ah = frag_rows<HD>(ih, g, blk, ks), al = frag_rows<HD>(il, g, blk, ks);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.h[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.l[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.h[ks], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// registers 8 t .. 8 t + 7 of x as B-operand slots, both planes
+__device__ __forceinline__ void pack8x3(const f32x16& x, int t, bf16x8& hi, bf16x8& lo) {
+  union { uint32_t w[4]; bf16x8 b; } uh, ul;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x0 = x[8 * t + 2 * e], x1 = x[8 * t + 2 * e + 1];
+    const uint32_t w = pack2_bf16(x0, x1);
+    uh.w[e] = w;
+    ul.w[e] = pack2_bf16(x0 - __uint_as_float(w << 16), x1 - __uint_as_float(w & 0xffff0000u));
+  }
+  hi = uh.b; lo = ul.b;
+}
+// acc[db] += img^T[:, rows of blk] * x[rows, :]   (sequence contraction, transposed image reads)
+__device__ __forceinline__ void mma_seq3(const unsigned char* ih, const unsigned char* il, const LaneGeom& g, int blk, const f32x16& x,
+                                         f32x16 (&acc)[C::NDB]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    bf16x8 xh, xl;
+    pack8x3(x, t, xh, xl);
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) {
+      const bf16x8 ah = frag_tr<HD>(ih, g, blk, t, db), al = frag_tr<HD>(il, g, blk, t, db);
+      acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[db], 0, 0, 0);
+      acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[db], 0, 0, 0);
+      acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[db], 0, 0, 0);
+    }
+  }
+}
+// acc[db][r] = value of row n at column 32 db + 8 (r >> 2) + 4 h + (r & 3): 16-byte stores
+__device__ __forceinline__ void store_rows3(float* rowp, const f32x16 (&acc)[C::NDB], float scale, int h) {
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      *(f32x4*)(rowp + 32 * db + 8 * q4 + 4 * h) =
+          f32x4{acc[db][4 * q4] * scale, acc[db][4 * q4 + 1] * scale, acc[db][4 * q4 + 2] * scale, acc[db][4 * q4 + 3] * scale};
+}
+
+// =================================================================================================================
+// forward: wave w owns queries 32 w .. 32 w + 31
+// =================================================================================================================
+template <int NKB>
+__global__ __launch_bounds__(NT, 2) void fwd_kernel(const Params P) {
+  constexpr int PL = NKB * 32 * C::STR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *Kh = smem, *Kl = smem + PL, *Vh = smem + 2 * PL, *Vl = smem + 3 * PL;
+  const LaneGeom g = make_geom<HD>();
+  const int head = xcd_remap();
+  const int b = head / P.nh, hh = head - b * P.nh;
+  const int last_valid = P.skv - 32 * (NKB - 1);
+  const float c = P.alpha * LOG2E;
+  const int q = g.wave * 32 + g.n;
+
+  const Raw qr = load_raw(P.q + b * P.bq + (long)q * P.ldq + hh * HD, true, g.h);
+  fill_two<NKB * 32>(Kh, Kl, P.k + b * P.bk + hh * HD, P.ldk, Vh, Vl, P.v + b * P.bv + hh * HD, P.ldv, P.skv);
+  const FragB3 qf = split_raw(qr);
+  lds_barrier();
+
+  f32x16 s[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) s[kb] = mma_rows3(Kh, Kl, g, kb, qf, kb == NKB - 1 ? mask16(last_valid, g.h) : zero16());
+  float m = NEG_BIG;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kb][r]);
+  m = fmaxf(m, xhalf(m));
+  const float mc = m * c;
+  float l = 0.f;
+  f32x16 o[C::NDB];
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db) o[db] = zero16();
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc)); l += s[kb][r]; }
+    mma_seq3(Vh, Vl, g, kb, s[kb], o);
+  }
+  l += xhalf(l);
+  store_rows3(P.out + b * P.bo + (long)q * P.ldo + hh * HD, o, 1.0f / l, g.h);
+  if (g.h == 0) P.lse[(long)head * SQ + q] = m * P.alpha + __logf(l);
+}
+
+// =================================================================================================================
+// backward: phase 1 queries stationary (K, V planes) -> dQ; phase 2 keys stationary (Q, dO planes) -> dK, dV
+// =================================================================================================================
+template <bool PER_REG>
+__device__ __forceinline__ void p_and_ds(f32x16& s, f32x16& dp, float c, const f32x16& l2) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -(PER_REG ? l2[r] : l2[0])));
+    dp[r] = pv * dp[r];       // (dp arrives as dP - dsum: the dP product accumulates onto a C operand that holds -dsum)
+    s[r] = pv;
+  }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *Ah = smem, *Al = smem + PLANE, *Bh = smem + 2 * PLANE, *Bl = smem + 3 * PLANE;   // phase 1: K, V   phase 2: Q, dO
+  float* L2 = (float*)(smem + 4 * PLANE);      // lse * log2(e) per query in MFMA-row order: position 32 blk + i <-> query 32 blk + perm32(i)
+  float* DS = L2 + SQ;                         // -dsum, same order
+  const LaneGeom g = make_geom<HD>();
+  const int head = xcd_remap();
+  const int b = head / P.nh, hh = head - b * P.nh;
+  const int last_valid = P.skv - 32 * (NKB - 1);
+  const float c = P.alpha * LOG2E;
+  const float* qh = P.q + b * P.bq + hh * HD;
+  const float* kh = P.k + b * P.bk + hh * HD;
+  const float* vh = P.v + b * P.bv + hh * HD;
+  const float* doh = P.d_o + b * P.bdo + hh * HD;
+
+  // ---------------- phase 1 ----------------
+  {
+    const int q = g.wave * 32 + g.n;
+    const Raw qr = load_raw(qh + (long)q * P.ldq, true, g.h);
+    const Raw dor = load_raw(doh + (long)q * P.lddo, true, g.h);
+    const Raw orr = load_raw(P.o + b * P.bo + (long)q * P.ldo + hh * HD, true, g.h);
+    const float lse = P.lse[(long)head * SQ + q];
+    fill_two<NKB * 32>(Ah, Al, kh, P.ldk, Bh, Bl, vh, P.ldv, P.skv);
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d = fmaf(dor.a[ks][e], orr.a[ks][e], d); d = fmaf(dor.b[ks][e], orr.b[ks][e], d); }
+    d += xhalf(d);
+    const float l2 = lse * LOG2E;
+    if (g.h == 0) { L2[g.wave * 32 + perm32_inv(g.n)] = l2; DS[g.wave * 32 + perm32_inv(g.n)] = -d; }
+    const FragB3 qf = split_raw(qr), dof = split_raw(dor);
+    f32x16 l2v, dsv;
+    l2v[0] = l2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dsv[r] = -d;
+    lds_barrier();
+    f32x16 dq[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) dq[db] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      f32x16 s = mma_rows3(Ah, Al, g, kb, qf, kb == NKB - 1 ? mask16(last_valid, g.h) : zero16());
+      f32x16 dp = mma_rows3(Bh, Bl, g, kb, dof, dsv);
+      p_and_ds<false>(s, dp, c, l2v);
+      mma_seq3(Ah, Al, g, kb, dp, dq);
+    }
+    store_rows3(P.dq + b * P.bdq + (long)q * P.lddq + hh * HD, dq, P.alpha, g.h);
+  }
+  lds_barrier();       // everybody is done with the K, V planes; L2 / DS are written
+  // ---------------- phase 2 ----------------
+  {
+    const int key = g.wave * 32 + g.n;
+    const bool own = g.wave < NKB;                       // (wave-uniform)
+    const bool valid = own && key < P.skv;
+    const Raw kr = load_raw(kh + (long)key * P.ldk, valid, g.h);
+    const Raw vr = load_raw(vh + (long)key * P.ldv, valid, g.h);
+    fill_two<SQ>(Ah, Al, qh, P.ldq, Bh, Bl, doh, P.lddo, SQ);
+    const FragB3 kf = split_raw(kr), vf = split_raw(vr);
+    lds_barrier();
+    if (own) {
+      f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+#pragma unroll
+      for (int qb = 0; qb < SQ / 32; ++qb) {
+        f32x16 l2v, dsv;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+          const f32x4 a = *(const f32x4*)(L2 + qb * 32 + 8 * T + 4 * g.h);
+          const f32x4 dd = *(const f32x4*)(DS + qb * 32 + 8 * T + 4 * g.h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { l2v[4 * T + j] = a[j]; dsv[4 * T + j] = dd[j]; }
+        }
+        f32x16 s = mma_rows3(Ah, Al, g, qb, kf, zero16());
+        f32x16 dp = mma_rows3(Bh, Bl, g, qb, vf, dsv);
+        p_and_ds<true>(s, dp, c, l2v);
+        mma_seq3(Bh, Bl, g, qb, s, dv);
+        mma_seq3(Ah, Al, g, qb, dp, dk);
+      }
+      if (valid) {
+        store_rows3(P.dk + b * P.bdk + (long)key * P.lddk + hh * HD, dk, P.alpha, g.h);
+        store_rows3(P.dv + b * P.bdv + (long)key * P.lddv + hh * HD, dv, 1.0f, g.h);
+      }
+    }
+  }
+}
+
+static int nkb_of(int skv) { return (skv + 31) / 32; }
+static int check(const muse_attn_desc* d) {
+  if (!d || d->seq_q <= 0 || d->seq_kv <= 0 || d->heads <= 0) return MUSE_ERR_BAD_ARG;
+  if (d->head_dim != HD || d->seq_q != SQ || d->seq_kv > SQ) return MUSE_ERR_UNSUPPORTED;
+  const int nkb = nkb_of(d->seq_kv);
+  if (nkb != 8 && nkb != 3) return MUSE_ERR_UNSUPPORTED;
+  const int64_t lds[] = {d->ldq, d->ldk, d->ldv, d->ldo, d->bsq, d->bsk, d->bsv, d->bso};
+  for (int64_t x : lds) if (x & 3) return MUSE_ERR_ALIGN;     // 16-byte f32 vectors
+  const void* ps[] = {d->q, d->k, d->v, d->o};
+  for (const void* p : ps) if (((uintptr_t)p) & 15) return MUSE_ERR_ALIGN;
+  return 0;
+}
+static Params base(const muse_attn_desc* d) {
+  Params P = {};
+  P.q = (const float*)d->q; P.k = (const float*)d->k; P.v = (const float*)d->v;
+  P.ldq = d->ldq; P.ldk = d->ldk; P.ldv = d->ldv; P.ldo = d->ldo;
+  P.bq = d->bsq; P.bk = d->bsk; P.bv = d->bsv; P.bo = d->bso;
+  P.nh = d->heads; P.skv = d->seq_kv; P.alpha = d->alpha;
+  return P;
+}
+template <typename K>
+static int launch(K k, const Params& P, int heads_total, size_t lds, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(heads_total), dim3(NT), lds, st, P);
+  MUSE_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace attn3
+
+extern "C" int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* stream) {
+  using namespace attn3;
+  const int rc = check(d);
+  if (rc) return rc;
+  if (d->batch <= 0) return 0;
+  Params P = base(d);
+  P.out = (float*)d->o; P.lse = lse;
+  const int nkb = nkb_of(d->seq_kv);
+  const size_t lds = 4 * (size_t)nkb * 32 * C::STR;
+  return nkb == 8 ? launch(fwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
+                  : launch(fwd_kernel<3>, P, d->batch * d->heads, lds, (hipStream_t)stream);
+}
+
+extern "C" int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, int64_t lddo, int64_t bsdo, const float* lse, void* dq,
+                                     int64_t lddq, int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv, int64_t bsdv,
+                                     void* stream) {
+  using namespace attn3;
+  const int rc = check(d);
+  if (rc) return rc;
+  if ((lddo | bsdo | lddq | bsdq | lddk | bsdk | lddv | bsdv) & 3) return MUSE_ERR_ALIGN;
+  if ((((uintptr_t)d_o) | ((uintptr_t)dq) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 15) return MUSE_ERR_ALIGN;
+  if (d->batch <= 0) return 0;
+  Params P = base(d);
+  P.o = (const float*)d->o; P.d_o = (const float*)d_o; P.lddo = lddo; P.bdo = bsdo;
+  P.lse = (float*)lse;
+  P.dq = (float*)dq; P.lddq = lddq; P.bdq = bsdq;
+  P.dk = (float*)dk; P.lddk = lddk; P.bdk = bsdk;
+  P.dv = (float*)dv; P.lddv = lddv; P.bdv = bsdv;
+  const size_t lds = 4 * (size_t)PLANE + 2 * SQ * sizeof(float);
+  return nkb_of(d->seq_kv) == 8 ? launch(bwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
+                                : launch(bwd_kernel<3>, P, d->batch * d->heads, lds, (hipStream_t)stream);
+}

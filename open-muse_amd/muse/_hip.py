@@ -65,6 +65,9 @@ SIGNATURES = {
     "muse_attention_fwd_ex": [C.POINTER(AttnDesc), c_void_p, c_void_p],
     "muse_attention_bwd_ex": [C.POINTER(AttnDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p,
                               c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p],
+    "muse_attention_x3_fwd": [C.POINTER(AttnDesc), c_void_p, c_void_p],
+    "muse_attention_x3_bwd": [C.POINTER(AttnDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
+                              c_i64, c_i64, c_void_p],
     "muse_attention_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "muse_attention_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                            c_void_p],

@@ -706,6 +706,45 @@ def attention_bwd_ex(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None
     return dq, dk, dv
 
 
+def attention_x3_supported(Sq, Skv, hd):
+    """shapes of the fused bf16x3 attention (csrc/attention3.hip): config 4's 16 x 16 grid against itself or its 77 text states"""
+    return hd == 64 and Sq == 256 and (224 < Skv <= 256 or 64 < Skv <= 96)
+
+
+def attention_x3_fwd(q, k, v, B, Sq, Skv, nh, hd, alpha):
+    """fused softmax(alpha q k^T) v on f32 tensors with bf16x3 products (TF32-class: <= 2^-16 relative per product); q [B*Sq, H],
+    k / v [B*Skv, H] f32 views (slices of a packed projection are fine) -> (ctx [B*Sq, H] f32, lse [B*nh, 256] f32)"""
+    require_gpu(q, k, v)
+    if q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32:
+        raise _hip.MuseHipError("attention_x3: f32 operands")
+    ctx = torch.empty((B * Sq, nh * hd), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B * nh, Sq), dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
+    e0 = _prof_begin()
+    check(lib().muse_attention_x3_fwd(C.byref(d), lse.data_ptr(), stream()), "muse_attention_x3_fwd")
+    _prof_end(e0, "attn_fwd_bf16x3", 4.0 * B * nh * Sq * Skv * hd)
+    return ctx, lse
+
+
+def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None, dk=None, dv=None):
+    """-> (dq [B*Sq, H], dk, dv [B*Skv, H]) f32; dq / dk / dv may be views (the column blocks of a packed gradient)"""
+    require_gpu(q, k, v, ctx, dctx, lse)
+    H = nh * hd
+    dq = dq if dq is not None else torch.empty((B * Sq, H), dtype=torch.float32, device=q.device)
+    dk = dk if dk is not None else torch.empty((B * Skv, H), dtype=torch.float32, device=q.device)
+    dv = dv if dv is not None else torch.empty((B * Skv, H), dtype=torch.float32, device=q.device)
+    for t in (ctx, dctx, dq, dk, dv):
+        if t.dtype != torch.float32:
+            raise _hip.MuseHipError("attention_x3: f32 operands")
+    d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
+    (pdo, lddo), (pdq, lddq), (pdk, lddk), (pdv, lddv) = _row_view(dctx, H), _row_view(dq, H), _row_view(dk, H), _row_view(dv, H)
+    e0 = _prof_begin()
+    check(lib().muse_attention_x3_bwd(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), pdq, lddq, Sq * lddq, pdk, lddk, Skv * lddk,
+                                      pdv, lddv, Skv * lddv, stream()), "muse_attention_x3_bwd")
+    _prof_end(e0, "attn_bwd_bf16x3", 10.0 * B * nh * Sq * Skv * hd)
+    return dq, dk, dv
+
+
 def attention_fwd(qkv, B, S, nh, hd, alpha):
     """fused softmax(alpha q k^T) v; qkv [B*S, 3H] bf16 -> (ctx [B*S, H] bf16, lse [B*nh, seq_pad] f32)"""
     require_gpu(qkv)

@@ -17,6 +17,7 @@ from ._hip import MuseHipError
 
 # MUSE_UVIT_BF16_OPERANDS (experiments): bit 0 = AdaLN writes the bf16 GEMM operand, bit 1 = norm backward writes the bf16 copy of dv
 _X3_IMAGE_CACHE = os.environ.get("MUSE_X3_IMAGES", "1") != "0"   # bf16x3 mode: share operand images inside a step (0: split per product)
+_X3_ATTENTION = os.environ.get("MUSE_X3_ATTENTION", "1") != "0"   # bf16x3 mode: fused attention (csrc/attention3.hip) where it takes the shape
 _BF16_OPERANDS = int(os.environ.get("MUSE_UVIT_BF16_OPERANDS", "3"))
 
 
@@ -296,6 +297,24 @@ class TapeOps:
             y = ops.linear(o, self._wb(att.out), out_dtype=torch.float32, residual=residual, bias=self._b(att.out))
             return y, dict(fused=True, self_attn=self_attn, xb=xb, cb=cb, q=q, qkv=qkv, o=o, lse=lse,
                            dims=(B, Sq, Skv, nh, hd, Cq, alpha))
+        if (self.__dict__.get("_f32_split3", False) and _X3_ATTENTION and pdrop == 0.0 and ops.attention_x3_supported(Sq, Skv, hd)
+                and x.dtype == torch.float32 and ctx.dtype == torch.float32 and att.key.weight.shape[1] % 8 == 0):
+            # "bf16x3" mode: the same fused form on f32 tensors, every product of the core as three bf16 MFMA products like the mode's
+            # GEMMs (csrc/attention3.hip); packed q|k|v (self) / k|v (cross) projections: one forward, one dX and one dW product each
+            alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+            self_attn = ctx is x
+            if self_attn:
+                w = self._w2(att.query, att.key, att.value)                      # f32 [3C, C], stacked for this step (the tape keeps it)
+                qkv = self._mm(x, w, bias=self._b(att.query, att.key, att.value))
+                q, k, v = qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:]
+            else:
+                q = self._lin(x, att.query)
+                w = self._w2(att.key, att.value)
+                qkv = self._mm(ctx, w, bias=self._b(att.key, att.value))
+                k, v = qkv[:, :Cq], qkv[:, Cq:]
+            o, lse = ops.attention_x3_fwd(q, k, v, B, Sq, Skv, nh, hd, alpha)
+            y = self._lin(o, att.out, residual=residual)
+            return y, dict(fused_x3=True, self_attn=self_attn, x=x, ctx=ctx, q=q, qkv=qkv, w=w, o=o, lse=lse, dims=(B, Sq, Skv, nh, hd, Cq, alpha))
         q, k, v = self._lin(x, att.query), self._lin(ctx, att.key), self._lin(ctx, att.value)
         Sp = (Skv + 7) // 8 * 8
         P = torch.empty((B * nh, Sq, Sp), dtype=torch.float32, device=x.device)
@@ -314,6 +333,8 @@ class TapeOps:
         """-> (dx, dctx); for self attention the two are already summed and returned as dx (dctx = None)"""
         if sv.get("fused"):
             return self._attention_bwd_fused(dy, sv, att, name, G, self_attn)
+        if sv.get("fused_x3"):
+            return self._attention_bwd_x3(dy, sv, att, name, G, self_attn)
         B, Sq, Skv, nh, hd, Cq, Sp, alpha = sv["dims"]
         q, k, v, P = sv["q"], sv["k"], sv["v"], sv["P"]
         sQ, sK, sP = (Sq * Cq, hd), (Skv * Cq, hd), (nh * Sq * Sp, Sq * Sp)
@@ -337,6 +358,39 @@ class TapeOps:
             G[name + ".value.bias"] = ops.bias_grad(dv)
         # dctx += dv Wv ; for self attention query and context are the same tensor: everything lands in dx
         self._mm_dx(dv, wv, out=dctx, accumulate=True)
+        if self_attn:
+            return dx.add_(dctx), None
+        return dx, dctx
+
+    def _attention_bwd_x3(self, dy, sv, att, name, G, self_attn):
+        """backward of the "bf16x3" fused form: f32 tensors throughout, the packed projections' dX / dW as single products"""
+        B, Sq, Skv, nh, hd, Cq, alpha = sv["dims"]
+        do = self._lin_bwd(dy, sv["o"], att.out, name + ".out", G)                        # f32 [B*Sq, C]
+        q, qkv, w = sv["q"], sv["qkv"], sv["w"]
+        ub = self.__dict__.get("_use_bias", False)
+        if sv["self_attn"]:
+            if not self_attn:
+                raise MuseHipError("self-attention tape replayed as cross-attention")
+            dqkv = torch.empty_like(qkv)
+            ops.attention_x3_bwd(q, qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha,
+                                 dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq], dv=dqkv[:, 2 * Cq:])
+            gqkv = self._mm_dw(dqkv, sv["x"], (3 * Cq, Cq))
+            G[name + ".query.weight"], G[name + ".key.weight"], G[name + ".value.weight"] = gqkv[:Cq], gqkv[Cq:2 * Cq], gqkv[2 * Cq:]
+            if ub:
+                gb = ops.bias_grad(dqkv)
+                G[name + ".query.bias"], G[name + ".key.bias"], G[name + ".value.bias"] = gb[:Cq], gb[Cq:2 * Cq], gb[2 * Cq:]
+            return self._mm_dx(dqkv, w), None                                             # d(x) through q, k and v in one product
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(qkv)
+        ops.attention_x3_bwd(q, qkv[:, :Cq], qkv[:, Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:])
+        dx = self._lin_bwd(dq, sv["x"], att.query, name + ".query", G)
+        Ck = att.key.weight.shape[1]
+        gkv = self._mm_dw(dkv, sv["ctx"], (2 * Cq, Ck))
+        G[name + ".key.weight"], G[name + ".value.weight"] = gkv[:Cq], gkv[Cq:]
+        if ub:
+            gb = ops.bias_grad(dkv)
+            G[name + ".key.bias"], G[name + ".value.bias"] = gb[:Cq], gb[Cq:]
+        dctx = self._mm_dx(dkv, w)
         if self_attn:
             return dx.add_(dctx), None
         return dx, dctx

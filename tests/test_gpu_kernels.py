@@ -626,6 +626,64 @@ def test_one_tile_attention_blocks32(B, S, nh, monkeypatch):
     assert float(growdiff.max()) < 0.1, float(growdiff.max())
 
 
+@pytest.mark.parametrize("B,Skv,nh,packed", [(3, 256, 4, True), (2, 256, 16, True), (3, 77, 4, False), (2, 96, 3, False), (2, 240, 2, False),
+                                              (2, 65, 2, False)])
+def test_fused_attention_bf16x3(B, Skv, nh, packed):
+    """attention3.hip: the attention core of the "bf16x3" mode (f32 tensors, every product as three bf16 MFMA products of hi / lo planes
+    the kernel splits itself) - head_dim 64, 256 queries, self-attention on a packed q|k|v projection and cross-attention against 77
+    (65 .. 96) keys with the last key block masked.  Against float64: forward <= 2e-5, gradients <= 5e-5 of their scale (a bf16 core
+    is 1.5e-2 / 3e-2), i.e. the precision class of the mode's GEMMs; every row of every head written; and against the materialised
+    route the tape engines used before (exact-f32 batched products + softmax kernels)."""
+    ops = _ops()
+    Sq, hd = 256, 64
+    H = nh * hd
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+    if packed:
+        qkv = rnd((B * Sq, 3 * H), 160, 1.0)
+        qc, kc, vc = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+        qkv_d = qkv.to(DEV)
+        qd, kd, vd = qkv_d[:, :H], qkv_d[:, H:2 * H], qkv_d[:, 2 * H:]
+    else:
+        qc, kv = rnd((B * Sq, H), 161, 1.0), rnd((B * Skv, 2 * H), 162, 1.0)
+        kc, vc = kv[:, :H], kv[:, H:]
+        qd, kv_d = qc.to(DEV), kv.to(DEV)
+        kd, vd = kv_d[:, :H], kv_d[:, H:]
+    dctx = rnd((B * Sq, H), 163)
+    q = qc.double().reshape(B, Sq, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    k = kc.double().reshape(B, Skv, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    v = vc.double().reshape(B, Skv, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    sc = q @ k.transpose(-1, -2) * alpha
+    ref = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B * Sq, H)
+    ref.backward(dctx.double())
+    gq, gk, gv = (t.grad.transpose(1, 2).reshape(-1, H) for t in (q, k, v))
+    assert ops.attention_x3_supported(Sq, Skv, hd)
+    ctx, lse = ops.attention_x3_fwd(qd, kd, vd, B, Sq, Skv, nh, hd, alpha)
+    dq, dk, dv = ops.attention_x3_bwd(qd, kd, vd, ctx, dctx.to(DEV), lse, B, Sq, Skv, nh, hd, alpha)
+    assert ctx.dtype == torch.float32 and torch.isfinite(ctx).all() and all(torch.isfinite(t).all() for t in (dq, dk, dv))
+    ef = rel_err(ctx, ref.detach())
+    el = rel_err(lse, torch.logsumexp(sc, dim=-1).reshape(B * nh, Sq).detach())
+    eg = [rel_err(a, b) for a, b in ((dq, gq), (dk, gk), (dv, gv))]
+    print(f"bf16x3 attention S_kv {Skv}: ctx {ef:.1e}, lse {el:.1e}, dq / dk / dv {eg[0]:.1e} / {eg[1]:.1e} / {eg[2]:.1e} of float64")
+    assert ef < 2e-5 and el < 2e-6 and max(eg) < 5e-5
+    rowdiff = (ctx.double().cpu() - ref.detach()).abs().amax(dim=1)
+    assert float(rowdiff.max()) < 1e-4, float(rowdiff.max())
+    for a, b in ((dq, gq), (dk, gk), (dv, gv)):
+        assert float((a.double().cpu() - b).abs().amax(dim=1).max()) < 1e-4 * float(b.abs().max())
+    # the materialised route on the same inputs (exact-f32 MFMA products, softmax kernels): both sit inside the f64 tolerance
+    Sp = (Skv + 7) // 8 * 8
+    P = torch.empty((B * nh, Sq, Sp), dtype=torch.float32, device=DEV)
+    ldq, ldk = qd.stride(0), kd.stride(0)
+    ops.gemm(qd, kd, P, Sq, Skv, hd, la=0, lb=0, lda=ldq, ldb=ldk, ldc=Sp, alpha=alpha, batch=B * nh, zdiv=nh, sA=(Sq * ldq, hd), sB=(Skv * ldk, hd),
+             sC=(nh * Sq * Sp, Sq * Sp))
+    ops.softmax_(P, B * nh * Sq, Skv, Sp)
+    o = torch.empty((B * Sq, H), dtype=torch.float32, device=DEV)
+    ops.gemm(P, vd, o, Sq, hd, Skv, la=0, lb=1, lda=Sp, ldb=ldk, ldc=H, batch=B * nh, zdiv=nh, sA=(nh * Sq * Sp, Sq * Sp), sB=(Skv * ldk, hd),
+             sC=(Sq * H, hd))
+    assert rel_err(ctx, o.double()) < 3e-5
+    # shapes the kernel does not take are refused, not mis-computed
+    assert not ops.attention_x3_supported(257, 257, 64) and not ops.attention_x3_supported(256, 128, 64) and not ops.attention_x3_supported(256, 256, 48)
+
+
 def test_one_tile_attention_under_graph_capture():
     """the 32 x 32-block attention kernels inside a captured HIP graph (the decoding loop of generate2 captures its forward; a
     training step can be captured too): replay == eager, bit for bit, forward and backward"""
