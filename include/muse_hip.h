@@ -63,6 +63,14 @@ int muse_gemm(const muse_gemm_desc* d, void* stream);
 /* Block-tile edge muse_gemm will use for this descriptor: 256 (LDS-DMA kernel, one block per CU) or 128 (two / three
  * blocks per CU); < 0 = the error muse_gemm would return.  Host code sizes split_k with it (ops.wgrad_splits). */
 int muse_gemm_tile(const muse_gemm_desc* d);
+/* The f32-class "bf16x3" product as ONE kernel on four bf16 operand planes: C = alpha (A_hi B_hi^T + A_hi B_lo^T + A_lo B_hi^T) with f32
+ * accumulation, where x ~= hi + lo (muse_split_f32_to_bf16x2; 2^-16 relative per product: at or above the TF32 products
+ * configs/cc12m_uvit_clip.yaml:102-103 trains with).  d describes the product as for muse_gemm with dtype MUSE_BF16, out_dtype MUSE_F32,
+ * A / B = the hi planes; the lo planes sit a_lo / b_lo ELEMENTS behind them with the same leading dimensions (multiples of 8).  Every
+ * layout, bias / rowvec / residual / accumulate, split_k through a workspace; batch 1, no activation, M, N >= 128, K >= 64 and the
+ * 256-tile kernel's alignment rules - otherwise MUSE_ERR_UNSUPPORTED (the caller runs three muse_gemm products or one over
+ * K-concatenated operands, muse_split_f32_to_bf16_cat3). */
+int muse_gemm_x3(const muse_gemm_desc* d, int64_t a_lo, int64_t b_lo, void* stream);
 /* Kernel form behind that tile: 128, 256 (launch-per-tile LDS-DMA kernel) or 257 (the persistent tile-walking form of the 256 kernel,
  * csrc/gemm256p.h: bf16 operands, one batch, no split-K, no bias / activation; k-contiguous A); < 0 = muse_gemm's error.  Pure host
  * logic (tests assert that the train step's products take the persistent form; MUSE_G256P=0 turns it off). */

@@ -42,6 +42,7 @@ static int fill_params(const muse_gemm_desc* d, GemmParams& p) {
   p.split_stride = p.split_k > 1 ? d->split_stride : 0;
   if (p.split_k > 1 && (d->out_dtype != MUSE_F32 || d->bias || d->rowvec || d->residual || d->act)) return MUSE_ERR_BAD_ARG;
   p.cH = p.cW = p.cCin = p.cKS = p.cUps = 0; p.cCinShift = -1;
+  p.a_lo = p.b_lo = 0;
   return 0;
 }
 
@@ -94,6 +95,20 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
     return dispatch_layout<float, float>(p, d->layout_a, d->layout_b, batch, s);
   }
   return MUSE_ERR_BAD_ARG;
+}
+
+// ---- the bf16x3 product on four operand planes (gemm256.h: PipeX3) -----------------------------------------------------------------
+extern "C" int muse_gemm_x3(const muse_gemm_desc* d, int64_t a_lo, int64_t b_lo, void* stream) {
+  GemmParams p;
+  const int rc = fill_params(d, p);
+  if (rc) return rc;
+  if (d->dtype != MUSE_BF16 || d->out_dtype != MUSE_F32 || d->batch > 1 || d->act) return MUSE_ERR_UNSUPPORTED;
+  if (a_lo <= 0 || b_lo <= 0 || (a_lo & 7) || (b_lo & 7)) return MUSE_ERR_ALIGN;
+  if (d->M < 128 || d->N < 128 || d->K < 64 || !gemm256_ok<float>(p, d->layout_a, d->layout_b)) return MUSE_ERR_UNSUPPORTED;
+  {  // the lo planes are addressed through their own 32-bit buffer descriptors: same span as the hi planes (checked by fill_params)
+    p.a_lo = a_lo; p.b_lo = b_lo;
+  }
+  return launch_gemm256_x3<float>(p, d->layout_a, d->layout_b, (hipStream_t)stream);
 }
 
 // ---- grouped weight gradients (gemm256.h: kernel_group) ---------------------------------------------------------------------------

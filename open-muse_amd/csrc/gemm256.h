@@ -414,6 +414,103 @@ struct Pipe32 {
   }
 };
 
+// =====================================================================================================================
+// "bf16x3" K loop: C = A_hi B_hi + A_hi B_lo + A_lo B_hi from FOUR operand planes (A_hi, A_lo at A + a_lo elements, B_hi, B_lo at
+// B + b_lo; same leading dimension), f32 accumulation - the f32-class product of the tape engines' "bf16x3" mode as one kernel.
+// Why not the plain kernel over K-concatenated operands (hi | hi | lo) x (hi | lo | hi) (ops.split_cat3, rounds 4-5): that form moves
+// SIX operand tiles through the LDS-DMA path for three products, and the K loop of this tiling is bound by exactly that path
+// (~27 B/clk per CU sustained against 31.8 B/clk needed at MFMA speed).  Here a 32-wide K-tile brings its four
+// planes in once (64 KiB per stage, two stages) and the waves run 3 x 32 = 96 MFMAs on them: 21 B/clk of DMA at MFMA speed, and
+// each fragment read from LDS feeds 1.5 x as many MFMAs.  Tile formats, swizzles and fragment addressing are the BK = 32 pipeline's
+// (Dma32 / Frags32); per A-fragment row i: reads (a_hi, a_lo) of row i + 1, then b_lo x a_hi, b_hi x a_lo, b_hi x a_hi over the four B
+// fragments (small terms first; 4 independent accumulators between two MFMAs on the same one).  One barrier per K-tile, before the
+// last row: all fragment reads of the stage are complete there (row 7's were issued during row 6), so the DMA of tile t + 2 goes
+// into it, and the next tile's B fragments and row-0 A fragments are read under row 7's MFMAs.
+// =====================================================================================================================
+constexpr int X3_STAGE = 4 * TILE32, LDS_BYTES_X3 = 2 * X3_STAGE;
+
+template <int AL, int BL>
+struct PipeX3 {
+  static constexpr int RA = AL ? 2 : 1, RB = BL ? 2 : 1;
+  Dma32<AL> dah, dal;
+  Dma32<BL> dbh, dbl;
+  Frags32<AL, MI> fa;      // plane 0 of A inside a stage; the lo plane TILE32 bytes further
+  Frags32<BL, NI> fb;      // B_hi at 2 * TILE32, B_lo at 3 * TILE32
+  f32x4 acc[MI][NI];
+  bf16x8 ah[2], al[2];
+  bf16x8 bh[2][NI], bl[2][NI];
+  unsigned char* smem;
+  int wave;
+
+  template <int L, int F, int OFF, typename FR>
+  __device__ __forceinline__ static void rd(const FR& fr, bf16x8& d) {
+    if constexpr (L == 0) {
+      lds_read128<F * 1024 + OFF>(d, fr.cur[0]);
+    } else {
+      u32x2 h0, h1;
+      lds_read64_tr<OFF>(h0, fr.cur[F]);
+      lds_read64_tr<OFF + 2048>(h1, fr.cur[F]);
+      const u32x4 w = {h0[0], h0[1], h1[0], h1[1]};
+      d = __builtin_bit_cast(bf16x8, w);
+    }
+  }
+  template <int I, int SLOT> __device__ __forceinline__ void read_a() {
+    rd<AL, I, 0>(fa, ah[SLOT]);
+    rd<AL, I, TILE32>(fa, al[SLOT]);
+  }
+  template <int P, int J> __device__ __forceinline__ void read_b() {
+    if constexpr (J < NI) {
+      rd<BL, J, 0>(fb, bh[P][J]);
+      rd<BL, J, TILE32>(fb, bl[P][J]);
+      read_b<P, J + 1>();
+    }
+  }
+  __device__ __forceinline__ void issue_tile(int stage_off, int kt) {
+    dah.issue(smem, stage_off, kt, wave);
+    dal.issue(smem, stage_off + TILE32, kt, wave);
+    dbh.issue(smem, stage_off + 2 * TILE32, kt, wave);
+    dbl.issue(smem, stage_off + 3 * TILE32, kt, wave);
+  }
+  __device__ __forceinline__ void prologue(int kt0) {
+    issue_tile(0, kt0);
+    issue_tile(X3_STAGE, kt0 + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    fa.point_at(0u);
+    fb.point_at(0u);
+    read_b<0, 0>();
+    read_a<0, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // row I of the tile in stage S (its B fragments sit in bh[S] / bl[S])
+  template <int S, int I>
+  __device__ __forceinline__ void row(int kt, int kt_last) {
+    if constexpr (I == MI - 1) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile t+1 has landed; every read of this stage is complete
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < kt_last) issue_tile(S * X3_STAGE, kt + 2);
+      fa.point_at((unsigned)((S ^ 1) * X3_STAGE));
+      fb.point_at((unsigned)((S ^ 1) * X3_STAGE));
+      read_b<S ^ 1, 0>();                                           // (after the last tile: a stale stage, never used)
+      read_a<0, 0>();
+    } else {
+      read_a<I + 1, (I + 1) & 1>();
+      wait_lgkm<2 * RA>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[S][j], ah[I & 1], acc[I][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[S][j], al[I & 1], acc[I][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[S][j], ah[I & 1], acc[I][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + 1 < MI) row<S, I + 1>(kt, kt_last);
+  }
+};
+
 #ifdef G256_TIMESTAMPS   // timing experiments (scripts/exp/gemm_ts.py): s_memtime stamps per block - 0 entry, 1 prologue done, 2 K loop done, 3 exit
 __device__ long* g_gemm_ts = nullptr;
 #define G256_TS(IDX) if (g_gemm_ts && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_gemm_ts[(long)blockIdx.x * 4 + (IDX)] = (long)__builtin_amdgcn_s_memtime();
@@ -421,7 +518,7 @@ __device__ long* g_gemm_ts = nullptr;
 #define G256_TS(IDX)
 #endif
 // one 256 x 256 output tile (or one K slice of it): `tid_` = the tile's index in the problem's grouped raster
-template <typename TC, int AL, int BL, int BKV, bool SPREAD>
+template <typename TC, int AL, int BL, int BKV, bool SPREAD, bool X3 = false>
 __device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, unsigned char* smem) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   constexpr int GM = 4;
@@ -448,12 +545,23 @@ __device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, u
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = (wave >> 2) * 128, wc = (wave & 3) * 64;
 
-  using PipeT = std::conditional_t<BKV == 64, Pipe<AL, BL, SPREAD>, Pipe32<AL, BL>>;
+  using PipeT = std::conditional_t<X3, PipeX3<AL, BL>, std::conditional_t<BKV == 64, Pipe<AL, BL, SPREAD>, Pipe32<AL, BL>>>;
+  static_assert(!X3 || BKV == 32, "the bf16x3 K loop works on 32-wide K-tiles");
   PipeT pp;
   pp.smem = smem; pp.wave = wave;
-  pp.da.init(Ap, p.lda, p.M, p.K, kend, m0, wave, lane);
-  pp.db.init(Bp, p.ldb, p.N, p.K, kend, n0, wave, lane);
-  if constexpr (BKV == 64) {
+  if constexpr (X3) {
+    pp.dah.init(Ap, p.lda, p.M, p.K, kend, m0, wave, lane);
+    pp.dal.init(Ap + p.a_lo, p.lda, p.M, p.K, kend, m0, wave, lane);
+    pp.dbh.init(Bp, p.ldb, p.N, p.K, kend, n0, wave, lane);
+    pp.dbl.init(Bp + p.b_lo, p.ldb, p.N, p.K, kend, n0, wave, lane);
+    pp.fa.init(0, wr, lane);
+    pp.fb.init(2 * TILE32, wc, lane);
+  } else {
+    pp.da.init(Ap, p.lda, p.M, p.K, kend, m0, wave, lane);
+    pp.db.init(Bp, p.ldb, p.N, p.K, kend, n0, wave, lane);
+  }
+  if constexpr (X3) {
+  } else if constexpr (BKV == 64) {
     pp.fa.init(A_BASE, wr, lane);
     pp.fb.init(B_BASE, wc, lane);
   } else {
@@ -469,7 +577,14 @@ __device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, u
   const int kt_last = kt0 + ((nk - kt0 + 1) & ~1);
   pp.prologue(kt0);
   G256_TS(1)
-  if constexpr (BKV == 64) {
+  if constexpr (X3) {
+    for (int kt = kt0; kt < kt_last; kt += 2) {
+      pp.template row<0, 0>(kt, kt_last);
+      pp.template row<1, 0>(kt + 1, kt_last);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing look-ahead reads
+    __builtin_amdgcn_sched_barrier(0);
+  } else if constexpr (BKV == 64) {
     for (int kt = kt0; kt < kt_last; kt += 2) {
       pp.template group<0, 0>(kt, kt_last);
       pp.template group<1, 0>(kt + 1, kt_last);
@@ -615,6 +730,15 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   tile_body<TC, AL, BL, BKV, SPREAD>(p, tid_, smem);
 }
 
+template <typename TC, int AL, int BL>
+__global__ __launch_bounds__(512, 2) void kernel_x3(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+  const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int tid_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
+  tile_body<TC, AL, BL, 32, false, true>(p, tid_, smem);
+}
+
 // ---- grouped launch: the tiles of up to MAXG independent products in ONE grid (the four weight gradients of a transformer layer:
 // 72 + 36 + 27 + 9 tiles at config B).  Each product alone needs a deep K split to fill 256 CUs (out-proj: 9 tiles x 28 slices of 9
 // K-tiles each, a third of such a block is prologue + f32 epilogue) and ends in its own ragged round; together they fill the chip with
@@ -694,6 +818,25 @@ static inline int launch_gemm256_lb(const GemmParams& p, int batch, hipStream_t 
   }
   hipLaunchKernelGGL(kern, dim3(ntm * ntn, p.split_k > 1 ? p.split_k : 1, batch), dim3(512), lds, stream, p);
   return (int)hipGetLastError();
+}
+template <typename TC, int AL, int BL>
+static inline int launch_gemm256_x3_l(const GemmParams& p, hipStream_t stream) {
+  const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
+  auto kern = g256::kernel_x3<TC, AL, BL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES_X3);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, p.split_k > 1 ? p.split_k : 1, 1), dim3(512), g256::LDS_BYTES_X3, stream, p);
+  return (int)hipGetLastError();
+}
+template <typename TC>
+static inline int launch_gemm256_x3(const GemmParams& p, int la, int lb, hipStream_t stream) {
+  if (la == 0 && lb == 0) return launch_gemm256_x3_l<TC, 0, 0>(p, stream);
+  if (la == 0 && lb == 1) return launch_gemm256_x3_l<TC, 0, 1>(p, stream);
+  if (la == 1 && lb == 1) return launch_gemm256_x3_l<TC, 1, 1>(p, stream);
+  return launch_gemm256_x3_l<TC, 1, 0>(p, stream);
 }
 // MUSE_G256_BK = 64 (default): two 64 KiB stages of 64-wide K-tiles; 32: five 32 KiB stages of 32-wide K-tiles.  Measured
 // equal within 2-3 % (BK = 64 ahead: 574 vs 586 us on [16384x3072]x[6144x3072]^T): the LDS-DMA stream is throughput-bound

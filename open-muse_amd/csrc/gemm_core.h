@@ -40,6 +40,8 @@ struct GemmParams {
                       // muse_sum_slices); == 0: slices are added to C with f32 atomics (C pre-initialised)
   // implicit-GEMM convolution geometry (conv A loader only)
   int cH, cW, cCin, cKS, cUps, cCinShift;
+  // bf16x3 product (gemm256.h PipeX3): elements from A / B (the hi planes) to the lo planes
+  long a_lo, b_lo;
 };
 
 template <typename T> struct TileCfg;

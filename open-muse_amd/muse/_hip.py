@@ -45,6 +45,7 @@ class AttnDesc(C.Structure):
 SIGNATURES = {
     "muse_version": [],
     "muse_gemm": [C.POINTER(GemmDesc), c_void_p],
+    "muse_gemm_x3": [C.POINTER(GemmDesc), c_i64, c_i64, c_void_p],
     "muse_gemm_tile": [C.POINTER(GemmDesc)],
     "muse_gemm_path": [C.POINTER(GemmDesc)],
     "muse_transpose": [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_i64, c_int, c_i64, c_i64, c_void_p],

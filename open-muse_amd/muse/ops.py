@@ -82,10 +82,12 @@ SKINNY = int(os.environ.get("MUSE_GEMM_SKINNY", "1"))   # split-K + fused reduct
 
 def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_off=0, alpha=1.0, bias=None, rowvec=None,
          residual=None, ldr=0, batch=1, zdiv=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), accumulate=False, act=0, split_k=1,
-         split_stride=0):
+         split_stride=0, x3_lo=None):
     """C[z] = epilogue(alpha * A[z] @ B[z]^T).  A/B/C_ are tensors, *_off element offsets of the (0,0) entry.
 
     la/lb = 0: operand(r,k) at base + r*ld + k;  1: at base + k*ld + r (see include/muse_hip.h).
+    x3_lo = (a_lo, b_lo): A / B are the bf16 hi planes of a bf16x3 product, their lo planes that many elements behind them
+    (muse_gemm_x3); returns None when that kernel does not take the product.
     """
     require_gpu(A, B, C_)
     if A.dtype != B.dtype:
@@ -95,7 +97,7 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
                             zdiv, sA, sB, sC, accumulate)
         if done:
             return C_
-    if (SKINNY and A.dtype == torch.bfloat16 and batch == 1 and la == 0 and lb == 0 and act == 0 and rowvec is None and not accumulate
+    if (SKINNY and x3_lo is None and A.dtype == torch.bfloat16 and batch == 1 and la == 0 and lb == 0 and act == 0 and rowvec is None and not accumulate
             and split_k == 1 and M <= 2048 and K >= 512 and N % 4 == 0 and ldc % 4 == 0 and (residual is None or ldr % 4 == 0)
             and (SKINNY == 2 or torch.cuda.is_current_stream_capturing())):
         # small-batch decoding: a forward Linear of a few hundred rows has too few 128^2 tiles for 256 CUs ([512 x 1024] x [1024 x 1024]^T:
@@ -148,6 +150,13 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     d.split_k = split_k
     d.split_stride = split_stride
     e0 = _prof_begin()
+    if x3_lo is not None:
+        rc = lib().muse_gemm_x3(C.byref(d), int(x3_lo[0]), int(x3_lo[1]), stream())
+        if rc == -3:         # MUSE_ERR_UNSUPPORTED: a shape the four-plane kernel does not take
+            return None
+        check(rc, "muse_gemm_x3")
+        _prof_end(e0, f"gemm_bf16x3_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
+        return C_
     check(lib().muse_gemm(C.byref(d), stream()), "muse_gemm")
     _prof_end(e0, f"gemm_{'bf16' if d.dtype == BF16 else 'f32'}_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
     return C_
@@ -206,6 +215,24 @@ class X3Images:
             self.persist[key] = (t, out, ld)
         return out, ld
 
+    def planes(self, t):
+        """(hi, lo) planes [2, *t.shape] of a contiguous f32 tensor (the operand form of muse_gemm_x3): ONE image per tensor whatever
+        the product reads it as (forward A, dX A, dW A / B, a weight in the forward and in dX)"""
+        key = self._key(t, 9, 0)
+        hit = self.persist.get(key)
+        if hit is None:
+            hit = self.lru.get(key)
+        if hit is not None:
+            self.hits += 1
+            return hit[1]
+        self.misses += 1
+        out = _split_planes_now(t)
+        if self.backward:
+            self._recent(key, (t, out, 0))
+        else:
+            self.persist[key] = (t, out, 0)
+        return out
+
     def _recent(self, key, entry):
         self.lru[key] = entry
         while len(self.lru) > self.recent:
@@ -246,7 +273,21 @@ def split_f32(t):
     return hi, lo
 
 
+X3_NATIVE = os.environ.get("MUSE_X3_NATIVE", "1") != "0"   # bf16x3 GEMM mode: the four-plane kernel (muse_gemm_x3) where it takes the product
 X3_CAT = os.environ.get("MUSE_X3_CAT", "1") != "0"    # bf16x3 GEMM mode: one launch over a 3K-long concatenated operand pair (0: three launches)
+
+
+def _split_planes_now(t):
+    out = torch.empty((2,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+    check(lib().muse_split_f32_to_bf16x2(t.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), t.numel(), stream()), "muse_split_f32_to_bf16x2")
+    return out
+
+
+def split_planes(t):
+    """[2, *t.shape] bf16: hi = bf16(t), lo = bf16(t - hi), through the running step's image cache when there is one"""
+    require_gpu(t)
+    im = _X3_IMAGES[0]
+    return _split_planes_now(t) if im is None else im.planes(t)
 
 
 def split_cat3(t, layout, K, lo_pos, last_use=False):
@@ -293,6 +334,17 @@ def _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, 
         return False
     if (a_off % 8) or (b_off % 8) or lib().muse_gemm_tile(C.byref(d)) < 0:
         return False
+    full2d = (a_off == 0 and b_off == 0 and A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous() and K % 8 == 0
+              and A.stride(0) == lda and B.stride(0) == ldb and A.shape[1 if la == 0 else 0] == K and B.shape[1 if lb == 0 else 0] == K
+              and A.shape[0 if la == 0 else 1] >= M and B.shape[0 if lb == 0 else 1] >= N and A.numel() * 2 < (1 << 31) and B.numel() * 2 < (1 << 31))
+    if X3_NATIVE and full2d and lda % 8 == 0 and ldb % 8 == 0 and A.numel() % 8 == 0 and B.numel() % 8 == 0:
+        # ONE kernel on the four planes (hi, lo of each operand; csrc/gemm256.h PipeX3): every plane goes through the LDS-DMA path once
+        # per K-tile and feeds three MFMA products; one image per tensor serves every product that reads it
+        with f32_gemms_as_bf16x3(False):
+            a2, b2 = split_planes(A), split_planes(B)
+            if gemm(a2[0], b2[0], C_, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=ldc, c_off=c_off, alpha=alpha, bias=bias, rowvec=rowvec,
+                    residual=residual, ldr=ldr, accumulate=accumulate, x3_lo=(A.numel(), B.numel())) is not None:
+                return True
     if (X3_CAT and a_off == 0 and b_off == 0 and A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous() and K % 8 == 0
             and A.stride(0) == lda and B.stride(0) == ldb and A.shape[1 if la == 0 else 0] == K and B.shape[1 if lb == 0 else 0] == K
             and A.shape[0 if la == 0 else 1] >= M and B.shape[0 if lb == 0 else 1] >= N and 3 * A.numel() * 2 < (1 << 31)
@@ -364,7 +416,7 @@ def linear_dgrad(dy, w, out=None):
 SPLIT_K = os.environ.get("MUSE_SPLIT_K", "1") != "0"   # MUSE_SPLIT_K=0: deterministic (no f32 atomics) weight gradients
 
 
-def wgrad_splits(M, N, K, dtype, slots=512, tile=128):
+def wgrad_splits(M, N, K, dtype, slots=512, tile=128, ktile_us=1.8):
     """K slices for a weight-gradient GEMM.  The [N_out, K_in] output has few tiles while K = tokens is long, so the K
     loop is cut.  128^2 kernel (2 blocks per CU = 512 slots): the slice count that fills whole rounds of resident blocks
     best, with at least 4 K-tiles per slice.  256^2 LDS-DMA kernel (1 block per CU = 256 slots): the slice count with the
@@ -380,7 +432,7 @@ def wgrad_splits(M, N, K, dtype, slots=512, tile=128):
         s_eff = (nk + per - 1) // per          # every slice must own at least one K-tile
         blocks = tiles * s_eff
         if tile == 256:
-            cost = ((blocks + slots - 1) // slots) * (per * 1.8 + 6.0) + ((s_eff + 1) * 4.0 * M * N / 4e6 if s_eff > 1 else 0.0)
+            cost = ((blocks + slots - 1) // slots) * (per * ktile_us + 6.0) + ((s_eff + 1) * 4.0 * M * N / 4e6 if s_eff > 1 else 0.0)
             if cost < best_cost - 1e-9:
                 best, best_cost = s_eff, cost
         else:
@@ -415,12 +467,43 @@ def _wgrad_plan(dy, x, N, K, T_, lda, ldb):
     return plan
 
 
+_WGRAD_X3_PLAN = {}
+
+
+def _wgrad_x3_native(dy, x, dw, accumulate, M):
+    """dw (+)= dy^T x as the four-plane bf16x3 product (muse_gemm_x3, both operands k-major) with the K split of the 256-tile kernel;
+    False when that kernel does not take the shape"""
+    T_, ncols = dy.shape
+    N = M if M is not None else ncols
+    K = x.shape[1]
+    if N < 128 or K < 128 or T_ < 64 or dy.numel() % 8 or x.numel() % 8 or dy.numel() * 2 >= (1 << 31) or x.numel() * 2 >= (1 << 31):
+        return False
+    dy2, x2 = split_planes(dy), split_planes(x)
+    lo = (dy.numel(), x.numel())
+    splittable = dw.dtype == torch.float32 and dw.is_contiguous() and (N * K) % 4 == 0
+    sk = 1
+    if splittable:
+        sk = _WGRAD_X3_PLAN.get((N, K, T_))
+        if sk is None:      # a 64-wide K-tile of this kernel is three products: ~2.6 x the plain kernel's time per tile
+            sk = _WGRAD_X3_PLAN[(N, K, T_)] = wgrad_splits(N, K, T_, torch.bfloat16, slots=256, tile=256, ktile_us=4.7)
+    if sk <= 1:
+        return gemm(dy2[0], x2[0], dw, N, K, T_, la=1, lb=1, lda=ncols, ldb=K, ldc=dw.stride(0), accumulate=accumulate, x3_lo=lo) is not None
+    ws = torch.empty((sk, N, K), dtype=torch.float32, device=dw.device)
+    if gemm(dy2[0], x2[0], ws, N, K, T_, la=1, lb=1, lda=ncols, ldb=K, ldc=K, split_k=sk, split_stride=N * K, x3_lo=lo) is None:
+        return False
+    check(lib().muse_sum_slices(ws.data_ptr(), dw.data_ptr(), sk, N * K, N * K, 1 if accumulate else 0, stream()), "muse_sum_slices")
+    return True
+
+
 def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     """dw[N,K] (+)= dy[T,N]^T @ x[T,K]   (both operands k-major, f32 output into the flat grad buffer).
     Split-K slices write partial tiles to a workspace that muse_sum_slices folds into dw in a fixed order."""
     if _F32_AS_BF16X3[0] and dy.dtype == torch.float32 and x.dtype == torch.float32 and dw.dtype == torch.float32 \
             and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[1] % 8 == 0 and (M if M is not None else dy.shape[1]) % 8 == 0:
         with f32_gemms_as_bf16x3(False):
+            if (X3_NATIVE and dy.dim() == 2 and x.dim() == 2 and dy.is_contiguous() and x.is_contiguous() and (lda is None or lda == dy.stride(0))
+                    and dy.shape[0] == x.shape[0] and _wgrad_x3_native(dy, x, dw, accumulate, M)):
+                return dw
             if (X3_CAT and dy.dim() == 2 and x.dim() == 2 and dy.is_contiguous() and x.is_contiguous() and (lda is None or lda == dy.stride(0))
                     and dy.shape[0] == x.shape[0] and 3 * dy.numel() * 2 < (1 << 32) - 64 and 3 * x.numel() * 2 < (1 << 32) - 64):
                 # one product over 3 T slots: the ROW-concatenated images dY' [T, 3N] = (hi | lo | hi), X' [T, 3K] = (hi | hi | lo) - the ones

@@ -97,7 +97,7 @@ print('stdout lines', len(ls)); d=json.loads(ls[-1]); print('dp1', d['value'], d
 x3)     # bf16x3 attention bring-up: kernel + mode tests to a file, then the config-4 leg with and without the fused core
   timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -rP -k "bf16x3 or three_bf16 or uvit or UViT" > $O/${tag}_x3_pytest.txt 2>&1; echo "pytest exit $?" >> $O/${tag}_x3_pytest.txt
   grep -E "passed|failed|pytest exit|^FAILED|^ERROR|bf16x3 attention|operand images" $O/${tag}_x3_pytest.txt | tail -30
-  for v in 0 1; do MUSE_X3_ATTENTION=$v timeout 600 python bench.py --uvit-leg 64,256,2,x3 2>/dev/null | tail -1 | cut -c1-200 | sed "s/^/MUSE_X3_ATTENTION=$v /" | tee -a $O/${tag}_x3_leg.txt; done
+  for v in ${X3_VARS:-MUSE_X3_ATTENTION=0 MUSE_X3_ATTENTION=1}; do env $v timeout 600 python bench.py --uvit-leg 64,256,2,x3 2>/dev/null | tail -1 | cut -c1-200 | sed "s/^/$v /" | tee -a $O/${tag}_x3_leg.txt; done
   ;;
 c4prof) # config 4 (U-ViT) kernel profile, serial: scripts/gpu.sh c4prof <tag> [leg, default 64,256,2,x3]
   leg=${3:-64,256,2,x3}

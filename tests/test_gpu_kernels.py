@@ -1339,6 +1339,71 @@ def test_f32_gemm_as_three_bf16_products():
     assert torch.equal(c1, ops.linear(a, b))
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 768, 1024), (300, 384, 256), (1000, 520, 200), (264, 136, 72)])
+def test_bf16x3_four_plane_gemm(M, N, K):
+    """muse_gemm_x3 (csrc/gemm256.h PipeX3): the bf16x3 product as one kernel on the four (hi, lo) operand planes - every operand
+    layout, ragged tile edges, K that is no multiple of the 32-wide K-tile, bias + residual + accumulate in the epilogue; against float64
+    (2^-16 of sum |a||b|) and against the route it replaces (one product over K-concatenated operands: the same three terms in another
+    order).  Then the weight-gradient form with its K split on a long token dimension."""
+    ops = _ops()
+    import unittest.mock as um
+    a, b = rnd((M, K), 700).to(DEV), rnd((N, K), 701).to(DEV)
+    at, bt = a.t().contiguous(), b.t().contiguous()          # [K, M], [K, N]: the k-major forms
+    res, bias = rnd((M, N), 702).to(DEV), rnd((N,), 703).to(DEV)
+    ref = a.double() @ b.double().t()
+    scale = float((a.double().abs() @ b.double().abs().t()).max())
+    for la, lb, A, B in ((0, 0, a, b), (0, 1, a, bt), (1, 1, at, bt), (1, 0, at, b)):
+        lda, ldb = (K if la == 0 else M), (K if lb == 0 else N)
+        outs = []
+        for native in (True, False):
+            c = torch.empty((M, N), device=DEV)
+            with um.patch.object(ops, "X3_NATIVE", native), ops.f32_gemms_as_bf16x3():
+                ops.gemm(A, B, c, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=N)
+            outs.append(c)
+        e = float((outs[0].double() - ref).abs().max()) / scale
+        assert e < 2.0 ** -16, (la, lb, e)
+        assert rel_err(outs[0], outs[1].double()) < 2e-6, (la, lb)
+    # epilogue extras, then accumulation onto the result
+    c = torch.empty((M, N), device=DEV)
+    with ops.f32_gemms_as_bf16x3():
+        ops.gemm(a, b, c, M, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias, residual=res, ldr=N)
+        want = 0.5 * ref + bias.double() + res.double()
+        assert rel_err(c, want) < 2e-5
+        ops.gemm(a, b, c, M, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N, accumulate=True)
+        assert rel_err(c, want + ref) < 2e-5
+    # the kernel really ran (the route is a silent fallback otherwise): a shape it refuses returns None
+    with ops.f32_gemms_as_bf16x3(False):
+        a2, b2 = ops.split_planes(a), ops.split_planes(b)
+        c2 = torch.empty((M, N), device=DEV)
+        assert ops.gemm(a2[0], b2[0], c2, M, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N, x3_lo=(a.numel(), b.numel())) is c2
+        assert float((c2.double() - ref).abs().max()) / scale < 2.0 ** -16
+        small = torch.empty((64, N), device=DEV)
+        assert ops.gemm(a2[0], b2[0], small, 64, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N, x3_lo=(a.numel(), b.numel())) is None
+
+
+def test_bf16x3_weight_gradient_with_k_split():
+    """dW = dY^T X over 8192 tokens in the bf16x3 mode: the four-plane kernel with its K slices through a workspace (fixed summation
+    order), plain and accumulating; against float64 and against the K-concatenated route"""
+    ops = _ops()
+    import unittest.mock as um
+    T, N, K = 8192, 384, 512
+    dy, x = rnd((T, N), 710).to(DEV), rnd((T, K), 711).to(DEV)
+    ref = dy.double().t() @ x.double()
+    assert ops.wgrad_splits(N, K, T, torch.bfloat16, slots=256, tile=256, ktile_us=4.7) > 1
+    dw = torch.empty((N, K), device=DEV)
+    with ops.f32_gemms_as_bf16x3():
+        ops.linear_wgrad(dy, x, dw, False)
+        dw2 = dw.clone()
+        ops.linear_wgrad(dy, x, dw2, True)
+        again = torch.empty((N, K), device=DEV)
+        ops.linear_wgrad(dy, x, again, False)
+    with um.patch.object(ops, "X3_NATIVE", False), ops.f32_gemms_as_bf16x3():
+        dwc = torch.empty((N, K), device=DEV)
+        ops.linear_wgrad(dy, x, dwc, False)
+    assert rel_err(dw, ref) < 1e-5 and rel_err(dw2, 2 * ref) < 1e-5 and rel_err(dw, dwc.double()) < 2e-6
+    assert torch.equal(dw, again)                 # deterministic: slices are summed in a fixed order
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upsample2x_matches_interpolate(dtype):
     """muse_upsample2x_nhwc == F.interpolate(scale_factor=2, mode="nearest") (taming Upsample without its convolution), bit for bit"""
