@@ -290,6 +290,12 @@ struct Dma32 {
     }
   }
   __device__ __forceinline__ unsigned kk(int j) const { return L == 0 ? kk0 : (kk0 + 2u * j); }
+  // piece J of tile kt alone
+  template <int J>
+  __device__ __forceinline__ void issue1(unsigned char* smem, int lds_off, int kt, int wave) const {
+    const unsigned vo = ((unsigned)kt * 32u + kk(J)) < (unsigned)kend ? voff[J] : oob;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + lds_off + (wave * 2 + J) * 1024), 16, (int)vo, (int)((unsigned)kt * kstep), 0, 0);
+  }
   // tile kt -> LDS byte offset `lds_off` (stage base + operand base; wave-uniform)
   __device__ __forceinline__ void issue(unsigned char* smem, int lds_off, int kt, int wave) const {
     const unsigned soff = (unsigned)kt * kstep;
@@ -471,10 +477,32 @@ struct PipeX3 {
     dbh.issue(smem, stage_off + 2 * TILE32, kt, wave);
     dbl.issue(smem, stage_off + 3 * TILE32, kt, wave);
   }
-  __device__ __forceinline__ void prologue(int kt0) {
+  // The 8 DMA pieces of a tile are not issued as a burst behind the barrier (both waves of a SIMD sit at the same barrier: ~150 cycles
+  // of issue per piece with no MFMA under it, measured on the plain kernel - Pipe::SPREAD) but one between two MFMA loops: pieces 0..2 of
+  // tile t+2 in row 7 of tile t (its stage is free from the barrier on), pieces 3..7 in rows 0 and 1 of tile t+1 - five rows (~1900
+  // cycles) before the barrier that needs them.
+  template <int Q>
+  __device__ __forceinline__ void issue_piece(int stage_off, int kt, int kt_last) {
+    if (kt < kt_last) {
+      if constexpr (Q < 2) dah.template issue1<Q>(smem, stage_off, kt, wave);
+      else if constexpr (Q < 4) dal.template issue1<Q - 2>(smem, stage_off + TILE32, kt, wave);
+      else if constexpr (Q < 6) dbh.template issue1<Q - 4>(smem, stage_off + 2 * TILE32, kt, wave);
+      else dbl.template issue1<Q - 6>(smem, stage_off + 3 * TILE32, kt, wave);
+    }
+  }
+  // behind MFMA loop LOOP (0..2) of row I of the tile kt in stage S
+  template <int S, int I, int LOOP>
+  __device__ __forceinline__ void spread(int kt, int kt_last) {
+    if constexpr (I == MI - 1) issue_piece<LOOP>(S * X3_STAGE, kt + 2, kt_last);
+    else if constexpr (I == 0) issue_piece<3 + LOOP>((S ^ 1) * X3_STAGE, kt + 1, kt_last);
+    else if constexpr (I == 1 && LOOP < 2) issue_piece<6 + LOOP>((S ^ 1) * X3_STAGE, kt + 1, kt_last);
+  }
+  __device__ __forceinline__ void prologue(int kt0, int kt_last) {
     issue_tile(0, kt0);
-    issue_tile(X3_STAGE, kt0 + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    issue_piece<0>(X3_STAGE, kt0 + 1, kt_last);
+    issue_piece<1>(X3_STAGE, kt0 + 1, kt_last);
+    issue_piece<2>(X3_STAGE, kt0 + 1, kt_last);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     fa.point_at(0u);
@@ -490,7 +518,6 @@ struct PipeX3 {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile t+1 has landed; every read of this stage is complete
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < kt_last) issue_tile(S * X3_STAGE, kt + 2);
       fa.point_at((unsigned)((S ^ 1) * X3_STAGE));
       fb.point_at((unsigned)((S ^ 1) * X3_STAGE));
       read_b<S ^ 1, 0>();                                           // (after the last tile: a stale stage, never used)
@@ -502,10 +529,16 @@ struct PipeX3 {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[S][j], ah[I & 1], acc[I][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    spread<S, I, 0>(kt, kt_last);
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[S][j], al[I & 1], acc[I][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    spread<S, I, 1>(kt, kt_last);
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[S][j], ah[I & 1], acc[I][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    spread<S, I, 2>(kt, kt_last);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + 1 < MI) row<S, I + 1>(kt, kt_last);
   }
@@ -575,7 +608,8 @@ __device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, u
 
   // the tile count is rounded up to even (a tile beyond kend is all out-of-range chunks: zeros, no memory traffic)
   const int kt_last = kt0 + ((nk - kt0 + 1) & ~1);
-  pp.prologue(kt0);
+  if constexpr (X3) pp.prologue(kt0, kt_last);
+  else pp.prologue(kt0);
   G256_TS(1)
   if constexpr (X3) {
     for (int kt = kt0; kt < kt_last; kt += 2) {
