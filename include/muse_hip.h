@@ -162,10 +162,13 @@ int muse_attention_bwd_ex(const muse_attn_desc* d, const void* d_o, int64_t lddo
  * (<= 2^-16 relative per product), softmax and accumulation in f32.  head_dim 64, seq_q = 256, seq_kv in 225..256 or 65..96
  * (self-attention of config 4's 16 x 16 grid; its 77 text states); anything else: MUSE_ERR_UNSUPPORTED (the caller keeps the
  * materialised route: muse_gemm batched + muse_softmax_*).  lse is f32 [batch*heads, 256]. */
-int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* stream);
+int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* o_planes, int64_t o_lo, void* stream);
 int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, int64_t lddo, int64_t bsdo, const float* lse, void* dq,
                           int64_t lddq, int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv, int64_t bsdv,
-                          void* stream);
+                          void* dq_planes, int64_t dq_lo, void* dk_planes, int64_t dk_lo, void* dv_planes, int64_t dv_lo, void* stream);
+/* (*_planes, optional: the result ALSO as the bf16 operand planes of the products that read it - muse_gemm_x3 - so that no split pass
+ *  runs over it: the hi plane is addressed exactly like the f32 tensor (same strides, in elements), the lo plane sits *_lo elements
+ *  behind it; NULL = f32 only) */
 /* packed self-attention: qkv [B*S, 3*H] (q | k | v, H = heads*head_dim: the fused QKV projection), ctx [B*S, H], dqkv [B*S, 3*H] */
 int muse_attention_fwd(const void* qkv, void* ctx, float* lse, int32_t batch, int32_t seq, int32_t heads,
                        int32_t head_dim, float alpha, void* stream);
@@ -175,6 +178,10 @@ int muse_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const
 /* GLU: h = gelu_erf(a) * b with ab = [rows, 2*inter] (a = first half).  muse/modeling_transformer.py:789-792. */
 int muse_glu_fwd(const void* ab, void* h, int32_t dtype, int64_t rows, int32_t inter, void* stream);
 int muse_glu_bwd(const void* ab, const void* dh, void* dab, int32_t dtype, int64_t rows, int32_t inter, void* stream);
+/* The f32 GLU of the "bf16x3" compute mode: the same f32 results, written ALSO as the (hi, lo) bf16 operand planes muse_gemm_x3 reads
+ * (planes = [2][rows][cols] bf16, hi plane first; the bits muse_split_f32_to_bf16x2 would produce from the f32 result). */
+int muse_glu_fwd_x3(const float* ab, float* h, void* planes, int64_t rows, int32_t inter, void* stream);
+int muse_glu_bwd_x3(const float* ab, const float* dh, float* dab, void* planes, int64_t rows, int32_t inter, void* stream);
 /* Fused middle of the NormFormer GLU MLP (muse/modeling_transformer.py:789-797), one pass over ab = [rows, 2*inter]:
  *   fwd: h = gelu_erf(a) * b, hm = LayerNorm(h) * w (mean/rstd saved);
  *   bwd: dh = LN'(dhm) never leaves the CU, dab = (dh*b*gelu'(a), dh*gelu(a)); dw_partial [ceil(rows/R), inter] f32 with
@@ -470,6 +477,13 @@ int muse_norm_adaln_fwd(const float* x, const float* res, const float* w, const 
 int muse_norm_adaln_bwd(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv, void* dv_bf16,
                         float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch, int32_t cols, float eps,
                         int32_t mode, void* stream);
+/* "bf16x3" mode forms: the f32 result AND its (hi, lo) bf16 operand planes [2][rows][cols] (what muse_split_f32_to_bf16x2 makes of it),
+ * so that the products reading m / dv (muse_gemm_x3) need no split pass */
+int muse_norm_adaln_fwd_x3(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* planes,
+                           int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream);
+int muse_norm_adaln_bwd_x3(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv, void* planes,
+                           float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch, int32_t cols, float eps,
+                           int32_t mode, void* stream);
 int muse_colsum_segments(const float* part, float* out, int32_t nseg, int32_t seg_rows, int32_t cols, void* stream);
 int muse_adaln_bwd(const float* dy, const float* x, const float* ss, float* dx, float* dss, int32_t batch,
                    int64_t rows_per_batch, int32_t C, void* stream);

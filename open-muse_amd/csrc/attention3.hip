@@ -41,6 +41,10 @@ struct Params {
   long bq, bk, bv, bo, bdo, bdq, bdk, bdv;             // elements between consecutive images
   int nh, skv;
   float alpha;
+  // optional: the same results ALSO as (hi, lo) bf16 operand planes for the products that read them (muse_gemm_x3): hi plane pointers
+  // addressed like the f32 tensors (same strides, in elements), the lo plane lo_* elements behind
+  bf16_t *outp, *dqp, *dkp, *dvp;
+  long lo_out, lo_dq, lo_dk, lo_dv;
 };
 
 struct FragB3 { bf16x8 h[C::KS], l[C::KS]; };     // B operand of a head-dim contraction, both planes
@@ -149,14 +153,22 @@ __device__ __forceinline__ void mma_seq3(const unsigned char* ih, const unsigned
     }
   }
 }
-// acc[db][r] = value of row n at column 32 db + 8 (r >> 2) + 4 h + (r & 3): 16-byte stores
-__device__ __forceinline__ void store_rows3(float* rowp, const f32x16 (&acc)[C::NDB], float scale, int h) {
+// acc[db][r] = value of row n at column 32 db + 8 (r >> 2) + 4 h + (r & 3): 16-byte stores; planes (optional): the same four values
+// split into the hi / lo planes (8-byte stores), bit for bit what muse_split_f32_to_bf16x2 makes of the f32 result
+__device__ __forceinline__ void store_rows3(float* rowp, const f32x16 (&acc)[C::NDB], float scale, int h, bf16_t* hip = nullptr, long lo_off = 0) {
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4)
-      *(f32x4*)(rowp + 32 * db + 8 * q4 + 4 * h) =
-          f32x4{acc[db][4 * q4] * scale, acc[db][4 * q4 + 1] * scale, acc[db][4 * q4 + 2] * scale, acc[db][4 * q4 + 3] * scale};
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 v = {acc[db][4 * q4] * scale, acc[db][4 * q4 + 1] * scale, acc[db][4 * q4 + 2] * scale, acc[db][4 * q4 + 3] * scale};
+      *(f32x4*)(rowp + 32 * db + 8 * q4 + 4 * h) = v;
+      if (hip) {
+        u32x2 hi, lo;
+        split4_values(v[0], v[1], v[2], v[3], hi, lo);
+        *(u32x2*)(hip + 32 * db + 8 * q4 + 4 * h) = hi;
+        *(u32x2*)(hip + lo_off + 32 * db + 8 * q4 + 4 * h) = lo;
+      }
+    }
 }
 
 // =================================================================================================================
@@ -200,7 +212,8 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const Params P) {
     mma_seq3(Vh, Vl, g, kb, s[kb], o);
   }
   l += xhalf(l);
-  store_rows3(P.out + b * P.bo + (long)q * P.ldo + hh * HD, o, 1.0f / l, g.h);
+  const long oo = b * P.bo + (long)q * P.ldo + hh * HD;
+  store_rows3(P.out + oo, o, 1.0f / l, g.h, P.outp ? P.outp + oo : nullptr, P.lo_out);
   if (g.h == 0) P.lse[(long)head * SQ + q] = m * P.alpha + __logf(l);
 }
 
@@ -265,7 +278,8 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
       p_and_ds<false>(s, dp, c, l2v);
       mma_seq3(Ah, Al, g, kb, dp, dq);
     }
-    store_rows3(P.dq + b * P.bdq + (long)q * P.lddq + hh * HD, dq, P.alpha, g.h);
+    const long oq = b * P.bdq + (long)q * P.lddq + hh * HD;
+    store_rows3(P.dq + oq, dq, P.alpha, g.h, P.dqp ? P.dqp + oq : nullptr, P.lo_dq);
   }
   lds_barrier();       // everybody is done with the K, V planes; L2 / DS are written
   // ---------------- phase 2 ----------------
@@ -299,8 +313,9 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
         mma_seq3(Ah, Al, g, qb, dp, dk);
       }
       if (valid) {
-        store_rows3(P.dk + b * P.bdk + (long)key * P.lddk + hh * HD, dk, P.alpha, g.h);
-        store_rows3(P.dv + b * P.bdv + (long)key * P.lddv + hh * HD, dv, 1.0f, g.h);
+        const long ok = b * P.bdk + (long)key * P.lddk + hh * HD, ov = b * P.bdv + (long)key * P.lddv + hh * HD;
+        store_rows3(P.dk + ok, dk, P.alpha, g.h, P.dkp ? P.dkp + ok : nullptr, P.lo_dk);
+        store_rows3(P.dv + ov, dv, 1.0f, g.h, P.dvp ? P.dvp + ov : nullptr, P.lo_dv);
       }
     }
   }
@@ -336,13 +351,15 @@ static int launch(K k, const Params& P, int heads_total, size_t lds, hipStream_t
 
 }  // namespace attn3
 
-extern "C" int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* stream) {
+extern "C" int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* o_planes, int64_t o_lo, void* stream) {
   using namespace attn3;
   const int rc = check(d);
   if (rc) return rc;
+  if (o_planes && ((((uintptr_t)o_planes) & 7) || (o_lo & 3) || o_lo <= 0)) return MUSE_ERR_ALIGN;
   if (d->batch <= 0) return 0;
   Params P = base(d);
   P.out = (float*)d->o; P.lse = lse;
+  P.outp = (bf16_t*)o_planes; P.lo_out = o_lo;
   const int nkb = nkb_of(d->seq_kv);
   const size_t lds = 4 * (size_t)nkb * 32 * C::STR;
   return nkb == 8 ? launch(fwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
@@ -351,8 +368,10 @@ extern "C" int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* 
 
 extern "C" int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, int64_t lddo, int64_t bsdo, const float* lse, void* dq,
                                      int64_t lddq, int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv, int64_t bsdv,
+                                     void* dq_planes, int64_t dq_lo, void* dk_planes, int64_t dk_lo, void* dv_planes, int64_t dv_lo,
                                      void* stream) {
   using namespace attn3;
+  if (((((uintptr_t)dq_planes) | ((uintptr_t)dk_planes) | ((uintptr_t)dv_planes)) & 7) || ((dq_lo | dk_lo | dv_lo) & 3)) return MUSE_ERR_ALIGN;
   const int rc = check(d);
   if (rc) return rc;
   if ((lddo | bsdo | lddq | bsdq | lddk | bsdk | lddv | bsdv) & 3) return MUSE_ERR_ALIGN;
@@ -364,6 +383,7 @@ extern "C" int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, i
   P.dq = (float*)dq; P.lddq = lddq; P.bdq = bsdq;
   P.dk = (float*)dk; P.lddk = lddk; P.bdk = bsdk;
   P.dv = (float*)dv; P.lddv = lddv; P.bdv = bsdv;
+  P.dqp = (bf16_t*)dq_planes; P.lo_dq = dq_lo; P.dkp = (bf16_t*)dk_planes; P.lo_dk = dk_lo; P.dvp = (bf16_t*)dv_planes; P.lo_dv = dv_lo;
   const size_t lds = 4 * (size_t)PLANE + 2 * SQ * sizeof(float);
   return nkb_of(d->seq_kv) == 8 ? launch(bwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
                                 : launch(bwd_kernel<3>, P, d->batch * d->heads, lds, (hipStream_t)stream);

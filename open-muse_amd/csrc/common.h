@@ -37,6 +37,14 @@ __device__ __forceinline__ void split4(const u32x4& v, u32x2& hi, u32x2& lo) {
   lo[1] = pack2_bf16(x2 - __uint_as_float(hi[1] << 16), x3 - __uint_as_float(hi[1] & 0xffff0000u));
 }
 
+// the split of four COMPUTED values (a producer kernel that writes its f32 result and that result's operand planes): the values are
+// pinned in registers first - otherwise the compiler may contract a trailing multiply of their computation into the `x - hi` of the
+// split (one fma on the unrounded product), and the lo plane is no longer the split of the f32 value that was stored
+__device__ __forceinline__ void split4_values(float x0, float x1, float x2, float x3, u32x2& hi, u32x2& lo) {
+  asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+  split4(u32x4{__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)}, hi, lo);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }

@@ -976,6 +976,62 @@ __global__ void glu_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ d
   }
 }
 static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+// f32 GLU of the "bf16x3" compute mode: the same expressions as glu_*_kernel<float> (the same f32 bits), and the result ALSO as the
+// (hi, lo) bf16 operand planes of the product that reads it (muse_gemm_x3: h feeds the FFN's output projection, d(ab) the dX and dW
+// products of its input projection) - the separate split pass (read 4 + write 4 bytes per element) becomes 4 written bytes here.
+// planes: [2][rows][cols] bf16, hi plane first; split4 is the split muse_split_f32_to_bf16x2 applies, so the planes are its bits.
+__device__ __forceinline__ void store_planes4(bf16_t* hi, long plane, long idx, const float (&o)[4]) {
+  u32x2 h, l;
+  split4_values(o[0], o[1], o[2], o[3], h, l);
+  *(u32x2*)(hi + idx) = h;
+  *(u32x2*)(hi + plane + idx) = l;
+}
+__global__ void glu_fwd_x3_kernel(const float* __restrict__ ab, float* __restrict__ h, bf16_t* __restrict__ planes, long rows, int inter) {
+  const long n4 = rows * (inter / 4), plane = rows * inter;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (inter / 4);
+    const int c = (int)(i - r * (inter / 4)) * 4;
+    float a[4], b[4], o[4];
+    V4<float>::load(ab + r * 2 * inter + c, a);
+    V4<float>::load(ab + r * 2 * inter + inter + c, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = gelu_erf_t<false>(a[j]) * b[j];
+    V4<float>::store(h + r * inter + c, o);
+    store_planes4(planes, plane, r * inter + c, o);
+  }
+}
+__global__ void glu_bwd_x3_kernel(const float* __restrict__ ab, const float* __restrict__ dh, float* __restrict__ dab, bf16_t* __restrict__ planes,
+                                  long rows, int inter) {
+  const long n4 = rows * (inter / 4), plane = rows * 2 * inter;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (inter / 4);
+    const int c = (int)(i - r * (inter / 4)) * 4;
+    float a[4], b[4], d[4], da[4], db[4];
+    V4<float>::load(ab + r * 2 * inter + c, a);
+    V4<float>::load(ab + r * 2 * inter + inter + c, b);
+    V4<float>::load(dh + r * inter + c, d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { da[j] = d[j] * b[j] * gelu_erf_grad_t<false>(a[j]); db[j] = d[j] * gelu_erf_t<false>(a[j]); }
+    V4<float>::store(dab + r * 2 * inter + c, da);
+    V4<float>::store(dab + r * 2 * inter + inter + c, db);
+    store_planes4(planes, plane, r * 2 * inter + c, da);
+    store_planes4(planes, plane, r * 2 * inter + inter + c, db);
+  }
+}
+extern "C" int muse_glu_fwd_x3(const float* ab, float* h, void* planes, int64_t rows, int32_t inter, void* stream) {
+  if (inter % 4) return MUSE_ERR_BAD_ARG;
+  if (rows <= 0) return 0;
+  if ((((uintptr_t)ab) | ((uintptr_t)h)) & 15 || (((uintptr_t)planes) & 7) || ((rows * inter) & 3)) return MUSE_ERR_ALIGN;
+  hipLaunchKernelGGL(glu_fwd_x3_kernel, dim3(ew_grid(rows * (inter / 4))), dim3(256), 0, (hipStream_t)stream, ab, h, (bf16_t*)planes, (long)rows, inter);
+  return (int)hipGetLastError();
+}
+extern "C" int muse_glu_bwd_x3(const float* ab, const float* dh, float* dab, void* planes, int64_t rows, int32_t inter, void* stream) {
+  if (inter % 4) return MUSE_ERR_BAD_ARG;
+  if (rows <= 0) return 0;
+  if ((((uintptr_t)ab) | ((uintptr_t)dh) | ((uintptr_t)dab)) & 15 || (((uintptr_t)planes) & 7)) return MUSE_ERR_ALIGN;
+  hipLaunchKernelGGL(glu_bwd_x3_kernel, dim3(ew_grid(rows * (inter / 4))), dim3(256), 0, (hipStream_t)stream, ab, dh, dab, (bf16_t*)planes, (long)rows, inter);
+  return (int)hipGetLastError();
+}
 // bf16, inter % 8 == 0: eight columns of one row per thread (16-byte accesses), rows walked by blockIdx.y - no 64-bit index
 // division per element (the generic kernels above spend more on `i / (inter / 4)` than on the arithmetic), erf evaluated once per
 // element in the backward.  Same expressions per element as the generic kernels -> the same bits.

@@ -627,11 +627,24 @@ extern "C" int muse_norm_res_bwd(const float* dy, const float* dpre, const float
 //        image), then the norm backward of muse_norm_res_bwd on dn - one pass instead of adaln_bwd_dx + adaln_bwd_ss + norm_res_bwd
 //        (~34 -> 18 bytes per element).  16 rows per block, all of one image (rows_per_batch % 16 == 0); cols <= 1024.
 // =================================================================================================================
+// the bf16 copy of four results (the operand of the next weight GEMMs in the bf16 mode); lo_off != 0 ("bf16x3" mode): that copy is the hi
+// plane and bf16(o - hi) goes lo_off elements behind it - the (hi, lo) operand planes of muse_gemm_x3, bit for bit what
+// muse_split_f32_to_bf16x2 makes of the f32 result
+__device__ __forceinline__ void store_hi_lo(bf16_t* hi, long lo_off, long idx, const f32x4& o) {
+  if (lo_off) {
+    u32x2 h, l;
+    split4_values(o[0], o[1], o[2], o[3], h, l);
+    *(u32x2*)(hi + idx) = h;
+    *(u32x2*)(hi + lo_off + idx) = l;
+  } else {
+    *(u32x2*)(hi + idx) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+  }
+}
 template <int NIT>
 __global__ __launch_bounds__(256) void norm_adaln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ w, const float* __restrict__ ss,
                                                              float* __restrict__ pre, float* __restrict__ m, bf16_t* __restrict__ mb,
-                                                             long rows, long rpb, int cols, float eps, int mode) {
+                                                             long rows, long rpb, int cols, float eps, int mode, long lo_off) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -683,21 +696,31 @@ __global__ __launch_bounds__(256) void norm_adaln_fwd_kernel(const float* __rest
         o[j] = n * (1.0f + sc[j]) + sh[j];
       }
       if (m) *(f32x4*)(m + row * cols + c) = o;
-      if (mb) *(u32x2*)(mb + row * cols + c) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+      if (mb) store_hi_lo(mb, lo_off, row * cols + c, o);
     }
   }
 }
-extern "C" int muse_norm_adaln_fwd(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* m_bf16,
-                                   int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
+static int norm_adaln_fwd_launch(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* m_bf16, long lo_off,
+                                 int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
   if (cols % 4 || cols > 1024 || (mode != 0 && mode != 1) || (!m && !m_bf16)) return MUSE_ERR_UNSUPPORTED;
   const long rows = (long)batch * rows_per_batch;
   if (rows <= 0) return 0;
   const dim3 grid((unsigned)((rows + 3) / 4));
 #define NAF(N) hipLaunchKernelGGL(norm_adaln_fwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, res, w, ss, pre, m, (bf16_t*)m_bf16, rows, \
-                                  (long)rows_per_batch, cols, eps, mode)
+                                  (long)rows_per_batch, cols, eps, mode, lo_off)
   if (cols <= 256) NAF(1); else if (cols <= 512) NAF(2); else if (cols <= 768) NAF(3); else NAF(4);
 #undef NAF
   return (int)hipGetLastError();
+}
+extern "C" int muse_norm_adaln_fwd(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* m_bf16,
+                                   int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
+  return norm_adaln_fwd_launch(x, res, w, ss, pre, m, m_bf16, 0, batch, rows_per_batch, cols, eps, mode, stream);
+}
+// "bf16x3" mode: m as f32 AND as the (hi, lo) operand planes [2][rows][cols] of the products that read it
+extern "C" int muse_norm_adaln_fwd_x3(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* planes,
+                                      int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
+  if (!planes || !m) return MUSE_ERR_BAD_ARG;
+  return norm_adaln_fwd_launch(x, res, w, ss, pre, m, planes, (long)batch * rows_per_batch * cols, batch, rows_per_batch, cols, eps, mode, stream);
 }
 
 template <int NIT>
@@ -705,7 +728,7 @@ __global__ __launch_bounds__(256) void norm_adaln_bwd_kernel(const float* __rest
                                                              const float* __restrict__ v, const float* __restrict__ w,
                                                              const float* __restrict__ ss, float* __restrict__ dv, bf16_t* __restrict__ dvb,
                                                              float* __restrict__ dwp, float* __restrict__ dssp, long rows, long rpb,
-                                                             int cols, float eps, int mode) {
+                                                             int cols, float eps, int mode, long lo_off) {
   __shared__ float red[1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* sb = ss + (((long)blockIdx.x * NRB_ROWS) / rpb) * 2 * cols;       // the block's image
@@ -791,7 +814,7 @@ __global__ __launch_bounds__(256) void norm_adaln_bwd_kernel(const float* __rest
         for (int j = 0; j < 4; ++j) o[j] = rstd * (d[it][j] * wv4[it][j] - mg - (t[it][j] - mean) * rstd * mgx);
         if (dpre) o += pr[it];
         *(f32x4*)(dv + row * cols + c) = o;
-        if (dvb) *(u32x2*)(dvb + row * cols + c) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+        if (dvb) store_hi_lo(dvb, lo_off, row * cols + c, o);
       }
     }
   }
@@ -819,15 +842,31 @@ __global__ __launch_bounds__(256) void norm_adaln_bwd_kernel(const float* __rest
     __syncthreads();
   }
 }
+static int norm_adaln_bwd_launch(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
+                                 void* dv_bf16, long lo_off, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
+                                 int32_t cols, float eps, int32_t mode, void* stream);
 extern "C" int muse_norm_adaln_bwd(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
                                    void* dv_bf16, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
                                    int32_t cols, float eps, int32_t mode, void* stream) {
+  return norm_adaln_bwd_launch(dm, dpre, v, w, ss, dv, dv_bf16, 0, dw_partial, dss_partial, batch, rows_per_batch, cols, eps, mode, stream);
+}
+// "bf16x3" mode: dv as f32 AND as the (hi, lo) operand planes [2][rows][cols] of the dX / dW products that read it
+extern "C" int muse_norm_adaln_bwd_x3(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
+                                      void* planes, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
+                                      int32_t cols, float eps, int32_t mode, void* stream) {
+  if (!planes) return MUSE_ERR_BAD_ARG;
+  return norm_adaln_bwd_launch(dm, dpre, v, w, ss, dv, planes, (long)batch * rows_per_batch * cols, dw_partial, dss_partial, batch, rows_per_batch,
+                               cols, eps, mode, stream);
+}
+static int norm_adaln_bwd_launch(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
+                                 void* dv_bf16, long lo_off, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
+                                 int32_t cols, float eps, int32_t mode, void* stream) {
   if (cols % 4 || cols > 1024 || (mode != 0 && mode != 1) || (rows_per_batch % NRB_ROWS)) return MUSE_ERR_UNSUPPORTED;
   const long rows = (long)batch * rows_per_batch;
   if (rows <= 0) return 0;
   const int nblk = muse_norm_res_bwd_nblk(rows);
 #define NAB(N) hipLaunchKernelGGL(norm_adaln_bwd_kernel<N>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dm, dpre, v, w, ss, dv, (bf16_t*)dv_bf16, \
-                                  dw_partial, dss_partial, rows, (long)rows_per_batch, cols, eps, mode)
+                                  dw_partial, dss_partial, rows, (long)rows_per_batch, cols, eps, mode, lo_off)
   if (cols <= 256) NAB(1); else if (cols <= 512) NAB(2); else if (cols <= 768) NAB(3); else NAB(4);
 #undef NAB
   return (int)hipGetLastError();

@@ -66,14 +66,16 @@ SIGNATURES = {
     "muse_attention_fwd_ex": [C.POINTER(AttnDesc), c_void_p, c_void_p],
     "muse_attention_bwd_ex": [C.POINTER(AttnDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p,
                               c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p],
-    "muse_attention_x3_fwd": [C.POINTER(AttnDesc), c_void_p, c_void_p],
+    "muse_attention_x3_fwd": [C.POINTER(AttnDesc), c_void_p, c_void_p, c_i64, c_void_p],
     "muse_attention_x3_bwd": [C.POINTER(AttnDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
-                              c_i64, c_i64, c_void_p],
+                              c_i64, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
     "muse_attention_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "muse_attention_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                            c_void_p],
     "muse_glu_fwd": [c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_glu_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
+    "muse_glu_fwd_x3": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p],
+    "muse_glu_bwd_x3": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p],
     "muse_ffn_mid_rows_per_block": [],
     "muse_ffn_mid_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     "muse_ffn_mid_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -155,6 +157,8 @@ SIGNATURES = {
     "muse_adaln_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p],
     "muse_norm_adaln_fwd": [c_void_p] * 7 + [c_int, c_i64, c_int, c_float, c_int, c_void_p],
     "muse_norm_adaln_bwd": [c_void_p] * 9 + [c_int, c_i64, c_int, c_float, c_int, c_void_p],
+    "muse_norm_adaln_fwd_x3": [c_void_p] * 7 + [c_int, c_i64, c_int, c_float, c_int, c_void_p],
+    "muse_norm_adaln_bwd_x3": [c_void_p] * 9 + [c_int, c_i64, c_int, c_float, c_int, c_void_p],
     "muse_colsum_segments": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "muse_silu_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p],
     "muse_dwconv3x3_bwd_nchunk": [c_i64],

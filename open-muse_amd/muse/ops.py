@@ -187,7 +187,7 @@ class X3Images:
 
     def __init__(self, recent=12):
         self.persist, self.lru, self.recent, self.backward = {}, {}, int(recent), False
-        self.hits = self.misses = 0
+        self.hits = self.misses = self.produced = 0
 
     def clear(self):
         self.persist.clear()
@@ -232,6 +232,15 @@ class X3Images:
         else:
             self.persist[key] = (t, out, 0)
         return out
+
+    def put_planes(self, t, planes):
+        """a producer kernel wrote t's planes itself (same bits as the split of t): no split pass when a product reads t"""
+        key = self._key(t, 9, 0)
+        self.produced += 1
+        if self.backward:
+            self._recent(key, (t, planes, 0))
+        else:
+            self.persist[key] = (t, planes, 0)
 
     def _recent(self, key, entry):
         self.lru[key] = entry
@@ -803,14 +812,18 @@ def attention_x3_fwd(q, k, v, B, Sq, Skv, nh, hd, alpha):
     ctx = torch.empty((B * Sq, nh * hd), dtype=torch.float32, device=q.device)
     lse = torch.empty((B * nh, Sq), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
+    planes = x3_new_planes(ctx)          # ctx feeds the output projection: its operand planes come out of the kernel
     e0 = _prof_begin()
-    check(lib().muse_attention_x3_fwd(C.byref(d), lse.data_ptr(), stream()), "muse_attention_x3_fwd")
+    check(lib().muse_attention_x3_fwd(C.byref(d), lse.data_ptr(), ptr(planes), ctx.numel(), stream()), "muse_attention_x3_fwd")
     _prof_end(e0, "attn_fwd_bf16x3", 4.0 * B * nh * Sq * Skv * hd)
+    x3_put_planes(ctx, planes)
     return ctx, lse
 
 
-def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None, dk=None, dv=None):
-    """-> (dq [B*Sq, H], dk, dv [B*Skv, H]) f32; dq / dk / dv may be views (the column blocks of a packed gradient)"""
+def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None, dk=None, dv=None, planes=None):
+    """-> (dq [B*Sq, H], dk, dv [B*Skv, H]) f32; dq / dk / dv may be views (the column blocks of a packed gradient).
+    planes = ((dq_hi, dq_lo_off), (dk_hi, ..), (dv_hi, ..)): hi-plane views shaped / strided like dq / dk / dv and the element distance
+    to their lo planes (entries may be None) - the gradients also come out as operand planes (x3_new_planes of the packed tensor)"""
     require_gpu(q, k, v, ctx, dctx, lse)
     H = nh * hd
     dq = dq if dq is not None else torch.empty((B * Sq, H), dtype=torch.float32, device=q.device)
@@ -822,8 +835,16 @@ def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None
     d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
     (pdo, lddo), (pdq, lddq), (pdk, lddk), (pdv, lddv) = _row_view(dctx, H), _row_view(dq, H), _row_view(dk, H), _row_view(dv, H)
     e0 = _prof_begin()
+    pl = []
+    for ent, g in zip(planes or (None, None, None), (dq, dk, dv)):
+        if ent is None or ent[0] is None:
+            pl += [None, 0]
+        else:
+            if ent[0].stride() != g.stride() or ent[0].shape != g.shape or ent[0].dtype != torch.bfloat16:
+                raise _hip.MuseHipError("attention_x3_bwd: a hi-plane view must mirror its gradient view")
+            pl += [ent[0].data_ptr(), int(ent[1])]
     check(lib().muse_attention_x3_bwd(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), pdq, lddq, Sq * lddq, pdk, lddk, Skv * lddk,
-                                      pdv, lddv, Skv * lddv, stream()), "muse_attention_x3_bwd")
+                                      pdv, lddv, Skv * lddv, *pl, stream()), "muse_attention_x3_bwd")
     _prof_end(e0, "attn_bwd_bf16x3", 10.0 * B * nh * Sq * Skv * hd)
     return dq, dk, dv
 
@@ -853,10 +874,39 @@ def attention_bwd(qkv, ctx, dctx, lse, B, S, nh, hd, alpha):
     return dqkv
 
 
+X3_PRODUCERS = os.environ.get("MUSE_X3_PRODUCERS", "1") != "0"   # bf16x3 mode: kernels whose f32 result feeds a product write its operand planes too
+
+
+def _x3_producing(t):
+    """the running step's image cache when a producer of `t`-like f32 results should write operand planes next to them"""
+    im = _X3_IMAGES[0]
+    return im if (im is not None and X3_NATIVE and X3_PRODUCERS and t.dtype == torch.float32 and t.is_contiguous()) else None
+
+
+def x3_new_planes(t):
+    """[2, *t.shape] bf16 for a producer that writes t's operand planes next to t - None when nothing would read them (no bf16x3 step
+    running, the four-plane kernel off, or t no contiguous f32 tensor with whole 16-byte bf16 rows)"""
+    im = _x3_producing(t)
+    if im is None or t.dim() != 2 or t.shape[1] % 8:
+        return None
+    return torch.empty((2,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+
+
+def x3_put_planes(t, planes):
+    if planes is not None:
+        _X3_IMAGES[0].put_planes(t, planes)
+
+
 def glu_fwd(ab):
     require_gpu(ab)
     rows, two_i = ab.shape
     h = torch.empty((rows, two_i // 2), dtype=ab.dtype, device=ab.device)
+    im = _x3_producing(ab)
+    if im is not None and (two_i // 2) % 8 == 0:
+        planes = torch.empty((2, rows, two_i // 2), dtype=torch.bfloat16, device=ab.device)
+        check(lib().muse_glu_fwd_x3(ab.data_ptr(), h.data_ptr(), planes.data_ptr(), rows, two_i // 2, stream()), "muse_glu_fwd_x3")
+        im.put_planes(h, planes)
+        return h
     check(lib().muse_glu_fwd(ab.data_ptr(), h.data_ptr(), dt(ab), rows, two_i // 2, stream()), "muse_glu_fwd")
     return h
 
@@ -865,6 +915,12 @@ def glu_bwd(ab, dh):
     require_gpu(ab, dh)
     rows, two_i = ab.shape
     dab = torch.empty_like(ab)
+    im = _x3_producing(ab)
+    if im is not None and dh.dtype == torch.float32 and dh.is_contiguous() and two_i % 16 == 0:
+        planes = torch.empty((2, rows, two_i), dtype=torch.bfloat16, device=ab.device)
+        check(lib().muse_glu_bwd_x3(ab.data_ptr(), dh.data_ptr(), dab.data_ptr(), planes.data_ptr(), rows, two_i // 2, stream()), "muse_glu_bwd_x3")
+        im.put_planes(dab, planes)
+        return dab
     check(lib().muse_glu_bwd(ab.data_ptr(), dh.data_ptr(), dab.data_ptr(), dt(ab), rows, two_i // 2, stream()), "muse_glu_bwd")
     return dab
 
@@ -1576,6 +1632,13 @@ def norm_adaln_fwd(x, w, ss, batch, eps, mode, residual=None, out_dtype=torch.fl
     pre = torch.empty_like(x)
     m = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
     f32 = out_dtype == torch.float32
+    im = _x3_producing(x) if f32 else None
+    if im is not None and cols % 8 == 0:        # "bf16x3" mode: m feeds weight GEMMs - its operand planes come out of this kernel
+        planes = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=x.device)
+        check(lib().muse_norm_adaln_fwd_x3(x.data_ptr(), ptr(residual), ptr(w), ss.data_ptr(), pre.data_ptr(), m.data_ptr(), planes.data_ptr(),
+                                           batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_fwd_x3")
+        im.put_planes(m, planes)
+        return m, pre
     check(lib().muse_norm_adaln_fwd(x.data_ptr(), ptr(residual), ptr(w), ss.data_ptr(), pre.data_ptr(), m.data_ptr() if f32 else None,
                                     None if f32 else m.data_ptr(), batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_fwd")
     return m, pre
@@ -1590,8 +1653,15 @@ def norm_adaln_bwd(dm, v, w, ss, batch, eps, mode, dpre=None, also_bf16=False, d
     nblk = lib().muse_norm_res_bwd_nblk(rows)
     part = torch.empty((nblk, cols), dtype=torch.float32, device=v.device)
     spart = torch.empty((nblk, 2 * cols), dtype=torch.float32, device=v.device)
-    check(lib().muse_norm_adaln_bwd(dm.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), ss.data_ptr(), dv.data_ptr(), ptr(dvb), part.data_ptr(),
-                                    spart.data_ptr(), batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_bwd")
+    im = _x3_producing(v) if not also_bf16 else None
+    if im is not None and cols % 8 == 0:        # "bf16x3" mode: dv is the dY of the weight GEMMs below - planes from this kernel
+        planes = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=v.device)
+        check(lib().muse_norm_adaln_bwd_x3(dm.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), ss.data_ptr(), dv.data_ptr(), planes.data_ptr(),
+                                           part.data_ptr(), spart.data_ptr(), batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_bwd_x3")
+        im.put_planes(dv, planes)
+    else:
+        check(lib().muse_norm_adaln_bwd(dm.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), ss.data_ptr(), dv.data_ptr(), ptr(dvb), part.data_ptr(),
+                                        spart.data_ptr(), batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_bwd")
     dw = colsum(part, torch.empty(cols, dtype=torch.float32, device=v.device))
     dss = dss_out if dss_out is not None else torch.empty((batch, 2 * cols), dtype=torch.float32, device=v.device)
     check(lib().muse_colsum_segments(spart.data_ptr(), dss.data_ptr(), batch, nblk // batch, 2 * cols, stream()), "muse_colsum_segments")

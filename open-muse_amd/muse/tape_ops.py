@@ -372,8 +372,12 @@ class TapeOps:
             if not self_attn:
                 raise MuseHipError("self-attention tape replayed as cross-attention")
             dqkv = torch.empty_like(qkv)
+            pl = ops.x3_new_planes(dqkv)       # dqkv feeds one dW and one dX product: its operand planes come out of the kernel
+            lo = dqkv.numel()
             ops.attention_x3_bwd(q, qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha,
-                                 dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq], dv=dqkv[:, 2 * Cq:])
+                                 dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq], dv=dqkv[:, 2 * Cq:],
+                                 planes=None if pl is None else ((pl[0][:, :Cq], lo), (pl[0][:, Cq:2 * Cq], lo), (pl[0][:, 2 * Cq:], lo)))
+            ops.x3_put_planes(dqkv, pl)
             gqkv = self._mm_dw(dqkv, sv["x"], (3 * Cq, Cq))
             G[name + ".query.weight"], G[name + ".key.weight"], G[name + ".value.weight"] = gqkv[:Cq], gqkv[Cq:2 * Cq], gqkv[2 * Cq:]
             if ub:
@@ -382,7 +386,12 @@ class TapeOps:
             return self._mm_dx(dqkv, w), None                                             # d(x) through q, k and v in one product
         dq = torch.empty_like(q)
         dkv = torch.empty_like(qkv)
-        ops.attention_x3_bwd(q, qkv[:, :Cq], qkv[:, Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:])
+        plq, plkv = ops.x3_new_planes(dq), ops.x3_new_planes(dkv)
+        ops.attention_x3_bwd(q, qkv[:, :Cq], qkv[:, Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:],
+                             planes=(None if plq is None else (plq[0], dq.numel()), None if plkv is None else (plkv[0][:, :Cq], dkv.numel()),
+                                     None if plkv is None else (plkv[0][:, Cq:], dkv.numel())))
+        ops.x3_put_planes(dq, plq)
+        ops.x3_put_planes(dkv, plkv)
         dx = self._lin_bwd(dq, sv["x"], att.query, name + ".query", G)
         Ck = att.key.weight.shape[1]
         gkv = self._mm_dw(dkv, sv["ctx"], (2 * Cq, Ck))

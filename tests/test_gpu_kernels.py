@@ -1381,6 +1381,48 @@ def test_bf16x3_four_plane_gemm(M, N, K):
         assert ops.gemm(a2[0], b2[0], small, 64, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N, x3_lo=(a.numel(), b.numel())) is None
 
 
+def test_bf16x3_producers_write_operand_planes():
+    """Inside a bf16x3 step the kernels whose f32 result feeds a weight GEMM also write its (hi, lo) operand planes (GLU forward /
+    backward, AdaLN-norm forward / backward, the fused attention's context and gradients): bit for bit the split of the f32 result
+    (muse_split_f32_to_bf16x2), registered under the result tensor, so the product that reads it launches no split; the f32 results
+    are the plain kernels' bits.  Outside a step nothing changes."""
+    ops = _ops()
+    rows, inter, C_, B = 512, 256, 512, 2
+    ab, dh = rnd((rows, 2 * inter), 720).to(DEV), rnd((rows, inter), 721).to(DEV)
+    x, res, w, ss = rnd((rows, C_), 722).to(DEV), rnd((rows, C_), 723).to(DEV), rnd((C_,), 724).to(DEV) + 1.0, rnd((B, 2 * C_), 725).to(DEV)
+    nh, hd, Sq = 2, 64, 256
+    H = nh * hd
+    qkv, dctx = rnd((B * Sq, 3 * H), 726).to(DEV), rnd((B * Sq, H), 727).to(DEV)
+    alpha = 0.125
+
+    def run():
+        h = ops.glu_fwd(ab)
+        dab = ops.glu_bwd(ab, dh)
+        m, pre = ops.norm_adaln_fwd(x, w, ss, B, 1e-6, 1, residual=res)
+        dv, dw, dss = ops.norm_adaln_bwd(m, pre, w, ss, B, 1e-6, 1, dpre=x)
+        ctx, lse = ops.attention_x3_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, Sq, Sq, nh, hd, alpha)
+        dqkv = torch.empty_like(qkv)
+        pl = ops.x3_new_planes(dqkv)
+        lo = dqkv.numel()
+        ops.attention_x3_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], ctx, dctx, lse, B, Sq, Sq, nh, hd, alpha, dq=dqkv[:, :H],
+                             dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:],
+                             planes=None if pl is None else ((pl[0][:, :H], lo), (pl[0][:, H:2 * H], lo), (pl[0][:, 2 * H:], lo)))
+        ops.x3_put_planes(dqkv, pl)
+        return dict(h=h, dab=dab, m=m, dv=dv, ctx=ctx, dqkv=dqkv)
+    plain = run()
+    im = ops.X3Images()
+    with ops.f32_gemms_as_bf16x3(True, im):
+        fused = run()
+        assert im.produced == 6
+        for name, t in fused.items():
+            assert torch.equal(t, plain[name]), name                       # the f32 results do not change
+            misses = im.misses
+            planes = ops.split_planes(t)                                   # what a product reading t gets: the producer's planes
+            assert im.misses == misses, name
+            want = ops._split_planes_now(t)
+            assert torch.equal(planes, want), name
+
+
 def test_bf16x3_weight_gradient_with_k_split():
     """dW = dY^T X over 8192 tokens in the bf16x3 mode: the four-plane kernel with its K slices through a workspace (fixed summation
     order), plain and accumulating; against float64 and against the K-concatenated route"""
