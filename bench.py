@@ -344,9 +344,10 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False):
     tf = 3 * GF_UVIT_FWD[seq] * batch / dt / 1e3
     out = {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 1), "batch": batch, "seq_len": seq,
            "tflops": round(tf, 1), "mfma_frac": round(tf / (PEAK["bf16"] / 3 if x3 else PEAK["f32" if f32 else "bf16"]), 4), "loss": round(float(loss), 4), "parameters": n_params,
-           "dtype": ("bf16x3: f32 tensors, every GEMM (linears, dX, dW, attention products) as three bf16 MFMA products of hi / lo operand planes with f32 "
-                     "accumulation (<= 2^-16 relative per product: at or above the yaml's mixed_precision: no + enable_tf32, 10-bit mantissa products); "
-                     "mfma_frac against the 833 TFLOP/s roof of that scheme (2500 / 3)") if x3 else ("exact f32 everywhere (f32-input MFMA, 157 TFLOP/s peak): at or above the precision of the yaml's mixed_precision: no + "
+           "dtype": ("bf16x3: f32 tensors, every product (linears, dX, dW: muse_gemm_x3 on four operand planes; the attention core: "
+                     "muse_attention_x3_*) as three bf16 MFMA products of hi / lo operand planes with f32 accumulation (<= 2^-16 relative per "
+                     "product: at or above the yaml's mixed_precision: no + enable_tf32, 10-bit mantissa products); f32 softmax, norms, GLU, "
+                     "residual stream, loss, AdamW; mfma_frac against the 833 TFLOP/s roof of that scheme (2500 / 3)") if x3 else ("exact f32 everywhere (f32-input MFMA, 157 TFLOP/s peak): at or above the precision of the yaml's mixed_precision: no + "
                      "enable_tf32 (10-bit mantissa products); gfx950 has no xf32 MFMA") if f32 else
                     "bf16 weight-GEMM / attention operands, f32 accumulate, residual stream, norms, loss (the yaml itself sets mixed_precision: no)",
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
@@ -798,7 +799,8 @@ def main():
         # ... and at the YAML's own precision class (cc12m_uvit_clip.yaml:102-103 mixed_precision "no" + TF32): exact f32 here
         extra["config4_uvit_seq256_f32"] = uvit_leg_isolated(device, 32, 256, 2, f32=True)
         # ... and the same precision class on the bf16 matrix pipes: f32 tensors, three bf16 MFMA products per GEMM
-        extra["config4_uvit_seq256_bf16x3"] = uvit_leg_isolated(device, 64, 256, 2, x3=True)
+        extra["config4_uvit_seq256_bf16x3"] = uvit_leg_isolated(device, 64, 256, 2, x3=True)             # the yaml's 64 per GPU
+        extra["config4_uvit_seq256_bf16x3_b128"] = uvit_leg_isolated(device, 128, 256, 2, x3=True)       # ... and a batch that uses the HBM
         # the reference's PUBLISHED metric (its only published numbers): text-to-image pipeline latency, 12 steps, 256 x 256
         extra["inference_latency"] = leg_isolated("latency", lambda: latency_leg(device))
 

@@ -767,6 +767,7 @@ __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
 template <typename TC, int AL, int BL>
 __global__ __launch_bounds__(512, 2) void kernel_x3(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  G256_TS(0)
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
   const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
   const int tid_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
