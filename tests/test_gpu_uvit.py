@@ -560,8 +560,29 @@ def test_uvit_config4_vs_reference_golden(golden_dir):
     for cd in (torch.float32, "bf16x3", torch.bfloat16):
         model.set_compute_dtype(cd)
         model.zero_grad(set_to_none=True)
-        logits, loss = model(ids, enc, cond, micro, labels=labels)
-        loss.backward()
+        from muse import ops
+        counts = {"attn": 0, "gemm_x3": 0}
+        inner_a, inner_g = ops.attention_x3_fwd, ops.gemm
+
+        def count_a(*a, **k):
+            counts["attn"] += 1
+            return inner_a(*a, **k)
+
+        def count_g(*a, **k):
+            r = inner_g(*a, **k)
+            counts["gemm_x3"] += 1 if (k.get("x3_lo") is not None and r is not None) else 0
+            return r
+        ops.attention_x3_fwd, ops.gemm = count_a, count_g
+        try:
+            logits, loss = model(ids, enc, cond, micro, labels=labels)
+            loss.backward()
+        finally:
+            ops.attention_x3_fwd, ops.gemm = inner_a, inner_g
+        if cd == "bf16x3":     # the mode's own kernels ran (no silent fallback to the materialised core / the K-concatenated product)
+            print("bf16x3 step:", counts["attn"], "fused attention forwards,", counts["gemm_x3"], "four-plane products")
+            assert counts["attn"] >= 2 * 22 and counts["gemm_x3"] >= 3 * 6 * 22
+        else:
+            assert counts["attn"] == 0 and counts["gemm_x3"] == 0
         f32 = cd != torch.bfloat16
         assert tuple(logits.shape) == tuple(g["logits_shape"])
         el = float(np.abs(W.subsample(logits.detach().float(), 16384).cpu().numpy() - g["logits"]).max()) / float(g["logits_absmax"])
