@@ -60,6 +60,14 @@ def _prof_end(e0, name, work, kind="flop"):
         _PROF.append((name, work, e0, e1, kind))
 
 
+def _touched(t):
+    """a HIP kernel of this package just rewrote t through its raw pointer: bump autograd's version counter, the way a torch in-place
+    op would - X3Images keys a tensor's cached operand planes by (storage, shape, version), so a rewritten tensor never finds the planes
+    of its previous contents"""
+    torch.autograd.graph.increment_version(t)
+    return t
+
+
 def _nbytes(*tensors):
     return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
 
@@ -156,10 +164,10 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
             return None
         check(rc, "muse_gemm_x3")
         _prof_end(e0, f"gemm_bf16x3_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
-        return C_
+        return _touched(C_)
     check(lib().muse_gemm(C.byref(d), stream()), "muse_gemm")
     _prof_end(e0, f"gemm_{'bf16' if d.dtype == BF16 else 'f32'}_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
-    return C_
+    return _touched(C_)
 
 
 # ---- "bf16x3": every f32 GEMM as three bf16 MFMA products ---------------------------------------------------------------------------
@@ -736,14 +744,14 @@ def layernorm_pair_bwd(dln2, x1, w_pre, mean_pre, rstd_pre, dres, ao, w_post, me
 def softmax_(x, rows, cols, ld):
     require_gpu(x)
     check(lib().muse_softmax_fwd(x.data_ptr(), x.data_ptr(), dt(x), rows, cols, ld, stream()), "muse_softmax_fwd")
-    return x
+    return _touched(x)
 
 
 def softmax_bwd_(p, dp, rows, cols, ld):
     """in place on dp: ds = p * (dp - sum(p*dp))"""
     require_gpu(p, dp)
     check(lib().muse_softmax_bwd(p.data_ptr(), dp.data_ptr(), dp.data_ptr(), dt(p), rows, cols, ld, stream()), "muse_softmax_bwd")
-    return dp
+    return _touched(dp)
 
 
 def attention_supported(dtype, seq, head_dim, seq_kv=None):
@@ -1182,7 +1190,7 @@ def dropout(x, p, seed, offset, out=None):
     y = out if out is not None else torch.empty_like(x)
     check(lib().muse_dropout(x.data_ptr(), y.data_ptr(), dt(x), x.numel(), float(p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
                              stream()), "muse_dropout")
-    return y
+    return _touched(y) if out is not None else y
 
 
 def cond_dropout(x, empty, uniforms, prob):
@@ -1589,7 +1597,7 @@ def add_rowvec_(x, b):
     if x.dtype != torch.float32 or b.dtype != torch.float32 or not x.is_contiguous():
         raise _hip.MuseHipError("add_rowvec_: contiguous f32 rows and an f32 vector")
     check(lib().muse_add_rowvec(x.data_ptr(), b.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], stream()), "muse_add_rowvec")
-    return x
+    return _touched(x)
 
 
 def bias_grad(dy, cols=None):
