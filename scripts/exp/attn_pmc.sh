@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; O=gpurun_out; mkdir -p $O
 run_pmc () { # name, counters
   rm -rf $O/apmc_$1
-  timeout 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/apmc_$1 -o p -- python scripts/attn_bench.py 5 0 > $O/apmc_$1.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/apmc_$1 -o p -- python ${ATTN_PMC_CMD:-scripts/attn_bench.py 5 0} > $O/apmc_$1.log 2>&1
   f=$(find $O/apmc_$1 -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python - "$f" <<'PY' | tee -a $O/attn_pmc_summary.txt
 import csv, sys, collections
