@@ -179,7 +179,8 @@ int muse_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const
 int muse_glu_fwd(const void* ab, void* h, int32_t dtype, int64_t rows, int32_t inter, void* stream);
 int muse_glu_bwd(const void* ab, const void* dh, void* dab, int32_t dtype, int64_t rows, int32_t inter, void* stream);
 /* The f32 GLU of the "bf16x3" compute mode: the same f32 results, written ALSO as the (hi, lo) bf16 operand planes muse_gemm_x3 reads
- * (planes = [2][rows][cols] bf16, hi plane first; the bits muse_split_f32_to_bf16x2 would produce from the f32 result). */
+ * (planes = [2][rows][cols] bf16, hi plane first; the bits muse_split_f32_to_bf16x2 would produce from the f32 result).  h / dab may be
+ * NULL: planes only (a result that nothing but weight GEMMs reads - the GLU output and its input gradient inside an MLP). */
 int muse_glu_fwd_x3(const float* ab, float* h, void* planes, int64_t rows, int32_t inter, void* stream);
 int muse_glu_bwd_x3(const float* ab, const float* dh, float* dab, void* planes, int64_t rows, int32_t inter, void* stream);
 /* Fused middle of the NormFormer GLU MLP (muse/modeling_transformer.py:789-797), one pass over ab = [rows, 2*inter]:

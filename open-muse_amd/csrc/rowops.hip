@@ -996,7 +996,7 @@ __global__ void glu_fwd_x3_kernel(const float* __restrict__ ab, float* __restric
     V4<float>::load(ab + r * 2 * inter + inter + c, b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = gelu_erf_t<false>(a[j]) * b[j];
-    V4<float>::store(h + r * inter + c, o);
+    if (h) V4<float>::store(h + r * inter + c, o);
     store_planes4(planes, plane, r * inter + c, o);
   }
 }
@@ -1012,8 +1012,10 @@ __global__ void glu_bwd_x3_kernel(const float* __restrict__ ab, const float* __r
     V4<float>::load(dh + r * inter + c, d);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { da[j] = d[j] * b[j] * gelu_erf_grad_t<false>(a[j]); db[j] = d[j] * gelu_erf_t<false>(a[j]); }
-    V4<float>::store(dab + r * 2 * inter + c, da);
-    V4<float>::store(dab + r * 2 * inter + inter + c, db);
+    if (dab) {
+      V4<float>::store(dab + r * 2 * inter + c, da);
+      V4<float>::store(dab + r * 2 * inter + inter + c, db);
+    }
     store_planes4(planes, plane, r * 2 * inter + c, da);
     store_planes4(planes, plane, r * 2 * inter + inter + c, db);
   }
@@ -1021,6 +1023,7 @@ __global__ void glu_bwd_x3_kernel(const float* __restrict__ ab, const float* __r
 extern "C" int muse_glu_fwd_x3(const float* ab, float* h, void* planes, int64_t rows, int32_t inter, void* stream) {
   if (inter % 4) return MUSE_ERR_BAD_ARG;
   if (rows <= 0) return 0;
+  if (!planes) return MUSE_ERR_BAD_ARG;
   if ((((uintptr_t)ab) | ((uintptr_t)h)) & 15 || (((uintptr_t)planes) & 7) || ((rows * inter) & 3)) return MUSE_ERR_ALIGN;
   hipLaunchKernelGGL(glu_fwd_x3_kernel, dim3(ew_grid(rows * (inter / 4))), dim3(256), 0, (hipStream_t)stream, ab, h, (bf16_t*)planes, (long)rows, inter);
   return (int)hipGetLastError();
@@ -1028,6 +1031,7 @@ extern "C" int muse_glu_fwd_x3(const float* ab, float* h, void* planes, int64_t 
 extern "C" int muse_glu_bwd_x3(const float* ab, const float* dh, float* dab, void* planes, int64_t rows, int32_t inter, void* stream) {
   if (inter % 4) return MUSE_ERR_BAD_ARG;
   if (rows <= 0) return 0;
+  if (!planes) return MUSE_ERR_BAD_ARG;
   if ((((uintptr_t)ab) | ((uintptr_t)dh) | ((uintptr_t)dab)) & 15 || (((uintptr_t)planes) & 7)) return MUSE_ERR_ALIGN;
   hipLaunchKernelGGL(glu_bwd_x3_kernel, dim3(ew_grid(rows * (inter / 4))), dim3(256), 0, (hipStream_t)stream, ab, dh, dab, (bf16_t*)planes, (long)rows, inter);
   return (int)hipGetLastError();

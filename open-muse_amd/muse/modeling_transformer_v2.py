@@ -552,7 +552,10 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
                 ab = ops.linear(self._c(m3), w01, out_dtype=torch.bfloat16)
             else:
                 ab = self._mm(m3, w01)
-            gl = ops.glu_fwd(ab)
+            # (bf16x3 step: gl only ever feeds wo's forward and dW products - it exists as their operand planes, no f32 tensor)
+            po = (self.compute_dtype == torch.float32 and not self.__dict__.get("_use_bias", False) and ab.dtype == torch.float32
+                  and ops.planes_only_ok(ab.shape[0], ab.shape[1] // 2) and min(lyr.ffn.wo.weight.shape) >= 128 and min(w01.shape) >= 128)
+            gl = ops.glu_fwd(ab, planes_only=po)
             t = self._lin(gl, lyr.ffn.wo)
             T["layers"].append(dict(res1=res1, res2=res2, res3=res3, a1s=a1s, a2s=a2s, a3s=a3s, s1=s1, s2=s2, m3=m3, w01=w01, ab=ab,
                                     gl=gl))
@@ -650,7 +653,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
                 dgl = ops.linear_dgrad(dtb, wo2)
             else:
                 dgl = self._lin_bwd(dt, sv["gl"], lyr.ffn.wo, nm + ".ffn.wo", G)
-            dab = ops.glu_bwd(sv["ab"], dgl)
+            dab = ops.glu_bwd(sv["ab"], dgl, planes_only=isinstance(sv["gl"], ops.Planes) and ops.planes_only_ok(*sv["ab"].shape))
             gw01 = self._mm_dw(dab, sv["m3"], sv["w01"].shape)
             I = gw01.shape[0] // 2
             G[nm + ".ffn.wi_0.weight"], G[nm + ".ffn.wi_1.weight"] = gw01[:I], gw01[I:]

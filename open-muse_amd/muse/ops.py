@@ -256,6 +256,40 @@ class X3Images:
             self.lru.pop(next(iter(self.lru)))
 
 
+class Planes:
+    """An f32-class GEMM operand that exists ONLY as its (hi, lo) bf16 planes [2, rows, cols] - the result of a producer kernel that nothing
+    but weight GEMMs reads (the GLU output and its input gradient inside an MLP, planes_only=True): the f32 tensor is never written.
+    Quacks like the contiguous f32 [rows, cols] tensor it stands for as far as the GEMM entry points look (shape, dtype, strides); the
+    products that take it are the four-plane ones (muse_gemm_x3) - anything else raises instead of reading bytes that are not there."""
+    dtype = torch.float32
+    is_cuda = True
+    _version = 0
+
+    def __init__(self, planes):
+        self.planes = planes
+        self.shape = torch.Size(planes.shape[1:])
+        self.device = planes.device
+
+    def dim(self):
+        return 2
+
+    def numel(self):
+        return self.shape[0] * self.shape[1]
+
+    def stride(self, i=None):
+        st = (self.shape[1], 1)
+        return st if i is None else st[i]
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return self.planes.data_ptr()      # (only ever probed for alignment)
+
+    def record_stream(self, s):
+        self.planes.record_stream(s)
+
+
 class f32_gemms_as_bf16x3:
     """`images`: an X3Images to share operand images between the products of a step (None: every product splits its operands)"""
     def __init__(self, on=True, images=None):
@@ -302,6 +336,8 @@ def _split_planes_now(t):
 
 def split_planes(t):
     """[2, *t.shape] bf16: hi = bf16(t), lo = bf16(t - hi), through the running step's image cache when there is one"""
+    if isinstance(t, Planes):
+        return t.planes
     require_gpu(t)
     im = _X3_IMAGES[0]
     return _split_planes_now(t) if im is None else im.planes(t)
@@ -362,6 +398,8 @@ def _gemm_bf16x3(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, 
             if gemm(a2[0], b2[0], C_, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=ldc, c_off=c_off, alpha=alpha, bias=bias, rowvec=rowvec,
                     residual=residual, ldr=ldr, accumulate=accumulate, x3_lo=(A.numel(), B.numel())) is not None:
                 return True
+    if isinstance(A, Planes) or isinstance(B, Planes):
+        raise _hip.MuseHipError("a planes-only operand reached a product the four-plane kernel does not take")
     if (X3_CAT and a_off == 0 and b_off == 0 and A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous() and K % 8 == 0
             and A.stride(0) == lda and B.stride(0) == ldb and A.shape[1 if la == 0 else 0] == K and B.shape[1 if lb == 0 else 0] == K
             and A.shape[0 if la == 0 else 1] >= M and B.shape[0 if lb == 0 else 1] >= N and 3 * A.numel() * 2 < (1 << 31)
@@ -485,6 +523,7 @@ def _wgrad_plan(dy, x, N, K, T_, lda, ldb):
 
 
 _WGRAD_X3_PLAN = {}
+X3_WGRAD_KTILE_US = float(os.environ.get("MUSE_X3_WGRAD_KTILE_US", "4.7"))   # cost-model time of a 64-wide K chunk of kernel_x3 (plain kernel: 1.8)
 
 
 def _wgrad_x3_native(dy, x, dw, accumulate, M):
@@ -502,7 +541,7 @@ def _wgrad_x3_native(dy, x, dw, accumulate, M):
     if splittable:
         sk = _WGRAD_X3_PLAN.get((N, K, T_))
         if sk is None:      # a 64-wide K-tile of this kernel is three products: ~2.6 x the plain kernel's time per tile
-            sk = _WGRAD_X3_PLAN[(N, K, T_)] = wgrad_splits(N, K, T_, torch.bfloat16, slots=256, tile=256, ktile_us=4.7)
+            sk = _WGRAD_X3_PLAN[(N, K, T_)] = wgrad_splits(N, K, T_, torch.bfloat16, slots=256, tile=256, ktile_us=X3_WGRAD_KTILE_US)
     if sk <= 1:
         return gemm(dy2[0], x2[0], dw, N, K, T_, la=1, lb=1, lda=ncols, ldb=K, ldc=dw.stride(0), accumulate=accumulate, x3_lo=lo) is not None
     ws = torch.empty((sk, N, K), dtype=torch.float32, device=dw.device)
@@ -510,6 +549,13 @@ def _wgrad_x3_native(dy, x, dw, accumulate, M):
         return False
     check(lib().muse_sum_slices(ws.data_ptr(), dw.data_ptr(), sk, N * K, N * K, 1 if accumulate else 0, stream()), "muse_sum_slices")
     return True
+
+
+def planes_only_ok(rows, cols):
+    """may a producer hand its [rows, cols] result to the weight GEMMs as planes only?  (a bf16x3 step is running, the four-plane kernel
+    is on and takes products with this operand: >= 128 rows / columns, whole 16-byte rows)"""
+    return (_X3_IMAGES[0] is not None and _F32_AS_BF16X3[0] and X3_NATIVE and X3_PRODUCERS and X3_PLANES_ONLY and rows >= 128 and cols >= 128
+            and rows % 8 == 0 and cols % 8 == 0 and rows * cols * 2 < (1 << 31))
 
 
 def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
@@ -521,6 +567,8 @@ def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
             if (X3_NATIVE and dy.dim() == 2 and x.dim() == 2 and dy.is_contiguous() and x.is_contiguous() and (lda is None or lda == dy.stride(0))
                     and dy.shape[0] == x.shape[0] and _wgrad_x3_native(dy, x, dw, accumulate, M)):
                 return dw
+            if isinstance(dy, Planes) or isinstance(x, Planes):
+                raise _hip.MuseHipError("a planes-only operand reached a weight-gradient product the four-plane kernel does not take")
             if (X3_CAT and dy.dim() == 2 and x.dim() == 2 and dy.is_contiguous() and x.is_contiguous() and (lda is None or lda == dy.stride(0))
                     and dy.shape[0] == x.shape[0] and 3 * dy.numel() * 2 < (1 << 32) - 64 and 3 * x.numel() * 2 < (1 << 32) - 64):
                 # one product over 3 T slots: the ROW-concatenated images dY' [T, 3N] = (hi | lo | hi), X' [T, 3K] = (hi | hi | lo) - the ones
@@ -882,6 +930,7 @@ def attention_bwd(qkv, ctx, dctx, lse, B, S, nh, hd, alpha):
     return dqkv
 
 
+X3_PLANES_ONLY = os.environ.get("MUSE_X3_PLANES_ONLY", "1") != "0"   # ... and skip the f32 result where only weight GEMMs read it (ops.Planes)
 X3_PRODUCERS = os.environ.get("MUSE_X3_PRODUCERS", "1") != "0"   # bf16x3 mode: kernels whose f32 result feeds a product write its operand planes too
 
 
@@ -905,9 +954,16 @@ def x3_put_planes(t, planes):
         _X3_IMAGES[0].put_planes(t, planes)
 
 
-def glu_fwd(ab):
+def glu_fwd(ab, planes_only=False):
+    """planes_only (a bf16x3 step, see planes_only_ok): -> ops.Planes, the result as GEMM operand planes without its f32 tensor"""
     require_gpu(ab)
     rows, two_i = ab.shape
+    if planes_only:
+        if not (planes_only_ok(rows, two_i // 2) and ab.dtype == torch.float32 and ab.is_contiguous()):
+            raise _hip.MuseHipError("glu_fwd(planes_only=True) outside planes_only_ok")
+        planes = torch.empty((2, rows, two_i // 2), dtype=torch.bfloat16, device=ab.device)
+        check(lib().muse_glu_fwd_x3(ab.data_ptr(), None, planes.data_ptr(), rows, two_i // 2, stream()), "muse_glu_fwd_x3")
+        return Planes(planes)
     h = torch.empty((rows, two_i // 2), dtype=ab.dtype, device=ab.device)
     im = _x3_producing(ab)
     if im is not None and (two_i // 2) % 8 == 0:
@@ -919,9 +975,15 @@ def glu_fwd(ab):
     return h
 
 
-def glu_bwd(ab, dh):
+def glu_bwd(ab, dh, planes_only=False):
     require_gpu(ab, dh)
     rows, two_i = ab.shape
+    if planes_only:
+        if not (planes_only_ok(rows, two_i) and ab.dtype == torch.float32 and dh.dtype == torch.float32 and ab.is_contiguous() and dh.is_contiguous()):
+            raise _hip.MuseHipError("glu_bwd(planes_only=True) outside planes_only_ok")
+        planes = torch.empty((2, rows, two_i), dtype=torch.bfloat16, device=ab.device)
+        check(lib().muse_glu_bwd_x3(ab.data_ptr(), dh.data_ptr(), None, planes.data_ptr(), rows, two_i // 2, stream()), "muse_glu_bwd_x3")
+        return Planes(planes)
     dab = torch.empty_like(ab)
     im = _x3_producing(ab)
     if im is not None and dh.dtype == torch.float32 and dh.is_contiguous() and two_i % 16 == 0:

@@ -1423,6 +1423,37 @@ def test_bf16x3_producers_write_operand_planes():
             assert torch.equal(planes, want), name
 
 
+def test_bf16x3_planes_only_operands():
+    """ops.Planes: a GLU result that only weight GEMMs read exists as its operand planes alone (no f32 tensor).  The forward product, the
+    dX product and both weight-gradient roles give the bits of the route that also writes the f32 tensor; a product the four-plane
+    kernel does not take raises instead of reading bytes that are not there; outside a bf16x3 step planes_only is refused."""
+    ops = _ops()
+    from muse._hip import MuseHipError
+    rows, inter, N = 512, 256, 384
+    ab, dh = rnd((rows, 2 * inter), 730).to(DEV), rnd((rows, inter), 731).to(DEV)
+    w, x, wsmall = rnd((N, inter), 732).to(DEV), rnd((rows, N), 733).to(DEV), rnd((64, inter), 734).to(DEV)
+    w2 = rnd((2 * inter, N), 735).to(DEV)
+    with pytest.raises(MuseHipError):
+        ops.glu_fwd(ab, planes_only=True)
+    assert not ops.planes_only_ok(rows, inter)
+    with ops.f32_gemms_as_bf16x3(True, ops.X3Images()):
+        assert ops.planes_only_ok(rows, inter) and not ops.planes_only_ok(64, inter)
+        h, hp = ops.glu_fwd(ab), ops.glu_fwd(ab, planes_only=True)
+        dab, dabp = ops.glu_bwd(ab, dh), ops.glu_bwd(ab, dh, planes_only=True)
+        assert isinstance(hp, ops.Planes) and tuple(hp.shape) == (rows, inter) and torch.equal(hp.planes, ops._split_planes_now(h))
+        assert torch.equal(dabp.planes, ops._split_planes_now(dab))
+        assert torch.equal(ops.linear(hp, w), ops.linear(h, w))                                       # forward product, A operand
+        assert torch.equal(ops.linear_dgrad(dabp, w2), ops.linear_dgrad(dab, w2))                     # dX product, A operand
+        g0, g1 = torch.empty((N, inter), device=DEV), torch.empty((N, inter), device=DEV)
+        ops.linear_wgrad(x, h, g0, False); ops.linear_wgrad(x, hp, g1, False)                         # dW: planes as the B operand
+        assert torch.equal(g0, g1)
+        g2, g3 = torch.empty((2 * inter, N), device=DEV), torch.empty((2 * inter, N), device=DEV)
+        ops.linear_wgrad(dab, x, g2, False); ops.linear_wgrad(dabp, x, g3, False)                     # dW: planes as the A operand
+        assert torch.equal(g2, g3)
+        with pytest.raises(MuseHipError):
+            ops.linear(hp, wsmall)                                                                    # N = 64: not a four-plane product
+
+
 def test_bf16x3_weight_gradient_with_k_split():
     """dW = dY^T X over 8192 tokens in the bf16x3 mode: the four-plane kernel with its K slices through a workspace (fixed summation
     order), plain and accumulating; against float64 and against the K-concatenated route"""
