@@ -166,7 +166,8 @@ int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* o_planes, i
 int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, int64_t lddo, int64_t bsdo, const float* lse, void* dq,
                           int64_t lddq, int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv, int64_t bsdv,
                           void* dq_planes, int64_t dq_lo, void* dk_planes, int64_t dk_lo, void* dv_planes, int64_t dv_lo, void* stream);
-/* (*_planes, optional: the result ALSO as the bf16 operand planes of the products that read it - muse_gemm_x3 - so that no split pass
+/* (dq / dk / dv may be NULL when their planes are given: a gradient that only weight GEMMs read exists as planes alone.)
+ * (*_planes, optional: the result ALSO as the bf16 operand planes of the products that read it - muse_gemm_x3 - so that no split pass
  *  runs over it: the hi plane is addressed exactly like the f32 tensor (same strides, in elements), the lo plane sits *_lo elements
  *  behind it; NULL = f32 only) */
 /* packed self-attention: qkv [B*S, 3*H] (q | k | v, H = heads*head_dim: the fused QKV projection), ctx [B*S, H], dqkv [B*S, 3*H] */

@@ -161,7 +161,7 @@ __device__ __forceinline__ void store_rows3(float* rowp, const f32x16 (&acc)[C::
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const f32x4 v = {acc[db][4 * q4] * scale, acc[db][4 * q4 + 1] * scale, acc[db][4 * q4 + 2] * scale, acc[db][4 * q4 + 3] * scale};
-      *(f32x4*)(rowp + 32 * db + 8 * q4 + 4 * h) = v;
+      if (rowp) *(f32x4*)(rowp + 32 * db + 8 * q4 + 4 * h) = v;
       if (hip) {
         u32x2 hi, lo;
         split4_values(v[0], v[1], v[2], v[3], hi, lo);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
       mma_seq3(Ah, Al, g, kb, dp, dq);
     }
     const long oq = b * P.bdq + (long)q * P.lddq + hh * HD;
-    store_rows3(P.dq + oq, dq, P.alpha, g.h, P.dqp ? P.dqp + oq : nullptr, P.lo_dq);
+    store_rows3(P.dq ? P.dq + oq : nullptr, dq, P.alpha, g.h, P.dqp ? P.dqp + oq : nullptr, P.lo_dq);
   }
   lds_barrier();       // everybody is done with the K, V planes; L2 / DS are written
   // ---------------- phase 2 ----------------
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
       }
       if (valid) {
         const long ok = b * P.bdk + (long)key * P.lddk + hh * HD, ov = b * P.bdv + (long)key * P.lddv + hh * HD;
-        store_rows3(P.dk + ok, dk, P.alpha, g.h, P.dkp ? P.dkp + ok : nullptr, P.lo_dk);
-        store_rows3(P.dv + ov, dv, 1.0f, g.h, P.dvp ? P.dvp + ov : nullptr, P.lo_dv);
+        store_rows3(P.dk ? P.dk + ok : nullptr, dk, P.alpha, g.h, P.dkp ? P.dkp + ok : nullptr, P.lo_dk);
+        store_rows3(P.dv ? P.dv + ov : nullptr, dv, 1.0f, g.h, P.dvp ? P.dvp + ov : nullptr, P.lo_dv);
       }
     }
   }
@@ -376,6 +376,7 @@ extern "C" int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, i
   if (rc) return rc;
   if ((lddo | bsdo | lddq | bsdq | lddk | bsdk | lddv | bsdv) & 3) return MUSE_ERR_ALIGN;
   if ((((uintptr_t)d_o) | ((uintptr_t)dq) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 15) return MUSE_ERR_ALIGN;
+  if ((!dq && !dq_planes) || (!dk && !dk_planes) || (!dv && !dv_planes)) return MUSE_ERR_BAD_ARG;    // (a gradient may exist as planes only)
   if (d->batch <= 0) return 0;
   Params P = base(d);
   P.o = (const float*)d->o; P.d_o = (const float*)d_o; P.lddo = lddo; P.bdo = bsdo;

@@ -876,31 +876,39 @@ def attention_x3_fwd(q, k, v, B, Sq, Skv, nh, hd, alpha):
     return ctx, lse
 
 
-def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None, dk=None, dv=None, planes=None):
+def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None, dk=None, dv=None, planes=None, planes_only=False):
     """-> (dq [B*Sq, H], dk, dv [B*Skv, H]) f32; dq / dk / dv may be views (the column blocks of a packed gradient).
     planes = ((dq_hi, dq_lo_off), (dk_hi, ..), (dv_hi, ..)): hi-plane views shaped / strided like dq / dk / dv and the element distance
-    to their lo planes (entries may be None) - the gradients also come out as operand planes (x3_new_planes of the packed tensor)"""
+    to their lo planes (entries may be None) - the gradients also come out as operand planes (x3_new_planes of the packed tensor).
+    planes_only: no f32 gradients at all (dq / dk / dv stay None; the caller wraps the plane tensors in ops.Planes)"""
     require_gpu(q, k, v, ctx, dctx, lse)
     H = nh * hd
-    dq = dq if dq is not None else torch.empty((B * Sq, H), dtype=torch.float32, device=q.device)
-    dk = dk if dk is not None else torch.empty((B * Skv, H), dtype=torch.float32, device=q.device)
-    dv = dv if dv is not None else torch.empty((B * Skv, H), dtype=torch.float32, device=q.device)
+    planes = planes or (None, None, None)
+    if not planes_only:
+        dq = dq if dq is not None else torch.empty((B * Sq, H), dtype=torch.float32, device=q.device)
+        dk = dk if dk is not None else torch.empty((B * Skv, H), dtype=torch.float32, device=q.device)
+        dv = dv if dv is not None else torch.empty((B * Skv, H), dtype=torch.float32, device=q.device)
+    elif dq is not None or dk is not None or dv is not None or any(e is None or e[0] is None for e in planes):
+        raise _hip.MuseHipError("attention_x3_bwd(planes_only=True): three plane views and no f32 gradient tensors")
     for t in (ctx, dctx, dq, dk, dv):
-        if t.dtype != torch.float32:
+        if t is not None and t.dtype != torch.float32:
             raise _hip.MuseHipError("attention_x3: f32 operands")
     d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
-    (pdo, lddo), (pdq, lddq), (pdk, lddk), (pdv, lddv) = _row_view(dctx, H), _row_view(dq, H), _row_view(dk, H), _row_view(dv, H)
+    pdo, lddo = _row_view(dctx, H)
     e0 = _prof_begin()
+    args = []
     pl = []
-    for ent, g in zip(planes or (None, None, None), (dq, dk, dv)):
+    for ent, g, rows in zip(planes, (dq, dk, dv), (Sq, Skv, Skv)):
+        ref = g if g is not None else ent[0]               # (strides: the f32 view's, or - planes only - the hi-plane view's own)
+        pg, ldg = _row_view(ref, H)
+        args += [pg if g is not None else None, ldg, rows * ldg]
         if ent is None or ent[0] is None:
             pl += [None, 0]
         else:
-            if ent[0].stride() != g.stride() or ent[0].shape != g.shape or ent[0].dtype != torch.bfloat16:
+            if ent[0].stride() != ref.stride() or ent[0].shape != ref.shape or ent[0].dtype != torch.bfloat16:
                 raise _hip.MuseHipError("attention_x3_bwd: a hi-plane view must mirror its gradient view")
             pl += [ent[0].data_ptr(), int(ent[1])]
-    check(lib().muse_attention_x3_bwd(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), pdq, lddq, Sq * lddq, pdk, lddk, Skv * lddk,
-                                      pdv, lddv, Skv * lddv, *pl, stream()), "muse_attention_x3_bwd")
+    check(lib().muse_attention_x3_bwd(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), *args, *pl, stream()), "muse_attention_x3_bwd")
     _prof_end(e0, "attn_bwd_bf16x3", 10.0 * B * nh * Sq * Skv * hd)
     return dq, dk, dv
 

@@ -371,13 +371,20 @@ class TapeOps:
         if sv["self_attn"]:
             if not self_attn:
                 raise MuseHipError("self-attention tape replayed as cross-attention")
-            dqkv = torch.empty_like(qkv)
-            pl = ops.x3_new_planes(dqkv)       # dqkv feeds one dW and one dX product: its operand planes come out of the kernel
-            lo = dqkv.numel()
-            ops.attention_x3_bwd(q, qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha,
-                                 dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq], dv=dqkv[:, 2 * Cq:],
-                                 planes=None if pl is None else ((pl[0][:, :Cq], lo), (pl[0][:, Cq:2 * Cq], lo), (pl[0][:, 2 * Cq:], lo)))
-            ops.x3_put_planes(dqkv, pl)
+            lo = qkv.numel()
+            if not ub and ops.planes_only_ok(qkv.shape[0], qkv.shape[1]) and min(w.shape) >= 128:
+                # dqkv feeds one dW and one dX product and nothing else: it exists as their operand planes only
+                pl = torch.empty((2,) + tuple(qkv.shape), dtype=torch.bfloat16, device=qkv.device)
+                ops.attention_x3_bwd(q, qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, planes_only=True,
+                                     planes=((pl[0][:, :Cq], lo), (pl[0][:, Cq:2 * Cq], lo), (pl[0][:, 2 * Cq:], lo)))
+                dqkv = ops.Planes(pl)
+            else:
+                dqkv = torch.empty_like(qkv)
+                pl = ops.x3_new_planes(dqkv)       # ... or as f32 and planes, both out of the kernel
+                ops.attention_x3_bwd(q, qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha,
+                                     dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq], dv=dqkv[:, 2 * Cq:],
+                                     planes=None if pl is None else ((pl[0][:, :Cq], lo), (pl[0][:, Cq:2 * Cq], lo), (pl[0][:, 2 * Cq:], lo)))
+                ops.x3_put_planes(dqkv, pl)
             gqkv = self._mm_dw(dqkv, sv["x"], (3 * Cq, Cq))
             G[name + ".query.weight"], G[name + ".key.weight"], G[name + ".value.weight"] = gqkv[:Cq], gqkv[Cq:2 * Cq], gqkv[2 * Cq:]
             if ub:

@@ -1452,6 +1452,19 @@ def test_bf16x3_planes_only_operands():
         assert torch.equal(g2, g3)
         with pytest.raises(MuseHipError):
             ops.linear(hp, wsmall)                                                                    # N = 64: not a four-plane product
+        # the fused attention's packed gradient as planes only: the bits of the f32 + planes route
+        B, nh, hd, Sq = 2, 2, 64, 256
+        H = nh * hd
+        qkv, dctx = rnd((B * Sq, 3 * H), 736).to(DEV), rnd((B * Sq, H), 737).to(DEV)
+        ctx, lse = ops.attention_x3_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, Sq, Sq, nh, hd, 0.125)
+        dqkv = torch.empty_like(qkv)
+        ops.attention_x3_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], ctx, dctx, lse, B, Sq, Sq, nh, hd, 0.125, dq=dqkv[:, :H],
+                             dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:])
+        pl = torch.zeros((2,) + tuple(qkv.shape), dtype=torch.bfloat16, device=DEV)
+        lo = qkv.numel()
+        r = ops.attention_x3_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], ctx, dctx, lse, B, Sq, Sq, nh, hd, 0.125, planes_only=True,
+                                 planes=((pl[0][:, :H], lo), (pl[0][:, H:2 * H], lo), (pl[0][:, 2 * H:], lo)))
+        assert r == (None, None, None) and torch.equal(pl, ops._split_planes_now(dqkv))
 
 
 def test_bf16x3_weight_gradient_with_k_split():
