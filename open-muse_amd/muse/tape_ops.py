@@ -391,14 +391,23 @@ class TapeOps:
                 gb = ops.bias_grad(dqkv)
                 G[name + ".query.bias"], G[name + ".key.bias"], G[name + ".value.bias"] = gb[:Cq], gb[Cq:2 * Cq], gb[2 * Cq:]
             return self._mm_dx(dqkv, w), None                                             # d(x) through q, k and v in one product
-        dq = torch.empty_like(q)
-        dkv = torch.empty_like(qkv)
-        plq, plkv = ops.x3_new_planes(dq), ops.x3_new_planes(dkv)
-        ops.attention_x3_bwd(q, qkv[:, :Cq], qkv[:, Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:],
-                             planes=(None if plq is None else (plq[0], dq.numel()), None if plkv is None else (plkv[0][:, :Cq], dkv.numel()),
-                                     None if plkv is None else (plkv[0][:, Cq:], dkv.numel())))
-        ops.x3_put_planes(dq, plq)
-        ops.x3_put_planes(dkv, plkv)
+        if (not ub and ops.planes_only_ok(q.shape[0], q.shape[1]) and ops.planes_only_ok(qkv.shape[0], qkv.shape[1]) and min(w.shape) >= 128
+                and min(att.query.weight.shape) >= 128):
+            # dq and dkv feed one dW and one dX product each and nothing else: planes only
+            plq = torch.empty((2,) + tuple(q.shape), dtype=torch.bfloat16, device=q.device)
+            plkv = torch.empty((2,) + tuple(qkv.shape), dtype=torch.bfloat16, device=q.device)
+            ops.attention_x3_bwd(q, qkv[:, :Cq], qkv[:, Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, planes_only=True,
+                                 planes=((plq[0], q.numel()), (plkv[0][:, :Cq], qkv.numel()), (plkv[0][:, Cq:], qkv.numel())))
+            dq, dkv = ops.Planes(plq), ops.Planes(plkv)
+        else:
+            dq = torch.empty_like(q)
+            dkv = torch.empty_like(qkv)
+            plq, plkv = ops.x3_new_planes(dq), ops.x3_new_planes(dkv)
+            ops.attention_x3_bwd(q, qkv[:, :Cq], qkv[:, Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:],
+                                 planes=(None if plq is None else (plq[0], dq.numel()), None if plkv is None else (plkv[0][:, :Cq], dkv.numel()),
+                                         None if plkv is None else (plkv[0][:, Cq:], dkv.numel())))
+            ops.x3_put_planes(dq, plq)
+            ops.x3_put_planes(dkv, plkv)
         dx = self._lin_bwd(dq, sv["x"], att.query, name + ".query", G)
         Ck = att.key.weight.shape[1]
         gkv = self._mm_dw(dkv, sv["ctx"], (2 * Cq, Ck))
