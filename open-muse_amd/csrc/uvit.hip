@@ -719,7 +719,7 @@ extern "C" int muse_norm_adaln_fwd(const float* x, const float* res, const float
 // "bf16x3" mode: m as f32 AND as the (hi, lo) operand planes [2][rows][cols] of the products that read it
 extern "C" int muse_norm_adaln_fwd_x3(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* planes,
                                       int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
-  if (!planes || !m) return MUSE_ERR_BAD_ARG;
+  if (!planes) return MUSE_ERR_BAD_ARG;      // (m may be NULL: the planes only - a result that nothing but weight GEMMs reads)
   return norm_adaln_fwd_launch(x, res, w, ss, pre, m, planes, (long)batch * rows_per_batch * cols, batch, rows_per_batch, cols, eps, mode, stream);
 }
 

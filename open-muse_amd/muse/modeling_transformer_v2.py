@@ -372,15 +372,18 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         self._ada_dss(dss, sv, mod, name, G, scond, dscond)
         return dx
 
-    def _norm_adaln(self, x, norm_mod, ada: _AdaLN, scond, B, mode=None, residual=None):
+    def _norm_adaln(self, x, norm_mod, ada: _AdaLN, scond, B, mode=None, residual=None, gemm_only=False):
         """norm(x + residual) followed by its AdaLN modulation (TransformerLayer :757-792) as ONE kernel where the shape allows: the
         norm output itself is never written.  -> (m = GEMM operand of the next block, v = x + residual, tape entry)"""
         mode = self._nm(mode)
         ss, slot = self._ada_ss_of(ada, scond)
         if self.fuse_norm_adaln and ops.norm_adaln_ok(x.shape[0], x.shape[1], B):
             od = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
+            # gemm_only: the caller's m is read by weight GEMMs alone (all of them products the four-plane kernel takes) - in a bf16x3 step
+            # it exists as their operand planes, the f32 tensor is not written
+            po = gemm_only and od == torch.float32 and x.dtype == torch.float32 and ops.planes_only_ok(x.shape[0], x.shape[1])
             m, v = ops.norm_adaln_fwd(x, self._f(norm_mod.weight), ss, B, float(self.config.layer_norm_eps), mode, residual=residual,
-                                      out_dtype=od)
+                                      out_dtype=od, planes_only=po)
             return m, v, dict(ss=ss, slot=slot, fused=True)
         n, v = self._norm(x, norm_mod, mode=mode, residual=residual, want_pre=True)
         od = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and _BF16_OPERANDS & 1) else torch.float32
@@ -538,13 +541,16 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         res = None
         nh = c.num_attention_heads
         T["layers"] = []
+        # m1 / m2 / m3 are read by the layer's weight GEMMs only (q | k | v, q, wi_0 | wi_1: forward and dW), whatever attention route runs;
+        # without biases and with every such weight at least 128 wide they need no f32 tensor in a bf16x3 step
+        go = (not self.__dict__.get("_use_bias", False) and c.hidden_size >= 128 and 2 * c.intermediate_size >= 128)
         for lyr in self.transformer_layers:                                           # TransformerLayer :757-792
-            m1, res1, a1s = self._norm_adaln(t, lyr.attn_layer_norm, lyr.self_attn_adaLN_modulation, scond, B, residual=res)
+            m1, res1, a1s = self._norm_adaln(t, lyr.attn_layer_norm, lyr.self_attn_adaLN_modulation, scond, B, residual=res, gemm_only=go)
             a, s1 = self._attention(m1, m1, lyr.attention, B, S, S, nh)
-            m2, res2, a2s = self._norm_adaln(a, lyr.crossattn_layer_norm, lyr.cross_attn_adaLN_modulation, scond, B, residual=res1)
+            m2, res2, a2s = self._norm_adaln(a, lyr.crossattn_layer_norm, lyr.cross_attn_adaLN_modulation, scond, B, residual=res1, gemm_only=go)
             a2, s2 = self._attention(m2, enc, lyr.crossattention, B, S, L, nh)
             m3, res3, a3s = self._norm_adaln(a2, lyr.ffn.pre_mlp_layer_norm, lyr.ffn.adaLN_modulation, scond, B, mode=1,
-                                             residual=res2)                                                # LayerNorm (:928)
+                                             residual=res2, gemm_only=go)                                  # LayerNorm (:928)
             w01 = self._w2(lyr.ffn.wi_0, lyr.ffn.wi_1)
             if self.compute_dtype == torch.bfloat16:
                 # the reference's autocast regime: the GLU input and output live in bf16 between the two GEMMs (no f32 round trip,

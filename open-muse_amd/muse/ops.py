@@ -1703,11 +1703,19 @@ def norm_adaln_ok(rows, cols, batch):
     return cols % 4 == 0 and cols <= 1024 and rows % batch == 0 and (rows // batch) % 16 == 0
 
 
-def norm_adaln_fwd(x, w, ss, batch, eps, mode, residual=None, out_dtype=torch.float32):
-    """v = x (+ residual); m = Norm(v) * w * (1 + scale) + shift with (scale | shift) = ss [batch, 2C]  ->  (m in out_dtype, v)"""
+def norm_adaln_fwd(x, w, ss, batch, eps, mode, residual=None, out_dtype=torch.float32, planes_only=False):
+    """v = x (+ residual); m = Norm(v) * w * (1 + scale) + shift with (scale | shift) = ss [batch, 2C]  ->  (m in out_dtype, v).
+    planes_only (a bf16x3 step, planes_only_ok): m comes back as ops.Planes - operand planes without the f32 tensor"""
     require_gpu(x, ss)
     rows, cols = x.shape
     pre = torch.empty_like(x)
+    if planes_only:
+        if not (planes_only_ok(rows, cols) and x.dtype == torch.float32 and x.is_contiguous()):
+            raise _hip.MuseHipError("norm_adaln_fwd(planes_only=True) outside planes_only_ok")
+        planes = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=x.device)
+        check(lib().muse_norm_adaln_fwd_x3(x.data_ptr(), ptr(residual), ptr(w), ss.data_ptr(), pre.data_ptr(), None, planes.data_ptr(),
+                                           batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_fwd_x3")
+        return Planes(planes), pre
     m = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
     f32 = out_dtype == torch.float32
     im = _x3_producing(x) if f32 else None
