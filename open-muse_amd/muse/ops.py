@@ -184,14 +184,17 @@ _X3_IMAGES = [None]      # the operand-image cache of the pass that is running (
 class X3Images:
     """The bf16x3 operand images of ONE training step, so that a tensor is split once per step instead of once per product.  An
     activation x is the A operand of its Linear's forward product and the B operand of the weight-gradient product; a gradient dY is
-    the A operand of the dX product and the A operand of dW.  With the patterns chosen in `_gemm_bf16x3` / `linear_wgrad` ONE image
-    serves both uses: the row-concatenated image [T, 3K] of the forward / dX product, viewed as [3T, K], IS the token-stacked image of
-    the dW product (token t's three thirds are rows 3t .. 3t+2 - a contraction does not care about the order of its slots).
-    Keyed by (storage address, shape, strides, autograd version, layout, pattern); an entry keeps its source tensor alive, so an
-    address cannot come back with other contents while the entry exists.  HIP kernels of this package write through raw pointers
-    (no version bump): the owner clears the cache at the start of a forward and at the end of a backward - within those bounds a GEMM
-    operand is never rewritten between two uses (the tape needs the same bytes for dW).  Images made during the backward (dY) are
-    dead two products later: they live in a short LRU."""
+    the A operand of the dX product and the A operand of dW; a weight is the B operand of the forward and of the dX product.
+    Two image forms:
+      * planes [2, rows, cols] (hi, lo) for the four-plane kernel (muse_gemm_x3): ONE image per tensor whatever the product reads it as;
+        a producer kernel may hand them in itself (put_planes);
+      * K-concatenated images for the plain kernel (shapes muse_gemm_x3 refuses): with the patterns chosen in `_gemm_bf16x3` /
+        `linear_wgrad` the row-concatenated image [T, 3K] of the forward / dX product, viewed as [3T, K], IS the token-stacked image of
+        the dW product (token t's three thirds are rows 3t .. 3t+2 - a contraction does not care about the order of its slots).
+    Keyed by (storage address, shape, strides, autograd version, form); an entry keeps its source tensor alive, so an address cannot
+    come back with other contents while the entry exists, and the wrappers of kernels that rewrite a tensor in place bump its version
+    (`_touched`).  The owner clears the cache at the start of a forward and at the end of a backward.  Images made during the backward
+    (dY) are dead two products later: they live in a short LRU."""
 
     def __init__(self, recent=12):
         self.persist, self.lru, self.recent, self.backward = {}, {}, int(recent), False
