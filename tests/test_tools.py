@@ -52,3 +52,51 @@ def test_attention2_lane_arithmetic_on_cpu():
         assert out.returncode == 0, out.stderr[-1500:]
         assert "OK" in out.stdout and "worst multiplicity of a 16-byte slot inside a service group = 1" in out.stdout
         assert "worst multiplicity of a bank inside a 32-lane group = 1" in out.stdout
+
+
+def test_bf16x3_operand_image_cache_host_logic(monkeypatch):
+    """CPU: ops.X3Images (one operand image per tensor and training step) and ops.Planes (a planes-only operand) without a GPU - the split
+    is replaced by a counting stand-in.  A tensor is split once however many products read it; a rewritten tensor (version bump) is
+    split again; producer-written planes are found without a split; backward-made images live in a short LRU; clear() forgets all;
+    outside a step nothing is cached and planes-only results are refused."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    from muse import ops
+    calls = []
+
+    def fake_split(t):
+        calls.append(t)
+        return torch.zeros((2,) + tuple(t.shape), dtype=torch.bfloat16)
+    monkeypatch.setattr(ops, "_split_planes_now", fake_split)
+    monkeypatch.setattr(ops, "require_gpu", lambda *a: None)
+    a, b = torch.zeros(8, 16), torch.zeros(8, 16)
+    ops.split_planes(a); ops.split_planes(a)
+    assert len(calls) == 2                                        # no step running: every product splits its own operands
+    im = ops.X3Images(recent=2)
+    with ops.f32_gemms_as_bf16x3(True, im):
+        p1 = ops.split_planes(a)
+        assert ops.split_planes(a) is p1 and len(calls) == 3 and (im.hits, im.misses) == (1, 1)
+        assert ops.split_planes(b) is not p1 and len(calls) == 4  # same shape, other storage: its own image
+        ops._touched(a)                                           # a kernel rewrote a in place
+        assert ops.split_planes(a) is not p1 and len(calls) == 5
+        made = torch.ones((2, 8, 16), dtype=torch.bfloat16)
+        c = torch.zeros(8, 16)
+        im.put_planes(c, made)                                    # a producer kernel wrote c's planes itself
+        assert ops.split_planes(c) is made and len(calls) == 5 and im.produced == 1
+        with ops.f32_gemms_as_bf16x3(False):                      # (the products' own inner scope keeps the step's cache visible)
+            assert ops.split_planes(c) is made
+        im.backward = True
+        g = [torch.zeros(8, 16) for _ in range(3)]
+        for t in g:
+            ops.split_planes(t)
+        assert len(calls) == 8 and len(im.lru) == 2               # the oldest backward image was evicted ...
+        ops.split_planes(g[0])
+        assert len(calls) == 9                                    # ... and is split again when asked for
+        assert ops.split_planes(c) is made                        # forward images stay until the step ends
+        im.clear()
+        assert not im.persist and not im.lru
+    assert ops._X3_IMAGES[0] is None and not ops.planes_only_ok(512, 512)
+    pl = ops.Planes(torch.zeros((2, 256, 128), dtype=torch.bfloat16))
+    assert tuple(pl.shape) == (256, 128) and pl.dtype == torch.float32 and pl.stride() == (128, 1) and pl.stride(0) == 128
+    assert pl.dim() == 2 and pl.numel() == 256 * 128 and pl.is_contiguous() and ops.split_planes(pl) is pl.planes and len(calls) == 9
