@@ -701,9 +701,16 @@ __global__ __launch_bounds__(512, 2) void conv_slab_kernel(Params p) {
 //   and stores retire in order within their kind; a counted wait that still sees stores is merely conservative).
 constexpr int P_BUF1 = 92160, P_BBASE = 43008, P_STAGING = P_BUF1, P_HALF_ROWS = 128;
 constexpr int P_LDS_BYTES = P_STAGING + P_HALF_ROWS * CST;   // 159744
+// GN = true: two [2][Cin] f32 scale / shift tables behind the tile's map (this tile's image, the next tile's image): Cin <= 256
+constexpr int P_GSS = P_LDS_BYTES, P_GSS_MAX_CIN = 256, P_LDS_BYTES_GN = P_LDS_BYTES + 2 * 2 * P_GSS_MAX_CIN * 4;   // 163840 = all of it
 __host__ __device__ constexpr int p_stage_off(int st) { return st == 0 ? 32768 : (st - 1) * 16384; }   // relative to P_BBASE
-static_assert(P_BBASE + 3 * BSTAGE == P_BUF1 && P_BUF1 + SLAB <= P_LDS_BYTES && P_LDS_BYTES <= 163840, "LDS map");
+static_assert(P_BBASE + 3 * BSTAGE == P_BUF1 && P_BUF1 + SLAB <= P_LDS_BYTES && P_LDS_BYTES_GN <= 163840, "LDS map");
 
+// GN = true is the persistent form of conv_slab_kernel<true> (round 6): the f32 activation goes through registers, GroupNorm affine +
+// SiLU + hi / lo split are applied on the way into the slab buffer - same slots, same arithmetic, same bits as the launch-per-tile
+// kernel - and the look-ahead across the tile boundary carries the NEXT tile's first chunk through that same register path with the
+// next tile's image's scale / shift (second table, fetched by one 256-byte LDS-DMA per wave early in the tile).
+template <bool GN>
 __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int H = p.H, W = p.W, Cin = p.Cin;
@@ -715,8 +722,9 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  const unsigned bytesA = (unsigned)((long)p.M * Cin * 2);
-  const rsrc_t rs_xh = make_rsrc(p.xh, bytesA), rs_xl = make_rsrc(p.xl, bytesA);
+  constexpr int XE = GN ? 4 : 2;             // bytes per activation element in global memory
+  const unsigned bytesA = (unsigned)((long)p.M * Cin * XE);
+  const rsrc_t rs_xh = make_rsrc(GN ? (const void*)p.xf : (const void*)p.xh, bytesA), rs_xl = make_rsrc(GN ? (const void*)p.xf : (const void*)p.xl, bytesA);
   const unsigned oobA = (bytesA + 15u) & ~15u;
   const int wimg = wave >> 2;
   const unsigned bytesB = (unsigned)((long)p.N * p.K * 2);
@@ -730,7 +738,6 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) { int piece = wave + 8 * k; if (piece > 20) piece -= 8; slab_piece[k] = piece; }
   const int srcchunkA = (lane & 3) ^ (((lane >> 4) & 1) << 1);
-  const int srcchunkB = (lane & 3) ^ sw4((lane >> 4) & 3);
 
   // geometry of virtual block v (the XCD-aware walk of the launch-per-tile kernels: v -> tile)
   struct Geo { int img, prem, y0, x0, n0; };
@@ -745,17 +752,20 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
     g.y0 = ty << 4; g.x0 = tx << 4;
     return g;
   };
-  auto offsets_of = [&](const Geo& g, bool valid, unsigned (&so)[3], unsigned (&vb)[2]) {
+  // (`ln` = the lane id behind an empty asm: per-lane geometry is recomputed per tile instead of living in registers across the K loop)
+  auto offsets_of = [&](const Geo& g, bool valid, unsigned (&so)[3], unsigned (&vb)[2], int ln) {
+    const int srcchunkA = (ln & 3) ^ (((ln >> 4) & 1) << 1);
+    const int srcchunkB = (ln & 3) ^ sw4((ln >> 4) & 3);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int r = slab_piece[k] * 16 + (lane >> 2), sy = r / 18, sx = r - sy * 18;
+      const int r = slab_piece[k] * 16 + (ln >> 2), sy = r / 18, sx = r - sy * 18;
       const int y = g.y0 - 1 + sy, x = g.x0 - 1 + sx;
       const bool ok = valid && r < 324 && y >= 0 && y < H && x >= 0 && x < W;
-      so[k] = ok ? (unsigned)((((long)g.img * H + y) * W + x) * Cin * 2 + srcchunkA * 16) : oobA;
+      so[k] = ok ? (unsigned)(((((long)g.img * H + y) * W + x) * Cin + srcchunkA * 8) * XE) : oobA;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int n = g.n0 + ((wave & 3) * 2 + j) * 16 + (lane >> 2);
+      const int n = g.n0 + ((wave & 3) * 2 + j) * 16 + (ln >> 2);
       vb[j] = (valid && n < p.N) ? (unsigned)(((long)n * p.K + srcchunkB * 8) * 2) : oobB;
     }
   };
@@ -777,6 +787,51 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
     for (int j = 0; j < 2; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + P_BBASE + stage_off + wimg * 8192 + ((wave & 3) * 2 + j) * 1024),
                                                16, (int)(cur ? voffB[j] : voffB_n[j]), soff, 0, 0);
+  };
+
+  // ---- GN: the register path of the slab (conv_slab_kernel<true>), with the tile-boundary case ----
+  float* gss_cur = (float*)(smem + P_GSS);                       // [2][Cin] of the current tile's image
+  float* gss_nxt = gss_cur + 2 * P_GSS_MAX_CIN;                  // ... of the next tile's image
+  u32x4 xr[2];
+  float scv[4], shv[4];
+  auto issue_slab_f = [&](u32x4 (&r)[2], int k, int chunk) {
+    const bool cur = chunk < nchunks;
+    const unsigned vo = cur ? slab_off[k] : slab_off_n[k];
+    const unsigned soff = cur ? (unsigned)(chunk * 128) : 0u;
+    r[0] = buf_load16(rs_xh, vo, soff);
+    r[1] = buf_load16(rs_xh, vo + 16u, soff);
+  };
+  auto load_gss = [&](int chunk, int h) {
+    const float* q = (chunk < nchunks ? gss_cur + chunk * 32 : gss_nxt) + srcchunkA * 8 + h * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { scv[j] = q[j]; shv[j] = q[Cin + j]; }
+  };
+  auto xform_elem = [&](u32x4 (&r)[2], int e) {
+    float t = fmaf(__uint_as_float(r[e >> 2][e & 3]), scv[e & 3], shv[e & 3]);
+    t = gn_silu(t);
+    asm volatile("" : "+v"(t));   // the ROUNDED product is what gets split: no contraction of (x * r) - hi into one fma
+    r[e >> 2][e & 3] = __float_as_uint(t);
+  };
+  auto store_slab_f = [&](u32x4 (&r)[2], int buf, int k, int chunk) {
+    u32x4 hi4, lo4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x2 hi, lo;
+      split4(r[h], hi, lo);
+      hi4[2 * h] = hi[0]; hi4[2 * h + 1] = hi[1];
+      lo4[2 * h] = lo[0]; lo4[2 * h + 1] = lo[1];
+    }
+    if ((chunk < nchunks ? slab_off[k] : slab_off_n[k]) == oobA) { hi4 = u32x4{0u, 0u, 0u, 0u}; lo4 = hi4; }
+    unsigned char* dst = smem + (buf ? P_BUF1 : 0) + slab_piece[k] * 1024 + lane * 16;
+    *(u32x4*)dst = hi4;
+    *(u32x4*)(dst + PLANE) = lo4;
+  };
+  // scale / shift of image `img` into table `dst`: 2 * Cin / 64 pieces of 64 floats, one LDS-DMA per wave (the pieces repeat over the waves)
+  auto issue_gss = [&](float* dst, int img) {
+    const int npc = Cin >> 6, piece = wave % (2 * npc), isshift = piece >= npc ? 1 : 0, pc = piece - isshift * npc;
+    const int batch = p.M / (H * W);
+    const rsrc_t rs = make_rsrc(isshift ? p.gsh : p.gsc, (unsigned)((long)batch * Cin * 4));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + isshift * Cin + pc * 64), 4, (int)((unsigned)((long)img * Cin + pc * 64 + lane) * 4u), 0, 0, 0);
   };
 
   unsigned baseA[4][2], addrB;
@@ -824,21 +879,40 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
     acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.al[i_], acc[i_][j_], 0, 0, 0);                            \
     acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[j_], F.ah[i_], acc[i_][j_], 0, 0, 0);                            \
   }
+  // GN: thirds issued at (tap 0, slot 0) and (taps 2 / 4, slot 12), transformed in taps 2 / 4 / 6 - the slots of conv_slab_kernel<true>;
+  // the next tile's scale / shift table at (tap 3, slot 5) of a tile's first chunk pair (landed and barrier-published long before
+  // tap 11 first reads it)
 #define SLAB_ISSUE(T, Q)                                                                          \
-  if constexpr ((Q) == 0 && ((T) % 9) < 3) issue_slab(1 - (T) / 9, (T) % 9, chunk0 + (T) / 9 + 1);  \
+  if constexpr (!GN && (Q) == 0 && ((T) % 9) < 3) issue_slab(1 - (T) / 9, (T) % 9, chunk0 + (T) / 9 + 1);  \
+  if constexpr (GN && (Q) == 0 && ((T) % 9) == 0) issue_slab_f(xr, 0, chunk0 + (T) / 9 + 1);           \
+  if constexpr (GN && (Q) == 12 && (((T) % 9) == 2 || ((T) % 9) == 4)) issue_slab_f(xr, ((T) % 9) / 2, chunk0 + (T) / 9 + 1);  \
+  if constexpr (GN && (T) == 3 && (Q) == 5) { if (first) issue_gss(gss_nxt, gn.img); }               \
   if constexpr ((Q) == 2) issue_b(p_stage_off(((T) + 3) % 3), chunk0 + ((T) + 3) / 9, ((T) + 3) % 9);
+#define SLAB_XF(T, Q)                                                                             \
+  if constexpr (GN && ((T) % 9) >= 2 && ((T) % 9) <= 6 && ((T) % 9) % 2 == 0) {                    \
+    constexpr int k_ = ((T) % 9) / 2 - 1;                                                         \
+    if constexpr ((Q) == 1) load_gss(chunk0 + (T) / 9 + 1, 0);                                    \
+    if constexpr ((Q) >= 2 && (Q) < 6) xform_elem(xr, (Q) - 2);                                   \
+    if constexpr ((Q) == 6) load_gss(chunk0 + (T) / 9 + 1, 1);                                    \
+    if constexpr ((Q) >= 7 && (Q) < 11) xform_elem(xr, (Q) - 3);                                  \
+    if constexpr ((Q) == 11) store_slab_f(xr, 1 - (T) / 9, k_, chunk0 + (T) / 9 + 1);             \
+  }
 #define SLAB_SLOT(CUR, NXT, T, Q)                                                   \
   SLAB_PAIR(CUR, Q)                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                \
   SLAB_ISSUE(T, Q)                                                                  \
   SLAB_READ(NXT, (((T) + 1) % 3), (((T) + 1) % 9), Q)                               \
+  SLAB_XF(T, Q)                                                                     \
   __builtin_amdgcn_sched_barrier(0);
+  // counted waits as in the launch-per-tile kernels (GN: two more at the top of taps 1, 3, 4, 5, 6 of a chunk); the extra scale /
+  // shift DMA of a tile's first pass makes the waits of its taps 4 and 5 merely stricter
 #define SLAB_WAIT(T)                                                                                                        \
   if constexpr ((T) < 2) {                                                                                                  \
     if (first) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
     else if constexpr ((T) == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                               \
     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                                                        \
-  } else if constexpr (((T) % 9) >= 1 && ((T) % 9) <= 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");        \
+  } else if constexpr (GN ? (((T) % 9) == 1 || (((T) % 9) >= 3 && ((T) % 9) <= 6)) : (((T) % 9) >= 1 && ((T) % 9) <= 3))   \
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                                             \
   else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
 #define SLAB_TAP(CUR, NXT, T)                                                                         \
   SLAB_WAIT(T)                                                                                        \
@@ -854,17 +928,32 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
   // ---- first tile: its operands as the "next tile" of an empty predecessor ----
   int v = blockIdx.x;
   Geo g = geo_of(v);
-  offsets_of(g, true, slab_off_n, voffB_n);
-  {
+  offsets_of(g, true, slab_off_n, voffB_n, lane);
+  if constexpr (GN) {
+    // chunk 0 of the first tile through the register path, its image's table by plain loads
+    for (int c = threadIdx.x; c < Cin; c += NT) { gss_nxt[c] = p.gsc[(long)g.img * Cin + c]; gss_nxt[Cin + c] = p.gsh[(long)g.img * Cin + c]; }
+    u32x4 pr[3][2];
+    issue_slab_f(pr[0], 0, nchunks); issue_slab_f(pr[1], 1, nchunks); issue_slab_f(pr[2], 2, nchunks);
+    issue_b(p_stage_off(0), nchunks, 0); issue_b(p_stage_off(1), nchunks, 1); issue_b(p_stage_off(2), nchunks, 2);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      load_gss(nchunks, h);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xform_elem(pr[k], h * 4 + e);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) store_slab_f(pr[k], 0, k, nchunks);
+  } else {
     issue_slab(0, 0, nchunks); issue_slab(0, 1, nchunks); issue_slab(0, 2, nchunks);
     issue_b(p_stage_off(0), nchunks, 0); issue_b(p_stage_off(1), nchunks, 1); issue_b(p_stage_off(2), nchunks, 2);
   }
   // (Measured and rejected: starting the blocks in eight phases an eighth of a tile apart, to keep 256 CUs from writing their
   //  32 MB of output at the same instant.  scripts/exp/conv_seam.py: T(Cin) = 13-15 us + 8.1 us per 32-channel chunk per tile
-  //  with or without the stagger, launch-per-tile or persistent - the ~13 us is not a chip-wide burst but the CU's own
-  //  vector-memory path moving 128 KiB of output (+ 128 KiB of residual) at ~14 B/clk; only stores issued INSIDE the next
-  //  tile's K loop would hide it, and a second 128 KiB staging area or accumulator set does not fit next to this pipeline.)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  //  with or without the stagger, launch-per-tile or persistent.)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   SLAB_READ(f0, 0, 0, 0) SLAB_READ(f0, 0, 0, 1) SLAB_READ(f0, 0, 0, 2) SLAB_READ(f0, 0, 0, 3)
@@ -878,10 +967,15 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) slab_off[k] = slab_off_n[k];
     voffB[0] = voffB_n[0]; voffB[1] = voffB_n[1];
+    if constexpr (GN) { float* t = gss_cur; gss_cur = gss_nxt; gss_nxt = t; }
     const int vn = v + nblocks;
     const bool has_next = vn < ntiles;
     const Geo gn = geo_of(has_next ? vn : v);
-    offsets_of(gn, has_next, slab_off_n, voffB_n);
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      offsets_of(gn, has_next, slab_off_n, voffB_n, ln);
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -902,7 +996,10 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
     //      the store loop, and a spill reload is a `vmcnt(0)` behind every store.  They are re-read after the epilogue.) ----
     const int n0 = g.n0;
     constexpr int NITH = (P_HALF_ROWS * 32) / NT;   // 8 chunks of 16 bytes per thread and pass
-    const int col = (threadIdx.x & 31) * 4, n = n0 + col, rbase = threadIdx.x >> 5;
+    int tx = threadIdx.x;
+    asm volatile("" : "+v"(tx));                    // (the epilogue's per-thread geometry is not to be hoisted over the K loop)
+    const int lane_e = tx & 63;
+    const int col = (tx & 31) * 4, n = n0 + col, rbase = tx >> 5;
     // output / residual through buffer descriptors: one 32-bit offset register per thread, the patch row as a scalar offset
     const long pixp = ((long)g.img * H + g.y0) * W + g.x0;   // first pixel of the patch
     const unsigned obase = (unsigned)(((pixp + rbase) * p.N + n) * 4);
@@ -910,35 +1007,43 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // look-ahead DMAs and the tap-17 fragment reads
     __builtin_amdgcn_sched_barrier(0);
     CDMA_TSV(v, 2)
-    // residual: added to the accumulators in FRAGMENT layout (lane = pixel lane & 15 of patch row wm * 4 + i, four channels),
-    // one patch row ahead, so that every global load of the epilogue retires before its first store: a load waited for behind
-    // a store is a wait for that store's acknowledgement (reads and writes share vmcnt)
-    if (p.residual) {
-      const int nf = n0 + wn * 64 + 4 * (lane >> 4);
-      const unsigned fbase = (unsigned)((((pixp + (long)(wm * 4) * W + (lane & 15)) * p.N) + nf) * 4);
-      u32x4 rr[2][NI];
+    // bias and residual are added to the accumulators in FRAGMENT layout (lane = pixel lane & 15 of patch row wm * 4 + i, four
+    // channels), in the launch-per-tile kernels' order - (products + bias) + residual: same bits -, the residual one patch row ahead,
+    // so that every global load of the epilogue retires before its first store: a load waited for behind a store is a wait for
+    // that store's acknowledgement (reads and writes share vmcnt)
+    {
+      const int nf = n0 + wn * 64 + 4 * (lane_e >> 4);
+      f32x4 bj[NI];
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        rr[0][j] = (nf + j * 16) < p.N ? __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(fbase + j * 64), 0, 0) : u32x4{0u, 0u, 0u, 0u};
+        bj[j] = (p.bias && (nf + j * 16) < p.N) ? *(const f32x4*)(p.bias + nf + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.residual) {
+        const unsigned fbase = (unsigned)((((pixp + (long)(wm * 4) * W + (lane_e & 15)) * p.N) + nf) * 4);
+        u32x4 rr[2][NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if (i + 1 < MI) {
+        for (int j = 0; j < NI; ++j)
+          rr[0][j] = (nf + j * 16) < p.N ? __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(fbase + j * 64), 0, 0) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int j = 0; j < NI; ++j)
-            rr[(i + 1) & 1][j] = (nf + j * 16) < p.N ? __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(fbase + j * 64), (int)(rowstep * (i + 1)), 0)
-                                                     : u32x4{0u, 0u, 0u, 0u};
+        for (int i = 0; i < MI; ++i) {
+          if (i + 1 < MI) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              rr[(i + 1) & 1][j] = (nf + j * 16) < p.N ? __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(fbase + j * 64), (int)(rowstep * (i + 1)), 0)
+                                                       : u32x4{0u, 0u, 0u, 0u};
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = (acc[i][j] + bj[j]) + __builtin_bit_cast(f32x4, rr[i & 1][j]);
         }
+      } else {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] += __builtin_bit_cast(f32x4, rr[i & 1][j]);
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] += bj[j];
       }
     }
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n < p.N) bias4 = *(const f32x4*)(p.bias + n);
-    // nothing but loads in the queue: a cheap drain.  Written as the builtin plus a visible use of the last loaded value so
-    // that hipcc's own wait-count bookkeeping sees the drain here, in straight-line code - an inline-asm wait is invisible to
-    // it, and it would re-insert `vmcnt(0)` at the first use of bias4 inside each (exec-masked) store pass, i.e. behind the stores
+    // nothing but loads in the queue: a cheap drain.  The builtin (not inline asm) so that hipcc's own wait-count bookkeeping sees the
+    // drain here, in straight-line code, and inserts no `vmcnt(0)` of its own behind the stores below
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
-    asm volatile("" ::"v"(bias4));
     __builtin_amdgcn_sched_barrier(0);
     CDMA_TSV(v, 3)
     double gs = 0.0, gq = 0.0;
@@ -948,10 +1053,10 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
       if ((wm >> 1) == half) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          const int lr = (wm & 1) * 64 + i * 16 + (lane & 15);
+          const int lr = (wm & 1) * 64 + i * 16 + (lane_e & 15);
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            const int nl = wn * 64 + j * 16 + 4 * (lane >> 4);
+            const int nl = wn * 64 + j * 16 + 4 * (lane_e >> 4);
             *(f32x4*)(smem + P_STAGING + lr * CST + nl * 4) = acc[i][j];
           }
         }
@@ -960,8 +1065,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
       if (n < p.N) {
 #pragma unroll
         for (int it = 0; it < NITH; ++it) {
-          // (products + residual) + bias; the launch-per-tile kernels add (products + bias) + residual - same f32 class
-          const f32x4 w = *(const f32x4*)(smem + P_STAGING + (rbase + 16 * it) * CST + col * 4) + bias4;
+          const f32x4 w = *(const f32x4*)(smem + P_STAGING + (rbase + 16 * it) * CST + col * 4);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), rs_out, (int)obase, (int)(rowstep * (half * NITH + it)), 0);
           if (p.gn_partial) {
 #pragma unroll
@@ -976,17 +1080,17 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
       gq += __shfl_xor(gq, 32, 64);
       lds_barrier();
       double* red = (double*)(smem + P_STAGING);   // [8 waves][32 chunks][2]
-      if (lane < 32) { red[(wave * 32 + lane) * 2] = gs; red[(wave * 32 + lane) * 2 + 1] = gq; }
+      if (lane_e < 32) { red[(wave * 32 + lane_e) * 2] = gs; red[(wave * 32 + lane_e) * 2 + 1] = gq; }
       lds_barrier();
-      if (threadIdx.x < 32) {
+      if (tx < 32) {
         double cs = 0.0, cq = 0.0;
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) { cs += red[(w8 * 32 + threadIdx.x) * 2]; cq += red[(w8 * 32 + threadIdx.x) * 2 + 1]; }
+        for (int w8 = 0; w8 < 8; ++w8) { cs += red[(w8 * 32 + tx) * 2]; cq += red[(w8 * 32 + tx) * 2 + 1]; }
         const int cpc = p.gn_cpg >> 2;
         for (int o = 1; o < cpc; o <<= 1) { cs += __shfl_xor(cs, o, 64); cq += __shfl_xor(cq, o, 64); }
-        const int nn = n0 + (int)threadIdx.x * 4;
-        if ((threadIdx.x & (cpc - 1)) == 0 && nn < p.N) {
-          double* o2 = p.gn_partial + (((long)g.img * tpi + g.prem) * p.gn_groups + nn / p.gn_cpg) * 2;
+        const int nn = n0 + tx * 4;
+        if ((tx & (cpc - 1)) == 0 && nn < p.N) {
+          double* o2 = p.gn_partial + (((long)g.img * tpi + g.prem) * p.gn_groups + (nn >> __builtin_ctz(p.gn_cpg))) * 2;   // gn_cpg is a power of two (host check)
           o2[0] = cs; o2[1] = cq;
         }
       }
@@ -1006,6 +1110,7 @@ __global__ __launch_bounds__(512, 2) void conv_slab_persist_kernel(Params p) {
 #undef SLAB_TAP
 #undef SLAB_WAIT
 #undef SLAB_SLOT
+#undef SLAB_XF
 #undef SLAB_ISSUE
 #undef SLAB_PAIR
 #undef SLAB_READ
@@ -1057,9 +1162,9 @@ extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, con
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MUSE_ERR_UNSUPPORTED;
         ncu = prop.multiProcessorCount;
-        (void)hipFuncSetAttribute((const void*)cslab::conv_slab_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cslab::P_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)cslab::conv_slab_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cslab::P_LDS_BYTES);
       }
-      hipLaunchKernelGGL(cslab::conv_slab_persist_kernel, dim3(nslab < ncu ? nslab : ncu), dim3(512), cslab::P_LDS_BYTES, (hipStream_t)stream, p);
+      hipLaunchKernelGGL(cslab::conv_slab_persist_kernel<false>, dim3(nslab < ncu ? nslab : ncu), dim3(512), cslab::P_LDS_BYTES, (hipStream_t)stream, p);
       return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(cslab::conv_slab_kernel<false>, dim3(nslab), dim3(512), cslab::LDS_BYTES, (hipStream_t)stream, p);
@@ -1096,6 +1201,30 @@ extern "C" int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale,
   }
   p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.H = H; p.W = W; p.Cin = Cin;
   const int ntn = (p.N + cslab::BN - 1) / cslab::BN;
+  // persistent form (round 6): one workgroup per CU walks the tiles, the K loop's look-ahead runs on into the next tile.  Taken when a
+  // CU gets at least MUSE_CONV_PERSIST_MIN tiles (default 2), Cin <= 256 (two scale / shift tables behind the LDS map) and the output
+  // stays below 4 GiB (32-bit store offsets).  MUSE_CONV_PERSIST=0 keeps the launch-per-tile kernel; MUSE_CONV_PERSIST_GRID sets the
+  // number of workgroups (default: one per CU).
+  static const int persist = []() { const char* e = getenv("MUSE_CONV_PERSIST"); return e ? atoi(e) : 0; }();
+  if (persist && Cin <= cslab::P_GSS_MAX_CIN && (long)p.M * p.N * 4 < (1L << 32) - 64) {
+    static int ncu = 0, grid = 0, min_tiles = 2;
+    if (!ncu) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MUSE_ERR_UNSUPPORTED;
+      (void)hipFuncSetAttribute((const void*)cslab::conv_slab_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cslab::P_LDS_BYTES_GN);
+      const char* e = getenv("MUSE_CONV_PERSIST_GRID");
+      grid = e ? atoi(e) : prop.multiProcessorCount;
+      if (grid < 1) grid = 1;
+      const char* m = getenv("MUSE_CONV_PERSIST_MIN");
+      if (m) min_tiles = atoi(m);
+      ncu = prop.multiProcessorCount;
+    }
+    const int nslab = (p.M >> 8) * ntn;
+    if (nslab >= min_tiles * grid) {
+      hipLaunchKernelGGL(cslab::conv_slab_persist_kernel<true>, dim3(nslab < grid ? nslab : grid), dim3(512), cslab::P_LDS_BYTES_GN, (hipStream_t)stream, p);
+      return (int)hipGetLastError();
+    }
+  }
   constexpr int lds = cslab::LDS_BYTES + 2 * 2048 * 4;
   static bool attr = false;
   if (!attr) {

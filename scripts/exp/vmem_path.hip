@@ -1,0 +1,93 @@
+// What one CU's vector-memory path sustains, alone and with every other CU doing the same (round 6; the ceiling table's inputs).
+//   stores : every wave of a 512-thread block stores 128 KiB tiles from registers (16 B per lane, 512-byte rows) to its own region
+//   dma    : every wave pulls 1 KiB pieces of an L2-resident region into LDS (buffer_load_dwordx4 ... lds), 64 KiB per round
+//   loads  : the same bytes through registers (buffer_load_dwordx4), HBM-resident (each block its own region) or L2-resident
+// For G = 1, 8, 32, 64, 128, 256 blocks (one per CU): bytes per shader cycle per CU from s_memtime stamps around the timed loop, and
+// the wall-clock aggregate.   hipcc --offload-arch=gfx950 -O3 scripts/exp/vmem_path.hip -o /tmp/vmem_path && /tmp/vmem_path
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// mode 0: stores, mode 1: LDS-DMA loads, mode 2: register loads.  `region` bytes per block (stride between blocks: `stride`).
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k(unsigned char* base, long stride, unsigned region, int rounds, long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned char* mine = base + (long)blockIdx.x * stride;
+  const rsrc_t rs = make_rsrc(mine, region);
+  // a round = 64 KiB per block = 8 KiB per wave = 8 wave-instructions of 1 KiB
+  u32x4 v = {(unsigned)threadIdx.x, 1u, 2u, 3u};
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  __syncthreads();
+  const long t0 = (long)__builtin_amdgcn_s_memtime();
+  unsigned off = (unsigned)(wave * 8192 + lane * 16);
+  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned o = off + i * 1024;
+      if constexpr (MODE == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)o, 0, 0);
+      if constexpr (MODE == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + wave * 8192 + i * 1024), 16, (int)o, 0, 0, 0);
+      if constexpr (MODE == 2) { const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, 0); acc ^= x; }
+    }
+    off += 65536;
+    if (off >= region) off -= region;
+    if constexpr (MODE == 1) { if ((r & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const long t1 = (long)__builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { stamps[blockIdx.x * 2] = t0; stamps[blockIdx.x * 2 + 1] = t1; }
+  if (MODE == 2 && acc[0] == 0x12345678u) stamps[0] = acc[1];
+}
+
+template <int MODE> void run(const char* name, unsigned char* buf, long stride, unsigned region, int rounds, long* d_st) {
+  const int gs[] = {1, 8, 32, 64, 128, 256};
+  for (int g : gs) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+      CHECK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k<MODE>, dim3(g), dim3(512), 65536, 0, buf, stride, region, rounds, d_st);
+      CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+    }
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<long> st(2 * g); CHECK(hipMemcpy(st.data(), d_st, sizeof(long) * 2 * g, hipMemcpyDeviceToHost));
+    std::vector<double> bpc(g);
+    for (int b = 0; b < g; ++b) bpc[b] = (double)rounds * 65536.0 / (double)(st[2 * b + 1] - st[2 * b]);
+    std::sort(bpc.begin(), bpc.end());
+    const double bytes = (double)g * rounds * 65536.0;
+    printf("%-34s G %3d   B/tick/CU median %6.2f  min %6.2f  max %6.2f   wall %8.1f us   aggregate %7.3f TB/s  (%.1f MB)\n", name, g, bpc[g / 2], bpc[0],
+           bpc[g - 1], ms * 1e3, bytes / (ms * 1e-3) * 1e-12, bytes * 1e-6);
+  }
+}
+
+int main() {
+  const long big = 64L << 20;                 // 64 MiB per block: HBM-resident streams
+  unsigned char* buf; CHECK(hipMalloc(&buf, 256 * big));
+  CHECK(hipMemset(buf, 1, 256 * big));
+  long* d_st; CHECK(hipMalloc(&d_st, sizeof(long) * 512));
+  CHECK(hipFuncSetAttribute((const void*)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CHECK(hipFuncSetAttribute((const void*)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CHECK(hipFuncSetAttribute((const void*)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  // s_memtime rate: a known wall time
+  run<0>("stores, own 32 MiB stream", buf, big, 32u << 20, 512, d_st);
+  run<0>("stores, own 128 KiB re-written", buf, big, 128u << 10, 512, d_st);
+  run<1>("LDS-DMA, own 32 MiB stream (HBM)", buf, big, 32u << 20, 512, d_st);
+  run<1>("LDS-DMA, shared 1 MiB (L2)", buf, 0, 1u << 20, 512, d_st);
+  run<1>("LDS-DMA, own 256 KiB (L2)", buf, big, 256u << 10, 512, d_st);
+  run<2>("register loads, own 32 MiB (HBM)", buf, big, 32u << 20, 512, d_st);
+  run<2>("register loads, shared 1 MiB (L2)", buf, 0, 1u << 20, 512, d_st);
+  return 0;
+}
