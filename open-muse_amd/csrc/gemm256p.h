@@ -313,6 +313,7 @@ struct PipeP {
     w = u32x4{x0, x1, y0, y1};
   }
   __device__ __forceinline__ void store16(const u32x4& w, unsigned vo, unsigned soff) {
+    if (staux == 6) { asm volatile("" ::"v"(w), "v"(vo)); return; }   // ablation (round 6): the whole register epilogue, minus the store instructions
     if (staux == 2) __builtin_amdgcn_raw_buffer_store_b128(w, rsC, (int)vo, (int)soff, 2);
     else __builtin_amdgcn_raw_buffer_store_b128(w, rsC, (int)vo, (int)soff, 0);
   }

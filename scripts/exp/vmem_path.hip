@@ -53,6 +53,73 @@ __global__ __launch_bounds__(512, 2) void k(unsigned char* base, long stride, un
   if (MODE == 2 && acc[0] == 0x12345678u) stamps[0] = acc[1];
 }
 
+// mode 3 / 4: the persistent GEMM's mix - 12 rounds of LDS-DMA (64 KiB per round from an L2-resident region: one K-tile) then the tile's C
+// stores, 16 per wave (128 KiB per workgroup) to the workgroup's own HBM stream; STRIDED = the stores of an instruction go to 8 rows of
+// 128 bytes a row pitch apart (the register epilogue's whole-line form) instead of 1 KiB contiguous.  `with_stores` = 0 gives the same
+// loop without them: the difference is what the stores cost.
+template <int STRIDED>
+__global__ __launch_bounds__(512, 2) void kmix(unsigned char* l2buf, unsigned region, unsigned char* cbase, long cstride, unsigned cregion, int tiles,
+                                               int with_stores, unsigned pitch, int pace, int slack, long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const rsrc_t rs = make_rsrc(l2buf, region);
+  const rsrc_t rc = make_rsrc(cbase + (long)blockIdx.x * cstride, cregion);
+  u32x4 v = {(unsigned)threadIdx.x, 1u, 2u, 3u};
+  __syncthreads();
+  const long t0 = (long)__builtin_amdgcn_s_memtime();
+  unsigned off = (unsigned)(wave * 8192 + lane * 16), coff = 0;
+  for (int t = 0; t < tiles; ++t) {
+    for (int r = 0; r < 12; ++r) {
+      const long tr = (long)__builtin_amdgcn_s_memtime();
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + wave * 8192 + i * 1024), 16, (int)(off + i * 1024), 0, 0, 0);
+      off += 65536;
+      if (off >= region) off -= region;
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (pace) {   // the GEMM's K-tile time: the next round is issued `pace` ticks after this one
+        while ((long)__builtin_amdgcn_s_memtime() - tr < pace) __builtin_amdgcn_s_sleep(2);   // (a round that took longer than `pace` is not caught up)
+      }
+    }
+    if (with_stores) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        unsigned o;
+        if (STRIDED) o = coff + (unsigned)(wave * 16 + i) * 8u * pitch + (unsigned)(lane >> 3) * pitch + (unsigned)(lane & 7) * 16u;   // 8 rows x 128 B
+        else o = coff + (unsigned)((wave * 16 + i) * 1024 + lane * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rc, (int)o, 0, 0);
+      }
+      coff += STRIDED ? 128u : 131072u;
+      if (coff + (STRIDED ? 1024u * pitch : 131072u) > cregion) coff = 0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const long t1 = (long)__builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { stamps[blockIdx.x * 2] = t0; stamps[blockIdx.x * 2 + 1] = t1; }
+}
+
+template <int STRIDED> void run_mix(const char* name, unsigned char* buf, long big, long* d_st, int pace) {
+  const int gs[] = {8, 32, 64, 256};
+  const int tiles = 24;
+  for (int g : gs) {
+    double med[2];
+    for (int ws = 0; ws < 2; ++ws) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(kmix<STRIDED>, dim3(g), dim3(512), 65536, 0, buf, 1u << 20, buf + (2L << 20), big, 32u << 20, tiles, ws, 12288u, pace, 0, d_st);
+        CHECK(hipDeviceSynchronize());
+      }
+      std::vector<long> st(2 * g); CHECK(hipMemcpy(st.data(), d_st, sizeof(long) * 2 * g, hipMemcpyDeviceToHost));
+      std::vector<double> tk(g);
+      for (int b = 0; b < g; ++b) tk[b] = (double)(st[2 * b + 1] - st[2 * b]) / tiles;
+      std::sort(tk.begin(), tk.end());
+      med[ws] = tk[g / 2];
+    }
+    printf("%-44s G %3d   ticks per tile (12 x 64 KiB DMA): %8.0f without stores, %8.0f with 128 x 1 KiB stores -> %6.1f ticks per store instruction\n",
+           name, g, med[0], med[1], (med[1] - med[0]) / 128.0);
+  }
+}
+
 template <int MODE> void run(const char* name, unsigned char* buf, long stride, unsigned region, int rounds, long* d_st) {
   const int gs[] = {1, 8, 32, 64, 128, 256};
   for (int g : gs) {
@@ -89,5 +156,11 @@ int main() {
   run<1>("LDS-DMA, own 256 KiB (L2)", buf, big, 256u << 10, 512, d_st);
   run<2>("register loads, own 32 MiB (HBM)", buf, big, 32u << 20, 512, d_st);
   run<2>("register loads, shared 1 MiB (L2)", buf, 0, 1u << 20, 512, d_st);
+  CHECK(hipFuncSetAttribute((const void*)kmix<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CHECK(hipFuncSetAttribute((const void*)kmix<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  run_mix<0>("DMA flat out + C stores 1 KiB contiguous", buf, big, d_st, 0);
+  run_mix<1>("DMA flat out + C stores 8 rows x 128 B", buf, big, d_st, 0);
+  run_mix<0>("DMA paced 2500/K-tile + stores contiguous", buf, big, d_st, 2500);
+  run_mix<1>("DMA paced 2500/K-tile + stores 8 x 128 B", buf, big, d_st, 2500);
   return 0;
 }
