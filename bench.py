@@ -348,7 +348,8 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False):
            "precision_vs_yaml": "wider" if f32 else ("class-equal" if x3 else "narrower"),
            "tflops": round(tf, 1), "mfma_frac": round(tf / (PEAK["bf16"] / 3 if x3 else PEAK["f32" if f32 else "bf16"]), 4), "loss": round(float(loss), 4), "parameters": n_params,
            "dtype": ("bf16x3: f32 tensors, every product (linears, dX, dW: muse_gemm_x3 on four operand planes; the attention core: "
-                     + ("muse_attention_x3_*" if seq == 256 else "materialised in EXACT f32 at this sequence length - scores, softmax, P v on the f32-input MFMA kernel")
+                     + ("muse_attention_x3_*" if seq == 256 else "muse_attention_x3_* block by block - 256 query rows against 256-key blocks (or the 77 text states), "
+                                                               "key blocks merged by their log-sum-exps in f32 (ops.attention_x3_blocked)")
                      + ") as three bf16 MFMA products of hi / lo operand planes with f32 accumulation (<= 2^-16 relative per "
                      "product: at or above the yaml's mixed_precision: no + enable_tf32, 10-bit mantissa products); f32 softmax, norms, GLU, "
                      "residual stream, loss, AdamW; mfma_frac against the 833 TFLOP/s roof of that scheme (2500 / 3)") if x3 else ("exact f32 everywhere (f32-input MFMA, 157 TFLOP/s peak): at or above the precision of the yaml's mixed_precision: no + "
@@ -813,7 +814,8 @@ def main():
         extra["config4_uvit_seq256_bf16x3"] = uvit_leg_isolated(device, 64, 256, 2, x3=True)             # the yaml's 64 per GPU
         extra["config4_uvit_seq256_bf16x3_b128"] = uvit_leg_isolated(device, 128, 256, 2, x3=True)       # ... and a batch that uses the HBM
         # ... and BASELINE.json's sequence length in that precision class (round 6): every weight GEMM as bf16x3 products; the attention core
-        # of a 1024-token sequence is outside attention3.hip's one-tile shapes and runs materialised in exact f32 (wider than the yaml)
+        # of a 1024-token sequence runs attention3.hip's one-tile kernels block by block (52.3 images/s with the materialised exact-f32 core it
+        # replaced, 81.5 with the blocks: profiles/r06_c4_seq1024_x3*.txt)
         extra["config4_uvit_seq1024_bf16x3"] = uvit_leg_isolated(device, 32, 1024, 2, x3=True)
         # the reference's PUBLISHED metric (its only published numbers): text-to-image pipeline latency, 12 steps, 256 x 256
         extra["inference_latency"] = leg_isolated("latency", lambda: latency_leg(device))

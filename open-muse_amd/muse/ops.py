@@ -857,9 +857,90 @@ def attention_bwd_ex(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None
     return dq, dk, dv
 
 
+def _x3_one_tile_keys(Skv):
+    return 224 < Skv <= 256 or 64 < Skv <= 96
+
+
+def attention_x3_blocked(Sq, Skv):
+    """longer sequences (round 6: BASELINE config 4's 1024 tokens) run attention3.hip's one-tile kernels block by block: q rows in
+    blocks of 256, keys in blocks of 256 (or one block of <= 96 text states), the key blocks' partial results merged by their log-sum-exps"""
+    return Sq > 256 or Skv > 256
+
+
 def attention_x3_supported(Sq, Skv, hd):
-    """shapes of the fused bf16x3 attention (csrc/attention3.hip): config 4's 16 x 16 grid against itself or its 77 text states"""
-    return hd == 64 and Sq == 256 and (224 < Skv <= 256 or 64 < Skv <= 96)
+    """shapes of the fused bf16x3 attention (csrc/attention3.hip): config 4's 16 x 16 grid against itself or its 77 text states in one tile
+    per head, and whole multiples of 256 query rows / 256 keys block by block (attention_x3_blocked)"""
+    return hd == 64 and Sq >= 256 and Sq % 256 == 0 and (_x3_one_tile_keys(Skv) or (Skv >= 256 and Skv % 256 == 0))
+
+
+def _x3_block_desc(q, k, v, o, B, Sq, Skv, nh, hd, alpha, qi, kj, kb):
+    """descriptor of query block qi (256 rows) against key block kj (kb keys) of every image: full-sequence batch strides, block pointers"""
+    d = _attn_desc(q, k, v, o, B, Sq, Skv, nh, hd, alpha)
+    d.q += qi * 256 * d.ldq * 4
+    d.o += qi * 256 * d.ldo * 4
+    d.k += kj * 256 * d.ldk * 4
+    d.v += kj * 256 * d.ldv * 4
+    d.seq_q, d.seq_kv = 256, kb
+    return d
+
+
+def _attention_x3_fwd_blocks(q, k, v, B, Sq, Skv, nh, hd, alpha):
+    """-> (ctx [B*Sq, H] f32, lse [Sq // 256, B*nh, 256] f32).  softmax over all keys = the key blocks' softmaxes re-weighted by
+    exp(lse_block - lse): exact in exact arithmetic, f32 here (the products inside each block are the kernels' bf16x3 ones)."""
+    H = nh * hd
+    nq = Sq // 256
+    nk, kb = (Skv // 256, 256) if Skv > 256 else (1, Skv)
+    dev = q.device
+    ctx = torch.empty((B * Sq, H), dtype=torch.float32, device=dev)
+    lse = torch.empty((nq, B * nh, 256), dtype=torch.float32, device=dev)
+    e0 = _prof_begin()
+    if nk == 1:
+        for qi in range(nq):
+            d = _x3_block_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha, qi, 0, kb)
+            check(lib().muse_attention_x3_fwd(C.byref(d), lse[qi].data_ptr(), None, 0, stream()), "muse_attention_x3_fwd")
+    else:
+        part = torch.empty((nk, B * Sq, H), dtype=torch.float32, device=dev)
+        lp = torch.empty((nk, nq, B * nh, 256), dtype=torch.float32, device=dev)
+        for kj in range(nk):
+            for qi in range(nq):
+                d = _x3_block_desc(q, k, v, part[kj], B, Sq, Skv, nh, hd, alpha, qi, kj, kb)
+                check(lib().muse_attention_x3_fwd(C.byref(d), lp[kj, qi].data_ptr(), None, 0, stream()), "muse_attention_x3_fwd")
+        torch.logsumexp(lp, dim=0, out=lse)
+        w = torch.exp(lp - lse)                                                       # [nk, nq, B*nh, 256]
+        # weights per (key block, image, row, head) against part [nk, B, Sq, nh, hd]
+        w = w.view(nk, nq, B, nh, 256).permute(0, 2, 1, 4, 3).reshape(nk, B, Sq, nh, 1)
+        torch.sum(part.view(nk, B, Sq, nh, hd) * w, dim=0, out=ctx.view(B, Sq, nh, hd))
+    _prof_end(e0, "attn_fwd_bf16x3", 4.0 * B * nh * Sq * Skv * hd)
+    return ctx, lse
+
+
+def _attention_x3_bwd_blocks(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq, dk, dv):
+    """block-pair backward: every (query block, key block) pair with the query block's GLOBAL log-sum-exp and the final context (so the
+    probabilities and the row sums dO.O are the full-sequence ones); dq summed over key blocks, dk / dv over query blocks"""
+    H = nh * hd
+    nq = Sq // 256
+    nk, kb = (Skv // 256, 256) if Skv > 256 else (1, Skv)
+    dev = q.device
+    pdo, lddo = _row_view(dctx, H)
+    dqp = [dq] + [torch.empty((B * Sq, H), dtype=torch.float32, device=dev) for _ in range(nk - 1)]       # dq partial of key block kj
+    dkp = [dk] + [torch.empty((B * Skv, H), dtype=torch.float32, device=dev) for _ in range(nq - 1)]      # dk / dv partial of query block qi
+    dvp = [dv] + [torch.empty((B * Skv, H), dtype=torch.float32, device=dev) for _ in range(nq - 1)]
+    e0 = _prof_begin()
+    for qi in range(nq):
+        for kj in range(nk):
+            d = _x3_block_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha, qi, kj, kb)
+            (pq, ldq_), (pk, ldk_), (pv, ldv_) = _row_view(dqp[kj], H), _row_view(dkp[qi], H), _row_view(dvp[qi], H)
+            check(lib().muse_attention_x3_bwd(C.byref(d), pdo + qi * 256 * lddo * 4, lddo, Sq * lddo, lse[qi].data_ptr(),
+                                              pq + qi * 256 * ldq_ * 4, ldq_, Sq * ldq_, pk + kj * 256 * ldk_ * 4, ldk_, Skv * ldk_,
+                                              pv + kj * 256 * ldv_ * 4, ldv_, Skv * ldv_, None, 0, None, 0, None, 0, stream()), "muse_attention_x3_bwd")
+    for t in dqp[1:]:
+        dq.add_(t)
+    for t in dkp[1:]:
+        dk.add_(t)
+    for t in dvp[1:]:
+        dv.add_(t)
+    _prof_end(e0, "attn_bwd_bf16x3", 10.0 * B * nh * Sq * Skv * hd)
+    return dq, dk, dv
 
 
 def attention_x3_fwd(q, k, v, B, Sq, Skv, nh, hd, alpha):
@@ -868,6 +949,10 @@ def attention_x3_fwd(q, k, v, B, Sq, Skv, nh, hd, alpha):
     require_gpu(q, k, v)
     if q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32:
         raise _hip.MuseHipError("attention_x3: f32 operands")
+    if not attention_x3_supported(Sq, Skv, hd):
+        raise _hip.MuseHipError(f"attention_x3: shape ({Sq} x {Skv}, head_dim {hd}) outside attention_x3_supported")
+    if attention_x3_blocked(Sq, Skv):
+        return _attention_x3_fwd_blocks(q, k, v, B, Sq, Skv, nh, hd, alpha)
     ctx = torch.empty((B * Sq, nh * hd), dtype=torch.float32, device=q.device)
     lse = torch.empty((B * nh, Sq), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
@@ -896,6 +981,10 @@ def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None
     for t in (ctx, dctx, dq, dk, dv):
         if t is not None and t.dtype != torch.float32:
             raise _hip.MuseHipError("attention_x3: f32 operands")
+    if attention_x3_blocked(Sq, Skv):
+        if planes_only or any(e is not None and e[0] is not None for e in planes):
+            raise _hip.MuseHipError("attention_x3_bwd: the block-by-block form (more than 256 query rows or keys) writes f32 gradients, no operand planes")
+        return _attention_x3_bwd_blocks(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq, dk, dv)
     d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
     pdo, lddo = _row_view(dctx, H)
     e0 = _prof_begin()

@@ -368,11 +368,12 @@ class TapeOps:
         do = self._lin_bwd(dy, sv["o"], att.out, name + ".out", G)                        # f32 [B*Sq, C]
         q, qkv, w = sv["q"], sv["qkv"], sv["w"]
         ub = self.__dict__.get("_use_bias", False)
+        blocked = ops.attention_x3_blocked(Sq, Skv)      # (block-by-block form of the long sequences: f32 gradients, no operand planes)
         if sv["self_attn"]:
             if not self_attn:
                 raise MuseHipError("self-attention tape replayed as cross-attention")
             lo = qkv.numel()
-            if not ub and ops.planes_only_ok(qkv.shape[0], qkv.shape[1]) and min(w.shape) >= 128:
+            if not blocked and not ub and ops.planes_only_ok(qkv.shape[0], qkv.shape[1]) and min(w.shape) >= 128:
                 # dqkv feeds one dW and one dX product and nothing else: it exists as their operand planes only
                 pl = torch.empty((2,) + tuple(qkv.shape), dtype=torch.bfloat16, device=qkv.device)
                 ops.attention_x3_bwd(q, qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, planes_only=True,
@@ -380,7 +381,7 @@ class TapeOps:
                 dqkv = ops.Planes(pl)
             else:
                 dqkv = torch.empty_like(qkv)
-                pl = ops.x3_new_planes(dqkv)       # ... or as f32 and planes, both out of the kernel
+                pl = None if blocked else ops.x3_new_planes(dqkv)       # ... or as f32 and planes, both out of the kernel
                 ops.attention_x3_bwd(q, qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha,
                                      dq=dqkv[:, :Cq], dk=dqkv[:, Cq:2 * Cq], dv=dqkv[:, 2 * Cq:],
                                      planes=None if pl is None else ((pl[0][:, :Cq], lo), (pl[0][:, Cq:2 * Cq], lo), (pl[0][:, 2 * Cq:], lo)))
@@ -391,7 +392,7 @@ class TapeOps:
                 gb = ops.bias_grad(dqkv)
                 G[name + ".query.bias"], G[name + ".key.bias"], G[name + ".value.bias"] = gb[:Cq], gb[Cq:2 * Cq], gb[2 * Cq:]
             return self._mm_dx(dqkv, w), None                                             # d(x) through q, k and v in one product
-        if (not ub and ops.planes_only_ok(q.shape[0], q.shape[1]) and ops.planes_only_ok(qkv.shape[0], qkv.shape[1]) and min(w.shape) >= 128
+        if (not blocked and not ub and ops.planes_only_ok(q.shape[0], q.shape[1]) and ops.planes_only_ok(qkv.shape[0], qkv.shape[1]) and min(w.shape) >= 128
                 and min(att.query.weight.shape) >= 128):
             # dq and dkv feed one dW and one dX product each and nothing else: planes only
             plq = torch.empty((2,) + tuple(q.shape), dtype=torch.bfloat16, device=q.device)
@@ -402,7 +403,7 @@ class TapeOps:
         else:
             dq = torch.empty_like(q)
             dkv = torch.empty_like(qkv)
-            plq, plkv = ops.x3_new_planes(dq), ops.x3_new_planes(dkv)
+            plq, plkv = (None, None) if blocked else (ops.x3_new_planes(dq), ops.x3_new_planes(dkv))
             ops.attention_x3_bwd(q, qkv[:, :Cq], qkv[:, Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, dq=dq, dk=dkv[:, :Cq], dv=dkv[:, Cq:],
                                  planes=(None if plq is None else (plq[0], dq.numel()), None if plkv is None else (plkv[0][:, :Cq], dkv.numel()),
                                          None if plkv is None else (plkv[0][:, Cq:], dkv.numel())))

@@ -682,6 +682,55 @@ def test_fused_attention_bf16x3(B, Skv, nh, packed):
     assert rel_err(ctx, o.double()) < 3e-5
     # shapes the kernel does not take are refused, not mis-computed
     assert not ops.attention_x3_supported(257, 257, 64) and not ops.attention_x3_supported(256, 128, 64) and not ops.attention_x3_supported(256, 256, 48)
+    assert not ops.attention_x3_supported(384, 384, 64) and not ops.attention_x3_supported(1024, 300, 64)
+
+
+@pytest.mark.parametrize("B,Sq,Skv,nh,packed", [(2, 1024, 1024, 2, True), (1, 512, 512, 3, True), (2, 1024, 77, 2, False), (1, 512, 96, 2, False)])
+def test_fused_attention_bf16x3_block_by_block(B, Sq, Skv, nh, packed):
+    """round 6 (BASELINE config 4's 1024-token sequences in the bf16x3 mode): query rows in blocks of 256 against key blocks of 256 (or the
+    <= 96 text states) on attention3.hip's one-tile kernels, the key blocks merged by their log-sum-exps; backward per block pair with the
+    query block's GLOBAL log-sum-exp and the final context.  Same tolerances against float64 as the one-tile form."""
+    ops = _ops()
+    hd = 64
+    H = nh * hd
+    alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
+    assert ops.attention_x3_supported(Sq, Skv, hd) and ops.attention_x3_blocked(Sq, Skv)
+    if packed:
+        qkv = rnd((B * Sq, 3 * H), 170, 1.0)
+        qc, kc, vc = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+        qkv_d = qkv.to(DEV)
+        qd, kd, vd = qkv_d[:, :H], qkv_d[:, H:2 * H], qkv_d[:, 2 * H:]
+    else:
+        qc, kv = rnd((B * Sq, H), 171, 1.0), rnd((B * Skv, 2 * H), 172, 1.0)
+        kc, vc = kv[:, :H], kv[:, H:]
+        qd, kv_d = qc.to(DEV), kv.to(DEV)
+        kd, vd = kv_d[:, :H], kv_d[:, H:]
+    dctx = rnd((B * Sq, H), 173)
+    q = qc.double().reshape(B, Sq, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    k = kc.double().reshape(B, Skv, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    v = vc.double().reshape(B, Skv, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    sc = q @ k.transpose(-1, -2) * alpha
+    ref = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B * Sq, H)
+    ref.backward(dctx.double())
+    gq, gk, gv = (t.grad.transpose(1, 2).reshape(-1, H) for t in (q, k, v))
+    ctx, lse = ops.attention_x3_fwd(qd, kd, vd, B, Sq, Skv, nh, hd, alpha)
+    if packed:
+        dqkv = torch.full_like(qkv_d, float("nan"))
+        dq, dk, dv = ops.attention_x3_bwd(qd, kd, vd, ctx, dctx.to(DEV), lse, B, Sq, Skv, nh, hd, alpha, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:])
+    else:
+        dq, dk, dv = ops.attention_x3_bwd(qd, kd, vd, ctx, dctx.to(DEV), lse, B, Sq, Skv, nh, hd, alpha)
+    assert ctx.dtype == torch.float32 and torch.isfinite(ctx).all() and all(torch.isfinite(t).all() for t in (dq, dk, dv))
+    ef = rel_err(ctx, ref.detach())
+    lref = torch.logsumexp(sc, dim=-1).reshape(B * nh, Sq // 256, 256).transpose(0, 1).detach()       # [query block, B*nh, 256]
+    el = rel_err(lse, lref)
+    eg = [rel_err(a, b) for a, b in ((dq, gq), (dk, gk), (dv, gv))]
+    print(f"bf16x3 attention, blocks, {Sq} x {Skv}: ctx {ef:.1e}, lse {el:.1e}, dq / dk / dv {eg[0]:.1e} / {eg[1]:.1e} / {eg[2]:.1e} of float64")
+    assert ef < 2e-5 and el < 2e-6 and max(eg) < 5e-5
+    assert float((ctx.double().cpu() - ref.detach()).abs().amax(dim=1).max()) < 1e-4
+    for a, b in ((dq, gq), (dk, gk), (dv, gv)):
+        assert float((a.double().cpu() - b).abs().amax(dim=1).max()) < 1e-4 * float(b.abs().max())
+    with pytest.raises(Exception):     # operand planes are the one-tile form's
+        ops.attention_x3_bwd(qd, kd, vd, ctx, dctx.to(DEV), lse, B, Sq, Skv, nh, hd, alpha, planes_only=True, planes=((None, 0), (None, 0), (None, 0)))
 
 
 def test_one_tile_attention_under_graph_capture():
