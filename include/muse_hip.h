@@ -247,7 +247,9 @@ int muse_adamw_multi(const int64_t* table, const int32_t* chunk_first, int32_t n
  * _flat_groups: the flat buffer is cut into segments, seg_end[s] (device int64, ascending ABSOLUTE element offsets of the flat
  * buffer) closes segment s and seg_group[s] (device int32) names its group; the call updates elements [base, base + n) - p, g, m, v,
  * p_bf16 point at element `base` - so range-wise updates (inside backward, behind an all-reduce bucket) share one table.
- * _multi_groups: muse_adamw_multi's table with a seventh column, the tensor's group.
+ * _multi_groups: muse_adamw_multi's table with a seventh column, the tensor's group in its low 8 bits; above them (optional, round 6) the
+ *   element distance from p_bf16 to a second bf16 plane: p_bf16 then receives hi = bf16(p) and that plane lo = bf16(p - hi), the
+ *   bf16x3 operand planes of the updated weight (muse_gemm_x3 reads them next step; 0 = plain bf16 copy).
  * A one-group call is bit-identical to muse_adamw_flat / muse_adamw_multi. */
 int muse_adamw_flat_groups(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, int64_t base,
                            const int64_t* seg_end, const int32_t* seg_group, int32_t nseg, const float* group_hyper,

@@ -1207,7 +1207,7 @@ extern "C" int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale,
   // number of workgroups (default: one per CU).
   static const int persist = []() { const char* e = getenv("MUSE_CONV_PERSIST"); return e ? atoi(e) : 0; }();
   if (persist && Cin <= cslab::P_GSS_MAX_CIN && (long)p.M * p.N * 4 < (1L << 32) - 64) {
-    static int ncu = 0, grid = 0, min_tiles = 2;
+    static int ncu = 0, grid = 0, min_tiles = 2, min_given = 0;
     if (!ncu) {
       int dev = 0; hipDeviceProp_t prop;
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MUSE_ERR_UNSUPPORTED;
@@ -1216,7 +1216,7 @@ extern "C" int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale,
       grid = e ? atoi(e) : prop.multiProcessorCount;
       if (grid < 1) grid = 1;
       const char* m = getenv("MUSE_CONV_PERSIST_MIN");
-      if (m) min_tiles = atoi(m);
+      if (m) { min_tiles = atoi(m); min_given = 1; }
       ncu = prop.multiProcessorCount;
     }
     const int nslab = (p.M >> 8) * ntn;
@@ -1224,7 +1224,7 @@ extern "C" int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale,
     // is handed back to the dispatcher (and to the other streams' kernels) every k tiles
     static const int per_wg = []() { const char* e = getenv("MUSE_CONV_PERSIST_TILES"); return e ? atoi(e) : 0; }();
     if (per_wg > 0) {
-      if (nslab >= 2 * per_wg * ncu) {
+      if (nslab >= (min_given ? (min_tiles > 1 ? min_tiles : 1) * per_wg : 2 * per_wg * ncu)) {
         hipLaunchKernelGGL(cslab::conv_slab_persist_kernel<true>, dim3((nslab + per_wg - 1) / per_wg), dim3(512), cslab::P_LDS_BYTES_GN, (hipStream_t)stream, p);
         return (int)hipGetLastError();
       }

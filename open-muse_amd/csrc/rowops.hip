@@ -1622,7 +1622,7 @@ extern "C" int muse_adamw_flat_groups(float* p, const float* g, float* m, float*
                      (bf16_t*)p_bf16, (long)n, (long)base, (const long*)seg_end, seg_group, nseg, G, grad_scale);
   return (int)hipGetLastError();
 }
-// Multi-tensor form with groups: `table` is 7 x int64 per tensor {p, g, m, v, p_bf16 or 0, n, group}.
+// Multi-tensor form with groups: `table` is 7 x int64 per tensor {p, g, m, v, p_bf16 or 0, n, group | lo_plane_distance << 8}.
 __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __restrict__ table, const int* __restrict__ chunk_first, int nt,
                                                                  AdamGroups G, float gscale) {
   int lo = 0, hi = nt;
@@ -1631,9 +1631,12 @@ __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __r
   float* p = (float*)e[0]; const float* g = (const float*)e[1]; float* m = (float*)e[2]; float* v = (float*)e[3];
   bf16_t* pb = (bf16_t*)e[4];
   const AdamHyper h = G.h[(int)e[6] & (MUSE_ADAMW_MAX_GROUPS - 1)];
+  // column 6 above bit 8: p_bf16 is the HI plane of the parameter's bf16x3 operand planes and the lo plane sits that many elements behind
+  // it (hi = bf16(p), lo = bf16(p - hi): split_f2bb_kernel's arithmetic) - the planes the next step's weight GEMMs read; 0 = a plain bf16 copy
+  const long plo = e[6] >> 8;
   const long n = e[5], base = (long)((int)blockIdx.x - chunk_first[lo]) * 4096;
   const long end = base + 4096 < n ? base + 4096 : n;
-  const bool vec = !((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) && !(((uintptr_t)pb) & 7);
+  const bool vec = !((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) && !(((uintptr_t)pb) & 7) && !(plo & 3);
   if (vec) {
     for (long i = base + threadIdx.x * 4; i + 3 < end; i += 1024) {
       float pp[4], gg[4], mm[4], vv[4];
@@ -1641,7 +1644,15 @@ __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __r
 #pragma unroll
       for (int j = 0; j < 4; ++j) adam_update1(pp[j], gg[j] * gscale, mm[j], vv[j], h);
       V4<float>::store(p + i, pp); V4<float>::store(m + i, mm); V4<float>::store(v + i, vv);
-      if (pb) V4<bf16_t>::store(pb + i, pp);
+      if (pb) {
+        V4<bf16_t>::store(pb + i, pp);
+        if (plo) {
+          float rr[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rr[j] = pp[j] - bf16_to_f32(f32_to_bf16(pp[j]));
+          V4<bf16_t>::store(pb + plo + i, rr);
+        }
+      }
     }
   }
   const long s0 = vec ? base + ((end - base) & ~3L) : base;
@@ -1649,7 +1660,11 @@ __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __r
     float pp = p[i], mm = m[i], vv = v[i];
     adam_update1(pp, g[i] * gscale, mm, vv, h);
     p[i] = pp; m[i] = mm; v[i] = vv;
-    if (pb) pb[i] = f32_to_bf16(pp);
+    if (pb) {
+      const bf16_t hi = f32_to_bf16(pp);
+      pb[i] = hi;
+      if (plo) pb[plo + i] = f32_to_bf16(pp - bf16_to_f32(hi));
+    }
   }
 }
 extern "C" int muse_adamw_multi_groups(const int64_t* table, const int32_t* chunk_first, int32_t num_tensors, int32_t num_chunks,

@@ -551,7 +551,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
             a2, s2 = self._attention(m2, enc, lyr.crossattention, B, S, L, nh)
             m3, res3, a3s = self._norm_adaln(a2, lyr.ffn.pre_mlp_layer_norm, lyr.ffn.adaLN_modulation, scond, B, mode=1,
                                              residual=res2, gemm_only=go)                                  # LayerNorm (:928)
-            w01 = self._w2(lyr.ffn.wi_0, lyr.ffn.wi_1)
+            w01 = self._w2(lyr.ffn.wi_0, lyr.ffn.wi_1, rows=m3.shape[0])
             if self.compute_dtype == torch.bfloat16:
                 # the reference's autocast regime: the GLU input and output live in bf16 between the two GEMMs (no f32 round trip,
                 # no separate cast of the wo operand)

@@ -105,6 +105,9 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
                             zdiv, sA, sB, sC, accumulate)
         if done:
             return C_
+    if isinstance(A, Planes) or isinstance(B, Planes):
+        # a planes-only operand has no f32 bytes behind data_ptr(): every path below would read its bf16 planes as something else
+        raise _hip.MuseHipError("a planes-only operand reached a product the four-plane kernel does not take")
     if (SKINNY and x3_lo is None and A.dtype == torch.bfloat16 and batch == 1 and la == 0 and lb == 0 and act == 0 and rowvec is None and not accumulate
             and split_k == 1 and M <= 2048 and K >= 512 and N % 4 == 0 and ldc % 4 == 0 and (residual is None or ldr % 4 == 0)
             and (SKINNY == 2 or torch.cuda.is_current_stream_capturing())):
@@ -134,6 +137,8 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     #  256-CU chip - N = 6144 / 3072 / 2048: the step came out 0.45 ms SLOWER, 53.08 against 52.64 ms same box, transformer alone 33.34
     #  against 32.85: the extra launches cost more than the rounds, and in the step other streams fill the tail anyway.)
     if not USE_TR and A.dtype == torch.bfloat16 and (la == 1 or lb == 1):
+        if x3_lo is not None:
+            return None        # (the bring-up transpose route would drop the lo planes: the caller falls back to its three-product form)
         return _gemm_via_transpose(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, a_off, b_off, c_off, alpha, bias, rowvec,
                                    residual, ldr, batch, zdiv, sA, sB, sC, accumulate, act)
     d = GemmDesc()
@@ -564,8 +569,11 @@ def planes_only_ok(rows, cols):
 def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     """dw[N,K] (+)= dy[T,N]^T @ x[T,K]   (both operands k-major, f32 output into the flat grad buffer).
     Split-K slices write partial tiles to a workspace that muse_sum_slices folds into dw in a fixed order."""
-    if _F32_AS_BF16X3[0] and dy.dtype == torch.float32 and x.dtype == torch.float32 and dw.dtype == torch.float32 \
-            and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[1] % 8 == 0 and (M if M is not None else dy.shape[1]) % 8 == 0:
+    x3 = _F32_AS_BF16X3[0] and dy.dtype == torch.float32 and x.dtype == torch.float32 and dw.dtype == torch.float32 \
+        and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[1] % 8 == 0 and (M if M is not None else dy.shape[1]) % 8 == 0
+    if not x3 and (isinstance(dy, Planes) or isinstance(x, Planes)):
+        raise _hip.MuseHipError("a planes-only operand reached a weight-gradient product outside the bf16x3 mode's preconditions")
+    if x3:
         with f32_gemms_as_bf16x3(False):
             if (X3_NATIVE and dy.dim() == 2 and x.dim() == 2 and dy.is_contiguous() and x.is_contiguous() and (lda is None or lda == dy.stride(0))
                     and dy.shape[0] == x.shape[0] and _wgrad_x3_native(dy, x, dw, accumulate, M)):

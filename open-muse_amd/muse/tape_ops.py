@@ -21,6 +21,9 @@ _X3_ATTENTION = os.environ.get("MUSE_X3_ATTENTION", "1") != "0"   # bf16x3 mode:
 _BF16_OPERANDS = int(os.environ.get("MUSE_UVIT_BF16_OPERANDS", "3"))
 
 
+X3_WEIGHT_PLANES = os.environ.get("MUSE_X3_WEIGHT_PLANES", "1") != "0"   # bf16x3 mode: weight operand planes kept across steps, refreshed by FusedAdamW
+
+
 class TapeOps:
     # Data-parallel training: `grad_tensors_hook(tensors, final, side_stream)` is called from inside the hand-written backward every
     # time a block's parameter gradients are COMPLETE (muse.GradReducer hangs itself here) - the all-reduce of a bucket then runs on
@@ -155,14 +158,54 @@ class TapeOps:
         for m in mods:   # muse.FusedAdamW writes each parameter's refreshed bf16 copy straight into its row block of the cached tensor
             n = m.weight.shape[0]
             m.weight._muse_shadow = wb[off:off + n]
+            if hasattr(m.weight, "_muse_planes"):
+                del m.weight._muse_planes       # (one compute copy per parameter: the bf16x3 mode's planes are stale from here on)
             off += n
         return wb
 
-    def _w2(self, *mods):
-        """the weight(s) as the GEMM operand of the current compute mode: cached bf16 copy, or the f32 master (stacked on the fly)"""
+    def _wp(self, *mods):
+        """bf16x3 mode: the (hi, lo) operand planes of one weight, or of several stacked along the output dim, as ops.Planes [N_out_total, K_in]
+        - cached ACROSS steps like _wb's bf16 copy: muse.FusedAdamW writes each parameter's refreshed planes straight into its row block
+        (`p._muse_planes` = (hi-plane rows, elements to the lo plane)) inside its own kernel, so no weight is split (and no q|k|v stacked)
+        per step.  Valid while no source parameter has been updated in place by anything else (autograd version counters)."""
+        key = tuple(id(m.weight) for m in mods)
+        ver = tuple(m.weight._version for m in mods)
+        cache = self.__dict__.setdefault("_pcache", {})
+        owner = self.__dict__.setdefault("_pcache_owner", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver and hit[1].planes.device == mods[0].weight.device:
+            return hit[1]
+        ws = [self._f(m.weight).reshape(m.weight.shape[0], -1) for m in mods]
+        pl = ops._split_planes_now((ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)).contiguous())
+        for pid in key:
+            prev = owner.get(pid)
+            if prev is not None and prev != key:
+                cache.pop(prev, None)
+                for q in prev:
+                    if owner.get(q) == prev:
+                        del owner[q]
+            owner[pid] = key
+        wp = ops.Planes(pl)
+        cache[key] = (ver, wp)
+        off, lo = 0, pl[0].numel()
+        for m in mods:
+            n = m.weight.shape[0]
+            m.weight._muse_planes = (pl[0][off:off + n], lo)
+            if hasattr(m.weight, "_muse_shadow"):
+                del m.weight._muse_shadow       # (one compute copy per parameter: the bf16 mode's is stale from here on)
+            off += n
+        return wp
+
+    def _w2(self, *mods, rows=None):
+        """the weight(s) as the GEMM operand of the current compute mode: cached bf16 copy, cached operand planes (bf16x3 mode, when the
+        caller names the `rows` of the activation it multiplies and the products are ones the four-plane kernel takes), or the f32 master
+        (stacked on the fly)"""
         k_in = mods[0].weight.numel() // mods[0].weight.shape[0]
         if self.compute_dtype == torch.bfloat16 and k_in % 8 == 0:
             return self._wb(*mods)
+        if (rows is not None and rows >= 128 and self.__dict__.get("_f32_split3", False) and X3_WEIGHT_PLANES and k_in >= 128
+                and ops.planes_only_ok(sum(m.weight.shape[0] for m in mods), k_in)):
+            return self._wp(*mods)
         # (bf16 rows must be whole 16-byte chunks: a weight whose input width is not a multiple of 8 - no shipped configuration -
         #  keeps its products in exact f32, see _f32_pair)
         ws = [self._f(m.weight).reshape(m.weight.shape[0], -1) for m in mods]
@@ -233,10 +276,10 @@ class TapeOps:
         return dw
 
     def _lin(self, x, mod, residual=None):
-        return self._mm(x, self._w2(mod), residual=residual, bias=self._b(mod))
+        return self._mm(x, self._w2(mod, rows=x.shape[0]), residual=residual, bias=self._b(mod))
 
     def _lin_bwd(self, dy, x, mod, name, G, need_dx=True):
-        w2 = self._w2(mod)
+        w2 = self._w2(mod, rows=dy.shape[0])
         if self.__dict__.get("_use_bias", False):
             G[name + ".bias"] = ops.bias_grad(dy)
         dyc = dy if w2.dtype == torch.float32 else self._c(dy)            # one cast feeds both the dW and the dX product
@@ -304,12 +347,12 @@ class TapeOps:
             alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
             self_attn = ctx is x
             if self_attn:
-                w = self._w2(att.query, att.key, att.value)                      # f32 [3C, C], stacked for this step (the tape keeps it)
+                w = self._w2(att.query, att.key, att.value, rows=x.shape[0])     # [3C, C] operand planes kept across steps (or f32, stacked for this step)
                 qkv = self._mm(x, w, bias=self._b(att.query, att.key, att.value))
                 q, k, v = qkv[:, :Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:]
             else:
                 q = self._lin(x, att.query)
-                w = self._w2(att.key, att.value)
+                w = self._w2(att.key, att.value, rows=ctx.shape[0])
                 qkv = self._mm(ctx, w, bias=self._b(att.key, att.value))
                 k, v = qkv[:, :Cq], qkv[:, Cq:]
             o, lse = ops.attention_x3_fwd(q, k, v, B, Sq, Skv, nh, hd, alpha)

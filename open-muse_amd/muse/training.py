@@ -367,8 +367,9 @@ class FusedAdamW(torch.optim.Optimizer):
         semantics: a parameter without a gradient is skipped and keeps its own state; the step count is shared (all
         parameters of these models receive a gradient every step).  With several parameter groups the table carries each
         tensor's group and the launch is muse_adamw_multi_groups."""
-        multi = len(self.param_groups) > 1
         params = [(p, k) for k, grp in enumerate(self.param_groups) for p in grp["params"] if p.grad is not None]
+        # (operand planes of the bf16x3 mode ride in the group column of the grouped table: a one-group model with planes takes that kernel too)
+        multi = len(self.param_groups) > 1 or any(getattr(p, "_muse_planes", None) is not None for p, _ in params)
         if not params:
             return loss
         if self._m is None:
@@ -387,9 +388,16 @@ class FusedAdamW(torch.optim.Optimizer):
             shadow = getattr(p, "_muse_shadow", None)   # the model's cached bf16 compute copy of this weight (MaskGiTUViT bf16 mode)
             if shadow is not None and (shadow.numel() != p.numel() or shadow.device != p.device or not shadow.is_contiguous()):
                 shadow = None
+            # ... or (bf16x3 mode, tape_ops._wp) its (hi, lo) operand planes: hi-plane rows + the element distance to the lo plane, which
+            # rides in the group column above bit 8
+            lo = 0
+            planes = getattr(p, "_muse_planes", None)
+            if planes is not None and shadow is None and planes[0].numel() == p.numel() and planes[0].device == p.device \
+                    and planes[0].is_contiguous() and planes[1] > 0:
+                shadow, lo = planes[0], int(planes[1])
             row = (p.data.data_ptr(), p.grad.data_ptr(), self._m[k].data_ptr(), self._v[k].data_ptr(),
                    shadow.data_ptr() if shadow is not None else 0, p.numel())
-            rows.append(row + (gk,) if multi else row)
+            rows.append(row + (gk | (lo << 8),) if multi else row)
         # one launch for all tensors.  Gradients are fresh allocations every step, so the pointer table is rebuilt every step: ~500
         # rows staged through two alternating PINNED host buffers and copied asynchronously (a pageable copy would make the host
         # wait for the stream and lose its run-ahead into the next step)

@@ -1241,6 +1241,20 @@ def test_conv_with_fused_groupnorm_input_is_bit_identical(B, H, W, Cin, Cout, re
     assert rel_err(got, y) < 5e-5
 
 
+@pytest.mark.parametrize("env", [{"MUSE_CONV_PERSIST_GRID": "3"}, {"MUSE_CONV_PERSIST_GRID": "8"}, {"MUSE_CONV_PERSIST_TILES": "2", "MUSE_CONV_PERSIST_MIN": "0"}])
+def test_persistent_fused_convolution_is_bit_identical(env):
+    """conv_slab_persist_kernel<true> (round 6; MUSE_CONV_PERSIST=1, off by default: it loses on the concurrent step): the parity cases of
+    test_conv_with_fused_groupnorm_input_is_bit_identical with the persistent kernel taking every shape it can - workgroups that walk several
+    tiles across image and N-tile changes (grid 3), one tile each (grid 8), k-tile workgroups.  The library reads its switches once per
+    process, so the cases run in a child interpreter."""
+    import subprocess
+    import sys
+    e = dict(os.environ, MUSE_CONV_PERSIST="1", MUSE_CONV_PERSIST_MIN="0", **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "test_conv_with_fused_groupnorm_input_is_bit_identical"], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _hip_lib():
     from muse import _hip
     return _hip.lib()

@@ -298,6 +298,54 @@ def test_uvit_train_step_with_fused_adamw(golden_dir):
         assert rel_err(p, q) < 1e-5, name
 
 
+def test_bf16x3_weight_planes_refreshed_by_fused_adamw(golden_dir):
+    """round 6: in the bf16x3 mode the weights' (hi, lo) operand planes are cached across steps (tape_ops._wp: one stacked tensor per
+    q|k|v / k|v / wi_0|wi_1 / single Linear) and muse.FusedAdamW writes every updated parameter's planes inside its own kernel (table
+    column 6 above bit 8).  Three steps on a model wide enough for the four-plane kernel: after each step every cached plane pair
+    equals a fresh split of the f32 master bit for bit, the parameters equal those of the same run with MUSE_X3_WEIGHT_PLANES off
+    (per-step split) bit for bit, and at least one cache hit served a product from planes the optimizer wrote."""
+    import muse
+    from muse import ops, tape_ops
+    cfg = dict(vocab_size=520, hidden_size=256, in_channels=128, block_out_channels=(128,), encoder_hidden_size=128, cond_embed_dim=128,
+               micro_cond_encode_dim=32, micro_cond_embed_dim=160, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+               block_num_heads=2, num_res_blocks=1, codebook_size=512, mask_token_id=519)
+    B, S = 2, 256
+    gen = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    labels = torch.where(torch.rand(B, S, generator=gen) < 0.5, torch.randint(0, 512, (B, S), generator=gen), torch.full((B, S), -100)).to(DEV)
+    enc, cond = torch.randn(B, 77, 128, generator=gen).to(DEV), torch.randn(B, 128, generator=gen).to(DEV)
+    micro = torch.tensor([[256.0, 256.0, 0.0, 0.0, 6.0]]).repeat(B, 1).to(DEV)
+    results = []
+    for planes_on in (True, False):
+        torch.manual_seed(11)
+        model = muse.MaskGiTUViT(**cfg)
+        model.to(DEV).train().set_compute_dtype("bf16x3")
+        opt = muse.FusedAdamW(muse.grouped_parameters(model, 0.01), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, eps=1e-8)
+        old = tape_ops.X3_WEIGHT_PLANES
+        tape_ops.X3_WEIGHT_PLANES = planes_on
+        try:
+            for step in range(3):
+                model.zero_grad(set_to_none=True)
+                _, loss = model(ids, enc, cond, micro, labels=labels)
+                loss.backward()
+                opt.step()
+                cache = model.__dict__.get("_pcache", {})
+                assert (len(cache) > 0) == planes_on
+                for key, (ver, wp) in cache.items():
+                    ws = [p for p in model.parameters() if id(p) in key]
+                    ws.sort(key=lambda p: key.index(id(p)))
+                    fresh = ops._split_planes_now(torch.cat([w.detach().reshape(w.shape[0], -1) for w in ws], dim=0).contiguous())
+                    assert torch.equal(wp.planes, fresh), f"stale operand planes after step {step}"
+        finally:
+            tape_ops.X3_WEIGHT_PLANES = old
+        results.append(([p.detach().clone() for p in model.parameters()], float(loss)))
+        if planes_on:
+            assert any(getattr(p, "_muse_planes", None) is not None for p in model.parameters())
+    for a, b in zip(results[0][0], results[1][0]):
+        assert torch.equal(a, b)
+    assert results[0][1] == results[1][1]
+
+
 def test_uvit_fused_adamw_parameter_groups(golden_dir):
     """training/train_muse.py:425-445 on the U-ViT: two groups (no weight decay on bias / layer_norm.weight / mlm_ln.weight /
     embeddings.weight) through ONE muse_adamw_multi_groups launch == torch.optim.AdamW with the same groups"""
