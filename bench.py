@@ -17,7 +17,7 @@ images is in cpu_baseline.vq_index_mismatches).
 
 The line carries
   roofline      the dominant kernel (live HIP-event timing of every launch of one instrumented step) against its roof; `traffic`
-                = HBM bytes per launch of that kernel from the committed PMC passes (profiles/r05_traffic.json, FETCH_SIZE x 2
+                = HBM bytes per launch of that kernel from the committed PMC passes (profiles/r06_traffic.json, FETCH_SIZE x 2
                 + WRITE_SIZE as /opt/skills/guides/MI355X_MICROARCH.md prescribes), null when no such profile is in the tree
   cpu_baseline  the CPU oracle (port of the reference path) on the node's host cores: warm-up + median of 3, per phase
   extra         the north_star's own targets: transformer_mfma_frac (3 x forward GFLOP / transformer fwd+bwd time / 2.5 PF),
@@ -56,8 +56,8 @@ UVIT_CC12M = dict(
     initializer_range=0.02, norm_type="rmsnorm", layer_norm_eps=1e-6, use_normformer=False, use_encoder_layernorm=True,
     use_bias=False, hidden_dropout=0.0, attention_dropout=0.0, use_codebook_size_for_output=True, block_num_heads=16,
 )
-TRAFFIC_JSON = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json")) if os.path.exists(f)),
-                    os.path.join(ROOT, "profiles", "r05_traffic.json"))
+TRAFFIC_JSON = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json")) if os.path.exists(f)),
+                    os.path.join(ROOT, "profiles", "r06_traffic.json"))
 # rocprof kernel name fragment of each instrumented kernel family (to look its counters up in TRAFFIC_JSON)
 KERNEL_OF = {"conv_bf16x3_dma": "cslab::conv_slab_kernel<true>", "gemm_bf16_NN": "g256p::kernel<unsigned short, 0, 0", "gemm_bf16_NT": "g256p::kernel<unsigned short, 0, 1",
              "gemm_bf16_TT": "g256::kernel_group<float, 1, 1", "conv_bf16x3": "conv_split_kernel", "attn_fwd_bf16": "attn2::fwd_kernel"}
@@ -483,7 +483,7 @@ def comm_block(info, world, dp_ms, plain_ms, grad_dtype, rccl_log):
 
 
 def traffic_of(kernel_family):
-    """HBM bytes per launch of a kernel family from the committed PMC passes (scripts/gpu.sh final -> profiles/r05_traffic.json)"""
+    """HBM bytes per launch of a kernel family from the committed PMC passes (scripts/gpu.sh final -> profiles/r06_traffic.json)"""
     if not os.path.exists(TRAFFIC_JSON) or kernel_family not in KERNEL_OF:
         return None, None
     t = json.load(open(TRAFFIC_JSON))

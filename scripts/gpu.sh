@@ -3,7 +3,7 @@
 #   scripts/gpu.sh <stage> [args]        stages: attn | tests | bench | final | prof
 # Everything a stage prints that should survive goes to gpurun_out/<tag>_*.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; O=gpurun_out; mkdir -p $O
-stage=$1; tag=${2:-r5}
+stage=$1; tag=${2:-r6}
 case $stage in
 attn)   # attention2.hip bring-up: parity tests, then old vs new (and build variants) on the config-B shape
   timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -p no:cacheprovider -k "attention" > $O/${tag}_attn_pytest.txt 2>&1
@@ -44,6 +44,8 @@ trace)  # concurrency picture of the default multi-stream step: kernel trace of 
   cd $OLDPWD
   f=$(find $O/${tag}_trace -name "t_kernel_trace.csv" | head -1)
   python scripts/overlap_report.py $f --last-ms 250 > $O/${tag}_overlap.txt 2>&1; tail -60 $O/${tag}_overlap.txt
+  python scripts/step_trace_report.py $f --steps 5 --serial profiles/r05_final_kernel_stats.csv > $O/${tag}_concurrent_step.txt 2>&1
+  python scripts/step_timeline.py $f --dump $O/${tag}_step_kernels.csv > $O/${tag}_step_timeline.txt 2>&1
   g=$(find $O/${tag}_trace -name "t_kernel_stats.csv" | head -1); cp $g $O/${tag}_kernel_stats.csv
   find $O/${tag}_trace -name "*.csv" -size +3M -delete
   ;;
@@ -76,7 +78,7 @@ final)  # validation of the committed tree: device, full GPU suite (printed erro
     echo "$c exit $?"
   done
   f=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && [ -n "$w" ] && python scripts/traffic_summary.py "$f" "$w" $O/${T}_traffic.json && cp $O/${T}_traffic.json profiles/r05_traffic.json
+  [ -n "$f" ] && [ -n "$w" ] && python scripts/traffic_summary.py "$f" "$w" $O/${T}_traffic.json && cp $O/${T}_traffic.json profiles/r06_traffic.json
   find $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE -name "*.csv" -size +4M -delete
   rm -rf $O/pmc_mfma
   REPS=3 WHICH=nn,nt,grp,conv timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o p -- python scripts/gemm_probe.py > $O/pmc_mfma.log 2>&1
