@@ -788,6 +788,24 @@ def main():
              "mfma_ms_in_instrumented_step": round(sum(v[1] for v in mfma.values()), 2),
              "hbm_kernel_ms_in_instrumented_step": round(sum(v[1] for v in hbm.values()), 2),
              "measured_parity_bf16_vs_f32_mode": {k: (round(v, 8) if isinstance(v, float) else v) for k, v in parity.items()}}
+    if args.config == "B" and args.batch == 64:
+        # per family the time its BINDING resource implies (derivation and sources: profiles/r06_ceiling.md) next to this
+        # run's serial time; a ratio above 1.15 has its measured decomposition there
+        def _ms(*names):
+            return round(sum(kinds[n]["ms_total"] for n in names if n in kinds) + sum(hbm_kinds[n]["ms_total"] for n in names if n in hbm_kinds), 3)
+        ceil_rows = {
+            "conv_bf16x3_dma": ("MFMA issue at the clock the kernel holds (1.72 GHz, power-limited): 3 x 8.155 TFLOP / (2.5 PF x 1.72 / 2.4)", 13.7,
+                                _ms("conv_bf16x3_dma")),
+            "gemm_fwd_dx": ("K loop bound by LDS cycles (2500 of 2048 MFMA cycles per K-tile) + whole 256^2 tiles on 256 CUs + 82 us tile change per layer "
+                            "(46 us register epilogue + 36 us stores, ablation)", 13.1, _ms("gemm_bf16_NN", "gemm_bf16_NT")),
+            "gemm_dw": ("the same K loop at K = 16448, five slices alone on the chip", 5.9, _ms("gemm_bf16_TT")),
+            "attention": ("HBM floor of q, k, v, o (+ dO, dq, dk, dv) at 6.3 TB/s", 1.15, _ms("attn_fwd_bf16", "attn_bwd_bf16")),
+            "row_kernels": ("HBM streaming at the 6.0 TB/s a three-operand stream reaches on this chip", 8.9,
+                            round(sum(v["ms_total"] for v in hbm_kinds.values()), 3)),
+        }
+        extra["ceiling"] = {"doc": "profiles/r06_ceiling.md",
+                            "families": {k: {"binding": b, "implied_ms": i, "measured_ms": m, "ratio": round(m / i, 2) if m else None}
+                                         for k, (b, i, m) in ceil_rows.items()}}
     if world == 1 and not args.no_extra:
         n2 = max(3, args.steps // 2)
 

@@ -31,7 +31,9 @@ namespace g256p {
 using namespace g256;
 
 constexpr int TK_OFF = LDS_BYTES;            // LDS word behind the two stages: next tile (queue position), written by wave 0
-constexpr int LDS_BYTES_P = LDS_BYTES + 64;
+// epilogue form 7 (round 6): a wave-private transposition buffer of 16 rows x 136 bytes per wave behind the ticket word
+constexpr int EPI_PITCH = 136, EPI_WAVE = 16 * EPI_PITCH, EPI_OFF = LDS_BYTES + 64;
+constexpr int LDS_BYTES_P = EPI_OFF + 8 * EPI_WAVE;    // 148 544 of 163 840
 
 struct Sched {
   int ntm_full, ntn, nstrip, q, r;           // full row tiles, column tiles, tiles of the ragged row strip; full tiles = 8 q + r
@@ -356,7 +358,56 @@ struct PipeP {
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      if (epi == 0) {   // plain 8-byte stores (bring-up reference)
+      if (epi == 7) {
+        // Round 6: the lane exchange through LDS instead of the register network.  The register forms above cost ~46 us per layer of pure
+        // instruction issue (conversion, 32 v_permlane16_swap with their wait states, DPP + select: measured with the stores compiled
+        // out, profiles/r06_g256p_epilogue.txt).  Here a fragment row (16 output rows x the wave's 64 columns = 2 KiB of bf16) goes
+        // through a wave-private LDS buffer: four ds_write_b64 (lane (pr, g) writes columns 16 j + 4 g .. + 3 of row pr; 136-byte row
+        // pitch: the sixteen lanes of a write group cover the 32 banks once) and two ds_read_b128 (lane l reads 16 bytes of row
+        // (l >> 3) + 8 h at column chunk l & 7), then two stores of eight whole 128-byte lines each - the store pattern of form 2.
+        // LDS operations of one wave execute in order, so row i + 1 is written behind the reads of row i without a wait; only the
+        // stores wait for their reads.  Same bytes as every other form.
+        const unsigned wbase = (unsigned)(EPI_OFF + wave * EPI_WAVE);
+        const unsigned waddr = wbase + (unsigned)(pr * EPI_PITCH + g * 8);
+        const int rr = ln >> 3, cc = ln & 7;
+        const unsigned raddr = wbase + (unsigned)(rr * EPI_PITCH + cc * 16);
+        const int rlim = M - m0 - wr - rr;                         // row 16 i + 8 h + rr of the wave's tile lies inside the matrix iff 16 i + 8 h < rlim
+        const unsigned vrow = (n0 + wc + cc * 8) < N ? (unsigned)(wr + rr) * ldc * 2u + (unsigned)(wc + cc * 8) * 2u : oobC;
+        const unsigned h8 = 8u * ldc * 2u;
+        auto put = [&](int i) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const u32x2 w = {pack2_bf16(acc[i][j][0], acc[i][j][1]), pack2_bf16(acc[i][j][2], acc[i][j][3])};
+            if (j == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(waddr), "v"(w) : "memory");
+            else if (j == 1) asm volatile("ds_write_b64 %0, %1 offset:32" ::"v"(waddr), "v"(w) : "memory");
+            else if (j == 2) asm volatile("ds_write_b64 %0, %1 offset:64" ::"v"(waddr), "v"(w) : "memory");
+            else asm volatile("ds_write_b64 %0, %1 offset:96" ::"v"(waddr), "v"(w) : "memory");
+          }
+        };
+        u32x4 d[2][2];
+        auto get = [&](int s_) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(d[s_][0]) : "v"(raddr) : "memory");
+          asm volatile("ds_read_b128 %0, %1 offset:1088" : "=v"(d[s_][1]) : "v"(raddr) : "memory");     // rows + 8: 8 x 136 bytes further
+        };
+        put(0);
+        get(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          // row i + 1 is converted and written behind the reads of row i (in-order LDS queue: no wait needed for the buffer), the
+          // stores of row i wait for its two reads only (the four writes of row i + 1 may still be in flight)
+          if (i + 1 < MI) {
+            put(i + 1);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          store16(d[i & 1][0], 16 * i < rlim ? vrow : oobC, soff + (unsigned)i * rstep);
+          store16(d[i & 1][1], 16 * i + 8 < rlim ? vrow + h8 : oobC, soff + (unsigned)i * rstep);
+          if (i + 1 < MI) get((i + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (epi == 0) {   // plain 8-byte stores (bring-up reference)
         const int cb = wc + 4 * g;
         unsigned vb[NI];
 #pragma unroll

@@ -1249,7 +1249,8 @@ def test_persistent_fused_convolution_is_bit_identical(env):
     process, so the cases run in a child interpreter."""
     import subprocess
     import sys
-    e = dict(os.environ, MUSE_CONV_PERSIST="1", MUSE_CONV_PERSIST_MIN="0", **env)
+    e = dict(os.environ, MUSE_CONV_PERSIST="1", MUSE_CONV_PERSIST_MIN="0")
+    e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
                         "test_conv_with_fused_groupnorm_input_is_bit_identical"], capture_output=True, text=True, timeout=600, env=e)
     assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
