@@ -92,9 +92,14 @@ class _GeneralFn(torch.autograd.Function):
     def forward(ctx, model, input_ids, enc, labels, label_smoothing, cond_dropout_prob, cond_uniforms, need_grad, *params):
         model._drop_step_caches()
         model.__dict__["_act_cache_on"] = bool(need_grad)
-        with model._gemm_mode():
-            logits, loss, tape = model._gen_forward(input_ids, enc, labels, label_smoothing, cond_dropout_prob, cond_uniforms, need_grad)
-        model.__dict__["_act_cache_on"] = False
+        try:
+            with model._gemm_mode():
+                logits, loss, tape = model._gen_forward(input_ids, enc, labels, label_smoothing, cond_dropout_prob, cond_uniforms, need_grad)
+        except BaseException:
+            model._drop_step_caches()      # a forward that raised keeps no activation copies / operand images alive
+            raise
+        finally:
+            model.__dict__["_act_cache_on"] = False
         ctx.model, ctx.tape = model, tape
         ctx.enc_grad = bool(need_grad and enc is not None and enc.requires_grad)
         ctx.set_materialize_grads(False)

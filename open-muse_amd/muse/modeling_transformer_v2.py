@@ -181,9 +181,14 @@ class _UViTFn(torch.autograd.Function):
     def forward(ctx, model, input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad, *params):
         model._drop_step_caches()
         model.__dict__["_act_cache_on"] = bool(need_grad)
-        with model._gemm_mode():
-            logits, loss, tape = model._run_forward(input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad)
-        model.__dict__["_act_cache_on"] = False
+        try:
+            with model._gemm_mode():
+                logits, loss, tape = model._run_forward(input_ids, enc, cond, micro, labels, label_smoothing, loss_weight, need_grad)
+        except BaseException:
+            model._drop_step_caches()      # a forward that raised keeps no activation copies / operand images alive
+            raise
+        finally:
+            model.__dict__["_act_cache_on"] = False
         ctx.model, ctx.tape = model, tape
         ctx.set_materialize_grads(False)
         if loss is None:

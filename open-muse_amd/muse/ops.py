@@ -132,7 +132,7 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
             gemm(A, B, ws, M, N, K, la=0, lb=0, lda=lda, ldb=ldb, ldc=N, a_off=a_off, b_off=b_off, alpha=alpha, split_k=sk, split_stride=M * N)
             check(lib().muse_sum_slices_epilogue(ws.data_ptr(), sk, M * N, ptr(bias), ptr(residual), ldr, C_.data_ptr() + c_off * _esz(C_),
                                                  dt(C_), ldc, M, N, stream()), "muse_sum_slices_epilogue")
-            return C_
+            return _touched(C_)
     # (Measured and dropped, round 5: the ragged last row tile of M = 16448 as a launch of its own wherever it saves a round of the
     #  256-CU chip - N = 6144 / 3072 / 2048: the step came out 0.45 ms SLOWER, 53.08 against 52.64 ms same box, transformer alone 33.34
     #  against 32.85: the extra launches cost more than the rounds, and in the step other streams fill the tail anyway.)
@@ -941,6 +941,8 @@ def _attention_x3_bwd_blocks(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha,
             check(lib().muse_attention_x3_bwd(C.byref(d), pdo + qi * 256 * lddo * 4, lddo, Sq * lddo, lse[qi].data_ptr(),
                                               pq + qi * 256 * ldq_ * 4, ldq_, Sq * ldq_, pk + kj * 256 * ldk_ * 4, ldk_, Skv * ldk_,
                                               pv + kj * 256 * ldv_ * 4, ldv_, Skv * ldv_, None, 0, None, 0, None, 0, stream()), "muse_attention_x3_bwd")
+    for t in (dq, dk, dv):
+        _touched(t)            # (written through raw pointers: cached operand planes of their previous contents must not be found)
     for t in dqp[1:]:
         dq.add_(t)
     for t in dkp[1:]:
@@ -1283,10 +1285,11 @@ def cast_to_bf16(src, dst=None):
 
 def cast_to_f32(src, dst=None):
     require_gpu(src)
+    given = dst is not None
     if dst is None:
         dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
     check(lib().muse_cast_bf16_to_f32(src.data_ptr(), dst.data_ptr(), src.numel(), stream()), "muse_cast_bf16_to_f32")
-    return dst
+    return _touched(dst) if given else dst
 
 
 def mask_sample(tokens, class_ids, timesteps, noise, mask_id, codebook_size, min_masking_rate=0.0):
@@ -1902,7 +1905,7 @@ def scale_rows_(x, w, num, den, cols):
     require_gpu(x, w, num, den)
     check(lib().muse_scale_rows(x.data_ptr(), w.data_ptr(), num.data_ptr(), den.data_ptr(), x.shape[0], cols, x.stride(0), stream()),
           "muse_scale_rows")
-    return x
+    return _touched(x)
 
 
 def probe_tr16(addr):
