@@ -170,6 +170,16 @@ int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, int64_t lddo
  * (*_planes, optional: the result ALSO as the bf16 operand planes of the products that read it - muse_gemm_x3 - so that no split pass
  *  runs over it: the hi plane is addressed exactly like the f32 tensor (same strides, in elements), the lo plane sits *_lo elements
  *  behind it; NULL = f32 only) */
+/* Block-by-block form of the longer sequences (round 6; reference modeling_transformer_v2.py:757-792 at the 1024 tokens of BASELINE config 4):
+ * muse_attention_x3_fwd / _bwd run per (256 query rows, <= 256 keys) block pair, these two put the pieces together.
+ * _merge: part[j] [batch*seq, heads*64] f32 (j < nk <= 8, part_stride elements apart) = key block j's softmax times its values, lp[j]
+ *   [seq/256][batch*heads][256] (lp_stride apart) its log-sum-exp: lse = log sum_j exp(lp_j), out = sum_j exp(lp_j - lse) part_j; writes out,
+ *   lse [seq/256][batch*heads][256] and optionally out's (hi, lo) bf16 operand planes (out_planes, lo plane out_lo elements behind).
+ * muse_sum_parts_strided: out[r, 0..cols) (row pitch ldo, += when accumulate) = sum over j < n of parts[j*part_stride + r*cols + c]. */
+int muse_attention_x3_merge(const float* part, int64_t part_stride, const float* lp, int64_t lp_stride, int32_t nk, float* out, float* lse,
+                            void* out_planes, int64_t out_lo, int32_t batch, int32_t seq, int32_t heads, void* stream);
+int muse_sum_parts_strided(const float* parts, int64_t part_stride, int32_t n, int64_t rows, int32_t cols, float* out, int64_t ldo,
+                           int32_t accumulate, void* stream);
 /* packed self-attention: qkv [B*S, 3*H] (q | k | v, H = heads*head_dim: the fused QKV projection), ctx [B*S, H], dqkv [B*S, 3*H] */
 int muse_attention_fwd(const void* qkv, void* ctx, float* lse, int32_t batch, int32_t seq, int32_t heads,
                        int32_t head_dim, float alpha, void* stream);

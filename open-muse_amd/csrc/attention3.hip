@@ -389,3 +389,89 @@ extern "C" int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, i
   return nkb_of(d->seq_kv) == 8 ? launch(bwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
                                 : launch(bwd_kernel<3>, P, d->batch * d->heads, lds, (hipStream_t)stream);
 }
+
+// ---- block-by-block form of the longer sequences (round 6: BASELINE config 4's 1024 tokens; muse/ops.py attention_x3_blocked) -------------------
+// The one-tile kernels above run per (256 query rows, <= 256 keys) block pair; these two row kernels put the pieces together.
+//
+// muse_attention_x3_merge: softmax over ALL keys from the key blocks' partial results.  part[j] [B * S, H] f32 = softmax over key block j times
+// its values, lp[j][qi][b * nh + h][r] its log-sum-exp (query block qi, row r of 256): lse = log sum_j exp(lp_j), out = sum_j exp(lp_j - lse) part_j,
+// f32 throughout.  Also writes lse [S / 256][B * nh][256] (what the block pairs' backward reads) and - optionally - the (hi, lo) operand planes of out
+// for the output projection.  One workgroup per token row, thread t owns four channels of head t / 16 (head_dim 64).
+namespace attn3m {
+constexpr int MAXB = 8;
+struct MergeParams {
+  const float* part; const float* lp; float* out; float* lse; bf16_t* planes;
+  long part_stride, lp_stride, lo;     // elements between key blocks' partials / their lse arrays; hi -> lo plane distance
+  int nk, B, S, nh;
+};
+__global__ __launch_bounds__(256) void merge_kernel(MergeParams P) {
+  const int H = P.nh * 64;
+  for (long row = blockIdx.x; row < (long)P.B * P.S; row += gridDim.x) {
+    const int b = (int)(row / P.S), s = (int)(row - (long)b * P.S), qi = s >> 8, r = s & 255;
+    for (int c = threadIdx.x * 4; c < H; c += 1024) {
+      const int h = c >> 6;
+      const long li = ((long)qi * P.B * P.nh + (long)b * P.nh + h) * 256 + r;
+      float l[MAXB], m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < MAXB; ++j)
+        if (j < P.nk) { l[j] = P.lp[j * P.lp_stride + li]; m = fmaxf(m, l[j]); }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXB; ++j)
+        if (j < P.nk) sum += expf(l[j] - m);
+      const float lse = m + logf(sum);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < MAXB; ++j)
+        if (j < P.nk) acc += expf(l[j] - lse) * *(const f32x4*)(P.part + j * P.part_stride + row * H + c);
+      *(f32x4*)(P.out + row * H + c) = acc;
+      if ((c & 63) == 0) P.lse[li] = lse;
+      if (P.planes) {
+        u32x2 hi, lo;
+        split4_values(acc[0], acc[1], acc[2], acc[3], hi, lo);
+        *(u32x2*)(P.planes + row * H + c) = hi;
+        *(u32x2*)(P.planes + P.lo + row * H + c) = lo;
+      }
+    }
+  }
+}
+// muse_sum_parts_strided: out[r, 0..cols) (row pitch ldo; += when accumulate) = sum_j parts[j * part_stride + r * cols + c] in the order j = 0, 1, ...
+// - the partial gradients of the block pairs (dq over key blocks, dk / dv over query blocks) into the column block of a packed gradient.
+struct SumParams { const float* parts; float* out; long part_stride, rows, ldo; int n, cols, accumulate; };
+__global__ __launch_bounds__(256) void sum_parts_kernel(SumParams P) {
+  const long per_row = P.cols >> 2, total = P.rows * per_row;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / per_row, c = (i - r * per_row) * 4;
+    f32x4 acc = *(const f32x4*)(P.parts + r * P.cols + c);
+    for (int j = 1; j < P.n; ++j) acc += *(const f32x4*)(P.parts + j * P.part_stride + r * P.cols + c);
+    float* o = P.out + r * P.ldo + c;
+    if (P.accumulate) acc += *(const f32x4*)o;
+    *(f32x4*)o = acc;
+  }
+}
+}  // namespace attn3m
+
+extern "C" int muse_attention_x3_merge(const float* part, int64_t part_stride, const float* lp, int64_t lp_stride, int32_t nk, float* out, float* lse,
+                                       void* out_planes, int64_t out_lo, int32_t batch, int32_t seq, int32_t heads, void* stream) {
+  if (nk < 1 || nk > attn3m::MAXB || batch <= 0 || seq <= 0 || (seq & 255) || heads <= 0) return nk < 1 || nk > attn3m::MAXB || (seq & 255) ? MUSE_ERR_UNSUPPORTED : 0;
+  if ((((uintptr_t)part) | ((uintptr_t)out)) & 15 || (part_stride & 3) || (out_planes && ((((uintptr_t)out_planes) & 7) || (out_lo & 3) || out_lo <= 0)))
+    return MUSE_ERR_ALIGN;
+  attn3m::MergeParams P;
+  P.part = part; P.lp = lp; P.out = out; P.lse = lse; P.planes = (bf16_t*)out_planes;
+  P.part_stride = part_stride; P.lp_stride = lp_stride; P.lo = out_lo; P.nk = nk; P.B = batch; P.S = seq; P.nh = heads;
+  const long rows = (long)batch * seq;
+  hipLaunchKernelGGL(attn3m::merge_kernel, dim3((unsigned)(rows < 65536 ? rows : 65536)), dim3(256), 0, (hipStream_t)stream, P);
+  return (int)hipGetLastError();
+}
+
+extern "C" int muse_sum_parts_strided(const float* parts, int64_t part_stride, int32_t n, int64_t rows, int32_t cols, float* out, int64_t ldo,
+                                      int32_t accumulate, void* stream) {
+  if (n < 1 || rows <= 0 || cols <= 0) return n < 1 ? MUSE_ERR_BAD_ARG : 0;
+  if ((cols & 3) || (ldo & 3) || (part_stride & 3) || ((((uintptr_t)parts) | ((uintptr_t)out)) & 15)) return MUSE_ERR_ALIGN;
+  attn3m::SumParams P;
+  P.parts = parts; P.out = out; P.part_stride = part_stride; P.rows = rows; P.ldo = ldo; P.n = n; P.cols = cols; P.accumulate = accumulate;
+  const long total = rows * (cols >> 2);
+  long g = (total + 255) / 256;
+  hipLaunchKernelGGL(attn3m::sum_parts_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, P);
+  return (int)hipGetLastError();
+}

@@ -903,9 +903,12 @@ def _attention_x3_fwd_blocks(q, k, v, B, Sq, Skv, nh, hd, alpha):
     lse = torch.empty((nq, B * nh, 256), dtype=torch.float32, device=dev)
     e0 = _prof_begin()
     if nk == 1:
+        planes = x3_new_planes(ctx)          # ctx feeds the output projection: every block writes its rows of the operand planes too
         for qi in range(nq):
             d = _x3_block_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha, qi, 0, kb)
-            check(lib().muse_attention_x3_fwd(C.byref(d), lse[qi].data_ptr(), None, 0, stream()), "muse_attention_x3_fwd")
+            pp = None if planes is None else planes.data_ptr() + qi * 256 * H * 2
+            check(lib().muse_attention_x3_fwd(C.byref(d), lse[qi].data_ptr(), pp, ctx.numel() if planes is not None else 0, stream()), "muse_attention_x3_fwd")
+        x3_put_planes(ctx, planes)
     else:
         part = torch.empty((nk, B * Sq, H), dtype=torch.float32, device=dev)
         lp = torch.empty((nk, nq, B * nh, 256), dtype=torch.float32, device=dev)
@@ -913,11 +916,10 @@ def _attention_x3_fwd_blocks(q, k, v, B, Sq, Skv, nh, hd, alpha):
             for qi in range(nq):
                 d = _x3_block_desc(q, k, v, part[kj], B, Sq, Skv, nh, hd, alpha, qi, kj, kb)
                 check(lib().muse_attention_x3_fwd(C.byref(d), lp[kj, qi].data_ptr(), None, 0, stream()), "muse_attention_x3_fwd")
-        torch.logsumexp(lp, dim=0, out=lse)
-        w = torch.exp(lp - lse)                                                       # [nk, nq, B*nh, 256]
-        # weights per (key block, image, row, head) against part [nk, B, Sq, nh, hd]
-        w = w.view(nk, nq, B, nh, 256).permute(0, 2, 1, 4, 3).reshape(nk, B, Sq, nh, 1)
-        torch.sum(part.view(nk, B, Sq, nh, hd) * w, dim=0, out=ctx.view(B, Sq, nh, hd))
+        planes = x3_new_planes(ctx)          # ctx feeds the output projection: its operand planes come out of the merge kernel
+        check(lib().muse_attention_x3_merge(part.data_ptr(), part[0].numel(), lp.data_ptr(), lp[0].numel(), nk, ctx.data_ptr(), lse.data_ptr(),
+                                            ptr(planes), ctx.numel(), B, Sq, nh, stream()), "muse_attention_x3_merge")
+        x3_put_planes(ctx, planes)
     _prof_end(e0, "attn_fwd_bf16x3", 4.0 * B * nh * Sq * Skv * hd)
     return ctx, lse
 
@@ -930,9 +932,14 @@ def _attention_x3_bwd_blocks(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha,
     nk, kb = (Skv // 256, 256) if Skv > 256 else (1, Skv)
     dev = q.device
     pdo, lddo = _row_view(dctx, H)
-    dqp = [dq] + [torch.empty((B * Sq, H), dtype=torch.float32, device=dev) for _ in range(nk - 1)]       # dq partial of key block kj
-    dkp = [dk] + [torch.empty((B * Skv, H), dtype=torch.float32, device=dev) for _ in range(nq - 1)]      # dk / dv partial of query block qi
-    dvp = [dv] + [torch.empty((B * Skv, H), dtype=torch.float32, device=dev) for _ in range(nq - 1)]
+    # partial gradients: dq of key block kj, dk / dv of query block qi - one contiguous stack each, folded by ONE row kernel into the
+    # caller's (possibly strided) views; a single block writes the view directly
+    dqs = None if nk == 1 else torch.empty((nk, B * Sq, H), dtype=torch.float32, device=dev)
+    dks = None if nq == 1 else torch.empty((nq, B * Skv, H), dtype=torch.float32, device=dev)
+    dvs = None if nq == 1 else torch.empty((nq, B * Skv, H), dtype=torch.float32, device=dev)
+    dqp = [dq] if dqs is None else list(dqs)
+    dkp = [dk] if dks is None else list(dks)
+    dvp = [dv] if dvs is None else list(dvs)
     e0 = _prof_begin()
     for qi in range(nq):
         for kj in range(nk):
@@ -941,14 +948,12 @@ def _attention_x3_bwd_blocks(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha,
             check(lib().muse_attention_x3_bwd(C.byref(d), pdo + qi * 256 * lddo * 4, lddo, Sq * lddo, lse[qi].data_ptr(),
                                               pq + qi * 256 * ldq_ * 4, ldq_, Sq * ldq_, pk + kj * 256 * ldk_ * 4, ldk_, Skv * ldk_,
                                               pv + kj * 256 * ldv_ * 4, ldv_, Skv * ldv_, None, 0, None, 0, None, 0, stream()), "muse_attention_x3_bwd")
+    for stack, g, rows in ((dqs, dq, B * Sq), (dks, dk, B * Skv), (dvs, dv, B * Skv)):
+        if stack is not None:
+            pg, ldg = _row_view(g, H)
+            check(lib().muse_sum_parts_strided(stack.data_ptr(), stack[0].numel(), stack.shape[0], rows, H, pg, ldg, 0, stream()), "muse_sum_parts_strided")
     for t in (dq, dk, dv):
         _touched(t)            # (written through raw pointers: cached operand planes of their previous contents must not be found)
-    for t in dqp[1:]:
-        dq.add_(t)
-    for t in dkp[1:]:
-        dk.add_(t)
-    for t in dvp[1:]:
-        dv.add_(t)
     _prof_end(e0, "attn_bwd_bf16x3", 10.0 * B * nh * Sq * Skv * hd)
     return dq, dk, dv
 
