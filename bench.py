@@ -796,7 +796,8 @@ def main():
         ceil_rows = {
             "conv_bf16x3_dma": ("MFMA issue at the clock the kernel holds (1.72 GHz, power-limited): 3 x 8.155 TFLOP / (2.5 PF x 1.72 / 2.4)", 13.7,
                                 _ms("conv_bf16x3_dma")),
-            "gemm_fwd_dx": ("K loop bound by LDS cycles (2500 of 2048 MFMA cycles per K-tile) + whole 256^2 tiles on 256 CUs + 82 us tile change per layer "
+            "gemm_fwd_dx": ("K loop bound by the operand stream from L2 into LDS (2500 cycles per K-tile against 2048 of MFMA: 26-28 B/clk/CU delivered, 32 needed) + "
+                            "whole 256^2 tiles on 256 CUs + 82 us tile change per layer "
                             "(46 us register epilogue + 36 us stores, ablation)", 13.1, _ms("gemm_bf16_NN", "gemm_bf16_NT")),
             "gemm_dw": ("the same K loop at K = 16448, five slices alone on the chip", 5.9, _ms("gemm_bf16_TT")),
             "attention": ("HBM floor of q, k, v, o (+ dO, dq, dk, dv) at 6.3 TB/s", 1.15, _ms("attn_fwd_bf16", "attn_bwd_bf16")),

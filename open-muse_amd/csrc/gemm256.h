@@ -165,6 +165,28 @@ struct Pipe {
   bf16x8 bk[2][NI];
   unsigned char* smem;
   int wave;
+#ifdef G256_L2_TOUCH   // experiment (scripts/exp/ablate256c.sh): one 4-byte load per lane and K-tile that touches every 128-byte line of the operand
+  unsigned touch_vo;   // tiles G256_L2_TOUCH K-tiles ahead, so that their LDS-DMA finds them in L2 (k-contiguous operands only)
+  unsigned touch_a, touch_b;   // destination registers of the touches in flight: reserved from one barrier to the next
+  __device__ __forceinline__ void touch_init(int m0, int n0, int M, int N, long lda, long ldb, int lane) {
+    const int row = wave * 32 + (lane & 31);
+    if (lane < 32) touch_vo = (m0 + row) < M ? (unsigned)((long)(m0 + row) * lda * 2) : da.oob;
+    else touch_vo = (n0 + row) < N ? (unsigned)((long)(n0 + row) * ldb * 2) : db.oob;
+    touch_a = touch_b = 0;
+  }
+  __device__ __forceinline__ void touch(int kt) {
+    if constexpr (AL == 0 && BL == 0) {
+      asm volatile("" ::"v"(touch_a), "v"(touch_b));   // (the previous touches have been waited for by the barrier's vmcnt(0))
+      const unsigned so = (unsigned)(kt + G256_L2_TOUCH) * 128u;
+      const bool ok = (unsigned)(kt + G256_L2_TOUCH) * 64u < (unsigned)da.kend;
+      // lanes 0-31 touch the A tile's rows, lanes 32-63 the B tile's: two descriptors -> two instructions, half the lanes each
+      unsigned va = lane_lo() && ok ? touch_vo : da.oob, vb = !lane_lo() && ok ? touch_vo : db.oob;
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(touch_a) : "v"(va), "s"(da.rs), "s"(so) : "memory");
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(touch_b) : "v"(vb), "s"(db.rs), "s"(so) : "memory");
+    }
+  }
+  static __device__ __forceinline__ bool lane_lo() { return (threadIdx.x & 63) < 32; }
+#endif
 
   static constexpr int nB(int x) { x = ((x % 16) + 16) % 16; return (x == GB1 || x == GBAR) ? NB : 0; }
   static constexpr int waitN(int g) {
@@ -185,14 +207,28 @@ struct Pipe {
   template <int STAGE, int Q>
   __device__ __forceinline__ void issue_piece(int kt) {
     if constexpr (Q < 4) da.template issue1<A_BASE + STAGE * TILE, Q>(smem, kt, wave);
+#if defined(G256_ABLATE_NO_B)      // timing experiments (scripts/exp/ablate256b.sh): the B operand's pieces are not issued at all ...
+    else (void)kt;
+#elif defined(G256_ABLATE_B_OOB)   // ... or issued out of range: the LDS write of a zero-filled piece happens, no memory traffic does
+    else db.template issue1<B_BASE + STAGE * TILE, Q - 4>(smem, 0x3fffff, wave);
+#else
     else db.template issue1<B_BASE + STAGE * TILE, Q - 4>(smem, kt, wave);
+#endif
   }
   __device__ __forceinline__ void prologue(int kt0) {
     da.template issue<A_BASE>(smem, kt0, wave);
     db.template issue<B_BASE>(smem, kt0, wave);
     if constexpr (SPREAD) {   // pieces 3..7 of the second tile follow in groups 0..4 of the first
       issue_piece<1, 0>(kt0 + 1); issue_piece<1, 1>(kt0 + 1); issue_piece<1, 2>(kt0 + 1);
+#if defined(G256_SPREAD_EARLY) && G256_SPREAD_EARLY == 1
+      issue_piece<1, 3>(kt0 + 1); issue_piece<1, 4>(kt0 + 1); issue_piece<1, 5>(kt0 + 1); issue_piece<1, 6>(kt0 + 1); issue_piece<1, 7>(kt0 + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#elif defined(G256_SPREAD_EARLY) && G256_SPREAD_EARLY == 2
+      issue_piece<1, 3>(kt0 + 1); issue_piece<1, 4>(kt0 + 1); issue_piece<1, 5>(kt0 + 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#else
       asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
     } else {
       da.template issue<A_BASE + TILE>(smem, kt0 + 1, wave);
       db.template issue<B_BASE + TILE>(smem, kt0 + 1, wave);
@@ -222,11 +258,23 @@ struct Pipe {
       }
 #endif
       fb.template read_range<S ^ 1, 0, 0, NI>(bk[0]);  // (after the last tile: a stale stage, never used)
+#ifdef G256_L2_TOUCH
+      touch(kt);
+#endif
     }
 #ifndef G256_ABLATE_NO_DMA
     if constexpr (SPREAD) {   // (tiles at or beyond kend are zero-fill pieces: the piece count per tile stays uniform for the waits)
+#if defined(G256_SPREAD_EARLY) && G256_SPREAD_EARLY == 1   // experiment: all eight pieces of tile t + 2 in the three groups behind the barrier (3 + 3 + 2)
+      if constexpr (G == GBAR) { issue_piece<S, 0>(kt + 2); issue_piece<S, 1>(kt + 2); issue_piece<S, 2>(kt + 2); }
+      if constexpr (G == GBAR + 1) { issue_piece<S, 3>(kt + 2); issue_piece<S, 4>(kt + 2); issue_piece<S, 5>(kt + 2); }
+      if constexpr (G == GBAR + 2) { issue_piece<S, 6>(kt + 2); issue_piece<S, 7>(kt + 2); }
+#elif defined(G256_SPREAD_EARLY) && G256_SPREAD_EARLY == 2  // experiment: two per group: 13, 14, 15 of tile t and group 0 of tile t + 1
+      if constexpr (G >= GBAR) { issue_piece<S, 2 * (G - GBAR)>(kt + 2); issue_piece<S, 2 * (G - GBAR) + 1>(kt + 2); }
+      else if constexpr (G == 0) { issue_piece<S ^ 1, 6>(kt + 1); issue_piece<S ^ 1, 7>(kt + 1); }
+#else
       if constexpr (G >= GBAR) issue_piece<S, G - GBAR>(kt + 2);
       else if constexpr (G < 8 - (16 - GBAR)) issue_piece<S ^ 1, G + (16 - GBAR)>(kt + 1);
+#endif
     }
 #endif
     if constexpr (G == GB1) fb.template read_range<S, 1, 0, NI>(bk[1]);
@@ -592,6 +640,9 @@ __device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, u
   } else {
     pp.da.init(Ap, p.lda, p.M, p.K, kend, m0, wave, lane);
     pp.db.init(Bp, p.ldb, p.N, p.K, kend, n0, wave, lane);
+#ifdef G256_L2_TOUCH
+    if constexpr (BKV == 64) pp.touch_init(m0, n0, p.M, p.N, p.lda, p.ldb, lane);
+#endif
   }
   if constexpr (X3) {
   } else if constexpr (BKV == 64) {

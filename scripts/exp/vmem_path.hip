@@ -120,6 +120,55 @@ template <int STRIDED> void run_mix(const char* name, unsigned char* buf, long b
   }
 }
 
+// mode 5: the GEMM's operand stream as it really is - 256 rows x 128 bytes per operand tile and K-tile, rows `pitch` bytes apart (a k-contiguous
+// [rows][K] bf16 operand: pitch = 2 K), 8 rows per wave-instruction; the 32 workgroups of an XCD (blockIdx & 7) share 4 A panels x 8 B panels
+// like the kernel's grouped raster does, XCDs work on different panels.  No compute: what the memory side delivers for this access pattern.
+__global__ __launch_bounds__(512, 2) void kpanel(unsigned char* base, unsigned pitch, int npan_a, int npan_b, int rounds, long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const long panel = 256L * pitch;
+  const int pa = bi % npan_a, pb = (bi / npan_a) % npan_b;
+  const unsigned char* A = base + ((long)xcd * (npan_a + npan_b) + pa) * panel;
+  const unsigned char* Bp = base + ((long)xcd * (npan_a + npan_b) + npan_a + pb) * panel;
+  const rsrc_t ra = make_rsrc(A, (unsigned)panel), rb = make_rsrc(Bp, (unsigned)panel);
+  unsigned vo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vo[j] = (unsigned)(((wave * 4 + j) * 8 + (lane >> 3)) * pitch + (lane & 7) * 16);
+  __syncthreads();
+  const long t0 = (long)__builtin_amdgcn_s_memtime();
+  unsigned koff = 0;
+  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(smem + (wave * 4 + j) * 1024), 16, (int)vo[j], (int)koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(smem + 32768 + (wave * 4 + j) * 1024), 16, (int)vo[j], (int)koff, 0, 0);
+    }
+    koff += 128;
+    if (koff >= pitch) koff = 0;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const long t1 = (long)__builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { stamps[blockIdx.x * 2] = t0; stamps[blockIdx.x * 2 + 1] = t1; }
+}
+void run_panel(unsigned char* buf, unsigned pitch, int na, int nb, long* d_st) {
+  const int rounds = 1024;
+  for (int g : {32, 256}) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(kpanel, dim3(g), dim3(512), 65536, 0, buf, pitch, na, nb, rounds, d_st);
+      CHECK(hipDeviceSynchronize());
+    }
+    std::vector<long> st(2 * g); CHECK(hipMemcpy(st.data(), d_st, sizeof(long) * 2 * g, hipMemcpyDeviceToHost));
+    std::vector<double> bpc(g);
+    for (int b = 0; b < g; ++b) bpc[b] = (double)rounds * 65536.0 / (double)(st[2 * b + 1] - st[2 * b]);
+    std::sort(bpc.begin(), bpc.end());
+    printf("operand panels, row pitch %5u B, %d A x %d B panels per XCD (%5.1f MB per XCD)   G %3d   B/tick/CU median %6.2f  min %6.2f  max %6.2f\n", pitch, na, nb,
+           (na + nb) * 256.0 * pitch * 1e-6, g, bpc[g / 2], bpc[0], bpc[g - 1]);
+  }
+}
+
 template <int MODE> void run(const char* name, unsigned char* buf, long stride, unsigned region, int rounds, long* d_st) {
   const int gs[] = {1, 8, 32, 64, 128, 256};
   for (int g : gs) {
@@ -158,6 +207,14 @@ int main() {
   run<2>("register loads, shared 1 MiB (L2)", buf, 0, 1u << 20, 512, d_st);
   CHECK(hipFuncSetAttribute((const void*)kmix<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   CHECK(hipFuncSetAttribute((const void*)kmix<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CHECK(hipFuncSetAttribute((const void*)kpanel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  run_panel(buf, 1536, 4, 8, d_st);      // K = 768
+  run_panel(buf, 6144, 4, 8, d_st);      // K = 3072
+  run_panel(buf, 12288, 4, 8, d_st);     // K = 6144
+  run_panel(buf, 6144 + 128, 4, 8, d_st);
+  run_panel(buf, 6144, 1, 1, d_st);      // every workgroup of an XCD on the same two panels
+  run_panel(buf, 6144, 2, 16, d_st);
+  run_panel(buf, 6144, 8, 4, d_st);
   run_mix<0>("DMA flat out + C stores 1 KiB contiguous", buf, big, d_st, 0);
   run_mix<1>("DMA flat out + C stores 8 rows x 128 B", buf, big, d_st, 0);
   run_mix<0>("DMA paced 2500/K-tile + stores contiguous", buf, big, d_st, 2500);
