@@ -865,7 +865,8 @@ class TrainStep:
             raise MuseHipError("TrainStep: next_pixel_values must be on the GPU")
         main = torch.cuda.current_stream(pixel_values.device)
         if self._pf_stream is None or self._pf_stream.device != pixel_values.device:
-            self._pf_stream = torch.cuda.Stream(device=pixel_values.device)
+            # MUSE_PF_PRIORITY: stream priority of the tokenizer's prefetch stream (default 0 = normal; 1 = low where the runtime offers it)
+            self._pf_stream = torch.cuda.Stream(device=pixel_values.device, priority=int(os.environ.get("MUSE_PF_PRIORITY", "0")))
         side = self._pf_stream
         side.wait_stream(main)                      # the images (and the previous use of the tokenizer's buffers) are ready
         with torch.cuda.stream(side):
