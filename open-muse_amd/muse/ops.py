@@ -621,6 +621,7 @@ def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
 # instrumented serial step of bench.py): 5 slices = 720 blocks = 2.8 rounds of the chip (1114 TFLOP/s alone; 1 slice: 798).
 WGRAD_GROUP = int(os.environ.get("MUSE_WGRAD_GROUP", "1"))
 WGRAD_GROUP_SERIAL = int(os.environ.get("MUSE_WGRAD_GROUP_SERIAL", "5"))
+WGRAD_SEQ_SLICES = int(os.environ.get("MUSE_WGRAD_SEQ_SLICES", "1"))   # (experiment: see linear_wgrad_group)
 
 
 def sum_multi(jobs):
@@ -674,7 +675,22 @@ def linear_wgrad_group(items, colsums=None, split=None):
             flush_colsums(colsums)
         return
     e0 = _prof_begin()
-    check(lib().muse_gemm_group(arr, len(items), split, stream()), "muse_gemm_group")
+    seq = WGRAD_SEQ_SLICES if split == 1 else 1
+    if seq > 1:
+        # experiment (round 6, MUSE_WGRAD_SEQ_SLICES): the token dimension cut into `seq` launches that accumulate into dw one after the other -
+        # no workspace, no reduction, the same tiles, but a workgroup of the dW stream holds its CU a `seq`-th as long (the step's
+        # critical path is the main stream's latency: profiles/r06_ceiling.md)
+        base = [(d.A, d.B, d.K, d.accumulate) for d in arr]
+        for i in range(seq):
+            for d, (a0, b0, T_, acc0) in zip(arr, base):
+                nk = (T_ + 63) // 64
+                k0 = (nk * i // seq) * 64
+                k1 = min(T_, (nk * (i + 1) // seq) * 64) if i + 1 < seq else T_
+                d.A, d.B, d.K = a0 + k0 * d.lda * 2, b0 + k0 * d.ldb * 2, k1 - k0
+                d.accumulate = acc0 if i == 0 else 1
+            check(lib().muse_gemm_group(arr, len(items), 1, stream()), "muse_gemm_group")
+    else:
+        check(lib().muse_gemm_group(arr, len(items), split, stream()), "muse_gemm_group")
     _prof_end(e0, "gemm_bf16_TT", sum(2.0 * N * K * T_ for N, K, T_ in meta))
     jobs = []
     if split > 1:
