@@ -100,3 +100,41 @@ def test_bf16x3_operand_image_cache_host_logic(monkeypatch):
     pl = ops.Planes(torch.zeros((2, 256, 128), dtype=torch.bfloat16))
     assert tuple(pl.shape) == (256, 128) and pl.dtype == torch.float32 and pl.stride() == (128, 1) and pl.stride(0) == 128
     assert pl.dim() == 2 and pl.numel() == 256 * 128 and pl.is_contiguous() and ops.split_planes(pl) is pl.planes and len(calls) == 9
+
+
+def test_bf16x3_attention_shape_logic_and_step_timeline_on_cpu(tmp_path):
+    """host logic added in round 6: which sequence shapes the bf16x3 attention takes in one tile / block by block / not at all
+    (ops.attention_x3_supported / attention_x3_blocked), and scripts/step_timeline.py on a synthetic kernel trace (two steps of three
+    streams: the per-bin busy shares add up)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    from muse import ops
+    for sq, skv, ok, blocked in [(256, 256, True, False), (256, 77, True, False), (256, 96, True, False), (256, 128, False, False),
+                                 (1024, 1024, True, True), (1024, 77, True, True), (512, 512, True, True), (512, 300, False, True),
+                                 (384, 384, False, True), (128, 128, False, False)]:
+        assert ops.attention_x3_supported(sq, skv, 64) == ok, (sq, skv)
+        assert ops.attention_x3_blocked(sq, skv) == blocked, (sq, skv)
+    assert not ops.attention_x3_supported(1024, 1024, 48)
+    # a synthetic trace: steps start with mask_sample_kernel on stream 1 every 10 ms; stream 2 busy the first half of each step
+    rows = ["Kind,Start_Timestamp,End_Timestamp,Kernel_Name,Queue_Id,Stream_Id"]
+    for st in range(4):
+        t0 = st * 10_000_000
+        rows.append(f'KERNEL_DISPATCH,{t0},{t0 + 50_000},"mask_sample_kernel(long)",1,1')
+        rows.append(f'KERNEL_DISPATCH,{t0 + 100_000},{t0 + 9_900_000},"void g256p::kernel<unsigned short, 0, 0>(g256p::PArgs)",1,1')
+        rows.append(f'KERNEL_DISPATCH,{t0},{t0 + 5_000_000},"void cslab::conv_slab_kernel<true>(cdma::Params)",2,2')
+    trace = tmp_path / "t_kernel_trace.csv"
+    trace.write_text("\n".join(rows) + "\n")
+    spec = importlib.util.spec_from_file_location("step_timeline", os.path.join(ROOT, "scripts", "step_timeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old_argv, old_out = sys.argv, sys.stdout
+    sys.argv, sys.stdout = ["step_timeline.py", str(trace), "--dump", str(tmp_path / "step.csv")], io.StringIO()
+    try:
+        mod.main()
+        out = sys.stdout.getvalue()
+    finally:
+        sys.argv, sys.stdout = old_argv, old_out
+    assert "step of 10.00 ms" in out and "gemmNN" in out and "conv" in out
+    lines = [l for l in out.splitlines() if " ms | " in l]
+    assert len(lines) >= 10 and lines[2].split("|")[2].strip().startswith("1.00") and lines[7].split("|")[2].strip().startswith("0.00")
+    assert (tmp_path / "step.csv").read_text().count("\n") >= 3
