@@ -634,11 +634,14 @@ def main():
             # per-kernel timing needs the kernels one at a time: no token prefetch, weight gradients on the main stream
             step._pf = None
             ws, model.wgrad_stream = model.wgrad_stream, False
-            step(px, cls)              # one un-timed step in this serial configuration first: the tokenizer's buffers now come from the
-            torch.cuda.synchronize()   # main stream's allocator pool (they lived on the prefetch stream), clocks and caches are warm
-            ops.profile_start()
-            step(px, cls)
-            prof = ops.profile_stop(with_kind=True)
+            # (the instrumented step times the kernels the TIMED step ran: beside a train step the tokenizer's fused convolutions are the
+            #  launch-per-tile ones - muse.TrainStep switches the persistent form off around its prefetch -, alone they are the persistent ones)
+            with ops.conv_persistent(not prefetch):
+                step(px, cls)              # one un-timed step in this serial configuration first: the tokenizer's buffers now come from the
+                torch.cuda.synchronize()   # main stream's allocator pool (they lived on the prefetch stream), clocks and caches are warm
+                ops.profile_start()
+                step(px, cls)
+                prof = ops.profile_stop(with_kind=True)
             model.wgrad_stream = ws
             prof_bytes.update(ops.PROF_BYTES)
             # the tokenizer once more with the GroupNorm applied by its own kernel (the two-kernel route the fused convolution replaced):

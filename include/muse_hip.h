@@ -385,6 +385,10 @@ int muse_groupnorm_nchunk(int32_t HW);
  * by muse_conv2d_nhwc_split2, without the write and re-read of the two planes.  Shapes: muse_conv2d_nhwc_gn_split2_ok (3x3, H and W
  * multiples of 16, Cin a multiple of 64); others return MUSE_ERR_UNSUPPORTED.  bias / residual / gn_partial as for _split2. */
 int muse_conv2d_nhwc_gn_split2_ok(int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS);
+/* muse_conv2d_nhwc_gn_split2's persistent form (one workgroup per CU walks the tiles; bit-identical; 6-8 % faster when the convolution has
+ * the chip to itself, slower for a step that shares the chip with it): mode 1 on (default unless MUSE_CONV_PERSIST=0), 0 off, -1 query;
+ * returns the mode in force.  A host-side switch read at launch time (round 6). */
+int muse_conv_persistent(int32_t mode);
 int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale, const float* gn_shift, const void* w_hi, const void* w_lo,
                                const float* bias, const float* residual, float* out, double* gn_partial, int32_t gn_groups,
                                int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS, void* stream);

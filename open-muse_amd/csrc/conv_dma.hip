@@ -1178,6 +1178,15 @@ extern "C" int muse_conv2d_nhwc_split2(const void* in_hi, const void* in_lo, con
 // gn_scale / gn_shift [batch][Cin] the per-image affine form of the normalisation (muse_groupnorm_scale_shift).  Same result, bit
 // for bit, as muse_groupnorm_silu_nhwc_split followed by muse_conv2d_nhwc_split2.  Patch-slab shapes only (H, W multiples of 16,
 // Cin a multiple of 64, Cin <= 2048); anything else returns MUSE_ERR_UNSUPPORTED and the caller keeps the two-kernel route.
+// Persistent form of the fused convolution on / off for the launches that follow on this host thread's behalf (mode 0 / 1; -1 = query).
+// Default: MUSE_CONV_PERSIST, else ON - the persistent kernel is 6-8 % faster whenever the convolution has the chip to itself (a tokenizer
+// or decoder pass on its own: BASELINE config 5, inline tokenizing, pre-encoding).  muse.TrainStep switches it OFF around the tokenizer
+// pass it enqueues BESIDE a train step: there a workgroup that holds its CU for a whole launch costs the step 2.2 ms (profiles/r06_ceiling.md).
+extern "C" int muse_conv_persistent(int32_t mode) {
+  static int state = []() { const char* e = getenv("MUSE_CONV_PERSIST"); return e ? atoi(e) : 1; }();
+  if (mode >= 0) state = mode;
+  return state;
+}
 extern "C" int muse_conv2d_nhwc_gn_split2_ok(int32_t batch, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KS) {
   const long M = (long)batch * H * W;
   return KS == 3 && (H % 16) == 0 && (W % 16) == 0 && (Cin % 64) == 0 && Cin <= 2048 && (Cout % 4) == 0 && M > 0 &&
@@ -1205,7 +1214,7 @@ extern "C" int muse_conv2d_nhwc_gn_split2(const float* x, const float* gn_scale,
   // CU gets at least MUSE_CONV_PERSIST_MIN tiles (default 2), Cin <= 256 (two scale / shift tables behind the LDS map) and the output
   // stays below 4 GiB (32-bit store offsets).  MUSE_CONV_PERSIST=0 keeps the launch-per-tile kernel; MUSE_CONV_PERSIST_GRID sets the
   // number of workgroups (default: one per CU).
-  static const int persist = []() { const char* e = getenv("MUSE_CONV_PERSIST"); return e ? atoi(e) : 0; }();
+  const int persist = muse_conv_persistent(-1);
   if (persist && Cin <= cslab::P_GSS_MAX_CIN && (long)p.M * p.N * 4 < (1L << 32) - 64) {
     static int ncu = 0, grid = 0, min_tiles = 2, min_given = 0;
     if (!ncu) {

@@ -129,6 +129,7 @@ SIGNATURES = {
                                 c_int, c_int, c_int, c_int, c_void_p],
     "muse_conv_in_direct": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "muse_conv2d_nhwc_gn_split2_ok": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "muse_conv_persistent": [c_int],
     "muse_conv2d_nhwc_gn_split2": [c_void_p] * 9 + [c_int] * 7 + [c_void_p],
     "muse_groupnorm_scale_shift": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "muse_groupnorm_silu_nhwc_split": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

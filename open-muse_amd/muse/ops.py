@@ -1524,6 +1524,23 @@ def upsample2x_split(x, B, H, W, C):
     return hi, lo
 
 
+class conv_persistent:
+    """with ops.conv_persistent(False): ... - the fused convolutions launched inside run on the launch-per-tile kernel (muse_conv_persistent):
+    what a tokenizer pass enqueued BESIDE a train step wants (muse.TrainStep); restored on exit"""
+
+    def __init__(self, on):
+        self.on = 1 if on else 0
+
+    def __enter__(self):
+        self.prev = lib().muse_conv_persistent(-1)
+        lib().muse_conv_persistent(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        lib().muse_conv_persistent(self.prev)
+        return False
+
+
 def conv_gn_split2_ok(B, H, W, Cin, Cout, KS):
     """shapes muse_conv2d_nhwc_gn_split2 takes (GroupNorm + SiLU + split fused into the patch-slab convolution)"""
     return bool(lib().muse_conv2d_nhwc_gn_split2_ok(B, H, W, Cin, Cout, KS))

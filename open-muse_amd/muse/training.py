@@ -869,7 +869,8 @@ class TrainStep:
             self._pf_stream = torch.cuda.Stream(device=pixel_values.device, priority=int(os.environ.get("MUSE_PF_PRIORITY", "0")))
         side = self._pf_stream
         side.wait_stream(main)                      # the images (and the previous use of the tokenizer's buffers) are ready
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.conv_persistent(False):
+            # (beside the step the launch-per-tile convolution: a persistent workgroup would hold its CU against the step's stream)
             tokens = self.vq_model.get_code(pixel_values)
             ev = torch.cuda.Event()
             ev.record(side)

@@ -74,7 +74,7 @@ final)  # validation of the committed tree: device, full GPU suite (printed erro
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${T}_smoke.txt 2>&1; echo "smoke exit $?" >> $O/${T}_smoke.txt; tail -2 $O/${T}_smoke.txt
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/pmc_$c
-    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prefetch > $O/pmc_$c.log 2>&1
+    MUSE_CONV_PERSIST=0 timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-prefetch > $O/pmc_$c.log 2>&1
     echo "$c exit $?"
   done
   f=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
@@ -87,7 +87,7 @@ final)  # validation of the committed tree: device, full GPU suite (printed erro
   timeout 1800 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err; echo "bench exit $?"; tail -c 400 $O/${T}_bench.err
   python scripts/bench_summary.py $O/${T}_bench.json
   rm -rf $O/prof_serial
-  MUSE_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-prefetch > $O/${T}_prof.txt 2>&1
+  MUSE_WGRAD_STREAM=0 MUSE_CONV_PERSIST=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-prefetch > $O/${T}_prof.txt 2>&1
   f=$(find $O/prof_serial -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${T}_kernel_stats.csv && head -14 "$f" | cut -c1-170
   find $O/prof_serial -name "*kernel_trace*" -size +8M -delete
   MUSE_BENCH_RCCL_DEBUG=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-extra --no-cpu-baseline 2>$O/${T}_dp1.err > $O/${T}_dp1.out

@@ -1243,7 +1243,7 @@ def test_conv_with_fused_groupnorm_input_is_bit_identical(B, H, W, Cin, Cout, re
 
 @pytest.mark.parametrize("env", [{"MUSE_CONV_PERSIST_GRID": "3"}, {"MUSE_CONV_PERSIST_GRID": "8"}, {"MUSE_CONV_PERSIST_TILES": "2", "MUSE_CONV_PERSIST_MIN": "0"}])
 def test_persistent_fused_convolution_is_bit_identical(env):
-    """conv_slab_persist_kernel<true> (round 6; MUSE_CONV_PERSIST=1, off by default: it loses on the concurrent step): the parity cases of
+    """conv_slab_persist_kernel<true> (round 6; the default whenever a tokenizer / decoder pass has the chip to itself and >= 2 tiles per CU - muse.TrainStep switches it off around the pass it enqueues beside a step): the parity cases of
     test_conv_with_fused_groupnorm_input_is_bit_identical with the persistent kernel taking every shape it can - workgroups that walk several
     tiles across image and N-tile changes (grid 3), one tile each (grid 8), k-tile workgroups.  The library reads its switches once per
     process, so the cases run in a child interpreter."""
