@@ -131,7 +131,7 @@ def leg_isolated(spec, fallback):
         return fallback()
 
 
-def uvit_leg_isolated(device, batch, seq, steps, f32=False, x3=False):
+def uvit_leg_isolated(device, batch, seq, steps, f32=False, x3=False, f16=False):
     """uvit_leg in a fresh process.  The U-ViT step is ~4500 small launches; at the end of this long-lived process (allocator state,
     Python heap of all the earlier legs) the same leg measured 205 ms per step against 163 ms in a process of its own, which is what a
     training job is - so it gets one (GPU memory of this process has been released by then)."""
@@ -139,14 +139,14 @@ def uvit_leg_isolated(device, batch, seq, steps, f32=False, x3=False):
     try:
         torch.cuda.empty_cache()
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--uvit-leg", f"{batch},{seq},{steps}" + (",f32" if f32 else "") + (",x3" if x3 else "")], capture_output=True, text=True,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--uvit-leg", f"{batch},{seq},{steps}" + (",f32" if f32 else "") + (",x3" if x3 else "") + (",f16" if f16 else "")], capture_output=True, text=True,
                            timeout=600, env=env)
         line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:   # noqa: BLE001  (a leg of `extra` must never take the bench line down)
         print(f"bench: config-4 leg {batch},{seq} did not run in a subprocess ({type(e).__name__}); running it in-process", file=sys.stderr)
         try:
-            out = uvit_leg(device, batch, seq, steps, f32, x3)
+            out = uvit_leg(device, batch, seq, steps, f32, x3, f16)
             out["note"] = f"in-process (subprocess failed: {type(e).__name__})"
         except Exception as e2:   # noqa: BLE001
             torch.cuda.empty_cache()
@@ -298,7 +298,7 @@ def latency_leg(device, timesteps=12):
     return out
 
 
-def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False):
+def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False, f16=False):
     """BASELINE.json config 4: configs/cc12m_uvit_clip.yaml MaskGiTUViT (UVIT_CC12M: 728.7 M parameters, 22 layers, hidden 1024, GLU 4096,
     1024-channel ResBlock / attention stages; block_num_heads 16 per SURVEY.md D3), synthetic CLIP states (77 x 768), tokens given,
     bf16 compute (fused self / cross attention, bf16 weight copies refreshed inside the AdamW kernel): forward + backward + FusedAdamW"""
@@ -312,7 +312,7 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False):
         M.MaskGiTUViT_v2._init_weights = init
     n_params = sum(p.numel() for p in model.parameters())
     assert n_params == 728725504, n_params          # the geometry GF_UVIT_FWD was counted on
-    model.to(device).train().set_compute_dtype("bf16x3" if x3 else (torch.float32 if f32 else torch.bfloat16))
+    model.to(device).train().set_compute_dtype("f16" if f16 else "bf16x3" if x3 else (torch.float32 if f32 else torch.bfloat16))
     g = torch.Generator(device=device).manual_seed(0)
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -345,9 +345,13 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False):
     out = {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 1), "batch": batch, "seq_len": seq,
            # against configs/cc12m_uvit_clip.yaml:102-103 (mixed_precision "no" + enable_tf32: 10-bit-mantissa products, f32 accumulate).
            # "narrower" legs are engineering figures, NOT config 4's number
-           "precision_vs_yaml": "wider" if f32 else ("class-equal" if x3 else "narrower"),
+           "precision_vs_yaml": "wider" if f32 else ("class-equal" if (x3 or f16) else "narrower"),
            "tflops": round(tf, 1), "mfma_frac": round(tf / (PEAK["bf16"] / 3 if x3 else PEAK["f32" if f32 else "bf16"]), 4), "loss": round(float(loss), 4), "parameters": n_params,
-           "dtype": ("bf16x3: f32 tensors, every product (linears, dX, dW: muse_gemm_x3 on four operand planes; the attention core: "
+           "dtype": ("f16: f32 tensors; every weight GEMM (linears, dX, dW) as ONE v_mfma_f32_16x16x32_f16 product of IEEE-half operand images with f32 "
+                     "accumulation - half's 10-bit mantissa is the TF32 operand format the yaml's enable_tf32 multiplies in (gfx950 has no xf32 MFMA); "
+                     "TF32's exponent range is covered by power-of-two operand scales (gradient operands x 2^10 x tokens, undone in alpha; "
+                     "clamped / flushed elements counted: f16_operand_stats); the attention core as in the bf16x3 leg (three bf16 products, tighter "
+                     "than TF32); f32 softmax, norms, GLU, residual stream, loss, AdamW; mfma_frac against the 2500 TFLOP/s half / bf16 peak") if f16 else ("bf16x3: f32 tensors, every product (linears, dX, dW: muse_gemm_x3 on four operand planes; the attention core: "
                      + ("muse_attention_x3_*" if seq == 256 else "muse_attention_x3_* block by block - 256 query rows against 256-key blocks (or the 77 text states), "
                                                                "key blocks merged by their log-sum-exps in f32 (ops.attention_x3_blocked)")
                      + ") as three bf16 MFMA products of hi / lo operand planes with f32 accumulation (<= 2^-16 relative per "
@@ -356,6 +360,9 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False):
                      "enable_tf32 (10-bit mantissa products); gfx950 has no xf32 MFMA") if f32 else
                     "bf16 weight-GEMM / attention operands, f32 accumulate, residual stream, norms, loss (the yaml itself sets mixed_precision: no)",
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    if f16:
+        sat, flushed = model.f16_stats()
+        out["f16_operand_stats"] = {"clamped": sat, "rounded_to_zero": flushed, "over": f"the {steps + 2} steps of this leg"}
     del model, opt
     torch.cuda.empty_cache()
     return out
@@ -514,7 +521,8 @@ def main():
         parts = args.uvit_leg.split(",")
         b, sq, st = (int(x) for x in parts[:3])
         torch.cuda.set_device(0)
-        print(json.dumps(uvit_leg(torch.device("cuda", 0), b, sq, st, f32=len(parts) > 3 and parts[3] == "f32", x3=len(parts) > 3 and parts[3] == "x3")))
+        print(json.dumps(uvit_leg(torch.device("cuda", 0), b, sq, st, f32=len(parts) > 3 and parts[3] == "f32", x3=len(parts) > 3 and parts[3] == "x3",
+                                  f16=len(parts) > 3 and parts[3] == "f16")))
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

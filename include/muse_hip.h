@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-enum { MUSE_F32 = 0, MUSE_BF16 = 1 };
+enum { MUSE_F32 = 0, MUSE_BF16 = 1, MUSE_F16 = 2 /* IEEE half: GEMM operands only (muse_gemm, muse_gemm_group) */ };
 enum { MUSE_ERR_BAD_ARG = -1, MUSE_ERR_ALIGN = -2, MUSE_ERR_UNSUPPORTED = -3 };
 
 int muse_version(void); /* ABI version of this header */
@@ -36,6 +36,11 @@ int muse_version(void); /* ABI version of this header */
  * Batch index z in [0,batch) addresses X + (z / zdiv) * sX0 + (z % zdiv) * sX1  (e.g. (image, head)).
  * Requirements: A, B 16-byte aligned; lda/ldb and batch strides multiples of 16 bytes; for a k-contiguous operand
  * with K % (16/elsize) != 0 the row must be physically padded with zeros up to the next 16-byte chunk.
+ * dtype MUSE_F16 (round 6): IEEE-half operands on v_mfma_f32_16x16x32_f16 with f32 accumulation and f32 output - 11 significant bits
+ * per operand = the TF32 operand format `enable_tf32` of configs/cc12m_uvit_clip.yaml:103 multiplies in (gfx950 has no xf32 MFMA), at
+ * the bf16 matrix rate; the narrower exponent is the caller's business (muse_cast_f32_to_f16 scales by a power of two, alpha undoes
+ * it).  Only the 256 x 256 LDS-DMA kernels carry it: M, N >= 128, K >= 64, no activation, batch / split_k as for bf16 operands with
+ * f32 output; anything else MUSE_ERR_UNSUPPORTED (muse_gemm_tile says so beforehand).
  */
 typedef struct muse_gemm_desc {
   const void* A;
@@ -44,7 +49,7 @@ typedef struct muse_gemm_desc {
   const void* bias;     /* f32 [N] or NULL: added per output column                       */
   const void* rowvec;   /* f32 [M] or NULL: added per output row                          */
   const void* residual; /* out_dtype [M, ldr] or NULL: added after the activation         */
-  int32_t dtype;        /* MUSE_F32 | MUSE_BF16 (A and B)                                  */
+  int32_t dtype;        /* MUSE_F32 | MUSE_BF16 | MUSE_F16 (A and B)                       */
   int32_t out_dtype;    /* MUSE_F32 | MUSE_BF16 (bf16 only with bf16 inputs)               */
   int32_t layout_a, layout_b;
   int32_t M, N, K;
@@ -287,6 +292,18 @@ int muse_sum_slices_epilogue(const float* ws, int32_t nslices, int64_t stride, c
 int muse_split_f32_to_bf16_cat3(const float* in, void* out, int64_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t mode,
                                 int32_t lo_pos, void* stream);
 int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* out = half(in * scale): the operand image of a MUSE_F16 product (round to nearest even, subnormals kept; a finite value beyond half's
+ * range becomes inf - the product turns NaN rather than silently wrong).  stats: NULL or int32[2], incremented by [0] the finite
+ * elements that overflowed, [1] the non-zero elements rounded to zero. */
+int muse_cast_f32_to_f16(const float* in, void* out, int64_t n, float scale, int32_t* stats, void* stream);
+/* What the producer entry points below that write operand images next to (or instead of) their f32 result - muse_glu_fwd_x3 / _bwd_x3,
+ * muse_norm_adaln_fwd_x3 / _bwd_x3, muse_attention_x3_fwd / _bwd / _merge - write as that image.  half = 0 (default): the (hi, lo) bf16
+ * planes of the "bf16x3" mode, as documented with each.  half = 1 ("f16" mode): ONE IEEE-half image [rows][cols] at the plane pointer =
+ * half(result * s), the bits muse_cast_f32_to_f16 makes of the f32 result, with s = 1 for forward results and s = grad_scale (a power
+ * of two) for the gradients the backward entry points produce; lo-plane distances are ignored; stats (device int32[2] or NULL): [0] is
+ * incremented per 4-element group that holds an inf / NaN half (muse_cast_f32_to_f16's overflow counter: a dynamic gradient scale backs
+ * off on it).  Process state (host code sets it around a pass: muse/ops.py f32_gemms_as_f16), not thread safe. */
+int muse_operand_images(int32_t half, float grad_scale, int32_t* stats);
 int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 
 /* prepare_inputs_and_labels (training/train_maskgit_imagenet.py:371-394) given the two uniform draws.

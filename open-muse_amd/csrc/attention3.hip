@@ -43,8 +43,11 @@ struct Params {
   float alpha;
   // optional: the same results ALSO as (hi, lo) bf16 operand planes for the products that read them (muse_gemm_x3): hi plane pointers
   // addressed like the f32 tensors (same strides, in elements), the lo plane lo_* elements behind
+  // ("f16" compute mode, img_format(): lo_* = -1 and the pointers receive ONE IEEE-half image half(x * img_scale) instead)
   bf16_t *outp, *dqp, *dkp, *dvp;
   long lo_out, lo_dq, lo_dk, lo_dv;
+  float img_scale;
+  int* img_stats;
 };
 
 struct FragB3 { bf16x8 h[C::KS], l[C::KS]; };     // B operand of a head-dim contraction, both planes
@@ -155,19 +158,15 @@ __device__ __forceinline__ void mma_seq3(const unsigned char* ih, const unsigned
 }
 // acc[db][r] = value of row n at column 32 db + 8 (r >> 2) + 4 h + (r & 3): 16-byte stores; planes (optional): the same four values
 // split into the hi / lo planes (8-byte stores), bit for bit what muse_split_f32_to_bf16x2 makes of the f32 result
-__device__ __forceinline__ void store_rows3(float* rowp, const f32x16 (&acc)[C::NDB], float scale, int h, bf16_t* hip = nullptr, long lo_off = 0) {
+__device__ __forceinline__ void store_rows3(float* rowp, const f32x16 (&acc)[C::NDB], float scale, int h, bf16_t* hip = nullptr, long lo_off = 0,
+                                            float img_scale = 1.f, int* img_stats = nullptr) {
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const f32x4 v = {acc[db][4 * q4] * scale, acc[db][4 * q4 + 1] * scale, acc[db][4 * q4 + 2] * scale, acc[db][4 * q4 + 3] * scale};
       if (rowp) *(f32x4*)(rowp + 32 * db + 8 * q4 + 4 * h) = v;
-      if (hip) {
-        u32x2 hi, lo;
-        split4_values(v[0], v[1], v[2], v[3], hi, lo);
-        *(u32x2*)(hip + 32 * db + 8 * q4 + 4 * h) = hi;
-        *(u32x2*)(hip + lo_off + 32 * db + 8 * q4 + 4 * h) = lo;
-      }
+      if (hip) store_image4(hip + 32 * db + 8 * q4 + 4 * h, lo_off, img_scale, img_stats, v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const Params P) {
   }
   l += xhalf(l);
   const long oo = b * P.bo + (long)q * P.ldo + hh * HD;
-  store_rows3(P.out + oo, o, 1.0f / l, g.h, P.outp ? P.outp + oo : nullptr, P.lo_out);
+  store_rows3(P.out + oo, o, 1.0f / l, g.h, P.outp ? P.outp + oo : nullptr, P.lo_out, P.img_scale, P.img_stats);
   if (g.h == 0) P.lse[(long)head * SQ + q] = m * P.alpha + __logf(l);
 }
 
@@ -279,7 +278,7 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
       mma_seq3(Ah, Al, g, kb, dp, dq);
     }
     const long oq = b * P.bdq + (long)q * P.lddq + hh * HD;
-    store_rows3(P.dq ? P.dq + oq : nullptr, dq, P.alpha, g.h, P.dqp ? P.dqp + oq : nullptr, P.lo_dq);
+    store_rows3(P.dq ? P.dq + oq : nullptr, dq, P.alpha, g.h, P.dqp ? P.dqp + oq : nullptr, P.lo_dq, P.img_scale, P.img_stats);
   }
   lds_barrier();       // everybody is done with the K, V planes; L2 / DS are written
   // ---------------- phase 2 ----------------
@@ -314,8 +313,8 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
       }
       if (valid) {
         const long ok = b * P.bdk + (long)key * P.lddk + hh * HD, ov = b * P.bdv + (long)key * P.lddv + hh * HD;
-        store_rows3(P.dk ? P.dk + ok : nullptr, dk, P.alpha, g.h, P.dkp ? P.dkp + ok : nullptr, P.lo_dk);
-        store_rows3(P.dv ? P.dv + ov : nullptr, dv, 1.0f, g.h, P.dvp ? P.dvp + ov : nullptr, P.lo_dv);
+        store_rows3(P.dk ? P.dk + ok : nullptr, dk, P.alpha, g.h, P.dkp ? P.dkp + ok : nullptr, P.lo_dk, P.img_scale, P.img_stats);
+        store_rows3(P.dv ? P.dv + ov : nullptr, dv, 1.0f, g.h, P.dvp ? P.dvp + ov : nullptr, P.lo_dv, P.img_scale, P.img_stats);
       }
     }
   }
@@ -359,7 +358,8 @@ extern "C" int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* 
   if (d->batch <= 0) return 0;
   Params P = base(d);
   P.out = (float*)d->o; P.lse = lse;
-  P.outp = (bf16_t*)o_planes; P.lo_out = o_lo;
+  const ImgFormat f = img_format(false);
+  P.outp = (bf16_t*)o_planes; P.lo_out = f.lo_sign < 0 ? -1 : o_lo; P.img_scale = f.scale; P.img_stats = f.stats;
   const int nkb = nkb_of(d->seq_kv);
   const size_t lds = 4 * (size_t)nkb * 32 * C::STR;
   return nkb == 8 ? launch(fwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
@@ -384,7 +384,9 @@ extern "C" int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, i
   P.dq = (float*)dq; P.lddq = lddq; P.bdq = bsdq;
   P.dk = (float*)dk; P.lddk = lddk; P.bdk = bsdk;
   P.dv = (float*)dv; P.lddv = lddv; P.bdv = bsdv;
-  P.dqp = (bf16_t*)dq_planes; P.lo_dq = dq_lo; P.dkp = (bf16_t*)dk_planes; P.lo_dk = dk_lo; P.dvp = (bf16_t*)dv_planes; P.lo_dv = dv_lo;
+  const ImgFormat f = img_format(true);
+  P.dqp = (bf16_t*)dq_planes; P.dkp = (bf16_t*)dk_planes; P.dvp = (bf16_t*)dv_planes; P.img_scale = f.scale; P.img_stats = f.stats;
+  P.lo_dq = f.lo_sign < 0 ? -1 : dq_lo; P.lo_dk = f.lo_sign < 0 ? -1 : dk_lo; P.lo_dv = f.lo_sign < 0 ? -1 : dv_lo;
   const size_t lds = 4 * (size_t)PLANE + 2 * SQ * sizeof(float);
   return nkb_of(d->seq_kv) == 8 ? launch(bwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
                                 : launch(bwd_kernel<3>, P, d->batch * d->heads, lds, (hipStream_t)stream);
@@ -401,8 +403,10 @@ namespace attn3m {
 constexpr int MAXB = 8;
 struct MergeParams {
   const float* part; const float* lp; float* out; float* lse; bf16_t* planes;
-  long part_stride, lp_stride, lo;     // elements between key blocks' partials / their lse arrays; hi -> lo plane distance
+  long part_stride, lp_stride, lo;     // elements between key blocks' partials / their lse arrays; hi -> lo plane distance (-1: half image)
   int nk, B, S, nh;
+  float img_scale;
+  int* img_stats;
 };
 __global__ __launch_bounds__(256) void merge_kernel(MergeParams P) {
   const int H = P.nh * 64;
@@ -426,12 +430,7 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeParams P) {
         if (j < P.nk) acc += expf(l[j] - lse) * *(const f32x4*)(P.part + j * P.part_stride + row * H + c);
       *(f32x4*)(P.out + row * H + c) = acc;
       if ((c & 63) == 0) P.lse[li] = lse;
-      if (P.planes) {
-        u32x2 hi, lo;
-        split4_values(acc[0], acc[1], acc[2], acc[3], hi, lo);
-        *(u32x2*)(P.planes + row * H + c) = hi;
-        *(u32x2*)(P.planes + P.lo + row * H + c) = lo;
-      }
+      if (P.planes) store_image4(P.planes + row * H + c, P.lo, P.img_scale, P.img_stats, acc[0], acc[1], acc[2], acc[3]);
     }
   }
 }
@@ -458,7 +457,8 @@ extern "C" int muse_attention_x3_merge(const float* part, int64_t part_stride, c
     return MUSE_ERR_ALIGN;
   attn3m::MergeParams P;
   P.part = part; P.lp = lp; P.out = out; P.lse = lse; P.planes = (bf16_t*)out_planes;
-  P.part_stride = part_stride; P.lp_stride = lp_stride; P.lo = out_lo; P.nk = nk; P.B = batch; P.S = seq; P.nh = heads;
+  const ImgFormat f = img_format(false);
+  P.part_stride = part_stride; P.lp_stride = lp_stride; P.lo = f.lo_sign < 0 ? -1 : out_lo; P.img_scale = f.scale; P.img_stats = f.stats; P.nk = nk; P.B = batch; P.S = seq; P.nh = heads;
   const long rows = (long)batch * seq;
   hipLaunchKernelGGL(attn3m::merge_kernel, dim3((unsigned)(rows < 65536 ? rows : 65536)), dim3(256), 0, (hipStream_t)stream, P);
   return (int)hipGetLastError();

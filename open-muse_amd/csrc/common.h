@@ -45,6 +45,33 @@ __device__ __forceinline__ void split4_values(float x0, float x1, float x2, floa
   split4(u32x4{__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)}, hi, lo);
 }
 
+// ---- operand images written by producer kernels -----------------------------------------------------------------------------------
+// A kernel whose f32 result feeds weight GEMMs also writes that result as the GEMMs' operand image, four values per call:
+//   lo_off > 0   "bf16x3" mode: the (hi, lo) bf16 planes, lo plane lo_off elements behind the hi plane (split4_values)
+//   lo_off < 0   "f16" mode: ONE IEEE-half image, half(x * scale) with scale a power of two (1 for forward results, the backward pass's
+//                gradient scale for gradients) - the bits muse_cast_f32_to_f16 makes of the f32 result; an overflow becomes inf (the
+//                product turns NaN: loud) and is counted in *stats (the host's dynamic gradient scale backs off on it)
+// Which of the two the *_x3 entry points write is process state set by muse_operand_images (rowops.hip); launchers ask img_format().
+struct ImgFormat { long lo_sign; float scale; int* stats; };      // lo_sign: -1 = half image, +1 = bf16 planes
+ImgFormat img_format(bool gradient);
+__device__ __forceinline__ void store_image4(bf16_t* p, long lo_off, float scale, int* stats, float x0, float x1, float x2, float x3) {
+  if (lo_off < 0) {
+    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+    typedef _Float16 h4_ __attribute__((ext_vector_type(4)));
+    const h4_ h = {(_Float16)(x0 * scale), (_Float16)(x1 * scale), (_Float16)(x2 * scale), (_Float16)(x3 * scale)};
+    const u32x2 w = __builtin_bit_cast(u32x2, h);
+    *(u32x2*)p = w;
+    // exponent all ones in any of the four halves (inf / NaN): rare, one atomic per offending lane
+    const unsigned e0 = w[0] & 0x7c007c00u, e1 = w[1] & 0x7c007c00u;
+    if (stats && (((e0 & 0xffffu) == 0x7c00u) | ((e0 >> 16) == 0x7c00u) | ((e1 & 0xffffu) == 0x7c00u) | ((e1 >> 16) == 0x7c00u))) atomicAdd(stats, 1);
+  } else {
+    u32x2 hi, lo;
+    split4_values(x0, x1, x2, x3, hi, lo);
+    *(u32x2*)p = hi;
+    *(u32x2*)(p + lo_off) = lo;
+  }
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }

@@ -20,7 +20,7 @@ static int dispatch_layout(const GemmParams& p, int la, int lb, int batch, hipSt
 
 static int fill_params(const muse_gemm_desc* d, GemmParams& p) {
   if (!d || !d->A || !d->B || !d->C) return MUSE_ERR_BAD_ARG;
-  const int esz = d->dtype == MUSE_BF16 ? 2 : 4;
+  const int esz = (d->dtype == MUSE_BF16 || d->dtype == MUSE_F16) ? 2 : 4;
   const int ch = 16 / esz;
   // 16-byte vector loads: leading dimensions and sub-matrix offsets must be multiples of one chunk
   if ((d->lda % ch) || (d->ldb % ch) || (((uintptr_t)d->A) & 15) || (((uintptr_t)d->B) & 15)) return MUSE_ERR_ALIGN;
@@ -48,6 +48,11 @@ static int fill_params(const muse_gemm_desc* d, GemmParams& p) {
 
 // does this descriptor go to the 256 x 256 LDS-DMA kernel (gemm256.h)?
 static bool takes_gemm256(const muse_gemm_desc* d, const GemmParams& p, int batch) {
+  if (d->dtype == MUSE_F16) {
+    // half operands exist on the 256^2 kernels only, with f32 output: no cost model - whatever those kernels take (the caller keeps
+    // a product they refuse in exact f32)
+    return d->out_dtype == MUSE_F32 && d->M >= 128 && d->N >= 128 && d->K >= 64 && gemm256_ok<float>(p, d->layout_a, d->layout_b);
+  }
   if (d->dtype != MUSE_BF16) return false;
   const bool pers = (d->out_dtype == MUSE_BF16 || d->out_dtype == MUSE_F32) &&
                     gemm256p_takes(p, d->layout_a, d->layout_b, batch, d->out_dtype == MUSE_F32);
@@ -61,7 +66,8 @@ extern "C" int muse_gemm_tile(const muse_gemm_desc* d) {
   GemmParams p;
   const int rc = fill_params(d, p);
   if (rc) return rc;
-  return takes_gemm256(d, p, d->batch > 0 ? d->batch : 1) ? 256 : 128;
+  if (takes_gemm256(d, p, d->batch > 0 ? d->batch : 1)) return 256;
+  return d->dtype == MUSE_F16 ? MUSE_ERR_UNSUPPORTED : 128;
 }
 
 extern "C" int muse_gemm_path(const muse_gemm_desc* d) {
@@ -69,7 +75,7 @@ extern "C" int muse_gemm_path(const muse_gemm_desc* d) {
   const int rc = fill_params(d, p);
   if (rc) return rc;
   const int batch = d->batch > 0 ? d->batch : 1;
-  if (!takes_gemm256(d, p, batch)) return 128;
+  if (!takes_gemm256(d, p, batch)) return d->dtype == MUSE_F16 ? MUSE_ERR_UNSUPPORTED : 128;
   return gemm256p_takes(p, d->layout_a, d->layout_b, batch, d->out_dtype == MUSE_F32) ? 257 : 256;
 }
 
@@ -79,12 +85,15 @@ extern "C" int muse_gemm(const muse_gemm_desc* d, void* stream) {
   if (rc) return rc;
   const int batch = d->batch > 0 ? d->batch : 1;
   hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == MUSE_F16 && !takes_gemm256(d, p, batch)) return MUSE_ERR_UNSUPPORTED;
   if (takes_gemm256(d, p, batch)) {
     // persistent tile-walking form first (gemm256p.h); -1 = no queue slot for this stream
+    const bool half_ops = d->dtype == MUSE_F16;
     if (gemm256p_takes(p, d->layout_a, d->layout_b, batch, d->out_dtype == MUSE_F32)) {
-      const int rp = launch_gemm256p(p, d->layout_a, d->layout_b, d->out_dtype == MUSE_F32, s);
+      const int rp = launch_gemm256p(p, d->layout_a, d->layout_b, d->out_dtype == MUSE_F32, s, half_ops);
       if (rp != -1) return rp;
     }
+    if (half_ops) return launch_gemm256_f16(p, d->layout_a, d->layout_b, batch, s);
     if (d->out_dtype == MUSE_BF16) return launch_gemm256<bf16_t>(p, d->layout_a, d->layout_b, batch, s);
     return launch_gemm256<float>(p, d->layout_a, d->layout_b, batch, s);
   }
@@ -119,7 +128,9 @@ static int group_fill(const muse_gemm_desc* d, int n, int split_k, g256::GroupPa
   if (!d || n < 1 || n > g256::MAXG || split_k < 1) return MUSE_ERR_BAD_ARG;
   int start = 0;
   for (int i = 0; i < n; ++i) {
-    if (d[i].dtype != MUSE_BF16 || d[i].out_dtype != MUSE_F32 || d[i].layout_a != 1 || d[i].layout_b != 1) return MUSE_ERR_UNSUPPORTED;
+    if ((d[i].dtype != MUSE_BF16 && d[i].dtype != MUSE_F16) || d[i].dtype != d[0].dtype || d[i].out_dtype != MUSE_F32 || d[i].layout_a != 1 ||
+        d[i].layout_b != 1)
+      return MUSE_ERR_UNSUPPORTED;
     if ((d[i].batch > 1) || d[i].bias || d[i].rowvec || d[i].residual || d[i].act) return MUSE_ERR_UNSUPPORTED;
     muse_gemm_desc di = d[i];
     di.split_k = split_k;
@@ -144,11 +155,12 @@ extern "C" int muse_gemm_group(const muse_gemm_desc* d, int32_t n, int32_t split
   g256::GroupParams gp;
   const int rc = group_fill(d, n, split_k, gp);
   if (rc) return rc;
-  auto kern = g256::kernel_group<float, 1, 1, true>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  const bool half_ops = d[0].dtype == MUSE_F16;
+  auto kern = half_ops ? g256::kernel_group<float, 1, 1, true, true> : g256::kernel_group<float, 1, 1, true>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[half_ops]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g256::LDS_BYTES);
-    attr_set = true;
+    attr_set[half_ops] = true;
   }
   hipLaunchKernelGGL(kern, dim3(gp.tile_start[n], split_k, 1), dim3(512), g256::LDS_BYTES, (hipStream_t)stream, gp);
   return (int)hipGetLastError();

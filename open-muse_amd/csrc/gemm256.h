@@ -37,6 +37,13 @@ template <int OFF> __device__ __forceinline__ void lds_read128(bf16x8& d, unsign
 template <int OFF> __device__ __forceinline__ void lds_read64_tr(u32x2& d, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
+// One MFMA of the K loop: bf16 operands, or (H) the same 16-bit lanes read as IEEE half - 11 significant bits per operand, the TF32
+// operand precision, at the bf16 rate (gfx950 has no xf32 MFMA); fragments, LDS images and DMA are the same bytes either way.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool H> __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 template <int N> __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -151,7 +158,7 @@ struct Frags {
 //   s_barrier                  ... and so have everyone's
 //   DMA tile t+2 -> this stage; fragment reads of tile t+1 begin, under the last DIST groups of MFMAs of tile t.
 // LDS reads return in order, so "fragment a(g) has arrived" == at most (reads issued after it) outstanding: waitN(g).
-template <int AL, int BL, bool SPREAD = false>
+template <int AL, int BL, bool SPREAD = false, bool H = false>
 struct Pipe {
   static constexpr int RA = AL ? 2 : 1, RB = BL ? 2 : 1, NB = NI * RB;
   static constexpr int NSLOT = 4, DIST = NSLOT - 1;
@@ -283,7 +290,7 @@ struct Pipe {
 #ifndef G256_ABLATE_NO_MFMA
 #pragma unroll
     for (int j = 0; j < NI; ++j)
-      acc[G & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j], 0, 0, 0);
+      acc[G & 7][j] = mfma16<H>(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j]);
 #else
     asm volatile("" ::"v"(ring[G & (NSLOT - 1)]), "v"(bk[G >> 3][0]), "v"(bk[G >> 3][1]), "v"(bk[G >> 3][2]), "v"(bk[G >> 3][3]));
 #endif
@@ -599,7 +606,7 @@ __device__ long* g_gemm_ts = nullptr;
 #define G256_TS(IDX)
 #endif
 // one 256 x 256 output tile (or one K slice of it): `tid_` = the tile's index in the problem's grouped raster
-template <typename TC, int AL, int BL, int BKV, bool SPREAD, bool X3 = false>
+template <typename TC, int AL, int BL, int BKV, bool SPREAD, bool X3 = false, bool H = false>
 __device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, unsigned char* smem) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   constexpr int GM = 4;
@@ -626,8 +633,9 @@ __device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, u
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = (wave >> 2) * 128, wc = (wave & 3) * 64;
 
-  using PipeT = std::conditional_t<X3, PipeX3<AL, BL>, std::conditional_t<BKV == 64, Pipe<AL, BL, SPREAD>, Pipe32<AL, BL>>>;
+  using PipeT = std::conditional_t<X3, PipeX3<AL, BL>, std::conditional_t<BKV == 64, Pipe<AL, BL, SPREAD, H>, Pipe32<AL, BL>>>;
   static_assert(!X3 || BKV == 32, "the bf16x3 K loop works on 32-wide K-tiles");
+  static_assert(!H || (BKV == 64 && !X3 && sizeof(TC) == 4), "half operands: the 64-wide K loop with f32 output");
   PipeT pp;
   pp.smem = smem; pp.wave = wave;
   if constexpr (X3) {
@@ -805,14 +813,14 @@ __device__ __forceinline__ void tile_body(const GemmParams& p, const int tid_, u
   G256_TS(3)
 }
 
-template <typename TC, int AL, int BL, int BKV, bool SPREAD = false>
+template <typename TC, int AL, int BL, int BKV, bool SPREAD = false, bool H = false>
 __global__ __launch_bounds__(512, 2) void kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   G256_TS(0)
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
   const int bq = ntiles >> 3, br = ntiles & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
   const int tid_ = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + bi;
-  tile_body<TC, AL, BL, BKV, SPREAD>(p, tid_, smem);
+  tile_body<TC, AL, BL, BKV, SPREAD, false, H>(p, tid_, smem);
 }
 
 template <typename TC, int AL, int BL>
@@ -836,7 +844,7 @@ struct GroupParams {
   int tile_start[MAXG + 1];   // first global tile index of each product (tile_start[n] = total)
   int n;
 };
-template <typename TC, int AL, int BL, bool SPREAD>
+template <typename TC, int AL, int BL, bool SPREAD, bool H = false>
 __global__ __launch_bounds__(512, 2) void kernel_group(const GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ntiles = gp.tile_start[gp.n];
@@ -847,7 +855,7 @@ __global__ __launch_bounds__(512, 2) void kernel_group(const GroupParams gp) {
   for (int k = 1; k < MAXG; ++k) pi += (k < gp.n && gt >= gp.tile_start[k]) ? 1 : 0;
   pi = __builtin_amdgcn_readfirstlane(pi);
   const GemmParams p = gp.p[pi];
-  tile_body<TC, AL, BL, 64, SPREAD>(p, gt - gp.tile_start[pi], smem);
+  tile_body<TC, AL, BL, 64, SPREAD, false, H>(p, gt - gp.tile_start[pi], smem);
 }
 
 }  // namespace g256
@@ -892,11 +900,11 @@ static inline bool gemm256_preferred(const GemmParams& p, int la, int lb, int ba
   return cost256 < cost128;
 }
 
-template <typename TC, int AL, int BL, int BKV, bool SPREAD = false>
+template <typename TC, int AL, int BL, int BKV, bool SPREAD = false, bool H = false>
 static inline int launch_gemm256_lb(const GemmParams& p, int batch, hipStream_t stream) {
   const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
   constexpr int lds = BKV == 64 ? g256::LDS_BYTES : g256::LDS_BYTES32;
-  auto kern = g256::kernel<TC, AL, BL, BKV, SPREAD>;
+  auto kern = g256::kernel<TC, AL, BL, BKV, SPREAD, H>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -942,4 +950,13 @@ static inline int launch_gemm256(const GemmParams& p, int la, int lb, int batch,
   if (la == 0 && lb == 1) return launch_gemm256_l<TC, 0, 1>(p, batch, stream);
   if (la == 1 && lb == 1) return launch_gemm256_l<TC, 1, 1>(p, batch, stream);
   return launch_gemm256_l<TC, 1, 0>(p, batch, stream);
+}
+
+// half operands (muse_gemm with dtype MUSE_F16: the TF32-class product of the tape engines' "f16" compute mode): f32 output, the 64-wide
+// K loop with the DMA pieces spread over the MFMA groups
+static inline int launch_gemm256_f16(const GemmParams& p, int la, int lb, int batch, hipStream_t stream) {
+  if (la == 0 && lb == 0) return launch_gemm256_lb<float, 0, 0, 64, true, true>(p, batch, stream);
+  if (la == 0 && lb == 1) return launch_gemm256_lb<float, 0, 1, 64, true, true>(p, batch, stream);
+  if (la == 1 && lb == 1) return launch_gemm256_lb<float, 1, 1, 64, true, true>(p, batch, stream);
+  return launch_gemm256_lb<float, 1, 0, 64, true, true>(p, batch, stream);
 }

@@ -142,7 +142,7 @@ struct DmaP {
 
 enum { M_NORMAL = 0, M_FIRST = 1, M_LAST = 2, M_PUBLISH = 3 };
 
-template <typename TC, int AL, int BL>
+template <typename TC, int AL, int BL, bool H = false>   // H: half operands (g256::mfma16)
 struct PipeP {
   static constexpr bool F32OUT = sizeof(TC) == 4;
   static constexpr int RA = AL ? 2 : 1, RB = BL ? 2 : 1, NB = NI * RB;
@@ -253,7 +253,7 @@ struct PipeP {
     wait_lgkm<waitN(G)>();
 #pragma unroll
     for (int j = 0; j < NI; ++j)
-      acc[G & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j], 0, 0, 0);
+      acc[G & 7][j] = mfma16<H>(bk[G >> 3][j], ring[G & (NSLOT - 1)], acc[G & 7][j]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (G + 1 < 16) group<S, G + 1, MODE>();
     else ++kti;
@@ -487,7 +487,7 @@ struct PipeP {
   }
 };
 
-template <typename TC, int AL, int BL>
+template <typename TC, int AL, int BL, bool H = false>
 __global__ __launch_bounds__(512, 2) void kernel(PArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const GemmParams& p = a.g;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void kernel(PArgs a) {
 
   int m0, n0;
   if (a.sched.decode(xcd, blockIdx.x >> 3, m0, n0)) {
-    PipeP<TC, AL, BL> pp;
+    PipeP<TC, AL, BL, H> pp;
     pp.smem = smem; pp.sched = a.sched; pp.counters = a.counters; pp.nk2 = a.nk2; pp.dyn = a.dyn; pp.epi = a.epi; pp.staux = a.staux; pp.stagger = a.stagger;
     pp.M = p.M; pp.N = p.N; pp.ldc = (unsigned)p.ldc; pp.alpha = p.alpha;
     pp.wave = wave; pp.lane = lane; pp.xcd = xcd; pp.nbx = nbx;

@@ -18,7 +18,7 @@ struct Slots {
   int n = 0;
   int cus = 0;
   bool failed = false;
-  bool attr_set[4] = {false, false, false, false};
+  bool attr_set[5] = {false, false, false, false, false};
 };
 std::mutex g_mu;
 Slots g_slots[kMaxDev];
@@ -81,7 +81,7 @@ bool eligible(const GemmParams& p, int la, int lb, int batch) {
   return true;
 }
 
-template <typename TC, int AL, int BL>
+template <typename TC, int AL, int BL, bool H = false>
 int launch(const GemmParams& p, hipStream_t stream) {
   int cus = 0;
   Slots* S = nullptr;
@@ -111,8 +111,8 @@ int launch(const GemmParams& p, hipStream_t stream) {
   static const int stagger = []() { const char* e = getenv("MUSE_G256P_STAGGER"); return e ? atoi(e) : 1; }();
   a.staux = staux;
   a.stagger = stagger;
-  auto kern = g256p::kernel<TC, AL, BL>;
-  constexpr int form = (sizeof(TC) == 4 ? 2 : 0) + BL;      // the dynamic-LDS attribute is per function AND per device
+  auto kern = g256p::kernel<TC, AL, BL, H>;
+  constexpr int form = H ? 4 : (sizeof(TC) == 4 ? 2 : 0) + BL;      // the dynamic-LDS attribute is per function AND per device
   if (!S->attr_set[form]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g256p::LDS_BYTES_P);
     S->attr_set[form] = true;
@@ -121,8 +121,9 @@ int launch(const GemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int launch_l(const GemmParams& p, int la, int lb, bool f32_out, hipStream_t s) {
+int launch_l(const GemmParams& p, int la, int lb, bool f32_out, hipStream_t s, bool half_ops) {
   if (la != 0) return -1;
+  if (half_ops) return (f32_out && lb == 0) ? launch<float, 0, 0, true>(p, s) : -1;
   if (f32_out) return lb == 0 ? launch<float, 0, 0>(p, s) : -1;
   return lb == 0 ? launch<bf16_t, 0, 0>(p, s) : launch<bf16_t, 0, 1>(p, s);
 }
@@ -136,6 +137,6 @@ bool gemm256p_takes(const GemmParams& p, int la, int lb, int batch, bool f32_out
   return f32_out ? eligible<float>(p, la, lb, batch) : eligible<bf16_t>(p, la, lb, batch);
 }
 
-int launch_gemm256p(const GemmParams& p, int la, int lb, bool f32_out, hipStream_t stream) {
-  return launch_l(p, la, lb, f32_out, stream);
+int launch_gemm256p(const GemmParams& p, int la, int lb, bool f32_out, hipStream_t stream, bool half_ops) {
+  return launch_l(p, la, lb, f32_out, stream, half_ops);
 }

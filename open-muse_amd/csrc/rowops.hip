@@ -980,14 +980,26 @@ static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 4
 // (hi, lo) bf16 operand planes of the product that reads it (muse_gemm_x3: h feeds the FFN's output projection, d(ab) the dX and dW
 // products of its input projection) - the separate split pass (read 4 + write 4 bytes per element) becomes 4 written bytes here.
 // planes: [2][rows][cols] bf16, hi plane first; split4 is the split muse_split_f32_to_bf16x2 applies, so the planes are its bits.
-__device__ __forceinline__ void store_planes4(bf16_t* hi, long plane, long idx, const float (&o)[4]) {
-  u32x2 h, l;
-  split4_values(o[0], o[1], o[2], o[3], h, l);
-  *(u32x2*)(hi + idx) = h;
-  *(u32x2*)(hi + plane + idx) = l;
+// (ImgFormat: the "f16" mode's half image instead - common.h store_image4)
+static int g_img_half = 0;
+static float g_img_grad_scale = 1.f;
+static int* g_img_stats = nullptr;
+ImgFormat img_format(bool gradient) {
+  return ImgFormat{g_img_half ? -1L : 1L, (g_img_half && gradient) ? g_img_grad_scale : 1.f, g_img_half ? g_img_stats : nullptr};
 }
-__global__ void glu_fwd_x3_kernel(const float* __restrict__ ab, float* __restrict__ h, bf16_t* __restrict__ planes, long rows, int inter) {
-  const long n4 = rows * (inter / 4), plane = rows * inter;
+extern "C" int muse_operand_images(int32_t half, float grad_scale, int32_t* stats) {
+  int e = 0;
+  if ((half != 0 && half != 1) || !(grad_scale > 0.f) || frexpf(grad_scale, &e) != 0.5f) return MUSE_ERR_BAD_ARG;   // a power of two
+  g_img_half = half;
+  g_img_grad_scale = grad_scale;
+  g_img_stats = half ? (int*)stats : nullptr;
+  return 0;
+}
+__device__ __forceinline__ void store_planes4(bf16_t* hi, long plane, const ImgFormat& f, long idx, const float (&o)[4]) {
+  store_image4(hi + idx, plane, f.scale, f.stats, o[0], o[1], o[2], o[3]);
+}
+__global__ void glu_fwd_x3_kernel(const float* __restrict__ ab, float* __restrict__ h, bf16_t* __restrict__ planes, long rows, int inter, ImgFormat f) {
+  const long n4 = rows * (inter / 4), plane = f.lo_sign * rows * inter;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const long r = i / (inter / 4);
     const int c = (int)(i - r * (inter / 4)) * 4;
@@ -997,12 +1009,12 @@ __global__ void glu_fwd_x3_kernel(const float* __restrict__ ab, float* __restric
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = gelu_erf_t<false>(a[j]) * b[j];
     if (h) V4<float>::store(h + r * inter + c, o);
-    store_planes4(planes, plane, r * inter + c, o);
+    store_planes4(planes, plane, f, r * inter + c, o);
   }
 }
 __global__ void glu_bwd_x3_kernel(const float* __restrict__ ab, const float* __restrict__ dh, float* __restrict__ dab, bf16_t* __restrict__ planes,
-                                  long rows, int inter) {
-  const long n4 = rows * (inter / 4), plane = rows * 2 * inter;
+                                  long rows, int inter, ImgFormat f) {
+  const long n4 = rows * (inter / 4), plane = f.lo_sign * rows * 2 * inter;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const long r = i / (inter / 4);
     const int c = (int)(i - r * (inter / 4)) * 4;
@@ -1016,8 +1028,8 @@ __global__ void glu_bwd_x3_kernel(const float* __restrict__ ab, const float* __r
       V4<float>::store(dab + r * 2 * inter + c, da);
       V4<float>::store(dab + r * 2 * inter + inter + c, db);
     }
-    store_planes4(planes, plane, r * 2 * inter + c, da);
-    store_planes4(planes, plane, r * 2 * inter + inter + c, db);
+    store_planes4(planes, plane, f, r * 2 * inter + c, da);
+    store_planes4(planes, plane, f, r * 2 * inter + inter + c, db);
   }
 }
 extern "C" int muse_glu_fwd_x3(const float* ab, float* h, void* planes, int64_t rows, int32_t inter, void* stream) {
@@ -1025,7 +1037,8 @@ extern "C" int muse_glu_fwd_x3(const float* ab, float* h, void* planes, int64_t 
   if (rows <= 0) return 0;
   if (!planes) return MUSE_ERR_BAD_ARG;
   if ((((uintptr_t)ab) | ((uintptr_t)h)) & 15 || (((uintptr_t)planes) & 7) || ((rows * inter) & 3)) return MUSE_ERR_ALIGN;
-  hipLaunchKernelGGL(glu_fwd_x3_kernel, dim3(ew_grid(rows * (inter / 4))), dim3(256), 0, (hipStream_t)stream, ab, h, (bf16_t*)planes, (long)rows, inter);
+  hipLaunchKernelGGL(glu_fwd_x3_kernel, dim3(ew_grid(rows * (inter / 4))), dim3(256), 0, (hipStream_t)stream, ab, h, (bf16_t*)planes, (long)rows, inter,
+                     img_format(false));
   return (int)hipGetLastError();
 }
 extern "C" int muse_glu_bwd_x3(const float* ab, const float* dh, float* dab, void* planes, int64_t rows, int32_t inter, void* stream) {
@@ -1033,7 +1046,8 @@ extern "C" int muse_glu_bwd_x3(const float* ab, const float* dh, float* dab, voi
   if (rows <= 0) return 0;
   if (!planes) return MUSE_ERR_BAD_ARG;
   if ((((uintptr_t)ab) | ((uintptr_t)dh) | ((uintptr_t)dab)) & 15 || (((uintptr_t)planes) & 7)) return MUSE_ERR_ALIGN;
-  hipLaunchKernelGGL(glu_bwd_x3_kernel, dim3(ew_grid(rows * (inter / 4))), dim3(256), 0, (hipStream_t)stream, ab, dh, dab, (bf16_t*)planes, (long)rows, inter);
+  hipLaunchKernelGGL(glu_bwd_x3_kernel, dim3(ew_grid(rows * (inter / 4))), dim3(256), 0, (hipStream_t)stream, ab, dh, dab, (bf16_t*)planes, (long)rows, inter,
+                     img_format(true));
   return (int)hipGetLastError();
 }
 // bf16, inter % 8 == 0: eight columns of one row per thread (16-byte accesses), rows walked by blockIdx.y - no 64-bit index
@@ -1622,7 +1636,8 @@ extern "C" int muse_adamw_flat_groups(float* p, const float* g, float* m, float*
                      (bf16_t*)p_bf16, (long)n, (long)base, (const long*)seg_end, seg_group, nseg, G, grad_scale);
   return (int)hipGetLastError();
 }
-// Multi-tensor form with groups: `table` is 7 x int64 per tensor {p, g, m, v, p_bf16 or 0, n, group | lo_plane_distance << 8}.
+// Multi-tensor form with groups: `table` is 7 x int64 per tensor {p, g, m, v, p_bf16 or 0, n, group | lo_plane_distance << 8}
+// (lo_plane_distance < 0: p_bf16 receives an IEEE-half copy).
 __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __restrict__ table, const int* __restrict__ chunk_first, int nt,
                                                                  AdamGroups G, float gscale) {
   int lo = 0, hi = nt;
@@ -1633,7 +1648,10 @@ __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __r
   const AdamHyper h = G.h[(int)e[6] & (MUSE_ADAMW_MAX_GROUPS - 1)];
   // column 6 above bit 8: p_bf16 is the HI plane of the parameter's bf16x3 operand planes and the lo plane sits that many elements behind
   // it (hi = bf16(p), lo = bf16(p - hi): split_f2bb_kernel's arithmetic) - the planes the next step's weight GEMMs read; 0 = a plain bf16 copy
-  const long plo = e[6] >> 8;
+  // ... and a NEGATIVE value there: p_bf16 is an IEEE-half copy instead (the weight's operand image of the "f16" compute mode)
+  const long plo_raw = e[6] >> 8;
+  const bool half_copy = plo_raw < 0;
+  const long plo = half_copy ? 0 : plo_raw;
   const long n = e[5], base = (long)((int)blockIdx.x - chunk_first[lo]) * 4096;
   const long end = base + 4096 < n ? base + 4096 : n;
   const bool vec = !((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) && !(((uintptr_t)pb) & 7) && !(plo & 3);
@@ -1644,7 +1662,10 @@ __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __r
 #pragma unroll
       for (int j = 0; j < 4; ++j) adam_update1(pp[j], gg[j] * gscale, mm[j], vv[j], h);
       V4<float>::store(p + i, pp); V4<float>::store(m + i, mm); V4<float>::store(v + i, vv);
-      if (pb) {
+      if (pb && half_copy) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        *(h4*)(pb + i) = h4{(_Float16)pp[0], (_Float16)pp[1], (_Float16)pp[2], (_Float16)pp[3]};
+      } else if (pb) {
         V4<bf16_t>::store(pb + i, pp);
         if (plo) {
           float rr[4];
@@ -1660,7 +1681,9 @@ __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __r
     float pp = p[i], mm = m[i], vv = v[i];
     adam_update1(pp, g[i] * gscale, mm, vv, h);
     p[i] = pp; m[i] = mm; v[i] = vv;
-    if (pb) {
+    if (pb && half_copy) {
+      ((_Float16*)pb)[i] = (_Float16)pp;
+    } else if (pb) {
       const bf16_t hi = f32_to_bf16(pp);
       pb[i] = hi;
       if (plo) pb[plo + i] = f32_to_bf16(pp - bf16_to_f32(hi));
@@ -1755,6 +1778,41 @@ extern "C" int muse_cast_f32_to_bf16(const float* in, void* out, int64_t n, void
   if (n <= 0) return 0;
   if ((((uintptr_t)in) & 15) || (((uintptr_t)out) & 7)) return MUSE_ERR_ALIGN;
   hipLaunchKernelGGL(cast_f2b_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)n);
+  return (int)hipGetLastError();
+}
+// f32 -> IEEE half operand image of the "f16" compute mode (muse_gemm dtype MUSE_F16): out = half(in * scale), round to nearest even,
+// subnormals kept; a finite in * scale beyond half's range becomes inf (the product, and the step's loss, turn NaN: loud - the same
+// bits the producer kernels write, common.h store_image4).  stats (optional, int32[2], accumulated with atomics by the waves that see
+// one): [0] finite elements that overflowed, [1] non-zero elements that became zero - the caller's gradient scale was too large / too small.
+__global__ void cast_f2h_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long n, float scale, int* __restrict__ stats) {
+  const long n4 = n >> 2;
+  bool sat = false, und = false;
+  auto cv = [&](float x) -> _Float16 {
+    const float v = x * scale;
+    const _Float16 h = (_Float16)v;
+    sat = sat || (fabsf(v) <= 3.0e38f && fabsf((float)h) > 65504.f);
+    und = und || (x != 0.f && (float)h == 0.f);
+    return h;
+  };
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float a[4]; V4<float>::load(in + i * 4, a);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 o = {cv(a[0]), cv(a[1]), cv(a[2]), cv(a[3])};
+    *(h4*)(out + i * 4) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const long i = (n4 << 2) + threadIdx.x; out[i] = cv(in[i]); }
+  if (stats) {
+    const unsigned long long bs = __ballot(sat), bu = __ballot(und);
+    if ((threadIdx.x & 63) == 0) {
+      if (bs) atomicAdd(stats, __popcll(bs));
+      if (bu) atomicAdd(stats + 1, __popcll(bu));
+    }
+  }
+}
+extern "C" int muse_cast_f32_to_f16(const float* in, void* out, int64_t n, float scale, int32_t* stats, void* stream) {
+  if (n <= 0) return 0;
+  if ((((uintptr_t)in) & 15) || (((uintptr_t)out) & 7)) return MUSE_ERR_ALIGN;
+  hipLaunchKernelGGL(cast_f2h_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, (_Float16*)out, (long)n, scale, (int*)stats);
   return (int)hipGetLastError();
 }
 extern "C" int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream) {

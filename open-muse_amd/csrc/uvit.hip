@@ -630,12 +630,10 @@ extern "C" int muse_norm_res_bwd(const float* dy, const float* dpre, const float
 // the bf16 copy of four results (the operand of the next weight GEMMs in the bf16 mode); lo_off != 0 ("bf16x3" mode): that copy is the hi
 // plane and bf16(o - hi) goes lo_off elements behind it - the (hi, lo) operand planes of muse_gemm_x3, bit for bit what
 // muse_split_f32_to_bf16x2 makes of the f32 result
-__device__ __forceinline__ void store_hi_lo(bf16_t* hi, long lo_off, long idx, const f32x4& o) {
+// (lo_off < 0, "f16" mode: ONE IEEE-half image half(o * scale) - common.h store_image4)
+__device__ __forceinline__ void store_hi_lo(bf16_t* hi, long lo_off, long idx, const f32x4& o, float scale = 1.f, int* stats = nullptr) {
   if (lo_off) {
-    u32x2 h, l;
-    split4_values(o[0], o[1], o[2], o[3], h, l);
-    *(u32x2*)(hi + idx) = h;
-    *(u32x2*)(hi + lo_off + idx) = l;
+    store_image4(hi + idx, lo_off, scale, stats, o[0], o[1], o[2], o[3]);
   } else {
     *(u32x2*)(hi + idx) = u32x2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
   }
@@ -644,7 +642,8 @@ template <int NIT>
 __global__ __launch_bounds__(256) void norm_adaln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ w, const float* __restrict__ ss,
                                                              float* __restrict__ pre, float* __restrict__ m, bf16_t* __restrict__ mb,
-                                                             long rows, long rpb, int cols, float eps, int mode, long lo_off) {
+                                                             long rows, long rpb, int cols, float eps, int mode, long lo_off, float img_scale,
+                                                             int* img_stats) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -696,31 +695,33 @@ __global__ __launch_bounds__(256) void norm_adaln_fwd_kernel(const float* __rest
         o[j] = n * (1.0f + sc[j]) + sh[j];
       }
       if (m) *(f32x4*)(m + row * cols + c) = o;
-      if (mb) store_hi_lo(mb, lo_off, row * cols + c, o);
+      if (mb) store_hi_lo(mb, lo_off, row * cols + c, o, img_scale, img_stats);
     }
   }
 }
 static int norm_adaln_fwd_launch(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* m_bf16, long lo_off,
-                                 int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
+                                 float img_scale, int* img_stats, int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
   if (cols % 4 || cols > 1024 || (mode != 0 && mode != 1) || (!m && !m_bf16)) return MUSE_ERR_UNSUPPORTED;
   const long rows = (long)batch * rows_per_batch;
   if (rows <= 0) return 0;
   const dim3 grid((unsigned)((rows + 3) / 4));
 #define NAF(N) hipLaunchKernelGGL(norm_adaln_fwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, x, res, w, ss, pre, m, (bf16_t*)m_bf16, rows, \
-                                  (long)rows_per_batch, cols, eps, mode, lo_off)
+                                  (long)rows_per_batch, cols, eps, mode, lo_off, img_scale, img_stats)
   if (cols <= 256) NAF(1); else if (cols <= 512) NAF(2); else if (cols <= 768) NAF(3); else NAF(4);
 #undef NAF
   return (int)hipGetLastError();
 }
 extern "C" int muse_norm_adaln_fwd(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* m_bf16,
                                    int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
-  return norm_adaln_fwd_launch(x, res, w, ss, pre, m, m_bf16, 0, batch, rows_per_batch, cols, eps, mode, stream);
+  return norm_adaln_fwd_launch(x, res, w, ss, pre, m, m_bf16, 0, 1.f, nullptr, batch, rows_per_batch, cols, eps, mode, stream);
 }
 // "bf16x3" mode: m as f32 AND as the (hi, lo) operand planes [2][rows][cols] of the products that read it
 extern "C" int muse_norm_adaln_fwd_x3(const float* x, const float* res, const float* w, const float* ss, float* pre, float* m, void* planes,
                                       int32_t batch, int64_t rows_per_batch, int32_t cols, float eps, int32_t mode, void* stream) {
   if (!planes) return MUSE_ERR_BAD_ARG;      // (m may be NULL: the planes only - a result that nothing but weight GEMMs reads)
-  return norm_adaln_fwd_launch(x, res, w, ss, pre, m, planes, (long)batch * rows_per_batch * cols, batch, rows_per_batch, cols, eps, mode, stream);
+  const ImgFormat f = img_format(false);     // ("f16" mode: planes receives ONE half image [rows][cols] instead)
+  return norm_adaln_fwd_launch(x, res, w, ss, pre, m, planes, f.lo_sign * (long)batch * rows_per_batch * cols, f.scale, f.stats, batch, rows_per_batch, cols, eps,
+                               mode, stream);
 }
 
 template <int NIT>
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(256) void norm_adaln_bwd_kernel(const float* __rest
                                                              const float* __restrict__ v, const float* __restrict__ w,
                                                              const float* __restrict__ ss, float* __restrict__ dv, bf16_t* __restrict__ dvb,
                                                              float* __restrict__ dwp, float* __restrict__ dssp, long rows, long rpb,
-                                                             int cols, float eps, int mode, long lo_off) {
+                                                             int cols, float eps, int mode, long lo_off, float img_scale, int* img_stats) {
   __shared__ float red[1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* sb = ss + (((long)blockIdx.x * NRB_ROWS) / rpb) * 2 * cols;       // the block's image
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(256) void norm_adaln_bwd_kernel(const float* __rest
         for (int j = 0; j < 4; ++j) o[j] = rstd * (d[it][j] * wv4[it][j] - mg - (t[it][j] - mean) * rstd * mgx);
         if (dpre) o += pr[it];
         *(f32x4*)(dv + row * cols + c) = o;
-        if (dvb) store_hi_lo(dvb, lo_off, row * cols + c, o);
+        if (dvb) store_hi_lo(dvb, lo_off, row * cols + c, o, img_scale, img_stats);
       }
     }
   }
@@ -843,30 +844,31 @@ __global__ __launch_bounds__(256) void norm_adaln_bwd_kernel(const float* __rest
   }
 }
 static int norm_adaln_bwd_launch(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
-                                 void* dv_bf16, long lo_off, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
+                                 void* dv_bf16, long lo_off, float img_scale, int* img_stats, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
                                  int32_t cols, float eps, int32_t mode, void* stream);
 extern "C" int muse_norm_adaln_bwd(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
                                    void* dv_bf16, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
                                    int32_t cols, float eps, int32_t mode, void* stream) {
-  return norm_adaln_bwd_launch(dm, dpre, v, w, ss, dv, dv_bf16, 0, dw_partial, dss_partial, batch, rows_per_batch, cols, eps, mode, stream);
+  return norm_adaln_bwd_launch(dm, dpre, v, w, ss, dv, dv_bf16, 0, 1.f, nullptr, dw_partial, dss_partial, batch, rows_per_batch, cols, eps, mode, stream);
 }
 // "bf16x3" mode: dv as f32 AND as the (hi, lo) operand planes [2][rows][cols] of the dX / dW products that read it
 extern "C" int muse_norm_adaln_bwd_x3(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
                                       void* planes, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
                                       int32_t cols, float eps, int32_t mode, void* stream) {
   if (!planes) return MUSE_ERR_BAD_ARG;
-  return norm_adaln_bwd_launch(dm, dpre, v, w, ss, dv, planes, (long)batch * rows_per_batch * cols, dw_partial, dss_partial, batch, rows_per_batch,
+  const ImgFormat f = img_format(true);      // ("f16" mode: ONE half image of dv, scaled by the backward pass's gradient scale)
+  return norm_adaln_bwd_launch(dm, dpre, v, w, ss, dv, planes, f.lo_sign * (long)batch * rows_per_batch * cols, f.scale, f.stats, dw_partial, dss_partial, batch, rows_per_batch,
                                cols, eps, mode, stream);
 }
 static int norm_adaln_bwd_launch(const float* dm, const float* dpre, const float* v, const float* w, const float* ss, float* dv,
-                                 void* dv_bf16, long lo_off, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
+                                 void* dv_bf16, long lo_off, float img_scale, int* img_stats, float* dw_partial, float* dss_partial, int32_t batch, int64_t rows_per_batch,
                                  int32_t cols, float eps, int32_t mode, void* stream) {
   if (cols % 4 || cols > 1024 || (mode != 0 && mode != 1) || (rows_per_batch % NRB_ROWS)) return MUSE_ERR_UNSUPPORTED;
   const long rows = (long)batch * rows_per_batch;
   if (rows <= 0) return 0;
   const int nblk = muse_norm_res_bwd_nblk(rows);
 #define NAB(N) hipLaunchKernelGGL(norm_adaln_bwd_kernel<N>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dm, dpre, v, w, ss, dv, (bf16_t*)dv_bf16, \
-                                  dw_partial, dss_partial, rows, (long)rows_per_batch, cols, eps, mode, lo_off)
+                                  dw_partial, dss_partial, rows, (long)rows_per_batch, cols, eps, mode, lo_off, img_scale, img_stats)
   if (cols <= 256) NAB(1); else if (cols <= 512) NAB(2); else if (cols <= 768) NAB(3); else NAB(4);
 #undef NAB
   return (int)hipGetLastError();

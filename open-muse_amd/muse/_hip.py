@@ -11,7 +11,7 @@ import os
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2     # F16: GEMM operands only (muse_gemm / muse_gemm_group)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MUSE_HIP_LIB") or os.path.join(_HERE, "libmuse_hip.so")   # (override: kernel experiments)
 _lib = None
@@ -113,6 +113,8 @@ SIGNATURES = {
     "muse_sum_slices": [c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_void_p],
     "muse_cast_f32_to_bf16": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_cast_bf16_to_f32": [c_void_p, c_void_p, c_i64, c_void_p],
+    "muse_cast_f32_to_f16": [c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p],
+    "muse_operand_images": [c_int, c_float, c_void_p],
     "muse_mask_sample": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64,
                          c_i64, c_float, c_void_p],
     "muse_sample_step": [c_void_p, c_void_p, c_float, c_i64, c_i64, c_int, c_void_p, c_i64, c_void_p, c_void_p, C.c_uint64, C.c_uint32,

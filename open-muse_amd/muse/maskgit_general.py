@@ -283,6 +283,7 @@ class GeneralMaskGitEngine(TapeOps):
         loss = None
         if labels is not None:
             lab = labels.reshape(-1).contiguous()
+            self.__dict__["_loss_rows"] = lab.numel()        # ("f16" mode: bounds d(logits), tape_ops.f16_grad_scale_for)
             loss_out, lse = ops.cross_entropy_fwd(logits_p, lab, float(label_smoothing), vocab=V)
             loss = loss_out[0]
             T["ce"] = dict(lab=lab, lse=lse, loss_out=loss_out, ls=float(label_smoothing))

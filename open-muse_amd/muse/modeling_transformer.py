@@ -280,15 +280,17 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
         self.gradient_checkpointing = True  # accepted and ignored: activations fit (288 GB HBM), never recomputed
 
     def set_compute_dtype(self, dtype):
-        if self._general and dtype == "bf16x3":      # f32 tensors, every f32 GEMM as three bf16 MFMA products (tape_ops.set_compute_dtype)
-            self._cd_request = torch.float32
-            self.__dict__["_f32_split3"] = True
+        if self._general and dtype in ("bf16x3", "f16"):      # f32 tensors; every f32 GEMM as three bf16 MFMA products / one half product
+            self._cd_request = torch.float32                  # (tape_ops.set_compute_dtype)
+            self.__dict__["_f32_split3"] = dtype == "bf16x3"
+            self.__dict__["_f32_f16"] = dtype == "f16"
             return self
         if dtype not in ("auto", torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be 'auto', torch.float32 or torch.bfloat16")
         if self._general:
             self._cd_request = dtype          # (the tape helpers read self.compute_dtype: resolved at every forward)
             self.__dict__["_f32_split3"] = False
+            self.__dict__["_f32_f16"] = False
             return self
         self.compute_dtype = dtype
         self._shadow_fresh = False

@@ -599,6 +599,7 @@ class MaskGiTUViT_v2(TapeOps, ModelMixin, ConfigMixin):
         loss = None
         if labels is not None:
             lab = labels.reshape(-1).contiguous()
+            self.__dict__["_loss_rows"] = lab.numel()        # ("f16" mode: bounds d(logits), tape_ops.f16_grad_scale_for)
             loss_out, lse, rows = ops.cross_entropy_fwd(logits_p, lab, float(label_smoothing), vocab=V, want_rows=True)
             lw = None
             if loss_weight is None:

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _hip
-from ._hip import BF16, F32, GemmDesc, check, dt, lib, ptr, require_gpu, stream
+from ._hip import BF16, F16, F32, GemmDesc, check, dt, lib, ptr, require_gpu, stream
 
 # MUSE_GEMM_TR=0 routes k-major GEMM operands through an explicit transpose + the k-contiguous path instead of the
 # ds_read_b64_tr_b16 path (debug / bring-up switch; both run on the GPU through libmuse_hip).
@@ -98,6 +98,9 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     (muse_gemm_x3); returns None when that kernel does not take the product.
     """
     require_gpu(A, B, C_)
+    if (_F32_AS_F16[0] and C_.dtype == torch.float32 and (A.dtype, B.dtype) in _F16_MODE_PAIRS and act == 0 and split_k == 1 and batch == 1
+            and _gemm_f16(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, c_off, alpha, bias, rowvec, residual, ldr, accumulate, a_off, b_off)):
+        return C_
     if A.dtype != B.dtype:
         raise _hip.MuseHipError("gemm operands must share a dtype")
     if _F32_AS_BF16X3[0] and A.dtype == torch.float32 and C_.dtype == torch.float32 and act == 0 and split_k == 1:
@@ -148,7 +151,7 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     d.bias = ptr(bias)
     d.rowvec = ptr(rowvec)
     d.residual = ptr(residual)
-    d.dtype = dt(A)
+    d.dtype = F16 if A.dtype == torch.float16 else dt(A)
     d.out_dtype = dt(C_)
     d.layout_a, d.layout_b = la, lb
     d.M, d.N, d.K = M, N, K
@@ -157,7 +160,8 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
     d.sA0, d.sA1 = sA
     d.sB0, d.sB1 = sB
     d.sC0, d.sC1 = sC
-    d.alpha = alpha
+    # (half operand images carry the power of two they were scaled by: the product is handed back unscaled)
+    d.alpha = alpha / (getattr(A, "_muse_scale", 1.0) * getattr(B, "_muse_scale", 1.0)) if d.dtype == F16 else alpha
     d.accumulate = 1 if accumulate else 0
     d.act = act
     d.split_k = split_k
@@ -171,8 +175,191 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
         _prof_end(e0, f"gemm_bf16x3_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
         return _touched(C_)
     check(lib().muse_gemm(C.byref(d), stream()), "muse_gemm")
-    _prof_end(e0, f"gemm_{'bf16' if d.dtype == BF16 else 'f32'}_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
+    _prof_end(e0, f"gemm_{ {BF16: 'bf16', F16: 'f16'}.get(d.dtype, 'f32')}_{'NT'[la]}{'NT'[lb]}", 2.0 * M * N * K * batch)
     return _touched(C_)
+
+
+# ---- "f16": every f32 weight GEMM as ONE product of IEEE-half operand images ----------------------------------------------------------
+# configs/cc12m_uvit_clip.yaml:102-103 trains f32 tensors with `enable_tf32`: the products round their operands to TF32 (10-bit mantissa,
+# 8-bit exponent) and accumulate in f32.  gfx950 has no xf32 MFMA; IEEE half has the SAME 10-bit mantissa, and its MFMA
+# (v_mfma_f32_16x16x32_f16, f32 accumulation) runs at the bf16 rate - a third of the "bf16x3" mode's cost for the operand precision the
+# YAML asks for.  What half lacks is TF32's exponent range, which is the host's job here: an operand image is half(x * s) with s a power
+# of two (exact) and the product's alpha carries 1 / (s_a s_b).  Forward operands (normalised activations, weights) use s = 1; every
+# GRADIENT operand of a backward pass uses the pass's `grad_scale` (per-token loss gradients are ~1 / tokens: far below half's normal
+# range unscaled).  Elements beyond +-65504 / s are clamped and counted, non-zero elements rounded to zero are counted (F16Images.stats())
+# - a step whose counters are not (0, small) ran with the wrong scale.  Products the 256^2 half kernels refuse stay in exact f32.
+_F32_AS_F16 = [False]
+_F16_IMAGES = [None]
+# operand dtypes of a product the mode converts: f32 tensors, or an f32 tensor against an operand that already IS a half image (a
+# weight's copy kept across steps: tape_ops._wb)
+_F16_MODE_PAIRS = {(torch.float32, torch.float32), (torch.float32, torch.float16), (torch.float16, torch.float32)}
+
+
+class F16Images:
+    """The half operand images of ONE training step (the role X3Images plays for the bf16x3 mode): a tensor is converted once per step,
+    whichever products read it - keyed by (storage, shape, strides, version, scale); images made during the backward live in a short LRU.
+    `backward`: the pass running is a backward pass - the A operand of its products and the dy of its weight gradients are gradients and
+    take `grad_scale`."""
+
+    def __init__(self, grad_scale=1.0, recent=12):
+        self.persist, self.lru, self.recent, self.backward = {}, {}, int(recent), False
+        self.grad_scale = float(grad_scale)
+        self.hits = self.misses = 0
+        self._stats = None
+
+    def clear(self):
+        self.persist.clear()
+        self.lru.clear()
+
+    def set_grad_scale(self, s):
+        m, e = __import__("math").frexp(float(s))
+        if s <= 0 or m != 0.5:
+            raise _hip.MuseHipError(f"f16 mode: the gradient scale must be a power of two, got {s}")
+        self.grad_scale = float(s)
+
+    def _ensure_stats(self, device=None):
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        if self._stats is None or self._stats.device != device:
+            self._stats = torch.zeros(2, dtype=torch.int32, device=device)
+        return self._stats
+
+    def stats(self, reset=True):
+        """(operand elements / 4-element groups that overflowed half's range, non-zero elements rounded to zero by a cast) since the
+        last reset - one device read"""
+        if self._stats is None:
+            return (0, 0)
+        v = self._stats.tolist()
+        if reset:
+            self._stats.zero_()
+        return (int(v[0]), int(v[1]))
+
+    def image(self, t, scale):
+        if isinstance(t, Planes):          # a producer's result that exists as its half image only
+            if not t.half:
+                raise _hip.MuseHipError("a bf16x3 planes-only operand reached a half product")
+            return t.half_image()
+        if t.dtype == torch.float16:       # already an image (a weight's half copy): its own scale rides on it
+            return t
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, float(scale))
+        hit = self.persist.get(key)
+        if hit is None:
+            hit = self.lru.get(key)
+        if hit is not None:
+            self.hits += 1
+            return hit[1]
+        self.misses += 1
+        out = cast_to_f16(t, scale, self._ensure_stats(t.device))
+        if self.backward:
+            self.lru[key] = (t, out)
+            while len(self.lru) > self.recent:
+                self.lru.pop(next(iter(self.lru)))
+        else:
+            self.persist[key] = (t, out)
+        return out
+
+
+    def put_planes(self, t, planes):
+        """a producer kernel wrote t's half image itself ([1, *t.shape], the bits muse_cast_f32_to_f16 makes of t with the scale the
+        kernel was given: the pass's gradient scale in a backward pass, 1 in a forward one): no cast pass when a product reads t"""
+        scale = self.grad_scale if self.backward else 1.0
+        img = planes[0]
+        img._muse_scale = scale
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, float(scale))
+        self.produced = getattr(self, "produced", 0) + 1
+        if self.backward:
+            self.lru[key] = (t, img)
+            while len(self.lru) > self.recent:
+                self.lru.pop(next(iter(self.lru)))
+        else:
+            self.persist[key] = (t, img)
+
+
+class f32_gemms_as_f16:
+    """`images`: the F16Images of the step (None: a private one - every product converts its operands)"""
+    def __init__(self, on=True, images=None):
+        self.on = bool(on)
+        self.images = images if images is not None else (F16Images() if on else None)
+
+    @staticmethod
+    def _tell_kernels(on, images):
+        # the producer kernels (*_x3 entry points) write half images with this pass's gradient scale while the mode is on
+        live = on and images is not None
+        check(lib().muse_operand_images(1 if on else 0, float(images.grad_scale) if live else 1.0, images._ensure_stats().data_ptr() if live else None),
+              "muse_operand_images")
+
+    def __enter__(self):
+        self.prev = (_F32_AS_F16[0], _F16_IMAGES[0])
+        _F32_AS_F16[0] = self.on
+        if self.on:
+            _F16_IMAGES[0] = self.images
+        if self.on or self.prev[0]:
+            self._tell_kernels(self.on, self.images)
+        return self
+
+    def __exit__(self, *exc):
+        _F32_AS_F16[0], _F16_IMAGES[0] = self.prev
+        if self.on or self.prev[0]:
+            self._tell_kernels(self.prev[0], self.prev[1])
+        return False
+
+
+def cast_to_f16(t, scale=1.0, stats=None):
+    """half(t * scale) of a contiguous f32 tensor (muse_cast_f32_to_f16); the image remembers its scale (`_muse_scale`: gemm divides alpha
+    by it)"""
+    require_gpu(t)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _hip.MuseHipError("cast_to_f16: contiguous f32 tensor")
+    out = torch.empty(t.shape, dtype=torch.float16, device=t.device)
+    check(lib().muse_cast_f32_to_f16(t.data_ptr(), out.data_ptr(), t.numel(), float(scale), ptr(stats), stream()), "muse_cast_f32_to_f16")
+    out._muse_scale = float(scale)
+    return out
+
+
+def _f16_operands_ok(A, B, M, N, K, la, lb, lda, ldb):
+    """whole contiguous 2-D f32 tensors read as [rows, K] / [K, rows] operands with 16-byte half rows (what an image can stand for)"""
+    return (A.dim() == 2 and B.dim() == 2 and A.is_contiguous() and B.is_contiguous() and K % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0
+            and A.stride(0) == lda and B.stride(0) == ldb and A.shape[1 if la == 0 else 0] == K and B.shape[1 if lb == 0 else 0] == K
+            and A.shape[0 if la == 0 else 1] >= M and B.shape[0 if lb == 0 else 1] >= N and M >= 128 and N >= 128 and K >= 64
+            and A.numel() * 2 < (1 << 31) and B.numel() * 2 < (1 << 31))
+
+
+def _f16_kernel_takes(A, B, c_ptr, M, N, K, la, lb, lda, ldb, ldc, residual=None, ldr=0):
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), c_ptr           # (the f32 tensors' addresses stand in for their images': alignment probe)
+    d.dtype, d.out_dtype, d.layout_a, d.layout_b = F16, F32, la, lb
+    d.M, d.N, d.K, d.batch, d.zdiv = M, N, K, 1, 1
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.residual = ptr(residual)
+    d.alpha = 1.0
+    return lib().muse_gemm_tile(C.byref(d)) == 256
+
+
+def _gemm_f16(A, B, C_, M, N, K, la, lb, lda, ldb, ldc, c_off, alpha, bias, rowvec, residual, ldr, accumulate, a_off, b_off):
+    """-> True when the product ran on half operand images, False when the half kernels do not take it (it then runs in exact f32)"""
+    if a_off or b_off or not _f16_operands_ok(A, B, M, N, K, la, lb, lda, ldb):
+        return False
+    if not _f16_kernel_takes(A, B, C_.data_ptr() + c_off * 4, M, N, K, la, lb, lda, ldb, ldc, residual, ldr):
+        return False
+    im = _F16_IMAGES[0]
+    a16 = im.image(A, im.grad_scale if im.backward else 1.0)
+    b16 = im.image(B, 1.0)
+    gemm(a16, b16, C_, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=ldc, c_off=c_off, alpha=alpha, bias=bias, rowvec=rowvec,
+         residual=residual, ldr=ldr, accumulate=accumulate)
+    return True
+
+
+def f16_wgrad_operands(dy, x, M=None, lda=None):
+    """the half images (dy with the pass's gradient scale, x unscaled) of a weight-gradient product dy^T x the half kernels take, through
+    the running step's image cache - or None (no f16 step running / a shape they refuse: the caller keeps the f32 tensors)"""
+    if not (_F32_AS_F16[0] and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.dim() == 2 and x.dim() == 2
+            and (lda is None or lda == dy.stride(0)) and dy.shape[0] == x.shape[0]):
+        return None
+    N = M if M is not None else dy.shape[1]
+    if not (_f16_operands_ok(dy, x, N, x.shape[1], dy.shape[0], 1, 1, dy.stride(0), x.stride(0))
+            and _f16_kernel_takes(dy, x, dy.data_ptr(), N, x.shape[1], dy.shape[0], 1, 1, dy.stride(0), x.stride(0), x.shape[1])):
+        return None
+    im = _F16_IMAGES[0]
+    return im.image(dy, im.grad_scale), im.image(x, 1.0)
 
 
 # ---- "bf16x3": every f32 GEMM as three bf16 MFMA products ---------------------------------------------------------------------------
@@ -277,6 +464,16 @@ class Planes:
         self.planes = planes
         self.shape = torch.Size(planes.shape[1:])
         self.device = planes.device
+        # "f16" mode: ONE IEEE-half image [1, rows, cols] = half(x * scale); the scale is the one the producer kernel applied - the
+        # running pass's gradient scale for a backward result, 1 for a forward one (muse_operand_images)
+        self.half = planes.dtype == torch.float16
+        im = _F16_IMAGES[0]
+        self.scale = (im.grad_scale if (im is not None and im.backward) else 1.0) if self.half else 1.0
+
+    def half_image(self):
+        t = self.planes[0]
+        t._muse_scale = self.scale
+        return t
 
     def dim(self):
         return 2
@@ -515,11 +712,11 @@ def _wgrad_plan(dy, x, N, K, T_, lda, ldb):
     plan = _WGRAD_PLAN.get(key)
     if plan is None:
         plan = wgrad_splits(N, K, T_, dy.dtype, slots=512, tile=128)
-        if dy.dtype == torch.bfloat16:
+        if dy.dtype in (torch.bfloat16, torch.float16):
             sk = wgrad_splits(N, K, T_, dy.dtype, slots=256, tile=256)
             d = GemmDesc()
             d.A, d.B, d.C = dy.data_ptr(), x.data_ptr(), dy.data_ptr()   # (pointers only checked for alignment)
-            d.dtype, d.out_dtype, d.layout_a, d.layout_b = BF16, F32, 1, 1
+            d.dtype, d.out_dtype, d.layout_a, d.layout_b = (F16 if dy.dtype == torch.float16 else BF16), F32, 1, 1
             d.M, d.N, d.K, d.batch, d.zdiv = N, K, T_, 1, 1
             d.lda, d.ldb, d.ldc = lda, ldb, K
             d.alpha = 1.0
@@ -562,13 +759,18 @@ def _wgrad_x3_native(dy, x, dw, accumulate, M):
 def planes_only_ok(rows, cols):
     """may a producer hand its [rows, cols] result to the weight GEMMs as planes only?  (a bf16x3 step is running, the four-plane kernel
     is on and takes products with this operand: >= 128 rows / columns, whole 16-byte rows)"""
-    return (_X3_IMAGES[0] is not None and _F32_AS_BF16X3[0] and X3_NATIVE and X3_PRODUCERS and X3_PLANES_ONLY and rows >= 128 and cols >= 128
-            and rows % 8 == 0 and cols % 8 == 0 and rows * cols * 2 < (1 << 31))
+    on = ((_X3_IMAGES[0] is not None and _F32_AS_BF16X3[0] and X3_NATIVE and X3_PRODUCERS)
+          or (_F16_IMAGES[0] is not None and _F32_AS_F16[0] and F16_PRODUCERS))       # ("f16" mode: the result as its half image only)
+    return (on and X3_PLANES_ONLY and rows >= 128 and cols >= 128 and rows % 8 == 0 and cols % 8 == 0 and rows * cols * 2 < (1 << 31))
 
 
 def linear_wgrad(dy, x, dw, accumulate, M=None, lda=None):
     """dw[N,K] (+)= dy[T,N]^T @ x[T,K]   (both operands k-major, f32 output into the flat grad buffer).
     Split-K slices write partial tiles to a workspace that muse_sum_slices folds into dw in a fixed order."""
+    if _F32_AS_F16[0] and dw.dtype == torch.float32 and dw.is_contiguous() and dw.data_ptr() % 16 == 0:
+        pair = f16_wgrad_operands(dy, x, M, lda)      # half operand images: dy is a gradient (the pass's scale), x a saved activation
+        if pair is not None:
+            return linear_wgrad(pair[0], pair[1], dw, accumulate, M=M, lda=lda)
     x3 = _F32_AS_BF16X3[0] and dy.dtype == torch.float32 and x.dtype == torch.float32 and dw.dtype == torch.float32 \
         and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and x.shape[1] % 8 == 0 and (M if M is not None else dy.shape[1]) % 8 == 0
     if not x3 and (isinstance(dy, Planes) or isinstance(x, Planes)):
@@ -643,7 +845,8 @@ def linear_wgrad_group(items, colsums=None, split=None):
     256^2 kernel does not take every product (f32 mode, tiny shapes)."""
     split = WGRAD_GROUP if split is None else split
     descs, meta = [], []
-    ok = split >= 1 and 1 <= len(items) <= 8 and all(it[0].dtype == torch.bfloat16 and it[1].dtype == torch.bfloat16 for it in items)
+    dt16 = items[0][0].dtype if items else None
+    ok = split >= 1 and 1 <= len(items) <= 8 and dt16 in (torch.bfloat16, torch.float16) and all(it[0].dtype == dt16 and it[1].dtype == dt16 for it in items)
     if ok:
         arr = (GemmDesc * len(items))()
         for d, (dy, x, dw, accumulate, M, lda) in zip(arr, items):
@@ -653,10 +856,10 @@ def linear_wgrad_group(items, colsums=None, split=None):
             ok = ok and dw.dtype == torch.float32 and dw.is_contiguous() and (N * K) % 4 == 0
             ok = ok and (split == 1 or dw.data_ptr() % 16 == 0)   # muse_sum_multi's slice sums store 16 bytes at a time
             d.A, d.B = dy.data_ptr(), x.data_ptr()
-            d.dtype, d.out_dtype, d.layout_a, d.layout_b = BF16, F32, 1, 1
+            d.dtype, d.out_dtype, d.layout_a, d.layout_b = (F16 if dt16 == torch.float16 else BF16), F32, 1, 1
             d.M, d.N, d.K, d.batch, d.zdiv = N, K, T_, 1, 1
             d.lda, d.ldb, d.ldc = (lda or dy.stride(0)), x.stride(0), K
-            d.alpha = 1.0
+            d.alpha = 1.0 / (getattr(dy, "_muse_scale", 1.0) * getattr(x, "_muse_scale", 1.0))      # (half images carry their power-of-two scale)
             meta.append((N, K, T_))
         if ok:
             ws = []
@@ -691,7 +894,7 @@ def linear_wgrad_group(items, colsums=None, split=None):
             check(lib().muse_gemm_group(arr, len(items), 1, stream()), "muse_gemm_group")
     else:
         check(lib().muse_gemm_group(arr, len(items), split, stream()), "muse_gemm_group")
-    _prof_end(e0, "gemm_bf16_TT", sum(2.0 * N * K * T_ for N, K, T_ in meta))
+    _prof_end(e0, "gemm_f16_TT" if dt16 == torch.float16 else "gemm_bf16_TT", sum(2.0 * N * K * T_ for N, K, T_ in meta))
     jobs = []
     if split > 1:
         # (the slice count the kernel really cuts: ceil(nk / ceil(nk / split)) slices are non-empty; the others leave their workspace
@@ -1028,7 +1231,7 @@ def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None
         if ent is None or ent[0] is None:
             pl += [None, 0]
         else:
-            if ent[0].stride() != ref.stride() or ent[0].shape != ref.shape or ent[0].dtype != torch.bfloat16:
+            if ent[0].stride() != ref.stride() or ent[0].shape != ref.shape or ent[0].dtype != (torch.float16 if _F32_AS_F16[0] else torch.bfloat16):
                 raise _hip.MuseHipError("attention_x3_bwd: a hi-plane view must mirror its gradient view")
             pl += [ent[0].data_ptr(), int(ent[1])]
     check(lib().muse_attention_x3_bwd(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), *args, *pl, stream()), "muse_attention_x3_bwd")
@@ -1063,10 +1266,14 @@ def attention_bwd(qkv, ctx, dctx, lse, B, S, nh, hd, alpha):
 
 X3_PLANES_ONLY = os.environ.get("MUSE_X3_PLANES_ONLY", "1") != "0"   # ... and skip the f32 result where only weight GEMMs read it (ops.Planes)
 X3_PRODUCERS = os.environ.get("MUSE_X3_PRODUCERS", "1") != "0"   # bf16x3 mode: kernels whose f32 result feeds a product write its operand planes too
+F16_PRODUCERS = os.environ.get("MUSE_F16_PRODUCERS", "1") != "0"  # f16 mode: ... write its half image too (0: every operand through muse_cast_f32_to_f16)
 
 
 def _x3_producing(t):
     """the running step's image cache when a producer of `t`-like f32 results should write operand planes next to them"""
+    if _F32_AS_F16[0]:
+        im = _F16_IMAGES[0]
+        return im if (im is not None and F16_PRODUCERS and t.dtype == torch.float32 and t.is_contiguous()) else None
     im = _X3_IMAGES[0]
     return im if (im is not None and X3_NATIVE and X3_PRODUCERS and t.dtype == torch.float32 and t.is_contiguous()) else None
 
@@ -1077,12 +1284,20 @@ def x3_new_planes(t):
     im = _x3_producing(t)
     if im is None or t.dim() != 2 or t.shape[1] % 8:
         return None
-    return torch.empty((2,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+    return planes_alloc(tuple(t.shape), t.device)
+
+
+def planes_alloc(shape, device):
+    """the operand-image tensor a producer kernel of the running step writes for a [rows, cols] result: [2, rows, cols] bf16 (hi, lo
+    planes, "bf16x3" mode) or [1, rows, cols] IEEE half ("f16" mode: muse_operand_images tells the kernels which)"""
+    if _F32_AS_F16[0]:
+        return torch.empty((1,) + tuple(shape), dtype=torch.float16, device=device)
+    return torch.empty((2,) + tuple(shape), dtype=torch.bfloat16, device=device)
 
 
 def x3_put_planes(t, planes):
     if planes is not None:
-        _X3_IMAGES[0].put_planes(t, planes)
+        (_F16_IMAGES[0] if _F32_AS_F16[0] else _X3_IMAGES[0]).put_planes(t, planes)
 
 
 def glu_fwd(ab, planes_only=False):
@@ -1092,13 +1307,13 @@ def glu_fwd(ab, planes_only=False):
     if planes_only:
         if not (planes_only_ok(rows, two_i // 2) and ab.dtype == torch.float32 and ab.is_contiguous()):
             raise _hip.MuseHipError("glu_fwd(planes_only=True) outside planes_only_ok")
-        planes = torch.empty((2, rows, two_i // 2), dtype=torch.bfloat16, device=ab.device)
+        planes = planes_alloc((rows, two_i // 2), ab.device)
         check(lib().muse_glu_fwd_x3(ab.data_ptr(), None, planes.data_ptr(), rows, two_i // 2, stream()), "muse_glu_fwd_x3")
         return Planes(planes)
     h = torch.empty((rows, two_i // 2), dtype=ab.dtype, device=ab.device)
     im = _x3_producing(ab)
     if im is not None and (two_i // 2) % 8 == 0:
-        planes = torch.empty((2, rows, two_i // 2), dtype=torch.bfloat16, device=ab.device)
+        planes = planes_alloc((rows, two_i // 2), ab.device)
         check(lib().muse_glu_fwd_x3(ab.data_ptr(), h.data_ptr(), planes.data_ptr(), rows, two_i // 2, stream()), "muse_glu_fwd_x3")
         im.put_planes(h, planes)
         return h
@@ -1112,13 +1327,13 @@ def glu_bwd(ab, dh, planes_only=False):
     if planes_only:
         if not (planes_only_ok(rows, two_i) and ab.dtype == torch.float32 and dh.dtype == torch.float32 and ab.is_contiguous() and dh.is_contiguous()):
             raise _hip.MuseHipError("glu_bwd(planes_only=True) outside planes_only_ok")
-        planes = torch.empty((2, rows, two_i), dtype=torch.bfloat16, device=ab.device)
+        planes = planes_alloc((rows, two_i), ab.device)
         check(lib().muse_glu_bwd_x3(ab.data_ptr(), dh.data_ptr(), None, planes.data_ptr(), rows, two_i // 2, stream()), "muse_glu_bwd_x3")
         return Planes(planes)
     dab = torch.empty_like(ab)
     im = _x3_producing(ab)
     if im is not None and dh.dtype == torch.float32 and dh.is_contiguous() and two_i % 16 == 0:
-        planes = torch.empty((2, rows, two_i), dtype=torch.bfloat16, device=ab.device)
+        planes = planes_alloc((rows, two_i), ab.device)
         check(lib().muse_glu_bwd_x3(ab.data_ptr(), dh.data_ptr(), dab.data_ptr(), planes.data_ptr(), rows, two_i // 2, stream()), "muse_glu_bwd_x3")
         im.put_planes(dab, planes)
         return dab
@@ -1853,7 +2068,7 @@ def norm_adaln_fwd(x, w, ss, batch, eps, mode, residual=None, out_dtype=torch.fl
     if planes_only:
         if not (planes_only_ok(rows, cols) and x.dtype == torch.float32 and x.is_contiguous()):
             raise _hip.MuseHipError("norm_adaln_fwd(planes_only=True) outside planes_only_ok")
-        planes = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=x.device)
+        planes = planes_alloc((rows, cols), x.device)
         check(lib().muse_norm_adaln_fwd_x3(x.data_ptr(), ptr(residual), ptr(w), ss.data_ptr(), pre.data_ptr(), None, planes.data_ptr(),
                                            batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_fwd_x3")
         return Planes(planes), pre
@@ -1861,7 +2076,7 @@ def norm_adaln_fwd(x, w, ss, batch, eps, mode, residual=None, out_dtype=torch.fl
     f32 = out_dtype == torch.float32
     im = _x3_producing(x) if f32 else None
     if im is not None and cols % 8 == 0:        # "bf16x3" mode: m feeds weight GEMMs - its operand planes come out of this kernel
-        planes = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=x.device)
+        planes = planes_alloc((rows, cols), x.device)
         check(lib().muse_norm_adaln_fwd_x3(x.data_ptr(), ptr(residual), ptr(w), ss.data_ptr(), pre.data_ptr(), m.data_ptr(), planes.data_ptr(),
                                            batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_fwd_x3")
         im.put_planes(m, planes)
@@ -1882,7 +2097,7 @@ def norm_adaln_bwd(dm, v, w, ss, batch, eps, mode, dpre=None, also_bf16=False, d
     spart = torch.empty((nblk, 2 * cols), dtype=torch.float32, device=v.device)
     im = _x3_producing(v) if not also_bf16 else None
     if im is not None and cols % 8 == 0:        # "bf16x3" mode: dv is the dY of the weight GEMMs below - planes from this kernel
-        planes = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=v.device)
+        planes = planes_alloc((rows, cols), v.device)
         check(lib().muse_norm_adaln_bwd_x3(dm.data_ptr(), ptr(dpre), v.data_ptr(), ptr(w), ss.data_ptr(), dv.data_ptr(), planes.data_ptr(),
                                            part.data_ptr(), spart.data_ptr(), batch, rows // batch, cols, eps, mode, stream()), "muse_norm_adaln_bwd_x3")
         im.put_planes(dv, planes)

@@ -22,6 +22,8 @@ _BF16_OPERANDS = int(os.environ.get("MUSE_UVIT_BF16_OPERANDS", "3"))
 
 
 X3_WEIGHT_PLANES = os.environ.get("MUSE_X3_WEIGHT_PLANES", "1") != "0"   # bf16x3 mode: weight operand planes kept across steps, refreshed by FusedAdamW
+F16_WEIGHT_IMAGES = os.environ.get("MUSE_F16_WEIGHT_IMAGES", "1") != "0"   # f16 mode: the weights' half images kept across steps, refreshed by FusedAdamW
+F16_WGRAD_GROUP = os.environ.get("MUSE_F16_WGRAD_GROUP", "1") != "0"       # f16 mode: a block's weight gradients as one grouped launch on the dW stream
 
 
 class TapeOps:
@@ -70,13 +72,18 @@ class TapeOps:
         (linears, 1x1 convs, their dX / dW) are rounded to bf16 and run on the bf16 MFMA kernels with f32 accumulation and f32
         outputs - the reference's autocast regime; the residual stream, norms, AdaLN, GRN, depthwise conv, softmax / attention
         core and the loss stay f32."""
-        if dtype not in (torch.float32, torch.bfloat16, "bf16x3"):
-            raise ValueError('compute dtype must be torch.float32, torch.bfloat16 or "bf16x3"')
+        if dtype not in (torch.float32, torch.bfloat16, "bf16x3", "f16"):
+            raise ValueError('compute dtype must be torch.float32, torch.bfloat16, "bf16x3" or "f16"')
         # "bf16x3": the f32 mode's tensors and kernels, with every f32 GEMM computed as three bf16 MFMA products of hi / lo operand
         # planes (ops.f32_gemms_as_bf16x3): TF32-class-or-tighter products (2^-16 relative) at 1/3 of the bf16 matrix rate instead of
         # the 157 TFLOP/s exact-f32 MFMA - the CDNA4 counterpart of the `enable_tf32` regime of configs/cc12m_uvit_clip.yaml:102-103
+        # "f16" (round 6): the f32 mode's tensors and kernels, with every weight GEMM as ONE product of IEEE-half operand images
+        # (ops.f32_gemms_as_f16): half's 10-bit mantissa IS the TF32 operand format of that `enable_tf32` regime, at the bf16 matrix rate;
+        # the exponent range TF32 has and half lacks is covered by power-of-two operand scales (gradients: `f16_grad_scale`).  The
+        # attention core runs the bf16x3 mode's fused kernels (csrc/attention3.hip: tighter than TF32).
         self.__dict__["_f32_split3"] = dtype == "bf16x3"
-        self.compute_dtype = torch.float32 if dtype == "bf16x3" else dtype
+        self.__dict__["_f32_f16"] = dtype == "f16"
+        self.compute_dtype = torch.float32 if dtype in ("bf16x3", "f16") else dtype
         self._wcache, self._wcache_owner = {}, {}
         self.__dict__["_wgen"] = self.__dict__.get("_wgen", 0) + 1      # (a kept decoding graph reads the old weight copies: generate2 re-captures)
         return self
@@ -85,6 +92,14 @@ class TapeOps:
         """context manager for one forward / backward pass: f32 GEMMs as three bf16 products in "bf16x3" mode.  A training step
         (forward that records a tape, then its backward) shares the operand images of its products (ops.X3Images): an activation /
         gradient is split once, not once per product that reads it."""
+        if self.__dict__.get("_f32_f16", False):
+            images = self.__dict__.get("_f16_images")
+            if images is None:
+                images = self.__dict__["_f16_images"] = ops.F16Images()
+            images.backward = bool(backward)
+            if backward:
+                images.set_grad_scale(self.f16_grad_scale_for(self.__dict__.get("_loss_rows", 1)))
+            return ops.f32_gemms_as_f16(True, images)
         on = self.__dict__.get("_f32_split3", False)
         images = None
         if on and _X3_IMAGE_CACHE and (backward or self.__dict__.get("_act_cache_on", False)):
@@ -94,12 +109,48 @@ class TapeOps:
             images.backward = bool(backward)
         return ops.f32_gemms_as_bf16x3(on, images)
 
+    f16_grad_scale = None      # "f16" mode: the power of two every gradient operand image is scaled by; None = from the loss's row count
+
+    def f16_grad_scale_for(self, loss_rows):
+        """"f16" mode: the scale of a backward pass's gradient operands.  The loss is a mean over `loss_rows` token rows, so the largest
+        element of d(logits) is at most 1 / loss_rows; the scale puts that bound at 2^10, which leaves a factor 64 of headroom for
+        gradients that grow on the way down (clamped elements are counted: `f16_stats`) and keeps full half precision down to 2^-24 of it."""
+        if self.f16_grad_scale is not None:
+            return float(self.f16_grad_scale)
+        n = 1
+        while n < int(loss_rows):
+            n *= 2
+        return float(n) * 1024.0
+
+    def f16_stats(self, reset=True):
+        """"f16" mode: (operand elements that overflowed half's range, non-zero elements rounded to zero) since the last call - a device read"""
+        images = self.__dict__.get("_f16_images")
+        return (0, 0) if images is None else images.stats(reset)
+
+    def f16_update_grad_scale(self, growth_interval=2000):
+        """"f16" mode, the dynamic loss-scaling recipe of fp16 training (torch.cuda.amp.GradScaler's policy) applied to the gradient OPERAND
+        scale: call after backward().  An operand overflowed half's range (the gradients are NaN): the scale is halved and False comes
+        back - skip the optimizer step.  Otherwise True, and after `growth_interval` good steps in a row the scale doubles.  The scale
+        only moves rounding (it is undone exactly in every product's alpha), never values; one device read per call."""
+        overflowed, _ = self.f16_stats()
+        cur = self.f16_grad_scale_for(self.__dict__.get("_loss_rows", 1))
+        if overflowed:
+            self.f16_grad_scale = max(cur * 0.5, 1.0)
+            self.__dict__["_f16_good_steps"] = 0
+            return False
+        good = self.__dict__.get("_f16_good_steps", 0) + 1
+        if good >= growth_interval:
+            self.f16_grad_scale, good = cur * 2.0, 0
+        self.__dict__["_f16_good_steps"] = good
+        return True
+
     def _drop_step_caches(self):
-        """start of a forward / end of a backward: nothing of the previous pass (bf16 activation copies, bf16x3 operand images) survives"""
+        """start of a forward / end of a backward: nothing of the previous pass (bf16 activation copies, bf16x3 / half operand images) survives"""
         self.__dict__["_act_cache"] = {}
-        images = self.__dict__.get("_x3_images")
-        if images is not None:
-            images.clear()
+        for name in ("_x3_images", "_f16_images"):
+            images = self.__dict__.get(name)
+            if images is not None:
+                images.clear()
 
     def mark_weights_changed(self):
         """call after writing parameters behind autograd's back (`p.data.copy_`, EMA swap): drops the cached bf16 weights"""
@@ -144,7 +195,9 @@ class TapeOps:
         if hit is not None and hit[0] == ver and hit[1].device == mods[0].weight.device:
             return hit[1]
         ws = [self._f(m.weight).reshape(m.weight.shape[0], -1) for m in mods]
-        wb = ops.cast_to_bf16((ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)).contiguous())
+        w32 = (ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)).contiguous()
+        # ("f16" mode: the copy is the weight's IEEE-half operand image, unscaled - FusedAdamW refreshes it as such)
+        wb = ops.cast_to_f16(w32) if self.__dict__.get("_f32_f16", False) else ops.cast_to_bf16(w32)
         for pid in key:
             prev = owner.get(pid)
             if prev is not None and prev != key:
@@ -203,6 +256,9 @@ class TapeOps:
         k_in = mods[0].weight.numel() // mods[0].weight.shape[0]
         if self.compute_dtype == torch.bfloat16 and k_in % 8 == 0:
             return self._wb(*mods)
+        if (self.__dict__.get("_f32_f16", False) and F16_WEIGHT_IMAGES and rows is not None and rows >= 128 and k_in >= 128 and k_in % 8 == 0
+                and sum(m.weight.shape[0] for m in mods) >= 128 and sum(m.weight.shape[0] for m in mods) % 8 == 0):
+            return self._wb(*mods)          # the half image kept across steps (every product of this Linear is one the half kernels take)
         if (rows is not None and rows >= 128 and self.__dict__.get("_f32_split3", False) and X3_WEIGHT_PLANES and k_in >= 128
                 and ops.planes_only_ok(sum(m.weight.shape[0] for m in mods), k_in)):
             return self._wp(*mods)
@@ -249,7 +305,14 @@ class TapeOps:
             xc = x if x.dtype == torch.float32 else ops.cast_to_f32(x.contiguous())
         else:
             dyc, xc = self._c(dy), self._c(x)
-        if not (self.wgrad_stream and self.compute_dtype == torch.bfloat16 and x.is_cuda):
+        half = None
+        if self.__dict__.get("_f32_f16", False) and F16_WGRAD_GROUP and self.wgrad_stream and x.is_cuda and ops.WGRAD_GROUP >= 1:
+            # f16 mode: the half images of both operands (the ones the dX / forward products made: the step's image cache) go to the
+            # grouped launch on the weight-gradient stream like the bf16 mode's copies
+            half = ops.f16_wgrad_operands(dyc, xc, M, lda)
+            if half is not None:
+                dyc, xc = half
+        if not (self.wgrad_stream and (self.compute_dtype == torch.bfloat16 or half is not None) and x.is_cuda):
             dw = torch.empty(shape2, dtype=torch.float32, device=x.device)
             ops.linear_wgrad(dyc, xc, dw, False, M=M, lda=lda)
             return dw
@@ -257,7 +320,7 @@ class TapeOps:
         if self._side_stream is None or self._side_stream.device != x.device:
             self._side_stream = torch.cuda.Stream(device=x.device)
         side = self._side_stream
-        if ops.WGRAD_GROUP >= 1 and dyc.dtype == torch.bfloat16 and xc.dtype == torch.bfloat16:
+        if ops.WGRAD_GROUP >= 1 and dyc.dtype == xc.dtype and dyc.dtype in (torch.bfloat16, torch.float16):
             # grouped form: the block's weight gradients are collected and issued as ONE launch over all their tiles when the block is
             # done (_flush_dw, called from _report_grads) - the returned tensor is filled then; nothing reads a weight gradient earlier
             with torch.cuda.stream(side):
@@ -340,7 +403,8 @@ class TapeOps:
             y = ops.linear(o, self._wb(att.out), out_dtype=torch.float32, residual=residual, bias=self._b(att.out))
             return y, dict(fused=True, self_attn=self_attn, xb=xb, cb=cb, q=q, qkv=qkv, o=o, lse=lse,
                            dims=(B, Sq, Skv, nh, hd, Cq, alpha))
-        if (self.__dict__.get("_f32_split3", False) and _X3_ATTENTION and pdrop == 0.0 and ops.attention_x3_supported(Sq, Skv, hd)
+        if ((self.__dict__.get("_f32_split3", False) or self.__dict__.get("_f32_f16", False)) and _X3_ATTENTION and pdrop == 0.0
+                and ops.attention_x3_supported(Sq, Skv, hd)
                 and x.dtype == torch.float32 and ctx.dtype == torch.float32 and att.key.weight.shape[1] % 8 == 0):
             # "bf16x3" mode: the same fused form on f32 tensors, every product of the core as three bf16 MFMA products like the mode's
             # GEMMs (csrc/attention3.hip); packed q|k|v (self) / k|v (cross) projections: one forward, one dX and one dW product each
@@ -418,7 +482,7 @@ class TapeOps:
             lo = qkv.numel()
             if not blocked and not ub and ops.planes_only_ok(qkv.shape[0], qkv.shape[1]) and min(w.shape) >= 128:
                 # dqkv feeds one dW and one dX product and nothing else: it exists as their operand planes only
-                pl = torch.empty((2,) + tuple(qkv.shape), dtype=torch.bfloat16, device=qkv.device)
+                pl = ops.planes_alloc(tuple(qkv.shape), qkv.device)
                 ops.attention_x3_bwd(q, qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, planes_only=True,
                                      planes=((pl[0][:, :Cq], lo), (pl[0][:, Cq:2 * Cq], lo), (pl[0][:, 2 * Cq:], lo)))
                 dqkv = ops.Planes(pl)
@@ -438,8 +502,8 @@ class TapeOps:
         if (not blocked and not ub and ops.planes_only_ok(q.shape[0], q.shape[1]) and ops.planes_only_ok(qkv.shape[0], qkv.shape[1]) and min(w.shape) >= 128
                 and min(att.query.weight.shape) >= 128):
             # dq and dkv feed one dW and one dX product each and nothing else: planes only
-            plq = torch.empty((2,) + tuple(q.shape), dtype=torch.bfloat16, device=q.device)
-            plkv = torch.empty((2,) + tuple(qkv.shape), dtype=torch.bfloat16, device=q.device)
+            plq = ops.planes_alloc(tuple(q.shape), q.device)
+            plkv = ops.planes_alloc(tuple(qkv.shape), q.device)
             ops.attention_x3_bwd(q, qkv[:, :Cq], qkv[:, Cq:], sv["o"], do, sv["lse"], B, Sq, Skv, nh, hd, alpha, planes_only=True,
                                  planes=((plq[0], q.numel()), (plkv[0][:, :Cq], qkv.numel()), (plkv[0][:, Cq:], qkv.numel())))
             dq, dkv = ops.Planes(plq), ops.Planes(plkv)

@@ -369,7 +369,8 @@ class FusedAdamW(torch.optim.Optimizer):
         tensor's group and the launch is muse_adamw_multi_groups."""
         params = [(p, k) for k, grp in enumerate(self.param_groups) for p in grp["params"] if p.grad is not None]
         # (operand planes of the bf16x3 mode ride in the group column of the grouped table: a one-group model with planes takes that kernel too)
-        multi = len(self.param_groups) > 1 or any(getattr(p, "_muse_planes", None) is not None for p, _ in params)
+        multi = len(self.param_groups) > 1 or any(getattr(p, "_muse_planes", None) is not None
+                                                  or getattr(getattr(p, "_muse_shadow", None), "dtype", None) == torch.float16 for p, _ in params)
         if not params:
             return loss
         if self._m is None:
@@ -390,7 +391,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 shadow = None
             # ... or (bf16x3 mode, tape_ops._wp) its (hi, lo) operand planes: hi-plane rows + the element distance to the lo plane, which
             # rides in the group column above bit 8
-            lo = 0
+            lo = -1 if (shadow is not None and shadow.dtype == torch.float16) else 0     # ("f16" mode: the copy is IEEE half)
             planes = getattr(p, "_muse_planes", None)
             if planes is not None and shadow is None and planes[0].numel() == p.numel() and planes[0].device == p.device \
                     and planes[0].is_contiguous() and planes[1] > 0:

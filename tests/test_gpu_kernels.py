@@ -1554,6 +1554,167 @@ def test_bf16x3_weight_gradient_with_k_split():
     assert torch.equal(dw, again)                 # deterministic: slices are summed in a fixed order
 
 
+def _tf32(x):
+    """round to nearest even at 10 mantissa bits: the TF32 operand format (f32 in, f32 out)"""
+    i = x.contiguous().view(torch.int32)
+    return ((i + 0xFFF + ((i >> 13) & 1)) & ~0x1FFF).view(torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 1024), (300, 384, 256), (1000, 520, 200), (264, 136, 72)])
+def test_f16_mode_product_is_the_tf32_product(M, N, K):
+    """ops.f32_gemms_as_f16 (muse_gemm dtype MUSE_F16, v_mfma_f32_16x16x32_f16): one product of IEEE-half operand images with f32
+    accumulation.  Half and TF32 share the 10-bit mantissa, so on operands inside half's exponent range the result is the TF32 product
+    configs/cc12m_uvit_clip.yaml:103 (`enable_tf32`) computes: equal to an emulated one (operands rounded to 10 mantissa bits, float64
+    accumulation) up to f32 accumulation error (1e-6 of sum |a||b|), and 2^-11 of sum |a||b| from float64 like it.  Every operand layout,
+    ragged tile edges, epilogue extras; a gradient-sized operand through the power-of-two scale; half subnormals through the MFMA."""
+    ops = _ops()
+    a, b = rnd((M, K), 720).to(DEV), rnd((N, K), 721, 0.05).to(DEV)
+    at, bt = a.t().contiguous(), b.t().contiguous()
+    res, bias = rnd((M, N), 722).to(DEV), rnd((N,), 723).to(DEV)
+    ref = a.double() @ b.double().t()
+    emu = _tf32(a).double() @ _tf32(b).double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    for la, lb, A, B in ((0, 0, a, b), (0, 1, a, bt), (1, 1, at, bt), (1, 0, at, b)):
+        lda, ldb = (K if la == 0 else M), (K if lb == 0 else N)
+        c = torch.empty((M, N), device=DEV)
+        im = ops.F16Images()
+        with ops.f32_gemms_as_f16(True, im):
+            ops.gemm(A, B, c, M, N, K, la=la, lb=lb, lda=lda, ldb=ldb, ldc=N)
+        if (la and M % 8) or (lb and N % 8):       # rows of a k-major half operand must be whole 16-byte chunks: the product stays exact f32
+            assert im.misses == 0 and float(((c.double() - ref).abs() / mag).max()) < 1e-6, (la, lb)
+            continue
+        assert im.misses == 2                                              # the half kernel ran (no silent exact-f32 product)
+        assert float(((c.double() - emu).abs() / mag).max()) < 1e-6, (la, lb)
+        assert float(((c.double() - ref).abs() / mag).max()) < 2.0 ** -11, (la, lb)
+        assert im.stats()[0] == 0
+    c = torch.empty((M, N), device=DEV)
+    with ops.f32_gemms_as_f16():
+        ops.gemm(a, b, c, M, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias, residual=res, ldr=N)
+        want = 0.5 * emu + bias.double() + res.double()
+        assert rel_err(c, want) < 2e-6
+        ops.gemm(a, b, c, M, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N, accumulate=True)
+        assert rel_err(c, want + emu) < 2e-6
+        tiny = torch.empty((64, N), device=DEV)                           # a shape the half kernels refuse stays exact f32
+        ops.gemm(a[:64].contiguous(), b, tiny, 64, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N)
+        assert rel_err(tiny, ref[:64]) < 1e-5
+    # a gradient-sized operand: unscaled it falls below half's range (elements rounded to zero are counted), with the pass's
+    # power-of-two scale it is the TF32 product again - the scale is undone exactly in alpha
+    g = a * 1e-7
+    for scale, bound in ((None, None), (2.0 ** 24, 1e-6)):
+        im = ops.F16Images()
+        if scale is not None:
+            im.backward = True
+            im.set_grad_scale(scale)
+        with ops.f32_gemms_as_f16(True, im):
+            ops.gemm(g, b, c, M, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N)
+        err = float(((c.double() - _tf32(g).double() @ _tf32(b).double().t()).abs() / (mag * 1e-7)).max())
+        clamped, flushed = im.stats()
+        if scale is None:
+            assert flushed > 0.1 * g.numel() and err > 1e-3
+        else:
+            assert err < bound and clamped == 0 and flushed < 1e-4 * g.numel()
+    with pytest.raises(Exception):
+        ops.F16Images().set_grad_scale(3.0)                                # not a power of two: the un-scaling would round
+    # operands that are half SUBNORMALS (exactly representable): the MFMA does not flush them - the product is exact
+    sub = torch.randint(-512, 512, (M, K), device=DEV).float() * 2.0 ** -24
+    bb = torch.randint(-8, 8, (N, K), device=DEV).float()
+    with ops.f32_gemms_as_f16():
+        ops.gemm(sub, bb, c, M, N, K, la=0, lb=0, lda=K, ldb=K, ldc=N)
+    assert torch.equal(c.double(), sub.double() @ bb.double().t())
+
+
+def test_f16_mode_weight_gradient_with_k_split():
+    """dW = dY^T X over 8192 tokens in the f16 mode: half images of both operands (dY with the pass's gradient scale), the 256^2
+    kernel's K slices through a workspace - the emulated TF32 product to f32 accumulation error, deterministic, accumulating"""
+    ops = _ops()
+    T, N, K = 8192, 384, 512
+    dy, x = (rnd((T, N), 730) * 3e-6).to(DEV), rnd((T, K), 731).to(DEV)
+    emu = _tf32(dy).double().t() @ _tf32(x).double()
+    im = ops.F16Images()
+    im.backward = True
+    im.set_grad_scale(2.0 ** 20)
+    dw = torch.empty((N, K), device=DEV)
+    with ops.f32_gemms_as_f16(True, im):
+        ops.linear_wgrad(dy, x, dw, False)
+        dw2 = dw.clone()
+        ops.linear_wgrad(dy, x, dw2, True)
+        again = torch.empty((N, K), device=DEV)
+        ops.linear_wgrad(dy, x, again, False)
+    assert im.misses == 2 and im.hits == 4 and im.stats() == (0, 0)
+    assert rel_err(dw, emu) < 2e-6 and rel_err(dw2, 2 * emu) < 2e-6
+    assert torch.equal(dw, again)
+
+
+def test_f16_mode_producers_write_half_images():
+    """Inside an f16 step the producer kernels (GLU forward / backward, AdaLN-norm forward / backward, the fused attention's context and
+    gradients) write their result's IEEE-half operand image next to the f32 result (muse_operand_images): bit for bit what
+    muse_cast_f32_to_f16 makes of that result - unscaled in a forward pass, times the pass's gradient scale in a backward pass -
+    registered under the result tensor so the product that reads it launches no cast; the f32 results are the plain kernels' bits.
+    A result only weight GEMMs read exists as its image alone (ops.Planes) and gives the same products."""
+    ops = _ops()
+    rows, inter, C_, B = 512, 256, 512, 2
+    ab, dh = rnd((rows, 2 * inter), 740).to(DEV), rnd((rows, inter), 741, 1e-5).to(DEV)
+    x, res, w, ss = rnd((rows, C_), 742).to(DEV), rnd((rows, C_), 743).to(DEV), rnd((C_,), 744).to(DEV) + 1.0, rnd((B, 2 * C_), 745).to(DEV)
+    nh, hd, Sq = 2, 64, 256
+    H = nh * hd
+    qkv, dctx = rnd((B * Sq, 3 * H), 746).to(DEV), rnd((B * Sq, H), 747, 1e-5).to(DEV)
+    wl = rnd((384, inter), 748).to(DEV)
+
+    def forward():
+        h = ops.glu_fwd(ab)
+        m, pre = ops.norm_adaln_fwd(x, w, ss, B, 1e-6, 1, residual=res)
+        ctx, lse = ops.attention_x3_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, Sq, Sq, nh, hd, 0.125)
+        return dict(h=h, m=m, ctx=ctx), pre, lse
+
+    def backward(m, pre, ctx, lse):
+        dab = ops.glu_bwd(ab, dh)
+        dv, dw, dss = ops.norm_adaln_bwd(m * 1e-5, pre, w, ss, B, 1e-6, 1, dpre=x * 1e-5)
+        dqkv = torch.empty_like(qkv)
+        pl = ops.x3_new_planes(dqkv)
+        lo = dqkv.numel()
+        ops.attention_x3_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], ctx, dctx, lse, B, Sq, Sq, nh, hd, 0.125, dq=dqkv[:, :H],
+                             dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:],
+                             planes=None if pl is None else ((pl[0][:, :H], lo), (pl[0][:, H:2 * H], lo), (pl[0][:, 2 * H:], lo)))
+        ops.x3_put_planes(dqkv, pl)
+        return dict(dab=dab, dv=dv, dqkv=dqkv)
+    pf, pre, lse = forward()
+    pb = backward(pf["m"], pre, pf["ctx"], lse)
+    im = ops.F16Images()
+    S = 2.0 ** 14
+    for bwd, plain in ((False, pf), (True, pb)):
+        im.backward = bwd
+        im.set_grad_scale(S)
+        with ops.f32_gemms_as_f16(True, im):
+            fused = backward(pf["m"], pre, pf["ctx"], lse) if bwd else forward()[0]
+            for name, t in fused.items():
+                assert torch.equal(t, plain[name]), name                   # the f32 results do not change
+                misses = im.misses
+                img = im.image(t, S if bwd else 1.0)                       # what a product reading t gets: the producer's image
+                assert im.misses == misses, name
+                assert torch.equal(img, ops.cast_to_f16(t, S if bwd else 1.0)), name
+                assert img._muse_scale == (S if bwd else 1.0)
+            # a result that exists as its image only: the same forward / dX / dW products
+            assert ops.planes_only_ok(rows, inter)
+            if not bwd:
+                hp = ops.glu_fwd(ab, planes_only=True)
+                assert isinstance(hp, ops.Planes) and hp.half and torch.equal(hp.planes[0], ops.cast_to_f16(fused["h"]))
+                assert torch.equal(ops.linear(hp, wl), ops.linear(fused["h"], wl))
+            else:
+                dp = ops.glu_bwd(ab, dh, planes_only=True)
+                assert dp.half and dp.scale == S and torch.equal(dp.planes[0], ops.cast_to_f16(fused["dab"], S))
+                w2 = rnd((2 * inter, 384), 749).to(DEV)
+                assert torch.equal(ops.linear_dgrad(dp, w2), ops.linear_dgrad(fused["dab"], w2))
+                g0, g1 = torch.empty((2 * inter, 384), device=DEV), torch.empty((2 * inter, 384), device=DEV)
+                xx = rnd((rows, 384), 750).to(DEV)
+                ops.linear_wgrad(fused["dab"], xx, g0, False); ops.linear_wgrad(dp, xx, g1, False)
+                assert torch.equal(g0, g1)
+    assert im.produced >= 6
+    # outside the mode the same entry points write bf16 planes again (the kernels' image format is restored on exit)
+    with ops.f32_gemms_as_bf16x3(True, ops.X3Images()):
+        h = ops.glu_fwd(ab)
+        assert torch.equal(ops.split_planes(h), ops._split_planes_now(h))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upsample2x_matches_interpolate(dtype):
     """muse_upsample2x_nhwc == F.interpolate(scale_factor=2, mode="nearest") (taming Upsample without its convolution), bit for bit"""
