@@ -350,8 +350,8 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False, f16=False):
            "dtype": ("f16: f32 tensors; every weight GEMM (linears, dX, dW) as ONE v_mfma_f32_16x16x32_f16 product of IEEE-half operand images with f32 "
                      "accumulation - half's 10-bit mantissa is the TF32 operand format the yaml's enable_tf32 multiplies in (gfx950 has no xf32 MFMA); "
                      "TF32's exponent range is covered by power-of-two operand scales (gradient operands x 2^10 x tokens, undone in alpha; "
-                     "clamped / flushed elements counted: f16_operand_stats); the attention core as in the bf16x3 leg (three bf16 products, tighter "
-                     "than TF32); f32 softmax, norms, GLU, residual stream, loss, AdamW; mfma_frac against the 2500 TFLOP/s half / bf16 peak") if f16 else ("bf16x3: f32 tensors, every product (linears, dX, dW: muse_gemm_x3 on four operand planes; the attention core: "
+                     "overflowed / flushed elements counted: f16_operand_stats); the attention core (muse_attention_x3_*, block by block at 1024 tokens) "
+                     "with one half plane per operand and one half MFMA per K step; f32 softmax, norms, GLU, residual stream, loss, AdamW; mfma_frac against the 2500 TFLOP/s half / bf16 peak") if f16 else ("bf16x3: f32 tensors, every product (linears, dX, dW: muse_gemm_x3 on four operand planes; the attention core: "
                      + ("muse_attention_x3_*" if seq == 256 else "muse_attention_x3_* block by block - 256 query rows against 256-key blocks (or the 77 text states), "
                                                                "key blocks merged by their log-sum-exps in f32 (ops.attention_x3_blocked)")
                      + ") as three bf16 MFMA products of hi / lo operand planes with f32 accumulation (<= 2^-16 relative per "
@@ -362,7 +362,7 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False, f16=False):
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     if f16:
         sat, flushed = model.f16_stats()
-        out["f16_operand_stats"] = {"clamped": sat, "rounded_to_zero": flushed, "over": f"the {steps + 2} steps of this leg"}
+        out["f16_operand_stats"] = {"overflowed": sat, "rounded_to_zero": flushed, "over": f"the {steps + 2} steps of this leg"}
     del model, opt
     torch.cuda.empty_cache()
     return out
@@ -847,6 +847,12 @@ def main():
         # of a 1024-token sequence runs attention3.hip's one-tile kernels block by block (52.3 images/s with the materialised exact-f32 core it
         # replaced, 81.5 with the blocks: profiles/r06_c4_seq1024_x3*.txt)
         extra["config4_uvit_seq1024_bf16x3"] = uvit_leg_isolated(device, 32, 1024, 2, x3=True)
+        # ... and that precision class at its natural cost on this chip (round 6): IEEE half has TF32's 10-bit mantissa and its MFMA runs at the
+        # bf16 rate - every weight GEMM as ONE half product (muse_gemm dtype MUSE_F16), gradient operands through a power-of-two scale
+        # (the "f16" compute mode; equal to an emulated TF32 product to 1e-7: profiles/r06_f16_mode_parity.txt)
+        extra["config4_uvit_seq256_f16"] = uvit_leg_isolated(device, 64, 256, 2, f16=True)
+        extra["config4_uvit_seq256_f16_b128"] = uvit_leg_isolated(device, 128, 256, 2, f16=True)
+        extra["config4_uvit_seq1024_f16"] = uvit_leg_isolated(device, 32, 1024, 2, f16=True)
         # the reference's PUBLISHED metric (its only published numbers): text-to-image pipeline latency, 12 steps, 256 x 256
         extra["inference_latency"] = leg_isolated("latency", lambda: latency_leg(device))
 

@@ -300,7 +300,8 @@ int muse_cast_f32_to_f16(const float* in, void* out, int64_t n, float scale, int
  * muse_norm_adaln_fwd_x3 / _bwd_x3, muse_attention_x3_fwd / _bwd / _merge - write as that image.  half = 0 (default): the (hi, lo) bf16
  * planes of the "bf16x3" mode, as documented with each.  half = 1 ("f16" mode): ONE IEEE-half image [rows][cols] at the plane pointer =
  * half(result * s), the bits muse_cast_f32_to_f16 makes of the f32 result, with s = 1 for forward results and s = grad_scale (a power
- * of two) for the gradients the backward entry points produce; lo-plane distances are ignored; stats (device int32[2] or NULL): [0] is
+ * of two) for the gradients the backward entry points produce; lo-plane distances are ignored; muse_attention_x3_fwd / _bwd also COMPUTE in
+ * that format (one half plane per operand, one half MFMA per K step; dO and dS times grad_scale, results divided by it); stats (device int32[2] or NULL): [0] is
  * incremented per 4-element group that holds an inf / NaN half (muse_cast_f32_to_f16's overflow counter: a dynamic gradient scale backs
  * off on it).  Process state (host code sets it around a pass: muse/ops.py f32_gemms_as_f16), not thread safe. */
 int muse_operand_images(int32_t half, float grad_scale, int32_t* stats);

@@ -20,6 +20,10 @@
 //   * a block product is three MFMAs per K step (lo*hi, hi*lo, hi*hi: small terms first); P and dS are split in registers;
 //   * four planes of 256 rows are 147 KB: ONE 8-wave workgroup per CU and head, each wave owns one 32-query block (forward,
 //     backward phase 1) / one 32-key block (backward phase 2).
+// H16 (round 6, the "f16" compute mode: muse_operand_images(1, ..)): the same kernels with ONE IEEE-half plane per operand and one
+// v_mfma_f32_32x32x16_f16 per K step - half's 10-bit mantissa is the TF32 operand format, like the mode's GEMMs.  Two planes are 74 KB:
+// two workgroups share a CU and overlap each other's phases.  Gradient operands (dO, dS) are converted times the pass's power-of-two
+// gradient scale S and the results handed back divided by it: dO S, -dsum S -> S (dP - dsum) -> S dS -> S dQ, S dK; P^T (dO S) = S dV.
 #include "attention_blocks.h"
 #include "../../include/muse_hip.h"
 
@@ -48,7 +52,20 @@ struct Params {
   long lo_out, lo_dq, lo_dk, lo_dv;
   float img_scale;
   int* img_stats;
+  float gscale;        // H16 backward: the power of two gradient operands are scaled by before their conversion to half (else 1)
 };
+
+typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+// eight f32 values (times s) as one half fragment
+__device__ __forceinline__ bf16x8 half8(const f32x4& a, const f32x4& b, float s) {
+  const f16x8_ h = {(_Float16)(a[0] * s), (_Float16)(a[1] * s), (_Float16)(a[2] * s), (_Float16)(a[3] * s),
+                    (_Float16)(b[0] * s), (_Float16)(b[1] * s), (_Float16)(b[2] * s), (_Float16)(b[3] * s)};
+  return __builtin_bit_cast(bf16x8, h);
+}
+template <bool H16> __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (H16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_, a), __builtin_bit_cast(f16x8_, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 struct FragB3 { bf16x8 h[C::KS], l[C::KS]; };     // B operand of a head-dim contraction, both planes
 
@@ -76,18 +93,23 @@ __device__ __forceinline__ Raw load_raw(const float* rowp, bool valid, int h) {
   }
   return r;
 }
-__device__ __forceinline__ FragB3 split_raw(const Raw& r) {
+template <bool H16 = false>
+__device__ __forceinline__ FragB3 split_raw(const Raw& r, float s = 1.f) {
   FragB3 f;
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) split8(r.a[ks], r.b[ks], f.h[ks], f.l[ks]);
+  for (int ks = 0; ks < C::KS; ++ks) {
+    if constexpr (H16) f.h[ks] = half8(r.a[ks], r.b[ks], s);
+    else split8(r.a[ks], r.b[ks], f.h[ks], f.l[ks]);
+  }
   return f;
 }
 
 // rows 0 .. nrows-1 of two [.][64] f32 slices -> their (hi, lo) image planes; rows at or past `valid` are zeros.  Every load of both
 // slices is in flight before the first conversion.  nrows * 8 sixteen-byte slots per plane, NT threads: slot s = row * 8 + chunk.
-template <int NROWS>
+// (H16: one half plane each, the lo pointers are not touched; sb scales the second slice - dO times the gradient scale)
+template <int NROWS, bool H16 = false>
 __device__ __forceinline__ void fill_two(unsigned char* ah, unsigned char* al, const float* a, long lda, unsigned char* bh, unsigned char* bl,
-                                         const float* b, long ldb, int valid) {
+                                         const float* b, long ldb, int valid, float sb = 1.f) {
   constexpr int PER = (NROWS * 8 + NT - 1) / NT;
   f32x4 va[PER][2], vb[PER][2];
 #pragma unroll
@@ -106,25 +128,36 @@ __device__ __forceinline__ void fill_two(unsigned char* ah, unsigned char* al, c
   for (int i = 0; i < PER; ++i) {
     const int s = (int)threadIdx.x + i * NT, row = s >> 3, c = s & 7;
     if (s < NROWS * 8) {
-      bf16x8 hi, lo;
-      split8(va[i][0], va[i][1], hi, lo);
-      *(bf16x8*)(ah + row * C::STR + c * 16) = hi;
-      *(bf16x8*)(al + row * C::STR + c * 16) = lo;
-      split8(vb[i][0], vb[i][1], hi, lo);
-      *(bf16x8*)(bh + row * C::STR + c * 16) = hi;
-      *(bf16x8*)(bl + row * C::STR + c * 16) = lo;
+      if constexpr (H16) {
+        *(bf16x8*)(ah + row * C::STR + c * 16) = half8(va[i][0], va[i][1], 1.f);
+        *(bf16x8*)(bh + row * C::STR + c * 16) = half8(vb[i][0], vb[i][1], sb);
+      } else {
+        bf16x8 hi, lo;
+        split8(va[i][0], va[i][1], hi, lo);
+        *(bf16x8*)(ah + row * C::STR + c * 16) = hi;
+        *(bf16x8*)(al + row * C::STR + c * 16) = lo;
+        split8(vb[i][0], vb[i][1], hi, lo);
+        *(bf16x8*)(bh + row * C::STR + c * 16) = hi;
+        *(bf16x8*)(bl + row * C::STR + c * 16) = lo;
+      }
     }
   }
 }
 
 // acc += rows(blk) of the image x fragment, three products per K step
+template <bool H16 = false>
 __device__ __forceinline__ f32x16 mma_rows3(const unsigned char* ih, const unsigned char* il, const LaneGeom& g, int blk, const FragB3& b, f32x16 acc) {
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) {
-    const bf16x8 ah = frag_rows<HD>(ih, g, blk, ks), al = frag_rows<HD>(il, g, blk, ks);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.h[ks], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.l[ks], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.h[ks], acc, 0, 0, 0);
+    const bf16x8 ah = frag_rows<HD>(ih, g, blk, ks);
+    if constexpr (H16) {
+      acc = mfma32<true>(ah, b.h[ks], acc);
+    } else {
+      const bf16x8 al = frag_rows<HD>(il, g, blk, ks);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.h[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.l[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.h[ks], acc, 0, 0, 0);
+    }
   }
   return acc;
 }
@@ -141,18 +174,28 @@ __device__ __forceinline__ void pack8x3(const f32x16& x, int t, bf16x8& hi, bf16
   hi = uh.b; lo = ul.b;
 }
 // acc[db] += img^T[:, rows of blk] * x[rows, :]   (sequence contraction, transposed image reads)
+template <bool H16 = false>
 __device__ __forceinline__ void mma_seq3(const unsigned char* ih, const unsigned char* il, const LaneGeom& g, int blk, const f32x16& x,
                                          f32x16 (&acc)[C::NDB]) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     bf16x8 xh, xl;
-    pack8x3(x, t, xh, xl);
+    if constexpr (H16) {
+      xh = half8(f32x4{x[8 * t], x[8 * t + 1], x[8 * t + 2], x[8 * t + 3]}, f32x4{x[8 * t + 4], x[8 * t + 5], x[8 * t + 6], x[8 * t + 7]}, 1.f);
+    } else {
+      pack8x3(x, t, xh, xl);
+    }
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) {
-      const bf16x8 ah = frag_tr<HD>(ih, g, blk, t, db), al = frag_tr<HD>(il, g, blk, t, db);
-      acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[db], 0, 0, 0);
-      acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[db], 0, 0, 0);
-      acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[db], 0, 0, 0);
+      const bf16x8 ah = frag_tr<HD>(ih, g, blk, t, db);
+      if constexpr (H16) {
+        acc[db] = mfma32<true>(ah, xh, acc[db]);
+      } else {
+        const bf16x8 al = frag_tr<HD>(il, g, blk, t, db);
+        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[db], 0, 0, 0);
+        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[db], 0, 0, 0);
+        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[db], 0, 0, 0);
+      }
     }
   }
 }
@@ -173,11 +216,11 @@ __device__ __forceinline__ void store_rows3(float* rowp, const f32x16 (&acc)[C::
 // =================================================================================================================
 // forward: wave w owns queries 32 w .. 32 w + 31
 // =================================================================================================================
-template <int NKB>
+template <int NKB, bool H16 = false>
 __global__ __launch_bounds__(NT, 2) void fwd_kernel(const Params P) {
   constexpr int PL = NKB * 32 * C::STR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *Kh = smem, *Kl = smem + PL, *Vh = smem + 2 * PL, *Vl = smem + 3 * PL;
+  unsigned char *Kh = smem, *Kl = smem + PL, *Vh = smem + (H16 ? 1 : 2) * PL, *Vl = smem + 3 * PL;   // (H16: two planes, the lo pointers unused)
   const LaneGeom g = make_geom<HD>();
   const int head = xcd_remap();
   const int b = head / P.nh, hh = head - b * P.nh;
@@ -186,13 +229,13 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const Params P) {
   const int q = g.wave * 32 + g.n;
 
   const Raw qr = load_raw(P.q + b * P.bq + (long)q * P.ldq + hh * HD, true, g.h);
-  fill_two<NKB * 32>(Kh, Kl, P.k + b * P.bk + hh * HD, P.ldk, Vh, Vl, P.v + b * P.bv + hh * HD, P.ldv, P.skv);
-  const FragB3 qf = split_raw(qr);
+  fill_two<NKB * 32, H16>(Kh, Kl, P.k + b * P.bk + hh * HD, P.ldk, Vh, Vl, P.v + b * P.bv + hh * HD, P.ldv, P.skv);
+  const FragB3 qf = split_raw<H16>(qr);
   lds_barrier();
 
   f32x16 s[NKB];
 #pragma unroll
-  for (int kb = 0; kb < NKB; ++kb) s[kb] = mma_rows3(Kh, Kl, g, kb, qf, kb == NKB - 1 ? mask16(last_valid, g.h) : zero16());
+  for (int kb = 0; kb < NKB; ++kb) s[kb] = mma_rows3<H16>(Kh, Kl, g, kb, qf, kb == NKB - 1 ? mask16(last_valid, g.h) : zero16());
   float m = NEG_BIG;
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb)
@@ -208,7 +251,7 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const Params P) {
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc)); l += s[kb][r]; }
-    mma_seq3(Vh, Vl, g, kb, s[kb], o);
+    mma_seq3<H16>(Vh, Vl, g, kb, s[kb], o);
   }
   l += xhalf(l);
   const long oo = b * P.bo + (long)q * P.ldo + hh * HD;
@@ -229,11 +272,12 @@ __device__ __forceinline__ void p_and_ds(f32x16& s, f32x16& dp, float c, const f
   }
 }
 
-template <int NKB>
+template <int NKB, bool H16 = false>
 __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *Ah = smem, *Al = smem + PLANE, *Bh = smem + 2 * PLANE, *Bl = smem + 3 * PLANE;   // phase 1: K, V   phase 2: Q, dO
-  float* L2 = (float*)(smem + 4 * PLANE);      // lse * log2(e) per query in MFMA-row order: position 32 blk + i <-> query 32 blk + perm32(i)
+  unsigned char *Ah = smem, *Al = smem + PLANE, *Bh = smem + (H16 ? 1 : 2) * PLANE, *Bl = smem + 3 * PLANE;   // phase 1: K, V   phase 2: Q, dO
+  float* L2 = (float*)(smem + (H16 ? 2 : 4) * PLANE);      // lse * log2(e) per query in MFMA-row order: position 32 blk + i <-> query 32 blk + perm32(i)
+  const float S = H16 ? P.gscale : 1.f;        // gradient operands are converted times S (see the header)
   float* DS = L2 + SQ;                         // -dsum, same order
   const LaneGeom g = make_geom<HD>();
   const int head = xcd_remap();
@@ -252,16 +296,17 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
     const Raw dor = load_raw(doh + (long)q * P.lddo, true, g.h);
     const Raw orr = load_raw(P.o + b * P.bo + (long)q * P.ldo + hh * HD, true, g.h);
     const float lse = P.lse[(long)head * SQ + q];
-    fill_two<NKB * 32>(Ah, Al, kh, P.ldk, Bh, Bl, vh, P.ldv, P.skv);
+    fill_two<NKB * 32, H16>(Ah, Al, kh, P.ldk, Bh, Bl, vh, P.ldv, P.skv);
     float d = 0.f;
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { d = fmaf(dor.a[ks][e], orr.a[ks][e], d); d = fmaf(dor.b[ks][e], orr.b[ks][e], d); }
     d += xhalf(d);
+    d *= S;
     const float l2 = lse * LOG2E;
     if (g.h == 0) { L2[g.wave * 32 + perm32_inv(g.n)] = l2; DS[g.wave * 32 + perm32_inv(g.n)] = -d; }
-    const FragB3 qf = split_raw(qr), dof = split_raw(dor);
+    const FragB3 qf = split_raw<H16>(qr), dof = split_raw<H16>(dor, S);
     f32x16 l2v, dsv;
     l2v[0] = l2;
 #pragma unroll
@@ -272,13 +317,13 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
     for (int db = 0; db < C::NDB; ++db) dq[db] = zero16();
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      f32x16 s = mma_rows3(Ah, Al, g, kb, qf, kb == NKB - 1 ? mask16(last_valid, g.h) : zero16());
-      f32x16 dp = mma_rows3(Bh, Bl, g, kb, dof, dsv);
+      f32x16 s = mma_rows3<H16>(Ah, Al, g, kb, qf, kb == NKB - 1 ? mask16(last_valid, g.h) : zero16());
+      f32x16 dp = mma_rows3<H16>(Bh, Bl, g, kb, dof, dsv);
       p_and_ds<false>(s, dp, c, l2v);
-      mma_seq3(Ah, Al, g, kb, dp, dq);
+      mma_seq3<H16>(Ah, Al, g, kb, dp, dq);
     }
     const long oq = b * P.bdq + (long)q * P.lddq + hh * HD;
-    store_rows3(P.dq ? P.dq + oq : nullptr, dq, P.alpha, g.h, P.dqp ? P.dqp + oq : nullptr, P.lo_dq, P.img_scale, P.img_stats);
+    store_rows3(P.dq ? P.dq + oq : nullptr, dq, P.alpha / S, g.h, P.dqp ? P.dqp + oq : nullptr, P.lo_dq, P.img_scale, P.img_stats);
   }
   lds_barrier();       // everybody is done with the K, V planes; L2 / DS are written
   // ---------------- phase 2 ----------------
@@ -288,8 +333,8 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
     const bool valid = own && key < P.skv;
     const Raw kr = load_raw(kh + (long)key * P.ldk, valid, g.h);
     const Raw vr = load_raw(vh + (long)key * P.ldv, valid, g.h);
-    fill_two<SQ>(Ah, Al, qh, P.ldq, Bh, Bl, doh, P.lddo, SQ);
-    const FragB3 kf = split_raw(kr), vf = split_raw(vr);
+    fill_two<SQ, H16>(Ah, Al, qh, P.ldq, Bh, Bl, doh, P.lddo, SQ, S);
+    const FragB3 kf = split_raw<H16>(kr), vf = split_raw<H16>(vr);
     lds_barrier();
     if (own) {
       f32x16 dk[C::NDB], dv[C::NDB];
@@ -305,16 +350,16 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { l2v[4 * T + j] = a[j]; dsv[4 * T + j] = dd[j]; }
         }
-        f32x16 s = mma_rows3(Ah, Al, g, qb, kf, zero16());
-        f32x16 dp = mma_rows3(Bh, Bl, g, qb, vf, dsv);
+        f32x16 s = mma_rows3<H16>(Ah, Al, g, qb, kf, zero16());
+        f32x16 dp = mma_rows3<H16>(Bh, Bl, g, qb, vf, dsv);
         p_and_ds<true>(s, dp, c, l2v);
-        mma_seq3(Bh, Bl, g, qb, s, dv);
-        mma_seq3(Ah, Al, g, qb, dp, dk);
+        mma_seq3<H16>(Bh, Bl, g, qb, s, dv);
+        mma_seq3<H16>(Ah, Al, g, qb, dp, dk);
       }
       if (valid) {
         const long ok = b * P.bdk + (long)key * P.lddk + hh * HD, ov = b * P.bdv + (long)key * P.lddv + hh * HD;
-        store_rows3(P.dk ? P.dk + ok : nullptr, dk, P.alpha, g.h, P.dkp ? P.dkp + ok : nullptr, P.lo_dk, P.img_scale, P.img_stats);
-        store_rows3(P.dv ? P.dv + ov : nullptr, dv, 1.0f, g.h, P.dvp ? P.dvp + ov : nullptr, P.lo_dv, P.img_scale, P.img_stats);
+        store_rows3(P.dk ? P.dk + ok : nullptr, dk, P.alpha / S, g.h, P.dkp ? P.dkp + ok : nullptr, P.lo_dk, P.img_scale, P.img_stats);
+        store_rows3(P.dv ? P.dv + ov : nullptr, dv, 1.0f / S, g.h, P.dvp ? P.dvp + ov : nullptr, P.lo_dv, P.img_scale, P.img_stats);
       }
     }
   }
@@ -361,6 +406,11 @@ extern "C" int muse_attention_x3_fwd(const muse_attn_desc* d, float* lse, void* 
   const ImgFormat f = img_format(false);
   P.outp = (bf16_t*)o_planes; P.lo_out = f.lo_sign < 0 ? -1 : o_lo; P.img_scale = f.scale; P.img_stats = f.stats;
   const int nkb = nkb_of(d->seq_kv);
+  if (f.lo_sign < 0) {      // the "f16" compute mode is on: the core's products are single half products like the mode's GEMMs
+    const size_t lds = 2 * (size_t)nkb * 32 * C::STR;
+    return nkb == 8 ? launch(fwd_kernel<8, true>, P, d->batch * d->heads, lds, (hipStream_t)stream)
+                    : launch(fwd_kernel<3, true>, P, d->batch * d->heads, lds, (hipStream_t)stream);
+  }
   const size_t lds = 4 * (size_t)nkb * 32 * C::STR;
   return nkb == 8 ? launch(fwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
                   : launch(fwd_kernel<3>, P, d->batch * d->heads, lds, (hipStream_t)stream);
@@ -387,6 +437,12 @@ extern "C" int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, i
   const ImgFormat f = img_format(true);
   P.dqp = (bf16_t*)dq_planes; P.dkp = (bf16_t*)dk_planes; P.dvp = (bf16_t*)dv_planes; P.img_scale = f.scale; P.img_stats = f.stats;
   P.lo_dq = f.lo_sign < 0 ? -1 : dq_lo; P.lo_dk = f.lo_sign < 0 ? -1 : dk_lo; P.lo_dv = f.lo_sign < 0 ? -1 : dv_lo;
+  P.gscale = f.lo_sign < 0 ? f.scale : 1.f;
+  if (f.lo_sign < 0) {
+    const size_t lds = 2 * (size_t)PLANE + 2 * SQ * sizeof(float);
+    return nkb_of(d->seq_kv) == 8 ? launch(bwd_kernel<8, true>, P, d->batch * d->heads, lds, (hipStream_t)stream)
+                                  : launch(bwd_kernel<3, true>, P, d->batch * d->heads, lds, (hipStream_t)stream);
+  }
   const size_t lds = 4 * (size_t)PLANE + 2 * SQ * sizeof(float);
   return nkb_of(d->seq_kv) == 8 ? launch(bwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
                                 : launch(bwd_kernel<3>, P, d->batch * d->heads, lds, (hipStream_t)stream);

@@ -199,10 +199,11 @@ class F16Images:
     """The half operand images of ONE training step (the role X3Images plays for the bf16x3 mode): a tensor is converted once per step,
     whichever products read it - keyed by (storage, shape, strides, version, scale); images made during the backward live in a short LRU.
     `backward`: the pass running is a backward pass - the A operand of its products and the dy of its weight gradients are gradients and
-    take `grad_scale`."""
+    take `grad_scale`.  `keep` (forward passes): images stay until clear() because the backward pass reads them again; a forward that
+    records no tape (inference) sets it False and its images share the short LRU, so no activation outlives its consumers."""
 
     def __init__(self, grad_scale=1.0, recent=12):
-        self.persist, self.lru, self.recent, self.backward = {}, {}, int(recent), False
+        self.persist, self.lru, self.recent, self.backward, self.keep = {}, {}, int(recent), False, True
         self.grad_scale = float(grad_scale)
         self.hits = self.misses = 0
         self._stats = None
@@ -249,7 +250,7 @@ class F16Images:
             return hit[1]
         self.misses += 1
         out = cast_to_f16(t, scale, self._ensure_stats(t.device))
-        if self.backward:
+        if self.backward or not self.keep:
             self.lru[key] = (t, out)
             while len(self.lru) > self.recent:
                 self.lru.pop(next(iter(self.lru)))
@@ -266,7 +267,7 @@ class F16Images:
         img._muse_scale = scale
         key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, float(scale))
         self.produced = getattr(self, "produced", 0) + 1
-        if self.backward:
+        if self.backward or not self.keep:
             self.lru[key] = (t, img)
             while len(self.lru) > self.recent:
                 self.lru.pop(next(iter(self.lru)))

@@ -97,6 +97,7 @@ class TapeOps:
             if images is None:
                 images = self.__dict__["_f16_images"] = ops.F16Images()
             images.backward = bool(backward)
+            images.keep = bool(backward or self.__dict__.get("_act_cache_on", False))
             if backward:
                 images.set_grad_scale(self.f16_grad_scale_for(self.__dict__.get("_loss_rows", 1)))
             return ops.f32_gemms_as_f16(True, images)

@@ -70,7 +70,7 @@ def part_a():
             c, st = run(mode, la, lb)
             e_exact = float(((c.double() - exact).abs() / mag).max())
             e_emu = float(((c.double() - emu).abs() / mag).max())
-            row.append(f"{mode}: vs float64 {e_exact:.2e}" + (f", vs emulated TF32 {e_emu:.2e}, clamped / flushed {st}" if mode == "f16" else ""))
+            row.append(f"{mode}: vs float64 {e_exact:.2e}" + (f", vs emulated TF32 {e_emu:.2e}, overflowed / flushed {st}" if mode == "f16" else ""))
         e_tf = float(((emu - exact).abs() / mag).max())
         print(f"  la{la} lb{lb}  " + " | ".join(row) + f" | emulated TF32 vs float64 {e_tf:.2e}")
     # gradient-scale path: A is a "gradient" of magnitude 1e-7 (far below half's normal range)
@@ -82,7 +82,7 @@ def part_a():
         a = a_small
         c, st = run("f16", 0, 0, scale)
         a = a_keep
-        print(f"  A x 1e-7, gradient scale {scale}: vs float64 {float(((c.double() - exact_s).abs() / mag_s).max()):.2e}, clamped / flushed {st}")
+        print(f"  A x 1e-7, gradient scale {scale}: vs float64 {float(((c.double() - exact_s).abs() / mag_s).max()):.2e}, overflowed / flushed {st}")
     # half subnormals through the MFMA: operands exactly representable as half subnormals
     sub = (torch.randint(-512, 512, (M, K), device=DEV).float() * 2.0 ** -24)
     bb = torch.randint(-8, 8, (N, K), device=DEV).float()
@@ -123,7 +123,7 @@ def part_b():
         errs = {k: float(np.abs(W.subsample(params[k].grad.detach().float()).cpu().numpy() - g["grad." + k]).max()) / float(g["absmax." + k]) for k in keys}
         nerrs = {k: abs(float(params[k].grad.double().norm()) - float(g["norm." + k])) / float(g["norm." + k]) for k in keys}
         print(f"  {cd}: logits {el:.2e}  loss {lrel:.1e}  worst grad {max(errs.values()):.1e}  worst grad norm {max(nerrs.values()):.1e}"
-              + (f"  clamped / flushed {model.f16_stats()}  grad scale {model.f16_grad_scale_for(model.__dict__['_loss_rows'])}" if cd == "f16" else ""))
+              + (f"  overflowed / flushed {model.f16_stats()}  grad scale {model.f16_grad_scale_for(model.__dict__['_loss_rows'])}" if cd == "f16" else ""))
 
 
 def part_c():

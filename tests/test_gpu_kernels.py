@@ -1645,11 +1645,62 @@ def test_f16_mode_weight_gradient_with_k_split():
     assert torch.equal(dw, again)
 
 
+@pytest.mark.parametrize("B,Sq,Skv,nh,packed", [(3, 256, 256, 4, True), (2, 256, 77, 3, False), (2, 256, 240, 2, False), (1, 512, 512, 2, True), (1, 512, 77, 2, False)])
+def test_fused_attention_f16_mode(B, Sq, Skv, nh, packed):
+    """attention3.hip H16: inside an f16 step (muse_operand_images) the fused attention core runs every product as ONE half MFMA
+    product - q, k, v, P rounded to half's 10-bit mantissa (the TF32 operand format), dO and dS times the pass's power-of-two gradient
+    scale before their conversion, results handed back divided by it.  Against float64: forward and gradients to TF32-class error
+    (2e-3 of their scale; the bf16x3 kernels: 2e-5 / 5e-5, a bf16 core: 1.5e-2 / 3e-2); a gradient-sized dO (1e-6) needs the scale
+    (without it dS falls below half's range) and with it matches the same bound; the result does not depend on the scale beyond rounding;
+    one-tile shapes and the block-by-block form of longer sequences."""
+    ops = _ops()
+    hd = 64
+    H = nh * hd
+    alpha = 0.125
+    if packed:
+        qkv = rnd((B * Sq, 3 * H), 760, 1.0).to(DEV)
+        qd, kd, vd = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    else:
+        qd, kv = rnd((B * Sq, H), 761, 1.0).to(DEV), rnd((B * Skv, 2 * H), 762, 1.0).to(DEV)
+        kd, vd = kv[:, :H], kv[:, H:]
+    dctx = rnd((B * Sq, H), 763).to(DEV) * 1e-6
+    q = qd.double().reshape(B, Sq, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    k = kd.double().reshape(B, Skv, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    v = vd.double().reshape(B, Skv, nh, hd).transpose(1, 2).detach().requires_grad_(True)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * alpha, dim=-1) @ v).transpose(1, 2).reshape(B * Sq, H)
+    ref.backward(dctx.double())
+    gq, gk, gv = (t.grad.transpose(1, 2).reshape(-1, H) for t in (q, k, v))
+    outs = {}
+    for S in (1.0, 2.0 ** 20, 2.0 ** 22):
+        im = ops.F16Images()
+        with ops.f32_gemms_as_f16(True, im):
+            ctx, lse = ops.attention_x3_fwd(qd, kd, vd, B, Sq, Skv, nh, hd, alpha)
+        im.backward = True
+        im.set_grad_scale(S)
+        with ops.f32_gemms_as_f16(True, im):
+            dq, dk, dv = ops.attention_x3_bwd(qd, kd, vd, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha)
+        outs[S] = (ctx, dq, dk, dv)
+        ef = rel_err(ctx, ref.detach())
+        eg = [rel_err(a, b) for a, b in ((dq, gq), (dk, gk), (dv, gv))]
+        print(f"f16-mode attention {Sq} x {Skv}, gradient scale {S:g}: ctx {ef:.1e}, dq / dk / dv {eg[0]:.1e} / {eg[1]:.1e} / {eg[2]:.1e} of float64; overflowed {im.stats()[0]}")
+        assert ef < 2e-3
+        if S == 1.0:
+            assert max(eg) > 1e-2          # dO ~ 1e-6 unscaled: dS is far below half's normal range
+        else:
+            assert max(eg) < 2e-3 and im.stats()[0] == 0
+    for a, b in zip(outs[2.0 ** 20][1:], outs[2.0 ** 22][1:]):
+        assert rel_err(a, b.double()) < 2e-3
+    # outside the mode the same entry points are the bf16x3 kernels again
+    ctx3, _ = ops.attention_x3_fwd(qd, kd, vd, B, Sq, Skv, nh, hd, alpha)
+    assert rel_err(ctx3, ref.detach()) < 2e-5
+
+
 def test_f16_mode_producers_write_half_images():
     """Inside an f16 step the producer kernels (GLU forward / backward, AdaLN-norm forward / backward, the fused attention's context and
     gradients) write their result's IEEE-half operand image next to the f32 result (muse_operand_images): bit for bit what
     muse_cast_f32_to_f16 makes of that result - unscaled in a forward pass, times the pass's gradient scale in a backward pass -
-    registered under the result tensor so the product that reads it launches no cast; the f32 results are the plain kernels' bits.
+    registered under the result tensor so the product that reads it launches no cast; the f32 results are the plain kernels' bits
+    (the attention core's, which computes in half itself inside the mode, to that precision).
     A result only weight GEMMs read exists as its image alone (ops.Planes) and gives the same products."""
     ops = _ops()
     rows, inter, C_, B = 512, 256, 512, 2
@@ -1687,7 +1738,10 @@ def test_f16_mode_producers_write_half_images():
         with ops.f32_gemms_as_f16(True, im):
             fused = backward(pf["m"], pre, pf["ctx"], lse) if bwd else forward()[0]
             for name, t in fused.items():
-                assert torch.equal(t, plain[name]), name                   # the f32 results do not change
+                if name in ("ctx", "dqkv"):                                # the attention core itself computes in half inside the mode
+                    assert rel_err(t, plain[name].double()) < 2e-3, name
+                else:
+                    assert torch.equal(t, plain[name]), name               # the f32 results do not change
                 misses = im.misses
                 img = im.image(t, S if bwd else 1.0)                       # what a product reading t gets: the producer's image
                 assert im.misses == misses, name

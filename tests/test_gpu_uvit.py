@@ -702,7 +702,7 @@ def test_uvit_config4_vs_reference_golden(golden_dir):
             assert counts["attn"] >= 2 * 22 and counts["gemm_x3"] >= 3 * 6 * 22
         elif cd == "f16":
             clamped, flushed = model.f16_stats()
-            print("f16 step:", counts["attn"], "fused attention forwards,", counts["gemm_f16"], "half products; operand elements clamped / rounded to zero:",
+            print("f16 step:", counts["attn"], "fused attention forwards,", counts["gemm_f16"], "half products; operand elements overflowed / rounded to zero:",
                   clamped, "/", flushed)
             assert counts["attn"] >= 2 * 22 and counts["gemm_f16"] >= 3 * 6 * 22 and counts["gemm_x3"] == 0 and clamped == 0
         else:

@@ -3,6 +3,8 @@ import importlib.util
 import io
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -100,6 +102,79 @@ def test_bf16x3_operand_image_cache_host_logic(monkeypatch):
     pl = ops.Planes(torch.zeros((2, 256, 128), dtype=torch.bfloat16))
     assert tuple(pl.shape) == (256, 128) and pl.dtype == torch.float32 and pl.stride() == (128, 1) and pl.stride(0) == 128
     assert pl.dim() == 2 and pl.numel() == 256 * 128 and pl.is_contiguous() and ops.split_planes(pl) is pl.planes and len(calls) == 9
+
+
+def test_f16_mode_host_logic(monkeypatch):
+    """CPU: the host side of the "f16" compute mode without a GPU - the cast is a counting stand-in.  One half image per tensor, scale and
+    step; a gradient scale must be a power of two (it is undone exactly in alpha); backward images live in a short LRU, and so do a
+    tape-less forward's (keep = False: no activation outlives its consumers); a producer's image is found without a cast and carries
+    the pass's scale; the default gradient scale is 2^10 x the loss's token rows rounded up to a power of two; the dynamic policy halves
+    on overflow (skip the step) and doubles after `growth_interval` good steps."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    from muse import ops, tape_ops
+    from muse._hip import MuseHipError
+    casts = []
+
+    def fake_cast(t, scale=1.0, stats=None):
+        casts.append((t, scale))
+        out = torch.zeros(t.shape, dtype=torch.float16)
+        out._muse_scale = float(scale)
+        return out
+    monkeypatch.setattr(ops, "cast_to_f16", fake_cast)
+    monkeypatch.setattr(ops.F16Images, "_ensure_stats", lambda self, device=None: None)
+    im = ops.F16Images(recent=2)
+    with pytest.raises(MuseHipError):
+        im.set_grad_scale(3.0)
+    with pytest.raises(MuseHipError):
+        im.set_grad_scale(0.0)
+    im.set_grad_scale(2.0 ** 19)
+    a, b = torch.zeros(8, 16), torch.zeros(8, 16)
+    i1 = im.image(a, 1.0)
+    assert im.image(a, 1.0) is i1 and len(casts) == 1 and (im.hits, im.misses) == (1, 1)
+    assert im.image(a, 2.0 ** 19) is not i1 and len(casts) == 2          # the same tensor as a gradient operand: another image
+    assert im.image(b, 1.0) is not i1 and len(casts) == 3
+    ops._touched(a)
+    assert im.image(a, 1.0) is not i1 and len(casts) == 4                 # rewritten in place: converted again
+    w16 = torch.zeros(8, 16, dtype=torch.float16)
+    assert im.image(w16, 1.0) is w16 and len(casts) == 4                  # a weight's cached half copy is its own image
+    im.backward = True
+    made = torch.zeros((1, 8, 16), dtype=torch.float16)
+    c = torch.zeros(8, 16)
+    im.put_planes(c, made)                                                # a backward producer wrote c's image with the pass's scale
+    got = im.image(c, im.grad_scale)
+    assert got._muse_scale == 2.0 ** 19 and got.data_ptr() == made.data_ptr() and len(casts) == 4
+    for t in [torch.zeros(8, 16) for _ in range(3)]:
+        im.image(t, im.grad_scale)
+    assert len(im.lru) == 2 and len(im.persist) == 4
+    im.clear()
+    im.backward, im.keep = False, False                                   # inference forward: nothing persists
+    im.image(a, 1.0)
+    assert not im.persist and len(im.lru) == 1
+    # a planes-only half operand knows its scale
+    ops._F16_IMAGES[0] = im
+    try:
+        im.backward = True
+        pl = ops.Planes(torch.zeros((1, 256, 128), dtype=torch.float16))
+        assert pl.half and pl.scale == 2.0 ** 19 and tuple(pl.shape) == (256, 128) and pl.half_image()._muse_scale == 2.0 ** 19
+        assert im.image(pl, 1.0).data_ptr() == pl.planes.data_ptr()
+        with pytest.raises(MuseHipError):
+            im.image(ops.Planes(torch.zeros((2, 256, 128), dtype=torch.bfloat16)), 1.0)
+    finally:
+        ops._F16_IMAGES[0] = None
+
+    class Host(tape_ops.TapeOps):
+        pass
+    h = Host()
+    assert h.f16_grad_scale_for(16384) == 2.0 ** 24 and h.f16_grad_scale_for(16385) == 2.0 ** 25 and h.f16_grad_scale_for(1) == 1024.0
+    h.__dict__["_loss_rows"] = 512
+    stats = [(3, 0), (0, 7), (0, 0), (0, 0)]
+    monkeypatch.setattr(Host, "f16_stats", lambda self, reset=True: stats.pop(0))
+    assert h.f16_update_grad_scale(growth_interval=2) is False and h.f16_grad_scale == 2.0 ** 18      # overflow: halve, skip the step
+    assert h.f16_update_grad_scale(growth_interval=2) is True and h.f16_grad_scale == 2.0 ** 18
+    assert h.f16_update_grad_scale(growth_interval=2) is True and h.f16_grad_scale == 2.0 ** 19       # two good steps: double
+    assert h.f16_update_grad_scale(growth_interval=2) is True and h.f16_grad_scale == 2.0 ** 19
 
 
 def test_bf16x3_attention_shape_logic_and_step_timeline_on_cpu(tmp_path):
