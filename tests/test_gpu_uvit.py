@@ -405,6 +405,15 @@ def test_f16_mode_training_steps(golden_dir):
         finally:
             tape_ops.F16_WEIGHT_IMAGES, ops.F16_PRODUCERS = old
         results.append(([p.detach().clone() for p in model.parameters()], losses))
+    # a forward without a tape (inference): the mode's images do not outlive their consumers, logits to TF32-class error of the f32 mode's
+    with torch.no_grad():
+        model.set_compute_dtype("f16")
+        lf = model(ids, enc, cond, micro)
+        images = model.__dict__["_f16_images"]
+        assert not images.persist and len(images.lru) <= images.recent
+        model.set_compute_dtype(torch.float32)
+        l32 = model(ids, enc, cond, micro)
+    assert rel_err(lf, l32) < 5e-3
     assert results_skipped[0] == results_skipped[1]            # (an overflow is a property of the values, not of who wrote the image)
     for a, b in zip(results[0][0], results[1][0]):
         assert torch.equal(a, b)
