@@ -706,7 +706,7 @@ def main():
 
     def run_leg(cfgn, vqd, mode, n, batch):
         e2, _, _, _ = run(cfgn, vqd, n, 2, tokens_given=(mode == "tokens"), inline_tokenizer=(mode == "inline"),
-                          transformer_dtype=torch.float32 if mode == "transformer_f32" else torch.bfloat16)
+                          transformer_dtype=torch.float32 if mode == "transformer_f32" else ("f16" if mode == "transformer_f16" else torch.bfloat16))
         return {"images_per_s": round(batch * n / e2, 1)}
 
     if args.leg:

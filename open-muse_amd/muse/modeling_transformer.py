@@ -16,6 +16,7 @@ There is no CPU path: calling forward with CPU tensors raises.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import weakref
 from typing import Callable, List, Optional
@@ -87,7 +88,8 @@ class _MaskGitFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, input_ids, labels, label_smoothing, need_grad, *params):
-        logits, loss, saved = model._run_forward(input_ids, labels, label_smoothing, need_grad)
+        with model._flat_gemm_mode(False):
+            logits, loss, saved = model._run_forward(input_ids, labels, label_smoothing, need_grad)
         ctx.model, ctx.saved = model, saved
         ctx.set_materialize_grads(False)
         if loss is None:
@@ -99,7 +101,8 @@ class _MaskGitFn(torch.autograd.Function):
         model = ctx.model
         if ctx.saved is None:
             raise MuseHipError("backward called on a forward that ran without grad")
-        grads = model._run_backward(ctx.saved, g_logits, g_loss)
+        with model._flat_gemm_mode(True):
+            grads = model._run_backward(ctx.saved, g_logits, g_loss)
         ctx.saved = None
         return (None, None, None, None, None) + tuple(grads)
 
@@ -285,16 +288,40 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
             self.__dict__["_f32_split3"] = dtype == "bf16x3"
             self.__dict__["_f32_f16"] = dtype == "f16"
             return self
+        if dtype == "f16":      # the flat engine's f32 mode with every weight GEMM as one IEEE-half product (_flat_gemm_mode)
+            self.compute_dtype = torch.float32
+            self.__dict__["_f32_f16"] = True
+            self._shadow_fresh = False
+            return self
         if dtype not in ("auto", torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be 'auto', torch.float32 or torch.bfloat16")
+            raise ValueError("compute dtype must be 'auto', torch.float32, torch.bfloat16 or \"f16\"")
         if self._general:
             self._cd_request = dtype          # (the tape helpers read self.compute_dtype: resolved at every forward)
             self.__dict__["_f32_split3"] = False
             self.__dict__["_f32_f16"] = False
             return self
         self.compute_dtype = dtype
+        self.__dict__["_f32_f16"] = False
         self._shadow_fresh = False
         return self
+
+    def _flat_gemm_mode(self, backward):
+        """the flat (class-conditional) engine's "f16" compute mode: its exact-f32 mode - f32 tensors, kernels and saved activations -
+        with every weight GEMM the half kernels take (the layers' four Linears, the head's dense layer; their dX and dW) as ONE
+        IEEE-half product with f32 accumulation: TF32's operand precision (tape_ops.set_compute_dtype has the reasoning), gradient
+        operands through the pass's power-of-two scale (f16_grad_scale / f16_update_grad_scale / f16_stats as for the tape engines).
+        The batched per-head products of the materialised attention core (257 tokens) and the 2025-wide logits head stay exact f32.
+        Operands are converted per product (no image cache: this engine rewrites its buffers in place)."""
+        if self._general or not self.__dict__.get("_f32_f16", False):
+            return contextlib.nullcontext()
+        images = self.__dict__.get("_f16_images")
+        if images is None:
+            images = self.__dict__["_f16_images"] = ops.F16Images(recent=0)
+        images.clear()
+        images.backward, images.keep = bool(backward), False
+        if backward:
+            images.set_grad_scale(self.f16_grad_scale_for(self.__dict__.get("_loss_rows", 1)))
+        return ops.f32_gemms_as_f16(True, images)
 
     def _resolve_cd(self):
         want = self._cd_request if self._general else self.compute_dtype
@@ -520,6 +547,7 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
         loss_out = lse = lab = None
         if labels is not None:
             lab = labels.contiguous().view(-1)
+            self.__dict__["_loss_rows"] = T          # ("f16" mode: bounds d(logits), tape_ops.f16_grad_scale_for)
             loss_out, lse = ops.cross_entropy_fwd(logits, lab, label_smoothing, vocab=V)
             loss = loss_out[0]
         if need_grad:
