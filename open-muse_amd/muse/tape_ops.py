@@ -128,11 +128,16 @@ class TapeOps:
         images = self.__dict__.get("_f16_images")
         return (0, 0) if images is None else images.stats(reset)
 
-    def f16_update_grad_scale(self, growth_interval=2000):
+    def f16_update_grad_scale(self, growth_interval=2000, group=None):
         """"f16" mode, the dynamic loss-scaling recipe of fp16 training (torch.cuda.amp.GradScaler's policy) applied to the gradient OPERAND
         scale: call after backward().  An operand overflowed half's range (the gradients are NaN): the scale is halved and False comes
         back - skip the optimizer step.  Otherwise True, and after `growth_interval` good steps in a row the scale doubles.  The scale
-        only moves rounding (it is undone exactly in every product's alpha), never values; one device read per call."""
+        only moves rounding (it is undone exactly in every product's alpha), never values; one device read per call.  Under data
+        parallelism (torch.distributed initialised) the overflow count is summed over `group` first, so every rank takes the same
+        decision and keeps the same scale - like GradScaler's found_inf all-reduce."""
+        images = self.__dict__.get("_f16_images")
+        if images is not None and images._stats is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(images._stats, group=group)
         overflowed, _ = self.f16_stats()
         cur = self.f16_grad_scale_for(self.__dict__.get("_loss_rows", 1))
         if overflowed:

@@ -397,3 +397,37 @@ def test_grad_reducer_no_sync_accumulation_world2(tmp_path):
         t0, t1 = r[0]["tape_two_sync"][j], r[1]["tape_two_sync"][j]
         assert torch.equal(t0, t1) and torch.allclose(t0, torch.full_like(g0, sum(per_rank) / world) + 2 * ramp)
 
+
+
+def _worker_f16_scale(rank, world, port, out):
+    """the "f16" compute mode's dynamic gradient scale under data parallelism: the overflow count is summed over the ranks before the
+    decision, so a rank that saw no overflow skips the step and halves its scale together with the rank that did"""
+    sys.path.insert(0, os.path.join(ROOT, "open-muse_amd"))
+    from muse import ops, tape_ops
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Host(tape_ops.TapeOps):
+        pass
+    h = Host()
+    im = ops.F16Images()
+    h.__dict__["_f16_images"] = im
+    h.__dict__["_loss_rows"] = 512
+    log = []
+    for step, counts in enumerate(([5, 0], [0, 0], [0, 3])):       # per step: [rank 0's overflow count, rank 1's]
+        im._stats = torch.tensor([counts[rank], 0], dtype=torch.int32)
+        ok = h.f16_update_grad_scale(growth_interval=1000)
+        log.append((ok, h.f16_grad_scale_for(512)))
+    torch.save(log, os.path.join(out, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_f16_grad_scale_decision_is_shared_world2(tmp_path):
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_f16_scale, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    assert r0 == r1
+    assert [ok for ok, _ in r0] == [False, True, False]
+    assert [s for _, s in r0] == [2.0 ** 18, 2.0 ** 18, 2.0 ** 17]
