@@ -6,6 +6,7 @@ MuseHipError if the tensors are not on the GPU or the native library is missing:
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 
 import torch
@@ -186,8 +187,10 @@ def gemm(A, B, C_, M, N, K, *, la=0, lb=0, lda, ldb, ldc, a_off=0, b_off=0, c_of
 # YAML asks for.  What half lacks is TF32's exponent range, which is the host's job here: an operand image is half(x * s) with s a power
 # of two (exact) and the product's alpha carries 1 / (s_a s_b).  Forward operands (normalised activations, weights) use s = 1; every
 # GRADIENT operand of a backward pass uses the pass's `grad_scale` (per-token loss gradients are ~1 / tokens: far below half's normal
-# range unscaled).  Elements beyond +-65504 / s are clamped and counted, non-zero elements rounded to zero are counted (F16Images.stats())
-# - a step whose counters are not (0, small) ran with the wrong scale.  Products the 256^2 half kernels refuse stay in exact f32.
+# range unscaled).  A finite element beyond +-65504 / s becomes inf - the product and the step's gradients turn NaN rather than silently
+# wrong - and is counted, by the cast kernel and by every producer kernel; non-zero elements a cast rounds to zero are counted too
+# (F16Images.stats()).  The fp16-training recipe applies on top: TapeOps.f16_update_grad_scale() halves the scale and has the caller
+# skip the step.  Products the 256^2 half kernels refuse stay in exact f32.
 _F32_AS_F16 = [False]
 _F16_IMAGES = [None]
 # operand dtypes of a product the mode converts: f32 tensors, or an f32 tensor against an operand that already IS a half image (a
@@ -205,7 +208,7 @@ class F16Images:
     def __init__(self, grad_scale=1.0, recent=12):
         self.persist, self.lru, self.recent, self.backward, self.keep = {}, {}, int(recent), False, True
         self.grad_scale = float(grad_scale)
-        self.hits = self.misses = 0
+        self.hits = self.misses = self.produced = 0
         self._stats = None
 
     def clear(self):
@@ -213,8 +216,7 @@ class F16Images:
         self.lru.clear()
 
     def set_grad_scale(self, s):
-        m, e = __import__("math").frexp(float(s))
-        if s <= 0 or m != 0.5:
+        if s <= 0 or math.frexp(float(s))[0] != 0.5:
             raise _hip.MuseHipError(f"f16 mode: the gradient scale must be a power of two, got {s}")
         self.grad_scale = float(s)
 
@@ -258,7 +260,6 @@ class F16Images:
             self.persist[key] = (t, out)
         return out
 
-
     def put_planes(self, t, planes):
         """a producer kernel wrote t's half image itself ([1, *t.shape], the bits muse_cast_f32_to_f16 makes of t with the scale the
         kernel was given: the pass's gradient scale in a backward pass, 1 in a forward one): no cast pass when a product reads t"""
@@ -266,7 +267,7 @@ class F16Images:
         img = planes[0]
         img._muse_scale = scale
         key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, float(scale))
-        self.produced = getattr(self, "produced", 0) + 1
+        self.produced += 1
         if self.backward or not self.keep:
             self.lru[key] = (t, img)
             while len(self.lru) > self.recent:

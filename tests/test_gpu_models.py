@@ -402,8 +402,8 @@ def test_general_transformer_f16_mode_vs_reference_golden(golden_dir):
     worst = max(float(np.abs(W.subsample(params[k].grad.detach()).cpu().numpy() - g["grad." + k]).max()) / float(g["absmax." + k]) for k in keys)
     im = m.__dict__["_f16_images"]
     print(f"f16 mode at the cc12m width vs the reference (f32): logits {el:.2e}, loss {lrel:.1e}, worst gradient {worst:.2e}; "
-          f"images: {im.hits} shared reads, {im.misses} casts, {getattr(im, 'produced', 0)} written by producers; overflowed / flushed {m.f16_stats()}")
-    assert im.misses + getattr(im, "produced", 0) > 10 and not im.persist and not im.lru
+          f"images: {im.hits} shared reads, {im.misses} casts, {im.produced} written by producers; overflowed / flushed {m.f16_stats()}")
+    assert im.misses + im.produced > 10 and not im.persist and not im.lru
     assert el < 2e-3 and lrel < 1e-4 and worst < 6e-3
 
 

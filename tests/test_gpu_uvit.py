@@ -399,8 +399,8 @@ def test_f16_mode_training_steps(golden_dir):
             if mode == "f16":
                 images = model.__dict__["_f16_images"]
                 print("f16 mode, fusions", fused, ": steps skipped on operand overflow", skipped, "-> gradient scale", model.f16_grad_scale,
-                      "; image cache hits / casts / produced", images.hits, images.misses, getattr(images, "produced", 0))
-                assert (getattr(images, "produced", 0) > 0) == fused
+                      "; image cache hits / casts / produced", images.hits, images.misses, images.produced)
+                assert (images.produced > 0) == fused
                 results_skipped.append(skipped)
         finally:
             tape_ops.F16_WEIGHT_IMAGES, ops.F16_PRODUCERS = old
