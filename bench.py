@@ -349,7 +349,8 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False, f16=False):
            "tflops": round(tf, 1), "mfma_frac": round(tf / (PEAK["bf16"] / 3 if x3 else PEAK["f32" if f32 else "bf16"]), 4), "loss": round(float(loss), 4), "parameters": n_params,
            "dtype": ("f16: f32 tensors; every weight GEMM (linears, dX, dW) as ONE v_mfma_f32_16x16x32_f16 product of IEEE-half operand images with f32 "
                      "accumulation - half's 10-bit mantissa is the TF32 operand format the yaml's enable_tf32 multiplies in (gfx950 has no xf32 MFMA); "
-                     "TF32's exponent range is covered by power-of-two operand scales (gradient operands x 2^10 x tokens, undone in alpha; "
+                     "(against the real reference's f32 run at full size: logits 9.2e-4, worst gradient 2.2e-3; the reference under emulated TF32: 1.0e-3 / 2.1e-3 - "
+                     "tests/golden/make_golden_tf32.py); TF32's exponent range is covered by power-of-two operand scales (gradient operands x 2^10 x tokens, undone in alpha; "
                      "overflowed / flushed elements counted: f16_operand_stats); the attention core (muse_attention_x3_*, block by block at 1024 tokens) "
                      "with one half plane per operand and one half MFMA per K step; f32 softmax, norms, GLU, residual stream, loss, AdamW; mfma_frac against the 2500 TFLOP/s half / bf16 peak") if f16 else ("bf16x3: f32 tensors, every product (linears, dX, dW: muse_gemm_x3 on four operand planes; the attention core: "
                      + ("muse_attention_x3_*" if seq == 256 else "muse_attention_x3_* block by block - 256 query rows against 256-key blocks (or the 77 text states), "

@@ -352,3 +352,21 @@ def test_ema_oracle_vs_reference_golden(golden_dir):
                 assert np.array_equal(sh, g[f"s{si}.shadow{step}.{i}"]), (si, step, i)
         assert used == (steps if kw.get("update_every", 1) == 1 else steps // 2)
 
+
+
+def test_reference_tf32_regime_golden_sits_tf32_class_from_its_f32_run():
+    """tests/golden/uvit_full_tf32emu.npz (make_golden_tf32.py): the REAL reference at config 4's full size with the operands of every
+    matmul rounded to TF32's 10-bit mantissa - the `enable_tf32` regime of configs/cc12m_uvit_clip.yaml:102-103 emulated on the CPU -
+    next to its plain f32 run (uvit_full.npz).  The gap between the two is what "the YAML's precision class" means in numbers; the
+    f16 compute mode of this package is held to it on the GPU (test_uvit_config4_vs_reference_golden)."""
+    import numpy as np
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, t = np.load(os.path.join(here, "uvit_full.npz")), np.load(os.path.join(here, "uvit_full_tf32emu.npz"))
+    assert int(g["seed"]) == int(t["seed"]) and tuple(g["logits_shape"]) == tuple(t["logits_shape"])
+    keys = [k[5:] for k in g.files if k.startswith("grad.")]
+    el = float(np.abs(t["logits"] - g["logits"]).max()) / float(g["logits_absmax"])
+    eg = max(float(np.abs(t["grad." + k] - g["grad." + k]).max()) / float(g["absmax." + k]) for k in keys)
+    lrel = abs(float(t["loss"]) - float(g["loss"])) / float(g["loss"])
+    print(f"reference under emulated TF32 vs its f32 run: logits {el:.2e}, loss {lrel:.1e}, worst gradient {eg:.1e}")
+    assert 3e-4 < el < 3e-3 and 5e-4 < eg < 6e-3 and lrel < 1e-4      # TF32 class: far from f32-exact (1e-6), far from bf16 (1e-2)
