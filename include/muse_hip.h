@@ -175,6 +175,17 @@ int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, int64_t lddo
  * (*_planes, optional: the result ALSO as the bf16 operand planes of the products that read it - muse_gemm_x3 - so that no split pass
  *  runs over it: the hi plane is addressed exactly like the f32 tensor (same strides, in elements), the lo plane sits *_lo elements
  *  behind it; NULL = f32 only) */
+/* Streaming forms for sequences of whole 256-row blocks on BOTH sides (round 6: the self-attention of BASELINE config 4's 1024 tokens;
+ * reference modeling_transformer_v2.py:881-915).  d describes the FULL sequences (seq_q, seq_kv multiples of 256, head_dim 64; batch
+ * strides of the whole tensors).  _fwd_stream: a workgroup keeps 256 queries and streams the key blocks through LDS with an online
+ * softmax - context and lse [seq_q/256][batch*heads][256] written once (o_planes as for muse_attention_x3_fwd).  _bwd_stream: dQ per
+ * query block over the streamed key blocks (it also writes dO.O per query into dsum, a workspace shaped like lse), then dK / dV per
+ * key block over the streamed query blocks; every gradient written once (f32 and / or operand images, as for muse_attention_x3_bwd). */
+int muse_attention_x3_fwd_stream(const muse_attn_desc* d, float* lse, void* o_planes, int64_t o_lo, void* stream);
+int muse_attention_x3_bwd_stream(const muse_attn_desc* d, const float* d_o, int64_t lddo, int64_t bsdo, const float* lse, float* dsum,
+                                 float* dq, int64_t lddq, int64_t bsdq, float* dk, int64_t lddk, int64_t bsdk, float* dv, int64_t lddv,
+                                 int64_t bsdv, void* dq_planes, int64_t dq_lo, void* dk_planes, int64_t dk_lo, void* dv_planes, int64_t dv_lo,
+                                 void* stream);
 /* Block-by-block form of the longer sequences (round 6; reference modeling_transformer_v2.py:757-792 at the 1024 tokens of BASELINE config 4):
  * muse_attention_x3_fwd / _bwd run per (256 query rows, <= 256 keys) block pair, these two put the pieces together.
  * _merge: part[j] [batch*seq, heads*64] f32 (j < nk <= 8, part_stride elements apart) = key block j's softmax times its values, lp[j]

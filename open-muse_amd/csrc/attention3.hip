@@ -53,6 +53,9 @@ struct Params {
   float img_scale;
   int* img_stats;
   float gscale;        // H16 backward: the power of two gradient operands are scaled by before their conversion to half (else 1)
+  // streaming forms (longer sequences: whole multiples of 256 queries / keys; q, k, v, o, dO, dq, dk, dv are the FULL-sequence tensors):
+  int nqb, nkj;        // query blocks (= gridDim.y of the forward / dQ kernels) and key blocks (= gridDim.y of the dK / dV kernel)
+  float* dsum;         // [nqb][B * nh][256]: dO . O per query, written by the dQ kernel, read by the dK / dV kernel
 };
 
 typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
@@ -365,6 +368,166 @@ __global__ __launch_bounds__(NT, 2) void bwd_kernel(const Params P) {
   }
 }
 
+// =================================================================================================================
+// Streaming forms for sequences of whole 256-row blocks (round 6: BASELINE config 4's 1024 tokens).  The one-tile kernels above, run per
+// (query block, key block) pair, reload q / k / v for every pair and leave partial results to be merged; here a workgroup keeps its 256
+// queries (forward, dQ) or its 256 keys (dK / dV) and STREAMS the other side's 256-row blocks through the same LDS planes:
+//   forward   online softmax - running row maximum m and sum l per query, the accumulated P V rescaled by exp2((m_old - m_new) c) when a
+//             block raises the maximum; one pass, the context and its log-sum-exp written once (no partials, no merge kernel)
+//   dQ        phase 1 of bwd_kernel per key block with the GLOBAL log-sum-exp: dQ accumulates over the key blocks; also writes dO . O
+//   dK / dV   phase 2 of bwd_kernel per query block (Q, dO planes; lse and -dO.O of the block from the arrays the other kernels wrote)
+// S and dP are computed twice (once per kernel: 7 block products instead of 5) and every gradient is written once (no partial stacks).
+// =================================================================================================================
+template <bool H16>
+__global__ __launch_bounds__(NT, 2) void fwd_stream_kernel(const Params P) {
+  constexpr int NKB = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *Kh = smem, *Kl = smem + PLANE, *Vh = smem + (H16 ? 1 : 2) * PLANE, *Vl = smem + 3 * PLANE;
+  const LaneGeom g = make_geom<HD>();
+  const int head = xcd_remap(), qi = blockIdx.y;
+  const int b = head / P.nh, hh = head - b * P.nh;
+  const float c = P.alpha * LOG2E;
+  const int q = qi * SQ + g.wave * 32 + g.n;
+  const Raw qr = load_raw(P.q + b * P.bq + (long)q * P.ldq + hh * HD, true, g.h);
+  const FragB3 qf = split_raw<H16>(qr);
+  float m = NEG_BIG, l = 0.f;
+  f32x16 o[C::NDB];
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db) o[db] = zero16();
+  for (int kj = 0; kj < P.nkj; ++kj) {
+    if (kj) lds_barrier();                      // every wave is done with the previous key block's planes
+    fill_two<SQ, H16>(Kh, Kl, P.k + b * P.bk + (long)kj * SQ * P.ldk + hh * HD, P.ldk, Vh, Vl, P.v + b * P.bv + (long)kj * SQ * P.ldv + hh * HD, P.ldv, SQ);
+    lds_barrier();
+    f32x16 s[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) s[kb] = mma_rows3<H16>(Kh, Kl, g, kb, qf, zero16());
+    float mj = m;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mj = fmaxf(mj, s[kb][r]);
+    mj = fmaxf(mj, xhalf(mj));
+    const float resc = __builtin_amdgcn_exp2f((m - mj) * c);     // (first block: exp2(-huge) = 0 on zeros)
+    m = mj;
+    l *= resc;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= resc;
+    const float mc = m * c;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc)); l += s[kb][r]; }
+      mma_seq3<H16>(Vh, Vl, g, kb, s[kb], o);
+    }
+  }
+  l += xhalf(l);
+  const long oo = b * P.bo + (long)q * P.ldo + hh * HD;
+  store_rows3(P.out + oo, o, 1.0f / l, g.h, P.outp ? P.outp + oo : nullptr, P.lo_out, P.img_scale, P.img_stats);
+  if (g.h == 0) P.lse[((long)qi * gridDim.x + head) * SQ + g.wave * 32 + g.n] = m * P.alpha + __logf(l);
+}
+
+template <bool H16>
+__global__ __launch_bounds__(NT, 2) void bwd_dq_stream_kernel(const Params P) {
+  constexpr int NKB = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *Ah = smem, *Al = smem + PLANE, *Bh = smem + (H16 ? 1 : 2) * PLANE, *Bl = smem + 3 * PLANE;   // K, V of the streamed key block
+  const float S = H16 ? P.gscale : 1.f;
+  const LaneGeom g = make_geom<HD>();
+  const int head = xcd_remap(), qi = blockIdx.y;
+  const int b = head / P.nh, hh = head - b * P.nh;
+  const float c = P.alpha * LOG2E;
+  const int q = qi * SQ + g.wave * 32 + g.n;
+  const Raw qr = load_raw(P.q + b * P.bq + (long)q * P.ldq + hh * HD, true, g.h);
+  const Raw dor = load_raw(P.d_o + b * P.bdo + (long)q * P.lddo + hh * HD, true, g.h);
+  const Raw orr = load_raw(P.o + b * P.bo + (long)q * P.ldo + hh * HD, true, g.h);
+  const long li = ((long)qi * gridDim.x + head) * SQ + g.wave * 32 + g.n;
+  const float lse = P.lse[li];
+  float d = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d = fmaf(dor.a[ks][e], orr.a[ks][e], d); d = fmaf(dor.b[ks][e], orr.b[ks][e], d); }
+  d += xhalf(d);
+  if (g.h == 0) P.dsum[li] = d;
+  d *= S;
+  const FragB3 qf = split_raw<H16>(qr), dof = split_raw<H16>(dor, S);
+  f32x16 l2v, dsv;
+  l2v[0] = lse * LOG2E;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dsv[r] = -d;
+  f32x16 dq[C::NDB];
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db) dq[db] = zero16();
+  for (int kj = 0; kj < P.nkj; ++kj) {
+    if (kj) lds_barrier();
+    fill_two<SQ, H16>(Ah, Al, P.k + b * P.bk + (long)kj * SQ * P.ldk + hh * HD, P.ldk, Bh, Bl, P.v + b * P.bv + (long)kj * SQ * P.ldv + hh * HD, P.ldv, SQ);
+    lds_barrier();
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      f32x16 s = mma_rows3<H16>(Ah, Al, g, kb, qf, zero16());
+      f32x16 dp = mma_rows3<H16>(Bh, Bl, g, kb, dof, dsv);
+      p_and_ds<false>(s, dp, c, l2v);
+      mma_seq3<H16>(Ah, Al, g, kb, dp, dq);
+    }
+  }
+  const long oq = b * P.bdq + (long)q * P.lddq + hh * HD;
+  store_rows3(P.dq ? P.dq + oq : nullptr, dq, P.alpha / S, g.h, P.dqp ? P.dqp + oq : nullptr, P.lo_dq, P.img_scale, P.img_stats);
+}
+
+template <bool H16>
+__global__ __launch_bounds__(NT, 2) void bwd_dkv_stream_kernel(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *Ah = smem, *Al = smem + PLANE, *Bh = smem + (H16 ? 1 : 2) * PLANE, *Bl = smem + 3 * PLANE;   // Q, dO of the streamed query block
+  float* L2 = (float*)(smem + (H16 ? 2 : 4) * PLANE);      // lse * log2(e) of the block's queries in MFMA-row order (bwd_kernel)
+  float* DS = L2 + SQ;                                     // -dO.O * S, same order
+  const float S = H16 ? P.gscale : 1.f;
+  const LaneGeom g = make_geom<HD>();
+  const int head = xcd_remap(), kj = blockIdx.y;
+  const int b = head / P.nh, hh = head - b * P.nh;
+  const float c = P.alpha * LOG2E;
+  const int key = kj * SQ + g.wave * 32 + g.n;
+  const Raw kr = load_raw(P.k + b * P.bk + (long)key * P.ldk + hh * HD, true, g.h);
+  const Raw vr = load_raw(P.v + b * P.bv + (long)key * P.ldv + hh * HD, true, g.h);
+  const FragB3 kf = split_raw<H16>(kr), vf = split_raw<H16>(vr);
+  f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+  for (int qi = 0; qi < P.nqb; ++qi) {
+    if (qi) lds_barrier();
+    fill_two<SQ, H16>(Ah, Al, P.q + b * P.bq + (long)qi * SQ * P.ldq + hh * HD, P.ldq, Bh, Bl, P.d_o + b * P.bdo + (long)qi * SQ * P.lddo + hh * HD,
+                      P.lddo, SQ, S);
+    if (threadIdx.x < SQ) {     // query r of the block sits at position 32 (r / 32) + perm32_inv(r % 32)
+      const int r = threadIdx.x;
+      const long li = ((long)qi * gridDim.x + head) * SQ + r;
+      const int pos = (r & ~31) + perm32_inv(r & 31);
+      L2[pos] = P.lse[li] * LOG2E;
+      DS[pos] = -P.dsum[li] * S;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int qb = 0; qb < SQ / 32; ++qb) {
+      f32x16 l2v, dsv;
+#pragma unroll
+      for (int T = 0; T < 4; ++T) {
+        const f32x4 a = *(const f32x4*)(L2 + qb * 32 + 8 * T + 4 * g.h);
+        const f32x4 dd = *(const f32x4*)(DS + qb * 32 + 8 * T + 4 * g.h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { l2v[4 * T + j] = a[j]; dsv[4 * T + j] = dd[j]; }
+      }
+      f32x16 s = mma_rows3<H16>(Ah, Al, g, qb, kf, zero16());
+      f32x16 dp = mma_rows3<H16>(Bh, Bl, g, qb, vf, dsv);
+      p_and_ds<true>(s, dp, c, l2v);
+      mma_seq3<H16>(Bh, Bl, g, qb, s, dv);
+      mma_seq3<H16>(Ah, Al, g, qb, dp, dk);
+    }
+  }
+  const long ok = b * P.bdk + (long)key * P.lddk + hh * HD, ov = b * P.bdv + (long)key * P.lddv + hh * HD;
+  store_rows3(P.dk ? P.dk + ok : nullptr, dk, P.alpha / S, g.h, P.dkp ? P.dkp + ok : nullptr, P.lo_dk, P.img_scale, P.img_stats);
+  store_rows3(P.dv ? P.dv + ov : nullptr, dv, 1.0f / S, g.h, P.dvp ? P.dvp + ov : nullptr, P.lo_dv, P.img_scale, P.img_stats);
+}
+
 static int nkb_of(int skv) { return (skv + 31) / 32; }
 static int check(const muse_attn_desc* d) {
   if (!d || d->seq_q <= 0 || d->seq_kv <= 0 || d->heads <= 0) return MUSE_ERR_BAD_ARG;
@@ -390,6 +553,23 @@ static int launch(K k, const Params& P, int heads_total, size_t lds, hipStream_t
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(heads_total), dim3(NT), lds, st, P);
   MUSE_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename K>
+static int launch2(K k, const Params& P, int heads_total, int ny, size_t lds, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(heads_total, ny), dim3(NT), lds, st, P);
+  MUSE_CHECK_LAUNCH();
+  return 0;
+}
+static int check_stream(const muse_attn_desc* d) {
+  if (!d || d->seq_q <= 0 || d->seq_kv <= 0 || d->heads <= 0) return MUSE_ERR_BAD_ARG;
+  if (d->head_dim != HD || (d->seq_q % SQ) || (d->seq_kv % SQ)) return MUSE_ERR_UNSUPPORTED;
+  const int64_t lds[] = {d->ldq, d->ldk, d->ldv, d->ldo, d->bsq, d->bsk, d->bsv, d->bso};
+  for (int64_t x : lds) if (x & 3) return MUSE_ERR_ALIGN;
+  const void* ps[] = {d->q, d->k, d->v, d->o};
+  for (const void* p : ps) if (((uintptr_t)p) & 15) return MUSE_ERR_ALIGN;
   return 0;
 }
 
@@ -446,6 +626,56 @@ extern "C" int muse_attention_x3_bwd(const muse_attn_desc* d, const void* d_o, i
   const size_t lds = 4 * (size_t)PLANE + 2 * SQ * sizeof(float);
   return nkb_of(d->seq_kv) == 8 ? launch(bwd_kernel<8>, P, d->batch * d->heads, lds, (hipStream_t)stream)
                                 : launch(bwd_kernel<3>, P, d->batch * d->heads, lds, (hipStream_t)stream);
+}
+
+// ---- streaming forms: whole multiples of 256 queries AND keys (self-attention of the longer sequences) ---------------------------------------------
+// d describes the FULL sequences (seq_q, seq_kv multiples of 256; batch strides of the whole tensors).  lse [seq_q / 256][batch * heads][256].
+extern "C" int muse_attention_x3_fwd_stream(const muse_attn_desc* d, float* lse, void* o_planes, int64_t o_lo, void* stream) {
+  using namespace attn3;
+  const int rc = check_stream(d);
+  if (rc) return rc;
+  if (o_planes && ((((uintptr_t)o_planes) & 7) || (o_lo & 3) || o_lo <= 0)) return MUSE_ERR_ALIGN;
+  if (d->batch <= 0) return 0;
+  Params P = base(d);
+  P.out = (float*)d->o; P.lse = lse;
+  const ImgFormat f = img_format(false);
+  P.outp = (bf16_t*)o_planes; P.lo_out = f.lo_sign < 0 ? -1 : o_lo; P.img_scale = f.scale; P.img_stats = f.stats;
+  P.nqb = d->seq_q / SQ; P.nkj = d->seq_kv / SQ;
+  if (f.lo_sign < 0) return launch2(fwd_stream_kernel<true>, P, d->batch * d->heads, P.nqb, 2 * (size_t)PLANE, (hipStream_t)stream);
+  return launch2(fwd_stream_kernel<false>, P, d->batch * d->heads, P.nqb, 4 * (size_t)PLANE, (hipStream_t)stream);
+}
+// dsum: workspace [seq_q / 256][batch * heads][256] f32 (dO . O per query: written by the dQ pass, read by the dK / dV pass).  Gradients as for
+// muse_attention_x3_bwd (f32 tensors and / or operand images; leading dimensions and batch strides of the full-sequence tensors).
+extern "C" int muse_attention_x3_bwd_stream(const muse_attn_desc* d, const float* d_o, int64_t lddo, int64_t bsdo, const float* lse, float* dsum,
+                                            float* dq, int64_t lddq, int64_t bsdq, float* dk, int64_t lddk, int64_t bsdk, float* dv, int64_t lddv,
+                                            int64_t bsdv, void* dq_planes, int64_t dq_lo, void* dk_planes, int64_t dk_lo, void* dv_planes, int64_t dv_lo,
+                                            void* stream) {
+  using namespace attn3;
+  if (((((uintptr_t)dq_planes) | ((uintptr_t)dk_planes) | ((uintptr_t)dv_planes)) & 7) || ((dq_lo | dk_lo | dv_lo) & 3)) return MUSE_ERR_ALIGN;
+  const int rc = check_stream(d);
+  if (rc) return rc;
+  if ((lddo | bsdo | lddq | bsdq | lddk | bsdk | lddv | bsdv) & 3) return MUSE_ERR_ALIGN;
+  if ((((uintptr_t)d_o) | ((uintptr_t)dq) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 15) return MUSE_ERR_ALIGN;
+  if (!dsum || !lse || (!dq && !dq_planes) || (!dk && !dk_planes) || (!dv && !dv_planes)) return MUSE_ERR_BAD_ARG;
+  if (d->batch <= 0) return 0;
+  Params P = base(d);
+  P.o = (const float*)d->o; P.d_o = d_o; P.lddo = lddo; P.bdo = bsdo;
+  P.lse = (float*)lse; P.dsum = dsum;
+  P.dq = dq; P.lddq = lddq; P.bdq = bsdq;
+  P.dk = dk; P.lddk = lddk; P.bdk = bsdk;
+  P.dv = dv; P.lddv = lddv; P.bdv = bsdv;
+  const ImgFormat f = img_format(true);
+  P.dqp = (bf16_t*)dq_planes; P.dkp = (bf16_t*)dk_planes; P.dvp = (bf16_t*)dv_planes; P.img_scale = f.scale; P.img_stats = f.stats;
+  P.lo_dq = f.lo_sign < 0 ? -1 : dq_lo; P.lo_dk = f.lo_sign < 0 ? -1 : dk_lo; P.lo_dv = f.lo_sign < 0 ? -1 : dv_lo;
+  P.gscale = f.lo_sign < 0 ? f.scale : 1.f;
+  P.nqb = d->seq_q / SQ; P.nkj = d->seq_kv / SQ;
+  const bool h16 = f.lo_sign < 0;
+  const size_t lds1 = (h16 ? 2 : 4) * (size_t)PLANE, lds2 = lds1 + 2 * SQ * sizeof(float);
+  int r = h16 ? launch2(bwd_dq_stream_kernel<true>, P, d->batch * d->heads, P.nqb, lds1, (hipStream_t)stream)
+              : launch2(bwd_dq_stream_kernel<false>, P, d->batch * d->heads, P.nqb, lds1, (hipStream_t)stream);
+  if (r) return r;
+  return h16 ? launch2(bwd_dkv_stream_kernel<true>, P, d->batch * d->heads, P.nkj, lds2, (hipStream_t)stream)
+             : launch2(bwd_dkv_stream_kernel<false>, P, d->batch * d->heads, P.nkj, lds2, (hipStream_t)stream);
 }
 
 // ---- block-by-block form of the longer sequences (round 6: BASELINE config 4's 1024 tokens; muse/ops.py attention_x3_blocked) -------------------

@@ -69,6 +69,9 @@ SIGNATURES = {
     "muse_attention_x3_fwd": [C.POINTER(AttnDesc), c_void_p, c_void_p, c_i64, c_void_p],
     "muse_attention_x3_bwd": [C.POINTER(AttnDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
                               c_i64, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
+    "muse_attention_x3_fwd_stream": [C.POINTER(AttnDesc), c_void_p, c_void_p, c_i64, c_void_p],
+    "muse_attention_x3_bwd_stream": [C.POINTER(AttnDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
+                                     c_void_p, c_i64, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p],
     "muse_attention_x3_merge": [c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p],
     "muse_sum_parts_strided": [c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_i64, c_int, c_void_p],
     "muse_attention_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],

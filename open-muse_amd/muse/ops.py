@@ -1086,6 +1086,9 @@ def attention_bwd_ex(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None
     return dq, dk, dv
 
 
+X3_STREAM = os.environ.get("MUSE_X3_STREAM", "1") != "0"   # sequences of several 256-key blocks: the streaming kernels (0: block pairs + merge)
+
+
 def _x3_one_tile_keys(Skv):
     return 224 < Skv <= 256 or 64 < Skv <= 96
 
@@ -1094,6 +1097,12 @@ def attention_x3_blocked(Sq, Skv):
     """longer sequences (round 6: BASELINE config 4's 1024 tokens) run attention3.hip's one-tile kernels block by block: q rows in
     blocks of 256, keys in blocks of 256 (or one block of <= 96 text states), the key blocks' partial results merged by their log-sum-exps"""
     return Sq > 256 or Skv > 256
+
+
+def attention_x3_streamed(Sq, Skv):
+    """whole 256-row blocks on both sides and more than one key block: the streaming kernels (online-softmax forward, dQ and dK / dV
+    passes; csrc/attention3.hip) - one writer per result, so operand images / planes-only gradients work as in the one-tile form"""
+    return X3_STREAM and Sq % 256 == 0 and Skv % 256 == 0 and Skv > 256
 
 
 def attention_x3_supported(Sq, Skv, hd):
@@ -1123,7 +1132,15 @@ def _attention_x3_fwd_blocks(q, k, v, B, Sq, Skv, nh, hd, alpha):
     ctx = torch.empty((B * Sq, H), dtype=torch.float32, device=dev)
     lse = torch.empty((nq, B * nh, 256), dtype=torch.float32, device=dev)
     e0 = _prof_begin()
-    if nk == 1:
+    if nk > 1 and X3_STREAM:
+        # whole 256-row blocks on both sides: a workgroup keeps its 256 queries and streams the key blocks through LDS with an online
+        # softmax (csrc/attention3.hip fwd_stream_kernel) - q read once, the context and its log-sum-exp written once, no partials
+        planes = x3_new_planes(ctx)
+        d = _attn_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha)
+        check(lib().muse_attention_x3_fwd_stream(C.byref(d), lse.data_ptr(), ptr(planes), ctx.numel() if planes is not None else 0, stream()),
+              "muse_attention_x3_fwd_stream")
+        x3_put_planes(ctx, planes)
+    elif nk == 1:
         planes = x3_new_planes(ctx)          # ctx feeds the output projection: every block writes its rows of the operand planes too
         for qi in range(nq):
             d = _x3_block_desc(q, k, v, ctx, B, Sq, Skv, nh, hd, alpha, qi, 0, kb)
@@ -1217,7 +1234,8 @@ def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None
     for t in (ctx, dctx, dq, dk, dv):
         if t is not None and t.dtype != torch.float32:
             raise _hip.MuseHipError("attention_x3: f32 operands")
-    if attention_x3_blocked(Sq, Skv):
+    streamed = attention_x3_streamed(Sq, Skv)
+    if attention_x3_blocked(Sq, Skv) and not streamed:
         if planes_only or any(e is not None and e[0] is not None for e in planes):
             raise _hip.MuseHipError("attention_x3_bwd: the block-by-block form (more than 256 query rows or keys) writes f32 gradients, no operand planes")
         return _attention_x3_bwd_blocks(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq, dk, dv)
@@ -1236,7 +1254,17 @@ def attention_x3_bwd(q, k, v, ctx, dctx, lse, B, Sq, Skv, nh, hd, alpha, dq=None
             if ent[0].stride() != ref.stride() or ent[0].shape != ref.shape or ent[0].dtype != (torch.float16 if _F32_AS_F16[0] else torch.bfloat16):
                 raise _hip.MuseHipError("attention_x3_bwd: a hi-plane view must mirror its gradient view")
             pl += [ent[0].data_ptr(), int(ent[1])]
-    check(lib().muse_attention_x3_bwd(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), *args, *pl, stream()), "muse_attention_x3_bwd")
+    if streamed:
+        # dQ per query block over the streamed key blocks (it also leaves dO . O per query in dsum), then dK / dV per key block over the
+        # streamed query blocks: every gradient written once (bwd_dq_stream_kernel / bwd_dkv_stream_kernel)
+        dsum = torch.empty_like(lse)
+        check(lib().muse_attention_x3_bwd_stream(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), dsum.data_ptr(), *args, *pl, stream()),
+              "muse_attention_x3_bwd_stream")
+        for t in (dq, dk, dv):
+            if t is not None:
+                _touched(t)
+    else:
+        check(lib().muse_attention_x3_bwd(C.byref(d), pdo, lddo, Sq * lddo, lse.data_ptr(), *args, *pl, stream()), "muse_attention_x3_bwd")
     _prof_end(e0, "attn_bwd_bf16x3", 10.0 * B * nh * Sq * Skv * hd)
     return dq, dk, dv
 

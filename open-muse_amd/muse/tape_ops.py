@@ -481,7 +481,8 @@ class TapeOps:
         do = self._lin_bwd(dy, sv["o"], att.out, name + ".out", G)                        # f32 [B*Sq, C]
         q, qkv, w = sv["q"], sv["qkv"], sv["w"]
         ub = self.__dict__.get("_use_bias", False)
-        blocked = ops.attention_x3_blocked(Sq, Skv)      # (block-by-block form of the long sequences: f32 gradients, no operand planes)
+        # (block-by-block form of the long sequences: f32 gradients, no operand planes - the streaming form writes them like the one-tile one)
+        blocked = ops.attention_x3_blocked(Sq, Skv) and not ops.attention_x3_streamed(Sq, Skv)
         if sv["self_attn"]:
             if not self_attn:
                 raise MuseHipError("self-attention tape replayed as cross-attention")

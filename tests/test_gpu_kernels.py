@@ -686,11 +686,16 @@ def test_fused_attention_bf16x3(B, Skv, nh, packed):
 
 
 @pytest.mark.parametrize("B,Sq,Skv,nh,packed", [(2, 1024, 1024, 2, True), (1, 512, 512, 3, True), (2, 1024, 77, 2, False), (1, 512, 96, 2, False)])
-def test_fused_attention_bf16x3_block_by_block(B, Sq, Skv, nh, packed):
+@pytest.mark.parametrize("stream", [True, False])
+def test_fused_attention_bf16x3_block_by_block(B, Sq, Skv, nh, packed, stream, monkeypatch):
     """round 6 (BASELINE config 4's 1024-token sequences in the bf16x3 mode): query rows in blocks of 256 against key blocks of 256 (or the
-    <= 96 text states) on attention3.hip's one-tile kernels, the key blocks merged by their log-sum-exps; backward per block pair with the
-    query block's GLOBAL log-sum-exp and the final context.  Same tolerances against float64 as the one-tile form."""
+    <= 96 text states).  stream (the default for several key blocks): a workgroup keeps its 256 queries / keys and streams the other
+    side's blocks through LDS - online softmax forward, dQ and dK / dV passes with the global log-sum-exp, every result written once.
+    Otherwise (and for the text states): attention3.hip's one-tile kernels per block pair, the key blocks merged by their log-sum-exps,
+    backward per block pair with the query block's GLOBAL log-sum-exp and the final context.  Same tolerances against float64 as the
+    one-tile form either way."""
     ops = _ops()
+    monkeypatch.setattr(ops, "X3_STREAM", stream)
     hd = 64
     H = nh * hd
     alpha = 1.0 / float(torch.sqrt(torch.tensor(hd, dtype=torch.float32)))
