@@ -353,8 +353,8 @@ def uvit_leg(device, batch, seq, steps=3, f32=False, x3=False, f16=False):
                      "tests/golden/make_golden_tf32.py); TF32's exponent range is covered by power-of-two operand scales (gradient operands x 2^10 x tokens, undone in alpha; "
                      "overflowed / flushed elements counted: f16_operand_stats); the attention core (muse_attention_x3_*, block by block at 1024 tokens) "
                      "with one half plane per operand and one half MFMA per K step; f32 softmax, norms, GLU, residual stream, loss, AdamW; mfma_frac against the 2500 TFLOP/s half / bf16 peak") if f16 else ("bf16x3: f32 tensors, every product (linears, dX, dW: muse_gemm_x3 on four operand planes; the attention core: "
-                     + ("muse_attention_x3_*" if seq == 256 else "muse_attention_x3_* block by block - 256 query rows against 256-key blocks (or the 77 text states), "
-                                                               "key blocks merged by their log-sum-exps in f32 (ops.attention_x3_blocked)")
+                     + ("muse_attention_x3_*" if seq == 256 else "muse_attention_x3_*_stream - 256 queries / keys per workgroup, the other side's 256-row blocks streamed "
+                                                               "through LDS, online softmax (the 77 text states: one-tile kernels per query block)")
                      + ") as three bf16 MFMA products of hi / lo operand planes with f32 accumulation (<= 2^-16 relative per "
                      "product: at or above the yaml's mixed_precision: no + enable_tf32, 10-bit mantissa products); f32 softmax, norms, GLU, "
                      "residual stream, loss, AdamW; mfma_frac against the 833 TFLOP/s roof of that scheme (2500 / 3)") if x3 else ("exact f32 everywhere (f32-input MFMA, 157 TFLOP/s peak): at or above the precision of the yaml's mixed_precision: no + "
@@ -845,8 +845,9 @@ def main():
         extra["config4_uvit_seq256_bf16x3"] = uvit_leg_isolated(device, 64, 256, 2, x3=True)             # the yaml's 64 per GPU
         extra["config4_uvit_seq256_bf16x3_b128"] = uvit_leg_isolated(device, 128, 256, 2, x3=True)       # ... and a batch that uses the HBM
         # ... and BASELINE.json's sequence length in that precision class (round 6): every weight GEMM as bf16x3 products; the attention core
-        # of a 1024-token sequence runs attention3.hip's one-tile kernels block by block (52.3 images/s with the materialised exact-f32 core it
-        # replaced, 81.5 with the blocks: profiles/r06_c4_seq1024_x3*.txt)
+        # of a 1024-token sequence runs attention3.hip's streaming kernels (online-softmax forward, dQ and dK / dV passes over 256-row blocks;
+        # one-tile kernels against the 77 text states): 52.3 images/s with the materialised exact-f32 core round 5 had, 81.5 with block pairs +
+        # merge (profiles/r06_c4_seq1024_x3*.txt), 92 streaming
         extra["config4_uvit_seq1024_bf16x3"] = uvit_leg_isolated(device, 32, 1024, 2, x3=True)
         # ... and that precision class at its natural cost on this chip (round 6): IEEE half has TF32's 10-bit mantissa and its MFMA runs at the
         # bf16 rate - every weight GEMM as ONE half product (muse_gemm dtype MUSE_F16), gradient operands through a power-of-two scale
