@@ -316,6 +316,10 @@ int muse_cast_f32_to_f16(const float* in, void* out, int64_t n, float scale, int
  * incremented per 4-element group that holds an inf / NaN half (muse_cast_f32_to_f16's overflow counter: a dynamic gradient scale backs
  * off on it).  Process state (host code sets it around a pass: muse/ops.py f32_gemms_as_f16), not thread safe. */
 int muse_operand_images(int32_t half, float grad_scale, int32_t* stats);
+/* Overflow guard of the "f16" mode for the multi-tensor optimizer kernels (muse_adamw_multi, muse_adamw_multi_groups): while flag is
+ * non-NULL those kernels read *flag (device int32: the overflow counter muse_operand_images / muse_cast_f32_to_f16 increment) and leave
+ * parameters and moments untouched when it is non-zero - GradScaler's found_inf without a host round trip.  Process state; NULL = off. */
+int muse_adamw_skip_flag(const int32_t* flag);
 int muse_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 
 /* prepare_inputs_and_labels (training/train_maskgit_imagenet.py:371-394) given the two uniform draws.

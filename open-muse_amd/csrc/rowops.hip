@@ -1452,9 +1452,16 @@ extern "C" int muse_adamw_flat(float* p, const float* g, float* m, float* v, voi
 // a flat buffer: MaskGiTUViT has ~500, and 500 launches of 9 us each were 4 % of its step).  The table is 6 x int64 per tensor:
 // {p, g, m, v, p_bf16 or 0, n}; `chunk_first[t]` = index of tensor t's first 4096-element chunk (exclusive prefix sum, nt + 1
 // entries); block b owns chunk b: binary search -> (tensor, offset).  Same arithmetic, same order, as adamw_kernel.
+// Overflow guard of the "f16" compute mode (muse_adamw_skip_flag): when set, the multi-tensor kernels read *skip first and leave every
+// tensor untouched if it is non-zero - the gradients of a backward pass whose operand images overflowed half's range are NaN, and the
+// update is skipped ON THE DEVICE (torch.cuda.amp.GradScaler's found_inf, without a host round trip).  Process state like
+// muse_operand_images; NULL (default) = no guard.
+static const int* g_adamw_skip = nullptr;
+extern "C" int muse_adamw_skip_flag(const int32_t* flag) { g_adamw_skip = (const int*)flag; return 0; }
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const long* __restrict__ table, const int* __restrict__ chunk_first, int nt,
                                                           float b2, float eps, float decay, float omb1, float omb2,
-                                                          float step_size, float bc2_sqrt, float gscale) {
+                                                          float step_size, float bc2_sqrt, float gscale, const int* __restrict__ skip) {
+  if (skip && *skip != 0) return;
   int lo = 0, hi = nt;                    // largest t with chunk_first[t] <= blockIdx.x
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
   const long* e = table + (long)lo * 6;
@@ -1543,7 +1550,7 @@ extern "C" int muse_adamw_multi(const int64_t* table, const int32_t* chunk_first
   const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
   const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
   hipLaunchKernelGGL(adamw_multi_kernel, dim3(num_chunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, chunk_first, num_tensors,
-                     beta2, eps, decay, omb1, omb2, step_size, bc2_sqrt, grad_scale);
+                     beta2, eps, decay, omb1, omb2, step_size, bc2_sqrt, grad_scale, g_adamw_skip);
   return (int)hipGetLastError();
 }
 
@@ -1639,7 +1646,8 @@ extern "C" int muse_adamw_flat_groups(float* p, const float* g, float* m, float*
 // Multi-tensor form with groups: `table` is 7 x int64 per tensor {p, g, m, v, p_bf16 or 0, n, group | lo_plane_distance << 8}
 // (lo_plane_distance < 0: p_bf16 receives an IEEE-half copy).
 __global__ __launch_bounds__(256) void adamw_multi_groups_kernel(const long* __restrict__ table, const int* __restrict__ chunk_first, int nt,
-                                                                 AdamGroups G, float gscale) {
+                                                                 AdamGroups G, float gscale, const int* __restrict__ skip) {
+  if (skip && *skip != 0) return;       // (the f16 mode's overflow guard: muse_adamw_skip_flag)
   int lo = 0, hi = nt;
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
   const long* e = table + (long)lo * 7;
@@ -1697,7 +1705,7 @@ extern "C" int muse_adamw_multi_groups(const int64_t* table, const int32_t* chun
   const int rc = adam_fill_groups(G, group_hyper, ngroups, step);
   if (rc) return rc;
   hipLaunchKernelGGL(adamw_multi_groups_kernel, dim3(num_chunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, chunk_first,
-                     num_tensors, G, grad_scale);
+                     num_tensors, G, grad_scale, g_adamw_skip);
   return (int)hipGetLastError();
 }
 

@@ -118,6 +118,7 @@ SIGNATURES = {
     "muse_cast_bf16_to_f32": [c_void_p, c_void_p, c_i64, c_void_p],
     "muse_cast_f32_to_f16": [c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p],
     "muse_operand_images": [c_int, c_float, c_void_p],
+    "muse_adamw_skip_flag": [c_void_p],
     "muse_mask_sample": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64,
                          c_i64, c_float, c_void_p],
     "muse_sample_step": [c_void_p, c_void_p, c_float, c_i64, c_i64, c_int, c_void_p, c_i64, c_void_p, c_void_p, C.c_uint64, C.c_uint32,

@@ -320,6 +320,9 @@ class MaskGitTransformer(GeneralMaskGitEngine, ModelMixin, ConfigMixin):
         images.clear()
         images.backward, images.keep = bool(backward), False
         if backward:
+            for ov, _ in images.consume_snapshots():
+                if self.f16_auto_scale:
+                    self._f16_scale_policy(ov, self.f16_growth_interval)
             images.set_grad_scale(self.f16_grad_scale_for(self.__dict__.get("_loss_rows", 1)))
         return ops.f32_gemms_as_f16(True, images)
 

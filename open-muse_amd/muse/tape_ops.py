@@ -99,6 +99,9 @@ class TapeOps:
             images.backward = bool(backward)
             images.keep = bool(backward or self.__dict__.get("_act_cache_on", False))
             if backward:
+                for ov, _ in images.consume_snapshots():      # counters of guarded optimizer steps (muse.FusedAdamW) that have arrived
+                    if self.f16_auto_scale:
+                        self._f16_scale_policy(ov, self.f16_growth_interval)
                 images.set_grad_scale(self.f16_grad_scale_for(self.__dict__.get("_loss_rows", 1)))
             return ops.f32_gemms_as_f16(True, images)
         on = self.__dict__.get("_f32_split3", False)
@@ -139,10 +142,20 @@ class TapeOps:
         if images is not None and images._stats is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(images._stats, group=group)
         overflowed, _ = self.f16_stats()
+        return self._f16_scale_policy(overflowed, growth_interval)
+
+    # With muse.FusedAdamW nothing has to be called: its multi-tensor kernel skips the update on the device when the backward pass that
+    # made the gradients overflowed (muse_adamw_skip_flag), and the next backward pass reads that step's counters - copied to pinned
+    # memory behind the update - and moves the scale by the same policy.  f16_auto_scale = False leaves the scale to the caller.
+    f16_auto_scale = True
+    f16_growth_interval = 2000
+
+    def _f16_scale_policy(self, overflowed, growth_interval):
         cur = self.f16_grad_scale_for(self.__dict__.get("_loss_rows", 1))
         if overflowed:
             self.f16_grad_scale = max(cur * 0.5, 1.0)
             self.__dict__["_f16_good_steps"] = 0
+            self.__dict__["_f16_skipped_steps"] = self.__dict__.get("_f16_skipped_steps", 0) + 1
             return False
         good = self.__dict__.get("_f16_good_steps", 0) + 1
         if good >= growth_interval:

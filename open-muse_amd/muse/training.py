@@ -428,13 +428,29 @@ class FusedAdamW(torch.optim.Optimizer):
             self._chunk_first[:nt + 1].copy_(hf[:nt + 1], non_blocking=True)
             ev.record(torch.cuda.current_stream(dev))
             self._table_key, self._nchunks = key, nchunks
-        if multi:
-            ops.adamw_multi_groups(self._table, self._chunk_first, len(rows), self._nchunks, self.param_groups, self._step,
-                                   grad_scale=float(self.grad_scale))
-            return loss
-        grp = self.param_groups[0]
-        ops.adamw_multi(self._table, self._chunk_first, len(rows), self._nchunks, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
-                        grp["eps"], grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
+        # "f16" compute mode: the update is guarded ON THE DEVICE by the overflow counter of the backward pass that made these gradients
+        # (an operand beyond half's range turns them NaN): the kernel leaves parameters and moments untouched when it is non-zero, the
+        # model's next backward pass halves the gradient scale (tape_ops._gemm_mode) - GradScaler's policy without a host round trip
+        guard = ops._F16_GUARD[0]
+        if guard is not None and (guard._stats is None or guard._stats.device != dev):
+            guard = None
+        if guard is not None:
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(guard._stats)        # every rank skips together (GradScaler's found_inf all-reduce)
+            ops.check(ops.lib().muse_adamw_skip_flag(guard._stats.data_ptr()), "muse_adamw_skip_flag")
+        try:
+            if multi:
+                ops.adamw_multi_groups(self._table, self._chunk_first, len(rows), self._nchunks, self.param_groups, self._step,
+                                       grad_scale=float(self.grad_scale))
+            else:
+                grp = self.param_groups[0]
+                ops.adamw_multi(self._table, self._chunk_first, len(rows), self._nchunks, float(grp["lr"]), grp["betas"][0], grp["betas"][1],
+                                grp["eps"], grp["weight_decay"], self._step, grad_scale=float(self.grad_scale))
+        finally:
+            if guard is not None:
+                ops.check(ops.lib().muse_adamw_skip_flag(None), "muse_adamw_skip_flag")
+                guard.after_optimizer_step()
+                ops._F16_GUARD[0] = None
         return loss
 
     # ---- checkpointing in torch.optim.AdamW's layout ----------------------------------------------------------------

@@ -422,6 +422,53 @@ def test_f16_mode_training_steps(golden_dir):
         assert abs(lf - l32) < 2e-3 * abs(l32), (results[0][1], results[2][1])
 
 
+def test_f16_mode_optimizer_guard(golden_dir):
+    """the f16 mode with muse.FusedAdamW and NO call in the training loop: the toy model of test_f16_mode_training_steps overflows half's range
+    at the default gradient scale (NaN gradients).  The optimizer kernel reads the backward pass's overflow counter on the device and
+    leaves parameters and moments untouched (muse_adamw_skip_flag); the next backward pass reads that step's counters from pinned memory
+    and halves the scale.  Parameters stay finite throughout, three updates are skipped, the scale ends where the explicit recipe puts
+    it, and the loss of the steps that were applied falls like the exact-f32 run's."""
+    import muse
+    cfg = dict(vocab_size=520, hidden_size=256, in_channels=128, block_out_channels=(128,), encoder_hidden_size=128, cond_embed_dim=128,
+               micro_cond_encode_dim=32, micro_cond_embed_dim=160, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+               block_num_heads=2, num_res_blocks=1, codebook_size=512, mask_token_id=519)
+    B, S = 2, 256
+    gen = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 512, (B, S), generator=gen).to(DEV)
+    labels = torch.where(torch.rand(B, S, generator=gen) < 0.5, torch.randint(0, 512, (B, S), generator=gen), torch.full((B, S), -100)).to(DEV)
+    enc, cond = torch.randn(B, 77, 128, generator=gen).to(DEV), torch.randn(B, 128, generator=gen).to(DEV)
+    micro = torch.tensor([[256.0, 256.0, 0.0, 0.0, 6.0]]).repeat(B, 1).to(DEV)
+    torch.manual_seed(11)
+    model = muse.MaskGiTUViT(**cfg)
+    model.to(DEV).train().set_compute_dtype("f16")
+    opt = muse.FusedAdamW(muse.grouped_parameters(model, 0.01), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, eps=1e-8)
+    before = [p.detach().clone() for p in model.parameters()]
+    losses, moved = [], []
+    for it in range(8):
+        model.zero_grad(set_to_none=True)
+        _, loss = model(ids, enc, cond, micro, labels=labels)
+        loss.backward()
+        opt.step()                                  # (no f16_update_grad_scale: the guard lives in the optimizer kernel)
+        losses.append(float(loss.detach()))         # (a device read: the step's counter copy has arrived before the next backward
+        torch.cuda.synchronize()                    #  pass, so the scale moves one step after each overflow - deterministic here)
+        assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), it
+        moved.append(any(not torch.equal(p.detach(), q) for p, q in zip(model.parameters(), before)))
+    model.zero_grad(set_to_none=True)
+    _, loss = model(ids, enc, cond, micro, labels=labels)
+    torch.cuda.synchronize()
+    loss.backward()                                 # (reads the last step's counters)
+    skipped = model.__dict__.get("_f16_skipped_steps", 0)
+    print("f16 mode, optimizer guard: losses", [round(l, 4) for l in losses], "; updates applied after iteration", moved.index(True),
+          "; skipped", skipped, "; gradient scale", model.f16_grad_scale)
+    assert moved[:3] == [False, False, False] and moved[3] and skipped == 3 and model.f16_grad_scale == 2.0 ** 16
+    assert losses[0] == losses[1] == losses[2] == losses[3] and losses[-1] < losses[3]
+    assert model.f16_stats()[0] > 0                  # (what the three overflowed passes counted; the call resets the counters)
+    model.zero_grad(set_to_none=True)
+    _, loss = model(ids, enc, cond, micro, labels=labels)
+    loss.backward()
+    assert model.f16_stats()[0] == 0                 # at the scale the policy settled on nothing overflows
+
+
 def test_uvit_fused_adamw_parameter_groups(golden_dir):
     """training/train_muse.py:425-445 on the U-ViT: two groups (no weight decay on bias / layer_norm.weight / mlm_ln.weight /
     embeddings.weight) through ONE muse_adamw_multi_groups launch == torch.optim.AdamW with the same groups"""
