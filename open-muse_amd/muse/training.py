@@ -431,6 +431,8 @@ class FusedAdamW(torch.optim.Optimizer):
         # "f16" compute mode: the update is guarded ON THE DEVICE by the overflow counter of the backward pass that made these gradients
         # (an operand beyond half's range turns them NaN): the kernel leaves parameters and moments untouched when it is non-zero, the
         # model's next backward pass halves the gradient scale (tape_ops._gemm_mode) - GradScaler's policy without a host round trip
+        # (the host does not know about the skip when it happens: self._step advances anyway, so the bias corrections of the following
+        #  updates are those of one step later - a factor that tends to 1)
         guard = ops._F16_GUARD[0]
         if guard is not None and (guard._stats is None or guard._stats.device != dev):
             guard = None
